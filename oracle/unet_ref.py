@@ -1,0 +1,190 @@
+"""Oracle: 3D UNet / ResUNet forward (and, through torch autograd, backward).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+A functional restatement of ``/root/reference/model/dim3/{unet,unet_utils,
+conv_layers,utils}.py`` over a ``state_dict`` that uses the reference's own
+parameter names, written with stock ``torch.nn.functional`` ops in NCDHW layout
+on the CPU.  All line numbers below are in ``/root/reference``.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Sequence
+
+import torch
+import torch.nn.functional as F
+
+IN_EPS_CONV = 1e-4  # conv_layers.py:40,42  norm(ch, eps=1e-4)
+
+
+def _k3(k):
+    return [k] * 3 if isinstance(k, int) else list(k)
+
+
+def _pad(k):  # conv_layers.py:62,77 / unet_utils.py:13  pad_size = [i//2 for i in kernel_size]
+    return [i // 2 for i in k]
+
+
+def _act(x, act: str = "relu"):
+    # model/dim3/utils.py:23-30 act map; UNet passes no act -> nn.ReLU (conv_layers.py:23)
+    if act == "relu":
+        return F.relu(x)
+    if act == "lrelu":
+        return F.leaky_relu(x, 0.01)
+    if act == "gelu":
+        return F.gelu(x)
+    if act == "swish":
+        return F.silu(x)
+    raise ValueError(act)
+
+
+def instance_norm(x, eps=IN_EPS_CONV):
+    """nn.InstanceNorm3d(C, eps) with affine=False, no running stats
+    (model/dim3/utils.py:15-21, conv_layers.py:40-42): per (n, c) biased variance."""
+    return F.instance_norm(x, None, None, None, None, True, 0.0, eps)
+
+
+def conv_norm_act(sd, prefix, x, k, preact, act="relu"):
+    """ConvNormAct.forward (conv_layers.py:46-53); conv has bias=False (:23)."""
+    w = sd[prefix + "conv.weight"]
+    b = sd.get(prefix + "conv.bias")
+    if preact:  # :48-49  conv(act(norm(x)))
+        return F.conv3d(_act(instance_norm(x), act), w, b, 1, _pad(k))
+    return _act(instance_norm(F.conv3d(x, w, b, 1, _pad(k))), act)  # :51
+
+
+def single_conv(sd, prefix, x, k):
+    """SingleConv.forward (conv_layers.py:56-68): one post-activation ConvNormAct."""
+    return conv_norm_act(sd, prefix + "conv.", x, k, preact=False)
+
+
+def basic_block(sd, prefix, x, k):
+    """BasicBlock.forward (conv_layers.py:86-94), preact=True default (:72).
+    shortcut is a full k-sized pre-act ConvNormAct when in_ch != out_ch (:83-84)."""
+    out = conv_norm_act(sd, prefix + "conv1.", x, k, preact=True)
+    out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True)
+    if prefix + "shortcut.conv.weight" in sd:
+        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True)
+    else:
+        res = x
+    return out + res  # :92
+
+
+def bottleneck(sd, prefix, x, k):
+    """Bottleneck.forward (conv_layers.py:116-125): 1x1 -> kxk -> 1x1, all pre-act."""
+    out = conv_norm_act(sd, prefix + "conv1.", x, [1, 1, 1], preact=True)
+    out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True)
+    out = conv_norm_act(sd, prefix + "conv3.", out, [1, 1, 1], preact=True)
+    if prefix + "shortcut.conv.weight" in sd:
+        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True)
+    else:
+        res = x
+    return out + res
+
+
+_BLOCKS = {"SingleConv": single_conv, "BasicBlock": basic_block, "Bottleneck": bottleneck}
+
+
+def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size,
+                 block: str = "BasicBlock", return_features: bool = False):
+    """UNet.forward (unet.py:50-64).
+
+    inconv      unet_utils.py:18-21   raw Conv3d (bias False) then one block
+    down_block  unet_utils.py:35-46   MaxPool3d(scale) -> block -> block
+    up_block    unet_utils.py:68-75   trilinear(align_corners=True) to skip size ->
+                                      cat([skip, up]) -> block -> block
+    outc        unet.py:47            1x1x1 conv with bias
+    """
+    blk = _BLOCKS[block]
+    ks = [_k3(k) for k in kernel_size]
+    sc = [_k3(s) for s in scale]
+    feats = OrderedDict()
+
+    h = F.conv3d(x, sd["inc.conv1.weight"], None, 1, _pad(ks[0]))
+    x1 = blk(sd, "inc.conv2.", h, ks[0])
+    feats["x1"] = x1
+    skips = [x1]
+    cur = x1
+    for lvl in range(4):  # down1..down4 use kernel_size[lvl+1], scale[lvl]  (unet.py:37-40)
+        cur = F.max_pool3d(cur, sc[lvl])
+        cur = blk(sd, f"down{lvl+1}.conv.1.", cur, ks[lvl + 1])
+        cur = blk(sd, f"down{lvl+1}.conv.2.", cur, ks[lvl + 1])
+        feats[f"x{lvl+2}"] = cur
+        skips.append(cur)
+    out = skips[4]
+    for i in range(4):  # up1..up4 use kernel_size[3-i]  (unet.py:42-45)
+        skip = skips[3 - i]
+        up = F.interpolate(out, size=skip.shape[2:], mode="trilinear", align_corners=True)
+        out = torch.cat([skip, up], dim=1)  # unet_utils.py:71
+        out = blk(sd, f"up{i+1}.conv.0.", out, ks[3 - i])
+        out = blk(sd, f"up{i+1}.conv.1.", out, ks[3 - i])
+        feats[f"u{i+1}"] = out
+    logits = F.conv3d(out, sd["outc.weight"], sd["outc.bias"])
+    if return_features:
+        return logits, feats
+    return logits
+
+
+# ----------------------------------------------------------------------------------------
+# Deterministic "reference default init" state_dict (so that tests on the GPU box, where
+# /root/reference does not exist, can rebuild exactly the weights the reference constructor
+# would draw for a given torch seed).  Creation ORDER mirrors unet.py:35-47 /
+# unet_utils.py / conv_layers.py so the RNG stream is consumed identically; nn.Conv3d's own
+# reset_parameters is used (kaiming_uniform(a=sqrt(5)) + uniform bias).
+# ----------------------------------------------------------------------------------------
+
+def _conv(sd, name, cin, cout, k, bias=False):
+    m = torch.nn.Conv3d(cin, cout, kernel_size=k, padding=_pad(k), bias=bias)
+    sd[name + "weight"] = m.weight.detach().clone()
+    if bias:
+        sd[name + "bias"] = m.bias.detach().clone()
+
+
+def _make_block(sd, prefix, block, cin, cout, k):
+    if block == "SingleConv":
+        _conv(sd, prefix + "conv.conv.", cin, cout, k)
+    elif block == "BasicBlock":  # conv_layers.py:79-84 creation order conv1, conv2, shortcut
+        _conv(sd, prefix + "conv1.conv.", cin, cout, k)
+        _conv(sd, prefix + "conv2.conv.", cout, cout, k)
+        if cin != cout:
+            _conv(sd, prefix + "shortcut.conv.", cin, cout, k)
+    elif block == "Bottleneck":  # conv_layers.py:106-113
+        _conv(sd, prefix + "conv1.conv.", cin, cout // 2, [1, 1, 1])
+        _conv(sd, prefix + "conv2.conv.", cout // 2, cout // 2, k)
+        _conv(sd, prefix + "conv3.conv.", cout // 2, cout, [1, 1, 1])
+        if cin != cout:
+            _conv(sd, prefix + "shortcut.conv.", cin, cout, k)
+    else:
+        raise KeyError(block)
+
+
+def make_unet_state_dict(in_ch, base_ch, num_classes, kernel_size, block="BasicBlock", seed=None):
+    if seed is not None:
+        torch.manual_seed(seed)
+    ks = [_k3(k) for k in kernel_size]
+    sd = OrderedDict()
+    b = base_ch
+    _conv(sd, "inc.conv1.", in_ch, b, ks[0])
+    _make_block(sd, "inc.conv2.", block, b, b, ks[0])
+    chans = [b, 2 * b, 4 * b, 8 * b, 10 * b]  # unet.py:37-40
+    for lvl in range(4):
+        _make_block(sd, f"down{lvl+1}.conv.1.", block, chans[lvl], chans[lvl + 1], ks[lvl + 1])
+        _make_block(sd, f"down{lvl+1}.conv.2.", block, chans[lvl + 1], chans[lvl + 1], ks[lvl + 1])
+    for i in range(4):  # up1: (10b -> 8b) ... up4: (2b -> b); block in = in+out (unet_utils.py:62)
+        cin, cout = chans[4 - i], chans[3 - i]
+        _make_block(sd, f"up{i+1}.conv.0.", block, cin + cout, cout, ks[3 - i])
+        _make_block(sd, f"up{i+1}.conv.1.", block, cout, cout, ks[3 - i])
+    _conv(sd, "outc.", b, num_classes, [1, 1, 1], bias=True)
+    return sd
+
+
+def state_dict_checksum(sd) -> float:
+    """Order-sensitive scalar fingerprint of a state_dict (float64)."""
+    acc = 0.0
+    for i, (k, v) in enumerate(sd.items()):
+        v = v.double().flatten()
+        w = torch.arange(1, v.numel() + 1, dtype=torch.float64) / v.numel()
+        acc += (i + 1) * float((v * w).sum())
+    return acc

@@ -1,0 +1,74 @@
+"""Pins the oracle (oracle/) against fixtures produced by the REAL reference
+(tests/golden/make_golden.py) and, where /root/reference is present, against the
+reference executed live.  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref, unet_ref
+from tests.util import CASES, golden_state_dict, load_golden, rel_err
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_golden(name):
+    in_ch, base, classes, scale, ks, block, shape, batch, seed = CASES[name]
+    g = load_golden(name)
+    sd = golden_state_dict(name)          # also checks seed->weights == reference constructor
+    assert int(g["n_params"]) == sum(v.numel() for v in sd.values())
+    assert int(g["n_tensors"]) == len(sd)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = torch.from_numpy(g["x"])
+    lab = torch.from_numpy(g["label"])
+    w = torch.from_numpy(g["weight"])
+    logits = unet_ref.unet_forward(sd, x, scale=scale, kernel_size=ks, block=block)
+    assert rel_err(logits, g["logits"]) < 2e-5
+    ce = loss_ref.cross_entropy(logits, lab.squeeze(1), w)
+    dl = loss_ref.dice_loss(logits, lab)
+    assert abs(float(ce) - float(g["ce"])) < 1e-5
+    assert abs(float(dl) - float(g["dice"])) < 1e-5
+    (ce + dl).backward()
+    keys = [str(k) for k in g["keys"]]
+    for i, k in enumerate(keys):
+        gn = float(sd[k].grad.double().norm())
+        assert abs(gn - g["grad_norms"][i]) <= 2e-3 * max(g["grad_norms"][i], 1e-6), (k, gn, g["grad_norms"][i])
+    for k in ("inc.conv1.weight", "outc.weight", "outc.bias"):
+        assert rel_err(sd[k].grad, g["g:" + k]) < 2e-3, k
+
+
+def test_full_state_dict_fixture_roundtrip():
+    g = load_golden("resunet_b2_32")
+    sd = golden_state_dict("resunet_b2_32")
+    for k, v in sd.items():
+        np.testing.assert_array_equal(v.numpy(), g["p:" + k])
+
+
+def test_pinned_facts():
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "facts.npz"))
+    assert tuple(f["resunet_amos"]) == (40561008, 45, 0)
+    assert tuple(f["unet_acdc"]) == (16266660, 20, 0)
+    sd = unet_ref.make_unet_state_dict(1, 32, 16, [[3, 3, 3]] * 5, "BasicBlock", seed=0)
+    assert sum(v.numel() for v in sd.values()) == 40561008 and len(sd) == 45
+    torch.manual_seed(7)
+    pred = torch.randn(2, 10, 8, 16, 16)
+    target = torch.zeros(2, 1, 8, 16, 16).long()
+    assert abs(float(loss_ref.dice_loss(pred, target)) - float(f["dice_zero_target"])) < 1e-6
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model/dim3"), reason="reference tree not mounted")
+def test_oracle_vs_live_reference():
+    from tests.golden.make_golden import import_reference
+    UNet, DiceLoss = import_reference()
+    torch.manual_seed(11)
+    ks = [[3, 3, 3]] * 5
+    sc = [[2, 2, 2]] * 4
+    net = UNet(1, 4, scale=sc, kernel_size=ks, num_classes=5, block="BasicBlock", norm="in")
+    x = torch.randn(1, 1, 32, 32, 32)
+    lab = torch.randint(0, 5, (1, 1, 32, 32, 32))
+    ref = net(x)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    out = unet_ref.unet_forward(sd, x, scale=sc, kernel_size=ks, block="BasicBlock")
+    assert rel_err(out, ref.detach()) < 1e-5
+    assert abs(float(DiceLoss()(ref, lab)) - float(loss_ref.dice_loss(out, lab))) < 1e-6
