@@ -1,0 +1,103 @@
+"""ctypes binding of the C ABI in ``include/cbim_hip.h`` (libcbim_hip.so, gfx950).
+
+The product library is ``libcbim_hip.so`` next to this file (built by
+``__graft_entry__.build()`` / ``csrc/Makefile``).  There is NO fallback: if the library is
+missing or an entry point fails, a RuntimeError is raised.  ``CBIM_HIP_LIBRARY`` may name an
+explicit library file; the CPU test-suite uses it to load the host-side kernel executor built
+from the very same sources under ``tests/emu`` (backend string "emu", CPU tensors only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lock = threading.Lock()
+_lib = None
+
+vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "dtype", "N", "Di", "Hi", "Wi", "Cin", "Do", "Ho", "Wo", "Cout",
+        "kD", "kH", "kW", "pD", "pH", "pW", "act")]
+
+
+_dp = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes)   (mirrors include/cbim_hip.h one to one)
+_SIGS = {
+    "cbim_version": (i32, []),
+    "cbim_backend": (C.c_char_p, []),
+    "cbim_last_error_string": (C.c_char_p, []),
+    "cbim_stats_parts": (i32, [i64, i32]),
+    "cbim_instnorm_stats": (i32, [i32, vp, i64, i32, i64, i32, f32, vp, i32, vp, vp]),
+    "cbim_stats_finalize": (i32, [vp, i32, i32, i32, f64, f32, i32, vp, vp]),
+    "cbim_norm_act_fwd": (i32, [i32, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
+    "cbim_norm_bwd_reduce": (i32, [i32, vp, i64, vp, i64, vp, i32, i64, i32, i32, i32, vp, i32, vp]),
+    "cbim_norm_bwd_apply": (i32, [i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, i32, i64, i32, i32, i32, vp]),
+    "cbim_maxpool3d_fwd": (i32, [i32, vp, vp, vp] + [i32] * 8 + [vp]),
+    "cbim_maxpool3d_bwd": (i32, [i32, vp, vp, vp] + [i32] * 8 + [vp]),
+    "cbim_upcat_fwd": (i32, [i32, vp, vp, vp] + [i32] * 10 + [vp]),
+    "cbim_upcat_bwd": (i32, [i32, vp, vp, vp] + [i32] * 10 + [vp]),
+    "cbim_conv3d_packed_bytes": (sz, [_dp, i32]),
+    "cbim_conv3d_pack_weights": (i32, [_dp, i32, vp, vp, vp]),
+    "cbim_conv3d_num_tiles": (i32, [_dp]),
+    "cbim_conv3d_igemm": (i32, [_dp, vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp]),
+    "cbim_conv3d_wgrad_workspace": (sz, [_dp]),
+    "cbim_conv3d_wgrad": (i32, [_dp, vp, i64, vp, vp, i64, vp, vp, sz, vp]),
+    "cbim_stem_conv_fwd": (i32, [i32, vp, vp, vp] + [i32] * 15 + [vp]),
+    "cbim_stem_conv_wgrad_workspace": (sz, [i32] * 9),
+    "cbim_stem_conv_wgrad": (i32, [i32, vp, vp, vp] + [i32] * 15 + [vp, sz, vp]),
+    "cbim_head_fwd": (i32, [i32, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "cbim_head_bwd_workspace": (sz, [i64, i32, i32, i32]),
+    "cbim_head_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, sz, vp]),
+    "cbim_dice_ce_workspace": (sz, [i32, i32, i64]),
+    "cbim_dice_ce_fwd": (i32, [vp, vp, vp, i32, i32, i64, vp, vp, vp, sz, vp]),
+    "cbim_dice_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, vp]),
+    "cbim_ncdhw_to_ndhwc": (i32, [i32, vp, vp, i32, i32, i64, vp]),
+    "cbim_ndhwc_to_ncdhw": (i32, [i32, vp, vp, i32, i32, i64, vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def library_path() -> str:
+    return os.environ.get("CBIM_HIP_LIBRARY") or os.path.join(_HERE, "libcbim_hip.so")
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.isfile(path):
+            raise RuntimeError(
+                f"cbim_amd: HIP kernel library not found at {path}; build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (there is no fallback path)")
+        h = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            try:
+                fn = getattr(h, name)
+            except AttributeError as e:  # pragma: no cover
+                raise RuntimeError(f"cbim_amd: {path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+        return _lib
+
+
+def backend() -> str:
+    return lib().cbim_backend().decode()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().cbim_last_error_string().decode()
+        raise RuntimeError(f"cbim_amd: {what} failed with code {rc}: {msg}")

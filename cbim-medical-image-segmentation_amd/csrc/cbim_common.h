@@ -1,0 +1,143 @@
+// cbim_common.h — shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Activations live in HBM as channels-last NDHWC ("[voxel][channel]") tensors of T = bf16
+// (fast mode) or f32 (parity mode); every kernel moves them in 16-byte channel chunks
+// (8 bf16 / 4 f32 per lane) so a wave touches 1 KiB of contiguous memory per instruction.
+#pragma once
+#ifdef CBIM_EMU
+#include "hip_emu.h"   // tests/emu: host-side executor used only by the CPU test-suite
+#else
+#include <hip/hip_runtime.h>
+#define CBIM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+#endif
+#include <stdint.h>
+
+#include "../../include/cbim_hip.h"
+
+namespace cbim {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct bf16_tag {};  // element-type tags (bf16 carried as raw bits)
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  typedef float type;
+  static constexpr int CPC = 4;  // channels per 16-byte chunk
+  static constexpr int SIZE = 4;
+  static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+    f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) {
+    u32x4 v;
+    v.x = __float_as_uint(f[0]); v.y = __float_as_uint(f[1]);
+    v.z = __float_as_uint(f[2]); v.w = __float_as_uint(f[3]);
+    return v;
+  }
+  static __device__ __forceinline__ float load1(const void* p, size_t i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void store1(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+  static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<bf16_tag> {
+  typedef bf16_t type;
+  static constexpr int CPC = 8;
+  static constexpr int SIZE = 2;
+  static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) {
+    u32x4 v;
+    v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+    v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    return v;
+  }
+  static __device__ __forceinline__ float load1(const void* p, size_t i) { return bf2f(((const bf16_t*)p)[i]); }
+  static __device__ __forceinline__ void store1(void* p, size_t i, float v) { ((bf16_t*)p)[i] = f2bf(v); }
+  static __device__ __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
+};
+
+// 16-byte chunk load/store at ELEMENT index `e` (must be a multiple of CPC) of a T tensor.
+template <typename T>
+__device__ __forceinline__ u32x4 ld_chunk(const void* base, size_t e) {
+  return *(const u32x4*)((const char*)base + e * Elem<T>::SIZE);
+}
+template <typename T>
+__device__ __forceinline__ void st_chunk(void* base, size_t e, const u32x4& v) {
+  *(u32x4*)((char*)base + e * Elem<T>::SIZE) = v;
+}
+
+// ---- activations (model/dim3/utils.py:23-30 of the reference) ---------------------------------
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case CBIM_ACT_RELU: return x > 0.f ? x : 0.f;
+    case CBIM_ACT_LRELU: return x > 0.f ? x : 0.01f * x;
+    case CBIM_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case CBIM_ACT_SILU: return x / (1.f + __expf(-x));
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+  switch (act) {
+    case CBIM_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case CBIM_ACT_LRELU: return x > 0.f ? 1.f : 0.01f;
+    case CBIM_ACT_GELU: {
+      float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+      float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case CBIM_ACT_SILU: {
+      float s = 1.f / (1.f + __expf(-x));
+      return s * (1.f + x * (1.f - s));
+    }
+    default: return 1.f;
+  }
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware block remap: consecutive logical tiles land on the same XCD (its private 4 MiB L2),
+// block b runs on XCD b % 8 (MI355X_MICROARCH.md, observed placement; speed only, never correctness).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned nx = 8;
+  unsigned q = nblk / nx, r = nblk % nx;
+  unsigned xcd = bid % nx, idx = bid / nx;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace cbim
+
+// ---- host-side error plumbing (cbim_api.cpp) -----------------------------------------------------
+void cbim_set_error(const char* fmt, ...);
+#define CBIM_CHECK(cond, code, ...)            \
+  do {                                         \
+    if (!(cond)) {                             \
+      cbim_set_error(__VA_ARGS__);             \
+      return (code);                           \
+    }                                          \
+  } while (0)

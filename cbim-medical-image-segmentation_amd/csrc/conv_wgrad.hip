@@ -1,0 +1,324 @@
+// conv_wgrad.hip — weight gradient of the 3-D convolution on the CDNA4 matrix cores.
+//
+//   dw[co][ci][tap] = sum_{n,v} dy[v][co] * a[v + tap - p][ci],   a = act(InstanceNorm(x)) (zero padded)
+//
+//   GEMM view per tap: M = co (32), N = ci (32), K = voxels.  The contraction runs over VOXELS while
+//   both tensors are channels-last, so each MFMA operand is a transposed read of a [voxel][channel]
+//   LDS tile: bf16 uses ds_read_b64_tr_b16 (the gfx950 LDS transpose read: a 16-lane group fetches a
+//   [4 voxels][16 channels] block and every lane receives one channel's 4 voxels), f32 needs no
+//   transpose because the 32x32x2 MFMA takes a single scalar per lane.
+//   Workgroup (256 threads, 4 waves) owns a (32 co x 32 ci) block and a STRIP of spatial tiles; per
+//   tile the dy tile and the transformed input halo are staged once into LDS; the taps are dealt
+//   round-robin to the 4 waves (<= 7 accumulators of 16 VGPRs per wave), the dy fragment is re-used
+//   by all of a wave's taps.  Accumulators live across the whole strip and are written once to a
+//   per-strip fp32 slab; a second kernel adds the slabs in fixed order (deterministic, no atomics)
+//   into the natural nn.Conv3d [Cout][Cin][kD][kH][kW] fp32 gradient.
+//
+// Replaces aten::convolution_backward(weight) for nn.Conv3d in ConvNormAct
+// (/root/reference/model/dim3/conv_layers.py:29-38).
+#include "cbim_common.h"
+
+namespace cbim {
+
+static constexpr int NT = 256;
+static constexpr int TPW = 7;  // taps per wave (4 waves -> up to 28 taps)
+
+struct WgradParams {
+  const void* x; int64_t x_stride; const float* in_stats;
+  const void* dy; int64_t dy_stride;
+  float* ws;
+  int N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout;
+  int kD, kH, kW, pD, pH, pW, act;
+  int tD, tH, lgH, tiles_d, tiles_h, tiles_w, hD, hH, hW, taps;
+  int strips_per_n, tiles_per_strip, ci_blocks, Cout_pad, Cin_pad;
+};
+
+#ifdef CBIM_EMU
+#define CBIM_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
+#else
+#define CBIM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+// 4 consecutive-voxel bf16 of one channel via the LDS transpose read (per-lane address of 4 bf16).
+__device__ __forceinline__ u32x2 lds_tr16_b64(const unsigned char* p) {
+#ifdef CBIM_EMU
+  unsigned short o[4];
+  emu_ds_read_tr16_b64(p, o);
+  u32x2 r;
+  r.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+  r.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+  return r;
+#else
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  return __builtin_bit_cast(u32x2, v);
+#endif
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
+  constexpr int CPC = Elem<T>::CPC;
+  constexpr int ES = Elem<T>::SIZE;
+  constexpr int ROWB = 32 * ES;        // LDS row = 32 channels
+  constexpr int SLOTS = ROWB / 16;
+  constexpr bool IS_BF16 = (ES == 2);
+  CBIM_DYN_SMEM(smem);
+  const int BMv = p.tD * p.tH * 8;
+  const int hV = p.hD * p.hH * p.hW;
+  unsigned char* dyL = smem;
+  unsigned char* aL = smem + (size_t)BMv * ROWB;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
+  const int n = blockIdx.x / p.strips_per_n, strip = blockIdx.x % p.strips_per_n;
+  const int cb = blockIdx.y / p.ci_blocks, ib = blockIdx.y % p.ci_blocks;
+  const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+  const int t_begin = strip * p.tiles_per_strip;
+  int t_end = t_begin + p.tiles_per_strip;
+  if (t_end > tiles_per_n) t_end = tiles_per_n;
+
+  // taps of this wave: tap = wave + 4*tl
+  int tapoff[TPW];
+#pragma unroll
+  for (int tl = 0; tl < TPW; ++tl) {
+    int tap = wave + 4 * tl;
+    int kw = tap % p.kW, r = tap / p.kW;
+    int kh = r % p.kH, kd = r / p.kH;
+    tapoff[tl] = (kd * p.hH + kh) * p.hW + kw;
+  }
+  const int my_ntaps = p.taps > wave ? (p.taps - wave + 3) / 4 : 0;
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
+
+  const int my_slot = tid & (SLOTS - 1);
+  const int ci0 = ib * 32 + my_slot * CPC;   // staged input channel chunk of this thread
+  const int co0 = cb * 32 + my_slot * CPC;   // staged dy channel chunk of this thread
+  float mean[CPC], rstd[CPC];
+  if (p.in_stats && ci0 < p.Cin) {
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      mean[j] = p.in_stats[((size_t)n * p.Cin + ci0 + j) * 2];
+      rstd[j] = p.in_stats[((size_t)n * p.Cin + ci0 + j) * 2 + 1];
+    }
+  }
+  const size_t nbase_in = (size_t)n * p.Di * p.Hi * p.Wi;
+  const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
+
+  // per-lane voxel bookkeeping for the fragment reads
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int od0 = (t / (p.tiles_w * p.tiles_h)) * p.tD;
+    const int oh0 = ((t / p.tiles_w) % p.tiles_h) * p.tH;
+    const int ow0 = (t % p.tiles_w) * 8;
+    const int id0 = od0 - p.pD, ih0 = oh0 - p.pH, iw0 = ow0 - p.pW;
+    __syncthreads();
+    // ---- stage dy tile: dense [BMv][32 co] ------------------------------------------------------------
+    for (int item = tid; item < BMv * SLOTS; item += NT) {
+      int m = item / SLOTS;
+      int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
+      int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (co0 < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo) {
+        size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+        v = ld_chunk<T>(p.dy, row * p.dy_stride + co0);
+      }
+      *(u32x4*)(dyL + (size_t)m * ROWB + my_slot * 16) = v;
+    }
+    // ---- stage the transformed input halo: [hV][32 ci] --------------------------------------------------
+    for (int item = tid; item < hV * SLOTS; item += NT) {
+      int hv = item / SLOTS;
+      int hw = hv % p.hW;
+      int r2 = hv / p.hW;
+      int hh = r2 % p.hH, hd = r2 / p.hH;
+      int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ci0 < p.Cin && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi) {
+        size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
+        v = ld_chunk<T>(p.x, row * p.x_stride + ci0);
+        if (p.in_stats) {
+          float f[CPC];
+          Elem<T>::unpack(v, f);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
+          v = Elem<T>::pack(f);
+        }
+      }
+      *(u32x4*)(aL + (size_t)hv * ROWB + my_slot * 16) = v;
+    }
+    __syncthreads();
+    // ---- contraction over the tile's voxels ------------------------------------------------------------------
+    if (IS_BF16) {
+      for (int ks = 0; ks < BMv / 16; ++ks) {
+        // lane's two voxel quads: m = ks*16 + 8*half + 4*s + (i16>>2), s = 0,1
+        int m0 = ks * 16 + 8 * half + (i16 >> 2);
+        int m1 = m0 + 4;
+        int col = (16 * g16 + 4 * (i16 & 3)) * 2;  // byte offset of the lane's 4-channel group
+        u32x2 a0 = lds_tr16_b64(dyL + (size_t)m0 * ROWB + col);
+        u32x2 a1 = lds_tr16_b64(dyL + (size_t)m1 * ROWB + col);
+        u32x4 af = {a0.x, a0.y, a1.x, a1.y};
+        int hvm0, hvm1;
+        {
+          int tw = m0 & 7, th = (m0 >> 3) & (p.tH - 1), td = m0 >> (3 + p.lgH);
+          hvm0 = (td * p.hH + th) * p.hW + tw;
+          tw = m1 & 7; th = (m1 >> 3) & (p.tH - 1); td = m1 >> (3 + p.lgH);
+          hvm1 = (td * p.hH + th) * p.hW + tw;
+        }
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+          if (tl < my_ntaps) {
+            u32x2 b0 = lds_tr16_b64(aL + (size_t)(hvm0 + tapoff[tl]) * ROWB + col);
+            u32x2 b1 = lds_tr16_b64(aL + (size_t)(hvm1 + tapoff[tl]) * ROWB + col);
+            u32x4 bf = {b0.x, b0.y, b1.x, b1.y};
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
+                                                              __builtin_bit_cast(bf16x8, bf), acc[tl], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      for (int ks = 0; ks < BMv / 2; ++ks) {
+        int m = ks * 2 + half;
+        float av = *(const float*)(dyL + (size_t)m * ROWB + li * 4);
+        int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
+        int hvm = (td * p.hH + th) * p.hW + tw;
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+          if (tl < my_ntaps) {
+            float bv = *(const float*)(aL + (size_t)(hvm + tapoff[tl]) * ROWB + li * 4);
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tl], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- write this strip's slab: ws[(n*strips+strip)][tap][Cout_pad][Cin_pad] -------------------------------------
+  const size_t slab = (size_t)p.taps * p.Cout_pad * p.Cin_pad;
+  float* wsb = p.ws + (size_t)blockIdx.x * slab;
+#pragma unroll
+  for (int tl = 0; tl < TPW; ++tl) {
+    if (tl < my_ntaps) {
+      int tap = wave + 4 * tl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        int ci = ib * 32 + li;
+        wsb[((size_t)tap * p.Cout_pad + co) * p.Cin_pad + ci] = acc[tl][r];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw,
+                                                     int n_slabs, int taps, int Cout, int Cin, int Cout_pad,
+                                                     int Cin_pad, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int ci = (int)(i % Cin);
+    int64_t r = i / Cin;
+    int co = (int)(r % Cout);
+    int tap = (int)(r / Cout);
+    size_t o = ((size_t)tap * Cout_pad + co) * Cin_pad + ci;
+    size_t slab = (size_t)taps * Cout_pad * Cin_pad;
+    float a = 0.f;
+    for (int s = 0; s < n_slabs; ++s) a += ws[(size_t)s * slab + o];
+    dw[((size_t)co * Cin + ci) * taps + tap] = a;
+  }
+}
+
+struct WgCfg { int tD, tH, lgH, tiles_d, tiles_h, tiles_w, strips_per_n, tiles_per_strip, co_blocks, ci_blocks; };
+
+static WgCfg wg_cfg(const cbim_conv_desc* d) {
+  WgCfg c;
+  int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
+  if (S >= 32768 && d->Do >= 4 && d->Ho >= 8) { c.tD = 4; c.tH = 8; c.lgH = 3; }
+  else if (d->Do <= 2) { c.tD = 2; c.tH = 8; c.lgH = 3; }
+  else { c.tD = 4; c.tH = 4; c.lgH = 2; }
+  c.tiles_d = (d->Do + c.tD - 1) / c.tD;
+  c.tiles_h = (d->Ho + c.tH - 1) / c.tH;
+  c.tiles_w = (d->Wo + 7) / 8;
+  c.co_blocks = (d->Cout + 31) / 32;
+  c.ci_blocks = (d->Cin + 31) / 32;
+  int tiles_per_n = c.tiles_d * c.tiles_h * c.tiles_w;
+  int64_t pairs = (int64_t)c.co_blocks * c.ci_blocks;
+  int64_t want = 2048 / (pairs * d->N);  // aim at ~2048 workgroups
+  if (want < 1) want = 1;
+  if (want > tiles_per_n) want = tiles_per_n;
+  // cap the slab workspace at ~96 MiB
+  int taps = d->kD * d->kH * d->kW;
+  size_t slab = (size_t)taps * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
+  int64_t cap = (int64_t)((96ull << 20) / (slab * d->N));
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  c.tiles_per_strip = (int)((tiles_per_n + want - 1) / want);
+  c.strips_per_n = (tiles_per_n + c.tiles_per_strip - 1) / c.tiles_per_strip;
+  return c;
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+extern "C" size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* d) {
+  if (!d) return 0;
+  WgCfg c = wg_cfg(d);
+  int taps = d->kD * d->kH * d->kW;
+  return (size_t)d->N * c.strips_per_n * taps * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
+}
+
+template <typename T>
+static int launch_wgrad(const WgradParams& p, dim3 grid, size_t smem, hipStream_t st) {
+#ifndef CBIM_EMU
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_wgrad<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+#endif
+  CBIM_LAUNCH((k_conv_wgrad<T>), grid, dim3(NT), smem, st, p);
+  hipError_t e = hipGetLastError();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv wgrad launch: %s", hipGetErrorString(e));
+  return CBIM_OK;
+}
+
+extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t x_stride,
+                                 const float* in_stats, const void* dy, int64_t dy_stride, float* dw,
+                                 void* workspace, size_t ws_bytes, void* stream) {
+  CBIM_CHECK(d && x && dy && dw, CBIM_EINVAL, "null argument");
+  CBIM_CHECK(d->dtype == CBIM_F32 || d->dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype");
+  int cpc = d->dtype == CBIM_BF16 ? 8 : 4;
+  CBIM_CHECK(d->Cin % cpc == 0 && d->Cout % cpc == 0, CBIM_EUNSUPPORTED,
+             "wgrad needs Cin (%d) and Cout (%d) to be multiples of %d", d->Cin, d->Cout, cpc);
+  int taps = d->kD * d->kH * d->kW;
+  CBIM_CHECK(taps <= 4 * TPW, CBIM_EUNSUPPORTED, "wgrad supports at most %d taps", 4 * TPW);
+  size_t need = cbim_conv3d_wgrad_workspace(d);
+  CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "wgrad workspace %zu < %zu", ws_bytes, need);
+  WgCfg c = wg_cfg(d);
+  WgradParams p;
+  p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.dy = dy; p.dy_stride = dy_stride;
+  p.ws = (float*)workspace;
+  p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin;
+  p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.kD = d->kD; p.kH = d->kH; p.kW = d->kW; p.pD = d->pD; p.pH = d->pH; p.pW = d->pW; p.act = d->act;
+  p.tD = c.tD; p.tH = c.tH; p.lgH = c.lgH; p.tiles_d = c.tiles_d; p.tiles_h = c.tiles_h; p.tiles_w = c.tiles_w;
+  p.hD = c.tD + d->kD - 1; p.hH = c.tH + d->kH - 1; p.hW = 8 + d->kW - 1;
+  p.taps = taps; p.strips_per_n = c.strips_per_n; p.tiles_per_strip = c.tiles_per_strip;
+  p.ci_blocks = c.ci_blocks; p.Cout_pad = c.co_blocks * 32; p.Cin_pad = c.ci_blocks * 32;
+  int es = d->dtype == CBIM_BF16 ? 2 : 4;
+  size_t smem = ((size_t)c.tD * c.tH * 8 + (size_t)p.hD * p.hH * p.hW) * 32 * es;
+  CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "wgrad tile needs %zu B of LDS", smem);
+  dim3 grid((unsigned)(d->N * c.strips_per_n), (unsigned)(c.co_blocks * c.ci_blocks));
+  hipStream_t st = (hipStream_t)stream;
+  int rc = d->dtype == CBIM_BF16 ? launch_wgrad<bf16_tag>(p, grid, smem, st) : launch_wgrad<float>(p, grid, smem, st);
+  if (rc) return rc;
+  int64_t total = (int64_t)taps * d->Cout * d->Cin;
+  int64_t blocks = (total + NT - 1) / NT;
+  if (blocks > 4096) blocks = 4096;
+  CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, st, (const float*)workspace, dw,
+              d->N * c.strips_per_n, taps, d->Cout, d->Cin, p.Cout_pad, p.Cin_pad, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}

@@ -1,0 +1,210 @@
+// loss_kernels.hip — fused weighted cross-entropy + soft Dice (Tversky, adaptive alpha) loss.
+//
+// Reference: nn.CrossEntropyLoss(weight=w) + DiceLoss()  (/root/reference/train.py:80-81,212;
+// /root/reference/training/losses.py:18-58).  The reference materialises ~10 full-size fp32
+// temporaries (softmax, one-hot, TP/FP/FN maps ...); here the logits are read ONCE in the forward
+// (per-class sums of P*M, P and M plus the CE numerator/denominator) and once in the backward.
+//
+// With TP_c = sum P_c*M_c, SP_c = sum P_c, CNT_c = sum M_c over batch and space:
+//   FP = SP-TP, FN = CNT-TP, alpha = clamp(FP/(FP+FN+eps), .2, .8) (NOT detached, losses.py:38-40),
+//   den = TP + alpha*FP + (1-alpha)*FN = alpha*SP + (1-alpha)*CNT, dice = TP/(den+eps),
+//   L = mean_c(1-dice_c);  d L/d P_c(voxel) = dL/dTP_c * M_c + dL/dSP_c.
+// HBM-bound: logits are NCDHW fp32, one thread per voxel, coalesced plane reads.
+#include "cbim_common.h"
+
+namespace cbim {
+
+static constexpr int NT = 256;
+static constexpr int CMAX = 32;
+static constexpr float SMOOTH = 1e-5f;
+
+// partial layout per workgroup: [3*C + 2] = TP[C], SP[C], CNT[C], ce_num, ce_den
+__global__ void __launch_bounds__(NT) k_dice_ce_fwd(const float* __restrict__ z, const int64_t* __restrict__ y,
+                                                    const float* __restrict__ wgt, int C, int64_t S,
+                                                    int64_t total, float* __restrict__ partials) {
+  float tp[CMAX], sp[CMAX], cnt[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) { tp[c] = 0.f; sp[c] = 0.f; cnt[c] = 0.f; }
+  float ce_num = 0.f, ce_den = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < total; r += (int64_t)gridDim.x * NT) {
+    int64_t n = r / S, v = r % S;
+    const float* zp = z + (size_t)n * C * S + v;
+    int lab = (int)y[r];
+    float l[CMAX];
+    float mx = -INFINITY, zy = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) { l[c] = zp[(size_t)c * S]; mx = fmaxf(mx, l[c]); if (c == lab) zy = l[c]; }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) { l[c] = __expf(l[c] - mx); se += l[c]; }
+    float inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        float pc = l[c] * inv;
+        sp[c] += pc;
+        if (c == lab) { tp[c] += pc; cnt[c] += 1.f; }
+      }
+    float wy = wgt ? wgt[lab] : 1.f;
+    ce_num += wy * (__logf(se) + mx - zy);
+    ce_den += wy;
+  }
+  // workgroup reduction (fixed order): wave shuffles then 4 waves through LDS
+  __shared__ float red[4][3 * CMAX + 2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    if (c < C) {
+      float a = wave_sum(tp[c]), b = wave_sum(sp[c]), d = wave_sum(cnt[c]);
+      if (lane == 0) { red[wave][c] = a; red[wave][CMAX + c] = b; red[wave][2 * CMAX + c] = d; }
+    }
+  }
+  {
+    float a = wave_sum(ce_num), b = wave_sum(ce_den);
+    if (lane == 0) { red[wave][3 * CMAX] = a; red[wave][3 * CMAX + 1] = b; }
+  }
+  __syncthreads();
+  float* out = partials + (size_t)blockIdx.x * (3 * C + 2);
+  for (int i = threadIdx.x; i < 3 * C + 2; i += NT) {
+    int src = i < 3 * C ? (i / C) * CMAX + (i % C) : 3 * CMAX + (i - 3 * C);
+    out[i] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+  }
+}
+
+// single workgroup: reduce partials in fp64, evaluate the loss and its class-level derivatives.
+__global__ void __launch_bounds__(NT) k_dice_ce_finalize(const float* __restrict__ partials, int nblk, int C,
+                                                         float* __restrict__ out, float* __restrict__ coef) {
+  __shared__ double tot[3 * CMAX + 2];
+  __shared__ double dice_term[CMAX];
+  const int nv = 3 * C + 2;
+  for (int i = threadIdx.x; i < nv; i += NT) {
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += (double)partials[(size_t)b * nv + i];
+    tot[i] = a;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    int c = threadIdx.x;
+    double TP = tot[c], SP = tot[C + c], CNT = tot[2 * C + c];
+    double eps = (double)SMOOTH;
+    double FP = SP - TP, FN = CNT - TP;
+    double T = FP + FN + eps;
+    double r = FP / T;
+    bool open = (r >= 0.2 && r <= 0.8);
+    double alpha = r < 0.2 ? 0.2 : (r > 0.8 ? 0.8 : r);
+    double den = TP + alpha * FP + (1.0 - alpha) * FN;
+    double dice = TP / (den + eps);
+    dice_term[c] = 1.0 - dice;
+    // d alpha / d TP, d alpha / d SP (only inside the clamp)
+    double da_dTP = open ? (FP - FN - eps) / (T * T) : 0.0;
+    double da_dSP = open ? (FN + eps) / (T * T) : 0.0;
+    double dden_dTP = (SP - CNT) * da_dTP;            // the explicit TP terms cancel
+    double dden_dSP = alpha + (SP - CNT) * da_dSP;
+    double q = TP / ((den + eps) * (den + eps));
+    double ddice_dTP = 1.0 / (den + eps) - q * dden_dTP;
+    double ddice_dSP = -q * dden_dSP;
+    coef[c] = (float)(-ddice_dTP / C);
+    coef[C + c] = (float)(-ddice_dSP / C);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double dl = 0.0;
+    for (int c = 0; c < C; ++c) dl += dice_term[c];
+    dl /= C;
+    double ce = tot[3 * C] / tot[3 * C + 1];
+    out[0] = (float)ce;
+    out[1] = (float)dl;
+    out[2] = (float)(ce + dl);
+    coef[2 * C] = (float)(1.0 / tot[3 * C + 1]);
+  }
+}
+
+// dlogits = g_ce * dCE/dz + g_dice * dDice/dz   (grad_out = {g_ce, g_dice} on the device)
+__global__ void __launch_bounds__(NT) k_dice_ce_bwd(const float* __restrict__ z, const int64_t* __restrict__ y,
+                                                    const float* __restrict__ wgt, const float* __restrict__ coef,
+                                                    const float* __restrict__ grad_out, float* __restrict__ dz,
+                                                    int C, int64_t S, int64_t total) {
+  __shared__ float cf[2 * CMAX + 1];
+  if ((int)threadIdx.x < 2 * C + 1) cf[threadIdx.x] = coef[threadIdx.x];
+  __syncthreads();
+  const float g_ce = grad_out[0], g_dice = grad_out[1];
+  const float inv_w = cf[2 * C];
+  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < total; r += (int64_t)gridDim.x * NT) {
+    int64_t n = r / S, v = r % S;
+    const float* zp = z + (size_t)n * C * S + v;
+    float* dp = dz + (size_t)n * C * S + v;
+    int lab = (int)y[r];
+    float l[CMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) { l[c] = zp[(size_t)c * S]; mx = fmaxf(mx, l[c]); }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) { l[c] = __expf(l[c] - mx); se += l[c]; }
+    float inv = 1.f / se;
+    float dot = 0.f;  // sum_k p_k G_k
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        l[c] *= inv;
+        float G = cf[C + c] + (c == lab ? cf[c] : 0.f);
+        dot += l[c] * G;
+      }
+    float wy = (wgt ? wgt[lab] : 1.f) * inv_w;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        float G = cf[C + c] + (c == lab ? cf[c] : 0.f);
+        float d_dice = l[c] * (G - dot);
+        float d_ce = wy * (l[c] - (c == lab ? 1.f : 0.f));
+        dp[(size_t)c * S] = g_ce * d_ce + g_dice * d_dice;
+      }
+  }
+}
+
+static int loss_blocks(int64_t total) {
+  int64_t b = (total + NT * 8 - 1) / (NT * 8);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+extern "C" size_t cbim_dice_ce_workspace(int N, int C, int64_t S) {
+  return (size_t)loss_blocks((int64_t)N * S) * (3 * C + 2) * sizeof(float);
+}
+
+extern "C" int cbim_dice_ce_fwd(const float* logits, const int64_t* labels, const float* weight, int N, int C,
+                                int64_t S, float* out, float* coef, void* workspace, size_t ws_bytes,
+                                void* stream) {
+  CBIM_CHECK(logits && labels && out && coef, CBIM_EINVAL, "null argument");
+  CBIM_CHECK(C >= 1 && C <= CMAX, CBIM_EUNSUPPORTED, "loss supports up to %d classes (got %d)", CMAX, C);
+  size_t need = cbim_dice_ce_workspace(N, C, S);
+  CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "loss workspace %zu < %zu", ws_bytes, need);
+  int64_t total = (int64_t)N * S;
+  int nb = loss_blocks(total);
+  hipStream_t st = (hipStream_t)stream;
+  CBIM_LAUNCH(k_dice_ce_fwd, dim3(nb), dim3(NT), 0, st, logits, labels, weight, C, S, total, (float*)workspace);
+  CBIM_LAUNCH(k_dice_ce_finalize, dim3(1), dim3(NT), 0, st, (const float*)workspace, nb, C, out, coef);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_dice_ce_bwd(const float* logits, const int64_t* labels, const float* weight,
+                                const float* coef, const float* grad_out, float* dlogits, int N, int C,
+                                int64_t S, void* stream) {
+  CBIM_CHECK(logits && labels && coef && grad_out && dlogits, CBIM_EINVAL, "null argument");
+  CBIM_CHECK(C >= 1 && C <= CMAX, CBIM_EUNSUPPORTED, "loss supports up to %d classes (got %d)", CMAX, C);
+  int64_t total = (int64_t)N * S;
+  int64_t b = (total + NT - 1) / NT;
+  if (b > 256 * 16) b = 256 * 16;
+  CBIM_LAUNCH(k_dice_ce_bwd, dim3((unsigned)b), dim3(NT), 0, (hipStream_t)stream, logits, labels, weight, coef,
+              grad_out, dlogits, C, S, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}

@@ -1,0 +1,314 @@
+// norm_kernels.hip — InstanceNorm3d statistics / normalise+activation / backward pieces.
+//
+// HBM-bound streaming kernels over channels-last [voxel][C] tensors.  Work item = one 16-byte
+// channel chunk (8 bf16 / 4 f32); a thread keeps a FIXED channel chunk and strides over voxels,
+// so per-channel sums stay in registers; lanes of a wave read consecutive chunks (1 KiB per
+// wave instruction when C*esize >= 1 KiB, whole rows otherwise).
+//
+// Reference semantics: nn.InstanceNorm3d(C, eps=1e-4), affine=False, biased variance
+// (/root/reference/model/dim3/conv_layers.py:40-42, model/dim3/utils.py:15-21);
+// backward dx = rstd*(dy - mean(dy) - xh*mean(dy*xh)).
+#include "cbim_common.h"
+
+namespace cbim {
+
+static constexpr int NT = 256;
+
+struct RowMap {  // thread -> (channel chunk, voxel lane)
+  int cch;       // chunks per row
+  int vl_count;  // voxel lanes per block
+};
+
+// ---- partial sums: (sum u, sum u*v) per channel over a slab of voxels -----------------------------
+// MODE 0: u = x, v = x                      (forward statistics)
+// MODE 1: u = g', v = xh  with xh=(x-mean)*rstd, g' = masked ? g*act'(xh) : g
+template <typename T, int MODE>
+__global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a, int64_t a_stride,
+                                                     const void* __restrict__ x, int64_t x_stride,
+                                                     const float* __restrict__ stats, int64_t S, int C,
+                                                     int P, int act, int masked,
+                                                     float* __restrict__ partials) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  const int vlc = NT / cch;            // host guarantees cch <= NT
+  const int t = threadIdx.x;
+  const int cc = t % cch, vl = t / cch;
+  const int part = blockIdx.x, n = blockIdx.y;
+  const int64_t per = (S + P - 1) / P;
+  const int64_t v0 = (int64_t)part * per;
+  int64_t v1 = v0 + per;
+  if (v1 > S) v1 = S;
+
+  float s0[CPC], s1[CPC], mean[CPC], rstd[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f; }
+  const bool active = vl < vlc;
+  if (MODE == 1 && active) {
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      mean[j] = stats[((size_t)n * C + cc * CPC + j) * 2 + 0];
+      rstd[j] = stats[((size_t)n * C + cc * CPC + j) * 2 + 1];
+    }
+  }
+  if (active) {
+    const size_t nb = (size_t)n * S;
+    for (int64_t v = v0 + vl; v < v1; v += vlc) {
+      float fa[CPC];
+      Elem<T>::unpack(ld_chunk<T>(a, (nb + v) * a_stride + (size_t)cc * CPC), fa);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) { s0[j] += fa[j]; s1[j] += fa[j] * fa[j]; }
+      } else {
+        float fx[CPC];
+        Elem<T>::unpack(ld_chunk<T>(x, (nb + v) * x_stride + (size_t)cc * CPC), fx);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          float xh = (fx[j] - mean[j]) * rstd[j];
+          float g = masked ? fa[j] * act_grad(xh, act) : fa[j];
+          s0[j] += g;
+          s1[j] += g * xh;
+        }
+      }
+    }
+  }
+  // reduce over the voxel lanes through LDS (fixed order -> deterministic)
+  __shared__ float red[NT * 2 * 8];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) {
+    red[(t * CPC + j) * 2 + 0] = s0[j];
+    red[(t * CPC + j) * 2 + 1] = s1[j];
+  }
+  __syncthreads();
+  if (vl == 0 && active) {
+    for (int j = 0; j < CPC; ++j) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int q = 0; q < vlc; ++q) {
+        a0 += red[((q * cch + cc) * CPC + j) * 2 + 0];
+        a1 += red[((q * cch + cc) * CPC + j) * 2 + 1];
+      }
+      size_t o = (((size_t)n * P + part) * C + cc * CPC + j) * 2;
+      partials[o] = a0;
+      partials[o + 1] = a1;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_stats_finalize(const float* __restrict__ partials, int N, int P,
+                                                       int C, double count, float eps, int mode,
+                                                       float* __restrict__ out) {
+  int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= N * C) return;
+  int n = i / C, c = i % C;
+  double a0 = 0.0, a1 = 0.0;
+  for (int p = 0; p < P; ++p) {
+    size_t o = (((size_t)n * P + p) * C + c) * 2;
+    a0 += (double)partials[o];
+    a1 += (double)partials[o + 1];
+  }
+  if (mode == 0) {
+    double m = a0 / count;
+    double var = a1 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    out[(size_t)i * 2] = (float)m;
+    out[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    out[(size_t)i * 2] = (float)(a0 / count);
+    out[(size_t)i * 2 + 1] = (float)(a1 / count);
+  }
+}
+
+// ---- y = act((x-mean)*rstd) -------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x, int64_t x_stride,
+                                                     const float* __restrict__ stats, void* __restrict__ y,
+                                                     int64_t y_stride, int64_t S, int C, int act,
+                                                     int64_t total_chunks) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * NT) {
+    int64_t row = i / cch;  // n*S + v
+    int cc = (int)(i % cch);
+    int n = (int)(row / S);
+    float f[CPC];
+    Elem<T>::unpack(ld_chunk<T>(x, (size_t)row * x_stride + (size_t)cc * CPC), f);
+    const float* st = stats + ((size_t)n * C + cc * CPC) * 2;
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - st[2 * j]) * st[2 * j + 1], act);
+    st_chunk<T>(y, (size_t)row * y_stride + (size_t)cc * CPC, Elem<T>::pack(f));
+  }
+}
+
+// ---- dx = rstd*(g' - m1 - xh*m2) [+ add] --------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) k_norm_bwd_apply(const void* __restrict__ g, int64_t g_stride,
+                                                       const void* __restrict__ x, int64_t x_stride,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ sums,
+                                                       const void* __restrict__ add, int64_t add_stride,
+                                                       void* __restrict__ dx, int64_t dx_stride, int64_t S,
+                                                       int C, int act, int masked, int64_t total_chunks) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * NT) {
+    int64_t row = i / cch;
+    int cc = (int)(i % cch);
+    int n = (int)(row / S);
+    float fg[CPC], fx[CPC], fa[CPC];
+    Elem<T>::unpack(ld_chunk<T>(g, (size_t)row * g_stride + (size_t)cc * CPC), fg);
+    Elem<T>::unpack(ld_chunk<T>(x, (size_t)row * x_stride + (size_t)cc * CPC), fx);
+    if (add) Elem<T>::unpack(ld_chunk<T>(add, (size_t)row * add_stride + (size_t)cc * CPC), fa);
+    const float* st = stats + ((size_t)n * C + cc * CPC) * 2;
+    const float* sm = sums + ((size_t)n * C + cc * CPC) * 2;
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      float rstd = st[2 * j + 1];
+      float xh = (fx[j] - st[2 * j]) * rstd;
+      float gg = masked ? fg[j] * act_grad(xh, act) : fg[j];
+      float d = rstd * (gg - sm[2 * j] - xh * sm[2 * j + 1]);
+      fg[j] = add ? d + fa[j] : d;
+    }
+    st_chunk<T>(dx, (size_t)row * dx_stride + (size_t)cc * CPC, Elem<T>::pack(fg));
+  }
+}
+
+// ---- layout helpers ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) k_ncdhw_to_ndhwc(const float* __restrict__ x, void* __restrict__ y,
+                                                       int C, int64_t S, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int c = (int)(i % C);
+    int64_t row = i / C;  // n*S+v
+    int64_t n = row / S, v = row % S;
+    Elem<T>::store1(y, (size_t)i, x[((size_t)n * C + c) * S + v]);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(NT) k_ndhwc_to_ncdhw(const void* __restrict__ x, float* __restrict__ y,
+                                                       int C, int64_t S, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int64_t v = i % S;
+    int64_t nc = i / S;
+    int64_t n = nc / C;
+    int c = (int)(nc % C);
+    y[i] = Elem<T>::load1(x, ((size_t)n * S + v) * C + c);
+  }
+}
+
+static inline int grid_for(int64_t items) {
+  int64_t b = (items + NT - 1) / NT;
+  if (b > 256 * 16) b = 256 * 16;  // ~16 blocks per CU, grid-stride the rest
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+static int check_c(int dtype, int C) {
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
+  CBIM_CHECK(C > 0 && C % cpc == 0, CBIM_EUNSUPPORTED, "channel count %d is not a multiple of %d", C, cpc);
+  CBIM_CHECK(C / cpc <= NT, CBIM_EUNSUPPORTED, "channel count %d too large", C);
+  return 0;
+}
+
+extern "C" int cbim_stats_parts(int64_t S, int C) {
+  (void)C;
+  int64_t p = (S + 255) / 256;
+  if (p < 1) p = 1;
+  if (p > 1024) p = 1024;
+  return (int)p;
+}
+
+extern "C" int cbim_instnorm_stats(int dtype, const void* x, int64_t x_stride, int N, int64_t S, int C,
+                                   float eps, float* partials, int P, float* stats, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  CBIM_CHECK(P >= 1 && N >= 1 && S >= 1, CBIM_EINVAL, "bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(P, N);
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_partial_sums<bf16_tag, 0>), grid, dim3(NT), 0, st, x, x_stride, x, x_stride,
+                (const float*)nullptr, S, C, P, 0, 0, partials);
+  else
+    CBIM_LAUNCH((k_partial_sums<float, 0>), grid, dim3(NT), 0, st, x, x_stride, x, x_stride,
+                (const float*)nullptr, S, C, P, 0, 0, partials);
+  return cbim_stats_finalize(partials, N, P, C, (double)S, eps, 0, stats, stream);
+}
+
+extern "C" int cbim_stats_finalize(const float* partials, int N, int P, int C, double count, float eps,
+                                   int mode, float* out, void* stream) {
+  CBIM_CHECK(N >= 1 && P >= 1 && C >= 1, CBIM_EINVAL, "bad sizes");
+  CBIM_LAUNCH(k_stats_finalize, dim3((N * C + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, partials, N,
+              P, C, count, eps, mode, out);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_norm_act_fwd(int dtype, const void* x, int64_t x_stride, const float* stats, void* y,
+                                 int64_t y_stride, int N, int64_t S, int C, int act, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * S * (C / cpc);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_norm_act_fwd<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, x, x_stride, stats, y,
+                y_stride, S, C, act, total);
+  else
+    CBIM_LAUNCH((k_norm_act_fwd<float>), dim3(grid_for(total)), dim3(NT), 0, st, x, x_stride, stats, y,
+                y_stride, S, C, act, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_norm_bwd_reduce(int dtype, const void* g, int64_t g_stride, const void* x,
+                                    int64_t x_stride, const float* stats, int N, int64_t S, int C, int act,
+                                    int masked, float* partials, int P, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(P, N);
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_partial_sums<bf16_tag, 1>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, C,
+                P, act, masked, partials);
+  else
+    CBIM_LAUNCH((k_partial_sums<float, 1>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, C, P,
+                act, masked, partials);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_norm_bwd_apply(int dtype, const void* g, int64_t g_stride, const void* x,
+                                   int64_t x_stride, const float* stats, const float* sums, const void* add,
+                                   int64_t add_stride, void* dx, int64_t dx_stride, int N, int64_t S, int C,
+                                   int act, int masked, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * S * (C / cpc);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_norm_bwd_apply<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, g, g_stride, x,
+                x_stride, stats, sums, add, add_stride, dx, dx_stride, S, C, act, masked, total);
+  else
+    CBIM_LAUNCH((k_norm_bwd_apply<float>), dim3(grid_for(total)), dim3(NT), 0, st, g, g_stride, x, x_stride,
+                stats, sums, add, add_stride, dx, dx_stride, S, C, act, masked, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S,
+                                   void* stream) {
+  int64_t total = (int64_t)N * C * S;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype_out == CBIM_BF16)
+    CBIM_LAUNCH((k_ncdhw_to_ndhwc<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, x, y, C, S, total);
+  else
+    CBIM_LAUNCH((k_ncdhw_to_ndhwc<float>), dim3(grid_for(total)), dim3(NT), 0, st, x, y, C, S, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S,
+                                   void* stream) {
+  int64_t total = (int64_t)N * C * S;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype_in == CBIM_BF16)
+    CBIM_LAUNCH((k_ndhwc_to_ncdhw<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, x, y, C, S, total);
+  else
+    CBIM_LAUNCH((k_ndhwc_to_ncdhw<float>), dim3(grid_for(total)), dim3(NT), 0, st, x, y, C, S, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}

@@ -1,0 +1,308 @@
+// pool_up_kernels.hip — MaxPool3d and trilinear(align_corners=True)-upsample + concat.
+//
+// HBM-bound gather kernels on channels-last tensors; one work item = one 16-byte channel chunk
+// of one output voxel, so every global access of a wave is a run of whole 16-byte chunks.
+//
+// Reference call sites (/root/reference): nn.MaxPool3d(down_scale) unet_utils.py:36;
+// F.interpolate(x1, size=x2.shape[2:], mode='trilinear', align_corners=True) + torch.cat([x2,x1],1)
+// unet_utils.py:69-71.  Index/weight arithmetic follows ATen's align_corners rule:
+// scale=(in-1)/(out-1) (0 if out==1), src=scale*dst, i0=(int)src, i1=min(i0+1,in-1), l1=src-i0.
+#include "cbim_common.h"
+
+namespace cbim {
+
+static constexpr int NT = 256;
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_maxpool_fwd(const void* __restrict__ x, void* __restrict__ y,
+                                                    uint8_t* __restrict__ idx, int D, int H, int W, int C,
+                                                    int sD, int sH, int sW, int Do, int Ho, int Wo,
+                                                    int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int cc = (int)(i % cch);
+    int64_t r = i / cch;
+    int wo = (int)(r % Wo); r /= Wo;
+    int ho = (int)(r % Ho); r /= Ho;
+    int dz = (int)(r % Do);
+    int64_t n = r / Do;
+    float m[CPC];
+    uint8_t am[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) { m[j] = -INFINITY; am[j] = 0; }
+    int pos = 0;
+    for (int a = 0; a < sD; ++a)
+      for (int b = 0; b < sH; ++b)
+        for (int c = 0; c < sW; ++c, ++pos) {
+          size_t row = (((size_t)n * D + (dz * sD + a)) * H + (ho * sH + b)) * W + (wo * sW + c);
+          float f[CPC];
+          Elem<T>::unpack(ld_chunk<T>(x, row * C + (size_t)cc * CPC), f);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j)
+            if (f[j] > m[j] || f[j] != f[j]) { m[j] = f[j]; am[j] = (uint8_t)pos; }
+        }
+    size_t orow = (((size_t)n * Do + dz) * Ho + ho) * Wo + wo;
+    st_chunk<T>(y, orow * C + (size_t)cc * CPC, Elem<T>::pack(m));
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) idx[orow * C + (size_t)cc * CPC + j] = am[j];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_maxpool_bwd(const void* __restrict__ dy,
+                                                    const uint8_t* __restrict__ idx, void* __restrict__ dx,
+                                                    int D, int H, int W, int C, int sD, int sH, int sW,
+                                                    int Do, int Ho, int Wo, int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int cc = (int)(i % cch);
+    int64_t r = i / cch;
+    int w = (int)(r % W); r /= W;
+    int h = (int)(r % H); r /= H;
+    int d = (int)(r % D);
+    int64_t n = r / D;
+    float f[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) f[j] = 0.f;
+    int dz = d / sD, ho = h / sH, wo = w / sW;
+    if (dz < Do && ho < Ho && wo < Wo) {
+      int pos = ((d - dz * sD) * sH + (h - ho * sH)) * sW + (w - wo * sW);
+      size_t orow = (((size_t)n * Do + dz) * Ho + ho) * Wo + wo;
+      float g[CPC];
+      Elem<T>::unpack(ld_chunk<T>(dy, orow * C + (size_t)cc * CPC), g);
+#pragma unroll
+      for (int j = 0; j < CPC; ++j)
+        if (idx[orow * C + (size_t)cc * CPC + j] == (uint8_t)pos) f[j] = g[j];
+    }
+    size_t row = (((size_t)n * D + d) * H + h) * W + w;
+    st_chunk<T>(dx, row * C + (size_t)cc * CPC, Elem<T>::pack(f));
+  }
+}
+
+// ---- trilinear align_corners source index ------------------------------------------------------
+struct Lin { int i0, i1; float l0, l1; };
+__device__ __forceinline__ float lin_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+__device__ __forceinline__ Lin lin_src(int dst, float scale, int in) {
+  float src = scale * (float)dst;
+  int i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  float l1 = src - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  Lin r;
+  r.i0 = i0;
+  r.i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  r.l1 = l1;
+  r.l0 = 1.f - l1;
+  return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_upcat_fwd(const void* __restrict__ low, const void* __restrict__ skip,
+                                                  void* __restrict__ out, int Dl, int Hl, int Wl, int Cl,
+                                                  int D, int H, int W, int Cs, int skip_first,
+                                                  int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int Ct = Cs + Cl;
+  const int cch = Ct / CPC;
+  const float sd = lin_scale(Dl, D), sh = lin_scale(Hl, H), sw = lin_scale(Wl, W);
+  const int skip_lo = skip_first ? 0 : Cl;
+  const int low_lo = skip_first ? Cs : 0;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int cc = (int)(i % cch);
+    int64_t r = i / cch;  // output row
+    int c0 = cc * CPC;
+    bool is_skip = c0 >= skip_lo && c0 < skip_lo + Cs;
+    if (is_skip) {
+      st_chunk<T>(out, (size_t)r * Ct + c0, ld_chunk<T>(skip, (size_t)r * Cs + (c0 - skip_lo)));
+      continue;
+    }
+    int64_t q = r;
+    int w = (int)(q % W); q /= W;
+    int h = (int)(q % H); q /= H;
+    int d = (int)(q % D);
+    int64_t n = q / D;
+    Lin ld = lin_src(d, sd, Dl), lh = lin_src(h, sh, Hl), lw = lin_src(w, sw, Wl);
+    int cl = c0 - low_lo;
+    float acc[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int dd = a ? ld.i1 : ld.i0;
+      float wa = a ? ld.l1 : ld.l0;
+      float pa[CPC];
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) pa[j] = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        int hh = b ? lh.i1 : lh.i0;
+        float wb = b ? lh.l1 : lh.l0;
+        size_t rbase = (((size_t)n * Dl + dd) * Hl + hh) * Wl;
+        float f0[CPC], f1[CPC];
+        Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl), f0);
+        Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl), f1);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) pa[j] += wb * (lw.l0 * f0[j] + lw.l1 * f1[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) acc[j] += wa * pa[j];
+    }
+    st_chunk<T>(out, (size_t)r * Ct + c0, Elem<T>::pack(acc));
+  }
+}
+
+// candidate range of destination indices whose interpolation footprint can touch source index l
+__device__ __forceinline__ void dst_range(int l, float scale, int out, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+  float a = ((float)l - 1.f) / scale, b = ((float)l + 1.f) / scale;
+  lo = (int)floorf(a) - 1;
+  hi = (int)ceilf(b) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+__device__ __forceinline__ float lin_weight_to(int dst, float scale, int in, int l) {
+  Lin s = lin_src(dst, scale, in);
+  float w = 0.f;
+  if (s.i0 == l) w += s.l0;
+  if (s.i1 == l) w += s.l1;
+  return w;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_upcat_bwd_low(const void* __restrict__ dout, void* __restrict__ dlow,
+                                                      int Dl, int Hl, int Wl, int Cl, int D, int H, int W,
+                                                      int Ct, int low_lo, int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = Cl / CPC;
+  const float sd = lin_scale(Dl, D), sh = lin_scale(Hl, H), sw = lin_scale(Wl, W);
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int cc = (int)(i % cch);
+    int64_t q = i / cch;
+    int wl = (int)(q % Wl); q /= Wl;
+    int hl = (int)(q % Hl); q /= Hl;
+    int dl = (int)(q % Dl);
+    int64_t n = q / Dl;
+    int d0, d1, h0, h1, w0, w1;
+    dst_range(dl, sd, D, d0, d1);
+    dst_range(hl, sh, H, h0, h1);
+    dst_range(wl, sw, W, w0, w1);
+    float acc[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
+    for (int d = d0; d <= d1; ++d) {
+      float wd = lin_weight_to(d, sd, Dl, dl);
+      if (wd == 0.f) continue;
+      for (int h = h0; h <= h1; ++h) {
+        float wh = lin_weight_to(h, sh, Hl, hl);
+        if (wh == 0.f) continue;
+        float wdh = wd * wh;
+        size_t rbase = (((size_t)n * D + d) * H + h) * W;
+        for (int w = w0; w <= w1; ++w) {
+          float ww = lin_weight_to(w, sw, Wl, wl);
+          if (ww == 0.f) continue;
+          float f[CPC];
+          Elem<T>::unpack(ld_chunk<T>(dout, (rbase + w) * Ct + low_lo + (size_t)cc * CPC), f);
+          float wt = wdh * ww;
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) acc[j] += wt * f[j];
+        }
+      }
+    }
+    size_t row = (((size_t)n * Dl + dl) * Hl + hl) * Wl + wl;
+    st_chunk<T>(dlow, row * Cl + (size_t)cc * CPC, Elem<T>::pack(acc));
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_slice_copy(const void* __restrict__ src, int64_t src_stride, int c_off,
+                                                   void* __restrict__ dst, int C, int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int cc = (int)(i % cch);
+    int64_t r = i / cch;
+    st_chunk<T>(dst, (size_t)r * C + (size_t)cc * CPC,
+                ld_chunk<T>(src, (size_t)r * src_stride + c_off + (size_t)cc * CPC));
+  }
+}
+
+static inline int grid_for(int64_t items) {
+  int64_t b = (items + NT - 1) / NT;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+#define DISPATCH_T(dtype, KERNEL, grid, st, ...)                                        \
+  do {                                                                                  \
+    if ((dtype) == CBIM_BF16)                                                           \
+      CBIM_LAUNCH((KERNEL<bf16_tag>), grid, dim3(NT), 0, st, __VA_ARGS__);              \
+    else                                                                                \
+      CBIM_LAUNCH((KERNEL<float>), grid, dim3(NT), 0, st, __VA_ARGS__);                 \
+  } while (0)
+
+static int check_c(int dtype, int C, const char* what) {
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  CBIM_CHECK(C > 0 && C % cpc == 0, CBIM_EUNSUPPORTED, "%s channel count %d is not a multiple of %d", what, C, cpc);
+  return 0;
+}
+
+extern "C" int cbim_maxpool3d_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int D, int H,
+                                  int W, int C, int sD, int sH, int sW, void* stream) {
+  if (int e = check_c(dtype, C, "maxpool")) return e;
+  CBIM_CHECK(sD >= 1 && sH >= 1 && sW >= 1 && sD * sH * sW <= 255, CBIM_EUNSUPPORTED, "pool window too large");
+  int Do = D / sD, Ho = H / sH, Wo = W / sW;
+  CBIM_CHECK(Do >= 1 && Ho >= 1 && Wo >= 1, CBIM_EINVAL, "pool output empty");
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * Do * Ho * Wo * (C / cpc);
+  DISPATCH_T(dtype, k_maxpool_fwd, dim3(grid_for(total)), (hipStream_t)stream, x, y, idx, D, H, W, C, sD, sH,
+             sW, Do, Ho, Wo, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_maxpool3d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int D,
+                                  int H, int W, int C, int sD, int sH, int sW, void* stream) {
+  if (int e = check_c(dtype, C, "maxpool")) return e;
+  int Do = D / sD, Ho = H / sH, Wo = W / sW;
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * D * H * W * (C / cpc);
+  DISPATCH_T(dtype, k_maxpool_bwd, dim3(grid_for(total)), (hipStream_t)stream, dy, idx, dx, D, H, W, C, sD,
+             sH, sW, Do, Ho, Wo, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_upcat_fwd(int dtype, const void* low, const void* skip, void* out, int N, int Dl, int Hl,
+                              int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream) {
+  if (int e = check_c(dtype, Cl, "upcat low")) return e;
+  if (Cs > 0) if (int e = check_c(dtype, Cs, "upcat skip")) return e;
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * D * H * W * ((Cs + Cl) / cpc);
+  DISPATCH_T(dtype, k_upcat_fwd, dim3(grid_for(total)), (hipStream_t)stream, low, skip, out, Dl, Hl, Wl, Cl,
+             D, H, W, Cs, skip_first, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dskip, int N, int Dl, int Hl,
+                              int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream) {
+  if (int e = check_c(dtype, Cl, "upcat low")) return e;
+  if (Cs > 0) if (int e = check_c(dtype, Cs, "upcat skip")) return e;
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int Ct = Cs + Cl;
+  int low_lo = skip_first ? Cs : 0, skip_lo = skip_first ? 0 : Cl;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t total = (int64_t)N * Dl * Hl * Wl * (Cl / cpc);
+  DISPATCH_T(dtype, k_upcat_bwd_low, dim3(grid_for(total)), st, dout, dlow, Dl, Hl, Wl, Cl, D, H, W, Ct,
+             low_lo, total);
+  if (Cs > 0 && dskip) {
+    int64_t t2 = (int64_t)N * D * H * W * (Cs / cpc);
+    DISPATCH_T(dtype, k_slice_copy, dim3(grid_for(t2)), st, dout, (int64_t)Ct, skip_lo, dskip, Cs, t2);
+  }
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}

@@ -1,0 +1,438 @@
+// stem_head_kernels.hip — the two HBM-bound convolutions at the model boundary.
+//
+//   stem: inconv.conv1 = nn.Conv3d(in_ch, base, k, pad k//2, bias=False)  (unet_utils.py:14,19):
+//         reads the caller's NCDHW fp32 volume (in_ch is 1..4), writes channels-last T.
+//         AI ~ 13 FLOP/B -> direct VALU kernel, LDS halo of the input, weights broadcast from LDS.
+//   head: outc = nn.Conv3d(base, classes, 1) with bias (unet.py:47): channels-last T in, NCDHW fp32
+//         logits out (the layout nn.CrossEntropyLoss / DiceLoss consume, train.py:212).
+#include "cbim_common.h"
+
+namespace cbim {
+
+static constexpr int NT = 256;
+static constexpr int MAXTAPS = 27;
+static constexpr int KMAX = 32;   // classes handled per pass of the head kernels
+
+struct StemParams {
+  const float* x; const float* w; void* y; const void* dy; float* ws;
+  int N, Cin, Di, Hi, Wi, Cout, kD, kH, kW, pD, pH, pW, Do, Ho, Wo;
+  int tiles_d, tiles_h, tiles_w, hD, hH, hW, taps;
+  int strips_per_n, tiles_per_strip;
+};
+
+#ifdef CBIM_EMU
+#define CBIM_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
+#else
+#define CBIM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+// tile = 4 x 8 x 8 output voxels, one thread per voxel, 8 couts per register pass.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_stem_fwd(StemParams p) {
+  constexpr int CPC = Elem<T>::CPC;
+  CBIM_DYN_SMEM(smem);
+  const int hV = p.hD * p.hH * p.hW;
+  float* xL = (float*)smem;                       // [Cin][hV]
+  float* wL = xL + (size_t)p.Cin * hV;            // [taps*Cin][Cout]  (cout fastest -> broadcast reads)
+  const int tid = threadIdx.x;
+  const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int n = bid / tiles_per_n, t = bid % tiles_per_n;
+  const int od0 = (t / (p.tiles_w * p.tiles_h)) * 4, oh0 = ((t / p.tiles_w) % p.tiles_h) * 8, ow0 = (t % p.tiles_w) * 8;
+  const size_t Sin = (size_t)p.Di * p.Hi * p.Wi;
+  for (int i = tid; i < p.Cin * hV; i += NT) {
+    int ci = i / hV, hv = i % hV;
+    int hw = hv % p.hW, r = hv / p.hW, hh = r % p.hH, hd = r / p.hH;
+    int id = od0 - p.pD + hd, ih = oh0 - p.pH + hh, iw = ow0 - p.pW + hw;
+    float v = 0.f;
+    if (id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi)
+      v = p.x[((size_t)n * p.Cin + ci) * Sin + ((size_t)id * p.Hi + ih) * p.Wi + iw];
+    xL[i] = v;
+  }
+  for (int i = tid; i < p.taps * p.Cin * p.Cout; i += NT) {
+    int co = i % p.Cout, r = i / p.Cout;       // r = tap*Cin + ci
+    int ci = r % p.Cin, tap = r / p.Cin;
+    wL[i] = p.w[((size_t)co * p.Cin + ci) * p.taps + tap];
+  }
+  __syncthreads();
+  const int tw = tid & 7, th = (tid >> 3) & 7, td = tid >> 6;
+  const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+  const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+  const int hv0 = (td * p.hH + th) * p.hW + tw;
+  const size_t row = (size_t)n * p.Do * p.Ho * p.Wo + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+  for (int cg = 0; cg < p.Cout; cg += CPC) {
+    float acc[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
+    for (int ci = 0; ci < p.Cin; ++ci) {
+      int tap = 0;
+      for (int kd = 0; kd < p.kD; ++kd)
+        for (int kh = 0; kh < p.kH; ++kh)
+          for (int kw = 0; kw < p.kW; ++kw, ++tap) {
+            float xv = xL[ci * hV + hv0 + (kd * p.hH + kh) * p.hW + kw];
+            const float* wr = wL + (size_t)(tap * p.Cin + ci) * p.Cout + cg;
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+          }
+    }
+    if (ok) st_chunk<T>(p.y, row * p.Cout + cg, Elem<T>::pack(acc));
+  }
+}
+
+// dw[co][ci][tap] = sum_v dy[v][co] * x[v+tap-p][ci]; thread = (co lane, voxel group); strip of tiles
+// per workgroup; per-strip slab [Cin][taps][Cout] then a fixed-order reduce.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
+  CBIM_DYN_SMEM(smem);
+  const int hV = p.hD * p.hH * p.hW;
+  float* xL = (float*)smem;                           // [hV]
+  float* red = xL + hV;                               // [NT/32 groups][MAXTAPS][32]
+  const int tid = threadIdx.x, col = tid & 31, vg = tid >> 5;   // 8 voxel groups
+  const int n = blockIdx.x / p.strips_per_n, strip = blockIdx.x % p.strips_per_n;
+  const int cob = blockIdx.y;   // block of 32 couts
+  const int co = cob * 32 + col;
+  const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+  const int t_begin = strip * p.tiles_per_strip;
+  int t_end = t_begin + p.tiles_per_strip;
+  if (t_end > tiles_per_n) t_end = tiles_per_n;
+  const size_t Sin = (size_t)p.Di * p.Hi * p.Wi;
+  const size_t slab = (size_t)p.Cin * p.taps * p.Cout;
+  __shared__ int toff[MAXTAPS];
+  if (tid < MAXTAPS) {
+    int k = tid < p.taps ? tid : 0;
+    int kw = k % p.kW, r = k / p.kW, kh = r % p.kH, kd = r / p.kH;
+    toff[tid] = (kd * p.hH + kh) * p.hW + kw;
+  }
+  for (int ci = 0; ci < p.Cin; ++ci) {
+    float acc[MAXTAPS];
+#pragma unroll
+    for (int k = 0; k < MAXTAPS; ++k) acc[k] = 0.f;
+    for (int t = t_begin; t < t_end; ++t) {
+      const int od0 = (t / (p.tiles_w * p.tiles_h)) * 4, oh0 = ((t / p.tiles_w) % p.tiles_h) * 8, ow0 = (t % p.tiles_w) * 8;
+      __syncthreads();
+      for (int hv = tid; hv < hV; hv += NT) {
+        int hw = hv % p.hW, r = hv / p.hW, hh = r % p.hH, hd = r / p.hH;
+        int id = od0 - p.pD + hd, ih = oh0 - p.pH + hh, iw = ow0 - p.pW + hw;
+        float v = 0.f;
+        if (id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi)
+          v = p.x[((size_t)n * p.Cin + ci) * Sin + ((size_t)id * p.Hi + ih) * p.Wi + iw];
+        xL[hv] = v;
+      }
+      __syncthreads();
+      for (int m = vg; m < 256; m += 8) {
+        int tw = m & 7, th = (m >> 3) & 7, td = m >> 6;
+        int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+        if (co < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo) {
+          size_t row = (size_t)n * p.Do * p.Ho * p.Wo + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+          float g = Elem<T>::load1(p.dy, row * p.Cout + co);
+          int hv0 = (td * p.hH + th) * p.hW + tw;
+#pragma unroll
+          for (int k = 0; k < MAXTAPS; ++k) {
+            if (k < p.taps) acc[k] = fmaf(g, xL[hv0 + toff[k]], acc[k]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXTAPS; ++k) red[(vg * MAXTAPS + k) * 32 + col] = acc[k];
+    __syncthreads();
+    for (int i = tid; i < p.taps * 32; i += NT) {
+      int c = i & 31, k = i >> 5;
+      float a = 0.f;
+      for (int g = 0; g < 8; ++g) a += red[(g * MAXTAPS + k) * 32 + c];
+      if (cob * 32 + c < p.Cout) p.ws[(size_t)blockIdx.x * slab + ((size_t)ci * p.taps + k) * p.Cout + cob * 32 + c] = a;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_stem_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw,
+                                                          int n_slabs, int Cin, int taps, int Cout) {
+  int total = Cin * taps * Cout;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
+    int co = i % Cout, r = i / Cout;
+    int k = r % taps, ci = r / taps;
+    float a = 0.f;
+    for (int s = 0; s < n_slabs; ++s) a += ws[(size_t)s * total + i];
+    dw[((size_t)co * Cin + ci) * taps + k] = a;
+  }
+}
+
+// ---- head ------------------------------------------------------------------------------------------------
+// one thread per voxel; the voxel's channels stream through registers chunk by chunk; weights and
+// bias are broadcast LDS reads; logits are written plane by plane (coalesced over voxels).
+template <typename T>
+__global__ void __launch_bounds__(NT) k_head_fwd(const void* __restrict__ x, const float* __restrict__ w,
+                                                 const float* __restrict__ b, float* __restrict__ logits,
+                                                 int64_t S, int Cin, int K, int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  CBIM_DYN_SMEM(smem);
+  float* wL = (float*)smem;  // [Cin][K]  (k fastest)
+  for (int i = threadIdx.x; i < Cin * K; i += NT) {
+    int k = i % K, c = i / K;
+    wL[i] = w[(size_t)k * Cin + c];
+  }
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += KMAX) {
+    for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < total; r += (int64_t)gridDim.x * NT) {
+      float out[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) out[k] = (k0 + k < K) ? b[k0 + k] : 0.f;
+      for (int c0 = 0; c0 < Cin; c0 += CPC) {
+        float f[CPC];
+        Elem<T>::unpack(ld_chunk<T>(x, (size_t)r * Cin + c0), f);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          const float* wr = wL + (size_t)(c0 + j) * K + k0;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            if (k0 + k < K) out[k] = fmaf(f[j], wr[k], out[k]);
+        }
+      }
+      int64_t n = r / S, v = r % S;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k0 + k < K) logits[((size_t)n * K + k0 + k) * S + v] = out[k];
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_head_bwd_dx(const float* __restrict__ w, const float* __restrict__ dz,
+                                                    void* __restrict__ dx, int64_t S, int Cin, int K,
+                                                    int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  CBIM_DYN_SMEM(smem);
+  float* wL = (float*)smem;  // [K][Cin]
+  for (int i = threadIdx.x; i < Cin * K; i += NT) wL[i] = w[i];
+  __syncthreads();
+  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < total; r += (int64_t)gridDim.x * NT) {
+    int64_t n = r / S, v = r % S;
+    for (int c0 = 0; c0 < Cin; c0 += CPC) {
+      float f[CPC];
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) f[j] = 0.f;
+      for (int k = 0; k < K; ++k) {
+        float g = dz[((size_t)n * K + k) * S + v];
+        const float* wr = wL + (size_t)k * Cin + c0;
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) f[j] = fmaf(g, wr[j], f[j]);
+      }
+      st_chunk<T>(dx, (size_t)r * Cin + c0, Elem<T>::pack(f));
+    }
+  }
+}
+
+// dw[k][c] = sum_v dz[k][v] x[v][c], db[k] = sum_v dz[k][v]; workgroup = strip of voxels, 64-voxel LDS
+// tiles, thread owns up to PAIRS (k,c) pairs; slab per workgroup, fixed-order reduce.
+static constexpr int HB_TILE = 64;
+static constexpr int HB_PAIRS = 8;
+template <typename T>
+__global__ void __launch_bounds__(NT) k_head_bwd_dw(const void* __restrict__ x, const float* __restrict__ dz,
+                                                    float* __restrict__ ws, int64_t S, int Cin, int K,
+                                                    int64_t vox_per_block) {
+  CBIM_DYN_SMEM(smem);
+  float* xL = (float*)smem;               // [HB_TILE][Cin+1]
+  float* zL = xL + HB_TILE * (Cin + 1);   // [K][HB_TILE]
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int npairs = K * (Cin + 1);       // c == Cin -> bias column
+  float acc[HB_PAIRS];
+#pragma unroll
+  for (int q = 0; q < HB_PAIRS; ++q) acc[q] = 0.f;
+  int64_t v_begin = (int64_t)blockIdx.x * vox_per_block;
+  int64_t v_end = v_begin + vox_per_block;
+  if (v_end > S) v_end = S;
+  for (int64_t vb = v_begin; vb < v_end; vb += HB_TILE) {
+    __syncthreads();
+    for (int i = tid; i < HB_TILE * Cin; i += NT) {
+      int c = i % Cin, m = i / Cin;
+      int64_t v = vb + m;
+      xL[m * (Cin + 1) + c] = v < v_end ? Elem<T>::load1(x, ((size_t)n * S + v) * Cin + c) : 0.f;
+    }
+    for (int i = tid; i < HB_TILE; i += NT) xL[i * (Cin + 1) + Cin] = 1.f;
+    for (int i = tid; i < HB_TILE * K; i += NT) {
+      int m = i % HB_TILE, k = i / HB_TILE;
+      int64_t v = vb + m;
+      zL[k * HB_TILE + m] = v < v_end ? dz[((size_t)n * K + k) * S + v] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < HB_PAIRS; ++q) {
+      int pr = tid + q * NT;
+      if (pr < npairs) {
+        int c = pr % (Cin + 1), k = pr / (Cin + 1);
+        float a = acc[q];
+        for (int m = 0; m < HB_TILE; ++m) a = fmaf(zL[k * HB_TILE + m], xL[m * (Cin + 1) + c], a);
+        acc[q] = a;
+      }
+    }
+  }
+  float* slab = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * npairs;
+#pragma unroll
+  for (int q = 0; q < HB_PAIRS; ++q) {
+    int pr = tid + q * NT;
+    if (pr < npairs) slab[pr] = acc[q];
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_head_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dw,
+                                                        float* __restrict__ db, int n_slabs, int Cin, int K) {
+  int npairs = K * (Cin + 1);
+  for (int i = blockIdx.x * NT + threadIdx.x; i < npairs; i += gridDim.x * NT) {
+    int c = i % (Cin + 1), k = i / (Cin + 1);
+    float a = 0.f;
+    for (int s = 0; s < n_slabs; ++s) a += ws[(size_t)s * npairs + i];
+    if (c < Cin) dw[(size_t)k * Cin + c] = a;
+    else db[k] = a;
+  }
+}
+
+static inline int grid_for(int64_t items) {
+  int64_t b = (items + NT - 1) / NT;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+struct StemCfg { int tiles_d, tiles_h, tiles_w, strips_per_n, tiles_per_strip; };
+static StemCfg stem_cfg(int N, int Do, int Ho, int Wo) {
+  StemCfg c;
+  c.tiles_d = (Do + 3) / 4; c.tiles_h = (Ho + 7) / 8; c.tiles_w = (Wo + 7) / 8;
+  int tiles = c.tiles_d * c.tiles_h * c.tiles_w;
+  int want = 1024 / N;
+  if (want < 1) want = 1;
+  if (want > tiles) want = tiles;
+  c.tiles_per_strip = (tiles + want - 1) / want;
+  c.strips_per_n = (tiles + c.tiles_per_strip - 1) / c.tiles_per_strip;
+  return c;
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+static int stem_check(int dtype, int Cin, int Cout, int kD, int kH, int kW) {
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype");
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  CBIM_CHECK(Cout % cpc == 0, CBIM_EUNSUPPORTED, "stem Cout %d is not a multiple of %d", Cout, cpc);
+  CBIM_CHECK(Cin >= 1 && Cin <= 16, CBIM_EUNSUPPORTED, "stem Cin %d unsupported (1..16)", Cin);
+  CBIM_CHECK(kD * kH * kW <= MAXTAPS, CBIM_EUNSUPPORTED, "stem kernel too large");
+  return 0;
+}
+
+static void stem_fill(StemParams& p, int N, int Cin, int Di, int Hi, int Wi, int Cout, int kD, int kH, int kW,
+                      int pD, int pH, int pW, int Do, int Ho, int Wo) {
+  p.N = N; p.Cin = Cin; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cout = Cout; p.kD = kD; p.kH = kH; p.kW = kW;
+  p.pD = pD; p.pH = pH; p.pW = pW; p.Do = Do; p.Ho = Ho; p.Wo = Wo;
+  StemCfg c = stem_cfg(N, Do, Ho, Wo);
+  p.tiles_d = c.tiles_d; p.tiles_h = c.tiles_h; p.tiles_w = c.tiles_w;
+  p.hD = 4 + kD - 1; p.hH = 8 + kH - 1; p.hW = 8 + kW - 1; p.taps = kD * kH * kW;
+  p.strips_per_n = c.strips_per_n; p.tiles_per_strip = c.tiles_per_strip;
+}
+
+extern "C" int cbim_stem_conv_fwd(int dtype_out, const float* x, const float* w, void* y, int N, int Cin,
+                                  int Di, int Hi, int Wi, int Cout, int kD, int kH, int kW, int pD, int pH,
+                                  int pW, int Do, int Ho, int Wo, void* stream) {
+  if (int e = stem_check(dtype_out, Cin, Cout, kD, kH, kW)) return e;
+  StemParams p;
+  p.x = x; p.w = w; p.y = y; p.dy = nullptr; p.ws = nullptr;
+  stem_fill(p, N, Cin, Di, Hi, Wi, Cout, kD, kH, kW, pD, pH, pW, Do, Ho, Wo);
+  size_t smem = ((size_t)Cin * p.hD * p.hH * p.hW + (size_t)p.taps * Cin * Cout) * sizeof(float);
+  CBIM_CHECK(smem <= 64 * 1024, CBIM_EUNSUPPORTED, "stem needs %zu B of LDS", smem);
+  dim3 grid((unsigned)(N * p.tiles_d * p.tiles_h * p.tiles_w));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype_out == CBIM_BF16) CBIM_LAUNCH((k_stem_fwd<bf16_tag>), grid, dim3(NT), smem, st, p);
+  else CBIM_LAUNCH((k_stem_fwd<float>), grid, dim3(NT), smem, st, p);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" size_t cbim_stem_conv_wgrad_workspace(int N, int Cin, int Cout, int kD, int kH, int kW, int Do,
+                                                 int Ho, int Wo) {
+  StemCfg c = stem_cfg(N, Do, Ho, Wo);
+  return (size_t)N * c.strips_per_n * Cin * kD * kH * kW * Cout * sizeof(float);
+}
+
+extern "C" int cbim_stem_conv_wgrad(int dtype, const float* x, const void* dy, float* dw, int N, int Cin,
+                                    int Di, int Hi, int Wi, int Cout, int kD, int kH, int kW, int pD, int pH,
+                                    int pW, int Do, int Ho, int Wo, void* workspace, size_t ws_bytes,
+                                    void* stream) {
+  if (int e = stem_check(dtype, Cin, Cout, kD, kH, kW)) return e;
+  size_t need = cbim_stem_conv_wgrad_workspace(N, Cin, Cout, kD, kH, kW, Do, Ho, Wo);
+  CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "stem wgrad workspace %zu < %zu", ws_bytes, need);
+  StemParams p;
+  p.x = x; p.w = nullptr; p.y = nullptr; p.dy = dy; p.ws = (float*)workspace;
+  stem_fill(p, N, Cin, Di, Hi, Wi, Cout, kD, kH, kW, pD, pH, pW, Do, Ho, Wo);
+  size_t smem = ((size_t)p.hD * p.hH * p.hW + (size_t)(NT / 32) * MAXTAPS * 32) * sizeof(float);
+  dim3 grid((unsigned)(N * p.strips_per_n), (unsigned)((Cout + 31) / 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CBIM_BF16) CBIM_LAUNCH((k_stem_wgrad<bf16_tag>), grid, dim3(NT), smem, st, p);
+  else CBIM_LAUNCH((k_stem_wgrad<float>), grid, dim3(NT), smem, st, p);
+  int total = Cin * p.taps * Cout;
+  CBIM_LAUNCH(k_stem_wgrad_reduce, dim3((total + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw,
+              N * p.strips_per_n, Cin, p.taps, Cout);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+static int head_check(int dtype, int Cin, int K) {
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype");
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  CBIM_CHECK(Cin % cpc == 0 && Cin <= 512, CBIM_EUNSUPPORTED, "head Cin %d unsupported", Cin);
+  CBIM_CHECK(K >= 1 && K * (Cin + 1) <= HB_PAIRS * NT, CBIM_EUNSUPPORTED, "head K=%d x Cin=%d too large", K, Cin);
+  return 0;
+}
+
+extern "C" int cbim_head_fwd(int dtype, const void* x, const float* w, const float* b, float* logits, int N,
+                             int64_t S, int Cin, int K, void* stream) {
+  if (int e = head_check(dtype, Cin, K)) return e;
+  int64_t total = (int64_t)N * S;
+  size_t smem = (size_t)Cin * K * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_head_fwd<bf16_tag>), dim3(grid_for(total)), dim3(NT), smem, st, x, w, b, logits, S, Cin, K, total);
+  else
+    CBIM_LAUNCH((k_head_fwd<float>), dim3(grid_for(total)), dim3(NT), smem, st, x, w, b, logits, S, Cin, K, total);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+static int head_bwd_blocks(int64_t S) {
+  int64_t b = (S + 4095) / 4096;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" size_t cbim_head_bwd_workspace(int64_t S, int N, int Cin, int K) {
+  return (size_t)N * head_bwd_blocks(S) * K * (Cin + 1) * sizeof(float);
+}
+
+extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const float* dlogits, void* dx,
+                             float* dw, float* db, int N, int64_t S, int Cin, int K, void* workspace,
+                             size_t ws_bytes, void* stream) {
+  if (int e = head_check(dtype, Cin, K)) return e;
+  size_t need = cbim_head_bwd_workspace(S, N, Cin, K);
+  CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "head bwd workspace %zu < %zu", ws_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t total = (int64_t)N * S;
+  size_t smem = (size_t)Cin * K * sizeof(float);
+  if (dx) {
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_head_bwd_dx<bf16_tag>), dim3(grid_for(total)), dim3(NT), smem, st, w, dlogits, dx, S, Cin, K, total);
+    else
+      CBIM_LAUNCH((k_head_bwd_dx<float>), dim3(grid_for(total)), dim3(NT), smem, st, w, dlogits, dx, S, Cin, K, total);
+  }
+  int nb = head_bwd_blocks(S);
+  int64_t vpb = (S + nb - 1) / nb;
+  vpb = (vpb + HB_TILE - 1) / HB_TILE * HB_TILE;
+  size_t smem2 = ((size_t)HB_TILE * (Cin + 1) + (size_t)K * HB_TILE) * sizeof(float);
+  CBIM_CHECK(smem2 <= 64 * 1024, CBIM_EUNSUPPORTED, "head bwd needs %zu B LDS", smem2);
+  dim3 grid((unsigned)nb, (unsigned)N);
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_head_bwd_dw<bf16_tag>), grid, dim3(NT), smem2, st, x, dlogits, (float*)workspace, S, Cin, K, vpb);
+  else
+    CBIM_LAUNCH((k_head_bwd_dw<float>), grid, dim3(NT), smem2, st, x, dlogits, (float*)workspace, S, Cin, K, vpb);
+  int npairs = K * (Cin + 1);
+  CBIM_LAUNCH(k_head_bwd_reduce, dim3((npairs + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw, db,
+              N * nb, Cin, K);
+  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}

@@ -1,0 +1,344 @@
+"""Thin tensor-level wrappers over the C ABI (``include/cbim_hip.h``).
+
+Tensors are torch tensors used purely as device memory: activations are channels-last
+``[N, D, H, W, C]`` contiguous, dtype ``torch.bfloat16`` (fast mode) or ``torch.float32``
+(parity mode); InstanceNorm statistics are ``float32 [N, C, 2]`` (mean, rstd).
+Every function launches asynchronously on the current HIP stream.  There is no CPU or
+PyTorch fallback: tensors must live where the loaded kernel library executes
+(``cuda`` for libcbim_hip.so; ``cpu`` only for the test-suite's kernel executor).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "gelu": 3, "swish": 4, "silu": 4}
+IN_EPS = 1e-4  # /root/reference/model/dim3/conv_layers.py:40,42
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return 1
+    if t.dtype == torch.float32:
+        return 0
+    raise TypeError(f"cbim_amd: unsupported activation dtype {t.dtype}")
+
+
+def _dev_ok(*ts):
+    want = "cpu" if _lib.backend() == "emu" else "cuda"
+    for t in ts:
+        if t is None:
+            continue
+        if t.device.type != want:
+            raise RuntimeError(
+                f"cbim_amd: tensor on '{t.device.type}' but the loaded kernel library "
+                f"({_lib.backend()}) executes on '{want}' — there is no fallback path")
+        if not t.is_contiguous():
+            raise RuntimeError("cbim_amd: non-contiguous tensor passed to a kernel")
+
+
+def _stream(t: torch.Tensor):
+    if t.device.type == "cuda":
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _spatial(x):
+    return int(x.shape[1]) * int(x.shape[2]) * int(x.shape[3])
+
+
+# ------------------------------------------------------------------------------------------------
+# InstanceNorm pieces
+# ------------------------------------------------------------------------------------------------
+
+def instnorm_stats(x: torch.Tensor, eps: float = IN_EPS) -> torch.Tensor:
+    _dev_ok(x)
+    N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
+    L = _lib.lib()
+    P = L.cbim_stats_parts(S, Cc)
+    part = torch.empty((N, P, Cc, 2), dtype=torch.float32, device=x.device)
+    stats = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
+    check(L.cbim_instnorm_stats(_dt(x), _p(x), Cc, N, S, Cc, eps, _p(part), P, _p(stats), _stream(x)),
+          "instnorm_stats")
+    return stats
+
+
+def stats_finalize(partials: torch.Tensor, count: float, eps: float, mode: int) -> torch.Tensor:
+    N, P, Cc, _ = partials.shape
+    out = torch.empty((N, Cc, 2), dtype=torch.float32, device=partials.device)
+    check(_lib.lib().cbim_stats_finalize(_p(partials), N, P, Cc, float(count), eps, mode, _p(out),
+                                         _stream(partials)), "stats_finalize")
+    return out
+
+
+def norm_act_fwd(x, stats, act: int):
+    _dev_ok(x, stats)
+    N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
+    y = torch.empty_like(x)
+    check(_lib.lib().cbim_norm_act_fwd(_dt(x), _p(x), Cc, _p(stats), _p(y), Cc, N, S, Cc, act, _stream(x)),
+          "norm_act_fwd")
+    return y
+
+
+def norm_bwd_sums(g, x, stats, act: int, masked: bool):
+    """(mean(g'), mean(g'*xh)) per (n, c), g' = g*act'(xh) when masked."""
+    _dev_ok(g, x, stats)
+    N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
+    L = _lib.lib()
+    P = L.cbim_stats_parts(S, Cc)
+    part = torch.empty((N, P, Cc, 2), dtype=torch.float32, device=x.device)
+    check(L.cbim_norm_bwd_reduce(_dt(x), _p(g), Cc, _p(x), Cc, _p(stats), N, S, Cc, act, int(masked), _p(part),
+                                 P, _stream(x)), "norm_bwd_reduce")
+    return stats_finalize(part, S, 0.0, 1)
+
+
+def norm_bwd_apply(g, x, stats, sums, act: int, masked: bool, add=None):
+    _dev_ok(g, x, stats, sums, add)
+    N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
+    dx = torch.empty_like(x)
+    check(_lib.lib().cbim_norm_bwd_apply(_dt(x), _p(g), Cc, _p(x), Cc, _p(stats), _p(sums), _p(add), Cc, _p(dx),
+                                         Cc, N, S, Cc, act, int(masked), _stream(x)), "norm_bwd_apply")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / upsample+concat
+# ------------------------------------------------------------------------------------------------
+
+def maxpool_fwd(x, scale: Sequence[int]):
+    _dev_ok(x)
+    N, D, H, W, Cc = map(int, x.shape)
+    sD, sH, sW = map(int, scale)
+    y = torch.empty((N, D // sD, H // sH, W // sW, Cc), dtype=x.dtype, device=x.device)
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+    check(_lib.lib().cbim_maxpool3d_fwd(_dt(x), _p(x), _p(y), _p(idx), N, D, H, W, Cc, sD, sH, sW, _stream(x)),
+          "maxpool3d_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_shape, scale):
+    _dev_ok(dy, idx)
+    N, D, H, W, Cc = map(int, in_shape)
+    sD, sH, sW = map(int, scale)
+    dx = torch.empty(tuple(in_shape), dtype=dy.dtype, device=dy.device)
+    check(_lib.lib().cbim_maxpool3d_bwd(_dt(dy), _p(dy), _p(idx), _p(dx), N, D, H, W, Cc, sD, sH, sW,
+                                        _stream(dy)), "maxpool3d_bwd")
+    return dx
+
+
+def upcat_fwd(low, skip, skip_first: bool = True):
+    _dev_ok(low, skip)
+    N, Dl, Hl, Wl, Cl = map(int, low.shape)
+    _, D, H, W, Cs = map(int, skip.shape)
+    out = torch.empty((N, D, H, W, Cs + Cl), dtype=low.dtype, device=low.device)
+    check(_lib.lib().cbim_upcat_fwd(_dt(low), _p(low), _p(skip), _p(out), N, Dl, Hl, Wl, Cl, D, H, W, Cs,
+                                    int(skip_first), _stream(low)), "upcat_fwd")
+    return out
+
+
+def upcat_bwd(dout, low_shape, Cs: int, skip_first: bool = True):
+    _dev_ok(dout)
+    N, Dl, Hl, Wl, Cl = map(int, low_shape)
+    _, D, H, W, Ct = map(int, dout.shape)
+    dlow = torch.empty(tuple(low_shape), dtype=dout.dtype, device=dout.device)
+    dskip = torch.empty((N, D, H, W, Cs), dtype=dout.dtype, device=dout.device)
+    check(_lib.lib().cbim_upcat_bwd(_dt(dout), _p(dout), _p(dlow), _p(dskip), N, Dl, Hl, Wl, Cl, D, H, W, Cs,
+                                    int(skip_first), _stream(dout)), "upcat_bwd")
+    return dlow, dskip
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution (implicit GEMM on the matrix cores)
+# ------------------------------------------------------------------------------------------------
+
+class ConvGeom:
+    """Geometry of one stride-1 nn.Conv3d call: forward and dgrad descriptors."""
+
+    def __init__(self, dtype: torch.dtype, N, in_dhw, Cin, Cout, k, pad, act: int):
+        self.k = tuple(int(i) for i in k)
+        self.pad = tuple(int(i) for i in pad)
+        Di, Hi, Wi = (int(i) for i in in_dhw)
+        Do, Ho, Wo = (Di + 2 * self.pad[0] - self.k[0] + 1, Hi + 2 * self.pad[1] - self.k[1] + 1,
+                      Wi + 2 * self.pad[2] - self.k[2] + 1)
+        dt = 1 if dtype == torch.bfloat16 else 0
+        self.N, self.Cin, self.Cout = int(N), int(Cin), int(Cout)
+        self.in_dhw, self.out_dhw = (Di, Hi, Wi), (Do, Ho, Wo)
+        self.fwd = ConvDesc(dt, N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, *self.k, *self.pad, act)
+        dpad = tuple(kk - 1 - pp for kk, pp in zip(self.k, self.pad))
+        self.bwd = ConvDesc(dt, N, Do, Ho, Wo, Cout, Di, Hi, Wi, Cin, *self.k, *dpad, act)
+        self.dtype = dtype
+
+
+def pack_weights(w: torch.Tensor, geom: ConvGeom, mode: int) -> torch.Tensor:
+    """fp32 [Cout,Cin,kD,kH,kW] -> MFMA B-fragment order in the activation dtype."""
+    _dev_ok(w)
+    L = _lib.lib()
+    nbytes = L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), mode)
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+    check(L.cbim_conv3d_pack_weights(C.byref(geom.fwd), mode, _p(w), _p(packed), _stream(w)), "pack_weights")
+    return packed
+
+
+def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, mask_x=None, mask_stats=None,
+               want_partials: bool = False):
+    _dev_ok(x, w_packed, in_stats, res, mask_x, mask_stats)
+    L = _lib.lib()
+    y = torch.empty(tuple(out_shape), dtype=x.dtype, device=x.device)
+    part = None
+    if want_partials:
+        tiles = L.cbim_conv3d_num_tiles(C.byref(desc))
+        part = torch.empty((desc.N, tiles, desc.Cout, 2), dtype=torch.float32, device=x.device)
+    check(L.cbim_conv3d_igemm(C.byref(desc), _p(x), int(x.shape[-1]), _p(in_stats), _p(w_packed),
+                              _p(res), int(res.shape[-1]) if res is not None else 0,
+                              _p(mask_x), int(mask_x.shape[-1]) if mask_x is not None else 0, _p(mask_stats),
+                              _p(y), int(y.shape[-1]), _p(part), _stream(x)), "conv3d_igemm")
+    return y, part
+
+
+def conv_fwd(x, w_packed, geom: ConvGeom, in_stats=None, res=None, want_stats=False, eps=IN_EPS):
+    """y = conv(act(IN(x))) [+ res]; optionally the InstanceNorm statistics of y (epilogue-fused)."""
+    out_shape = (geom.N,) + geom.out_dhw + (geom.Cout,)
+    y, part = conv_igemm(geom.fwd, x, w_packed, out_shape, in_stats=in_stats, res=res, want_partials=want_stats)
+    stats = None
+    if want_stats:
+        S = geom.out_dhw[0] * geom.out_dhw[1] * geom.out_dhw[2]
+        stats = stats_finalize(part, S, eps, 0)
+    return y, stats
+
+
+def conv_dgrad(dy, w_packed_dgrad, geom: ConvGeom, mask_x=None, mask_stats=None, accumulate=None):
+    """g = dgrad(dy) [+ accumulate] [* act'(xh(mask_x))]; with a mask also returns the two
+    InstanceNorm-backward means (m1, m2) computed in the epilogue."""
+    out_shape = (geom.N,) + geom.in_dhw + (geom.Cin,)
+    g, part = conv_igemm(geom.bwd, dy, w_packed_dgrad, out_shape, res=accumulate, mask_x=mask_x,
+                         mask_stats=mask_stats, want_partials=mask_x is not None)
+    sums = None
+    if part is not None:
+        S = geom.in_dhw[0] * geom.in_dhw[1] * geom.in_dhw[2]
+        sums = stats_finalize(part, S, 0.0, 1)
+    return g, sums
+
+
+def conv_wgrad(x, in_stats, dy, geom: ConvGeom) -> torch.Tensor:
+    _dev_ok(x, in_stats, dy)
+    L = _lib.lib()
+    nbytes = L.cbim_conv3d_wgrad_workspace(C.byref(geom.fwd))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((geom.Cout, geom.Cin) + geom.k, dtype=torch.float32, device=x.device)
+    check(L.cbim_conv3d_wgrad(C.byref(geom.fwd), _p(x), int(x.shape[-1]), _p(in_stats), _p(dy),
+                              int(dy.shape[-1]), _p(dw), _p(ws), nbytes, _stream(x)), "conv3d_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
+# stem / head
+# ------------------------------------------------------------------------------------------------
+
+def stem_fwd(x_ncdhw: torch.Tensor, w: torch.Tensor, pad, out_dtype: torch.dtype):
+    _dev_ok(x_ncdhw, w)
+    N, Cin, Di, Hi, Wi = map(int, x_ncdhw.shape)
+    Cout, _, kD, kH, kW = map(int, w.shape)
+    pD, pH, pW = map(int, pad)
+    Do, Ho, Wo = Di + 2 * pD - kD + 1, Hi + 2 * pH - kH + 1, Wi + 2 * pW - kW + 1
+    y = torch.empty((N, Do, Ho, Wo, Cout), dtype=out_dtype, device=x_ncdhw.device)
+    check(_lib.lib().cbim_stem_conv_fwd(_dt(y), _p(x_ncdhw), _p(w), _p(y), N, Cin, Di, Hi, Wi, Cout, kD, kH, kW,
+                                        pD, pH, pW, Do, Ho, Wo, _stream(y)), "stem_conv_fwd")
+    return y
+
+
+def stem_wgrad(x_ncdhw, dy, w_shape, pad):
+    _dev_ok(x_ncdhw, dy)
+    N, Cin, Di, Hi, Wi = map(int, x_ncdhw.shape)
+    Cout, _, kD, kH, kW = map(int, w_shape)
+    pD, pH, pW = map(int, pad)
+    _, Do, Ho, Wo, _ = map(int, dy.shape)
+    L = _lib.lib()
+    nbytes = L.cbim_stem_conv_wgrad_workspace(N, Cin, Cout, kD, kH, kW, Do, Ho, Wo)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dy.device)
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=dy.device)
+    check(L.cbim_stem_conv_wgrad(_dt(dy), _p(x_ncdhw), _p(dy), _p(dw), N, Cin, Di, Hi, Wi, Cout, kD, kH, kW,
+                                 pD, pH, pW, Do, Ho, Wo, _p(ws), nbytes, _stream(dy)), "stem_conv_wgrad")
+    return dw
+
+
+def head_fwd(x, w2d, b):
+    """x [N,D,H,W,Cin] -> logits float32 [N,K,D,H,W]; w2d float32 [K,Cin]."""
+    _dev_ok(x, w2d, b)
+    N, D, H, W, Cin = map(int, x.shape)
+    K = int(w2d.shape[0])
+    logits = torch.empty((N, K, D, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cbim_head_fwd(_dt(x), _p(x), _p(w2d), _p(b), _p(logits), N, D * H * W, Cin, K, _stream(x)),
+          "head_fwd")
+    return logits
+
+
+def head_bwd(x, w2d, dlogits, need_dx=True):
+    _dev_ok(x, w2d, dlogits)
+    N, D, H, W, Cin = map(int, x.shape)
+    K = int(w2d.shape[0])
+    S = D * H * W
+    L = _lib.lib()
+    nbytes = L.cbim_head_bwd_workspace(S, N, Cin, K)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty((K, Cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((K,), dtype=torch.float32, device=x.device)
+    check(L.cbim_head_bwd(_dt(x), _p(x), _p(w2d), _p(dlogits), _p(dx), _p(dw), _p(db), N, S, Cin, K, _p(ws), nbytes,
+                          _stream(x)), "head_bwd")
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------
+
+def dice_ce_fwd(logits, labels, weight=None):
+    """-> out float32[3] = (CE, Dice, CE+Dice), coef float32[2C+1] (for the backward)."""
+    _dev_ok(logits, labels, weight)
+    N, Cc = int(logits.shape[0]), int(logits.shape[1])
+    S = logits.numel() // (N * Cc)
+    L = _lib.lib()
+    nbytes = L.cbim_dice_ce_workspace(N, Cc, S)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=logits.device)
+    out = torch.empty((3,), dtype=torch.float32, device=logits.device)
+    coef = torch.empty((2 * Cc + 1,), dtype=torch.float32, device=logits.device)
+    check(L.cbim_dice_ce_fwd(_p(logits), _p(labels), _p(weight), N, Cc, S, _p(out), _p(coef), _p(ws), nbytes,
+                             _stream(logits)), "dice_ce_fwd")
+    return out, coef
+
+
+def dice_ce_bwd(logits, labels, weight, coef, grad2):
+    _dev_ok(logits, labels, weight, coef, grad2)
+    N, Cc = int(logits.shape[0]), int(logits.shape[1])
+    S = logits.numel() // (N * Cc)
+    dz = torch.empty_like(logits)
+    check(_lib.lib().cbim_dice_ce_bwd(_p(logits), _p(labels), _p(weight), _p(coef), _p(grad2), _p(dz), N, Cc, S,
+                                      _stream(logits)), "dice_ce_bwd")
+    return dz
+
+
+def ncdhw_to_ndhwc(x: torch.Tensor, dtype: torch.dtype):
+    _dev_ok(x)
+    N, Cc = int(x.shape[0]), int(x.shape[1])
+    S = x.numel() // (N * Cc)
+    y = torch.empty((N,) + tuple(x.shape[2:]) + (Cc,), dtype=dtype, device=x.device)
+    check(_lib.lib().cbim_ncdhw_to_ndhwc(_dt(y), _p(x), _p(y), N, Cc, S, _stream(x)), "ncdhw_to_ndhwc")
+    return y
+
+
+def ndhwc_to_ncdhw(x: torch.Tensor):
+    _dev_ok(x)
+    N, Cc = int(x.shape[0]), int(x.shape[-1])
+    S = x.numel() // (N * Cc)
+    y = torch.empty((N, Cc) + tuple(x.shape[1:-1]), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cbim_ndhwc_to_ncdhw(_dt(x), _p(x), _p(y), N, Cc, S, _stream(x)), "ndhwc_to_ncdhw")
+    return y

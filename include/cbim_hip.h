@@ -1,0 +1,183 @@
+/* cbim_hip.h — C ABI of libcbim_hip.so: the MI355X (gfx950) kernels behind the
+ * model/dim3 forward/backward hot path of yhygao/CBIM-Medical-Image-Segmentation.
+ *
+ * The reference has NO native code and no FFI: its hot path is stock torch.nn modules
+ * (SURVEY.md §0.1).  The boundary a maintainer binds is therefore ours to define; each entry
+ * point below names the reference call site (file:line under /root/reference) whose ATen
+ * work it replaces.  INTEGRATION.md shows the ctypes binding and the get_model() hook.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Every pointer is DEVICE memory owned by the caller
+ *    (PyTorch caching allocator); kernels never allocate, free or retain pointers.
+ *  - Launch-only and asynchronous on `stream` (a hipStream_t passed as void*); re-entrant.
+ *  - Activations are channels-last NDHWC: element (n,d,h,w,c) of a tensor view lives at
+ *    ptr[((n*D+d)*H+h)*W+w) * row_stride + c]; `row_stride` (in elements) lets a view address
+ *    a channel slice of a wider tensor.  dtype: CBIM_F32 or CBIM_BF16.  Channel counts must be
+ *    multiples of 8 (bf16) / 4 (f32) so rows are whole 16-byte chunks.
+ *  - Instance-norm statistics are float [N][C][2] = (mean, rstd) pairs.
+ *  - Return 0 on success, a negative CBIM_E* code otherwise (never throws);
+ *    cbim_last_error_string() gives the thread-local reason.
+ */
+#ifndef CBIM_HIP_H
+#define CBIM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBIM_F32 0
+#define CBIM_BF16 1
+
+#define CBIM_ACT_NONE 0
+#define CBIM_ACT_RELU 1   /* nn.ReLU      (model/dim3/utils.py:25) */
+#define CBIM_ACT_LRELU 2  /* nn.LeakyReLU (model/dim3/utils.py:26), slope 0.01 */
+#define CBIM_ACT_GELU 3   /* nn.GELU      (model/dim3/utils.py:27) */
+#define CBIM_ACT_SILU 4   /* nn.SiLU      (model/dim3/utils.py:28) */
+
+#define CBIM_OK 0
+#define CBIM_EINVAL (-1)
+#define CBIM_EUNSUPPORTED (-2)
+#define CBIM_EWORKSPACE (-3)
+#define CBIM_ELAUNCH (-4)
+
+int cbim_version(void);
+const char* cbim_backend(void);            /* "hip-gfx950" (product) or "emu" (tests/emu) */
+const char* cbim_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * InstanceNorm3d statistics — replaces the statistics half of aten::native_batch_norm reached
+ * from nn.InstanceNorm3d(C, eps=1e-4) (model/dim3/conv_layers.py:40-42, model/dim3/utils.py:17).
+ * Two launches: per-slab partial (sum, sum of squares) then a fixed-order fp64 finalize, so the
+ * result is deterministic.  partials: float [N][P][C][2], P = cbim_stats_parts(S, C).
+ * ------------------------------------------------------------------------------------------ */
+int cbim_stats_parts(int64_t S, int C);
+int cbim_instnorm_stats(int dtype, const void* x, int64_t x_stride, int N, int64_t S, int C,
+                        float eps, float* partials, int P, float* stats, void* stream);
+/* mode 0: (mean, rstd) from (sum x, sum x^2) with `count` elements and eps;
+ * mode 1: (sum0/count, sum1/count) — the two means the InstanceNorm backward needs. */
+int cbim_stats_finalize(const float* partials, int N, int P, int C, double count, float eps,
+                        int mode, float* out, void* stream);
+
+/* y = act((x-mean)*rstd) — post-activation ConvNormAct tail (conv_layers.py:51). */
+int cbim_norm_act_fwd(int dtype, const void* x, int64_t x_stride, const float* stats, void* y,
+                      int64_t y_stride, int N, int64_t S, int C, int act, void* stream);
+/* Partial sums for the InstanceNorm backward: with xh=(x-mean)*rstd and
+ * g' = masked ? g*act'(xh) : g :  partials[...][c] = (sum g', sum g'*xh). */
+int cbim_norm_bwd_reduce(int dtype, const void* g, int64_t g_stride, const void* x, int64_t x_stride,
+                         const float* stats, int N, int64_t S, int C, int act, int masked,
+                         float* partials, int P, void* stream);
+/* dx = rstd*(g' - m1 - xh*m2) [+ add]   (sums = float [N][C][2] = (m1, m2)). */
+int cbim_norm_bwd_apply(int dtype, const void* g, int64_t g_stride, const void* x, int64_t x_stride,
+                        const float* stats, const float* sums, const void* add, int64_t add_stride,
+                        void* dx, int64_t dx_stride, int N, int64_t S, int C, int act, int masked,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * nn.MaxPool3d(scale) — unet_utils.py:36 (kernel = stride = scale, floor mode).
+ * idx: uint8 [N][Do][Ho][Wo][C] window position of the first maximum (scan order d,h,w).
+ * ------------------------------------------------------------------------------------------ */
+int cbim_maxpool3d_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int D, int H, int W,
+                       int C, int sD, int sH, int sW, void* stream);
+int cbim_maxpool3d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int D, int H,
+                       int W, int C, int sD, int sH, int sW, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * up_block head — unet_utils.py:68-71: F.interpolate(low, size=skip.shape[2:], 'trilinear',
+ * align_corners=True) then torch.cat([skip, up], 1), written in one pass.
+ * out: [N][D][H][W][Cs+Cl] with channels [0,Cs) = skip, [Cs,Cs+Cl) = upsampled low
+ * (skip_first=1, UNet) or the opposite order (skip_first=0, MedFormer medformer_utils.py:358).
+ * bwd: dskip = slice copy, dlow = exact transpose of the interpolation (gather, no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int cbim_upcat_fwd(int dtype, const void* low, const void* skip, void* out, int N, int Dl, int Hl,
+                   int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
+int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dskip, int N, int Dl, int Hl,
+                   int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3-D convolution as implicit GEMM on the matrix cores — replaces aten::convolution /
+ * convolution_backward reached from nn.Conv3d in ConvNormAct (conv_layers.py:29-38,46-53),
+ * stride 1, dilation 1, groups 1, bias-free.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cbim_conv_desc {
+  int dtype;            /* activation dtype */
+  int N;
+  int Di, Hi, Wi, Cin;  /* input extent / channels  */
+  int Do, Ho, Wo, Cout; /* output extent / channels */
+  int kD, kH, kW;       /* kernel extent            */
+  int pD, pH, pW;       /* leading zero padding     */
+  int act;              /* activation fused on the input load (with in_stats) / mask rule */
+} cbim_conv_desc;
+
+/* Weights are re-laid into MFMA B-fragment order once per optimizer step.
+ * mode 0: forward  (w[co][ci][tap]           -> Cin  is K, Cout is N)
+ * mode 1: dgrad    (w[ci][co][flipped tap]   -> Cout is K, Cin  is N); desc is the FORWARD desc. */
+size_t cbim_conv3d_packed_bytes(const cbim_conv_desc* fwd_desc, int mode);
+int cbim_conv3d_pack_weights(const cbim_conv_desc* fwd_desc, int mode, const float* w, void* packed,
+                             void* stream);
+/* Number of spatial tiles per sample = rows of the per-tile partial-sum buffer. */
+int cbim_conv3d_num_tiles(const cbim_conv_desc* desc);
+/* y = conv(xform(x), w) [+ res];  xform(x) = act((x-mean)*rstd) when in_stats != NULL (zero
+ * padding is applied AFTER the transform, conv_layers.py:48-49).  Optional epilogue:
+ *   mask_x != NULL : y *= act'((mask_x-mean)*rstd)      (dgrad through a pre-activation)
+ *   partials != NULL: per-tile (sum u, sum u*v) over the stored values, float
+ *                     [N][tiles][Cout][2]; v = u (forward: InstanceNorm statistics of y) or
+ *                     v = xh of mask_x (dgrad: the two InstanceNorm-backward sums).
+ * For dgrad pass the dgrad desc (input = dy extent/Cout, output = x extent/Cin, p' = k-1-p). */
+int cbim_conv3d_igemm(const cbim_conv_desc* desc, const void* x, int64_t x_stride,
+                      const float* in_stats, const void* w_packed, const void* res,
+                      int64_t res_stride, const void* mask_x, int64_t mask_stride,
+                      const float* mask_stats, void* y, int64_t y_stride, float* partials,
+                      void* stream);
+/* dw[co][ci][tap] (fp32, natural nn.Conv3d layout) = sum_v dy[v][co] * xform(x)[v+tap][ci].
+ * desc is the FORWARD desc.  workspace: cbim_conv3d_wgrad_workspace(desc) bytes. */
+size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* fwd_desc);
+int cbim_conv3d_wgrad(const cbim_conv_desc* fwd_desc, const void* x, int64_t x_stride,
+                      const float* in_stats, const void* dy, int64_t dy_stride, float* dw,
+                      void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stem: inconv.conv1 = raw nn.Conv3d(in_ch, base, k, pad k//2, bias=False) (unet_utils.py:14,19)
+ * reading the model input in the caller's NCDHW fp32 layout, writing NDHWC.
+ * ------------------------------------------------------------------------------------------ */
+int cbim_stem_conv_fwd(int dtype_out, const float* x_ncdhw, const float* w, void* y, int N, int Cin,
+                       int Di, int Hi, int Wi, int Cout, int kD, int kH, int kW, int pD, int pH,
+                       int pW, int Do, int Ho, int Wo, void* stream);
+size_t cbim_stem_conv_wgrad_workspace(int N, int Cin, int Cout, int kD, int kH, int kW, int Do, int Ho, int Wo);
+int cbim_stem_conv_wgrad(int dtype, const float* x_ncdhw, const void* dy, float* dw, int N, int Cin,
+                         int Di, int Hi, int Wi, int Cout, int kD, int kH, int kW, int pD, int pH,
+                         int pW, int Do, int Ho, int Wo, void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Head: outc = nn.Conv3d(base, classes, 1) with bias (unet.py:47), NDHWC in, NCDHW fp32 logits out.
+ * ------------------------------------------------------------------------------------------ */
+int cbim_head_fwd(int dtype, const void* x, const float* w, const float* b, float* logits, int N,
+                  int64_t S, int Cin, int K, void* stream);
+size_t cbim_head_bwd_workspace(int64_t S, int N, int Cin, int K);
+int cbim_head_bwd(int dtype, const void* x, const float* w, const float* dlogits, void* dx, float* dw,
+                  float* db, int N, int64_t S, int Cin, int K, void* workspace, size_t ws_bytes,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss: nn.CrossEntropyLoss(weight)(logits, label) + DiceLoss()(logits, label)
+ * (train.py:80-81,212; training/losses.py:18-58) in one read of the logits.
+ * logits float [N][C][S] (NCDHW), labels int64 [N][S].
+ * fwd: out[0]=CE, out[1]=Dice, out[2]=CE+Dice; coef float [2][C] = (dL/dTP_c, dL/dSP_c) and
+ *      coef[2C] = 1/sum_i w[y_i] for the backward.  workspace: cbim_dice_ce_workspace(N,C,S).
+ * bwd: dlogits = grad_out[0] * d(CE+Dice)/dlogits  (grad_out is a DEVICE scalar).
+ * ------------------------------------------------------------------------------------------ */
+size_t cbim_dice_ce_workspace(int N, int C, int64_t S);
+int cbim_dice_ce_fwd(const float* logits, const int64_t* labels, const float* weight, int N, int C,
+                     int64_t S, float* out, float* coef, void* workspace, size_t ws_bytes, void* stream);
+int cbim_dice_ce_bwd(const float* logits, const int64_t* labels, const float* weight, const float* coef,
+                     const float* grad_out, float* dlogits, int N, int C, int64_t S, void* stream);
+
+/* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
+int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
+int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBIM_HIP_H */

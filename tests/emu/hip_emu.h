@@ -1,0 +1,185 @@
+// hip_emu.h — TEST INFRASTRUCTURE ONLY.
+//
+// A tiny host-side executor for the gfx950 kernels in
+// cbim-medical-image-segmentation_amd/csrc so that their index arithmetic (halo tiles,
+// MFMA fragment maps, masks, reductions) can be exercised in the GPU-less build container.
+// One workgroup = up to 1024 fibers (ucontext) run round-robin on one OS thread; a wave is
+// 64 consecutive fibers; __syncthreads(), wave shuffles and the MFMA builtins are modelled as
+// rendez-vous points.  Workgroups are spread over OS threads.  It models the documented
+// lane<->element maps of the gfx950 MFMA / ds_read_tr instructions
+// (/opt/skills/guides/cdna_hip_programming.md §3, T10) — the real silicon is still the judge
+// (tests/ -m gpu).  Never built into, or loaded by, the product library.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <math.h>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define __restrict__ __restrict
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+namespace cbim_emu {
+struct Lane {
+  dim3 tid;
+  unsigned flat;  // linear thread id in block
+};
+struct BlockCtx;
+BlockCtx* ctx();                 // current block context (thread_local)
+Lane* lane();                    // current fiber's lane
+const dim3& block_idx();
+const dim3& block_dim();
+const dim3& grid_dim();
+void sync_block();
+// wave rendez-vous: every lane deposits `bytes` at slot[lane]; returns pointer to the 64-slot
+// exchange buffer (stride `bytes`) valid until this lane's next collective.
+const unsigned char* wave_exchange(const void* mine, size_t bytes);
+unsigned char* dyn_smem();
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+}  // namespace cbim_emu
+
+#define threadIdx (cbim_emu::lane()->tid)
+#define blockIdx (cbim_emu::block_idx())
+#define blockDim (cbim_emu::block_dim())
+#define gridDim (cbim_emu::grid_dim())
+#define warpSize 64
+
+inline void __syncthreads() { cbim_emu::sync_block(); }
+inline void __threadfence() {}
+
+#define CBIM_EMU_LANE_ID() (cbim_emu::lane()->flat & 63)
+
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+  const unsigned char* buf = cbim_emu::wave_exchange(&v, sizeof(T));
+  int l = CBIM_EMU_LANE_ID();
+  int base = l & ~(width - 1);
+  T r;
+  memcpy(&r, buf + (size_t)(base + (src & (width - 1))) * sizeof(T), sizeof(T));
+  return r;
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  const unsigned char* buf = cbim_emu::wave_exchange(&v, sizeof(T));
+  int l = CBIM_EMU_LANE_ID();
+  int src = l ^ mask;
+  if ((src & ~(width - 1)) != (l & ~(width - 1))) src = l;
+  T r;
+  memcpy(&r, buf + (size_t)src * sizeof(T), sizeof(T));
+  return r;
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  const unsigned char* buf = cbim_emu::wave_exchange(&v, sizeof(T));
+  int l = CBIM_EMU_LANE_ID();
+  int src = l + (int)delta;
+  if ((src & ~(width - 1)) != (l & ~(width - 1))) src = l;
+  T r;
+  memcpy(&r, buf + (size_t)src * sizeof(T), sizeof(T));
+  return r;
+}
+
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __expf(float x) { return expf(x); }
+inline float __logf(float x) { return logf(x); }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+
+inline float atomicAdd(float* p, float v) {
+  unsigned* up = (unsigned*)p;
+  unsigned old = __atomic_load_n(up, __ATOMIC_RELAXED), nw;
+  do {
+    nw = __float_as_uint(__uint_as_float(old) + v);
+  } while (!__atomic_compare_exchange_n(up, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return __uint_as_float(old);
+}
+inline double atomicAdd(double* p, double v) {
+  uint64_t* up = (uint64_t*)p;
+  uint64_t old = __atomic_load_n(up, __ATOMIC_RELAXED), nw;
+  double o, n;
+  do {
+    memcpy(&o, &old, 8);
+    n = o + v;
+    memcpy(&nw, &n, 8);
+  } while (!__atomic_compare_exchange_n(up, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return o;
+}
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+// ---- MFMA models (lane<->element maps: cdna_hip_programming.md §3) -------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 emu_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float emu_f32x16;
+typedef __attribute__((ext_vector_type(4))) float emu_f32x4;
+
+inline float emu_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// D = A(32x16) * B(16x32) + C ; A lane l: row l&31, k = 8*(l>>5)+j ; B lane l: col l&31, same k;
+// C/D lane l: col l&31, row (r&3)+8*(r>>2)+4*(l>>5).
+inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c, int, int, int) {
+  struct P { unsigned short a[8], b[8]; } mine;
+  memcpy(mine.a, &a, 16);
+  memcpy(mine.b, &b, 16);
+  const P* buf = (const P*)cbim_emu::wave_exchange(&mine, sizeof(P));
+  int l = CBIM_EMU_LANE_ID();
+  int col = l & 31;
+  emu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 16; ++k) {
+      float av = emu_bf2f(buf[row + 32 * (k >> 3)].a[k & 7]);
+      float bv = emu_bf2f(buf[col + 32 * (k >> 3)].b[k & 7]);
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+// f32 32x32x2: A lane l: A[i=l&31][k=l>>5]; B lane l: B[k=l>>5][j=l&31].
+inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
+  struct P { float a, b; } mine = {a, b};
+  const P* buf = (const P*)cbim_emu::wave_exchange(&mine, sizeof(P));
+  int l = CBIM_EMU_LANE_ID();
+  int col = l & 31;
+  emu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 2; ++k) acc = fmaf(buf[row + 32 * k].a, buf[col + 32 * k].b, acc);
+    d[r] = acc;
+  }
+  return d;
+}
+
+// ds_read_b64_tr_b16 model (cdna_hip_programming.md T10): every lane supplies the LDS address
+// of 4 contiguous b16; inside each 16-lane group the 16x4 elements form a [4 rows][16 cols]
+// block (lane i of the group holds row i/4, cols 4*(i%4)..+3); lane i receives column i:
+// element j = block[j][i].
+inline void emu_ds_read_tr16_b64(const void* my_addr, unsigned short out[4]) {
+  struct P { unsigned short v[4]; } mine;
+  memcpy(mine.v, my_addr, 8);
+  const P* buf = (const P*)cbim_emu::wave_exchange(&mine, sizeof(P));
+  int l = CBIM_EMU_LANE_ID();
+  int g = l & ~15, i = l & 15;
+  for (int j = 0; j < 4; ++j) out[j] = buf[g + j * 4 + (i >> 2)].v[i & 3];
+}
+
+#define CBIM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  cbim_emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
