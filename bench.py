@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — volumes/s of the model/dim3 training step (forward + CE/Dice loss + backward
+[+ gradient all-reduce] + AdamW) on synthetic 1x1x128^3 volumes, BASELINE.json configs[1]:
+3D UNet ResBasicBlock (config/amos_ct/resunet_3d.yaml: base 32, 16 classes), bf16, 1 volume per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  roofline     : matrix-core roofline of the dominant kernel (all k_conv_igemm launches of a step),
+                 algorithmic FLOPs / HIP-event time measured live on the launch stream
+  cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/) timed on this box's
+                 host cores on one 1x1x128^3 volume (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FWD_FLOPS_128 = 2.592e12          # ResUNet-BasicBlock fwd at 1x1x128^3, 16 classes
+PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_F32_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+ALG_BYTES_BF16 = 11.6e9            # SURVEY.md §8d compulsory traffic fwd+bwd (bf16)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--base", type=int, default=32)
+    ap.add_argument("--classes", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=128, help="edge of the CPU-baseline sample volume")
+    return ap.parse_args()
+
+
+def synthetic(batch, classes, size, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, 1, size, size, size, generator=g).clamp_(-7.4, 2.2)   # AMOS-CT intensity range
+    coarse = torch.randint(0, classes, (batch, 1, size // 8, size // 8, size // 8), generator=g)
+    lab = torch.nn.functional.interpolate(coarse.float(), size=(size,) * 3, mode="nearest").long()
+    return x.to(device), lab.to(device)
+
+
+def cpu_baseline(args):
+    """Oracle fwd + loss + bwd on the host cores, one volume (bounded sample)."""
+    from oracle import loss_ref, unet_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
+    sd = unet_ref.make_unet_state_dict(1, args.base, args.classes, ks, "BasicBlock", seed=2023)
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    s = args.cpu_size
+    x, lab = synthetic(1, args.classes, s, "cpu", 2023)
+    w = torch.ones(args.classes)
+    w[0] = 0.5
+    t0 = time.perf_counter()
+    logits = unet_ref.unet_forward(sd, x, scale=sc, kernel_size=ks, block="BasicBlock")
+    loss = loss_ref.ce_dice_loss(logits, lab, w)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    scale = (128.0 / s) ** 3 if s != 128 else 1.0
+    return {"value": 1.0 / (dt * scale), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"1 volume 1x1x{s}^3 fwd+loss+bwd, fp32, torch {torch.__version__} CPU, {dt:.1f} s"
+                      + ("" if s == 128 else f" (scaled x{scale:.2f} to 128^3)")}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cbim_amd
+    from cbim_amd import _lib, ops
+    from cbim_amd.model.dim3 import UNet
+    from cbim_amd.parallel import GradAllReduce
+    from cbim_amd.training.losses import DiceCELoss
+    assert _lib.backend() == "hip-gfx950"
+    cbim_amd.set_compute_dtype(args.dtype)
+
+    torch.manual_seed(2023)
+    ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
+    net = UNet(1, args.base, scale=sc, kernel_size=ks, num_classes=args.classes, block="BasicBlock", norm="in").to(dev)
+    net.train()
+    w = torch.ones(args.classes)
+    w[0] = 0.5
+    crit = DiceCELoss(w).to(dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=6e-4, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5, fused=True)
+    ddp = GradAllReduce(net) if world > 1 else None
+    x, lab = synthetic(1, args.classes, args.size, dev, 2023 + rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = net(x)
+        loss = crit(logits, lab)
+        loss.backward()
+        if ddp is not None:
+            ddp.synchronize()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = world * 1.0 / (dt / args.steps)       # 1 volume per GPU per step (train_ddp.py:330)
+    loss_val = float(loss.item())
+
+    out = {
+        "metric": "3D volumes/sec (fwd+bwd) at 128^3", "value": value, "unit": "volumes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"3D UNet ResBasicBlock (amos_ct/resunet_3d.yaml), 1x1x{args.size}^3 per GPU, "
+                               f"{args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
+                               + (", bucketed grad all-reduce (RCCL)" if world > 1 else ""),
+                   "global_batch": world, "parallelism": f"dp{world}", "final_loss": loss_val},
+    }
+
+    # ---- roofline of the dominant kernel: every k_conv_igemm launch of one step, HIP events on the launch stream
+    if not args.no_roofline and rank == 0:
+        per = {}
+        reps = 3
+        for _ in range(reps):
+            ops.PROFILE = []
+            step()
+            torch.cuda.synchronize()
+            for name, flops, e0, e1, shape in ops.PROFILE:
+                d = per.setdefault(name, [0.0, 0.0, 0])
+                d[0] += flops
+                d[1] += e0.elapsed_time(e1) * 1e-3
+                d[2] += 1
+            ops.PROFILE = None
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        table = {k: {"launches_per_step": v[2] // reps, "avg_launch_ms": v[1] / v[2] * 1e3,
+                     "alg_tflop_per_step": v[0] / reps / 1e12, "achieved_tflops": v[0] / v[1] / 1e12,
+                     "frac_of_peak": v[0] / v[1] / 1e12 / peak} for k, v in per.items()}
+        dom = max((k for k in per if k.startswith("k_conv_igemm")), key=lambda k: per[k][1])
+        f, tsec, nl = per[dom]
+        step_flops = 3.0 * FWD_FLOPS_128 * (args.size / 128.0) ** 3 * (args.base / 32.0) ** 2
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": f / tsec / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": f / tsec / 1e12 / peak, "traffic": None,
+            "alg_flops_per_launch": f / nl, "avg_launch_ms": tsec / nl * 1e3,
+            "step_flops": step_flops, "step_achieved": step_flops / (ms * 1e-3) / 1e12,
+            "step_frac_mfma": step_flops / (ms * 1e-3) / 1e12 / peak,
+            "step_frac_hbm": (ALG_BYTES_BF16 * (2 if args.dtype == "fp32" else 1) / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+            "kernels": table,
+        }
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,6 +120,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Running (count, mean, M2) statistics and Chan's pairwise merge: InstanceNorm variances are
+// formed from centred second moments, never from E[x^2]-mean^2 (which cancels catastrophically
+// when |mean| >> std, e.g. after residual adds).
+struct Moments { float n, mean, m2; };
+__device__ __forceinline__ Moments moments_merge(const Moments& a, const Moments& b) {
+  Moments r;
+  r.n = a.n + b.n;
+  if (r.n <= 0.f) { r.n = 0.f; r.mean = 0.f; r.m2 = 0.f; return r; }
+  float d = b.mean - a.mean;
+  float fb = b.n / r.n;
+  r.mean = a.mean + d * fb;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * fb;
+  return r;
+}
+// moments of values given as shifted sums: n values, sum d, sum d^2 with d = x - shift
+__device__ __forceinline__ Moments moments_from_shifted(float n, float shift, float sd, float sd2) {
+  Moments r;
+  r.n = n;
+  if (n <= 0.f) { r.mean = 0.f; r.m2 = 0.f; return r; }
+  float md = sd / n;
+  r.mean = shift + md;
+  r.m2 = sd2 - sd * md;
+  if (r.m2 < 0.f) r.m2 = 0.f;
+  return r;
+}
+
 // XCD-aware block remap: consecutive logical tiles land on the same XCD (its private 4 MiB L2),
 // block b runs on XCD b % 8 (MI355X_MICROARCH.md, observed placement; speed only, never correctness).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {

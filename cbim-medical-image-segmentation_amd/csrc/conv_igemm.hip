@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
 
   // ---- epilogue --------------------------------------------------------------------------------------
   __syncthreads();
-  float* red = (float*)smem;  // [4 waves][MT][BN][2]
+  float* red = (float*)smem;  // [4 waves * MT][BN][3]
   const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
 #pragma unroll
   for (int nt = 0; nt < NTL; ++nt) {
@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      float s0 = 0.f, s1 = 0.f;
+      // forward: shifted sums -> (count, mean, M2); dgrad: plain (sum g, sum g*xh)
+      float s0 = 0.f, s1 = 0.f, cnt = 0.f, shift = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int m = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -196,24 +197,34 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
           size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
           float v = acc[mt][nt][r];
           if (p.res) v += Elem<T>::load1(p.res, row * p.res_stride + co);
-          float u2 = v;
           if (p.mx) {
             float xh = (Elem<T>::load1(p.mx, row * p.mx_stride + co) - mmean) * mrstd;
             v *= act_grad(xh, p.act);
-            u2 = xh;
+            s0 += v;
+            s1 += v * xh;
+          } else {
+            if (cnt == 0.f) shift = v;
+            float d = v - shift;
+            s0 += d;
+            s1 += d * d;
           }
+          cnt += 1.f;
           Elem<T>::store1(p.y, row * p.y_stride + co, v);
-          if (!p.mx) u2 = v;
-          s0 += v;
-          s1 += v * u2;
         }
       }
       if (p.partials) {
-        s0 += __shfl_xor(s0, 32, 64);
-        s1 += __shfl_xor(s1, 32, 64);
+        Moments a;
+        if (p.mx) { a.n = 0.f; a.mean = s0; a.m2 = s1; }
+        else a = moments_from_shifted(cnt, shift, s0, s1);
+        Moments b;
+        b.n = __shfl_xor(a.n, 32, 64);
+        b.mean = __shfl_xor(a.mean, 32, 64);
+        b.m2 = __shfl_xor(a.m2, 32, 64);
         if (half == 0) {
-          red[(((wave * MT + mt) * BN) + nt * 32 + li) * 2] = s0;
-          red[(((wave * MT + mt) * BN) + nt * 32 + li) * 2 + 1] = s1;
+          if (p.mx) { a.mean += b.mean; a.m2 += b.m2; }
+          else a = moments_merge(a, b);
+          float* rr = red + (((wave * MT + mt) * BN) + nt * 32 + li) * 3;
+          rr[0] = a.n; rr[1] = a.mean; rr[2] = a.m2;
         }
       }
     }
@@ -221,14 +232,16 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
   if (p.partials) {
     __syncthreads();
     if (tid < BN && co0 + tid < p.Cout) {
-      float a0 = 0.f, a1 = 0.f;
+      Moments a = {0.f, 0.f, 0.f};
       for (int g = 0; g < 4 * MT; ++g) {
-        a0 += red[(g * BN + tid) * 2];
-        a1 += red[(g * BN + tid) * 2 + 1];
+        const float* rr = red + (g * BN + tid) * 3;
+        if (p.mx) { a.mean += rr[1]; a.m2 += rr[2]; }
+        else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
       }
-      size_t o = (((size_t)n * tiles_per_n + t) * p.Cout + co0 + tid) * 2;
-      p.partials[o] = a0;
-      p.partials[o + 1] = a1;
+      size_t o = (((size_t)n * tiles_per_n + t) * p.Cout + co0 + tid) * 3;
+      p.partials[o] = a.n;
+      p.partials[o + 1] = a.mean;
+      p.partials[o + 2] = a.m2;
     }
   }
 }
@@ -329,6 +342,13 @@ extern "C" int cbim_conv3d_pack_weights(const cbim_conv_desc* d, int mode, const
   return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
+extern "C" int cbim_conv3d_tile_config(const cbim_conv_desc* d, int out[4]) {
+  CBIM_CHECK(d && out, CBIM_EINVAL, "null argument");
+  TileCfg c = pick_cfg(d);
+  out[0] = c.MT; out[1] = c.NTL; out[2] = c.tD; out[3] = c.tH;
+  return CBIM_OK;
+}
+
 extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   if (!d) return 0;
   TileCfg c = pick_cfg(d);
@@ -376,7 +396,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   p.taps = d->kD * d->kH * d->kW;
   int BN = 32 * c.NTL;
   size_t smem = (size_t)p.hD * p.hH * p.hW * RB + (size_t)p.taps * KG * 2 * BN * 16;
-  size_t red = (size_t)4 * c.MT * BN * 2 * sizeof(float);
+  size_t red = (size_t)4 * c.MT * BN * 3 * sizeof(float);
   if (smem < red) smem = red;
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "conv tile needs %zu B of LDS", smem);
   int64_t nblk = (int64_t)d->N * p.tiles_d * p.tiles_h * p.tiles_w;

@@ -39,9 +39,10 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
   int64_t v1 = v0 + per;
   if (v1 > S) v1 = S;
 
-  float s0[CPC], s1[CPC], mean[CPC], rstd[CPC];
+  float s0[CPC], s1[CPC], mean[CPC], rstd[CPC], shift[CPC];
+  float cnt = 0.f;
 #pragma unroll
-  for (int j = 0; j < CPC; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f; }
+  for (int j = 0; j < CPC; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f; shift[j] = 0.f; }
   const bool active = vl < vlc;
   if (MODE == 1 && active) {
 #pragma unroll
@@ -56,8 +57,13 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
       float fa[CPC];
       Elem<T>::unpack(ld_chunk<T>(a, (nb + v) * a_stride + (size_t)cc * CPC), fa);
       if (MODE == 0) {
+        if (cnt == 0.f) {
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) { s0[j] += fa[j]; s1[j] += fa[j] * fa[j]; }
+          for (int j = 0; j < CPC; ++j) shift[j] = fa[j];
+        }
+        cnt += 1.f;
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) { float d = fa[j] - shift[j]; s0[j] += d; s1[j] += d * d; }
       } else {
         float fx[CPC];
         Elem<T>::unpack(ld_chunk<T>(x, (nb + v) * x_stride + (size_t)cc * CPC), fx);
@@ -72,23 +78,38 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
     }
   }
   // reduce over the voxel lanes through LDS (fixed order -> deterministic)
-  __shared__ float red[NT * 2 * 8];
+  __shared__ float red[NT * 3 * 8];
 #pragma unroll
   for (int j = 0; j < CPC; ++j) {
-    red[(t * CPC + j) * 2 + 0] = s0[j];
-    red[(t * CPC + j) * 2 + 1] = s1[j];
+    if (MODE == 0) {
+      Moments m = moments_from_shifted(cnt, shift[j], s0[j], s1[j]);
+      red[(t * CPC + j) * 3 + 0] = m.n;
+      red[(t * CPC + j) * 3 + 1] = m.mean;
+      red[(t * CPC + j) * 3 + 2] = m.m2;
+    } else {
+      red[(t * CPC + j) * 3 + 0] = 0.f;
+      red[(t * CPC + j) * 3 + 1] = s0[j];
+      red[(t * CPC + j) * 3 + 2] = s1[j];
+    }
   }
   __syncthreads();
   if (vl == 0 && active) {
     for (int j = 0; j < CPC; ++j) {
-      float a0 = 0.f, a1 = 0.f;
+      Moments acc = {0.f, 0.f, 0.f};
       for (int q = 0; q < vlc; ++q) {
-        a0 += red[((q * cch + cc) * CPC + j) * 2 + 0];
-        a1 += red[((q * cch + cc) * CPC + j) * 2 + 1];
+        const float* r = red + ((q * cch + cc) * CPC + j) * 3;
+        if (MODE == 0) {
+          Moments b = {r[0], r[1], r[2]};
+          acc = moments_merge(acc, b);
+        } else {
+          acc.mean += r[1];
+          acc.m2 += r[2];
+        }
       }
-      size_t o = (((size_t)n * P + part) * C + cc * CPC + j) * 2;
-      partials[o] = a0;
-      partials[o + 1] = a1;
+      size_t o = (((size_t)n * P + part) * C + cc * CPC + j) * 3;
+      partials[o] = acc.n;
+      partials[o + 1] = acc.mean;
+      partials[o + 2] = acc.m2;
     }
   }
 }
@@ -99,19 +120,28 @@ __global__ void __launch_bounds__(NT) k_stats_finalize(const float* __restrict__
   int i = blockIdx.x * NT + threadIdx.x;
   if (i >= N * C) return;
   int n = i / C, c = i % C;
-  double a0 = 0.0, a1 = 0.0;
-  for (int p = 0; p < P; ++p) {
-    size_t o = (((size_t)n * P + p) * C + c) * 2;
-    a0 += (double)partials[o];
-    a1 += (double)partials[o + 1];
-  }
-  if (mode == 0) {
-    double m = a0 / count;
-    double var = a1 / count - m * m;
-    if (var < 0.0) var = 0.0;
-    out[(size_t)i * 2] = (float)m;
+  if (mode == 0) {   // Chan merge of (count, mean, M2) records in fp64, fixed order
+    double na = 0.0, ma = 0.0, M2 = 0.0;
+    for (int p = 0; p < P; ++p) {
+      size_t o = (((size_t)n * P + p) * C + c) * 3;
+      double nb = (double)partials[o];
+      if (nb <= 0.0) continue;
+      double mb = (double)partials[o + 1], Mb = (double)partials[o + 2];
+      double nn = na + nb, d = mb - ma;
+      ma += d * (nb / nn);
+      M2 += Mb + d * d * (na * nb / nn);
+      na = nn;
+    }
+    double var = na > 0.0 ? M2 / na : 0.0;
+    out[(size_t)i * 2] = (float)ma;
     out[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   } else {
+    double a0 = 0.0, a1 = 0.0;
+    for (int p = 0; p < P; ++p) {
+      size_t o = (((size_t)n * P + p) * C + c) * 3;
+      a0 += (double)partials[o + 1];
+      a1 += (double)partials[o + 2];
+    }
     out[(size_t)i * 2] = (float)(a0 / count);
     out[(size_t)i * 2 + 1] = (float)(a1 / count);
   }

@@ -1,0 +1,234 @@
+"""Autograd glue: one ``torch.autograd.Function`` per fused block of the hot path.
+
+Each Function's forward/backward is a hand-scheduled sequence of HIP kernel launches
+(``ops``); autograd only chains the blocks, delivers parameter gradients to ``param.grad``
+(so DDP / optimizer hooks fire per parameter as the backward proceeds) and sums the two
+gradient contributions of a skip tensor.
+
+Fusion map (reference: /root/reference/model/dim3/conv_layers.py):
+  pre-activation ``conv(act(IN(x)))``      -> norm+act applied on the conv's input load,
+                                              statistics of the output from the conv epilogue
+  ``BasicBlock`` (conv_layers.py:86-94)     -> 2-3 conv launches; residual add in the epilogue;
+                                              backward = wgrad + dgrad(+act' mask, +IN-backward
+                                              sums in the epilogue) + one normalisation pass
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import ops
+from .ops import ACT, IN_EPS, ConvGeom
+
+_COMPUTE_DTYPE: Optional[torch.dtype] = None
+
+
+def set_compute_dtype(dtype):
+    global _COMPUTE_DTYPE
+    if dtype in (None, "auto"):
+        _COMPUTE_DTYPE = None
+    elif dtype in ("bf16", "bfloat16", torch.bfloat16):
+        _COMPUTE_DTYPE = torch.bfloat16
+    elif dtype in ("fp32", "float32", torch.float32):
+        _COMPUTE_DTYPE = torch.float32
+    else:
+        raise ValueError(f"unsupported compute dtype {dtype!r}")
+
+
+def compute_dtype() -> torch.dtype:
+    if _COMPUTE_DTYPE is not None:
+        return _COMPUTE_DTYPE
+    if torch.is_autocast_enabled():  # train.py --amp (fp16 autocast there; bf16 storage here)
+        return torch.bfloat16
+    return torch.float32
+
+
+class FMap(NamedTuple):
+    """Channels-last feature map + (lazily computed) InstanceNorm statistics."""
+    t: torch.Tensor
+    stats: Optional[torch.Tensor] = None
+
+
+def ensure_stats(f: FMap, eps: float = IN_EPS) -> FMap:
+    if f.stats is not None:
+        return f
+    with torch.no_grad():
+        return FMap(f.t, ops.instnorm_stats(f.t.detach(), eps))
+
+
+def _geom(x: torch.Tensor, w: torch.Tensor, act: int) -> ConvGeom:
+    k = tuple(int(i) for i in w.shape[2:])
+    pad = tuple(i // 2 for i in k)  # conv_layers.py:62,77
+    return ConvGeom(x.dtype, int(x.shape[0]), tuple(x.shape[1:4]), int(w.shape[1]), int(w.shape[0]), k, pad, act)
+
+
+class StemFn(torch.autograd.Function):
+    """inconv.conv1: raw Conv3d, NCDHW fp32 in -> channels-last out (unet_utils.py:14,19)."""
+
+    @staticmethod
+    def forward(ctx, x, w, out_dtype):
+        x = x.contiguous().float()
+        wd = w.detach().contiguous()
+        pad = tuple(int(i) // 2 for i in w.shape[2:])
+        y = ops.stem_fwd(x, wd, pad, out_dtype)
+        ctx.save_for_backward(x)
+        ctx.w_shape, ctx.pad = tuple(w.shape), pad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dw = ops.stem_wgrad(x, dy.contiguous(), ctx.w_shape, ctx.pad)
+        return None, dw, None
+
+
+class BasicBlockFn(torch.autograd.Function):
+    """BasicBlock.forward (conv_layers.py:86-94) with pre-activation ConvNormAct (:48-49).
+
+    inputs : x (raw, pre-norm), its statistics, w1, w2, wsc (or None), act code
+    outputs: out = conv2(a(conv1(a(x)))) + shortcut, statistics of out (non-differentiable)
+    """
+
+    @staticmethod
+    def forward(ctx, x, x_stats, w1, w2, wsc, act, want_out_stats):
+        g1 = _geom(x, w1, act)
+        w1d, w2d = w1.detach().contiguous(), w2.detach().contiguous()
+        y1, s1 = ops.conv_fwd(x, ops.pack_weights(w1d, g1, 0), g1, in_stats=x_stats, want_stats=True)
+        g2 = _geom(y1, w2, act)
+        if wsc is not None:
+            gsc = _geom(x, wsc, act)
+            res, _ = ops.conv_fwd(x, ops.pack_weights(wsc.detach().contiguous(), gsc, 0), gsc, in_stats=x_stats)
+        else:
+            gsc = None
+            res = x
+        out, so = ops.conv_fwd(y1, ops.pack_weights(w2d, g2, 0), g2, in_stats=s1, res=res,
+                               want_stats=want_out_stats)
+        ctx.save_for_backward(x, x_stats, y1, s1, w1, w2, wsc if wsc is not None else torch.empty(0))
+        ctx.geoms = (g1, g2, gsc)
+        ctx.act = act
+        if so is None:
+            so = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(so)
+        return out, so
+
+    @staticmethod
+    def backward(ctx, dout, _dso):
+        x, x_stats, y1, s1, w1, w2, wsc = ctx.saved_tensors
+        g1, g2, gsc = ctx.geoms
+        act = ctx.act
+        dout = dout.contiguous()
+        # conv2
+        dw2 = ops.conv_wgrad(y1, s1, dout, g2)
+        gy1, sums2 = ops.conv_dgrad(dout, ops.pack_weights(w2.detach().contiguous(), g2, 1), g2,
+                                    mask_x=y1, mask_stats=s1)
+        dy1 = ops.norm_bwd_apply(gy1, y1, s1, sums2, act, masked=False)
+        # conv1 (+ shortcut conv share act(IN(x)))
+        dw1 = ops.conv_wgrad(x, x_stats, dy1, g1)
+        wd1 = ops.pack_weights(w1.detach().contiguous(), g1, 1)
+        if gsc is not None:
+            dwsc = ops.conv_wgrad(x, x_stats, dout, gsc)
+            gx_u, _ = ops.conv_dgrad(dy1, wd1, g1)
+            gx, sums1 = ops.conv_dgrad(dout, ops.pack_weights(wsc.detach().contiguous(), gsc, 1), gsc,
+                                       mask_x=x, mask_stats=x_stats, accumulate=gx_u)
+            dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False)
+        else:
+            dwsc = None
+            gx, sums1 = ops.conv_dgrad(dy1, wd1, g1, mask_x=x, mask_stats=x_stats)
+            dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False, add=dout)
+        return dx, None, dw1, dw2, dwsc, None, None
+
+
+class SingleConvFn(torch.autograd.Function):
+    """SingleConv = post-activation ConvNormAct: act(IN(conv(x))) (conv_layers.py:51,56-68)."""
+
+    @staticmethod
+    def forward(ctx, x, w, act, need_dx):
+        g = _geom(x, w, act)
+        z, sz = ops.conv_fwd(x, ops.pack_weights(w.detach().contiguous(), g, 0), g, want_stats=True)
+        y = ops.norm_act_fwd(z, sz, act)
+        ctx.save_for_backward(x, z, sz, w)
+        ctx.geom, ctx.act, ctx.need_dx = g, act, need_dx
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, sz, w = ctx.saved_tensors
+        g, act = ctx.geom, ctx.act
+        dy = dy.contiguous()
+        sums = ops.norm_bwd_sums(dy, z, sz, act, masked=True)
+        dz = ops.norm_bwd_apply(dy, z, sz, sums, act, masked=True)
+        dw = ops.conv_wgrad(x, None, dz, g)
+        dx = None
+        if ctx.need_dx:
+            dx, _ = ops.conv_dgrad(dz, ops.pack_weights(w.detach().contiguous(), g, 1), g)
+        return dx, dw, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool3d(scale) (unet_utils.py:36)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        y, idx = ops.maxpool_fwd(x, scale)
+        ctx.save_for_backward(idx)
+        ctx.in_shape, ctx.scale = tuple(x.shape), tuple(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool_bwd(dy.contiguous(), idx, ctx.in_shape, ctx.scale), None
+
+
+class UpCatFn(torch.autograd.Function):
+    """F.interpolate(low, size=skip size, trilinear, align_corners=True) + cat (unet_utils.py:69-71)."""
+
+    @staticmethod
+    def forward(ctx, low, skip, skip_first):
+        ctx.low_shape, ctx.Cs, ctx.skip_first = tuple(low.shape), int(skip.shape[-1]), skip_first
+        return ops.upcat_fwd(low, skip, skip_first)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dlow, dskip = ops.upcat_bwd(dout.contiguous(), ctx.low_shape, ctx.Cs, ctx.skip_first)
+        return dlow, dskip, None
+
+
+class HeadFn(torch.autograd.Function):
+    """outc = nn.Conv3d(base, classes, 1) with bias (unet.py:47): channels-last in, NCDHW fp32 out."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        w2d = w.detach().reshape(w.shape[0], w.shape[1]).contiguous()
+        ctx.save_for_backward(x, w2d)
+        ctx.w_shape = tuple(w.shape)
+        return ops.head_fwd(x, w2d, b.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, w2d = ctx.saved_tensors
+        dx, dw, db = ops.head_bwd(x, w2d, dlogits.contiguous().float(), need_dx=ctx.needs_input_grad[0])
+        return dx, dw.reshape(ctx.w_shape), db
+
+
+class DiceCEFn(torch.autograd.Function):
+    """(CE, Dice, CE+Dice) of train.py:212 in one pass over the logits (training/losses.py:18-58)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight):
+        logits = logits.contiguous().float()
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        out, coef = ops.dice_ce_fwd(logits, labels, weight)
+        ctx.save_for_backward(logits, labels, coef, weight if weight is not None else torch.empty(0))
+        ctx.has_w = weight is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, labels, coef, weight = ctx.saved_tensors
+        g2 = torch.stack([gout[0] + gout[2], gout[1] + gout[2]]).float().contiguous()
+        dz = ops.dice_ce_bwd(logits, labels, weight if ctx.has_w else None, coef, g2)
+        return dz, None, None

@@ -1,0 +1,17 @@
+"""Plugin registry with the reference's signature: ``get_model(args, pretrain=False)``
+(/root/reference/model/utils.py:6, 3D branches :70-122).  ``args`` is the argparse Namespace
+that carries every YAML key (train.py:266-270)."""
+
+
+def get_model(args, pretrain=False):
+    if args.dimension == "2d":
+        raise NotImplementedError("cbim_amd: the 2D model zoo is outside the model/dim3 hot path")
+    if args.dimension != "3d":
+        raise ValueError("Invalid dimension, should be '2d' or '3d'")
+    if args.model in ("resunet", "unet"):
+        from .dim3 import UNet
+        if pretrain and args.model == "resunet":
+            raise ValueError("No pretrain model available")
+        return UNet(args.in_chan, args.base_chan, num_classes=args.classes, scale=args.down_scale,
+                    norm=args.norm, kernel_size=args.kernel_size, block=args.block)
+    raise NotImplementedError(f"cbim_amd: 3D model '{args.model}' is not built yet")

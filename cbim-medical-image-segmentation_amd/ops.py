@@ -20,6 +20,10 @@ from ._lib import ConvDesc, check
 ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "gelu": 3, "swish": 4, "silu": 4}
 IN_EPS = 1e-4  # /root/reference/model/dim3/conv_layers.py:40,42
 
+# bench.py sets this to a list to collect (kernel, algorithmic flops, start event, end event, shape)
+# around every matrix-core launch (HIP events on the launch stream); None = no instrumentation.
+PROFILE = None
+
 
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.bfloat16:
@@ -65,7 +69,7 @@ def instnorm_stats(x: torch.Tensor, eps: float = IN_EPS) -> torch.Tensor:
     N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
     L = _lib.lib()
     P = L.cbim_stats_parts(S, Cc)
-    part = torch.empty((N, P, Cc, 2), dtype=torch.float32, device=x.device)
+    part = torch.empty((N, P, Cc, 3), dtype=torch.float32, device=x.device)
     stats = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
     check(L.cbim_instnorm_stats(_dt(x), _p(x), Cc, N, S, Cc, eps, _p(part), P, _p(stats), _stream(x)),
           "instnorm_stats")
@@ -95,7 +99,7 @@ def norm_bwd_sums(g, x, stats, act: int, masked: bool):
     N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
     L = _lib.lib()
     P = L.cbim_stats_parts(S, Cc)
-    part = torch.empty((N, P, Cc, 2), dtype=torch.float32, device=x.device)
+    part = torch.empty((N, P, Cc, 3), dtype=torch.float32, device=x.device)
     check(L.cbim_norm_bwd_reduce(_dt(x), _p(g), Cc, _p(x), Cc, _p(stats), N, S, Cc, act, int(masked), _p(part),
                                  P, _stream(x)), "norm_bwd_reduce")
     return stats_finalize(part, S, 0.0, 1)
@@ -196,11 +200,22 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
     part = None
     if want_partials:
         tiles = L.cbim_conv3d_num_tiles(C.byref(desc))
-        part = torch.empty((desc.N, tiles, desc.Cout, 2), dtype=torch.float32, device=x.device)
+        part = torch.empty((desc.N, tiles, desc.Cout, 3), dtype=torch.float32, device=x.device)
+    prof = PROFILE is not None and x.device.type == "cuda"
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.cbim_conv3d_igemm(C.byref(desc), _p(x), int(x.shape[-1]), _p(in_stats), _p(w_packed),
                               _p(res), int(res.shape[-1]) if res is not None else 0,
                               _p(mask_x), int(mask_x.shape[-1]) if mask_x is not None else 0, _p(mask_stats),
                               _p(y), int(y.shape[-1]), _p(part), _stream(x)), "conv3d_igemm")
+    if prof:
+        e1.record()
+        cfg = (C.c_int * 4)()
+        L.cbim_conv3d_tile_config(C.byref(desc), C.byref(cfg))
+        name = "k_conv_igemm<%s,%d,%d>" % ("bf16" if desc.dtype == 1 else "f32", cfg[0], cfg[1])
+        flops = 2.0 * desc.N * desc.Do * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.kD * desc.kH * desc.kW
+        PROFILE.append((name, flops, e0, e1, (desc.Cin, desc.Cout, desc.Do, desc.Ho, desc.Wo)))
     return y, part
 
 
@@ -234,8 +249,18 @@ def conv_wgrad(x, in_stats, dy, geom: ConvGeom) -> torch.Tensor:
     nbytes = L.cbim_conv3d_wgrad_workspace(C.byref(geom.fwd))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     dw = torch.empty((geom.Cout, geom.Cin) + geom.k, dtype=torch.float32, device=x.device)
+    prof = PROFILE is not None and x.device.type == "cuda"
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.cbim_conv3d_wgrad(C.byref(geom.fwd), _p(x), int(x.shape[-1]), _p(in_stats), _p(dy),
                               int(dy.shape[-1]), _p(dw), _p(ws), nbytes, _stream(x)), "conv3d_wgrad")
+    if prof:
+        e1.record()
+        d = geom.fwd
+        flops = 2.0 * d.N * d.Do * d.Ho * d.Wo * d.Cout * d.Cin * d.kD * d.kH * d.kW
+        PROFILE.append(("k_conv_wgrad<%s>+reduce" % ("bf16" if d.dtype == 1 else "f32"), flops, e0, e1,
+                        (d.Cin, d.Cout, d.Do, d.Ho, d.Wo)))
     return dw
 
 

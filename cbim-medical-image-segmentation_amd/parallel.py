@@ -1,0 +1,109 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce over RCCL/xGMI
+overlapped with the backward pass.
+
+The reference's only parallelism is ``torch.nn.parallel.DistributedDataParallel`` in
+``/root/reference/train_ddp.py:353`` (one replica per GPU, gradient all-reduce(mean) per step,
+``find_unused_parameters=True``).  The models here have no unused parameters, so
+the exchange is static: parameters are grouped into fixed buckets in REVERSE registration order
+(the order the backward produces them: decoder first); when the last gradient of a bucket has
+been accumulated its flat buffer is all-reduced asynchronously on the process group's own
+stream while the backward of the earlier layers keeps the compute stream busy.
+``backend="nccl"`` is RCCL on ROCm; the same code runs on ``gloo`` for the CPU tests.
+
+Sizing for xGMI (7 links x ~153 GB/s per GPU, point to point): a 162 MB fp32 gradient set in
+~6 buckets of 32 MB keeps each ring transfer per-link bound at >= 4 MB per step of the ring,
+large enough to run at link rate and small enough that the last bucket (encoder stem) is the
+only one not hidden behind compute.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("params", "numel", "pending", "flat", "work")
+
+    def __init__(self):
+        self.params: List[torch.nn.Parameter] = []
+        self.numel = 0
+        self.pending = 0
+        self.flat = None
+        self.work = None
+
+
+class GradAllReduce:
+    """Attach to a replica; gradients are averaged over the process group.
+
+        ddp = GradAllReduce(net)              # after net.to(device); broadcasts rank-0 weights
+        loss.backward()                       # buckets fire as their gradients complete
+        ddp.synchronize()                     # wait + write the averaged gradients back
+        optimizer.step()
+    """
+
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 32.0, process_group=None,
+                 broadcast_parameters: bool = True):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        if broadcast_parameters and self.world > 1:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=process_group)
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets: List[_Bucket] = []
+        cur = _Bucket()
+        for p in reversed(params):
+            if cur.params and cur.numel + p.numel() > cap:
+                self.buckets.append(cur)
+                cur = _Bucket()
+            cur.params.append(p)
+            cur.numel += p.numel()
+        if cur.params:
+            self.buckets.append(cur)
+        self._owner = {}
+        self._handles = []
+        for b in self.buckets:
+            b.pending = len(b.params)
+            for p in b.params:
+                self._owner[p] = b
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -- hooks ------------------------------------------------------------------------------------------
+    def _on_grad(self, p: torch.nn.Parameter):
+        b = self._owner[p]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket):
+        if self.world == 1:
+            return
+        b.flat = torch.cat([p.grad.reshape(-1) for p in b.params])
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def synchronize(self):
+        """Wait for every bucket and write the averaged gradients back into ``param.grad``."""
+        for b in self.buckets:
+            if b.pending != 0:
+                raise RuntimeError("GradAllReduce.synchronize(): a parameter received no gradient "
+                                   "(unused parameters are not supported)")
+            if b.work is not None:
+                b.work.wait()
+                b.flat.div_(self.world)
+                off = 0
+                views = []
+                for p in b.params:
+                    views.append(b.flat[off:off + p.numel()].view_as(p.grad))
+                    off += p.numel()
+                torch._foreach_copy_([p.grad for p in b.params], views)
+                b.work = None
+                b.flat = None
+            b.pending = len(b.params)
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -1,0 +1,33 @@
+"""Loss modules with the reference's call surface (/root/reference/training/losses.py:8-58,
+/root/reference/train.py:80-81,212), computed by the fused HIP Dice+CE kernels."""
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+
+
+class DiceLoss(nn.Module):
+    """DiceLoss()(preds[B,C,...], targets[B,1,...] int64) — losses.py:8-58 (size_average, reduce
+    defaults; alpha/beta constructor arguments are overwritten by the adaptive alpha, :38-42)."""
+
+    def __init__(self, alpha=0.5, beta=0.5, size_average=True, reduce=True):
+        super().__init__()
+        if not (size_average and reduce):
+            raise NotImplementedError("cbim_amd: DiceLoss(size_average=False / reduce=False) is not built")
+
+    def forward(self, preds, targets):
+        with torch.autocast(device_type=preds.device.type, enabled=False):
+            return Fn.DiceCEFn.apply(preds, targets, None)[1]
+
+
+class DiceCELoss(nn.Module):
+    """criterion(result, label.squeeze(1)) + criterion_dl(result, label) of train.py:212 in one
+    pass; ``weight`` is the class weight of nn.CrossEntropyLoss (train.py:80)."""
+
+    def __init__(self, weight=None):
+        super().__init__()
+        self.register_buffer("weight", None if weight is None else torch.as_tensor(weight, dtype=torch.float32))
+
+    def forward(self, logits, label):
+        with torch.autocast(device_type=logits.device.type, enabled=False):
+            return Fn.DiceCEFn.apply(logits, label, self.weight)[2]

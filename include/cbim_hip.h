@@ -50,7 +50,7 @@ const char* cbim_last_error_string(void);
  * InstanceNorm3d statistics — replaces the statistics half of aten::native_batch_norm reached
  * from nn.InstanceNorm3d(C, eps=1e-4) (model/dim3/conv_layers.py:40-42, model/dim3/utils.py:17).
  * Two launches: per-slab partial (sum, sum of squares) then a fixed-order fp64 finalize, so the
- * result is deterministic.  partials: float [N][P][C][2], P = cbim_stats_parts(S, C).
+ * result is deterministic.  partials: float [N][P][C][3] records, P = cbim_stats_parts(S, C).
  * ------------------------------------------------------------------------------------------ */
 int cbim_stats_parts(int64_t S, int C);
 int cbim_instnorm_stats(int dtype, const void* x, int64_t x_stride, int N, int64_t S, int C,
@@ -116,13 +116,16 @@ typedef struct cbim_conv_desc {
 size_t cbim_conv3d_packed_bytes(const cbim_conv_desc* fwd_desc, int mode);
 int cbim_conv3d_pack_weights(const cbim_conv_desc* fwd_desc, int mode, const float* w, void* packed,
                              void* stream);
+/* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
+ * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
+int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);
 /* Number of spatial tiles per sample = rows of the per-tile partial-sum buffer. */
 int cbim_conv3d_num_tiles(const cbim_conv_desc* desc);
 /* y = conv(xform(x), w) [+ res];  xform(x) = act((x-mean)*rstd) when in_stats != NULL (zero
  * padding is applied AFTER the transform, conv_layers.py:48-49).  Optional epilogue:
  *   mask_x != NULL : y *= act'((mask_x-mean)*rstd)      (dgrad through a pre-activation)
  *   partials != NULL: per-tile (sum u, sum u*v) over the stored values, float
- *                     [N][tiles][Cout][2]; v = u (forward: InstanceNorm statistics of y) or
+ *                     [N][tiles][Cout][3] records; v = u (forward: InstanceNorm statistics of y) or
  *                     v = xh of mask_x (dgrad: the two InstanceNorm-backward sums).
  * For dgrad pass the dgrad desc (input = dy extent/Cout, output = x extent/Cin, p' = k-1-p). */
 int cbim_conv3d_igemm(const cbim_conv_desc* desc, const void* x, int64_t x_stride,

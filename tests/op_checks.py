@@ -1,0 +1,179 @@
+"""Per-kernel parity checks against plain torch fp32 references of the same op.
+
+Shared by tests/test_ops_emu.py (CPU: kernels run on the host-side executor in tests/emu) and
+tests/test_gpu_ops.py (-m gpu: the real gfx950 library through the C ABI).  bf16 kernels are
+compared with the fp32 op evaluated on bf16-rounded inputs; tolerances are written per check.
+"""
+import torch
+import torch.nn.functional as F
+
+from cbim_amd import ops
+
+
+def to_cl(x, dtype):  # NCDHW fp32 -> channels-last dtype
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(dtype)
+
+
+def from_cl(x):
+    return x.float().permute(0, 4, 1, 2, 3)
+
+
+def tol(dtype, f32=1e-5, bf16=1e-2):
+    return bf16 if dtype == torch.bfloat16 else f32
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-20))
+
+
+def check_instnorm(dev, dtype, N=2, C=24, dhw=(5, 7, 9), act="relu"):
+    torch.manual_seed(1)
+    x = torch.randn(N, C, *dhw) * 2 + 3.0           # |mean| >> 0 exercises the centred moments
+    xl = to_cl(x, dtype).to(dev)
+    xr = from_cl(xl.cpu())
+    st = ops.instnorm_stats(xl).cpu()
+    m = xr.mean((2, 3, 4))
+    v = xr.var((2, 3, 4), unbiased=False)
+    assert relerr(st[..., 0], m) < 1e-5
+    assert relerr(st[..., 1], 1 / torch.sqrt(v + 1e-4)) < 1e-5
+    y = ops.norm_act_fwd(xl, st.to(dev), ops.ACT[act])
+    ref = F.relu(F.instance_norm(xr, eps=1e-4))
+    assert relerr(from_cl(y.cpu()), ref) < tol(dtype, 1e-5, 8e-3)
+    # backward of act(IN(x)) wrt x
+    xr2 = xr.clone().requires_grad_(True)
+    g = torch.randn_like(xr)
+    gl = to_cl(g, dtype).to(dev)
+    F.relu(F.instance_norm(xr2, eps=1e-4)).backward(from_cl(gl.cpu()))
+    sums = ops.norm_bwd_sums(gl, xl, st.to(dev), 1, True)
+    dx = ops.norm_bwd_apply(gl, xl, st.to(dev), sums, 1, True)
+    assert relerr(from_cl(dx.cpu()), xr2.grad) < tol(dtype, 2e-5, 1e-2)
+
+
+def check_maxpool(dev, dtype, N=1, C=16, dhw=(5, 8, 6), scale=(2, 2, 2)):
+    torch.manual_seed(2)
+    x = torch.randn(N, C, *dhw)
+    xl = to_cl(x, dtype).to(dev)
+    xr = from_cl(xl.cpu()).requires_grad_(True)
+    y, idx = ops.maxpool_fwd(xl, scale)
+    ref = F.max_pool3d(xr, scale)
+    assert torch.equal(from_cl(y.cpu()), ref.detach())
+    g = torch.randn_like(ref)
+    gl = to_cl(g, dtype).to(dev)
+    ref.backward(from_cl(gl.cpu()))
+    dx = ops.maxpool_bwd(gl, idx, tuple(xl.shape), scale)
+    assert torch.equal(from_cl(dx.cpu()), xr.grad)
+
+
+def check_upcat(dev, dtype, N=1, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_first=True):
+    torch.manual_seed(3)
+    lo = torch.randn(N, Cl, *low)
+    sk = torch.randn(N, Cs, *hi)
+    lol, skl = to_cl(lo, dtype).to(dev), to_cl(sk, dtype).to(dev)
+    lor = from_cl(lol.cpu()).requires_grad_(True)
+    skr = from_cl(skl.cpu()).requires_grad_(True)
+    up = F.interpolate(lor, size=hi, mode="trilinear", align_corners=True)
+    ref = torch.cat([skr, up] if skip_first else [up, skr], 1)
+    out = ops.upcat_fwd(lol, skl, skip_first)
+    assert relerr(from_cl(out.cpu()), ref.detach()) < tol(dtype, 2e-6, 8e-3)
+    g = torch.randn_like(ref)
+    gl = to_cl(g, dtype).to(dev)
+    ref.backward(from_cl(gl.cpu()))
+    dlow, dskip = ops.upcat_bwd(gl, tuple(lol.shape), Cs, skip_first)
+    assert relerr(from_cl(dlow.cpu()), lor.grad) < tol(dtype, 5e-6, 1e-2)
+    assert torch.equal(from_cl(dskip.cpu()), skr.grad)
+
+
+def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0):
+    """conv(relu(IN(x))) forward (+epilogue statistics, +residual), dgrad (+mask, +IN-backward sums,
+    +accumulate) and wgrad of one ConvNormAct (reference conv_layers.py:48-49)."""
+    torch.manual_seed(seed)
+    pad = [i // 2 for i in k]
+    x = torch.randn(N, Cin, *dhw) + 0.5
+    w = torch.randn(Cout, Cin, *k) * 0.1
+    xl = to_cl(x, dtype).to(dev)
+    xr = from_cl(xl.cpu())
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, 1)
+    wdev = w.to(dev)
+    wp = ops.pack_weights(wdev, geom, 0)
+    st = ops.instnorm_stats(xl)
+    xh = F.instance_norm(xr, eps=1e-4)
+    a = F.relu(xh)
+    wr = w
+    if dtype == torch.bfloat16:
+        a = a.bfloat16().float()
+        wr = w.bfloat16().float()
+    a.requires_grad_(True)
+    wr = wr.clone().requires_grad_(True)
+    yr = F.conv3d(a, wr, None, 1, pad)
+    res = torch.randn_like(yr)
+    resl = to_cl(res, dtype).to(dev)
+    y, ys = ops.conv_fwd(xl, wp, geom, in_stats=st, res=resl, want_stats=True)
+    ysum = yr.detach() + from_cl(resl.cpu())
+    t = tol(dtype, 2e-5, 1e-2)
+    assert relerr(from_cl(y.cpu()), ysum) < t, "fwd"
+    assert relerr(ys[..., 0].cpu(), ysum.mean((2, 3, 4))) < 1e-3 * (10 if dtype == torch.bfloat16 else 1) + 1e-4
+    rs = 1 / torch.sqrt(ysum.var((2, 3, 4), unbiased=False) + 1e-4)
+    assert relerr(ys[..., 1].cpu(), rs) < 1e-4
+    # backward
+    dy = torch.randn_like(yr)
+    dyl = to_cl(dy, dtype).to(dev)
+    yr.backward(from_cl(dyl.cpu()))
+    wpd = ops.pack_weights(wdev, geom, 1)
+    g, _ = ops.conv_dgrad(dyl, wpd, geom)
+    assert relerr(from_cl(g.cpu()), a.grad) < t, "dgrad"
+    dw = ops.conv_wgrad(xl, st, dyl, geom)
+    assert relerr(dw.cpu(), wr.grad) < tol(dtype, 2e-5, 2e-5), "wgrad"
+    accl = to_cl(torch.randn_like(a), dtype).to(dev)
+    g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=xl, mask_stats=st, accumulate=accl)
+    gm = (a.grad + from_cl(accl.cpu())) * (xh > 0)
+    assert relerr(from_cl(g2.cpu()), gm) < t, "masked dgrad"
+    assert float((sums[..., 0].cpu() - gm.mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
+    assert float((sums[..., 1].cpu() - (gm * xh).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
+
+
+def check_stem_head(dev, dtype, N=1, Cin=2, base=8, K=5, dhw=(6, 9, 10), k=(3, 3, 3)):
+    torch.manual_seed(4)
+    pad = [i // 2 for i in k]
+    x = torch.randn(N, Cin, *dhw)
+    w = (torch.randn(base, Cin, *k) * 0.2).requires_grad_(True)
+    yr = F.conv3d(x, w, None, 1, pad)
+    y = ops.stem_fwd(x.to(dev), w.detach().to(dev), pad, dtype)
+    assert relerr(from_cl(y.cpu()), yr.detach()) < tol(dtype, 2e-6, 8e-3)
+    dy = torch.randn_like(yr)
+    dyl = to_cl(dy, dtype).to(dev)
+    yr.backward(from_cl(dyl.cpu()))
+    dw = ops.stem_wgrad(x.to(dev), dyl, tuple(w.shape), pad)
+    assert relerr(dw.cpu(), w.grad) < 2e-5
+    # head
+    h = torch.randn(N, base, *dhw)
+    hl = to_cl(h, dtype).to(dev)
+    hr = from_cl(hl.cpu()).requires_grad_(True)
+    wh = (torch.randn(K, base, 1, 1, 1) * 0.3).requires_grad_(True)
+    bh = torch.randn(K).requires_grad_(True)
+    zr = F.conv3d(hr, wh, bh)
+    z = ops.head_fwd(hl, wh.detach().reshape(K, base).contiguous().to(dev), bh.detach().to(dev))
+    assert relerr(z.cpu(), zr.detach()) < 5e-6
+    dz = torch.randn_like(zr)
+    zr.backward(dz)
+    dx, dwh, dbh = ops.head_bwd(hl, wh.detach().reshape(K, base).contiguous().to(dev), dz.to(dev))
+    assert relerr(from_cl(dx.cpu()), hr.grad) < tol(dtype, 5e-6, 8e-3)
+    assert relerr(dwh.cpu(), wh.grad.reshape(K, base)) < 2e-5
+    assert relerr(dbh.cpu(), bh.grad) < 2e-5
+
+
+def check_loss(dev, N=2, C=6, dhw=(6, 7, 8), weighted=True, seed=5):
+    from oracle import loss_ref
+    torch.manual_seed(seed)
+    z = (torch.randn(N, C, *dhw) * 2).requires_grad_(True)
+    lab = torch.randint(0, C, (N, 1) + dhw)
+    lab[:, :, :2] = 0          # unbalanced: some alphas clamp, some do not
+    w = torch.rand(C) + 0.5 if weighted else None
+    ce = loss_ref.cross_entropy(z, lab.squeeze(1), w)
+    dl = loss_ref.dice_loss(z, lab)
+    (0.7 * ce + 1.3 * dl).backward()
+    out, coef = ops.dice_ce_fwd(z.detach().to(dev), lab.to(dev), None if w is None else w.to(dev))
+    assert abs(float(out[0]) - float(ce)) < 2e-6 * max(1.0, abs(float(ce)))
+    assert abs(float(out[1]) - float(dl)) < 2e-6
+    g2 = torch.tensor([0.7, 1.3], device=dev)
+    dz = ops.dice_ce_bwd(z.detach().to(dev), lab.to(dev), None if w is None else w.to(dev), coef, g2)
+    assert relerr(dz.cpu(), z.grad) < 2e-5

@@ -1,0 +1,97 @@
+"""world_size-2 gloo test of the bucketed gradient all-reduce (cbim_amd.parallel.GradAllReduce):
+the averaged gradients of two ranks, each with its own volume, equal the gradient of the mean loss
+over both volumes computed by a single process.  The replica's compute is the CPU oracle module
+(test infrastructure) — the exchange logic under test is device-agnostic."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class TinyOracleNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        from oracle.unet_ref import make_unet_state_dict
+        self.ks, self.sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
+        sd = make_unet_state_dict(1, 2, 3, self.ks, "BasicBlock", seed=5)
+        self.names = list(sd.keys())
+        self.ps = torch.nn.ParameterList([torch.nn.Parameter(v) for v in sd.values()])
+
+    def forward(self, x):
+        from oracle.unet_ref import unet_forward
+        sd = {k: p for k, p in zip(self.names, self.ps)}
+        return unet_forward(sd, x, scale=self.sc, kernel_size=self.ks, block="BasicBlock")
+
+
+def _data(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(1, 1, 32, 32, 32, generator=g), torch.randint(0, 3, (1, 1, 32, 32, 32), generator=g)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cbim_amd.parallel import GradAllReduce
+    from oracle.loss_ref import ce_dice_loss
+    net = TinyOracleNet()
+    if rank == 1:     # perturb: the constructor broadcast must restore rank-0 weights
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    ddp = GradAllReduce(net, bucket_mb=0.05)     # several buckets
+    assert len(ddp.buckets) > 2
+    for it in range(2):                          # two steps: bucket state must reset
+        net.zero_grad(set_to_none=True)
+        x, lab = _data(rank)
+        ce_dice_loss(net(x), lab).backward()
+        ddp.synchronize()
+    grads = [p.grad.clone() for p in net.parameters()]
+    if rank == 0:
+        q.put([g.numpy() for g in grads])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bucketed_allreduce_matches_single_process_mean():
+    from oracle.loss_ref import ce_dice_loss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    net = TinyOracleNet()
+    loss = 0
+    for r in range(2):
+        x, lab = _data(r)
+        loss = loss + 0.5 * ce_dice_loss(net(x), lab)
+    loss.backward()
+    for g, p in zip(got, net.parameters()):
+        assert torch.allclose(torch.from_numpy(g), p.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_world_size_one_is_a_no_op():
+    from cbim_amd.parallel import GradAllReduce
+    net = torch.nn.Linear(4, 3)
+    ddp = GradAllReduce(net)
+    net(torch.randn(2, 4)).sum().backward()
+    g = net.weight.grad.clone()
+    ddp.synchronize()
+    assert torch.equal(g, net.weight.grad)

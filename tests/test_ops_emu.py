@@ -1,0 +1,67 @@
+"""CPU run of the per-kernel parity checks: the gfx950 kernel sources executed by the host-side
+executor in tests/emu (see tests/emu/hip_emu.h).  The same checks run on silicon in
+tests/test_gpu_ops.py."""
+import pytest
+import torch
+
+from tests import op_checks as oc
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+@pytest.fixture(autouse=True)
+def _need_emu(dev):
+    if dev != "cpu":
+        pytest.skip("host-side executor tests run only in the CPU suite")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_instnorm(dev, dtype):
+    oc.check_instnorm(dev, dtype)
+    oc.check_instnorm(dev, dtype, N=1, C=72, dhw=(2, 3, 3))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_maxpool(dev, dtype):
+    oc.check_maxpool(dev, dtype)
+    oc.check_maxpool(dev, dtype, dhw=(4, 9, 7), scale=(1, 2, 2))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_upcat(dev, dtype):
+    oc.check_upcat(dev, dtype)
+    oc.check_upcat(dev, dtype, low=(9, 4, 4), hi=(18, 8, 8), skip_first=False)
+    oc.check_upcat(dev, dtype, low=(1, 3, 2), hi=(2, 6, 4))
+
+
+@pytest.mark.parametrize("dtype,N,Cin,Cout,dhw,k", [
+    (F32, 1, 8, 8, (4, 8, 8), (3, 3, 3)),
+    (F32, 2, 20, 40, (5, 9, 11), (3, 3, 3)),
+    (BF16, 2, 40, 72, (6, 9, 10), (3, 3, 3)),
+    (F32, 1, 8, 16, (5, 8, 8), (2, 3, 3)),      # even kernel: output D grows by 1 (ACDC yaml)
+    (BF16, 1, 16, 8, (3, 12, 8), (1, 3, 3)),
+    (BF16, 1, 8, 8, (33, 16, 16), (3, 3, 3)),   # MT=2 tiles
+    (F32, 1, 4, 4, (2, 2, 2), (3, 3, 3)),       # bottom of a 32^3 pyramid
+])
+def test_conv(dev, dtype, N, Cin, Cout, dhw, k):
+    oc.check_conv(dev, dtype, N, Cin, Cout, dhw, k)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_stem_head(dev, dtype):
+    oc.check_stem_head(dev, dtype)
+    oc.check_stem_head(dev, dtype, Cin=1, base=16, K=3, dhw=(4, 8, 8), k=(1, 3, 3))
+
+
+def test_loss(dev):
+    oc.check_loss(dev)
+    oc.check_loss(dev, N=1, C=3, dhw=(4, 4, 4), weighted=False, seed=9)
+
+
+def test_errors_are_loud(dev):
+    from cbim_amd import ops
+    x = torch.zeros(1, 2, 2, 2, 6)           # 6 channels: not a whole 16-byte chunk
+    with pytest.raises(RuntimeError, match="multiple"):
+        ops.instnorm_stats(x)
+    with pytest.raises(TypeError):
+        ops.instnorm_stats(torch.zeros(1, 2, 2, 2, 8, dtype=torch.float16))
