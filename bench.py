@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--classes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=128, help="edge of the CPU-baseline sample volume")
+    ap.add_argument("--cpu-size", type=int, default=96, help="edge of the CPU-baseline sample volume")
     return ap.parse_args()
 
 
@@ -59,7 +59,7 @@ def synthetic(batch, classes, size, device, seed):
 def cpu_baseline(args):
     """Oracle fwd + loss + bwd on the host cores, one volume (bounded sample)."""
     from oracle import loss_ref, unet_ref
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)   # one socket's worth; oneDNN conv3d stops scaling beyond
     torch.set_num_threads(cores)
     ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
     sd = unet_ref.make_unet_state_dict(1, args.base, args.classes, ks, "BasicBlock", seed=2023)

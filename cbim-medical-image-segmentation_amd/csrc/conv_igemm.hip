@@ -120,31 +120,61 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
         rstd[j] = p.in_stats[((size_t)n * p.Cin + c0 + j) * 2 + 1];
       }
     }
-    for (int item = tid; item < hV * SLOTS; item += NT) {
-      int hv = item / SLOTS;
-      int hw = hv % p.hW;
-      int r2 = hv / p.hW;
-      int hh = r2 % p.hH, hd = r2 / p.hH;
-      int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi) {
-        size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
-        v = ld_chunk<T>(p.x, row * p.x_stride + c0);
-        if (p.in_stats) {
-          float f[CPC];
-          Elem<T>::unpack(v, f);
+    // loads are issued in batches (UA / UB independent 16-byte loads in flight per thread) before any
+    // of them is consumed: the staging phase is latency-bound otherwise.
+    constexpr int UA = 5, UB = 7;
+    const int a_items = hV * SLOTS;
+    for (int base = tid; base < a_items; base += NT * UA) {
+      u32x4 v[UA];
+      int dst[UA];
+      bool ld[UA];
 #pragma unroll
-          for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
-          v = Elem<T>::pack(f);
+      for (int u = 0; u < UA; ++u) {
+        int item = base + u * NT;
+        int hv = item / SLOTS;
+        int hw = hv % p.hW;
+        int r2 = hv / p.hW;
+        int hh = r2 % p.hH, hd = r2 / p.hH;
+        int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+        dst[u] = item < a_items ? (int)(hv * RB + ((my_slot ^ (hh & (SLOTS - 1))) << 4)) : -1;
+        ld[u] = item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        if (ld[u]) {
+          size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
+          v[u] = ld_chunk<T>(p.x, row * p.x_stride + c0);
         }
       }
-      *(u32x4*)(As + (size_t)hv * RB + ((my_slot ^ (hh & (SLOTS - 1))) << 4)) = v;
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        if (dst[u] >= 0) {
+          u32x4 w = v[u];
+          if (p.in_stats && ld[u]) {
+            float f[CPC];
+            Elem<T>::unpack(w, f);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
+            w = Elem<T>::pack(f);
+          }
+          *(u32x4*)(As + dst[u]) = w;
+        }
+      }
     }
     // ---- stage this chunk's weights (already in fragment order): one contiguous block copy ---------
     {
       const unsigned char* wsrc = (const unsigned char*)p.w + ((size_t)nb * p.n_chunks + q) * b_bytes;
-      for (size_t o = (size_t)tid * 16; o < b_bytes; o += (size_t)NT * 16)
-        *(u32x4*)(Bs + o) = *(const u32x4*)(wsrc + o);
+      for (size_t ob = (size_t)tid * 16; ob < b_bytes; ob += (size_t)NT * 16 * UB) {
+        u32x4 v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          size_t o = ob + (size_t)u * NT * 16;
+          if (o < b_bytes) v[u] = *(const u32x4*)(wsrc + o);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          size_t o = ob + (size_t)u * NT * 16;
+          if (o < b_bytes) *(u32x4*)(Bs + o) = v[u];
+        }
+      }
     }
     __syncthreads();
     // ---- taps x k-groups ------------------------------------------------------------------------------

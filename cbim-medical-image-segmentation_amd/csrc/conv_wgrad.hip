@@ -117,38 +117,64 @@ __global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
     const int ow0 = (t % p.tiles_w) * 8;
     const int id0 = od0 - p.pD, ih0 = oh0 - p.pH, iw0 = ow0 - p.pW;
     __syncthreads();
-    // ---- stage dy tile: dense [BMv][32 co] ------------------------------------------------------------
-    for (int item = tid; item < BMv * SLOTS; item += NT) {
-      int m = item / SLOTS;
-      int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
-      int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (co0 < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo) {
-        size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
-        v = ld_chunk<T>(p.dy, row * p.dy_stride + co0);
-      }
-      *(u32x4*)(dyL + (size_t)m * ROWB + my_slot * 16) = v;
-    }
-    // ---- stage the transformed input halo: [hV][32 ci] --------------------------------------------------
-    for (int item = tid; item < hV * SLOTS; item += NT) {
-      int hv = item / SLOTS;
-      int hw = hv % p.hW;
-      int r2 = hv / p.hW;
-      int hh = r2 % p.hH, hd = r2 / p.hH;
-      int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ci0 < p.Cin && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi) {
-        size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
-        v = ld_chunk<T>(p.x, row * p.x_stride + ci0);
-        if (p.in_stats) {
-          float f[CPC];
-          Elem<T>::unpack(v, f);
+    // ---- stage dy tile: dense [BMv][32 co]; loads batched (UD/UA in flight per thread) -------------------
+    constexpr int UD = 4, UA = 5;
+    const int d_items = BMv * SLOTS;
+    for (int base = tid; base < d_items; base += NT * UD) {
+      u32x4 v[UD];
 #pragma unroll
-          for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
-          v = Elem<T>::pack(f);
+      for (int u = 0; u < UD; ++u) {
+        int item = base + u * NT;
+        int m = item / SLOTS;
+        int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
+        int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        if (item < d_items && co0 < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo) {
+          size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+          v[u] = ld_chunk<T>(p.dy, row * p.dy_stride + co0);
         }
       }
-      *(u32x4*)(aL + (size_t)hv * ROWB + my_slot * 16) = v;
+#pragma unroll
+      for (int u = 0; u < UD; ++u) {
+        int item = base + u * NT;
+        if (item < d_items) *(u32x4*)(dyL + (size_t)(item / SLOTS) * ROWB + my_slot * 16) = v[u];
+      }
+    }
+    // ---- stage the transformed input halo: [hV][32 ci] --------------------------------------------------
+    const int a_items = hV * SLOTS;
+    for (int base = tid; base < a_items; base += NT * UA) {
+      u32x4 v[UA];
+      bool ld[UA];
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        int item = base + u * NT;
+        int hv = item / SLOTS;
+        int hw = hv % p.hW;
+        int r2 = hv / p.hW;
+        int hh = r2 % p.hH, hd = r2 / p.hH;
+        int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+        ld[u] = item < a_items && ci0 < p.Cin && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        if (ld[u]) {
+          size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
+          v[u] = ld_chunk<T>(p.x, row * p.x_stride + ci0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        int item = base + u * NT;
+        if (item < a_items) {
+          u32x4 w = v[u];
+          if (p.in_stats && ld[u]) {
+            float f[CPC];
+            Elem<T>::unpack(w, f);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
+            w = Elem<T>::pack(f);
+          }
+          *(u32x4*)(aL + (size_t)(item / SLOTS) * ROWB + my_slot * 16) = w;
+        }
+      }
     }
     __syncthreads();
     // ---- contraction over the tile's voxels ------------------------------------------------------------------

@@ -114,36 +114,64 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
   }
 }
 
-__global__ void __launch_bounds__(NT) k_stats_finalize(const float* __restrict__ partials, int N, int P,
-                                                       int C, double count, float eps, int mode,
-                                                       float* __restrict__ out) {
-  int i = blockIdx.x * NT + threadIdx.x;
-  if (i >= N * C) return;
-  int n = i / C, c = i % C;
-  if (mode == 0) {   // Chan merge of (count, mean, M2) records in fp64, fixed order
-    double na = 0.0, ma = 0.0, M2 = 0.0;
-    for (int p = 0; p < P; ++p) {
-      size_t o = (((size_t)n * P + p) * C + c) * 3;
-      double nb = (double)partials[o];
-      if (nb <= 0.0) continue;
-      double mb = (double)partials[o + 1], Mb = (double)partials[o + 2];
-      double nn = na + nb, d = mb - ma;
-      ma += d * (nb / nn);
-      M2 += Mb + d * d * (na * nb / nn);
-      na = nn;
+// One workgroup per (n, c): FIN_T threads stride over the P records (independent loads in flight),
+// then a fixed-shape tree merge through LDS — deterministic, and no serial walk over 8192 tiles.
+static constexpr int FIN_T = 128;
+__global__ void __launch_bounds__(FIN_T) k_stats_finalize(const float* __restrict__ partials, int N, int P,
+                                                          int C, double count, float eps, int mode,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x;  // n*C + c
+  const int n = i / C, c = i % C;
+  const int t = threadIdx.x;
+  __shared__ double red[FIN_T * 3];
+  double na = 0.0, ma = 0.0, M2 = 0.0;
+  const float* base = partials + ((size_t)n * P * C + c) * 3;
+  for (int p = t; p < P; p += FIN_T) {
+    const float* r = base + (size_t)p * C * 3;
+    double nb = (double)r[0], mb = (double)r[1], Mb = (double)r[2];
+    if (mode == 0) {
+      if (nb > 0.0) {
+        double nn = na + nb, d = mb - ma;
+        ma += d * (nb / nn);
+        M2 += Mb + d * d * (na * nb / nn);
+        na = nn;
+      }
+    } else {
+      ma += mb;
+      M2 += Mb;
     }
-    double var = na > 0.0 ? M2 / na : 0.0;
-    out[(size_t)i * 2] = (float)ma;
-    out[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  } else {
-    double a0 = 0.0, a1 = 0.0;
-    for (int p = 0; p < P; ++p) {
-      size_t o = (((size_t)n * P + p) * C + c) * 3;
-      a0 += (double)partials[o + 1];
-      a1 += (double)partials[o + 2];
+  }
+  red[t * 3] = na; red[t * 3 + 1] = ma; red[t * 3 + 2] = M2;
+  __syncthreads();
+  for (int s = FIN_T / 2; s > 0; s >>= 1) {
+    if (t < s) {
+      double nb = red[(t + s) * 3], mb = red[(t + s) * 3 + 1], Mb = red[(t + s) * 3 + 2];
+      double xa = red[t * 3], xm = red[t * 3 + 1], xM = red[t * 3 + 2];
+      if (mode == 0) {
+        double nn = xa + nb;
+        if (nn > 0.0) {
+          double d = mb - xm;
+          xm += d * (nb / nn);
+          xM += Mb + d * d * (xa * nb / nn);
+        }
+        xa = nn;
+      } else {
+        xm += mb;
+        xM += Mb;
+      }
+      red[t * 3] = xa; red[t * 3 + 1] = xm; red[t * 3 + 2] = xM;
     }
-    out[(size_t)i * 2] = (float)(a0 / count);
-    out[(size_t)i * 2 + 1] = (float)(a1 / count);
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (mode == 0) {
+      double var = red[0] > 0.0 ? red[2] / red[0] : 0.0;
+      out[(size_t)i * 2] = (float)red[1];
+      out[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      out[(size_t)i * 2] = (float)(red[1] / count);
+      out[(size_t)i * 2 + 1] = (float)(red[2] / count);
+    }
   }
 }
 
@@ -269,7 +297,7 @@ extern "C" int cbim_instnorm_stats(int dtype, const void* x, int64_t x_stride, i
 extern "C" int cbim_stats_finalize(const float* partials, int N, int P, int C, double count, float eps,
                                    int mode, float* out, void* stream) {
   CBIM_CHECK(N >= 1 && P >= 1 && C >= 1, CBIM_EINVAL, "bad sizes");
-  CBIM_LAUNCH(k_stats_finalize, dim3((N * C + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, partials, N,
+  CBIM_LAUNCH(k_stats_finalize, dim3(N * C), dim3(FIN_T), 0, (hipStream_t)stream, partials, N,
               P, C, count, eps, mode, out);
   return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }

@@ -122,7 +122,9 @@ def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0):
     g, _ = ops.conv_dgrad(dyl, wpd, geom)
     assert relerr(from_cl(g.cpu()), a.grad) < t, "dgrad"
     dw = ops.conv_wgrad(xl, st, dyl, geom)
-    assert relerr(dw.cpu(), wr.grad) < tol(dtype, 2e-5, 2e-5), "wgrad"
+    # fp32 result of bf16 MFMA over up to ~10^5 voxels: accumulation order differs from torch's
+    e_w = relerr(dw.cpu(), wr.grad)
+    assert e_w < tol(dtype, 5e-5, 1e-3), f"wgrad {e_w:.3e}"
     accl = to_cl(torch.randn_like(a), dtype).to(dev)
     g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=xl, mask_stats=st, accumulate=accl)
     gm = (a.grad + from_cl(accl.cpu())) * (xh > 0)

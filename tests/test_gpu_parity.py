@@ -108,9 +108,15 @@ def test_training_reduces_loss_and_matches_oracle_at_64(dev):
             logits = net(x)
             if i == 0 and mode == "fp32":
                 err = float((logits.detach().cpu() - lo).abs().max() / lo.abs().max())
-                mism = int((logits.argmax(1).cpu() != lo.argmax(1)).sum())
-                print("64^3 fp32 vs oracle: logits rel err", err, "argmax mismatches", mism)
-                assert err < 1e-3 and mism <= 2      # <=1e-5 of voxels may sit on a fp32 tie
+                # argmax maps must be identical wherever the oracle's top-2 logit gap is not an fp32
+                # tie (< 1e-4: the reference's own fp32-vs-fp64 run flips such voxels)
+                top2 = lo.topk(2, dim=1).values
+                decided = (top2[:, 0] - top2[:, 1]) > 1e-4
+                diff = logits.argmax(1).cpu() != lo.argmax(1)
+                mism = int((diff & decided).sum())
+                print("64^3 fp32 vs oracle: logits rel err", err, "argmax mismatches", int(diff.sum()),
+                      "of which outside fp32 ties", mism, "tie voxels", int((~decided).sum()))
+                assert err < 1e-3 and mism == 0 and int(diff.sum()) <= 1e-4 * diff.numel()
                 dice_o = loss_ref.hard_dice(lo.argmax(1), lab.squeeze(1).cpu(), 8)
                 dice_h = loss_ref.hard_dice(logits.argmax(1).cpu(), lab.squeeze(1).cpu(), 8)
                 assert float((dice_o - dice_h).abs().max()) < 0.002
