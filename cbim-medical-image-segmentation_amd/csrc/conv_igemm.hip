@@ -4,20 +4,24 @@
 //   GEMM view:  M = output voxels, N = Cout, K = taps x Cin.
 //   Workgroup:  256 threads = 4 waves; output tile = tD x tH x 8 voxels (BM = 128*MT) x BN = 32*NTL
 //               couts; wave w owns m-tiles [w*MT, w*MT+MT) (32 voxels = 4 rows x 8 in W) and all NTL
-//               n-tiles, i.e. MT*NTL accumulators of 16 VGPRs.
+//               n-tiles, i.e. MT*NTL accumulators of 16 VGPRs.  LDS <= 75 KiB -> 2 workgroups per CU
+//               (2 waves per SIMD): one workgroup's staging overlaps the other's MFMA phase.
 //   K loop:     Cin in chunks of 64 BYTES per voxel (32 bf16 / 16 f32 channels).  Per chunk the
 //               (tD+kD-1)(tH+kH-1)(8+kW-1) input halo is staged ONCE into LDS — InstanceNorm +
 //               activation of the producer are applied on that load (pre-activation ConvNormAct,
 //               /root/reference/model/dim3/conv_layers.py:48-49; literal zeros for the padding) —
-//               and re-used by all taps; the chunk's weights for all taps sit beside it in LDS in
-//               MFMA B-fragment order (one contiguous block copy from the pre-packed buffer).
+//               and re-used by all taps; the weights are staged one kd-plane (kH*kW taps) at a time
+//               in MFMA B-fragment order (a contiguous block copy from the pre-packed buffer).
+//   Inner loop: one tap per step, fragments of the NEXT tap are fetched (ds_read_b128) into a second
+//               register set before the MFMAs of the current tap issue (software pipelining by hand:
+//               with 1-2 waves per SIMD nothing else hides the LDS latency).
 //   LDS layout: halo row = 64 B = four 16-B slots, slot index XOR (halo_row_h & 3): a 16-lane
 //               ds_read_b128 group (4 voxel rows x 4 voxels) then covers 16 distinct 16-B slots.
 //   Fragments:  one ds_read_b128 per operand per 16(bf16)/8(f32) channels; element order inside a
 //               k-group is (lane-half, j) -> channel 2kg*CPC + half*CPC + j on BOTH operands, which
 //               makes bf16 (one 32x32x16 MFMA) and f32 (four 32x32x2 MFMAs) byte-identical in LDS.
-//   Epilogue:   + residual, x act'(xh) mask (dgrad through a pre-activation), per-tile partial sums
-//               (InstanceNorm statistics of the output, or the two InstanceNorm-backward sums).
+//   Epilogue:   + residual, x act'(xh) mask (dgrad through a pre-activation), per-tile partial
+//               moments (InstanceNorm statistics of the output) or the two InstanceNorm-backward sums.
 //
 // Replaces aten::convolution / convolution_backward(input) for nn.Conv3d in ConvNormAct
 // (conv_layers.py:29-38), stride 1, groups 1, bias-free; padding k//2 (unet_utils.py:13).
@@ -44,6 +48,7 @@ struct IgemmParams {
   int tiles_d, tiles_h, tiles_w;
   int hD, hH, hW;                  // halo extent = tile + k - 1
   int n_chunks, taps;
+  unsigned mHW, mW;                // ceil(2^20 / (hH*hW)), ceil(2^20 / hW): division by multiply
 };
 
 template <typename T> struct Mma;
@@ -61,22 +66,38 @@ template <> struct Mma<float> {
   }
 };
 
+// ACT is a template parameter so the hot ReLU instantiation carries no erf/exp code (code size ->
+// instruction cache); ACT < 0 = runtime switch for the rarely used activations.
+template <int ACT> __device__ __forceinline__ float actf(float x, int rt) {
+  if (ACT == CBIM_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (ACT == CBIM_ACT_NONE) return x;
+  return act_fwd(x, rt);
+}
+template <int ACT> __device__ __forceinline__ float actg(float x, int rt) {
+  if (ACT == CBIM_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (ACT == CBIM_ACT_NONE) return 1.f;
+  return act_grad(x, rt);
+}
+
 #ifdef CBIM_EMU
 #define CBIM_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
 #else
 #define CBIM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
-template <typename T, int MT, int NTL>
-__global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
+template <int MT, int NTL> struct Frags { u32x4 a[KG][MT]; u32x4 b[KG][NTL]; };
+
+template <typename T, int MT, int NTL, int ACT>
+__global__ void __launch_bounds__(NT, 2) k_conv_igemm(IgemmParams p) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int KC = SLOTS * CPC;  // channels per chunk
   constexpr int BN = 32 * NTL;
   CBIM_DYN_SMEM(smem);
   const int hV = p.hD * p.hH * p.hW;
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + (size_t)hV * RB;
-  const size_t b_bytes = (size_t)p.taps * KG * 2 * BN * 16;
+  const unsigned a_bytes = (unsigned)hV * RB;           // B region starts here
+  const int ptaps = p.kH * p.kW;                        // taps per staged kd-plane
+  const unsigned tap_bytes = KG * 2 * BN * 16;
+  const unsigned plane_bytes = (unsigned)ptaps * tap_bytes;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -88,14 +109,16 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
   const int id0 = od0 - p.pD, ih0 = oh0 - p.pH, iw0 = ow0 - p.pW;
   const int nb = blockIdx.y, co0 = nb * BN;
 
-  int hv0[MT], thr[MT];
+  unsigned a_off[MT];   // LDS byte offset of the lane's voxel row at tap (0,0,0)
+  int thr[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int m = (wave * MT + mt) * 32 + li;
     int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
-    hv0[mt] = (td * p.hH + th) * p.hW + tw;
+    a_off[mt] = (unsigned)((td * p.hH + th) * p.hW + tw) * RB;
     thr[mt] = th;
   }
+  const unsigned b_lane = a_bytes + (unsigned)(half * BN + li) * 16;
   f32x16 acc[MT][NTL];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -106,99 +129,128 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
 
   const int my_slot = tid & (SLOTS - 1);  // NT % SLOTS == 0: a thread always stages the same slot
   const size_t nbase_in = (size_t)n * p.Di * p.Hi * p.Wi;
+  const int hHW = p.hH * p.hW;
+
+  // fragment fetch of one tap (kh, kw inside the staged plane; kd folded into a_plane)
+  auto fetch = [&](Frags<MT, NTL>& f, int tp, int kh, int kw, unsigned a_plane) {
+    const unsigned toff = a_plane + (unsigned)(kh * p.hW + kw) * RB;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt)
+        f.b[kg][nt] = *(const u32x4*)(smem + b_lane + (unsigned)tp * tap_bytes + (unsigned)(kg * 2 * BN + nt * 32) * 16);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        unsigned slot = (unsigned)((2 * kg + half) ^ ((thr[mt] + kh) & (SLOTS - 1)));
+        f.a[kg][mt] = *(const u32x4*)(smem + a_off[mt] + toff + (slot << 4));
+      }
+    }
+  };
+  auto mma = [&](const Frags<MT, NTL>& f) {
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) Mma<T>::run(f.a[kg][mt], f.b[kg][nt], acc[mt][nt]);
+  };
 
   for (int q = 0; q < p.n_chunks; ++q) {
     __syncthreads();  // previous chunk's fragments are consumed
     // ---- stage the input halo (with fused InstanceNorm + activation of the producer) --------------
-    const int c0 = q * KC + my_slot * CPC;
-    const bool c_ok = c0 < p.Cin;
-    float mean[CPC], rstd[CPC];
-    if (p.in_stats && c_ok) {
-#pragma unroll
-      for (int j = 0; j < CPC; ++j) {
-        mean[j] = p.in_stats[((size_t)n * p.Cin + c0 + j) * 2];
-        rstd[j] = p.in_stats[((size_t)n * p.Cin + c0 + j) * 2 + 1];
-      }
-    }
-    // loads are issued in batches (UA / UB independent 16-byte loads in flight per thread) before any
-    // of them is consumed: the staging phase is latency-bound otherwise.
-    constexpr int UA = 5, UB = 7;
-    const int a_items = hV * SLOTS;
-    for (int base = tid; base < a_items; base += NT * UA) {
-      u32x4 v[UA];
-      int dst[UA];
-      bool ld[UA];
-#pragma unroll
-      for (int u = 0; u < UA; ++u) {
-        int item = base + u * NT;
-        int hv = item / SLOTS;
-        int hw = hv % p.hW;
-        int r2 = hv / p.hW;
-        int hh = r2 % p.hH, hd = r2 / p.hH;
-        int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-        dst[u] = item < a_items ? (int)(hv * RB + ((my_slot ^ (hh & (SLOTS - 1))) << 4)) : -1;
-        ld[u] = item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
-        v[u] = u32x4{0u, 0u, 0u, 0u};
-        if (ld[u]) {
-          size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
-          v[u] = ld_chunk<T>(p.x, row * p.x_stride + c0);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UA; ++u) {
-        if (dst[u] >= 0) {
-          u32x4 w = v[u];
-          if (p.in_stats && ld[u]) {
-            float f[CPC];
-            Elem<T>::unpack(w, f);
-#pragma unroll
-            for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
-            w = Elem<T>::pack(f);
-          }
-          *(u32x4*)(As + dst[u]) = w;
-        }
-      }
-    }
-    // ---- stage this chunk's weights (already in fragment order): one contiguous block copy ---------
+    // loads are issued in batches (UA independent 16-byte loads in flight per thread) before any is
+    // consumed; (hd,hh,hw) decode by multiply-shift, no integer division.
     {
-      const unsigned char* wsrc = (const unsigned char*)p.w + ((size_t)nb * p.n_chunks + q) * b_bytes;
-      for (size_t ob = (size_t)tid * 16; ob < b_bytes; ob += (size_t)NT * 16 * UB) {
-        u32x4 v[UB];
+      const int c0 = q * KC + my_slot * CPC;
+      const bool c_ok = c0 < p.Cin;
+      float mean[CPC], rstd[CPC];
+      if (p.in_stats && c_ok) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          size_t o = ob + (size_t)u * NT * 16;
-          if (o < b_bytes) v[u] = *(const u32x4*)(wsrc + o);
+        for (int j = 0; j < CPC; ++j) {
+          mean[j] = p.in_stats[((size_t)n * p.Cin + c0 + j) * 2];
+          rstd[j] = p.in_stats[((size_t)n * p.Cin + c0 + j) * 2 + 1];
+        }
+      }
+      constexpr int UA = 5;
+      const int a_items = hV * SLOTS;
+      for (int base = tid; base < a_items; base += NT * UA) {
+        u32x4 v[UA];
+        int dst[UA];
+        bool ld[UA];
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+          int item = base + u * NT;
+          unsigned hv = (unsigned)item / SLOTS;
+          unsigned hd = (hv * p.mHW) >> 20;
+          unsigned r2 = hv - hd * hHW;
+          unsigned hh = (r2 * p.mW) >> 20;
+          unsigned hw = r2 - hh * p.hW;
+          int id = id0 + (int)hd, ih = ih0 + (int)hh, iw = iw0 + (int)hw;
+          dst[u] = item < a_items ? (int)(hv * RB + ((my_slot ^ (hh & (SLOTS - 1))) << 4)) : -1;
+          ld[u] = item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+          v[u] = u32x4{0u, 0u, 0u, 0u};
+          if (ld[u]) {
+            size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
+            v[u] = ld_chunk<T>(p.x, row * p.x_stride + c0);
+          }
         }
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          size_t o = ob + (size_t)u * NT * 16;
-          if (o < b_bytes) *(u32x4*)(Bs + o) = v[u];
+        for (int u = 0; u < UA; ++u) {
+          if (dst[u] >= 0) {
+            u32x4 w = v[u];
+            if (p.in_stats && ld[u]) {
+              float f[CPC];
+              Elem<T>::unpack(w, f);
+#pragma unroll
+              for (int j = 0; j < CPC; ++j) f[j] = actf<ACT>((f[j] - mean[j]) * rstd[j], p.act);
+              w = Elem<T>::pack(f);
+            }
+            *(u32x4*)(smem + dst[u]) = w;
+          }
         }
       }
     }
-    __syncthreads();
-    // ---- taps x k-groups ------------------------------------------------------------------------------
-    int tap = 0;
-    for (int kd = 0; kd < p.kD; ++kd)
-      for (int kh = 0; kh < p.kH; ++kh)
-        for (int kw = 0; kw < p.kW; ++kw, ++tap) {
-          const int tapoff = (kd * p.hH + kh) * p.hW + kw;
+    const unsigned char* wq = (const unsigned char*)p.w + ((size_t)nb * p.n_chunks + q) * ((size_t)p.kD * plane_bytes);
+    for (int kd = 0; kd < p.kD; ++kd) {
+      if (kd > 0) __syncthreads();  // the previous plane's weights are consumed
+      // ---- stage this kd-plane's weights (already in fragment order): contiguous block copy ------------
+      {
+        constexpr int UB = 5;
+        const unsigned char* wsrc = wq + (size_t)kd * plane_bytes;
+        for (unsigned ob = (unsigned)tid * 16; ob < plane_bytes; ob += NT * 16 * UB) {
+          u32x4 v[UB];
 #pragma unroll
-          for (int kg = 0; kg < KG; ++kg) {
-            u32x4 bf[NTL];
+          for (int u = 0; u < UB; ++u) {
+            unsigned o = ob + (unsigned)u * NT * 16;
+            if (o < plane_bytes) v[u] = *(const u32x4*)(wsrc + o);
+          }
 #pragma unroll
-            for (int nt = 0; nt < NTL; ++nt)
-              bf[nt] = *(const u32x4*)(Bs + ((size_t)((tap * KG + kg) * 2 + half) * BN + nt * 32 + li) * 16);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              int hv = hv0[mt] + tapoff;
-              int slot = (2 * kg + half) ^ ((thr[mt] + kh) & (SLOTS - 1));
-              u32x4 af = *(const u32x4*)(As + (size_t)hv * RB + (slot << 4));
-#pragma unroll
-              for (int nt = 0; nt < NTL; ++nt) Mma<T>::run(af, bf[nt], acc[mt][nt]);
-            }
+          for (int u = 0; u < UB; ++u) {
+            unsigned o = ob + (unsigned)u * NT * 16;
+            if (o < plane_bytes) *(u32x4*)(smem + a_bytes + o) = v[u];
           }
         }
+      }
+      __syncthreads();
+      // ---- the plane's taps, two per trip through statically named register sets ----------------------
+      const unsigned a_plane = (unsigned)(kd * hHW) * RB;
+      Frags<MT, NTL> f0, f1;
+      int kh = 0, kw = 0;   // (kh, kw) of the NEXT tap to fetch
+      fetch(f0, 0, 0, 0, a_plane);
+      if (++kw == p.kW) { kw = 0; ++kh; }
+      for (int tp = 0; tp < ptaps; tp += 2) {
+        if (tp + 1 < ptaps) {
+          fetch(f1, tp + 1, kh, kw, a_plane);
+          if (++kw == p.kW) { kw = 0; ++kh; }
+        }
+        mma(f0);
+        if (tp + 2 < ptaps) {
+          fetch(f0, tp + 2, kh, kw, a_plane);
+          if (++kw == p.kW) { kw = 0; ++kh; }
+        }
+        if (tp + 1 < ptaps) mma(f1);
+      }
+    }
   }
 
   // ---- epilogue --------------------------------------------------------------------------------------
@@ -229,7 +281,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
           if (p.res) v += Elem<T>::load1(p.res, row * p.res_stride + co);
           if (p.mx) {
             float xh = (Elem<T>::load1(p.mx, row * p.mx_stride + co) - mmean) * mrstd;
-            v *= act_grad(xh, p.act);
+            v *= actg<ACT>(xh, p.act);
             s0 += v;
             s1 += v * xh;
           } else {
@@ -385,21 +437,29 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   return ((d->Do + c.tD - 1) / c.tD) * ((d->Ho + c.tH - 1) / c.tH) * ((d->Wo + 7) / 8);
 }
 
-template <typename T, int MT, int NTL>
+template <typename T, int MT, int NTL, int ACT>
 static int launch_igemm(const IgemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
 #ifndef CBIM_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_igemm<T, MT, NTL>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_igemm<T, MT, NTL, ACT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
 #endif
-  CBIM_LAUNCH((k_conv_igemm<T, MT, NTL>), grid, dim3(NT), smem, st, p);
+  CBIM_LAUNCH((k_conv_igemm<T, MT, NTL, ACT>), grid, dim3(NT), smem, st, p);
   hipError_t e = hipGetLastError();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv igemm launch: %s", hipGetErrorString(e));
   return CBIM_OK;
+}
+
+template <typename T, int ACT>
+static int dispatch_tiles(const TileCfg& c, const IgemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
+  if (c.MT == 2 && c.NTL == 1) return launch_igemm<T, 2, 1, ACT>(p, grid, smem, st);
+  if (c.MT == 2 && c.NTL == 2) return launch_igemm<T, 2, 2, ACT>(p, grid, smem, st);
+  if (c.MT == 1 && c.NTL == 1) return launch_igemm<T, 1, 1, ACT>(p, grid, smem, st);
+  return launch_igemm<T, 1, 2, ACT>(p, grid, smem, st);
 }
 
 extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t x_stride,
@@ -421,11 +481,14 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   p.tD = c.tD; p.tH = c.tH; p.lgH = c.lgH;
   p.tiles_d = (d->Do + c.tD - 1) / c.tD; p.tiles_h = (d->Ho + c.tH - 1) / c.tH; p.tiles_w = (d->Wo + 7) / 8;
   p.hD = c.tD + d->kD - 1; p.hH = c.tH + d->kH - 1; p.hW = 8 + d->kW - 1;
+  CBIM_CHECK(p.hD * p.hH * p.hW <= 2048, CBIM_EUNSUPPORTED, "halo too large");
+  p.mHW = ((1u << 20) + (unsigned)(p.hH * p.hW) - 1) / (unsigned)(p.hH * p.hW);
+  p.mW = ((1u << 20) + (unsigned)p.hW - 1) / (unsigned)p.hW;
   int KC = kc_of(d->dtype);
   p.n_chunks = (d->Cin + KC - 1) / KC;
   p.taps = d->kD * d->kH * d->kW;
   int BN = 32 * c.NTL;
-  size_t smem = (size_t)p.hD * p.hH * p.hW * RB + (size_t)p.taps * KG * 2 * BN * 16;
+  size_t smem = (size_t)p.hD * p.hH * p.hW * RB + (size_t)d->kH * d->kW * KG * 2 * BN * 16;
   size_t red = (size_t)4 * c.MT * BN * 3 * sizeof(float);
   if (smem < red) smem = red;
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "conv tile needs %zu B of LDS", smem);
@@ -433,15 +496,10 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   CBIM_CHECK(nblk < (1ll << 31), CBIM_EUNSUPPORTED, "too many tiles");
   dim3 grid((unsigned)nblk, (unsigned)((d->Cout + BN - 1) / BN));
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CBIM_BF16) {
-    if (c.MT == 2 && c.NTL == 1) return launch_igemm<bf16_tag, 2, 1>(p, grid, smem, st);
-    if (c.MT == 2 && c.NTL == 2) return launch_igemm<bf16_tag, 2, 2>(p, grid, smem, st);
-    if (c.MT == 1 && c.NTL == 1) return launch_igemm<bf16_tag, 1, 1>(p, grid, smem, st);
-    return launch_igemm<bf16_tag, 1, 2>(p, grid, smem, st);
-  } else {
-    if (c.MT == 2 && c.NTL == 1) return launch_igemm<float, 2, 1>(p, grid, smem, st);
-    if (c.MT == 2 && c.NTL == 2) return launch_igemm<float, 2, 2>(p, grid, smem, st);
-    if (c.MT == 1 && c.NTL == 1) return launch_igemm<float, 1, 1>(p, grid, smem, st);
-    return launch_igemm<float, 1, 2>(p, grid, smem, st);
-  }
+  const bool relu = d->act == CBIM_ACT_RELU;
+  if (d->dtype == CBIM_BF16)
+    return relu ? dispatch_tiles<bf16_tag, CBIM_ACT_RELU>(c, p, grid, smem, st)
+                : dispatch_tiles<bf16_tag, -1>(c, p, grid, smem, st);
+  return relu ? dispatch_tiles<float, CBIM_ACT_RELU>(c, p, grid, smem, st)
+              : dispatch_tiles<float, -1>(c, p, grid, smem, st);
 }
