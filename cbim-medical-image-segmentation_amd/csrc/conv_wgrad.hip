@@ -7,12 +7,13 @@
 //   LDS tile: bf16 uses ds_read_b64_tr_b16 (the gfx950 LDS transpose read: a 16-lane group fetches a
 //   [4 voxels][16 channels] block and every lane receives one channel's 4 voxels), f32 needs no
 //   transpose because the 32x32x2 MFMA takes a single scalar per lane.
-//   Workgroup (256 threads, 4 waves) owns a (32 co x 32 ci) block and a STRIP of spatial tiles; per
-//   tile the dy tile and the transformed input halo are staged once into LDS; the taps are dealt
-//   round-robin to the 4 waves (<= 7 accumulators of 16 VGPRs per wave), the dy fragment is re-used
-//   by all of a wave's taps.  Accumulators live across the whole strip and are written once to a
-//   per-strip fp32 slab; a second kernel adds the slabs in fixed order (deterministic, no atomics)
-//   into the natural nn.Conv3d [Cout][Cin][kD][kH][kW] fp32 gradient.
+//   Workgroup (256 threads, 4 waves, 54 KiB LDS -> 2 per CU) owns a (32 co x 32 ci) block and a STRIP
+//   of spatial tiles; per tile the dy tile and the transformed input halo are staged once into LDS;
+//   the taps are dealt round-robin to the 4 waves (TPW accumulators of 16 VGPRs per wave), the dy
+//   fragment is re-used by all of a wave's taps; the fragments of voxel step k+1 are fetched into a
+//   second register set before the MFMAs of step k issue.  Accumulators live across the whole strip
+//   and are written once to a per-strip fp32 slab; a second kernel adds the slabs in fixed order
+//   (deterministic, no atomics) into the natural nn.Conv3d [Cout][Cin][kD][kH][kW] fp32 gradient.
 //
 // Replaces aten::convolution_backward(weight) for nn.Conv3d in ConvNormAct
 // (/root/reference/model/dim3/conv_layers.py:29-38).
@@ -21,7 +22,6 @@
 namespace cbim {
 
 static constexpr int NT = 256;
-static constexpr int TPW = 7;  // taps per wave (4 waves -> up to 28 taps)
 
 struct WgradParams {
   const void* x; int64_t x_stride; const float* in_stats;
@@ -31,6 +31,7 @@ struct WgradParams {
   int kD, kH, kW, pD, pH, pW, act;
   int tD, tH, lgH, tiles_d, tiles_h, tiles_w, hD, hH, hW, taps;
   int strips_per_n, tiles_per_strip, ci_blocks, Cout_pad, Cin_pad;
+  unsigned mHW, mW;
 };
 
 #ifdef CBIM_EMU
@@ -56,8 +57,17 @@ __device__ __forceinline__ u32x2 lds_tr16_b64(const unsigned char* p) {
 #endif
 }
 
-template <typename T>
-__global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
+template <int ACT> __device__ __forceinline__ float wg_actf(float x, int rt) {
+  if (ACT == CBIM_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (ACT == CBIM_ACT_NONE) return x;
+  return act_fwd(x, rt);
+}
+
+template <int TPW> struct WFrag { u32x4 a; u32x4 b[TPW]; };   // bf16: 8 voxels x 1 channel per operand
+template <int TPW> struct WFragF { float a; float b[TPW]; };  // f32 : 1 voxel per operand
+
+template <typename T, int TPW, int ACT>
+__global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int ES = Elem<T>::SIZE;
   constexpr int ROWB = 32 * ES;        // LDS row = 32 channels
@@ -66,8 +76,8 @@ __global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
   CBIM_DYN_SMEM(smem);
   const int BMv = p.tD * p.tH * 8;
   const int hV = p.hD * p.hH * p.hW;
-  unsigned char* dyL = smem;
-  unsigned char* aL = smem + (size_t)BMv * ROWB;
+  const unsigned aL = (unsigned)BMv * ROWB;   // halo region offset; dy tile at 0
+  const int hHW = p.hH * p.hW;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
   const int n = blockIdx.x / p.strips_per_n, strip = blockIdx.x % p.strips_per_n;
@@ -77,16 +87,16 @@ __global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
   int t_end = t_begin + p.tiles_per_strip;
   if (t_end > tiles_per_n) t_end = tiles_per_n;
 
-  // taps of this wave: tap = wave + 4*tl
-  int tapoff[TPW];
+  // taps of this wave: tap = wave + 4*tl (clamped: out-of-range slots redo the last tap and are dropped)
+  unsigned tapoff[TPW];
 #pragma unroll
   for (int tl = 0; tl < TPW; ++tl) {
     int tap = wave + 4 * tl;
+    if (tap > p.taps - 1) tap = p.taps - 1;
     int kw = tap % p.kW, r = tap / p.kW;
     int kh = r % p.kH, kd = r / p.kH;
-    tapoff[tl] = (kd * p.hH + kh) * p.hW + kw;
+    tapoff[tl] = (unsigned)((kd * p.hH + kh) * p.hW + kw) * ROWB;
   }
-  const int my_ntaps = p.taps > wave ? (p.taps - wave + 3) / 4 : 0;
 
   f32x16 acc[TPW];
 #pragma unroll
@@ -108,8 +118,45 @@ __global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
   const size_t nbase_in = (size_t)n * p.Di * p.Hi * p.Wi;
   const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
 
-  // per-lane voxel bookkeeping for the fragment reads
+  // per-lane constants of the fragment reads
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const unsigned colb = (unsigned)(16 * g16 + 4 * (i16 & 3)) * 2;   // bf16: byte offset of the 4-channel group
+  const int mq = 8 * half + (i16 >> 2);                             // bf16: voxel of the lane inside a k-step
+
+  auto halo_row = [&](int m) -> unsigned {   // LDS row (bytes) of tile voxel m at tap (0,0,0)
+    int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
+    return (unsigned)((td * p.hH + th) * p.hW + tw) * ROWB;
+  };
+  auto fetch16 = [&](WFrag<TPW>& f, int ks) {
+    int m0 = ks * 16 + mq, m1 = m0 + 4;
+    u32x2 a0 = lds_tr16_b64(smem + (unsigned)m0 * ROWB + colb);
+    u32x2 a1 = lds_tr16_b64(smem + (unsigned)m1 * ROWB + colb);
+    f.a = u32x4{a0.x, a0.y, a1.x, a1.y};
+    unsigned r0 = aL + halo_row(m0) + colb, r1 = aL + halo_row(m1) + colb;
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {
+      u32x2 b0 = lds_tr16_b64(smem + r0 + tapoff[tl]);
+      u32x2 b1 = lds_tr16_b64(smem + r1 + tapoff[tl]);
+      f.b[tl] = u32x4{b0.x, b0.y, b1.x, b1.y};
+    }
+  };
+  auto mma16 = [&](const WFrag<TPW>& f) {
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl)
+      acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a),
+                                                        __builtin_bit_cast(bf16x8, f.b[tl]), acc[tl], 0, 0, 0);
+  };
+  auto fetch32 = [&](WFragF<TPW>& f, int ks) {
+    int m = ks * 2 + half;
+    f.a = *(const float*)(smem + (unsigned)m * ROWB + li * 4);
+    unsigned r0 = aL + halo_row(m) + li * 4;
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) f.b[tl] = *(const float*)(smem + r0 + tapoff[tl]);
+  };
+  auto mma32 = [&](const WFragF<TPW>& f) {
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a, f.b[tl], acc[tl], 0, 0, 0);
+  };
 
   for (int t = t_begin; t < t_end; ++t) {
     const int od0 = (t / (p.tiles_w * p.tiles_h)) * p.tD;
@@ -137,7 +184,7 @@ __global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
 #pragma unroll
       for (int u = 0; u < UD; ++u) {
         int item = base + u * NT;
-        if (item < d_items) *(u32x4*)(dyL + (size_t)(item / SLOTS) * ROWB + my_slot * 16) = v[u];
+        if (item < d_items) *(u32x4*)(smem + (unsigned)(item / SLOTS) * ROWB + my_slot * 16) = v[u];
       }
     }
     // ---- stage the transformed input halo: [hV][32 ci] --------------------------------------------------
@@ -148,11 +195,12 @@ __global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
         int item = base + u * NT;
-        int hv = item / SLOTS;
-        int hw = hv % p.hW;
-        int r2 = hv / p.hW;
-        int hh = r2 % p.hH, hd = r2 / p.hH;
-        int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+        unsigned hv = (unsigned)item / SLOTS;
+        unsigned hd = (hv * p.mHW) >> 20;
+        unsigned r2 = hv - hd * hHW;
+        unsigned hh = (r2 * p.mW) >> 20;
+        unsigned hw = r2 - hh * p.hW;
+        int id = id0 + (int)hd, ih = ih0 + (int)hh, iw = iw0 + (int)hw;
         ld[u] = item < a_items && ci0 < p.Cin && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
         v[u] = u32x4{0u, 0u, 0u, 0u};
         if (ld[u]) {
@@ -169,55 +217,34 @@ __global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
             float f[CPC];
             Elem<T>::unpack(w, f);
 #pragma unroll
-            for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
+            for (int j = 0; j < CPC; ++j) f[j] = wg_actf<ACT>((f[j] - mean[j]) * rstd[j], p.act);
             w = Elem<T>::pack(f);
           }
-          *(u32x4*)(aL + (size_t)(item / SLOTS) * ROWB + my_slot * 16) = w;
+          *(u32x4*)(smem + aL + (unsigned)(item / SLOTS) * ROWB + my_slot * 16) = w;
         }
       }
     }
     __syncthreads();
-    // ---- contraction over the tile's voxels ------------------------------------------------------------------
+    // ---- contraction over the tile's voxels, two k-steps per trip through static register sets --------------
     if (IS_BF16) {
-      for (int ks = 0; ks < BMv / 16; ++ks) {
-        // lane's two voxel quads: m = ks*16 + 8*half + 4*s + (i16>>2), s = 0,1
-        int m0 = ks * 16 + 8 * half + (i16 >> 2);
-        int m1 = m0 + 4;
-        int col = (16 * g16 + 4 * (i16 & 3)) * 2;  // byte offset of the lane's 4-channel group
-        u32x2 a0 = lds_tr16_b64(dyL + (size_t)m0 * ROWB + col);
-        u32x2 a1 = lds_tr16_b64(dyL + (size_t)m1 * ROWB + col);
-        u32x4 af = {a0.x, a0.y, a1.x, a1.y};
-        int hvm0, hvm1;
-        {
-          int tw = m0 & 7, th = (m0 >> 3) & (p.tH - 1), td = m0 >> (3 + p.lgH);
-          hvm0 = (td * p.hH + th) * p.hW + tw;
-          tw = m1 & 7; th = (m1 >> 3) & (p.tH - 1); td = m1 >> (3 + p.lgH);
-          hvm1 = (td * p.hH + th) * p.hW + tw;
-        }
-#pragma unroll
-        for (int tl = 0; tl < TPW; ++tl) {
-          if (tl < my_ntaps) {
-            u32x2 b0 = lds_tr16_b64(aL + (size_t)(hvm0 + tapoff[tl]) * ROWB + col);
-            u32x2 b1 = lds_tr16_b64(aL + (size_t)(hvm1 + tapoff[tl]) * ROWB + col);
-            u32x4 bf = {b0.x, b0.y, b1.x, b1.y};
-            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
-                                                              __builtin_bit_cast(bf16x8, bf), acc[tl], 0, 0, 0);
-          }
-        }
+      const int nks = BMv / 16;   // even (BMv is 128 or 256)
+      WFrag<TPW> f0, f1;
+      fetch16(f0, 0);
+      for (int ks = 0; ks < nks; ks += 2) {
+        fetch16(f1, ks + 1);
+        mma16(f0);
+        if (ks + 2 < nks) fetch16(f0, ks + 2);
+        mma16(f1);
       }
     } else {
-      for (int ks = 0; ks < BMv / 2; ++ks) {
-        int m = ks * 2 + half;
-        float av = *(const float*)(dyL + (size_t)m * ROWB + li * 4);
-        int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
-        int hvm = (td * p.hH + th) * p.hW + tw;
-#pragma unroll
-        for (int tl = 0; tl < TPW; ++tl) {
-          if (tl < my_ntaps) {
-            float bv = *(const float*)(aL + (size_t)(hvm + tapoff[tl]) * ROWB + li * 4);
-            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tl], 0, 0, 0);
-          }
-        }
+      const int nks = BMv / 2;
+      WFragF<TPW> f0, f1;
+      fetch32(f0, 0);
+      for (int ks = 0; ks < nks; ks += 2) {
+        fetch32(f1, ks + 1);
+        mma32(f0);
+        if (ks + 2 < nks) fetch32(f0, ks + 2);
+        mma32(f1);
       }
     }
   }
@@ -227,8 +254,8 @@ __global__ void __launch_bounds__(NT) k_conv_wgrad(WgradParams p) {
   float* wsb = p.ws + (size_t)blockIdx.x * slab;
 #pragma unroll
   for (int tl = 0; tl < TPW; ++tl) {
-    if (tl < my_ntaps) {
-      int tap = wave + 4 * tl;
+    int tap = wave + 4 * tl;
+    if (tap < p.taps) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -249,9 +276,16 @@ __global__ void __launch_bounds__(NT) k_wgrad_reduce(const float* __restrict__ w
     int tap = (int)(r / Cout);
     size_t o = ((size_t)tap * Cout_pad + co) * Cin_pad + ci;
     size_t slab = (size_t)taps * Cout_pad * Cin_pad;
-    float a = 0.f;
-    for (int s = 0; s < n_slabs; ++s) a += ws[(size_t)s * slab + o];
-    dw[((size_t)co * Cin + ci) * taps + tap] = a;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // 4 independent chains: loads stay in flight
+    int s = 0;
+    for (; s + 3 < n_slabs; s += 4) {
+      a0 += ws[(size_t)s * slab + o];
+      a1 += ws[(size_t)(s + 1) * slab + o];
+      a2 += ws[(size_t)(s + 2) * slab + o];
+      a3 += ws[(size_t)(s + 3) * slab + o];
+    }
+    for (; s < n_slabs; ++s) a0 += ws[(size_t)s * slab + o];
+    dw[((size_t)co * Cin + ci) * taps + tap] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -270,13 +304,13 @@ static WgCfg wg_cfg(const cbim_conv_desc* d) {
   c.ci_blocks = (d->Cin + 31) / 32;
   int tiles_per_n = c.tiles_d * c.tiles_h * c.tiles_w;
   int64_t pairs = (int64_t)c.co_blocks * c.ci_blocks;
-  int64_t want = 2048 / (pairs * d->N);  // aim at ~2048 workgroups
+  // ~512 resident workgroups (2 per CU); every extra strip costs one slab of workspace traffic
+  int64_t want = (512 + pairs * d->N - 1) / (pairs * d->N);
   if (want < 1) want = 1;
   if (want > tiles_per_n) want = tiles_per_n;
-  // cap the slab workspace at ~96 MiB
   int taps = d->kD * d->kH * d->kW;
   size_t slab = (size_t)taps * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
-  int64_t cap = (int64_t)((96ull << 20) / (slab * d->N));
+  int64_t cap = (int64_t)((64ull << 20) / (slab * d->N));   // cap the slab workspace at ~64 MiB
   if (cap < 1) cap = 1;
   if (want > cap) want = cap;
   c.tiles_per_strip = (int)((tiles_per_n + want - 1) / want);
@@ -295,20 +329,30 @@ extern "C" size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* d) {
   return (size_t)d->N * c.strips_per_n * taps * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
 }
 
-template <typename T>
+template <typename T, int TPW, int ACT>
 static int launch_wgrad(const WgradParams& p, dim3 grid, size_t smem, hipStream_t st) {
 #ifndef CBIM_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_wgrad<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_wgrad<T, TPW, ACT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
 #endif
-  CBIM_LAUNCH((k_conv_wgrad<T>), grid, dim3(NT), smem, st, p);
+  CBIM_LAUNCH((k_conv_wgrad<T, TPW, ACT>), grid, dim3(NT), smem, st, p);
   hipError_t e = hipGetLastError();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv wgrad launch: %s", hipGetErrorString(e));
   return CBIM_OK;
+}
+
+template <typename T, int ACT>
+static int dispatch_tpw(int taps, const WgradParams& p, dim3 grid, size_t smem, hipStream_t st) {
+  int tpw = (taps + 3) / 4;
+  if (tpw <= 1) return launch_wgrad<T, 1, ACT>(p, grid, smem, st);
+  if (tpw <= 3) return launch_wgrad<T, 3, ACT>(p, grid, smem, st);
+  if (tpw <= 5) return launch_wgrad<T, 5, ACT>(p, grid, smem, st);
+  return launch_wgrad<T, 7, ACT>(p, grid, smem, st);
 }
 
 extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t x_stride,
@@ -320,7 +364,7 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   CBIM_CHECK(d->Cin % cpc == 0 && d->Cout % cpc == 0, CBIM_EUNSUPPORTED,
              "wgrad needs Cin (%d) and Cout (%d) to be multiples of %d", d->Cin, d->Cout, cpc);
   int taps = d->kD * d->kH * d->kW;
-  CBIM_CHECK(taps <= 4 * TPW, CBIM_EUNSUPPORTED, "wgrad supports at most %d taps", 4 * TPW);
+  CBIM_CHECK(taps <= 28, CBIM_EUNSUPPORTED, "wgrad supports at most 28 taps");
   size_t need = cbim_conv3d_wgrad_workspace(d);
   CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "wgrad workspace %zu < %zu", ws_bytes, need);
   WgCfg c = wg_cfg(d);
@@ -332,6 +376,9 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   p.kD = d->kD; p.kH = d->kH; p.kW = d->kW; p.pD = d->pD; p.pH = d->pH; p.pW = d->pW; p.act = d->act;
   p.tD = c.tD; p.tH = c.tH; p.lgH = c.lgH; p.tiles_d = c.tiles_d; p.tiles_h = c.tiles_h; p.tiles_w = c.tiles_w;
   p.hD = c.tD + d->kD - 1; p.hH = c.tH + d->kH - 1; p.hW = 8 + d->kW - 1;
+  CBIM_CHECK(p.hD * p.hH * p.hW <= 2048, CBIM_EUNSUPPORTED, "halo too large");
+  p.mHW = ((1u << 20) + (unsigned)(p.hH * p.hW) - 1) / (unsigned)(p.hH * p.hW);
+  p.mW = ((1u << 20) + (unsigned)p.hW - 1) / (unsigned)p.hW;
   p.taps = taps; p.strips_per_n = c.strips_per_n; p.tiles_per_strip = c.tiles_per_strip;
   p.ci_blocks = c.ci_blocks; p.Cout_pad = c.co_blocks * 32; p.Cin_pad = c.ci_blocks * 32;
   int es = d->dtype == CBIM_BF16 ? 2 : 4;
@@ -339,7 +386,12 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "wgrad tile needs %zu B of LDS", smem);
   dim3 grid((unsigned)(d->N * c.strips_per_n), (unsigned)(c.co_blocks * c.ci_blocks));
   hipStream_t st = (hipStream_t)stream;
-  int rc = d->dtype == CBIM_BF16 ? launch_wgrad<bf16_tag>(p, grid, smem, st) : launch_wgrad<float>(p, grid, smem, st);
+  const bool relu = d->act == CBIM_ACT_RELU || !in_stats;
+  int rc;
+  if (d->dtype == CBIM_BF16)
+    rc = relu ? dispatch_tpw<bf16_tag, CBIM_ACT_RELU>(taps, p, grid, smem, st) : dispatch_tpw<bf16_tag, -1>(taps, p, grid, smem, st);
+  else
+    rc = relu ? dispatch_tpw<float, CBIM_ACT_RELU>(taps, p, grid, smem, st) : dispatch_tpw<float, -1>(taps, p, grid, smem, st);
   if (rc) return rc;
   int64_t total = (int64_t)taps * d->Cout * d->Cin;
   int64_t blocks = (total + NT - 1) / NT;
