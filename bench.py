@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--classes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1: replay the whole step from one hipGraph (captured after warm-up; N=1 only)")
     ap.add_argument("--cpu-size", type=int, default=96, help="edge of the CPU-baseline sample volume")
     return ap.parse_args()
 
@@ -105,7 +107,9 @@ def main():
     w = torch.ones(args.classes)
     w[0] = 0.5
     crit = DiceCELoss(w).to(dev)
-    opt = torch.optim.AdamW(net.parameters(), lr=6e-4, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5, fused=True)
+    use_graph = bool(args.graph) and world == 1
+    opt = torch.optim.AdamW(net.parameters(), lr=6e-4, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5, fused=True,
+                            capturable=use_graph)
     ddp = GradAllReduce(net) if world > 1 else None
     x, lab = synthetic(1, args.classes, args.size, dev, 2023 + rank)
 
@@ -119,7 +123,27 @@ def main():
         opt.step()
         return loss
 
+    eager_step = step
     for _ in range(args.warmup):
+        step()
+    if use_graph:
+        # launch-bound inner loop -> one hipGraph: every kernel of fwd+loss+bwd+AdamW is captured once
+        # (all launches go to the capturing stream; buffers come from the graph's private pool).
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph, stream=side):
+                static_loss = eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+
+        def step():
+            graph.replay()
+            return static_loss
         step()
     if world > 1:
         dist.barrier()
@@ -146,6 +170,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"3D UNet ResBasicBlock (amos_ct/resunet_3d.yaml), 1x1x{args.size}^3 per GPU, "
                                f"{args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
+                               + (" (hipGraph replay)" if use_graph else "")
                                + (", bucketed grad all-reduce (RCCL)" if world > 1 else ""),
                    "global_batch": world, "parallelism": f"dp{world}", "final_loss": loss_val},
     }
@@ -156,7 +181,7 @@ def main():
         reps = 3
         for _ in range(reps):
             ops.PROFILE = []
-            step()
+            eager_step()
             torch.cuda.synchronize()
             for name, flops, e0, e1, shape in ops.PROFILE:
                 d = per.setdefault(name, [0.0, 0.0, 0])
