@@ -34,6 +34,18 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16x2 (RNE): one v_cvt_pk_bf16_f32 on gfx950 (no builtin; the bit-twiddling
+// form costs ~16 VALU per pair and made the conv staging/epilogue VALU-bound)
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+#ifdef CBIM_EMU
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+#else
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+#endif
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   typedef float type;
@@ -65,14 +77,14 @@ template <> struct Elem<bf16_tag> {
   }
   static __device__ __forceinline__ u32x4 pack(const float* f) {
     u32x4 v;
-    v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-    v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-    v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-    v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    v.x = pk_bf16(f[0], f[1]);
+    v.y = pk_bf16(f[2], f[3]);
+    v.z = pk_bf16(f[4], f[5]);
+    v.w = pk_bf16(f[6], f[7]);
     return v;
   }
   static __device__ __forceinline__ float load1(const void* p, size_t i) { return bf2f(((const bf16_t*)p)[i]); }
-  static __device__ __forceinline__ void store1(void* p, size_t i, float v) { ((bf16_t*)p)[i] = f2bf(v); }
+  static __device__ __forceinline__ void store1(void* p, size_t i, float v) { ((bf16_t*)p)[i] = (bf16_t)pk_bf16(v, 0.f); }
   static __device__ __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
 };
 

@@ -2,19 +2,21 @@
 // cores, written for gfx950 (wave64, v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32).
 //
 //   GEMM view:  M = output voxels, N = Cout, K = taps x Cin.
-//   Workgroup:  256 threads = 4 waves; output tile = tD x tH x 8 voxels (BM = 128*MT) x BN = 32*NTL
-//               couts; wave w owns m-tiles [w*MT, w*MT+MT) (32 voxels = 4 rows x 8 in W) and all NTL
-//               n-tiles, i.e. MT*NTL accumulators of 16 VGPRs.  LDS <= 75 KiB -> 2 workgroups per CU
-//               (2 waves per SIMD): one workgroup's staging overlaps the other's MFMA phase.
-//   K loop:     Cin in chunks of 64 BYTES per voxel (32 bf16 / 16 f32 channels).  Per chunk the
-//               (tD+kD-1)(tH+kH-1)(8+kW-1) input halo is staged ONCE into LDS — InstanceNorm +
-//               activation of the producer are applied on that load (pre-activation ConvNormAct,
-//               /root/reference/model/dim3/conv_layers.py:48-49; literal zeros for the padding) —
-//               and re-used by all taps; the weights are staged one kd-plane (kH*kW taps) at a time
-//               in MFMA B-fragment order (a contiguous block copy from the pre-packed buffer).
-//   Inner loop: one tap per step, fragments of the NEXT tap are fetched (ds_read_b128) into a second
-//               register set before the MFMAs of the current tap issue (software pipelining by hand:
-//               with 1-2 waves per SIMD nothing else hides the LDS latency).
+//   Workgroup:  512 threads = 8 waves (2 per SIMD), PERSISTENT: one workgroup per CU walks a
+//               contiguous strip of output tiles (XCD-contiguous, so neighbouring halos hit the same
+//               L2).  Tile = tD x 8 x 8 voxels (BM = 256*MT) x BN = 32*NTL couts; wave w owns m-tiles
+//               [w*MT, w*MT+MT) (32 voxels = 4 rows x 8 in W) and all NTL n-tiles.
+//   K loop:     Cin in chunks of 64 BYTES per voxel (32 bf16 / 16 f32 channels); a "unit" is one
+//               (tile, chunk), a "stage" one kd-plane (kH*kW taps) of a unit.
+//   Pipeline:   * weights of stage s+1 stream into the other half of a double LDS buffer by LDS-DMA
+//                 (global_load_lds_dwordx4: pre-packed in MFMA B-fragment order, so the copy is
+//                 contiguous and needs no registers) while stage s computes;
+//               * the input halo of unit u+1 is loaded into registers during the last stage of unit
+//                 u and written to LDS — InstanceNorm + activation of the producer applied on the way
+//                 (pre-activation ConvNormAct, /root/reference/model/dim3/conv_layers.py:48-49; literal
+//                 zeros for the padding) — right after it;
+//               * inside a stage the fragments of tap t+1 are fetched (ds_read_b128) into a second
+//                 register set before the MFMAs of tap t issue.
 //   LDS layout: halo row = 64 B = four 16-B slots, slot index XOR (halo_row_h & 3): a 16-lane
 //               ds_read_b128 group (4 voxel rows x 4 voxels) then covers 16 distinct 16-B slots.
 //   Fragments:  one ds_read_b128 per operand per 16(bf16)/8(f32) channels; element order inside a
@@ -29,10 +31,12 @@
 
 namespace cbim {
 
-static constexpr int NT = 256;
+static constexpr int NT = 512;
+static constexpr int NW = NT / 64;
 static constexpr int RB = 64;       // bytes per halo row (one Cin chunk)
 static constexpr int SLOTS = RB / 16;
 static constexpr int KG = RB / 32;  // k-groups (two 16-B slots each) per chunk
+static constexpr int UH = 8;        // halo prefetch registers (16-B quads) per thread: covers 1024 rows
 
 struct IgemmParams {
   const void* x; int64_t x_stride;
@@ -85,29 +89,60 @@ template <int ACT> __device__ __forceinline__ float actg(float x, int rt) {
 #define CBIM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
-template <int MT, int NTL> struct Frags { u32x4 a[KG][MT]; u32x4 b[KG][NTL]; };
+// LDS-DMA: lane l copies 16 bytes from its own global address to (wave-uniform LDS base) + 16*l.
+__device__ __forceinline__ void dma16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
+#ifdef CBIM_EMU
+  emu_global_load_lds16(gsrc, lds_wave_base);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+// wave-level rendez-vous for LDS data exchanged between lanes of ONE wave (LDS executes a wave's
+// instructions in order; the compiler must not reorder across it)
+__device__ __forceinline__ void wave_sync() {
+#ifdef CBIM_EMU
+  int z = 0;
+  (void)cbim_emu::wave_exchange(&z, sizeof(z));
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+__device__ __forceinline__ void wait_vm0() {
+#ifndef CBIM_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+template <int MT, int NTL> struct Frags { u32x4 a[MT]; u32x4 b[NTL]; };   // one k-group of one tap
 
 template <typename T, int MT, int NTL, int ACT>
-__global__ void __launch_bounds__(NT, 2) k_conv_igemm(IgemmParams p) {
+__global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int KC = SLOTS * CPC;  // channels per chunk
   constexpr int BN = 32 * NTL;
   CBIM_DYN_SMEM(smem);
   const int hV = p.hD * p.hH * p.hW;
-  const unsigned a_bytes = (unsigned)hV * RB;           // B region starts here
-  const int ptaps = p.kH * p.kW;                        // taps per staged kd-plane
+  const int hHW = p.hH * p.hW;
+  const int ptaps = p.kH * p.kW;                        // taps per stage (one kd-plane)
   const unsigned tap_bytes = KG * 2 * BN * 16;
-  const unsigned plane_bytes = (unsigned)ptaps * tap_bytes;
+  const unsigned stage_bytes = (unsigned)ptaps * tap_bytes;
+  const unsigned a_bytes = (unsigned)hV * RB;
+  const unsigned b_base = a_bytes;                      // two stage buffers follow the halo
+  const unsigned red_base = a_bytes + 2 * stage_bytes;  // [NW*MT][BN][3] floats
+  const unsigned st_base = red_base + (unsigned)(NW * BN * 3) * 4;   // [KC][2] floats: (mean, rstd) of the staged chunk
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
-  const int n = bid / tiles_per_n, t = bid % tiles_per_n;
-  const int od0 = (t / (p.tiles_w * p.tiles_h)) * p.tD;
-  const int oh0 = ((t / p.tiles_w) % p.tiles_h) * p.tH;
-  const int ow0 = (t % p.tiles_w) * 8;
-  const int id0 = od0 - p.pD, ih0 = oh0 - p.pH, iw0 = ow0 - p.pW;
+  const int n_tiles = p.N * tiles_per_n;
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int t_begin = (int)(((long long)lb * n_tiles) / gridDim.x);
+  const int t_end = (int)(((long long)(lb + 1) * n_tiles) / gridDim.x);
   const int nb = blockIdx.y, co0 = nb * BN;
+  if (t_begin >= t_end) return;
+  const int n_units = (t_end - t_begin) * p.n_chunks;
 
   unsigned a_off[MT];   // LDS byte offset of the lane's voxel row at tap (0,0,0)
   int thr[MT];
@@ -118,7 +153,7 @@ __global__ void __launch_bounds__(NT, 2) k_conv_igemm(IgemmParams p) {
     a_off[mt] = (unsigned)((td * p.hH + th) * p.hW + tw) * RB;
     thr[mt] = th;
   }
-  const unsigned b_lane = a_bytes + (unsigned)(half * BN + li) * 16;
+  const unsigned b_lane = (unsigned)(half * BN + li) * 16;
   f32x16 acc[MT][NTL];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -128,202 +163,289 @@ __global__ void __launch_bounds__(NT, 2) k_conv_igemm(IgemmParams p) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const int my_slot = tid & (SLOTS - 1);  // NT % SLOTS == 0: a thread always stages the same slot
-  const size_t nbase_in = (size_t)n * p.Di * p.Hi * p.Wi;
-  const int hHW = p.hH * p.hW;
 
-  // fragment fetch of one tap (kh, kw inside the staged plane; kd folded into a_plane)
-  auto fetch = [&](Frags<MT, NTL>& f, int tp, int kh, int kw, unsigned a_plane) {
-    const unsigned toff = a_plane + (unsigned)(kh * p.hW + kw) * RB;
+  // ---- weight stage s -> LDS buffer (s & 1) by LDS-DMA ------------------------------------------------
+  auto dma_stage = [&](int unit, int kd, int buf) {
+    const int q = unit % p.n_chunks;
+    const unsigned char* src = (const unsigned char*)p.w +
+        ((size_t)nb * p.n_chunks + q) * ((size_t)p.kD * stage_bytes) + (size_t)kd * stage_bytes;
+    unsigned char* dst = smem + b_base + (unsigned)buf * stage_bytes;
+    for (unsigned o = (unsigned)wave * 1024; o < stage_bytes; o += NW * 1024)
+      dma16(src + o + lane * 16, dst + o);
+  };
+
+  // ---- halo of a unit: issue loads into registers / write them (transformed) to LDS --------------------
+  // The (mean, rstd) pairs of the unit's chunk travel through 2 registers of the first KC threads and
+  // a 256-byte LDS table (written before the stage-end barrier, read by halo_store after it).
+  u32x4 hreg[UH];
+  unsigned hld = 0;
+  float sreg0 = 0.f, sreg1 = 1.f;
+  int h_id0 = 0, h_ih0 = 0, h_iw0 = 0;
+  auto halo_load = [&](int unit) {
+    const int t = t_begin + unit / p.n_chunks, q = unit % p.n_chunks;
+    const int n = t / tiles_per_n, tt = t % tiles_per_n;
+    h_id0 = (tt / (p.tiles_w * p.tiles_h)) * p.tD - p.pD;
+    h_ih0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH - p.pH;
+    h_iw0 = (tt % p.tiles_w) * 8 - p.pW;
+    const int c0 = q * KC + my_slot * CPC;
+    const bool c_ok = c0 < p.Cin;
+    const size_t nbase_in = (size_t)n * p.Di * p.Hi * p.Wi;
+    if (p.in_stats && tid < KC && q * KC + tid < p.Cin) {
+      sreg0 = p.in_stats[((size_t)n * p.Cin + q * KC + tid) * 2];
+      sreg1 = p.in_stats[((size_t)n * p.Cin + q * KC + tid) * 2 + 1];
+    }
+    hld = 0;
+    const int a_items = hV * SLOTS;
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-#pragma unroll
-      for (int nt = 0; nt < NTL; ++nt)
-        f.b[kg][nt] = *(const u32x4*)(smem + b_lane + (unsigned)tp * tap_bytes + (unsigned)(kg * 2 * BN + nt * 32) * 16);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        unsigned slot = (unsigned)((2 * kg + half) ^ ((thr[mt] + kh) & (SLOTS - 1)));
-        f.a[kg][mt] = *(const u32x4*)(smem + a_off[mt] + toff + (slot << 4));
+    for (int u = 0; u < UH; ++u) {
+      int item = tid + u * NT;
+      unsigned hv = (unsigned)item / SLOTS;
+      unsigned hd = (hv * p.mHW) >> 20;
+      unsigned r2 = hv - hd * hHW;
+      unsigned hh = (r2 * p.mW) >> 20;
+      unsigned hw = r2 - hh * p.hW;
+      int id = h_id0 + (int)hd, ih = h_ih0 + (int)hh, iw = h_iw0 + (int)hw;
+      bool ld = item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+      hreg[u] = u32x4{0u, 0u, 0u, 0u};
+      if (ld) {
+        size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
+        hreg[u] = ld_chunk<T>(p.x, row * p.x_stride + c0);
+        hld |= 1u << u;
       }
     }
   };
-  auto mma = [&](const Frags<MT, NTL>& f) {
+  auto stats_publish = [&]() {   // before a barrier that precedes halo_store
+    if (p.in_stats && tid < KC) {
+      float* st = (float*)(smem + st_base);
+      st[tid * 2] = sreg0;
+      st[tid * 2 + 1] = sreg1;
+    }
+  };
+  auto halo_store = [&]() {
+    const float* st = (const float*)(smem + st_base) + my_slot * CPC * 2;
+    const int a_items = hV * SLOTS;
+#pragma unroll
+    for (int u = 0; u < UH; ++u) {
+      int item = tid + u * NT;
+      if (item < a_items) {
+        unsigned hv = (unsigned)item / SLOTS;
+        unsigned hd = (hv * p.mHW) >> 20;
+        unsigned r2 = hv - hd * hHW;
+        unsigned hh = (r2 * p.mW) >> 20;
+        u32x4 w = hreg[u];
+        if (p.in_stats && ((hld >> u) & 1u)) {
+          float f[CPC];
+          Elem<T>::unpack(w, f);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) f[j] = actf<ACT>((f[j] - st[2 * j]) * st[2 * j + 1], p.act);
+          w = Elem<T>::pack(f);
+        }
+        *(u32x4*)(smem + hv * RB + ((my_slot ^ (hh & (SLOTS - 1))) << 4)) = w;
+      }
+    }
+  };
+
+  // ---- fragment fetch of one k-group of one tap.  The XOR-swizzled slot offset of a lane depends on kh
+  //      only through (th+kh)&3, so it is kept in registers (sl[kg][mt]) and refreshed when kh advances:
+  //      one v_add3 per ds_read in the steady state -------------------------------------------------------
+  unsigned sl[KG][MT];
+  auto set_kh = [&](int kh) {
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
+        sl[kg][mt] = (unsigned)((2 * kg + half) ^ ((thr[mt] + kh) & (SLOTS - 1))) << 4;
+  };
+  auto fetch = [&](Frags<MT, NTL>& f, int tp, int kg, unsigned toff, unsigned b_buf) {
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) Mma<T>::run(f.a[kg][mt], f.b[kg][nt], acc[mt][nt]);
+    for (int nt = 0; nt < NTL; ++nt)
+      f.b[nt] = *(const u32x4*)(smem + b_buf + b_lane + (unsigned)tp * tap_bytes + (unsigned)(kg * 2 * BN + nt * 32) * 16);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      f.a[mt] = *(const u32x4*)(smem + a_off[mt] + toff + sl[kg][mt]);
+  };
+  auto mma = [&](const Frags<MT, NTL>& f) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) Mma<T>::run(f.a[mt], f.b[nt], acc[mt][nt]);
   };
 
-  for (int q = 0; q < p.n_chunks; ++q) {
-    __syncthreads();  // previous chunk's fragments are consumed
-    // ---- stage the input halo (with fused InstanceNorm + activation of the producer) --------------
-    // loads are issued in batches (UA independent 16-byte loads in flight per thread) before any is
-    // consumed; (hd,hh,hw) decode by multiply-shift, no integer division.
-    {
-      const int c0 = q * KC + my_slot * CPC;
-      const bool c_ok = c0 < p.Cin;
-      float mean[CPC], rstd[CPC];
-      if (p.in_stats && c_ok) {
-#pragma unroll
-        for (int j = 0; j < CPC; ++j) {
-          mean[j] = p.in_stats[((size_t)n * p.Cin + c0 + j) * 2];
-          rstd[j] = p.in_stats[((size_t)n * p.Cin + c0 + j) * 2 + 1];
-        }
-      }
-      constexpr int UA = 5;
-      const int a_items = hV * SLOTS;
-      for (int base = tid; base < a_items; base += NT * UA) {
-        u32x4 v[UA];
-        int dst[UA];
-        bool ld[UA];
-#pragma unroll
-        for (int u = 0; u < UA; ++u) {
-          int item = base + u * NT;
-          unsigned hv = (unsigned)item / SLOTS;
-          unsigned hd = (hv * p.mHW) >> 20;
-          unsigned r2 = hv - hd * hHW;
-          unsigned hh = (r2 * p.mW) >> 20;
-          unsigned hw = r2 - hh * p.hW;
-          int id = id0 + (int)hd, ih = ih0 + (int)hh, iw = iw0 + (int)hw;
-          dst[u] = item < a_items ? (int)(hv * RB + ((my_slot ^ (hh & (SLOTS - 1))) << 4)) : -1;
-          ld[u] = item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
-          v[u] = u32x4{0u, 0u, 0u, 0u};
-          if (ld[u]) {
-            size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
-            v[u] = ld_chunk<T>(p.x, row * p.x_stride + c0);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < UA; ++u) {
-          if (dst[u] >= 0) {
-            u32x4 w = v[u];
-            if (p.in_stats && ld[u]) {
-              float f[CPC];
-              Elem<T>::unpack(w, f);
-#pragma unroll
-              for (int j = 0; j < CPC; ++j) f[j] = actf<ACT>((f[j] - mean[j]) * rstd[j], p.act);
-              w = Elem<T>::pack(f);
-            }
-            *(u32x4*)(smem + dst[u]) = w;
-          }
-        }
-      }
-    }
-    const unsigned char* wq = (const unsigned char*)p.w + ((size_t)nb * p.n_chunks + q) * ((size_t)p.kD * plane_bytes);
-    for (int kd = 0; kd < p.kD; ++kd) {
-      if (kd > 0) __syncthreads();  // the previous plane's weights are consumed
-      // ---- stage this kd-plane's weights (already in fragment order): contiguous block copy ------------
-      {
-        constexpr int UB = 5;
-        const unsigned char* wsrc = wq + (size_t)kd * plane_bytes;
-        for (unsigned ob = (unsigned)tid * 16; ob < plane_bytes; ob += NT * 16 * UB) {
-          u32x4 v[UB];
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            unsigned o = ob + (unsigned)u * NT * 16;
-            if (o < plane_bytes) v[u] = *(const u32x4*)(wsrc + o);
-          }
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            unsigned o = ob + (unsigned)u * NT * 16;
-            if (o < plane_bytes) *(u32x4*)(smem + a_bytes + o) = v[u];
-          }
-        }
-      }
-      __syncthreads();
-      // ---- the plane's taps, two per trip through statically named register sets ----------------------
-      const unsigned a_plane = (unsigned)(kd * hHW) * RB;
-      Frags<MT, NTL> f0, f1;
-      int kh = 0, kw = 0;   // (kh, kw) of the NEXT tap to fetch
-      fetch(f0, 0, 0, 0, a_plane);
-      if (++kw == p.kW) { kw = 0; ++kh; }
-      for (int tp = 0; tp < ptaps; tp += 2) {
-        if (tp + 1 < ptaps) {
-          fetch(f1, tp + 1, kh, kw, a_plane);
-          if (++kw == p.kW) { kw = 0; ++kh; }
-        }
-        mma(f0);
-        if (tp + 2 < ptaps) {
-          fetch(f0, tp + 2, kh, kw, a_plane);
-          if (++kw == p.kW) { kw = 0; ++kh; }
-        }
-        if (tp + 1 < ptaps) mma(f1);
-      }
-    }
-  }
-
-  // ---- epilogue --------------------------------------------------------------------------------------
+  // ---- prologue: first unit's halo and first stage of weights -----------------------------------------
+  dma_stage(0, 0, 0);
+  halo_load(0);
+  stats_publish();
   __syncthreads();
-  float* red = (float*)smem;  // [4 waves * MT][BN][3]
-  const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
-#pragma unroll
-  for (int nt = 0; nt < NTL; ++nt) {
-    const int co = co0 + nt * 32 + li;
-    const bool co_ok = co < p.Cout;
-    float mmean = 0.f, mrstd = 1.f;
-    if (p.mx && co_ok) {
-      mmean = p.m_stats[((size_t)n * p.Cout + co) * 2];
-      mrstd = p.m_stats[((size_t)n * p.Cout + co) * 2 + 1];
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      // forward: shifted sums -> (count, mean, M2); dgrad: plain (sum g, sum g*xh)
-      float s0 = 0.f, s1 = 0.f, cnt = 0.f, shift = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
-        int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-        if (co_ok && od < p.Do && oh < p.Ho && ow < p.Wo) {
-          size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
-          float v = acc[mt][nt][r];
-          if (p.res) v += Elem<T>::load1(p.res, row * p.res_stride + co);
-          if (p.mx) {
-            float xh = (Elem<T>::load1(p.mx, row * p.mx_stride + co) - mmean) * mrstd;
-            v *= actg<ACT>(xh, p.act);
-            s0 += v;
-            s1 += v * xh;
-          } else {
-            if (cnt == 0.f) shift = v;
-            float d = v - shift;
-            s0 += d;
-            s1 += d * d;
+  halo_store();
+  wait_vm0();
+  __syncthreads();
+
+  int stage = 0;
+  for (int unit = 0; unit < n_units; ++unit) {
+    const int t = t_begin + unit / p.n_chunks, q = unit % p.n_chunks;
+    for (int kd = 0; kd < p.kD; ++kd, ++stage) {
+      const bool last_plane = kd == p.kD - 1;
+      // ---- start the next stage's weight DMA (and the next unit's halo loads) before computing -------------
+      if (!last_plane) dma_stage(unit, kd + 1, (stage + 1) & 1);
+      else if (unit + 1 < n_units) {
+        dma_stage(unit + 1, 0, (stage + 1) & 1);
+        halo_load(unit + 1);
+      }
+      // ---- the plane's taps; the two k-groups of a tap alternate between two statically named register
+      //      sets, each fetched one step ahead of its MFMAs; branch-free (the fetch after the last tap reads
+      //      a few rows past the plane inside the LDS allocation and is never used) --------------------------
+      {
+        const unsigned a_plane = (unsigned)(kd * hHW) * RB;
+        const unsigned b_buf = b_base + (unsigned)(stage & 1) * stage_bytes;
+        Frags<MT, NTL> f0, f1;
+        int kh = 0, kw = 0;
+        unsigned toff = a_plane;
+        set_kh(0);
+        fetch(f0, 0, 0, toff, b_buf);
+        for (int tp = 0; tp < ptaps; ++tp) {
+          fetch(f1, tp, 1, toff, b_buf);
+          mma(f0);
+          ++kw;
+          toff += RB;
+          if (kw == p.kW) {   // wave-uniform
+            kw = 0;
+            ++kh;
+            toff += (unsigned)(p.hW - p.kW) * RB;
+            set_kh(kh);
           }
-          cnt += 1.f;
-          Elem<T>::store1(p.y, row * p.y_stride + co, v);
+          fetch(f0, tp + 1, 0, toff, b_buf);
+          mma(f1);
         }
       }
-      if (p.partials) {
-        Moments a;
-        if (p.mx) { a.n = 0.f; a.mean = s0; a.m2 = s1; }
-        else a = moments_from_shifted(cnt, shift, s0, s1);
-        Moments b;
-        b.n = __shfl_xor(a.n, 32, 64);
-        b.mean = __shfl_xor(a.mean, 32, 64);
-        b.m2 = __shfl_xor(a.m2, 32, 64);
-        if (half == 0) {
-          if (p.mx) { a.mean += b.mean; a.m2 += b.m2; }
-          else a = moments_merge(a, b);
-          float* rr = red + (((wave * MT + mt) * BN) + nt * 32 + li) * 3;
-          rr[0] = a.n; rr[1] = a.mean; rr[2] = a.m2;
+      // ---- stage end -------------------------------------------------------------------------------------------
+      const bool tile_done = last_plane && q == p.n_chunks - 1;
+      if (last_plane && unit + 1 < n_units) stats_publish();
+      wait_vm0();        // this wave's LDS-DMA (next stage's weights) has landed
+      __syncthreads();   // every wave is done with this stage's A/B reads
+      if (tile_done) {
+        // ---- epilogue: each wave transposes its own 32x32 accumulator tiles through a private 4 KiB LDS
+        //      scratch (inside the now dead halo region) so that residual / mask loads and the output
+        //      stores are whole 16-byte channel chunks; no workgroup barrier inside -----------------------------
+        constexpr int OCH = 32 / CPC;            // 16-byte chunks per 32-cout row
+        constexpr int IT = 32 * OCH / 64;        // chunk items per lane per 32x32 tile
+        const int n = t / tiles_per_n, tt = t % tiles_per_n;
+        const int od0 = (tt / (p.tiles_w * p.tiles_h)) * p.tD;
+        const int oh0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH;
+        const int ow0 = (tt % p.tiles_w) * 8;
+        const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
+        float* scr = (float*)(smem + (unsigned)wave * 4096);
+        float* red = (float*)(smem + red_base);
+        const int cc = lane % OCH;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+          const int cch0 = co0 + nt * 32 + cc * CPC;     // first channel of the lane's chunk
+          const bool c_ok = cch0 < p.Cout;
+          float mm[CPC], mr[CPC], s0[CPC], s1[CPC], sh[CPC];
+          float cnt = 0.f;
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) { mm[j] = 0.f; mr[j] = 1.f; s0[j] = 0.f; s1[j] = 0.f; sh[j] = 0.f; }
+          if (p.mx && c_ok) {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) {
+              mm[j] = p.m_stats[((size_t)n * p.Cout + cch0 + j) * 2];
+              mr[j] = p.m_stats[((size_t)n * p.Cout + cch0 + j) * 2 + 1];
+            }
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            wave_sync();   // the previous tile's scratch reads are done
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              scr[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[mt][nt][r];
+              acc[mt][nt][r] = 0.f;
+            }
+            wave_sync();
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+              const int vr = (lane + 64 * it) / OCH;                 // voxel row inside the 32-voxel m-tile
+              const int m = (wave * MT + mt) * 32 + vr;
+              const int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
+              const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+              float v[CPC];
+#pragma unroll
+              for (int j4 = 0; j4 < CPC; j4 += 4) {
+                f32x4 q4 = *(const f32x4*)(scr + vr * 32 + cc * CPC + j4);
+                v[j4] = q4.x; v[j4 + 1] = q4.y; v[j4 + 2] = q4.z; v[j4 + 3] = q4.w;
+              }
+              if (mt == 0 && it == 0 && !p.mx) {
+                // common shift per channel for the whole wave: the value lane `cc` holds for its first
+                // voxel (any finite value near the data works; shifted sums then simply add across lanes)
+#pragma unroll
+                for (int j = 0; j < CPC; ++j) sh[j] = __shfl(v[j], cc, 64);
+              }
+              if (c_ok && od < p.Do && oh < p.Ho && ow < p.Wo) {
+                const size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+                if (p.res) {
+                  float f[CPC];
+                  Elem<T>::unpack(ld_chunk<T>(p.res, row * p.res_stride + cch0), f);
+#pragma unroll
+                  for (int j = 0; j < CPC; ++j) v[j] += f[j];
+                }
+                if (p.mx) {
+                  float f[CPC];
+                  Elem<T>::unpack(ld_chunk<T>(p.mx, row * p.mx_stride + cch0), f);
+#pragma unroll
+                  for (int j = 0; j < CPC; ++j) {
+                    float xh = (f[j] - mm[j]) * mr[j];
+                    v[j] *= actg<ACT>(xh, p.act);
+                    s0[j] += v[j];
+                    s1[j] += v[j] * xh;
+                  }
+                } else {
+#pragma unroll
+                  for (int j = 0; j < CPC; ++j) { float d = v[j] - sh[j]; s0[j] += d; s1[j] += d * d; }
+                }
+                cnt += 1.f;
+                st_chunk<T>(p.y, row * p.y_stride + cch0, Elem<T>::pack(v));
+              }
+            }
+          }
+          if (p.partials) {
+            // lanes with the same channel chunk (lane % OCH) hold plain partial sums: xor-shuffle adds
+#pragma unroll
+            for (int msk = OCH; msk < 64; msk <<= 1) {
+              cnt += __shfl_xor(cnt, msk, 64);
+#pragma unroll
+              for (int j = 0; j < CPC; ++j) {
+                s0[j] += __shfl_xor(s0[j], msk, 64);
+                s1[j] += __shfl_xor(s1[j], msk, 64);
+              }
+            }
+            if (lane < OCH) {
+#pragma unroll
+              for (int j = 0; j < CPC; ++j) {
+                Moments a;
+                if (p.mx) { a.n = 0.f; a.mean = s0[j]; a.m2 = s1[j]; }
+                else a = moments_from_shifted(cnt, sh[j], s0[j], s1[j]);
+                float* rr = red + ((wave * BN) + nt * 32 + cc * CPC + j) * 3;
+                rr[0] = a.n; rr[1] = a.mean; rr[2] = a.m2;
+              }
+            }
+          }
+        }
+        __syncthreads();   // scratch reads are done (the halo may be overwritten); `red` is complete
+        if (p.partials && tid < BN && co0 + tid < p.Cout) {
+          Moments a = {0.f, 0.f, 0.f};
+          for (int g = 0; g < NW; ++g) {
+            const float* rr = red + (g * BN + tid) * 3;
+            if (p.mx) { a.mean += rr[1]; a.m2 += rr[2]; }
+            else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
+          }
+          size_t o = (((size_t)n * tiles_per_n + tt) * p.Cout + co0 + tid) * 3;
+          p.partials[o] = a.n;
+          p.partials[o + 1] = a.mean;
+          p.partials[o + 2] = a.m2;
         }
       }
-    }
-  }
-  if (p.partials) {
-    __syncthreads();
-    if (tid < BN && co0 + tid < p.Cout) {
-      Moments a = {0.f, 0.f, 0.f};
-      for (int g = 0; g < 4 * MT; ++g) {
-        const float* rr = red + (g * BN + tid) * 3;
-        if (p.mx) { a.mean += rr[1]; a.m2 += rr[2]; }
-        else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
+      if (last_plane && unit + 1 < n_units) {
+        halo_store();      // the next unit's halo replaces this one (nobody reads A any more)
+        __syncthreads();
       }
-      size_t o = (((size_t)n * tiles_per_n + t) * p.Cout + co0 + tid) * 3;
-      p.partials[o] = a.n;
-      p.partials[o + 1] = a.mean;
-      p.partials[o + 2] = a.m2;
     }
   }
 }
@@ -333,14 +455,14 @@ __global__ void __launch_bounds__(NT, 2) k_conv_igemm(IgemmParams p) {
 // mode 0: K = Cin, N = Cout, value w[cout][cin][tap]; mode 1 (dgrad): K = Cout_fwd, N = Cin_fwd,
 // value w[k_ch][n_ch][taps-1-tap]  (w is always the forward [Cout][Cin][taps] tensor).
 template <typename T>
-__global__ void __launch_bounds__(NT) k_pack_weights(const float* __restrict__ w, void* __restrict__ packed,
-                                                     int Cout_f, int Cin_f, int taps, int mode, int BN,
-                                                     int n_chunks, int64_t total) {
+__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, void* __restrict__ packed,
+                                                      int Cout_f, int Cin_f, int taps, int mode, int BN,
+                                                      int n_chunks, int64_t total) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int KC = SLOTS * CPC;
   const int Kdim = mode == 0 ? Cin_f : Cout_f;
   const int Ndim = mode == 0 ? Cout_f : Cin_f;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int64_t r = i;
     int j = (int)(r % CPC); r /= CPC;
     int nn = (int)(r % BN); r /= BN;
@@ -366,10 +488,10 @@ static TileCfg pick_cfg(const cbim_conv_desc* d) {
   TileCfg c;
   c.NTL = d->Cout <= 32 ? 1 : 2;
   int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
-  c.MT = (S >= 32768 && d->Do >= 4 && d->Ho >= 8) ? 2 : 1;
-  if (c.MT == 2) { c.tD = 4; c.tH = 8; c.lgH = 3; }
-  else if (d->Do <= 2) { c.tD = 2; c.tH = 8; c.lgH = 3; }
-  else { c.tD = 4; c.tH = 4; c.lgH = 2; }
+  // 8x8x8 tiles (BM = 512) when that still leaves >= 2 tiles per CU; otherwise 4x8x8 (BM = 256)
+  c.MT = (S >= 262144 && d->Do >= 8 && d->Ho >= 8) ? 2 : 1;
+  c.tH = 8; c.lgH = 3;
+  c.tD = c.MT == 2 ? 8 : 4;
   return c;
 }
 
@@ -385,7 +507,7 @@ static int validate(const cbim_conv_desc* d) {
   CBIM_CHECK(d->dtype == CBIM_F32 || d->dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", d->dtype);
   int cpc = d->dtype == CBIM_BF16 ? 8 : 4;
   CBIM_CHECK(d->Cin > 0 && d->Cin % cpc == 0, CBIM_EUNSUPPORTED, "conv Cin %d is not a multiple of %d", d->Cin, cpc);
-  CBIM_CHECK(d->Cout > 0, CBIM_EINVAL, "conv Cout %d", d->Cout);
+  CBIM_CHECK(d->Cout > 0 && d->Cout % cpc == 0, CBIM_EUNSUPPORTED, "conv Cout %d is not a multiple of %d", d->Cout, cpc);
   CBIM_CHECK(d->kD >= 1 && d->kH >= 1 && d->kW >= 1 && d->kD * d->kH * d->kW <= 64, CBIM_EUNSUPPORTED, "kernel extent unsupported");
   CBIM_CHECK(d->N >= 1 && d->Do >= 1 && d->Ho >= 1 && d->Wo >= 1, CBIM_EINVAL, "empty conv output");
   return 0;
@@ -412,14 +534,14 @@ extern "C" int cbim_conv3d_pack_weights(const cbim_conv_desc* d, int mode, const
   int n_chunks = (Kdim + KC - 1) / KC;
   int taps = d->kD * d->kH * d->kW;
   int64_t total = (int64_t)(cbim_conv3d_packed_bytes(d, mode) / elem_size(d->dtype));
-  int64_t blocks = (total + NT - 1) / NT;
+  int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_pack_weights<bf16_tag>), dim3((unsigned)blocks), dim3(NT), 0, st, w, packed, d->Cout, d->Cin,
+    CBIM_LAUNCH((k_pack_weights<bf16_tag>), dim3((unsigned)blocks), dim3(256), 0, st, w, packed, d->Cout, d->Cin,
                 taps, mode, BN, n_chunks, total);
   else
-    CBIM_LAUNCH((k_pack_weights<float>), dim3((unsigned)blocks), dim3(NT), 0, st, w, packed, d->Cout, d->Cin, taps,
+    CBIM_LAUNCH((k_pack_weights<float>), dim3((unsigned)blocks), dim3(256), 0, st, w, packed, d->Cout, d->Cin, taps,
                 mode, BN, n_chunks, total);
   return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
@@ -481,20 +603,23 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   p.tD = c.tD; p.tH = c.tH; p.lgH = c.lgH;
   p.tiles_d = (d->Do + c.tD - 1) / c.tD; p.tiles_h = (d->Ho + c.tH - 1) / c.tH; p.tiles_w = (d->Wo + 7) / 8;
   p.hD = c.tD + d->kD - 1; p.hH = c.tH + d->kH - 1; p.hW = 8 + d->kW - 1;
-  CBIM_CHECK(p.hD * p.hH * p.hW <= 2048, CBIM_EUNSUPPORTED, "halo too large");
+  CBIM_CHECK(p.hD * p.hH * p.hW * SLOTS <= UH * NT, CBIM_EUNSUPPORTED, "halo of %d rows too large", p.hD * p.hH * p.hW);
   p.mHW = ((1u << 20) + (unsigned)(p.hH * p.hW) - 1) / (unsigned)(p.hH * p.hW);
   p.mW = ((1u << 20) + (unsigned)p.hW - 1) / (unsigned)p.hW;
   int KC = kc_of(d->dtype);
   p.n_chunks = (d->Cin + KC - 1) / KC;
   p.taps = d->kD * d->kH * d->kW;
   int BN = 32 * c.NTL;
-  size_t smem = (size_t)p.hD * p.hH * p.hW * RB + (size_t)d->kH * d->kW * KG * 2 * BN * 16;
-  size_t red = (size_t)4 * c.MT * BN * 3 * sizeof(float);
-  if (smem < red) smem = red;
+  size_t smem = (size_t)p.hD * p.hH * p.hW * RB + 2 * (size_t)d->kH * d->kW * KG * 2 * BN * 16 +
+                (size_t)NW * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float);
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "conv tile needs %zu B of LDS", smem);
-  int64_t nblk = (int64_t)d->N * p.tiles_d * p.tiles_h * p.tiles_w;
-  CBIM_CHECK(nblk < (1ll << 31), CBIM_EUNSUPPORTED, "too many tiles");
-  dim3 grid((unsigned)nblk, (unsigned)((d->Cout + BN - 1) / BN));
+  int64_t n_tiles = (int64_t)d->N * p.tiles_d * p.tiles_h * p.tiles_w;
+  int n_nblk = (d->Cout + BN - 1) / BN;
+  // persistent grid: about one workgroup per CU (256 CUs), never more workgroups than tiles
+  int64_t G = 256 / n_nblk;
+  if (G < 1) G = 1;
+  if (G > n_tiles) G = n_tiles;
+  dim3 grid((unsigned)G, (unsigned)n_nblk);
   hipStream_t st = (hipStream_t)stream;
   const bool relu = d->act == CBIM_ACT_RELU;
   if (d->dtype == CBIM_BF16)

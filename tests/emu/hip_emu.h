@@ -181,5 +181,15 @@ inline void emu_ds_read_tr16_b64(const void* my_addr, unsigned short out[4]) {
   for (int j = 0; j < 4; ++j) out[j] = buf[g + j * 4 + (i >> 2)].v[i & 3];
 }
 
+// global_load_lds_dwordx4 model: the LDS destination is WAVE-UNIFORM base (M0, taken from the first
+// lane) + lane*16; the global source address is per lane.  The data "lands" immediately here; on
+// silicon it is only ordered by vmcnt + a barrier (the kernels wait before reading).
+inline void emu_global_load_lds16(const void* gsrc, void* lds_wave_base) {
+  struct P { void* base; } mine = {lds_wave_base};
+  const P* buf = (const P*)cbim_emu::wave_exchange(&mine, sizeof(P));
+  int l = CBIM_EMU_LANE_ID();
+  memcpy((unsigned char*)buf[0].base + (size_t)l * 16, gsrc, 16);
+}
+
 #define CBIM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   cbim_emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
