@@ -77,13 +77,19 @@ __global__ void __launch_bounds__(NT) k_dice_ce_fwd(const float* __restrict__ z,
 __global__ void __launch_bounds__(NT) k_dice_ce_finalize(const float* __restrict__ partials, int nblk, int C,
                                                          float* __restrict__ out, float* __restrict__ coef) {
   __shared__ double tot[3 * CMAX + 2];
+  __shared__ double part[4][3 * CMAX + 2];
   __shared__ double dice_term[CMAX];
   const int nv = 3 * C + 2;
-  for (int i = threadIdx.x; i < nv; i += NT) {
-    double a = 0.0;
-    for (int b = 0; b < nblk; ++b) a += (double)partials[(size_t)b * nv + i];
-    tot[i] = a;
+  {   // 4 thread groups stride over the workgroup partials (independent loads in flight), fixed-order merge
+    const int li = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    for (int i = li; i < nv; i += 64) {
+      double a = 0.0;
+      for (int b = pg; b < nblk; b += 4) a += (double)partials[(size_t)b * nv + i];
+      part[pg][i] = a;
+    }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nv; i += NT) tot[i] = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
   __syncthreads();
   if ((int)threadIdx.x < C) {
     int c = threadIdx.x;
@@ -168,7 +174,7 @@ __global__ void __launch_bounds__(NT) k_dice_ce_bwd(const float* __restrict__ z,
 
 static int loss_blocks(int64_t total) {
   int64_t b = (total + NT * 8 - 1) / (NT * 8);
-  if (b > 1024) b = 1024;
+  if (b > 1024) b = 1024;   // the finalize kernel walks these partials with 4 thread groups
   if (b < 1) b = 1;
   return (int)b;
 }

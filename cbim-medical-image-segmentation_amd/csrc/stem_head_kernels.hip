@@ -79,15 +79,16 @@ __global__ void __launch_bounds__(NT) k_stem_fwd(StemParams p) {
   }
 }
 
-// dw[co][ci][tap] = sum_v dy[v][co] * x[v+tap-p][ci]; thread = (co lane, voxel group); strip of tiles
-// per workgroup; per-strip slab [Cin][taps][Cout] then a fixed-order reduce.
+// dw[co][ci][tap] = sum_v dy[v][co] * x[v+tap-p][ci]; thread = (co lane, row group); a thread walks whole
+// 8-voxel W rows so each halo value it reads from LDS feeds up to kW FMAs (LDS reads per FMA ~0.4);
+// strip of tiles per workgroup; per-strip slab [Cin][taps][Cout] then a fixed-order reduce.
 template <typename T>
 __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
   CBIM_DYN_SMEM(smem);
   const int hV = p.hD * p.hH * p.hW;
   float* xL = (float*)smem;                           // [hV]
-  float* red = xL + hV;                               // [NT/32 groups][MAXTAPS][32]
-  const int tid = threadIdx.x, col = tid & 31, vg = tid >> 5;   // 8 voxel groups
+  float* red = xL + ((hV + 3) & ~3);                  // [NT/32 groups][MAXTAPS][32]
+  const int tid = threadIdx.x, col = tid & 31, vg = tid >> 5;   // 8 row groups
   const int n = blockIdx.x / p.strips_per_n, strip = blockIdx.x % p.strips_per_n;
   const int cob = blockIdx.y;   // block of 32 couts
   const int co = cob * 32 + col;
@@ -97,12 +98,6 @@ __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
   if (t_end > tiles_per_n) t_end = tiles_per_n;
   const size_t Sin = (size_t)p.Di * p.Hi * p.Wi;
   const size_t slab = (size_t)p.Cin * p.taps * p.Cout;
-  __shared__ int toff[MAXTAPS];
-  if (tid < MAXTAPS) {
-    int k = tid < p.taps ? tid : 0;
-    int kw = k % p.kW, r = k / p.kW, kh = r % p.kH, kd = r / p.kH;
-    toff[tid] = (kd * p.hH + kh) * p.hW + kw;
-  }
   for (int ci = 0; ci < p.Cin; ++ci) {
     float acc[MAXTAPS];
 #pragma unroll
@@ -119,16 +114,40 @@ __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
         xL[hv] = v;
       }
       __syncthreads();
-      for (int m = vg; m < 256; m += 8) {
-        int tw = m & 7, th = (m >> 3) & 7, td = m >> 6;
-        int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-        if (co < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo) {
-          size_t row = (size_t)n * p.Do * p.Ho * p.Wo + ((size_t)od * p.Ho + oh) * p.Wo + ow;
-          float g = Elem<T>::load1(p.dy, row * p.Cout + co);
-          int hv0 = (td * p.hH + th) * p.hW + tw;
+      for (int rowi = vg; rowi < 32; rowi += 8) {      // rows (td, th) of the 4x8x8 tile
+        const int td = rowi >> 3, th = rowi & 7;
+        const int od = od0 + td, oh = oh0 + th;
+        float g[8];
 #pragma unroll
-          for (int k = 0; k < MAXTAPS; ++k) {
-            if (k < p.taps) acc[k] = fmaf(g, xL[hv0 + toff[k]], acc[k]);
+        for (int w8 = 0; w8 < 8; ++w8) {
+          g[w8] = 0.f;
+          if (co < p.Cout && od < p.Do && oh < p.Ho && ow0 + w8 < p.Wo) {
+            size_t row = (size_t)n * p.Do * p.Ho * p.Wo + ((size_t)od * p.Ho + oh) * p.Wo + ow0 + w8;
+            g[w8] = Elem<T>::load1(p.dy, row * p.Cout + co);
+          }
+        }
+        // static 3x3x3 tap lattice (extents <= 3 per axis, guarded): accumulator indices stay compile-time
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+          if (kd < p.kD) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              if (kh < p.kH) {
+                const float* xr = xL + ((td + kd) * p.hH + th + kh) * p.hW;
+                float xv[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) xv[i] = i < 8 + p.kW - 1 ? xr[i] : 0.f;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                  if (kw < p.kW) {
+                    float a = acc[(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; ++w8) a = fmaf(g[w8], xv[w8 + kw], a);
+                    acc[(kd * 3 + kh) * 3 + kw] = a;
+                  }
+                }
+              }
+            }
           }
         }
       }
@@ -152,9 +171,16 @@ __global__ void __launch_bounds__(NT) k_stem_wgrad_reduce(const float* __restric
   for (int i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
     int co = i % Cout, r = i / Cout;
     int k = r % taps, ci = r / taps;
-    float a = 0.f;
-    for (int s = 0; s < n_slabs; ++s) a += ws[(size_t)s * total + i];
-    dw[((size_t)co * Cin + ci) * taps + k] = a;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < n_slabs; s += 4) {
+      a0 += ws[(size_t)s * total + i];
+      a1 += ws[(size_t)(s + 1) * total + i];
+      a2 += ws[(size_t)(s + 2) * total + i];
+      a3 += ws[(size_t)(s + 3) * total + i];
+    }
+    for (; s < n_slabs; ++s) a0 += ws[(size_t)s * total + i];
+    dw[((size_t)co * Cin + ci) * taps + k] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -178,15 +204,25 @@ __global__ void __launch_bounds__(NT) k_head_fwd(const void* __restrict__ x, con
       float out[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) out[k] = (k0 + k < K) ? b[k0 + k] : 0.f;
-      for (int c0 = 0; c0 < Cin; c0 += CPC) {
-        float f[CPC];
-        Elem<T>::unpack(ld_chunk<T>(x, (size_t)r * Cin + c0), f);
+      for (int cb = 0; cb < Cin; cb += 8 * CPC) {   // 8 chunk loads in flight before any is used
+        u32x4 raw[8];
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) {
-          const float* wr = wL + (size_t)(c0 + j) * K + k0;
+        for (int u = 0; u < 8; ++u)
+          if (cb + u * CPC < Cin) raw[u] = ld_chunk<T>(x, (size_t)r * Cin + cb + u * CPC);
 #pragma unroll
-          for (int k = 0; k < KMAX; ++k)
-            if (k0 + k < K) out[k] = fmaf(f[j], wr[k], out[k]);
+        for (int u = 0; u < 8; ++u) {
+          const int c0 = cb + u * CPC;
+          if (c0 < Cin) {
+            float f[CPC];
+            Elem<T>::unpack(raw[u], f);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) {
+              const float* wr = wL + (size_t)(c0 + j) * K + k0;
+#pragma unroll
+              for (int k = 0; k < KMAX; ++k)
+                if (k0 + k < K) out[k] = fmaf(f[j], wr[k], out[k]);
+            }
+          }
         }
       }
       int64_t n = r / S, v = r % S;
@@ -223,56 +259,88 @@ __global__ void __launch_bounds__(NT) k_head_bwd_dx(const float* __restrict__ w,
   }
 }
 
-// dw[k][c] = sum_v dz[k][v] x[v][c], db[k] = sum_v dz[k][v]; workgroup = strip of voxels, 64-voxel LDS
-// tiles, thread owns up to PAIRS (k,c) pairs; slab per workgroup, fixed-order reduce.
+// dw[k][c] = sum_v dz[k][v] x[v][c], db[k] = sum_v dz[k][v] (bias = an extra all-ones column of x).
+// Workgroup = strip of voxels staged in 64-voxel LDS tiles ([v][c] and [v][k], rows padded to 16 B);
+// a thread owns a 4(k) x 4(c) block of the product and one of VG voxel phases: two ds_read_b128 feed
+// 16 FMAs.  Slab per workgroup, fixed-order reduce.
 static constexpr int HB_TILE = 64;
-static constexpr int HB_PAIRS = 8;
 template <typename T>
 __global__ void __launch_bounds__(NT) k_head_bwd_dw(const void* __restrict__ x, const float* __restrict__ dz,
                                                     float* __restrict__ ws, int64_t S, int Cin, int K,
                                                     int64_t vox_per_block) {
   CBIM_DYN_SMEM(smem);
-  float* xL = (float*)smem;               // [HB_TILE][Cin+1]
-  float* zL = xL + HB_TILE * (Cin + 1);   // [K][HB_TILE]
+  const int XS = (Cin + 1 + 3) & ~3, ZS = (K + 3) & ~3;
+  const int KB = ZS / 4, CB = XS / 4, PB = KB * CB, VG = NT / PB;   // host guarantees PB <= NT
+  float* xL = (float*)smem;               // [HB_TILE][XS]
+  float* zL = xL + HB_TILE * XS;          // [HB_TILE][ZS]
+  float* red = zL + HB_TILE * ZS;         // [VG][PB][16]
   const int tid = threadIdx.x;
   const int n = blockIdx.y;
-  const int npairs = K * (Cin + 1);       // c == Cin -> bias column
-  float acc[HB_PAIRS];
+  const int pb = tid % PB, vg = tid / PB;
+  const int kb = pb / CB, cbk = pb % CB;
+  const bool live = vg < VG;
+  float acc[4][4];
 #pragma unroll
-  for (int q = 0; q < HB_PAIRS; ++q) acc[q] = 0.f;
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = 0.f;
   int64_t v_begin = (int64_t)blockIdx.x * vox_per_block;
   int64_t v_end = v_begin + vox_per_block;
   if (v_end > S) v_end = S;
   for (int64_t vb = v_begin; vb < v_end; vb += HB_TILE) {
     __syncthreads();
-    for (int i = tid; i < HB_TILE * Cin; i += NT) {
-      int c = i % Cin, m = i / Cin;
-      int64_t v = vb + m;
-      xL[m * (Cin + 1) + c] = v < v_end ? Elem<T>::load1(x, ((size_t)n * S + v) * Cin + c) : 0.f;
+    {   // x tile: whole 16-byte channel chunks per lane; column Cin = 1 (bias), padding columns = 0
+      constexpr int CPC = Elem<T>::CPC;
+      const int cch = Cin / CPC;
+      for (int i = tid; i < HB_TILE * cch; i += NT) {
+        int cc = i % cch, m = i / cch;
+        int64_t v = vb + m;
+        float f[CPC];
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) f[j] = 0.f;
+        if (v < v_end) Elem<T>::unpack(ld_chunk<T>(x, ((size_t)n * S + v) * Cin + (size_t)cc * CPC), f);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) xL[m * XS + cc * CPC + j] = f[j];
+      }
+      for (int i = tid; i < HB_TILE * (XS - Cin); i += NT) {
+        int c = Cin + i % (XS - Cin), m = i / (XS - Cin);
+        xL[m * XS + c] = (c == Cin && vb + m < v_end) ? 1.f : 0.f;
+      }
     }
-    for (int i = tid; i < HB_TILE; i += NT) xL[i * (Cin + 1) + Cin] = 1.f;
-    for (int i = tid; i < HB_TILE * K; i += NT) {
-      int m = i % HB_TILE, k = i / HB_TILE;
+    for (int i = tid; i < HB_TILE * ZS; i += NT) {
+      int m = i % HB_TILE, k = i / HB_TILE;     // coalesced over voxels per class plane
       int64_t v = vb + m;
-      zL[k * HB_TILE + m] = v < v_end ? dz[((size_t)n * K + k) * S + v] : 0.f;
+      zL[m * ZS + k] = (v < v_end && k < K) ? dz[((size_t)n * K + k) * S + v] : 0.f;
     }
     __syncthreads();
+    if (live) {
+      for (int m = vg; m < HB_TILE; m += VG) {
+        f32x4 zv = *(const f32x4*)(zL + m * ZS + kb * 4);
+        f32x4 xv = *(const f32x4*)(xL + m * XS + cbk * 4);
+        float zz[4] = {zv.x, zv.y, zv.z, zv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-    for (int q = 0; q < HB_PAIRS; ++q) {
-      int pr = tid + q * NT;
-      if (pr < npairs) {
-        int c = pr % (Cin + 1), k = pr / (Cin + 1);
-        float a = acc[q];
-        for (int m = 0; m < HB_TILE; ++m) a = fmaf(zL[k * HB_TILE + m], xL[m * (Cin + 1) + c], a);
-        acc[q] = a;
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = fmaf(zz[a], xx[b2], acc[a][b2]);
       }
     }
   }
-  float* slab = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * npairs;
+  __syncthreads();
+  if (live) {
 #pragma unroll
-  for (int q = 0; q < HB_PAIRS; ++q) {
-    int pr = tid + q * NT;
-    if (pr < npairs) slab[pr] = acc[q];
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2) red[(vg * PB + pb) * 16 + a * 4 + b2] = acc[a][b2];
+  }
+  __syncthreads();
+  const int npairs = K * (Cin + 1);
+  float* slab = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * npairs;
+  for (int pr = tid; pr < npairs; pr += NT) {
+    int c = pr % (Cin + 1), k = pr / (Cin + 1);
+    int pbi = (k / 4) * CB + (c / 4), e = (k % 4) * 4 + (c % 4);
+    float a = 0.f;
+    for (int g = 0; g < VG; ++g) a += red[(g * PB + pbi) * 16 + e];
+    slab[pr] = a;
   }
 }
 
@@ -317,7 +385,7 @@ static int stem_check(int dtype, int Cin, int Cout, int kD, int kH, int kW) {
   int cpc = dtype == CBIM_BF16 ? 8 : 4;
   CBIM_CHECK(Cout % cpc == 0, CBIM_EUNSUPPORTED, "stem Cout %d is not a multiple of %d", Cout, cpc);
   CBIM_CHECK(Cin >= 1 && Cin <= 16, CBIM_EUNSUPPORTED, "stem Cin %d unsupported (1..16)", Cin);
-  CBIM_CHECK(kD * kH * kW <= MAXTAPS, CBIM_EUNSUPPORTED, "stem kernel too large");
+  CBIM_CHECK(kD <= 3 && kH <= 3 && kW <= 3, CBIM_EUNSUPPORTED, "stem kernel extent > 3 unsupported");
   return 0;
 }
 
@@ -363,7 +431,7 @@ extern "C" int cbim_stem_conv_wgrad(int dtype, const float* x, const void* dy, f
   StemParams p;
   p.x = x; p.w = nullptr; p.y = nullptr; p.dy = dy; p.ws = (float*)workspace;
   stem_fill(p, N, Cin, Di, Hi, Wi, Cout, kD, kH, kW, pD, pH, pW, Do, Ho, Wo);
-  size_t smem = ((size_t)p.hD * p.hH * p.hW + (size_t)(NT / 32) * MAXTAPS * 32) * sizeof(float);
+  size_t smem = ((((size_t)p.hD * p.hH * p.hW + 3) & ~(size_t)3) + (size_t)(NT / 32) * MAXTAPS * 32) * sizeof(float);
   dim3 grid((unsigned)(N * p.strips_per_n), (unsigned)((Cout + 31) / 32));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CBIM_BF16) CBIM_LAUNCH((k_stem_wgrad<bf16_tag>), grid, dim3(NT), smem, st, p);
@@ -378,7 +446,7 @@ static int head_check(int dtype, int Cin, int K) {
   CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype");
   int cpc = dtype == CBIM_BF16 ? 8 : 4;
   CBIM_CHECK(Cin % cpc == 0 && Cin <= 512, CBIM_EUNSUPPORTED, "head Cin %d unsupported", Cin);
-  CBIM_CHECK(K >= 1 && K * (Cin + 1) <= HB_PAIRS * NT, CBIM_EUNSUPPORTED, "head K=%d x Cin=%d too large", K, Cin);
+  CBIM_CHECK(K >= 1 && ((K + 3) / 4) * ((Cin + 4) / 4) <= NT, CBIM_EUNSUPPORTED, "head K=%d x Cin=%d too large", K, Cin);
   return 0;
 }
 
@@ -397,7 +465,7 @@ extern "C" int cbim_head_fwd(int dtype, const void* x, const float* w, const flo
 
 static int head_bwd_blocks(int64_t S) {
   int64_t b = (S + 4095) / 4096;
-  if (b > 1024) b = 1024;
+  if (b > 512) b = 512;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -424,7 +492,9 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
   int nb = head_bwd_blocks(S);
   int64_t vpb = (S + nb - 1) / nb;
   vpb = (vpb + HB_TILE - 1) / HB_TILE * HB_TILE;
-  size_t smem2 = ((size_t)HB_TILE * (Cin + 1) + (size_t)K * HB_TILE) * sizeof(float);
+  const int XS = (Cin + 1 + 3) & ~3, ZS = (K + 3) & ~3;
+  const int PB = (ZS / 4) * (XS / 4);
+  size_t smem2 = ((size_t)HB_TILE * XS + (size_t)HB_TILE * ZS + (size_t)(NT / PB) * PB * 16) * sizeof(float);
   CBIM_CHECK(smem2 <= 64 * 1024, CBIM_EUNSUPPORTED, "head bwd needs %zu B LDS", smem2);
   dim3 grid((unsigned)nb, (unsigned)N);
   if (dtype == CBIM_BF16)
