@@ -40,6 +40,7 @@ static constexpr int UH = 8;        // halo prefetch registers (16-B quads) per 
 
 struct IgemmParams {
   const void* x; int64_t x_stride;
+  const void* x2; int64_t x2_stride; int cin_split;   // channels >= cin_split come from x2 (K-concatenated inputs)
   const float* in_stats;
   const void* w;
   const void* res; int64_t res_stride;
@@ -189,6 +190,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
     h_iw0 = (tt % p.tiles_w) * 8 - p.pW;
     const int c0 = q * KC + my_slot * CPC;
     const bool c_ok = c0 < p.Cin;
+    const bool from2 = p.x2 != nullptr && q * KC >= p.cin_split;   // block-uniform (split is chunk aligned)
     const size_t nbase_in = (size_t)n * p.Di * p.Hi * p.Wi;
     if (p.in_stats && tid < KC && q * KC + tid < p.Cin) {
       sreg0 = p.in_stats[((size_t)n * p.Cin + q * KC + tid) * 2];
@@ -209,7 +211,8 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
       hreg[u] = u32x4{0u, 0u, 0u, 0u};
       if (ld) {
         size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
-        hreg[u] = ld_chunk<T>(p.x, row * p.x_stride + c0);
+        hreg[u] = from2 ? ld_chunk<T>(p.x2, row * p.x2_stride + (c0 - p.cin_split))
+                        : ld_chunk<T>(p.x, row * p.x_stride + c0);
         hld |= 1u << u;
       }
     }
@@ -584,7 +587,8 @@ static int dispatch_tiles(const TileCfg& c, const IgemmParams& p, dim3 grid, siz
   return launch_igemm<T, 1, 2, ACT>(p, grid, smem, st);
 }
 
-extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t x_stride,
+extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2,
+                                 int64_t x2_stride, int cin_split,
                                  const float* in_stats, const void* w_packed, const void* res,
                                  int64_t res_stride, const void* mask_x, int64_t mask_stride,
                                  const float* mask_stats, void* y, int64_t y_stride, float* partials,
@@ -595,6 +599,9 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   TileCfg c = pick_cfg(d);
   IgemmParams p;
   p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.w = w_packed;
+  p.x2 = x2; p.x2_stride = x2_stride; p.cin_split = cin_split;
+  CBIM_CHECK(!x2 || (cin_split > 0 && cin_split < d->Cin && cin_split % kc_of(d->dtype) == 0), CBIM_EUNSUPPORTED,
+             "second input: split %d must be a multiple of the %d-channel chunk", cin_split, kc_of(d->dtype));
   p.res = res; p.res_stride = res_stride; p.mx = mask_x; p.mx_stride = mask_stride; p.m_stats = mask_stats;
   p.y = y; p.y_stride = y_stride; p.partials = partials;
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin;

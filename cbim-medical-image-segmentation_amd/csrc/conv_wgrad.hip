@@ -26,6 +26,7 @@ static constexpr int NT = 256;
 struct WgradParams {
   const void* x; int64_t x_stride; const float* in_stats;
   const void* dy; int64_t dy_stride;
+  const void* dy2; int64_t dy2_stride; int cout_split;   // couts >= cout_split come from dy2
   float* ws;
   int N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout;
   int kD, kH, kW, pD, pH, pW, act;
@@ -107,6 +108,7 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
   const int my_slot = tid & (SLOTS - 1);
   const int ci0 = ib * 32 + my_slot * CPC;   // staged input channel chunk of this thread
   const int co0 = cb * 32 + my_slot * CPC;   // staged dy channel chunk of this thread
+  const bool dy_from2 = p.dy2 != nullptr && cb * 32 >= p.cout_split;   // block-uniform
   float mean[CPC], rstd[CPC];
   if (p.in_stats && ci0 < p.Cin) {
 #pragma unroll
@@ -178,7 +180,8 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
         v[u] = u32x4{0u, 0u, 0u, 0u};
         if (item < d_items && co0 < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo) {
           size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
-          v[u] = ld_chunk<T>(p.dy, row * p.dy_stride + co0);
+          v[u] = dy_from2 ? ld_chunk<T>(p.dy2, row * p.dy2_stride + (co0 - p.cout_split))
+                          : ld_chunk<T>(p.dy, row * p.dy_stride + co0);
         }
       }
 #pragma unroll
@@ -356,7 +359,8 @@ static int dispatch_tpw(int taps, const WgradParams& p, dim3 grid, size_t smem, 
 }
 
 extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t x_stride,
-                                 const float* in_stats, const void* dy, int64_t dy_stride, float* dw,
+                                 const float* in_stats, const void* dy, int64_t dy_stride, const void* dy2,
+                                 int64_t dy2_stride, int cout_split, float* dw,
                                  void* workspace, size_t ws_bytes, void* stream) {
   CBIM_CHECK(d && x && dy && dw, CBIM_EINVAL, "null argument");
   CBIM_CHECK(d->dtype == CBIM_F32 || d->dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype");
@@ -370,6 +374,9 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   WgCfg c = wg_cfg(d);
   WgradParams p;
   p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.dy = dy; p.dy_stride = dy_stride;
+  p.dy2 = dy2; p.dy2_stride = dy2_stride; p.cout_split = cout_split;
+  CBIM_CHECK(!dy2 || (cout_split > 0 && cout_split < d->Cout && cout_split % 32 == 0), CBIM_EUNSUPPORTED,
+             "second dy: split %d must be a multiple of 32", cout_split);
   p.ws = (float*)workspace;
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin;
   p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;

@@ -83,29 +83,52 @@ class StemFn(torch.autograd.Function):
         return None, dw, None
 
 
+def _fusable(x: torch.Tensor, cout: int) -> bool:
+    """conv1 + shortcut conv can run as one Cout-/K-concatenated GEMM when the split lands on a
+    64-byte channel chunk (dgrad) and on a 32-channel block (wgrad)."""
+    kc = 32 if x.dtype == torch.bfloat16 else 16
+    return cout % kc == 0 and cout % 32 == 0
+
+
 class BasicBlockFn(torch.autograd.Function):
     """BasicBlock.forward (conv_layers.py:86-94) with pre-activation ConvNormAct (:48-49).
 
     inputs : x (raw, pre-norm), its statistics, w1, w2, wsc (or None), act code
     outputs: out = conv2(a(conv1(a(x)))) + shortcut, statistics of out (non-differentiable)
+
+    conv1 and the shortcut conv read the same act(IN(x)) (InstanceNorm is parameter-free), so when
+    the channel counts allow they run as ONE convolution with Cout-concatenated weights (forward,
+    wgrad) / K-concatenated inputs (dgrad): the halo is staged and normalised once.
     """
 
     @staticmethod
     def forward(ctx, x, x_stats, w1, w2, wsc, act, want_out_stats):
-        g1 = _geom(x, w1, act)
-        w1d, w2d = w1.detach().contiguous(), w2.detach().contiguous()
-        y1, s1 = ops.conv_fwd(x, ops.pack_weights(w1d, g1, 0), g1, in_stats=x_stats, want_stats=True)
-        g2 = _geom(y1, w2, act)
-        if wsc is not None:
-            gsc = _geom(x, wsc, act)
-            res, _ = ops.conv_fwd(x, ops.pack_weights(wsc.detach().contiguous(), gsc, 0), gsc, in_stats=x_stats)
+        cout = int(w1.shape[0])
+        fused = wsc is not None and _fusable(x, cout)
+        w2d = w2.detach().contiguous()
+        if fused:
+            wcat = torch.cat([w1.detach(), wsc.detach()], 0).contiguous()
+            gc = _geom(x, wcat, act)
+            ycat, scat = ops.conv_fwd(x, ops.pack_weights(wcat, gc, 0), gc, in_stats=x_stats, want_stats=True)
+            y1, res = ycat[..., :cout], ycat[..., cout:]
+            s1 = scat[:, :cout].contiguous()
+            g1 = gsc = None
         else:
-            gsc = None
-            res = x
+            gc = None
+            g1 = _geom(x, w1, act)
+            y1, s1 = ops.conv_fwd(x, ops.pack_weights(w1.detach().contiguous(), g1, 0), g1, in_stats=x_stats,
+                                  want_stats=True)
+            if wsc is not None:
+                gsc = _geom(x, wsc, act)
+                res, _ = ops.conv_fwd(x, ops.pack_weights(wsc.detach().contiguous(), gsc, 0), gsc, in_stats=x_stats)
+            else:
+                gsc = None
+                res = x
+        g2 = _geom(y1, w2, act)
         out, so = ops.conv_fwd(y1, ops.pack_weights(w2d, g2, 0), g2, in_stats=s1, res=res,
                                want_stats=want_out_stats)
         ctx.save_for_backward(x, x_stats, y1, s1, w1, w2, wsc if wsc is not None else torch.empty(0))
-        ctx.geoms = (g1, g2, gsc)
+        ctx.geoms = (g1, g2, gsc, gc)
         ctx.act = act
         if so is None:
             so = torch.empty(0, device=x.device)
@@ -115,7 +138,7 @@ class BasicBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dso):
         x, x_stats, y1, s1, w1, w2, wsc = ctx.saved_tensors
-        g1, g2, gsc = ctx.geoms
+        g1, g2, gsc, gc = ctx.geoms
         act = ctx.act
         dout = dout.contiguous()
         # conv2
@@ -123,6 +146,16 @@ class BasicBlockFn(torch.autograd.Function):
         gy1, sums2 = ops.conv_dgrad(dout, ops.pack_weights(w2.detach().contiguous(), g2, 1), g2,
                                     mask_x=y1, mask_stats=s1)
         dy1 = ops.norm_bwd_apply(gy1, y1, s1, sums2, act, masked=False)
+        if gc is not None:
+            # conv1 + shortcut as one GEMM: dy = [dy1 | dout]
+            cout = int(w1.shape[0])
+            wcat = torch.cat([w1.detach(), wsc.detach()], 0).contiguous()
+            dwcat = ops.conv_wgrad(x, x_stats, dy1, gc, dy2=dout)
+            dw1, dwsc = dwcat[:cout], dwcat[cout:]
+            gx, sums1 = ops.conv_dgrad(dy1, ops.pack_weights(wcat, gc, 1), gc, mask_x=x, mask_stats=x_stats,
+                                       dy2=dout)
+            dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False)
+            return dx, None, dw1, dw2, dwsc, None, None
         # conv1 (+ shortcut conv share act(IN(x)))
         dw1 = ops.conv_wgrad(x, x_stats, dy1, g1)
         wd1 = ops.pack_weights(w1.detach().contiguous(), g1, 1)

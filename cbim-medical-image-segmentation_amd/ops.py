@@ -42,8 +42,23 @@ def _dev_ok(*ts):
             raise RuntimeError(
                 f"cbim_amd: tensor on '{t.device.type}' but the loaded kernel library "
                 f"({_lib.backend()}) executes on '{want}' — there is no fallback path")
-        if not t.is_contiguous():
+        if not t.is_contiguous() and not _is_row_view(t):
             raise RuntimeError("cbim_amd: non-contiguous tensor passed to a kernel")
+
+
+def _is_row_view(t: torch.Tensor) -> bool:
+    """channels-last [N,D,H,W,C'] view that selects a channel range of a wider contiguous tensor:
+    unit channel stride, rows `row_stride` elements apart, voxels dense."""
+    if t.dim() != 5 or t.stride(-1) != 1:
+        return False
+    rs = t.stride(3)
+    N, D, H, W, _ = t.shape
+    return t.stride(2) == W * rs and t.stride(1) == H * W * rs and t.stride(0) == D * H * W * rs
+
+
+def _rs(t: torch.Tensor) -> int:
+    """row stride (elements between consecutive voxels)"""
+    return int(t.stride(3)) if t.dim() == 5 else int(t.shape[-1])
 
 
 def _stream(t: torch.Tensor):
@@ -71,7 +86,7 @@ def instnorm_stats(x: torch.Tensor, eps: float = IN_EPS) -> torch.Tensor:
     P = L.cbim_stats_parts(S, Cc)
     part = torch.empty((N, P, Cc, 3), dtype=torch.float32, device=x.device)
     stats = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
-    check(L.cbim_instnorm_stats(_dt(x), _p(x), Cc, N, S, Cc, eps, _p(part), P, _p(stats), _stream(x)),
+    check(L.cbim_instnorm_stats(_dt(x), _p(x), _rs(x), N, S, Cc, eps, _p(part), P, _p(stats), _stream(x)),
           "instnorm_stats")
     return stats
 
@@ -87,8 +102,8 @@ def stats_finalize(partials: torch.Tensor, count: float, eps: float, mode: int) 
 def norm_act_fwd(x, stats, act: int):
     _dev_ok(x, stats)
     N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
-    y = torch.empty_like(x)
-    check(_lib.lib().cbim_norm_act_fwd(_dt(x), _p(x), Cc, _p(stats), _p(y), Cc, N, S, Cc, act, _stream(x)),
+    y = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
+    check(_lib.lib().cbim_norm_act_fwd(_dt(x), _p(x), _rs(x), _p(stats), _p(y), Cc, N, S, Cc, act, _stream(x)),
           "norm_act_fwd")
     return y
 
@@ -100,7 +115,7 @@ def norm_bwd_sums(g, x, stats, act: int, masked: bool):
     L = _lib.lib()
     P = L.cbim_stats_parts(S, Cc)
     part = torch.empty((N, P, Cc, 3), dtype=torch.float32, device=x.device)
-    check(L.cbim_norm_bwd_reduce(_dt(x), _p(g), Cc, _p(x), Cc, _p(stats), N, S, Cc, act, int(masked), _p(part),
+    check(L.cbim_norm_bwd_reduce(_dt(x), _p(g), _rs(g), _p(x), _rs(x), _p(stats), N, S, Cc, act, int(masked), _p(part),
                                  P, _stream(x)), "norm_bwd_reduce")
     return stats_finalize(part, S, 0.0, 1)
 
@@ -108,8 +123,9 @@ def norm_bwd_sums(g, x, stats, act: int, masked: bool):
 def norm_bwd_apply(g, x, stats, sums, act: int, masked: bool, add=None):
     _dev_ok(g, x, stats, sums, add)
     N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
-    dx = torch.empty_like(x)
-    check(_lib.lib().cbim_norm_bwd_apply(_dt(x), _p(g), Cc, _p(x), Cc, _p(stats), _p(sums), _p(add), Cc, _p(dx),
+    dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
+    check(_lib.lib().cbim_norm_bwd_apply(_dt(x), _p(g), _rs(g), _p(x), _rs(x), _p(stats), _p(sums), _p(add),
+                                         _rs(add) if add is not None else 0, _p(dx),
                                          Cc, N, S, Cc, act, int(masked), _stream(x)), "norm_bwd_apply")
     return dx
 
@@ -193,8 +209,10 @@ def pack_weights(w: torch.Tensor, geom: ConvGeom, mode: int) -> torch.Tensor:
 
 
 def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, mask_x=None, mask_stats=None,
-               want_partials: bool = False):
-    _dev_ok(x, w_packed, in_stats, res, mask_x, mask_stats)
+               want_partials: bool = False, x2=None):
+    """x2: second input tensor; the conv's input is the channel concatenation [x | x2] (never
+    materialised), split at x.shape[-1]."""
+    _dev_ok(x, w_packed, in_stats, res, mask_x, mask_stats, x2)
     L = _lib.lib()
     y = torch.empty(tuple(out_shape), dtype=x.dtype, device=x.device)
     part = None
@@ -205,10 +223,11 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.cbim_conv3d_igemm(C.byref(desc), _p(x), int(x.shape[-1]), _p(in_stats), _p(w_packed),
-                              _p(res), int(res.shape[-1]) if res is not None else 0,
-                              _p(mask_x), int(mask_x.shape[-1]) if mask_x is not None else 0, _p(mask_stats),
-                              _p(y), int(y.shape[-1]), _p(part), _stream(x)), "conv3d_igemm")
+    check(L.cbim_conv3d_igemm(C.byref(desc), _p(x), _rs(x), _p(x2), _rs(x2) if x2 is not None else 0,
+                              int(x.shape[-1]) if x2 is not None else 0, _p(in_stats), _p(w_packed),
+                              _p(res), _rs(res) if res is not None else 0,
+                              _p(mask_x), _rs(mask_x) if mask_x is not None else 0, _p(mask_stats),
+                              _p(y), _rs(y), _p(part), _stream(x)), "conv3d_igemm")
     if prof:
         e1.record()
         cfg = (C.c_int * 4)()
@@ -230,12 +249,12 @@ def conv_fwd(x, w_packed, geom: ConvGeom, in_stats=None, res=None, want_stats=Fa
     return y, stats
 
 
-def conv_dgrad(dy, w_packed_dgrad, geom: ConvGeom, mask_x=None, mask_stats=None, accumulate=None):
+def conv_dgrad(dy, w_packed_dgrad, geom: ConvGeom, mask_x=None, mask_stats=None, accumulate=None, dy2=None):
     """g = dgrad(dy) [+ accumulate] [* act'(xh(mask_x))]; with a mask also returns the two
     InstanceNorm-backward means (m1, m2) computed in the epilogue."""
     out_shape = (geom.N,) + geom.in_dhw + (geom.Cin,)
     g, part = conv_igemm(geom.bwd, dy, w_packed_dgrad, out_shape, res=accumulate, mask_x=mask_x,
-                         mask_stats=mask_stats, want_partials=mask_x is not None)
+                         mask_stats=mask_stats, want_partials=mask_x is not None, x2=dy2)
     sums = None
     if part is not None:
         S = geom.in_dhw[0] * geom.in_dhw[1] * geom.in_dhw[2]
@@ -243,8 +262,9 @@ def conv_dgrad(dy, w_packed_dgrad, geom: ConvGeom, mask_x=None, mask_stats=None,
     return g, sums
 
 
-def conv_wgrad(x, in_stats, dy, geom: ConvGeom) -> torch.Tensor:
-    _dev_ok(x, in_stats, dy)
+def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None) -> torch.Tensor:
+    """dy2: gradient of the output channels >= dy.shape[-1] (Cout-concatenated convs)."""
+    _dev_ok(x, in_stats, dy, dy2)
     L = _lib.lib()
     nbytes = L.cbim_conv3d_wgrad_workspace(C.byref(geom.fwd))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
@@ -253,8 +273,10 @@ def conv_wgrad(x, in_stats, dy, geom: ConvGeom) -> torch.Tensor:
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.cbim_conv3d_wgrad(C.byref(geom.fwd), _p(x), int(x.shape[-1]), _p(in_stats), _p(dy),
-                              int(dy.shape[-1]), _p(dw), _p(ws), nbytes, _stream(x)), "conv3d_wgrad")
+    check(L.cbim_conv3d_wgrad(C.byref(geom.fwd), _p(x), _rs(x), _p(in_stats), _p(dy), _rs(dy),
+                              _p(dy2), _rs(dy2) if dy2 is not None else 0,
+                              int(dy.shape[-1]) if dy2 is not None else 0,
+                              _p(dw), _p(ws), nbytes, _stream(x)), "conv3d_wgrad")
     if prof:
         e1.record()
         d = geom.fwd

@@ -127,17 +127,24 @@ int cbim_conv3d_num_tiles(const cbim_conv_desc* desc);
  *   partials != NULL: per-tile (sum u, sum u*v) over the stored values, float
  *                     [N][tiles][Cout][3] records; v = u (forward: InstanceNorm statistics of y) or
  *                     v = xh of mask_x (dgrad: the two InstanceNorm-backward sums).
- * For dgrad pass the dgrad desc (input = dy extent/Cout, output = x extent/Cin, p' = k-1-p). */
-int cbim_conv3d_igemm(const cbim_conv_desc* desc, const void* x, int64_t x_stride,
+ * For dgrad pass the dgrad desc (input = dy extent/Cout, output = x extent/Cin, p' = k-1-p).
+ * x2 != NULL: the input is the channel concatenation [x | x2] without materialising it; channels
+ * >= cin_split (a multiple of the 64-byte chunk) come from x2 — the two dgrads of a BasicBlock that
+ * share act(IN(x)) (conv1 and the shortcut conv, conv_layers.py:86-94) run as ONE K-concatenated GEMM. */
+int cbim_conv3d_igemm(const cbim_conv_desc* desc, const void* x, int64_t x_stride, const void* x2,
+                      int64_t x2_stride, int cin_split,
                       const float* in_stats, const void* w_packed, const void* res,
                       int64_t res_stride, const void* mask_x, int64_t mask_stride,
                       const float* mask_stats, void* y, int64_t y_stride, float* partials,
                       void* stream);
 /* dw[co][ci][tap] (fp32, natural nn.Conv3d layout) = sum_v dy[v][co] * xform(x)[v+tap][ci].
- * desc is the FORWARD desc.  workspace: cbim_conv3d_wgrad_workspace(desc) bytes. */
+ * desc is the FORWARD desc.  workspace: cbim_conv3d_wgrad_workspace(desc) bytes.
+ * dy2 != NULL: output channels >= cout_split (a multiple of 32) take their gradient from dy2
+ * (Cout-concatenated conv1 + shortcut conv sharing one staged input halo). */
 size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* fwd_desc);
 int cbim_conv3d_wgrad(const cbim_conv_desc* fwd_desc, const void* x, int64_t x_stride,
-                      const float* in_stats, const void* dy, int64_t dy_stride, float* dw,
+                      const float* in_stats, const void* dy, int64_t dy_stride, const void* dy2,
+                      int64_t dy2_stride, int cout_split, float* dw,
                       void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -62,3 +62,8 @@ def test_stem_head(dev, dtype):
 def test_loss(dev):
     oc.check_loss(dev)
     oc.check_loss(dev, N=1, C=16, dhw=(32, 32, 32))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_fused_conv1_shortcut_block(dev, dtype):
+    oc.check_fused_block(dev, dtype)

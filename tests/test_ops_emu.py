@@ -65,3 +65,8 @@ def test_errors_are_loud(dev):
         ops.instnorm_stats(x)
     with pytest.raises(TypeError):
         ops.instnorm_stats(torch.zeros(1, 2, 2, 2, 8, dtype=torch.float16))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_fused_conv1_shortcut_block(dev, dtype):
+    oc.check_fused_block(dev, dtype)
