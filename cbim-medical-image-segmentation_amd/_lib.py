@@ -44,6 +44,7 @@ _SIGS = {
     "cbim_upcat_bwd": (i32, [i32, vp, vp, vp] + [i32] * 10 + [vp]),
     "cbim_conv3d_packed_bytes": (sz, [_dp, i32]),
     "cbim_conv3d_pack_weights": (i32, [_dp, i32, vp, vp, vp]),
+    "cbim_conv3d_pack_weights_both": (i32, [_dp, vp, vp, vp, vp]),
     "cbim_conv3d_num_tiles": (i32, [_dp]),
     "cbim_conv3d_tile_config": (i32, [_dp, C.POINTER(C.c_int * 4)]),
     "cbim_conv3d_igemm": (i32, [_dp, vp, i64, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp]),

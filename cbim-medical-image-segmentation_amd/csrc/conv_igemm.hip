@@ -28,6 +28,7 @@
 // Replaces aten::convolution / convolution_backward(input) for nn.Conv3d in ConvNormAct
 // (conv_layers.py:29-38), stride 1, groups 1, bias-free; padding k//2 (unet_utils.py:13).
 #include "cbim_common.h"
+#include <stdlib.h>
 
 namespace cbim {
 
@@ -54,6 +55,7 @@ struct IgemmParams {
   int hD, hH, hW;                  // halo extent = tile + k - 1
   int n_chunks, taps;
   unsigned mHW, mW;                // ceil(2^20 / (hH*hW)), ceil(2^20 / hW): division by multiply
+  int dbg;                         // timing ablations for tools/ (env CBIM_IGEMM_DBG); 0 in production
 };
 
 template <typename T> struct Mma;
@@ -119,7 +121,7 @@ __device__ __forceinline__ void wait_vm0() {
 
 template <int MT, int NTL> struct Frags { u32x4 a[MT]; u32x4 b[NTL]; };   // one k-group of one tap
 
-template <typename T, int MT, int NTL, int ACT>
+template <typename T, int MT, int NTL, int ACT, bool K3>
 __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int KC = SLOTS * CPC;  // channels per chunk
@@ -134,6 +136,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
   const unsigned b_base = a_bytes;                      // two stage buffers follow the halo
   const unsigned red_base = a_bytes + 2 * stage_bytes;  // [NW*MT][BN][3] floats
   const unsigned st_base = red_base + (unsigned)(NW * BN * 3) * 4;   // [KC][2] floats: (mean, rstd) of the staged chunk
+  const unsigned scr_base = st_base + 512;                           // NTL == 1 only: NW x 4 KiB epilogue scratch
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
   const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
@@ -167,6 +170,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
 
   // ---- weight stage s -> LDS buffer (s & 1) by LDS-DMA ------------------------------------------------
   auto dma_stage = [&](int unit, int kd, int buf) {
+    if (p.dbg & 2) return;
     const int q = unit % p.n_chunks;
     const unsigned char* src = (const unsigned char*)p.w +
         ((size_t)nb * p.n_chunks + q) * ((size_t)p.kD * stage_bytes) + (size_t)kd * stage_bytes;
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
       unsigned hh = (r2 * p.mW) >> 20;
       unsigned hw = r2 - hh * p.hW;
       int id = h_id0 + (int)hd, ih = h_ih0 + (int)hh, iw = h_iw0 + (int)hw;
-      bool ld = item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+      bool ld = !(p.dbg & 1) && item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
       hreg[u] = u32x4{0u, 0u, 0u, 0u};
       if (ld) {
         size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
@@ -273,6 +277,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
 #pragma unroll
       for (int nt = 0; nt < NTL; ++nt) Mma<T>::run(f.a[mt], f.b[nt], acc[mt][nt]);
   };
+  (void)0;
 
   // ---- prologue: first unit's halo and first stage of weights -----------------------------------------
   dma_stage(0, 0, 0);
@@ -288,36 +293,71 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
     const int t = t_begin + unit / p.n_chunks, q = unit % p.n_chunks;
     for (int kd = 0; kd < p.kD; ++kd, ++stage) {
       const bool last_plane = kd == p.kD - 1;
-      // ---- start the next stage's weight DMA (and the next unit's halo loads) before computing -------------
+      // ---- start the next stage's weight DMA before computing; the next unit's halo loads are issued
+      //      at the unit's FIRST stage so that they have the whole unit to land ------------------------------
       if (!last_plane) dma_stage(unit, kd + 1, (stage + 1) & 1);
-      else if (unit + 1 < n_units) {
-        dma_stage(unit + 1, 0, (stage + 1) & 1);
-        halo_load(unit + 1);
-      }
-      // ---- the plane's taps; the two k-groups of a tap alternate between two statically named register
-      //      sets, each fetched one step ahead of its MFMAs; branch-free (the fetch after the last tap reads
-      //      a few rows past the plane inside the LDS allocation and is never used) --------------------------
+      else if (unit + 1 < n_units) dma_stage(unit + 1, 0, (stage + 1) & 1);
+      if (kd == 0 && unit + 1 < n_units) halo_load(unit + 1);
       {
         const unsigned a_plane = (unsigned)(kd * hHW) * RB;
         const unsigned b_buf = b_base + (unsigned)(stage & 1) * stage_bytes;
         Frags<MT, NTL> f0, f1;
-        int kh = 0, kw = 0;
-        unsigned toff = a_plane;
-        set_kh(0);
-        fetch(f0, 0, 0, toff, b_buf);
-        for (int tp = 0; tp < ptaps; ++tp) {
-          fetch(f1, tp, 1, toff, b_buf);
-          mma(f0);
-          ++kw;
-          toff += RB;
-          if (kw == p.kW) {   // wave-uniform
-            kw = 0;
-            ++kh;
-            toff += (unsigned)(p.hW - p.kW) * RB;
-            set_kh(kh);
+        if (K3) {
+          // 3x3 plane on an 8x8 tile row pitch (hW = 10): all tap / k-group offsets are compile-time
+          // immediates of the ds_read; per kh only the XOR-swizzled lane bases are recomputed.  The 18
+          // (tap, k-group) steps are fully unrolled, fragments alternate between two static register sets.
+          unsigned ab[KG][MT];
+          const unsigned bb = b_buf + b_lane;
+          auto set_bases = [&](int kh) {
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+                ab[kg][mt] = a_off[mt] + a_plane +
+                             ((unsigned)((2 * kg + half) ^ ((thr[mt] + kh) & (SLOTS - 1))) << 4);
+          };
+          auto fetch3 = [&](Frags<MT, NTL>& f, int kh, int kw, int kg) {
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+              f.b[nt] = *(const u32x4*)(smem + bb + (unsigned)(((kh * 3 + kw) * KG + kg) * 2 * BN + nt * 32) * 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              f.a[mt] = *(const u32x4*)(smem + ab[kg][mt] + (unsigned)(kh * 10 + kw) * RB);
+          };
+          set_bases(0);
+          fetch3(f0, 0, 0, 0);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              fetch3(f1, kh, kw, 1);
+              mma(f0);
+              if (kw < 2) fetch3(f0, kh, kw + 1, 0);
+              else if (kh < 2) { set_bases(kh + 1); fetch3(f0, kh + 1, 0, 0); }
+              mma(f1);
+            }
           }
-          fetch(f0, tp + 1, 0, toff, b_buf);
-          mma(f1);
+        } else {
+          // generic plane: branch-free tap loop (the fetch after the last tap reads a few rows past the
+          // plane inside the LDS allocation and is never used)
+          int kh = 0, kw = 0;
+          unsigned toff = a_plane;
+          set_kh(0);
+          fetch(f0, 0, 0, toff, b_buf);
+          for (int tp = 0; tp < ptaps; ++tp) {
+            fetch(f1, tp, 1, toff, b_buf);
+            mma(f0);
+            ++kw;
+            toff += RB;
+            if (kw == p.kW) {   // wave-uniform
+              kw = 0;
+              ++kh;
+              toff += (unsigned)(p.hW - p.kW) * RB;
+              set_kh(kh);
+            }
+            fetch(f0, tp + 1, 0, toff, b_buf);
+            mma(f1);
+          }
         }
       }
       // ---- stage end -------------------------------------------------------------------------------------------
@@ -336,7 +376,10 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
         const int oh0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH;
         const int ow0 = (tt % p.tiles_w) * 8;
         const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
-        float* scr = (float*)(smem + (unsigned)wave * 4096);
+        // scratch: the stage buffer just consumed (NTL=2: 36 KiB) or a dedicated region (NTL=1), so the
+        // next halo can be written while other waves are still in their epilogue
+        float* scr = (float*)(smem + (NTL == 1 ? scr_base : b_base + (unsigned)(stage & 1) * stage_bytes) +
+                              (unsigned)wave * 4096);
         float* red = (float*)(smem + red_base);
         const int cc = lane % OCH;
 #pragma unroll
@@ -404,7 +447,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
                   for (int j = 0; j < CPC; ++j) { float d = v[j] - sh[j]; s0[j] += d; s1[j] += d * d; }
                 }
                 cnt += 1.f;
-                st_chunk<T>(p.y, row * p.y_stride + cch0, Elem<T>::pack(v));
+                if (!(p.dbg & 4)) st_chunk<T>(p.y, row * p.y_stride + cch0, Elem<T>::pack(v));
               }
             }
           }
@@ -431,23 +474,23 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
             }
           }
         }
-        __syncthreads();   // scratch reads are done (the halo may be overwritten); `red` is complete
-        if (p.partials && tid < BN && co0 + tid < p.Cout) {
-          Moments a = {0.f, 0.f, 0.f};
-          for (int g = 0; g < NW; ++g) {
-            const float* rr = red + (g * BN + tid) * 3;
-            if (p.mx) { a.mean += rr[1]; a.m2 += rr[2]; }
-            else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
-          }
-          size_t o = (((size_t)n * tiles_per_n + tt) * p.Cout + co0 + tid) * 3;
-          p.partials[o] = a.n;
-          p.partials[o + 1] = a.mean;
-          p.partials[o + 2] = a.m2;
-        }
       }
-      if (last_plane && unit + 1 < n_units) {
-        halo_store();      // the next unit's halo replaces this one (nobody reads A any more)
-        __syncthreads();
+      const bool more = last_plane && unit + 1 < n_units;
+      if (more) halo_store();      // the next unit's halo replaces this one (nobody reads A any more)
+      if (more || tile_done) __syncthreads();   // halo visible; scratch reads done; `red` complete
+      if (tile_done && p.partials && tid < BN && co0 + tid < p.Cout) {
+        const int n = t / tiles_per_n, tt = t % tiles_per_n;
+        const float* red = (const float*)(smem + red_base);
+        Moments a = {0.f, 0.f, 0.f};
+        for (int g = 0; g < NW; ++g) {
+          const float* rr = red + (g * BN + tid) * 3;
+          if (p.mx) { a.mean += rr[1]; a.m2 += rr[2]; }
+          else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
+        }
+        size_t o = (((size_t)n * tiles_per_n + tt) * p.Cout + co0 + tid) * 3;
+        p.partials[o] = a.n;
+        p.partials[o + 1] = a.mean;
+        p.partials[o + 2] = a.m2;
       }
     }
   }
@@ -458,30 +501,40 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
 // mode 0: K = Cin, N = Cout, value w[cout][cin][tap]; mode 1 (dgrad): K = Cout_fwd, N = Cin_fwd,
 // value w[k_ch][n_ch][taps-1-tap]  (w is always the forward [Cout][Cin][taps] tensor).
 template <typename T>
-__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, void* __restrict__ packed,
-                                                      int Cout_f, int Cin_f, int taps, int mode, int BN,
-                                                      int n_chunks, int64_t total) {
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, void* __restrict__ packed, int Cout_f,
+                                         int Cin_f, int taps, int mode, int BN, int n_chunks, int64_t i) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int KC = SLOTS * CPC;
   const int Kdim = mode == 0 ? Cin_f : Cout_f;
   const int Ndim = mode == 0 ? Cout_f : Cin_f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    int64_t r = i;
-    int j = (int)(r % CPC); r /= CPC;
-    int nn = (int)(r % BN); r /= BN;
-    int half = (int)(r % 2); r /= 2;
-    int kg = (int)(r % KG); r /= KG;
-    int tap = (int)(r % taps); r /= taps;
-    int q = (int)(r % n_chunks);
-    int nb = (int)(r / n_chunks);
-    int kc = q * KC + (2 * kg + half) * CPC + j;
-    int nc = nb * BN + nn;
-    float v = 0.f;
-    if (kc < Kdim && nc < Ndim) {
-      if (mode == 0) v = w[((size_t)nc * Cin_f + kc) * taps + tap];
-      else v = w[((size_t)kc * Cin_f + nc) * taps + (taps - 1 - tap)];
-    }
-    Elem<T>::store1(packed, (size_t)i, v);
+  int64_t r = i;
+  int j = (int)(r % CPC); r /= CPC;
+  int nn = (int)(r % BN); r /= BN;
+  int half = (int)(r % 2); r /= 2;
+  int kg = (int)(r % KG); r /= KG;
+  int tap = (int)(r % taps); r /= taps;
+  int q = (int)(r % n_chunks);
+  int nb = (int)(r / n_chunks);
+  int kc = q * KC + (2 * kg + half) * CPC + j;
+  int nc = nb * BN + nn;
+  float v = 0.f;
+  if (kc < Kdim && nc < Ndim) {
+    if (mode == 0) v = w[((size_t)nc * Cin_f + kc) * taps + tap];
+    else v = w[((size_t)kc * Cin_f + nc) * taps + (taps - 1 - tap)];
+  }
+  Elem<T>::store1(packed, (size_t)i, v);
+}
+
+// One launch packs the forward layout, the dgrad layout, or both (p0/p1 may be null).
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, void* __restrict__ p0,
+                                                      void* __restrict__ p1, int Cout_f, int Cin_f, int taps,
+                                                      int BN0, int nch0, int64_t total0, int BN1, int nch1,
+                                                      int64_t total1) {
+  const int64_t tmax = total0 > total1 ? total0 : total1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tmax; i += (int64_t)gridDim.x * 256) {
+    if (p0 && i < total0) pack_one<T>(w, p0, Cout_f, Cin_f, taps, 0, BN0, nch0, i);
+    if (p1 && i < total1) pack_one<T>(w, p1, Cout_f, Cin_f, taps, 1, BN1, nch1, i);
   }
 }
 
@@ -527,26 +580,38 @@ extern "C" size_t cbim_conv3d_packed_bytes(const cbim_conv_desc* d, int mode) {
   return (size_t)n_nblk * n_chunks * taps * KG * 2 * BN * 16;
 }
 
-extern "C" int cbim_conv3d_pack_weights(const cbim_conv_desc* d, int mode, const float* w, void* packed,
-                                        void* stream) {
+static int pack_launch(const cbim_conv_desc* d, const float* w, void* p0, void* p1, void* stream) {
   if (int e = validate(d)) return e;
-  CBIM_CHECK(mode == 0 || mode == 1, CBIM_EINVAL, "bad pack mode");
-  int Kdim = mode == 0 ? d->Cin : d->Cout, Ndim = mode == 0 ? d->Cout : d->Cin;
-  int NTL = Ndim <= 32 ? 1 : 2, BN = 32 * NTL;
-  int KC = kc_of(d->dtype);
-  int n_chunks = (Kdim + KC - 1) / KC;
-  int taps = d->kD * d->kH * d->kW;
-  int64_t total = (int64_t)(cbim_conv3d_packed_bytes(d, mode) / elem_size(d->dtype));
-  int64_t blocks = (total + 255) / 256;
+  int KC = kc_of(d->dtype), taps = d->kD * d->kH * d->kW, es = elem_size(d->dtype);
+  int BN0 = d->Cout <= 32 ? 32 : 64, BN1 = d->Cin <= 32 ? 32 : 64;
+  int nch0 = (d->Cin + KC - 1) / KC, nch1 = (d->Cout + KC - 1) / KC;
+  int64_t t0 = p0 ? (int64_t)(cbim_conv3d_packed_bytes(d, 0) / es) : 0;
+  int64_t t1 = p1 ? (int64_t)(cbim_conv3d_packed_bytes(d, 1) / es) : 0;
+  int64_t tmax = t0 > t1 ? t0 : t1;
+  int64_t blocks = (tmax + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_pack_weights<bf16_tag>), dim3((unsigned)blocks), dim3(256), 0, st, w, packed, d->Cout, d->Cin,
-                taps, mode, BN, n_chunks, total);
+    CBIM_LAUNCH((k_pack_weights<bf16_tag>), dim3((unsigned)blocks), dim3(256), 0, st, w, p0, p1, d->Cout, d->Cin, taps,
+                BN0, nch0, t0, BN1, nch1, t1);
   else
-    CBIM_LAUNCH((k_pack_weights<float>), dim3((unsigned)blocks), dim3(256), 0, st, w, packed, d->Cout, d->Cin, taps,
-                mode, BN, n_chunks, total);
+    CBIM_LAUNCH((k_pack_weights<float>), dim3((unsigned)blocks), dim3(256), 0, st, w, p0, p1, d->Cout, d->Cin, taps,
+                BN0, nch0, t0, BN1, nch1, t1);
   return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_conv3d_pack_weights(const cbim_conv_desc* d, int mode, const float* w, void* packed,
+                                        void* stream) {
+  CBIM_CHECK(mode == 0 || mode == 1, CBIM_EINVAL, "bad pack mode");
+  CBIM_CHECK(w && packed, CBIM_EINVAL, "null argument");
+  return mode == 0 ? pack_launch(d, w, packed, nullptr, stream) : pack_launch(d, w, nullptr, packed, stream);
+}
+
+extern "C" int cbim_conv3d_pack_weights_both(const cbim_conv_desc* d, const float* w, void* packed_fwd,
+                                             void* packed_dgrad, void* stream) {
+  CBIM_CHECK(w && packed_fwd && packed_dgrad, CBIM_EINVAL, "null argument");
+  return pack_launch(d, w, packed_fwd, packed_dgrad, stream);
 }
 
 extern "C" int cbim_conv3d_tile_config(const cbim_conv_desc* d, int out[4]) {
@@ -562,29 +627,29 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   return ((d->Do + c.tD - 1) / c.tD) * ((d->Ho + c.tH - 1) / c.tH) * ((d->Wo + 7) / 8);
 }
 
-template <typename T, int MT, int NTL, int ACT>
+template <typename T, int MT, int NTL, int ACT, bool K3>
 static int launch_igemm(const IgemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
 #ifndef CBIM_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_igemm<T, MT, NTL, ACT>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_igemm<T, MT, NTL, ACT, K3>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
 #endif
-  CBIM_LAUNCH((k_conv_igemm<T, MT, NTL, ACT>), grid, dim3(NT), smem, st, p);
+  CBIM_LAUNCH((k_conv_igemm<T, MT, NTL, ACT, K3>), grid, dim3(NT), smem, st, p);
   hipError_t e = hipGetLastError();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv igemm launch: %s", hipGetErrorString(e));
   return CBIM_OK;
 }
 
-template <typename T, int ACT>
+template <typename T, int ACT, bool K3>
 static int dispatch_tiles(const TileCfg& c, const IgemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
-  if (c.MT == 2 && c.NTL == 1) return launch_igemm<T, 2, 1, ACT>(p, grid, smem, st);
-  if (c.MT == 2 && c.NTL == 2) return launch_igemm<T, 2, 2, ACT>(p, grid, smem, st);
-  if (c.MT == 1 && c.NTL == 1) return launch_igemm<T, 1, 1, ACT>(p, grid, smem, st);
-  return launch_igemm<T, 1, 2, ACT>(p, grid, smem, st);
+  if (c.MT == 2 && c.NTL == 1) return launch_igemm<T, 2, 1, ACT, K3>(p, grid, smem, st);
+  if (c.MT == 2 && c.NTL == 2) return launch_igemm<T, 2, 2, ACT, K3>(p, grid, smem, st);
+  if (c.MT == 1 && c.NTL == 1) return launch_igemm<T, 1, 1, ACT, K3>(p, grid, smem, st);
+  return launch_igemm<T, 1, 2, ACT, K3>(p, grid, smem, st);
 }
 
 extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2,
@@ -616,9 +681,10 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   int KC = kc_of(d->dtype);
   p.n_chunks = (d->Cin + KC - 1) / KC;
   p.taps = d->kD * d->kH * d->kW;
+  { const char* e = getenv("CBIM_IGEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   int BN = 32 * c.NTL;
   size_t smem = (size_t)p.hD * p.hH * p.hW * RB + 2 * (size_t)d->kH * d->kW * KG * 2 * BN * 16 +
-                (size_t)NW * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float);
+                (size_t)NW * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float) + (c.NTL == 1 ? (size_t)NW * 4096 : 0);
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "conv tile needs %zu B of LDS", smem);
   int64_t n_tiles = (int64_t)d->N * p.tiles_d * p.tiles_h * p.tiles_w;
   int n_nblk = (d->Cout + BN - 1) / BN;
@@ -629,9 +695,13 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   dim3 grid((unsigned)G, (unsigned)n_nblk);
   hipStream_t st = (hipStream_t)stream;
   const bool relu = d->act == CBIM_ACT_RELU;
-  if (d->dtype == CBIM_BF16)
-    return relu ? dispatch_tiles<bf16_tag, CBIM_ACT_RELU>(c, p, grid, smem, st)
-                : dispatch_tiles<bf16_tag, -1>(c, p, grid, smem, st);
-  return relu ? dispatch_tiles<float, CBIM_ACT_RELU>(c, p, grid, smem, st)
-              : dispatch_tiles<float, -1>(c, p, grid, smem, st);
+  const bool k3 = d->kH == 3 && d->kW == 3 && c.tH == 8;   // hW == hH == 10: compile-time tap offsets
+  if (d->dtype == CBIM_BF16) {
+    if (relu && k3) return dispatch_tiles<bf16_tag, CBIM_ACT_RELU, true>(c, p, grid, smem, st);
+    if (relu) return dispatch_tiles<bf16_tag, CBIM_ACT_RELU, false>(c, p, grid, smem, st);
+    return dispatch_tiles<bf16_tag, -1, false>(c, p, grid, smem, st);
+  }
+  if (relu && k3) return dispatch_tiles<float, CBIM_ACT_RELU, true>(c, p, grid, smem, st);
+  if (relu) return dispatch_tiles<float, CBIM_ACT_RELU, false>(c, p, grid, smem, st);
+  return dispatch_tiles<float, -1, false>(c, p, grid, smem, st);
 }

@@ -176,23 +176,42 @@ __global__ void __launch_bounds__(FIN_T) k_stats_finalize(const float* __restric
 }
 
 // ---- y = act((x-mean)*rstd) -------------------------------------------------------------------------
+// Streaming kernels: a thread keeps one channel chunk (its statistics live in registers) and strides
+// over voxel rows, 4 rows per trip so that 4 independent 16-byte loads per tensor are in flight;
+// no integer division in the loop.  grid = (row blocks, N).
+static constexpr int RU = 4;
 template <typename T>
 __global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ stats, void* __restrict__ y,
-                                                     int64_t y_stride, int64_t S, int C, int act,
-                                                     int64_t total_chunks) {
+                                                     int64_t y_stride, int64_t S, int C, int act) {
   constexpr int CPC = Elem<T>::CPC;
-  const int cch = C / CPC;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * NT) {
-    int64_t row = i / cch;  // n*S + v
-    int cc = (int)(i % cch);
-    int n = (int)(row / S);
-    float f[CPC];
-    Elem<T>::unpack(ld_chunk<T>(x, (size_t)row * x_stride + (size_t)cc * CPC), f);
-    const float* st = stats + ((size_t)n * C + cc * CPC) * 2;
+  const int cch = C / CPC, vlc = NT / cch;
+  const int cc = threadIdx.x % cch, vl = threadIdx.x / cch;
+  if (vl >= vlc) return;
+  const int n = blockIdx.y;
+  float mean[CPC], rstd[CPC];
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - st[2 * j]) * st[2 * j + 1], act);
-    st_chunk<T>(y, (size_t)row * y_stride + (size_t)cc * CPC, Elem<T>::pack(f));
+  for (int j = 0; j < CPC; ++j) {
+    mean[j] = stats[((size_t)n * C + cc * CPC + j) * 2];
+    rstd[j] = stats[((size_t)n * C + cc * CPC + j) * 2 + 1];
+  }
+  const size_t nb = (size_t)n * S;
+  const int64_t step = (int64_t)gridDim.x * vlc;
+  for (int64_t v = (int64_t)blockIdx.x * vlc + vl; v < S; v += step * RU) {
+    u32x4 raw[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (v + u * step < S) raw[u] = ld_chunk<T>(x, (nb + v + u * step) * x_stride + (size_t)cc * CPC);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (v + u * step < S) {
+        float f[CPC];
+        Elem<T>::unpack(raw[u], f);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], act);
+        st_chunk<T>(y, (nb + v + u * step) * y_stride + (size_t)cc * CPC, Elem<T>::pack(f));
+      }
+    }
   }
 }
 
@@ -204,28 +223,49 @@ __global__ void __launch_bounds__(NT) k_norm_bwd_apply(const void* __restrict__ 
                                                        const float* __restrict__ sums,
                                                        const void* __restrict__ add, int64_t add_stride,
                                                        void* __restrict__ dx, int64_t dx_stride, int64_t S,
-                                                       int C, int act, int masked, int64_t total_chunks) {
+                                                       int C, int act, int masked) {
   constexpr int CPC = Elem<T>::CPC;
-  const int cch = C / CPC;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * NT) {
-    int64_t row = i / cch;
-    int cc = (int)(i % cch);
-    int n = (int)(row / S);
-    float fg[CPC], fx[CPC], fa[CPC];
-    Elem<T>::unpack(ld_chunk<T>(g, (size_t)row * g_stride + (size_t)cc * CPC), fg);
-    Elem<T>::unpack(ld_chunk<T>(x, (size_t)row * x_stride + (size_t)cc * CPC), fx);
-    if (add) Elem<T>::unpack(ld_chunk<T>(add, (size_t)row * add_stride + (size_t)cc * CPC), fa);
-    const float* st = stats + ((size_t)n * C + cc * CPC) * 2;
-    const float* sm = sums + ((size_t)n * C + cc * CPC) * 2;
+  const int cch = C / CPC, vlc = NT / cch;
+  const int cc = threadIdx.x % cch, vl = threadIdx.x / cch;
+  if (vl >= vlc) return;
+  const int n = blockIdx.y;
+  float mean[CPC], rstd[CPC], m1[CPC], m2[CPC];
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) {
-      float rstd = st[2 * j + 1];
-      float xh = (fx[j] - st[2 * j]) * rstd;
-      float gg = masked ? fg[j] * act_grad(xh, act) : fg[j];
-      float d = rstd * (gg - sm[2 * j] - xh * sm[2 * j + 1]);
-      fg[j] = add ? d + fa[j] : d;
+  for (int j = 0; j < CPC; ++j) {
+    mean[j] = stats[((size_t)n * C + cc * CPC + j) * 2];
+    rstd[j] = stats[((size_t)n * C + cc * CPC + j) * 2 + 1];
+    m1[j] = sums[((size_t)n * C + cc * CPC + j) * 2];
+    m2[j] = sums[((size_t)n * C + cc * CPC + j) * 2 + 1];
+  }
+  const size_t nb = (size_t)n * S;
+  const int64_t step = (int64_t)gridDim.x * vlc;
+  for (int64_t v = (int64_t)blockIdx.x * vlc + vl; v < S; v += step * RU) {
+    u32x4 rg[RU], rx[RU], ra[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (v + u * step < S) {
+        rg[u] = ld_chunk<T>(g, (nb + v + u * step) * g_stride + (size_t)cc * CPC);
+        rx[u] = ld_chunk<T>(x, (nb + v + u * step) * x_stride + (size_t)cc * CPC);
+        if (add) ra[u] = ld_chunk<T>(add, (nb + v + u * step) * add_stride + (size_t)cc * CPC);
+      }
     }
-    st_chunk<T>(dx, (size_t)row * dx_stride + (size_t)cc * CPC, Elem<T>::pack(fg));
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (v + u * step < S) {
+        float fg[CPC], fx[CPC], fa[CPC];
+        Elem<T>::unpack(rg[u], fg);
+        Elem<T>::unpack(rx[u], fx);
+        if (add) Elem<T>::unpack(ra[u], fa);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          float xh = (fx[j] - mean[j]) * rstd[j];
+          float gg = masked ? fg[j] * act_grad(xh, act) : fg[j];
+          float d = rstd[j] * (gg - m1[j] - xh * m2[j]);
+          fg[j] = add ? d + fa[j] : d;
+        }
+        st_chunk<T>(dx, (nb + v + u * step) * dx_stride + (size_t)cc * CPC, Elem<T>::pack(fg));
+      }
+    }
   }
 }
 
@@ -250,6 +290,16 @@ __global__ void __launch_bounds__(NT) k_ndhwc_to_ncdhw(const void* __restrict__ 
     int c = (int)(nc % C);
     y[i] = Elem<T>::load1(x, ((size_t)n * S + v) * C + c);
   }
+}
+
+// row-block count of the streaming norm kernels: ~8 workgroups per CU, each thread >= RU rows
+static inline unsigned row_blocks(int dtype, int64_t S, int C) {
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int vlc = NT / (C / cpc);
+  int64_t b = (S + (int64_t)vlc * RU - 1) / ((int64_t)vlc * RU);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
 }
 
 static inline int grid_for(int64_t items) {
@@ -305,15 +355,12 @@ extern "C" int cbim_stats_finalize(const float* partials, int N, int P, int C, d
 extern "C" int cbim_norm_act_fwd(int dtype, const void* x, int64_t x_stride, const float* stats, void* y,
                                  int64_t y_stride, int N, int64_t S, int C, int act, void* stream) {
   if (int e = check_c(dtype, C)) return e;
-  int cpc = dtype == CBIM_BF16 ? 8 : 4;
-  int64_t total = (int64_t)N * S * (C / cpc);
+  dim3 grid(row_blocks(dtype, S, C), N);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_norm_act_fwd<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, x, x_stride, stats, y,
-                y_stride, S, C, act, total);
+    CBIM_LAUNCH((k_norm_act_fwd<bf16_tag>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, C, act);
   else
-    CBIM_LAUNCH((k_norm_act_fwd<float>), dim3(grid_for(total)), dim3(NT), 0, st, x, x_stride, stats, y,
-                y_stride, S, C, act, total);
+    CBIM_LAUNCH((k_norm_act_fwd<float>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, C, act);
   return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
@@ -337,15 +384,14 @@ extern "C" int cbim_norm_bwd_apply(int dtype, const void* g, int64_t g_stride, c
                                    int64_t add_stride, void* dx, int64_t dx_stride, int N, int64_t S, int C,
                                    int act, int masked, void* stream) {
   if (int e = check_c(dtype, C)) return e;
-  int cpc = dtype == CBIM_BF16 ? 8 : 4;
-  int64_t total = (int64_t)N * S * (C / cpc);
+  dim3 grid(row_blocks(dtype, S, C), N);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_norm_bwd_apply<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, g, g_stride, x,
-                x_stride, stats, sums, add, add_stride, dx, dx_stride, S, C, act, masked, total);
+    CBIM_LAUNCH((k_norm_bwd_apply<bf16_tag>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
+                add_stride, dx, dx_stride, S, C, act, masked);
   else
-    CBIM_LAUNCH((k_norm_bwd_apply<float>), dim3(grid_for(total)), dim3(NT), 0, st, g, g_stride, x, x_stride,
-                stats, sums, add, add_stride, dx, dx_stride, S, C, act, masked, total);
+    CBIM_LAUNCH((k_norm_bwd_apply<float>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
+                add_stride, dx, dx_stride, S, C, act, masked);
   return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

@@ -106,28 +106,36 @@ class BasicBlockFn(torch.autograd.Function):
         cout = int(w1.shape[0])
         fused = wsc is not None and _fusable(x, cout)
         w2d = w2.detach().contiguous()
+        train = any(ctx.needs_input_grad)
+        # weights are re-laid into MFMA fragment order once per step; when a backward will follow, the
+        # dgrad layout comes out of the same launch and is kept for it
+        pk = (lambda w, g: ops.pack_weights_both(w, g)) if train else (lambda w, g: (ops.pack_weights(w, g, 0), None))
+        wdsc = None
         if fused:
             wcat = torch.cat([w1.detach(), wsc.detach()], 0).contiguous()
             gc = _geom(x, wcat, act)
-            ycat, scat = ops.conv_fwd(x, ops.pack_weights(wcat, gc, 0), gc, in_stats=x_stats, want_stats=True)
+            wp, wd1 = pk(wcat, gc)
+            ycat, scat = ops.conv_fwd(x, wp, gc, in_stats=x_stats, want_stats=True)
             y1, res = ycat[..., :cout], ycat[..., cout:]
             s1 = scat[:, :cout].contiguous()
             g1 = gsc = None
         else:
             gc = None
             g1 = _geom(x, w1, act)
-            y1, s1 = ops.conv_fwd(x, ops.pack_weights(w1.detach().contiguous(), g1, 0), g1, in_stats=x_stats,
-                                  want_stats=True)
+            wp, wd1 = pk(w1.detach().contiguous(), g1)
+            y1, s1 = ops.conv_fwd(x, wp, g1, in_stats=x_stats, want_stats=True)
             if wsc is not None:
                 gsc = _geom(x, wsc, act)
-                res, _ = ops.conv_fwd(x, ops.pack_weights(wsc.detach().contiguous(), gsc, 0), gsc, in_stats=x_stats)
+                wpsc, wdsc = pk(wsc.detach().contiguous(), gsc)
+                res, _ = ops.conv_fwd(x, wpsc, gsc, in_stats=x_stats)
             else:
                 gsc = None
                 res = x
         g2 = _geom(y1, w2, act)
-        out, so = ops.conv_fwd(y1, ops.pack_weights(w2d, g2, 0), g2, in_stats=s1, res=res,
-                               want_stats=want_out_stats)
+        wp2, wd2 = pk(w2d, g2)
+        out, so = ops.conv_fwd(y1, wp2, g2, in_stats=s1, res=res, want_stats=want_out_stats)
         ctx.save_for_backward(x, x_stats, y1, s1, w1, w2, wsc if wsc is not None else torch.empty(0))
+        ctx.packed = (wd1, wd2, wdsc)
         ctx.geoms = (g1, g2, gsc, gc)
         ctx.act = act
         if so is None:
@@ -139,31 +147,27 @@ class BasicBlockFn(torch.autograd.Function):
     def backward(ctx, dout, _dso):
         x, x_stats, y1, s1, w1, w2, wsc = ctx.saved_tensors
         g1, g2, gsc, gc = ctx.geoms
+        wd1, wd2, wdsc = ctx.packed
         act = ctx.act
         dout = dout.contiguous()
         # conv2
         dw2 = ops.conv_wgrad(y1, s1, dout, g2)
-        gy1, sums2 = ops.conv_dgrad(dout, ops.pack_weights(w2.detach().contiguous(), g2, 1), g2,
-                                    mask_x=y1, mask_stats=s1)
+        gy1, sums2 = ops.conv_dgrad(dout, wd2, g2, mask_x=y1, mask_stats=s1)
         dy1 = ops.norm_bwd_apply(gy1, y1, s1, sums2, act, masked=False)
         if gc is not None:
             # conv1 + shortcut as one GEMM: dy = [dy1 | dout]
             cout = int(w1.shape[0])
-            wcat = torch.cat([w1.detach(), wsc.detach()], 0).contiguous()
             dwcat = ops.conv_wgrad(x, x_stats, dy1, gc, dy2=dout)
             dw1, dwsc = dwcat[:cout], dwcat[cout:]
-            gx, sums1 = ops.conv_dgrad(dy1, ops.pack_weights(wcat, gc, 1), gc, mask_x=x, mask_stats=x_stats,
-                                       dy2=dout)
+            gx, sums1 = ops.conv_dgrad(dy1, wd1, gc, mask_x=x, mask_stats=x_stats, dy2=dout)
             dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False)
             return dx, None, dw1, dw2, dwsc, None, None
         # conv1 (+ shortcut conv share act(IN(x)))
         dw1 = ops.conv_wgrad(x, x_stats, dy1, g1)
-        wd1 = ops.pack_weights(w1.detach().contiguous(), g1, 1)
         if gsc is not None:
             dwsc = ops.conv_wgrad(x, x_stats, dout, gsc)
             gx_u, _ = ops.conv_dgrad(dy1, wd1, g1)
-            gx, sums1 = ops.conv_dgrad(dout, ops.pack_weights(wsc.detach().contiguous(), gsc, 1), gsc,
-                                       mask_x=x, mask_stats=x_stats, accumulate=gx_u)
+            gx, sums1 = ops.conv_dgrad(dout, wdsc, gsc, mask_x=x, mask_stats=x_stats, accumulate=gx_u)
             dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False)
         else:
             dwsc = None

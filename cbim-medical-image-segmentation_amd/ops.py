@@ -208,6 +208,16 @@ def pack_weights(w: torch.Tensor, geom: ConvGeom, mode: int) -> torch.Tensor:
     return packed
 
 
+def pack_weights_both(w: torch.Tensor, geom: ConvGeom):
+    """(forward layout, dgrad layout) in one launch."""
+    _dev_ok(w)
+    L = _lib.lib()
+    p0 = torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 0),), dtype=torch.uint8, device=w.device)
+    p1 = torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 1),), dtype=torch.uint8, device=w.device)
+    check(L.cbim_conv3d_pack_weights_both(C.byref(geom.fwd), _p(w), _p(p0), _p(p1), _stream(w)), "pack_weights_both")
+    return p0, p1
+
+
 def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, mask_x=None, mask_stats=None,
                want_partials: bool = False, x2=None):
     """x2: second input tensor; the conv's input is the channel concatenation [x | x2] (never

@@ -116,6 +116,9 @@ typedef struct cbim_conv_desc {
 size_t cbim_conv3d_packed_bytes(const cbim_conv_desc* fwd_desc, int mode);
 int cbim_conv3d_pack_weights(const cbim_conv_desc* fwd_desc, int mode, const float* w, void* packed,
                              void* stream);
+/* Both layouts in one launch (training: the dgrad layout is needed in the backward of the same step). */
+int cbim_conv3d_pack_weights_both(const cbim_conv_desc* fwd_desc, const float* w, void* packed_fwd,
+                                  void* packed_dgrad, void* stream);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);
