@@ -47,7 +47,8 @@ _SIGS = {
     "cbim_conv3d_pack_weights_both": (i32, [_dp, vp, vp, vp, vp]),
     "cbim_conv3d_num_tiles": (i32, [_dp]),
     "cbim_conv3d_tile_config": (i32, [_dp, C.POINTER(C.c_int * 4)]),
-    "cbim_conv3d_igemm": (i32, [_dp, vp, i64, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp]),
+    "cbim_conv3d_igemm": (i32, [_dp, vp, i64, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, sz, vp]),
+    "cbim_conv3d_igemm_workspace": (sz, [_dp]),
     "cbim_conv3d_wgrad_workspace": (sz, [_dp]),
     "cbim_conv3d_wgrad": (i32, [_dp, vp, i64, vp, vp, i64, vp, i64, i32, vp, vp, sz, vp]),
     "cbim_stem_conv_fwd": (i32, [i32, vp, vp, vp] + [i32] * 15 + [vp]),

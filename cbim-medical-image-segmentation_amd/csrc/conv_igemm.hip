@@ -56,6 +56,8 @@ struct IgemmParams {
   int n_chunks, taps;
   unsigned mHW, mW;                // ceil(2^20 / (hH*hW)), ceil(2^20 / hW): division by multiply
   int dbg;                         // timing ablations for tools/ (env CBIM_IGEMM_DBG); 0 in production
+  int ksplit;                      // > 1: blockIdx.z owns a slice of the Cin chunks, raw fp32 partials go to ws
+  float* ws;                       // [ksplit][N*Do*Ho*Wo][Cout] fp32
 };
 
 template <typename T> struct Mma;
@@ -146,7 +148,12 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
   const int t_end = (int)(((long long)(lb + 1) * n_tiles) / gridDim.x);
   const int nb = blockIdx.y, co0 = nb * BN;
   if (t_begin >= t_end) return;
-  const int n_units = (t_end - t_begin) * p.n_chunks;
+  // split-K: this workgroup's slice [q_lo, q_hi) of the Cin chunks
+  const int q_lo = (int)(((long long)blockIdx.z * p.n_chunks) / p.ksplit);
+  const int q_hi = (int)(((long long)(blockIdx.z + 1) * p.n_chunks) / p.ksplit);
+  const int nq = q_hi - q_lo;
+  if (nq <= 0) return;
+  const int n_units = (t_end - t_begin) * nq;
 
   unsigned a_off[MT];   // LDS byte offset of the lane's voxel row at tap (0,0,0)
   int thr[MT];
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
   // ---- weight stage s -> LDS buffer (s & 1) by LDS-DMA ------------------------------------------------
   auto dma_stage = [&](int unit, int kd, int buf) {
     if (p.dbg & 2) return;
-    const int q = unit % p.n_chunks;
+    const int q = q_lo + unit % nq;
     const unsigned char* src = (const unsigned char*)p.w +
         ((size_t)nb * p.n_chunks + q) * ((size_t)p.kD * stage_bytes) + (size_t)kd * stage_bytes;
     unsigned char* dst = smem + b_base + (unsigned)buf * stage_bytes;
@@ -187,7 +194,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
   float sreg0 = 0.f, sreg1 = 1.f;
   int h_id0 = 0, h_ih0 = 0, h_iw0 = 0;
   auto halo_load = [&](int unit) {
-    const int t = t_begin + unit / p.n_chunks, q = unit % p.n_chunks;
+    const int t = t_begin + unit / nq, q = q_lo + unit % nq;
     const int n = t / tiles_per_n, tt = t % tiles_per_n;
     h_id0 = (tt / (p.tiles_w * p.tiles_h)) * p.tD - p.pD;
     h_ih0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH - p.pH;
@@ -290,7 +297,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
 
   int stage = 0;
   for (int unit = 0; unit < n_units; ++unit) {
-    const int t = t_begin + unit / p.n_chunks, q = unit % p.n_chunks;
+    const int t = t_begin + unit / nq, q = q_lo + unit % nq;
     for (int kd = 0; kd < p.kD; ++kd, ++stage) {
       const bool last_plane = kd == p.kD - 1;
       // ---- start the next stage's weight DMA before computing; the next unit's halo loads are issued
@@ -338,8 +345,9 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
             }
           }
         } else {
-          // generic plane: branch-free tap loop (the fetch after the last tap reads a few rows past the
-          // plane inside the LDS allocation and is never used)
+          // generic plane: branch-free tap loop, fragments fetched one k-group step ahead (a second step of
+          // lookahead was measured 2x slower: the third register set spills in the hot loop).  The fetch
+          // after the last tap reads a few rows past the plane inside the LDS allocation, never used.
           int kh = 0, kw = 0;
           unsigned toff = a_plane;
           set_kh(0);
@@ -361,7 +369,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
         }
       }
       // ---- stage end -------------------------------------------------------------------------------------------
-      const bool tile_done = last_plane && q == p.n_chunks - 1;
+      const bool tile_done = last_plane && q == q_hi - 1;
       if (last_plane && unit + 1 < n_units) stats_publish();
       wait_vm0();        // this wave's LDS-DMA (next stage's weights) has landed
       __syncthreads();   // every wave is done with this stage's A/B reads
@@ -418,6 +426,15 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
                 f32x4 q4 = *(const f32x4*)(scr + vr * 32 + cc * CPC + j4);
                 v[j4] = q4.x; v[j4 + 1] = q4.y; v[j4 + 2] = q4.z; v[j4 + 3] = q4.w;
               }
+              if (p.ksplit > 1) {   // split-K: raw fp32 partial, finished by k_splitk_finish
+                if (c_ok && od < p.Do && oh < p.Ho && ow < p.Wo) {
+                  const size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+                  float* wp = p.ws + ((size_t)blockIdx.z * ((size_t)p.N * p.Do * p.Ho * p.Wo) + row) * p.Cout + cch0;
+#pragma unroll
+                  for (int j4 = 0; j4 < CPC; j4 += 4) *(f32x4*)(wp + j4) = f32x4{v[j4], v[j4 + 1], v[j4 + 2], v[j4 + 3]};
+                }
+                continue;
+              }
               if (mt == 0 && it == 0 && !p.mx) {
                 // common shift per channel for the whole wave: the value lane `cc` holds for its first
                 // voxel (any finite value near the data works; shifted sums then simply add across lanes)
@@ -451,7 +468,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
               }
             }
           }
-          if (p.partials) {
+          if (p.partials && p.ksplit == 1) {
             // lanes with the same channel chunk (lane % OCH) hold plain partial sums: xor-shuffle adds
 #pragma unroll
             for (int msk = OCH; msk < 64; msk <<= 1) {
@@ -478,7 +495,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
       const bool more = last_plane && unit + 1 < n_units;
       if (more) halo_store();      // the next unit's halo replaces this one (nobody reads A any more)
       if (more || tile_done) __syncthreads();   // halo visible; scratch reads done; `red` complete
-      if (tile_done && p.partials && tid < BN && co0 + tid < p.Cout) {
+      if (tile_done && p.partials && p.ksplit == 1 && tid < BN && co0 + tid < p.Cout) {
         const int n = t / tiles_per_n, tt = t % tiles_per_n;
         const float* red = (const float*)(smem + red_base);
         Moments a = {0.f, 0.f, 0.f};
@@ -492,6 +509,104 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
         p.partials[o + 1] = a.mean;
         p.partials[o + 2] = a.m2;
       }
+    }
+  }
+}
+
+// ---- split-K finish: sum the fp32 partials, then the same epilogue as the fused path ------------------
+// grid = (row blocks, N); a thread keeps one 16-byte output chunk and strides over voxel rows.
+static constexpr int FT = 256;
+template <typename T, int ACT>
+__global__ void __launch_bounds__(FT) k_splitk_finish(const float* __restrict__ ws, int ksplit, const void* res,
+                                                      int64_t res_stride, const void* mx, int64_t mx_stride,
+                                                      const float* __restrict__ m_stats, void* y, int64_t y_stride,
+                                                      float* partials, int64_t S, int64_t rows_total, int C, int act,
+                                                      int P) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC, vlc = FT / cch;
+  const int t = threadIdx.x, cc = t % cch, vl = t / cch;
+  const int n = blockIdx.y, part = blockIdx.x;
+  const bool active = vl < vlc;
+  const int64_t per = (S + P - 1) / P;
+  const int64_t v0 = (int64_t)part * per;
+  int64_t v1 = v0 + per;
+  if (v1 > S) v1 = S;
+  float mm[CPC], mr[CPC], s0[CPC], s1[CPC], sh[CPC];
+  float cnt = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) { mm[j] = 0.f; mr[j] = 1.f; s0[j] = 0.f; s1[j] = 0.f; sh[j] = 0.f; }
+  if (mx && active) {
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      mm[j] = m_stats[((size_t)n * C + cc * CPC + j) * 2];
+      mr[j] = m_stats[((size_t)n * C + cc * CPC + j) * 2 + 1];
+    }
+  }
+  if (active) {
+    for (int64_t v = v0 + vl; v < v1; v += vlc) {
+      const size_t row = (size_t)n * S + v;
+      float a[CPC];
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) a[j] = 0.f;
+#pragma unroll 4
+      for (int z = 0; z < ksplit; ++z) {
+        const float* wp = ws + ((size_t)z * rows_total + row) * C + (size_t)cc * CPC;
+#pragma unroll
+        for (int j4 = 0; j4 < CPC; j4 += 4) {
+          f32x4 q4 = *(const f32x4*)(wp + j4);
+          a[j4] += q4.x; a[j4 + 1] += q4.y; a[j4 + 2] += q4.z; a[j4 + 3] += q4.w;
+        }
+      }
+      if (res) {
+        float f[CPC];
+        Elem<T>::unpack(ld_chunk<T>(res, row * res_stride + (size_t)cc * CPC), f);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) a[j] += f[j];
+      }
+      if (mx) {
+        float f[CPC];
+        Elem<T>::unpack(ld_chunk<T>(mx, row * mx_stride + (size_t)cc * CPC), f);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          float xh = (f[j] - mm[j]) * mr[j];
+          a[j] *= actg<ACT>(xh, act);
+          s0[j] += a[j];
+          s1[j] += a[j] * xh;
+        }
+      } else {
+        if (cnt == 0.f) {
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) sh[j] = a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) { float d = a[j] - sh[j]; s0[j] += d; s1[j] += d * d; }
+      }
+      cnt += 1.f;
+      st_chunk<T>(y, row * y_stride + (size_t)cc * CPC, Elem<T>::pack(a));
+    }
+  }
+  if (!partials) return;
+  __shared__ float red[FT * 3 * 8];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) {
+    Moments m;
+    if (mx) { m.n = 0.f; m.mean = s0[j]; m.m2 = s1[j]; }
+    else m = moments_from_shifted(cnt, sh[j], s0[j], s1[j]);
+    red[(t * CPC + j) * 3 + 0] = m.n;
+    red[(t * CPC + j) * 3 + 1] = m.mean;
+    red[(t * CPC + j) * 3 + 2] = m.m2;
+  }
+  __syncthreads();
+  if (vl == 0 && active) {
+    for (int j = 0; j < CPC; ++j) {
+      Moments acc = {0.f, 0.f, 0.f};
+      for (int q = 0; q < vlc; ++q) {
+        const float* r = red + ((q * cch + cc) * CPC + j) * 3;
+        if (mx) { acc.mean += r[1]; acc.m2 += r[2]; }
+        else { Moments b = {r[0], r[1], r[2]}; acc = moments_merge(acc, b); }
+      }
+      size_t o = (((size_t)n * P + part) * C + cc * CPC + j) * 3;
+      partials[o] = acc.n; partials[o + 1] = acc.mean; partials[o + 2] = acc.m2;
     }
   }
 }
@@ -552,6 +667,27 @@ static TileCfg pick_cfg(const cbim_conv_desc* d) {
 }
 
 static int elem_size(int dtype) { return dtype == CBIM_BF16 ? 2 : 4; }
+
+// split-K factor: low-resolution layers have too few (tile, n-block) pairs to fill 256 CUs; the Cin
+// chunks are then shared out over blockIdx.z and summed by k_splitk_finish.
+static int pick_ksplit(const cbim_conv_desc* d, const TileCfg& c) {
+  int KC = RB / elem_size(d->dtype);
+  int n_chunks = (d->Cin + KC - 1) / KC;
+  int64_t tiles = (int64_t)d->N * ((d->Do + c.tD - 1) / c.tD) * ((d->Ho + c.tH - 1) / c.tH) * ((d->Wo + 7) / 8);
+  int BN = 32 * c.NTL;
+  int64_t wgs = tiles * ((d->Cout + BN - 1) / BN);
+  if (wgs >= 96 || n_chunks < 2 || d->Cout > 256 * 8) return 1;
+  int64_t s = (192 + wgs - 1) / wgs;
+  if (s > n_chunks) s = n_chunks;
+  if (s > 16) s = 16;
+  return (int)s;
+}
+static int finish_parts(int64_t S) {
+  int64_t p = (S + 15) / 16;
+  if (p > 512) p = 512;
+  if (p < 1) p = 1;
+  return (int)p;
+}
 static int kc_of(int dtype) { return RB / elem_size(dtype); }
 
 }  // namespace cbim
@@ -621,9 +757,18 @@ extern "C" int cbim_conv3d_tile_config(const cbim_conv_desc* d, int out[4]) {
   return CBIM_OK;
 }
 
+extern "C" size_t cbim_conv3d_igemm_workspace(const cbim_conv_desc* d) {
+  if (!d) return 0;
+  TileCfg c = pick_cfg(d);
+  int ks = pick_ksplit(d, c);
+  if (ks <= 1) return 0;
+  return (size_t)ks * d->N * d->Do * d->Ho * d->Wo * d->Cout * sizeof(float);
+}
+
 extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   if (!d) return 0;
   TileCfg c = pick_cfg(d);
+  if (pick_ksplit(d, c) > 1) return finish_parts((int64_t)d->Do * d->Ho * d->Wo);
   return ((d->Do + c.tD - 1) / c.tD) * ((d->Ho + c.tH - 1) / c.tH) * ((d->Wo + 7) / 8);
 }
 
@@ -657,7 +802,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
                                  const float* in_stats, const void* w_packed, const void* res,
                                  int64_t res_stride, const void* mask_x, int64_t mask_stride,
                                  const float* mask_stats, void* y, int64_t y_stride, float* partials,
-                                 void* stream) {
+                                 void* workspace, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
   CBIM_CHECK(x && w_packed && y, CBIM_EINVAL, "null tensor");
   CBIM_CHECK(!mask_x || mask_stats, CBIM_EINVAL, "mask_x needs mask_stats");
@@ -692,10 +837,47 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   int64_t G = 256 / n_nblk;
   if (G < 1) G = 1;
   if (G > n_tiles) G = n_tiles;
-  dim3 grid((unsigned)G, (unsigned)n_nblk);
+  p.ksplit = pick_ksplit(d, c);
+  p.ws = (float*)workspace;
+  if (p.ksplit > 1) {
+    size_t need = cbim_conv3d_igemm_workspace(d);
+    CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "conv split-K workspace %zu < %zu", ws_bytes, need);
+  }
+  dim3 grid((unsigned)G, (unsigned)n_nblk, (unsigned)p.ksplit);
   hipStream_t st = (hipStream_t)stream;
   const bool relu = d->act == CBIM_ACT_RELU;
-  const bool k3 = d->kH == 3 && d->kW == 3 && c.tH == 8;   // hW == hH == 10: compile-time tap offsets
+  if (p.ksplit > 1) {
+    // main kernel writes raw partials; the finish kernel owns residual / mask / statistics / store
+    IgemmParams q = p;
+    q.res = nullptr; q.mx = nullptr; q.partials = nullptr;
+    static const bool k3s_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : false;
+    const bool k3s = k3s_on && d->kH == 3 && d->kW == 3 && c.tH == 8;
+    int rc;
+    if (d->dtype == CBIM_BF16)
+      rc = (relu && k3s) ? dispatch_tiles<bf16_tag, CBIM_ACT_RELU, true>(c, q, grid, smem, st)
+         : relu ? dispatch_tiles<bf16_tag, CBIM_ACT_RELU, false>(c, q, grid, smem, st)
+                : dispatch_tiles<bf16_tag, -1, false>(c, q, grid, smem, st);
+    else
+      rc = (relu && k3s) ? dispatch_tiles<float, CBIM_ACT_RELU, true>(c, q, grid, smem, st)
+         : relu ? dispatch_tiles<float, CBIM_ACT_RELU, false>(c, q, grid, smem, st)
+                : dispatch_tiles<float, -1, false>(c, q, grid, smem, st);
+    if (rc) return rc;
+    int cpc = d->dtype == CBIM_BF16 ? 8 : 4;
+    CBIM_CHECK(d->Cout / cpc <= FT, CBIM_EUNSUPPORTED, "split-K finish: Cout %d too large", d->Cout);
+    const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
+    const int P = finish_parts(S);
+    dim3 fg((unsigned)P, (unsigned)d->N);
+    if (d->dtype == CBIM_BF16) {
+      if (relu) CBIM_LAUNCH((k_splitk_finish<bf16_tag, CBIM_ACT_RELU>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
+      else CBIM_LAUNCH((k_splitk_finish<bf16_tag, -1>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
+    } else {
+      if (relu) CBIM_LAUNCH((k_splitk_finish<float, CBIM_ACT_RELU>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
+      else CBIM_LAUNCH((k_splitk_finish<float, -1>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
+    }
+    return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  }
+  static const bool k3_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : false;
+  const bool k3 = k3_on && d->kH == 3 && d->kW == 3 && c.tH == 8;   // hW == hH == 10: compile-time tap offsets
   if (d->dtype == CBIM_BF16) {
     if (relu && k3) return dispatch_tiles<bf16_tag, CBIM_ACT_RELU, true>(c, p, grid, smem, st);
     if (relu) return dispatch_tiles<bf16_tag, CBIM_ACT_RELU, false>(c, p, grid, smem, st);

@@ -229,6 +229,8 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
     if want_partials:
         tiles = L.cbim_conv3d_num_tiles(C.byref(desc))
         part = torch.empty((desc.N, tiles, desc.Cout, 3), dtype=torch.float32, device=x.device)
+    wsb = L.cbim_conv3d_igemm_workspace(C.byref(desc))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device) if wsb else None
     prof = PROFILE is not None and x.device.type == "cuda"
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -237,7 +239,7 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
                               int(x.shape[-1]) if x2 is not None else 0, _p(in_stats), _p(w_packed),
                               _p(res), _rs(res) if res is not None else 0,
                               _p(mask_x), _rs(mask_x) if mask_x is not None else 0, _p(mask_stats),
-                              _p(y), _rs(y), _p(part), _stream(x)), "conv3d_igemm")
+                              _p(y), _rs(y), _p(part), _p(ws), wsb, _stream(x)), "conv3d_igemm")
     if prof:
         e1.record()
         cfg = (C.c_int * 4)()

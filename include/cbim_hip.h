@@ -139,7 +139,11 @@ int cbim_conv3d_igemm(const cbim_conv_desc* desc, const void* x, int64_t x_strid
                       const float* in_stats, const void* w_packed, const void* res,
                       int64_t res_stride, const void* mask_x, int64_t mask_stride,
                       const float* mask_stats, void* y, int64_t y_stride, float* partials,
-                      void* stream);
+                      void* workspace, size_t ws_bytes, void* stream);
+/* Bytes of scratch cbim_conv3d_igemm needs for `desc` (0 unless the launcher splits K: layers with
+ * too few output tiles to fill the chip share the Cin chunks over blockIdx.z and a finish kernel sums
+ * the fp32 partials in fixed order before the residual / mask / statistics epilogue). */
+size_t cbim_conv3d_igemm_workspace(const cbim_conv_desc* desc);
 /* dw[co][ci][tap] (fp32, natural nn.Conv3d layout) = sum_v dy[v][co] * xform(x)[v+tap][ci].
  * desc is the FORWARD desc.  workspace: cbim_conv3d_wgrad_workspace(desc) bytes.
  * dy2 != NULL: output channels >= cout_split (a multiple of 32) take their gradient from dy2
