@@ -60,6 +60,12 @@ _SIGS = {
     "cbim_dice_ce_workspace": (sz, [i32, i32, i64]),
     "cbim_dice_ce_fwd": (i32, [vp, vp, vp, i32, i32, i64, vp, vp, vp, sz, vp]),
     "cbim_dice_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, vp]),
+    "cbim_affine_sample3d": (i32, [vp, vp, i32, vp, vp, vp] + [i32] * 10 + [vp]),
+    "cbim_crop3d": (i32, [vp, vp, i32, vp, vp] + [i32] * 10 + [vp]),
+    "cbim_chan_stats_workspace": (sz, [i32, i64]),
+    "cbim_chan_stats": (i32, [vp, i32, i64, vp, vp, sz, vp]),
+    "cbim_intensity": (i32, [vp, vp, i32, i64, i32, vp, i32, vp, vp, i32, vp, vp]),
+    "cbim_gaussian_blur3d": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "cbim_ncdhw_to_ndhwc": (i32, [i32, vp, vp, i32, i32, i64, vp]),
     "cbim_ndhwc_to_ncdhw": (i32, [i32, vp, vp, i32, i32, i64, vp]),
 }

@@ -190,6 +190,37 @@ int cbim_dice_ce_fwd(const float* logits, const int64_t* labels, const float* we
 int cbim_dice_ce_bwd(const float* logits, const int64_t* labels, const float* weight, const float* coef,
                      const float* grad_out, float* dlogits, int N, int C, int64_t S, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * On-device augmentation — training/augmentation.py (tensor_img [1,C,D,H,W] fp32, tensor_lab
+ * [1,1,D,H,W] int8|int64), called per sample from the dataset (training/dataset/dim3/
+ * dataset_amos_ct.py:121-153).  Random parameters are drawn by the HOST in the reference's order.
+ * ------------------------------------------------------------------------------------------ */
+/* F.affine_grid(theta[3x4], size, align_corners=True) + F.grid_sample(img, bilinear, zeros) +
+ * F.grid_sample(lab, nearest, zeros).long()  (augmentation.py:283-289) in one pass; the output is
+ * the window [od0:od0+Do, oh0:oh0+Ho, ow0:ow0+Wo] of the full-size result, i.e. fused with the
+ * centre crop_3d that follows (:320-343).  theta12 is a HOST pointer (12 floats). lab may be NULL. */
+int cbim_affine_sample3d(const float* img, const void* lab, int lab_bytes, const float* theta12,
+                         float* out_img, int64_t* out_lab, int C, int Di, int Hi, int Wi, int Do, int Ho,
+                         int Wo, int od0, int oh0, int ow0, void* stream);
+/* crop_3d (augmentation.py:320-343) of image and label (label keeps its dtype). */
+int cbim_crop3d(const float* img, const void* lab, int lab_bytes, float* out_img, void* out_lab, int C,
+                int Di, int Hi, int Wi, int Do, int Ho, int Wo, int d0, int h0, int w0, void* stream);
+/* per-channel (min, max, mean, unbiased std): float [C][4]  (gamma :117-124, contrast :150-155). */
+size_t cbim_chan_stats_workspace(int C, int64_t S);
+int cbim_chan_stats(const float* x, int C, int64_t S, float* stats, void* workspace, size_t ws_bytes,
+                    void* stream);
+/* point-wise intensity transforms; prm/st/st2/noise are DEVICE pointers, prm = 2 floats per channel:
+ * mode 0 y=x*a+b (brightness_multiply :84-101 / brightness_additive :67-82)
+ * mode 1 y=pow((x-min)/rng,g)*rng+min (gamma :126)      mode 2 y=(x-mean_y)/std_y*std_x+mean_x (:128-130)
+ * mode 3 y=clamp((x-mean)*f+mean,min,max) (contrast :158-161)   mode 4 y=x+noise*std+mean (gaussian_noise :17) */
+int cbim_intensity(const float* x, float* y, int C, int64_t S, int mode, const float* prm,
+                   int prm_per_channel, const float* st, const float* st2, int st_per_channel,
+                   const float* noise, void* stream);
+/* gaussian_blur (augmentation.py:46-64): the dense normalised k^3 Gaussian with zero padding, done as
+ * three 1-D passes with the normalised 1-D kernel g_host[k] (HOST pointer); tmp = one scratch volume. */
+int cbim_gaussian_blur3d(const float* x, float* y, float* tmp, int C, int D, int H, int W,
+                         const float* g_host, int k, void* stream);
+
 /* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);

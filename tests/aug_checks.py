@@ -1,0 +1,61 @@
+"""Augmentation parity: the HIP ops (cbim_amd.training.augmentation) under the seeds of the golden
+fixture produced by the REAL reference functions (tests/golden/make_golden_aug.py)."""
+import numpy as np
+import torch
+
+from tests.golden.make_golden_aug import SEED
+from tests.util import load_golden
+
+
+def _seeded(fn):
+    np.random.seed(SEED)
+    torch.manual_seed(SEED)
+    return fn()
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def run(dev, A=None):
+    if A is None:
+        from cbim_amd.training import augmentation as A
+    g = load_golden("aug_1x1x20x24x28")
+    img = torch.from_numpy(g["img"]).to(dev)
+    lab = torch.from_numpy(g["lab"]).to(dev)
+    res = {}
+    oi, ol = _seeded(lambda: A.random_scale_rotate_translate_3d(img, lab, [0.3, 0.3, 0.3], [30, 30, 30], [0, 0, 0]))
+    res["affine_img"] = _rel(oi.cpu(), g["affine_img"])
+    res["affine_lab_mismatch"] = float((ol.cpu() != torch.from_numpy(g["affine_lab"])).float().mean())
+    assert ol.dtype == torch.int64
+    ci, cl = _seeded(lambda: A.crop_3d(img, lab, [12, 16, 20], mode="random"))
+    assert torch.equal(ci.cpu(), torch.from_numpy(g["crop_img"])) and torch.equal(cl.cpu(), torch.from_numpy(g["crop_lab"]))
+    res["bmul"] = _rel(_seeded(lambda: A.brightness_multiply(img, multiply_range=[0.7, 1.3])).cpu(), g["bmul"])
+    res["badd"] = _rel(_seeded(lambda: A.brightness_additive(img, std=0.1)).cpu(), g["badd"])
+    res["gamma"] = _rel(_seeded(lambda: A.gamma(img.clone(), gamma_range=[0.7, 1.5])).cpu(), g["gamma"])
+    res["contrast"] = _rel(_seeded(lambda: A.contrast(img.clone(), contrast_range=[0.7, 1.3])).cpu(), g["contrast"])
+    res["blur"] = _rel(_seeded(lambda: A.gaussian_blur(img, sigma_range=[0.5, 1.5])).cpu(), g["blur"])
+    res["noise"] = _rel(_seeded(lambda: A.gaussian_noise(img, std=0.05)).cpu(), g["noise"])
+    assert torch.equal(A.mirror(img, axis=1).cpu(), torch.from_numpy(g["mirror1"]))
+    return res
+
+
+def check(res, fused=None):
+    assert res["affine_img"] < 2e-5, res
+    assert res["affine_lab_mismatch"] < 2e-4, res     # nearest-neighbour ties at x.5 under fp32 coordinate rounding
+    for k in ("bmul", "badd", "contrast", "noise"):
+        assert res[k] < 2e-6, (k, res)
+    assert res["gamma"] < 2e-5 and res["blur"] < 2e-5, res
+
+
+def fused_crop(dev):
+    """random_affine_center_crop_3d == random_scale_rotate_translate_3d + crop_3d(center), same seed."""
+    from cbim_amd.training import augmentation as A
+    g = load_golden("aug_1x1x20x24x28")
+    img = torch.from_numpy(g["img"]).to(dev)
+    lab = torch.from_numpy(g["lab"]).to(dev)
+    fi, fl = _seeded(lambda: A.random_affine_center_crop_3d(img, lab, [12, 16, 20], [0.3] * 3, [30] * 3, [0] * 3))
+    oi, ol = _seeded(lambda: A.random_scale_rotate_translate_3d(img, lab, [0.3] * 3, [30] * 3, [0] * 3))
+    ci, cl = A.crop_3d(oi, ol, [12, 16, 20], mode="center")
+    assert torch.equal(fi, ci) and torch.equal(fl, cl)

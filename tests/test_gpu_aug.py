@@ -1,0 +1,12 @@
+"""-m gpu: on-device augmentation parity against the reference goldens through the C ABI."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_augmentation_matches_reference_golden(dev):
+    from tests import aug_checks
+    res = aug_checks.run(dev)
+    print(res)
+    aug_checks.check(res)
+    aug_checks.fused_crop(dev)
