@@ -32,6 +32,7 @@ _SIGS = {
     "cbim_version": (i32, []),
     "cbim_backend": (C.c_char_p, []),
     "cbim_last_error_string": (C.c_char_p, []),
+    "cbim_runtime_warmup": (i32, [vp]),
     "cbim_stats_parts": (i32, [i64, i32]),
     "cbim_instnorm_stats": (i32, [i32, vp, i64, i32, i64, i32, f32, vp, i32, vp, vp]),
     "cbim_stats_finalize": (i32, [vp, i32, i32, i32, f64, f32, i32, vp, vp]),

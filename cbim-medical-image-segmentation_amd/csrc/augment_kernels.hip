@@ -211,6 +211,12 @@ static inline int grid_for(int64_t items) {
 
 using namespace cbim;
 
+static int launch_status(const char* what) {
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "%s launch: %s", what, hipGetErrorString(e));
+  return CBIM_OK;
+}
+
 extern "C" int cbim_affine_sample3d(const float* img, const void* lab, int lab_bytes, const float* theta12,
                                     float* out_img, int64_t* out_lab, int C, int Di, int Hi, int Wi, int Do,
                                     int Ho, int Wo, int od0, int oh0, int ow0, void* stream) {
@@ -223,7 +229,7 @@ extern "C" int cbim_affine_sample3d(const float* img, const void* lab, int lab_b
   p.Do = Do; p.Ho = Ho; p.Wo = Wo; p.od0 = od0; p.oh0 = oh0; p.ow0 = ow0; p.lab_bytes = lab_bytes;
   for (int i = 0; i < 12; ++i) p.th[i] = theta12[i];   // HOST pointer: 12 floats drawn by the host RNG
   CBIM_LAUNCH(k_affine_sample3d, dim3(grid_for((int64_t)Do * Ho * Wo)), dim3(NT), 0, (hipStream_t)stream, p);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return launch_status("affine_sample3d");
 }
 
 extern "C" int cbim_crop3d(const float* img, const void* lab, int lab_bytes, float* out_img, void* out_lab, int C,
@@ -234,7 +240,7 @@ extern "C" int cbim_crop3d(const float* img, const void* lab, int lab_bytes, flo
              "crop window outside the volume");
   CBIM_LAUNCH(k_crop3d, dim3(grid_for((int64_t)Do * Ho * Wo)), dim3(NT), 0, (hipStream_t)stream, img, lab, out_img,
               out_lab, C, Di, Hi, Wi, Do, Ho, Wo, d0, h0, w0, lab_bytes);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 static int stat_blocks(int64_t S) {
@@ -253,7 +259,7 @@ extern "C" int cbim_chan_stats(const float* x, int C, int64_t S, float* stats, v
   hipStream_t st = (hipStream_t)stream;
   CBIM_LAUNCH(k_chan_stats_partial, dim3(nb, C), dim3(NT), 0, st, x, S, (float*)workspace);
   CBIM_LAUNCH(k_chan_stats_final, dim3(C), dim3(64), 0, st, (const float*)workspace, nb, stats);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 extern "C" int cbim_intensity(const float* x, float* y, int C, int64_t S, int mode, const float* prm,
@@ -265,7 +271,7 @@ extern "C" int cbim_intensity(const float* x, float* y, int C, int64_t S, int mo
   CBIM_CHECK(mode != 4 || noise, CBIM_EINVAL, "mode 4 needs noise");
   CBIM_LAUNCH(k_intensity, dim3(grid_for(S), C), dim3(NT), 0, (hipStream_t)stream, x, y, C, S, mode, prm,
               prm_per_channel, st, st2, st_per_channel, noise);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 // y = blur of x ([C][D][H][W]) with the normalised 1-D kernel g[k] along D, H and W; tmp: one more volume
@@ -288,5 +294,5 @@ extern "C" int cbim_gaussian_blur3d(const float* x, float* y, float* tmp, int C,
   // D axis: tmp -> y   (lines: c outer with stride D*H*W, (h,w) inner)
   p.x = tmp; p.y = y; p.len = D; p.stride = (int64_t)H * W; p.inner = (int64_t)H * W; p.outer_stride = S; p.n_lines = (int64_t)C * H * W;
   CBIM_LAUNCH(k_blur_axis, dim3(grid_for(total)), dim3(NT), 0, st, p);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }

@@ -6,10 +6,31 @@
 #pragma once
 #ifdef CBIM_EMU
 #include "hip_emu.h"   // tests/emu: host-side executor used only by the CPU test-suite
+#define CBIM_LAST_LAUNCH() 0
 #else
 #include <hip/hip_runtime.h>
+#include <tuple>
+#include <utility>
+// Launches go through hipLaunchKernel so that the status checked afterwards is the return code of
+// THIS launch (hipGetLastError() is a sticky per-thread value that unrelated runtime calls of the host
+// process can leave set — seen as a spurious "no ROCm-capable device is detected").
+namespace cbim {
+inline thread_local hipError_t g_launch_err = hipSuccess;
+template <typename... P, size_t... I>
+inline hipError_t launch_impl(void (*k)(P...), dim3 g, dim3 b, size_t sh, hipStream_t st, std::tuple<P...>& t,
+                              std::index_sequence<I...>) {
+  void* ptr[sizeof...(P) + 1] = {(void*)&std::get<I>(t)..., nullptr};
+  return hipLaunchKernel((const void*)k, g, b, ptr, sh, st);
+}
+template <typename... P, typename... A>
+inline void launch(void (*k)(P...), dim3 g, dim3 b, size_t sh, hipStream_t st, A&&... a) {
+  std::tuple<P...> t{static_cast<P>(a)...};
+  g_launch_err = launch_impl(k, g, b, sh, st, t, std::index_sequence_for<P...>{});
+}
+}  // namespace cbim
 #define CBIM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-  hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+  cbim::launch(kernel, grid, block, shmem, stream, ##__VA_ARGS__)
+#define CBIM_LAST_LAUNCH() (cbim::g_launch_err)
 #endif
 #include <stdint.h>
 

@@ -734,7 +734,7 @@ static int pack_launch(const cbim_conv_desc* d, const float* w, void* p0, void* 
   else
     CBIM_LAUNCH((k_pack_weights<float>), dim3((unsigned)blocks), dim3(256), 0, st, w, p0, p1, d->Cout, d->Cin, taps,
                 BN0, nch0, t0, BN1, nch1, t1);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 extern "C" int cbim_conv3d_pack_weights(const cbim_conv_desc* d, int mode, const float* w, void* packed,
@@ -784,7 +784,7 @@ static int launch_igemm(const IgemmParams& p, dim3 grid, size_t smem, hipStream_
   }
 #endif
   CBIM_LAUNCH((k_conv_igemm<T, MT, NTL, ACT, K3>), grid, dim3(NT), smem, st, p);
-  hipError_t e = hipGetLastError();
+  hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv igemm launch: %s", hipGetErrorString(e));
   return CBIM_OK;
 }
@@ -874,7 +874,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
       if (relu) CBIM_LAUNCH((k_splitk_finish<float, CBIM_ACT_RELU>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
       else CBIM_LAUNCH((k_splitk_finish<float, -1>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
     }
-    return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
   }
   static const bool k3_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : false;
   const bool k3 = k3_on && d->kH == 3 && d->kW == 3 && c.tH == 8;   // hW == hH == 10: compile-time tap offsets

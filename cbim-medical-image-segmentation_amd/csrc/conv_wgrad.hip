@@ -344,7 +344,7 @@ static int launch_wgrad(const WgradParams& p, dim3 grid, size_t smem, hipStream_
   }
 #endif
   CBIM_LAUNCH((k_conv_wgrad<T, TPW, ACT>), grid, dim3(NT), smem, st, p);
-  hipError_t e = hipGetLastError();
+  hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv wgrad launch: %s", hipGetErrorString(e));
   return CBIM_OK;
 }
@@ -405,5 +405,5 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   if (blocks > 4096) blocks = 4096;
   CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, st, (const float*)workspace, dw,
               d->N * c.strips_per_n, taps, d->Cout, d->Cin, p.Cout_pad, p.Cin_pad, total);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }

@@ -199,7 +199,7 @@ extern "C" int cbim_dice_ce_fwd(const float* logits, const int64_t* labels, cons
   hipStream_t st = (hipStream_t)stream;
   CBIM_LAUNCH(k_dice_ce_fwd, dim3(nb), dim3(NT), 0, st, logits, labels, weight, C, S, total, (float*)workspace);
   CBIM_LAUNCH(k_dice_ce_finalize, dim3(1), dim3(NT), 0, st, (const float*)workspace, nb, C, out, coef);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 extern "C" int cbim_dice_ce_bwd(const float* logits, const int64_t* labels, const float* weight,
@@ -212,5 +212,5 @@ extern "C" int cbim_dice_ce_bwd(const float* logits, const int64_t* labels, cons
   if (b > 256 * 16) b = 256 * 16;
   CBIM_LAUNCH(k_dice_ce_bwd, dim3((unsigned)b), dim3(NT), 0, (hipStream_t)stream, logits, labels, weight, coef,
               grad_out, dlogits, C, S, total);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }

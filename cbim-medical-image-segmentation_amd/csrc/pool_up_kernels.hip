@@ -264,7 +264,7 @@ extern "C" int cbim_maxpool3d_fwd(int dtype, const void* x, void* y, uint8_t* id
   int64_t total = (int64_t)N * Do * Ho * Wo * (C / cpc);
   DISPATCH_T(dtype, k_maxpool_fwd, dim3(grid_for(total)), (hipStream_t)stream, x, y, idx, D, H, W, C, sD, sH,
              sW, Do, Ho, Wo, total);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 extern "C" int cbim_maxpool3d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int D,
@@ -275,7 +275,7 @@ extern "C" int cbim_maxpool3d_bwd(int dtype, const void* dy, const uint8_t* idx,
   int64_t total = (int64_t)N * D * H * W * (C / cpc);
   DISPATCH_T(dtype, k_maxpool_bwd, dim3(grid_for(total)), (hipStream_t)stream, dy, idx, dx, D, H, W, C, sD,
              sH, sW, Do, Ho, Wo, total);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 extern "C" int cbim_upcat_fwd(int dtype, const void* low, const void* skip, void* out, int N, int Dl, int Hl,
@@ -286,7 +286,7 @@ extern "C" int cbim_upcat_fwd(int dtype, const void* low, const void* skip, void
   int64_t total = (int64_t)N * D * H * W * ((Cs + Cl) / cpc);
   DISPATCH_T(dtype, k_upcat_fwd, dim3(grid_for(total)), (hipStream_t)stream, low, skip, out, Dl, Hl, Wl, Cl,
              D, H, W, Cs, skip_first, total);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 extern "C" int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dskip, int N, int Dl, int Hl,
@@ -304,5 +304,5 @@ extern "C" int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dsk
     int64_t t2 = (int64_t)N * D * H * W * (Cs / cpc);
     DISPATCH_T(dtype, k_slice_copy, dim3(grid_for(t2)), st, dout, (int64_t)Ct, skip_lo, dskip, Cs, t2);
   }
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }

@@ -412,7 +412,7 @@ extern "C" int cbim_stem_conv_fwd(int dtype_out, const float* x, const float* w,
   hipStream_t st = (hipStream_t)stream;
   if (dtype_out == CBIM_BF16) CBIM_LAUNCH((k_stem_fwd<bf16_tag>), grid, dim3(NT), smem, st, p);
   else CBIM_LAUNCH((k_stem_fwd<float>), grid, dim3(NT), smem, st, p);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 extern "C" size_t cbim_stem_conv_wgrad_workspace(int N, int Cin, int Cout, int kD, int kH, int kW, int Do,
@@ -439,7 +439,7 @@ extern "C" int cbim_stem_conv_wgrad(int dtype, const float* x, const void* dy, f
   int total = Cin * p.taps * Cout;
   CBIM_LAUNCH(k_stem_wgrad_reduce, dim3((total + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw,
               N * p.strips_per_n, Cin, p.taps, Cout);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 static int head_check(int dtype, int Cin, int K) {
@@ -460,7 +460,7 @@ extern "C" int cbim_head_fwd(int dtype, const void* x, const float* w, const flo
     CBIM_LAUNCH((k_head_fwd<bf16_tag>), dim3(grid_for(total)), dim3(NT), smem, st, x, w, b, logits, S, Cin, K, total);
   else
     CBIM_LAUNCH((k_head_fwd<float>), dim3(grid_for(total)), dim3(NT), smem, st, x, w, b, logits, S, Cin, K, total);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 static int head_bwd_blocks(int64_t S) {
@@ -504,5 +504,5 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
   int npairs = K * (Cin + 1);
   CBIM_LAUNCH(k_head_bwd_reduce, dim3((npairs + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw, db,
               N * nb, Cin, K);
-  return hipGetLastError() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }

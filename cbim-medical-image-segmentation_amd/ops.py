@@ -61,9 +61,17 @@ def _rs(t: torch.Tensor) -> int:
     return int(t.stride(3)) if t.dim() == 5 else int(t.shape[-1])
 
 
+_WARM = False
+
+
 def _stream(t: torch.Tensor):
+    global _WARM
     if t.device.type == "cuda":
-        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        s = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        if not _WARM and not torch.cuda.is_current_stream_capturing():
+            _lib.lib().cbim_runtime_warmup(s)
+            _WARM = True
+        return s
     return None
 
 

@@ -45,6 +45,8 @@ extern "C" {
 int cbim_version(void);
 const char* cbim_backend(void);            /* "hip-gfx950" (product) or "emu" (tests/emu) */
 const char* cbim_last_error_string(void);
+/* One no-op launch (lazy module load) + clears the runtime's sticky error; call once per process. */
+int cbim_runtime_warmup(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * InstanceNorm3d statistics — replaces the statistics half of aten::native_batch_norm reached
