@@ -67,6 +67,18 @@ _SIGS = {
     "cbim_chan_stats": (i32, [vp, i32, i64, vp, vp, sz, vp]),
     "cbim_intensity": (i32, [vp, vp, i32, i64, i32, vp, i32, vp, vp, i32, vp, vp]),
     "cbim_gaussian_blur3d": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+    "cbim_dwconv3d": (i32, [i32, vp, i64, vp, i32, vp, vp, i32, vp, i64] + [i32] * 8 + [vp]),
+    "cbim_dwconv3d_wgrad_workspace": (sz, [i32] * 8),
+    "cbim_dwconv3d_wgrad": (i32, [i32, vp, i64, vp, i32, vp, i64, vp, vp] + [i32] * 8 + [vp, sz, vp]),
+    "cbim_space_to_depth": (i32, [i32, vp, vp] + [i32] * 9 + [vp]),
+    "cbim_bidir_attn_workspace": (sz, [i32] * 5),
+    "cbim_bidir_attn_fwd": (i32, [i32, vp, i64, vp, vp, vp, vp, vp] + [i32] * 5 + [f32, vp, sz, vp]),
+    "cbim_bidir_attn_bwd": (i32, [i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 5 + [f32, vp, sz, vp]),
+    "cbim_colsoftmax_pool_workspace": (sz, [i32] * 4),
+    "cbim_colsoftmax_pool_fwd": (i32, [i32, vp, i64, vp, vp] + [i32] * 4 + [vp, sz, vp]),
+    "cbim_colsoftmax_pool_bwd": (i32, [i32, vp, i64, vp, vp, vp, vp, i64] + [i32] * 4 + [vp]),
+    "cbim_trilinear_planes_fwd": (i32, [vp, vp] + [i32] * 7 + [vp]),
+    "cbim_trilinear_planes_bwd": (i32, [vp, vp] + [i32] * 7 + [vp]),
     "cbim_ncdhw_to_ndhwc": (i32, [i32, vp, vp, i32, i32, i64, vp]),
     "cbim_ndhwc_to_ncdhw": (i32, [i32, vp, vp, i32, i32, i64, vp]),
 }

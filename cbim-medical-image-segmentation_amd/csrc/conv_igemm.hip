@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
         const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
         // scratch: the stage buffer just consumed (NTL=2: 36 KiB) or a dedicated region (NTL=1), so the
         // next halo can be written while other waves are still in their epilogue
-        float* scr = (float*)(smem + (NTL == 1 ? scr_base : b_base + (unsigned)(stage & 1) * stage_bytes) +
+        float* scr = (float*)(smem + ((NTL == 1 || stage_bytes < NW * 4096u) ? scr_base : b_base + (unsigned)(stage & 1) * stage_bytes) +
                               (unsigned)wave * 4096);
         float* red = (float*)(smem + red_base);
         const int cc = lane % OCH;
@@ -829,7 +829,8 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   { const char* e = getenv("CBIM_IGEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   int BN = 32 * c.NTL;
   size_t smem = (size_t)p.hD * p.hH * p.hW * RB + 2 * (size_t)d->kH * d->kW * KG * 2 * BN * 16 +
-                (size_t)NW * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float) + (c.NTL == 1 ? (size_t)NW * 4096 : 0);
+                (size_t)NW * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float) +
+                ((c.NTL == 1 || (size_t)d->kH * d->kW * KG * 2 * BN * 16 < (size_t)NW * 4096) ? (size_t)NW * 4096 : 0);
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "conv tile needs %zu B of LDS", smem);
   int64_t n_tiles = (int64_t)d->N * p.tiles_d * p.tiles_h * p.tiles_w;
   int n_nblk = (d->Cout + BN - 1) / BN;

@@ -1,0 +1,752 @@
+// medformer_kernels.hip — the MedFormer-specific pieces of the model/dim3 hot path.
+//
+//   k_dwconv / k_dwconv_wgrad   depthwise k^3 convolution (DepthwiseSeparableConv.depthwise and the MBConv
+//                               depthwise ConvNormAct, /root/reference/model/dim3/conv_layers.py:126-157,211)
+//                               with the pre-activation InstanceNorm(+act) applied on the input load
+//   k_space_to_depth            PatchMerging's 8 strided slices + channel concat (medformer_utils.py:163-171)
+//   k_attn_fwd / k_attn_bwd     BidirectionAttention core (medformer_utils.py:63-97): logits q_f·q_m^T*scale
+//                               [L x M], row softmax -> feature side, column softmax over all L voxels ->
+//                               map side; one pass over q,v per direction, column softmax merged from
+//                               per-block online-softmax records in a fixed order (deterministic)
+//   k_mappool_fwd / _bwd        SemanticMapGeneration tail (medformer_utils.py:218-228): softmax over L per
+//                               map code + einsum('bij,bkj->bik')
+//
+// All of these are HBM/latency-bound (M=64 codes, d_head=32: ~4 GF per layer); they run on the vector
+// ALUs with the small map-side operands read through the scalar cache (uniform addresses).
+// Layout: feature maps channels-last [N][L][C]; head split is the reference's "(dim_head heads)":
+// channel c = d*heads + h (medformer_utils.py:43-51).  Map-side tensors are float32 [N][M][inner].
+#include "cbim_common.h"
+
+namespace cbim {
+
+static constexpr int NT = 256;
+static constexpr int AT = 128;  // voxels (= threads) per attention block
+static constexpr int MM = 64;   // max map codes
+
+static inline int grid_for(int64_t items) {
+  int64_t b = (items + NT - 1) / NT;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- depthwise convolution ------------------------------------------------------------------------
+// y[n,l,c] = sum_t w[c][t] * a(x[n,l+off(t),c]),  a = act((x-mean)*rstd) when in_stats else x, zero outside
+// the volume; `bias` (float [N][C], optional) is added to in-range inputs (used for dy + dmean/S in the
+// backward); flip=1 uses w[c][T-1-t] (data gradient of a same-padded stride-1 depthwise conv).
+template <typename T>
+__global__ void __launch_bounds__(NT) k_dwconv(const void* __restrict__ x, int64_t xs,
+                                               const float* __restrict__ in_stats, int act,
+                                               const float* __restrict__ bias, const float* __restrict__ w,
+                                               int flip, void* __restrict__ y, int64_t ys, int D, int H, int W,
+                                               int C, int kD, int kH, int kW, int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  const int TT = kD * kH * kW, pD = kD / 2, pH = kH / 2, pW = kW / 2;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int cc = (int)(i % cch);
+    int64_t r = i / cch;
+    int wo = (int)(r % W); r /= W;
+    int ho = (int)(r % H); r /= H;
+    int dz = (int)(r % D);
+    int64_t n = r / D;
+    const int c0 = cc * CPC;
+    float mean[CPC], rstd[CPC], bs[CPC], acc[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      mean[j] = in_stats ? in_stats[((size_t)n * C + c0 + j) * 2] : 0.f;
+      rstd[j] = in_stats ? in_stats[((size_t)n * C + c0 + j) * 2 + 1] : 1.f;
+      bs[j] = bias ? bias[(size_t)n * C + c0 + j] : 0.f;
+      acc[j] = 0.f;
+    }
+    for (int a = 0; a < kD; ++a) {
+      int dd = dz + a - pD;
+      if (dd < 0 || dd >= D) continue;
+      for (int b = 0; b < kH; ++b) {
+        int hh = ho + b - pH;
+        if (hh < 0 || hh >= H) continue;
+        for (int c = 0; c < kW; ++c) {
+          int ww = wo + c - pW;
+          if (ww < 0 || ww >= W) continue;
+          int tap = (a * kH + b) * kW + c;
+          int wt = flip ? TT - 1 - tap : tap;
+          size_t row = (((size_t)n * D + dd) * H + hh) * W + ww;
+          float f[CPC];
+          Elem<T>::unpack(ld_chunk<T>(x, row * xs + c0), f);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) {
+            float v = f[j];
+            if (in_stats) v = act_fwd((v - mean[j]) * rstd[j], act);
+            v += bs[j];
+            acc[j] += v * w[(size_t)(c0 + j) * TT + wt];
+          }
+        }
+      }
+    }
+    size_t orow = (((size_t)n * D + dz) * H + ho) * W + wo;
+    st_chunk<T>(y, orow * ys + c0, Elem<T>::pack(acc));
+  }
+}
+
+// dw[c][t] = sum_{n,l} a(x[n,l+off(t),c]) * (dy[n,l,c] + dy_bias[n,c]).  Thread = (channel chunk, tap);
+// block (bx, by) covers voxels [bx*vpb, +vpb) and chunks [by*G, +G), G = NT / T.  Per-block partial sums
+// go to part[bx][C][T]; k_dwconv_wgrad_reduce adds them in block order (deterministic).
+template <typename T>
+__global__ void __launch_bounds__(NT) k_dwconv_wgrad(const void* __restrict__ x, int64_t xs,
+                                                     const float* __restrict__ in_stats, int act,
+                                                     const void* __restrict__ dy, int64_t dys,
+                                                     const float* __restrict__ dy_bias, float* __restrict__ part,
+                                                     int N, int D, int H, int W, int C, int kD, int kH, int kW,
+                                                     int vpb) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  const int TT = kD * kH * kW, G = NT / TT;
+  const int cl = threadIdx.x / TT, tap = threadIdx.x % TT;
+  const int cc = blockIdx.y * G + cl;
+  if (cl >= G || cc >= cch) return;
+  const int a = tap / (kH * kW) - kD / 2, b = (tap / kW) % kH - kH / 2, c = tap % kW - kW / 2;
+  const int c0 = cc * CPC;
+  const int64_t S = (int64_t)D * H * W, tot = (int64_t)N * S;
+  int64_t v0 = (int64_t)blockIdx.x * vpb, v1 = v0 + vpb;
+  if (v1 > tot) v1 = tot;
+  float acc[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
+  for (int64_t v = v0; v < v1; ++v) {
+    int64_t r = v;
+    int wo = (int)(r % W); r /= W;
+    int ho = (int)(r % H); r /= H;
+    int dz = (int)(r % D);
+    int64_t n = r / D;
+    int dd = dz + a, hh = ho + b, ww = wo + c;
+    if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+    float g[CPC], f[CPC];
+    Elem<T>::unpack(ld_chunk<T>(dy, (size_t)v * dys + c0), g);
+    size_t row = (((size_t)n * D + dd) * H + hh) * W + ww;
+    Elem<T>::unpack(ld_chunk<T>(x, row * xs + c0), f);
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      float xv = f[j];
+      if (in_stats) {
+        float mean = in_stats[((size_t)n * C + c0 + j) * 2], rstd = in_stats[((size_t)n * C + c0 + j) * 2 + 1];
+        xv = act_fwd((xv - mean) * rstd, act);
+      }
+      float gv = g[j] + (dy_bias ? dy_bias[(size_t)n * C + c0 + j] : 0.f);
+      acc[j] += xv * gv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) part[((size_t)blockIdx.x * C + c0 + j) * TT + tap] = acc[j];
+}
+
+__global__ void __launch_bounds__(NT) k_dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
+                                                            int nblk, int CT) {
+  int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= CT) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * CT + i];
+  dw[i] = s;
+}
+
+// ---- PatchMerging gather ---------------------------------------------------------------------------
+// merged[n,d',h',w', ((i*sH+j)*sW+k)*C + c] = x[n, d'*sD+i, h'*sH+j, w'*sW+k, c]; inverse=1 copies back.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_space_to_depth(const void* __restrict__ src, void* __restrict__ dst,
+                                                       int D, int H, int W, int C, int sD, int sH, int sW,
+                                                       int inverse, int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int Do = D / sD, Ho = H / sH, Wo = W / sW;
+  const int Cm = C * sD * sH * sW, mch = Cm / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int mc = (int)(i % mch);
+    int64_t r = i / mch;
+    int wo = (int)(r % Wo); r /= Wo;
+    int ho = (int)(r % Ho); r /= Ho;
+    int dz = (int)(r % Do);
+    int64_t n = r / Do;
+    int cm = mc * CPC, oct = cm / C, c = cm % C;
+    int kk = oct % sW, jj = (oct / sW) % sH, ii = oct / (sW * sH);
+    size_t xrow = (((size_t)n * D + dz * sD + ii) * H + ho * sH + jj) * W + wo * sW + kk;
+    size_t mrow = (((size_t)n * Do + dz) * Ho + ho) * Wo + wo;
+    if (inverse)
+      st_chunk<T>(dst, xrow * C + c, ld_chunk<T>(src, mrow * Cm + cm));
+    else
+      st_chunk<T>(dst, mrow * Cm + cm, ld_chunk<T>(src, xrow * C + c));
+  }
+}
+
+// ---- bidirectional attention ------------------------------------------------------------------------
+// part record per (n, h, block, j): [colmax, colsum, acc[DH]]
+template <typename T, int DH>
+__global__ void __launch_bounds__(AT) k_attn_fwd(const void* __restrict__ qv, int64_t rs,
+                                                 const float* __restrict__ mq, const float* __restrict__ mv,
+                                                 void* __restrict__ fo, float* __restrict__ part, int L, int heads,
+                                                 int M, float scale, int nblk) {
+  __shared__ float E_s[AT][MM + 1];
+  __shared__ float v_s[AT][DH + 1];
+  __shared__ float red[2][MM];
+  __shared__ float colm[MM];
+  const int t = threadIdx.x, blk = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  const int inner = heads * DH;
+  const int l = blk * AT + t;
+  const bool valid = l < L;
+  const size_t row = ((size_t)n * L + (valid ? l : 0)) * rs;
+  float q[DH], v[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    q[d] = valid ? Elem<T>::load1(qv, row + d * heads + h) : 0.f;
+    v[d] = valid ? Elem<T>::load1(qv, row + inner + d * heads + h) : 0.f;
+  }
+  const float* mqh = mq + (size_t)n * M * inner + h;
+  const float* mvh = mv + (size_t)n * M * inner + h;
+  float a[MM];
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    float s = -INFINITY;
+    if (j < M) {
+      s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) s += q[d] * mqh[(size_t)j * inner + d * heads];
+      s *= scale;
+    }
+    a[j] = s;
+  }
+  // feature side: softmax over the M codes of this voxel
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MM; ++j) mx = fmaxf(mx, a[j]);
+  float sum = 0.f, o[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    if (j < M) {
+      float e = expf(a[j] - mx);
+      sum += e;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) o[d] += e * mvh[(size_t)j * inner + d * heads];
+    }
+  }
+  if (valid) {
+    float inv = 1.f / sum;
+    size_t orow = ((size_t)n * L + l) * inner;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) Elem<T>::store1(fo, orow + d * heads + h, o[d] * inv);
+  }
+  // map side: online-softmax record of this block's AT voxels per code
+#pragma unroll
+  for (int j = 0; j < MM; ++j) E_s[t][j] = valid ? a[j] : -INFINITY;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) v_s[t][d] = v[d];
+  __syncthreads();
+  {
+    int j = t & 63, hf = t >> 6;
+    float m = -INFINITY;
+    for (int r = 0; r < 64; ++r) m = fmaxf(m, E_s[hf * 64 + r][j]);
+    red[hf][j] = m;
+  }
+  __syncthreads();
+  if (t < MM) colm[t] = fmaxf(red[0][t], red[1][t]);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < MM; ++j) E_s[t][j] = (valid && j < M) ? expf(a[j] - colm[j]) : 0.f;
+  __syncthreads();
+  {
+    constexpr int HD = DH / 2;
+    int j = t >> 1, d0 = (t & 1) * HD;
+    float acc[HD], s = 0.f;
+#pragma unroll
+    for (int k = 0; k < HD; ++k) acc[k] = 0.f;
+    for (int r = 0; r < AT; ++r) {
+      float e = E_s[r][j];
+      s += e;
+#pragma unroll
+      for (int k = 0; k < HD; ++k) acc[k] += e * v_s[r][d0 + k];
+    }
+    if (j < M) {
+      float* p = part + ((((size_t)n * heads + h) * nblk + blk) * M + j) * (DH + 2);
+      if ((t & 1) == 0) { p[0] = colm[j]; p[1] = s; }
+#pragma unroll
+      for (int k = 0; k < HD; ++k) p[2 + d0 + k] = acc[k];
+    }
+  }
+}
+
+// merge the per-block records: map_out[n][j][d*heads+h], colstat[n][h][j] = (max, sum)
+__global__ void __launch_bounds__(NT) k_attn_merge(const float* __restrict__ part, float* __restrict__ map_out,
+                                                   float* __restrict__ colstat, int heads, int M, int DH, int nblk) {
+  const int h = blockIdx.x % heads, n = blockIdx.x / heads;
+  const int inner = heads * DH;
+  const float* base = part + ((size_t)n * heads + h) * nblk * M * (DH + 2);
+  for (int idx = threadIdx.x; idx < M * DH; idx += NT) {
+    int j = idx / DH, d = idx % DH;
+    float mx = -INFINITY;
+    for (int b = 0; b < nblk; ++b) mx = fmaxf(mx, base[((size_t)b * M + j) * (DH + 2)]);
+    float S = 0.f, A = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+      const float* p = base + ((size_t)b * M + j) * (DH + 2);
+      float sc = expf(p[0] - mx);
+      S += p[1] * sc;
+      A += p[2 + d] * sc;
+    }
+    map_out[((size_t)n * M + j) * inner + d * heads + h] = A / S;
+    if (d == 0) {
+      colstat[(((size_t)n * heads + h) * M + j) * 2] = mx;
+      colstat[(((size_t)n * heads + h) * M + j) * 2 + 1] = S;
+    }
+  }
+}
+
+// backward: part record per (n, h, block): [2][M][DH] = (dmv partial, dmq partial)
+template <typename T, int DH>
+__global__ void __launch_bounds__(AT) k_attn_bwd(const void* __restrict__ qv, int64_t rs,
+                                                 const float* __restrict__ mq, const float* __restrict__ mv,
+                                                 const float* __restrict__ colstat, const float* __restrict__ map_out,
+                                                 const void* __restrict__ dfo, const float* __restrict__ dmo,
+                                                 void* __restrict__ dqv, float* __restrict__ part, int L, int heads,
+                                                 int M, float scale, int nblk) {
+  __shared__ float A_s[AT][MM + 1];
+  __shared__ float B_s[AT][DH + 1];
+  __shared__ float cj[MM], cM[MM], cIS[MM];
+  const int t = threadIdx.x, blk = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  const int inner = heads * DH;
+  const int l = blk * AT + t;
+  const bool valid = l < L;
+  const size_t row = ((size_t)n * L + (valid ? l : 0)) * rs;
+  const size_t grow = ((size_t)n * L + (valid ? l : 0)) * inner;
+  float q[DH], v[DH], g[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    q[d] = valid ? Elem<T>::load1(qv, row + d * heads + h) : 0.f;
+    v[d] = valid ? Elem<T>::load1(qv, row + inner + d * heads + h) : 0.f;
+    g[d] = valid ? Elem<T>::load1(dfo, grow + d * heads + h) : 0.f;
+  }
+  const float* mqh = mq + (size_t)n * M * inner + h;
+  const float* mvh = mv + (size_t)n * M * inner + h;
+  const float* dmh = dmo + (size_t)n * M * inner + h;
+  const float* moh = map_out + (size_t)n * M * inner + h;
+  if (t < MM) {
+    float c = 0.f, m = 0.f, is = 0.f;
+    if (t < M) {
+      for (int d = 0; d < DH; ++d) c += moh[(size_t)t * inner + d * heads] * dmh[(size_t)t * inner + d * heads];
+      m = colstat[(((size_t)n * heads + h) * M + t) * 2];
+      is = 1.f / colstat[(((size_t)n * heads + h) * M + t) * 2 + 1];
+    }
+    cj[t] = c; cM[t] = m; cIS[t] = is;
+  }
+  __syncthreads();
+  float a[MM], dA[MM], dv[DH], dq[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) { dv[d] = 0.f; dq[d] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    float s = -INFINITY, da = 0.f;
+    if (j < M) {
+      s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) s += q[d] * mqh[(size_t)j * inner + d * heads];
+      s *= scale;
+      // map side: P2 = exp(a - colmax)/colsum; dA2 = P2*(v.dmo_j - <map_out_j, dmo_j>)
+      float p2 = expf(s - cM[j]) * cIS[j], dp2 = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        float w = dmh[(size_t)j * inner + d * heads];
+        dp2 += v[d] * w;
+        dv[d] += p2 * w;
+      }
+      da = p2 * (dp2 - cj[j]);
+    }
+    a[j] = s;
+    dA[j] = da;
+  }
+  // feature side: P1 = row softmax; dA1 = P1*(g.mv_j - sum_j P1 g.mv_j)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MM; ++j) mx = fmaxf(mx, a[j]);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < MM; ++j) { a[j] = j < M ? expf(a[j] - mx) : 0.f; sum += a[j]; }
+  float inv = 1.f / sum, rr = 0.f;
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    a[j] *= inv;
+    float dp = 0.f;
+    if (j < M) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dp += g[d] * mvh[(size_t)j * inner + d * heads];
+    }
+    A_s[t][j] = dp;  // own row only
+    rr += a[j] * dp;
+  }
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    dA[j] += a[j] * (A_s[t][j] - rr);
+    if (j < M) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dq[d] += dA[j] * mqh[(size_t)j * inner + d * heads];
+    }
+  }
+  if (valid) {
+    size_t drow = ((size_t)n * L + l) * (2 * inner);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      Elem<T>::store1(dqv, drow + d * heads + h, dq[d] * scale);
+      Elem<T>::store1(dqv, drow + inner + d * heads + h, dv[d]);
+    }
+  }
+  float* pbase = part + (((size_t)n * heads + h) * nblk + blk) * 2 * M * DH;
+  constexpr int HD = DH / 2;
+  for (int stage = 0; stage < 2; ++stage) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MM; ++j) A_s[t][j] = stage == 0 ? a[j] : dA[j] * scale;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) B_s[t][d] = stage == 0 ? g[d] : q[d];
+    __syncthreads();
+    int j = t >> 1, d0 = (t & 1) * HD;
+    float acc[HD];
+#pragma unroll
+    for (int k = 0; k < HD; ++k) acc[k] = 0.f;
+    for (int r = 0; r < AT; ++r) {
+      float e = A_s[r][j];
+#pragma unroll
+      for (int k = 0; k < HD; ++k) acc[k] += e * B_s[r][d0 + k];
+    }
+    if (j < M) {
+#pragma unroll
+      for (int k = 0; k < HD; ++k) pbase[((size_t)stage * M + j) * DH + d0 + k] = acc[k];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_attn_bwd_reduce(const float* __restrict__ part, float* __restrict__ dmq,
+                                                        float* __restrict__ dmv, int heads, int M, int DH, int nblk) {
+  const int h = blockIdx.x % heads, n = blockIdx.x / heads;
+  const int inner = heads * DH;
+  const float* base = part + ((size_t)n * heads + h) * nblk * 2 * M * DH;
+  for (int idx = threadIdx.x; idx < 2 * M * DH; idx += NT) {
+    int st = idx / (M * DH), j = (idx / DH) % M, d = idx % DH;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += base[(size_t)b * 2 * M * DH + idx];
+    (st == 0 ? dmv : dmq)[((size_t)n * M + j) * inner + d * heads + h] = s;
+  }
+}
+
+// ---- semantic map generation: column softmax over L + pooling ---------------------------------------
+// fw rows = [feat (C) | weight logits (M)]; part record per (n, block): [M][2 + C]
+template <typename T>
+__global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw, int64_t rs, float* __restrict__ part,
+                                                    int L, int C, int M, int nblk) {
+  __shared__ float E_s[AT][MM + 1];
+  __shared__ float f_s[AT][33];
+  __shared__ float red[2][MM];
+  __shared__ float colm[MM];
+  const int t = threadIdx.x, blk = blockIdx.x, n = blockIdx.z;
+  const int l = blk * AT + t;
+  const bool valid = l < L;
+  const size_t row = ((size_t)n * L + (valid ? l : 0)) * rs;
+  for (int j = 0; j < MM; ++j) E_s[t][j] = (valid && j < M) ? Elem<T>::load1(fw, row + C + j) : -INFINITY;
+  __syncthreads();
+  {
+    int j = t & 63, hf = t >> 6;
+    float m = -INFINITY;
+    for (int r = 0; r < 64; ++r) m = fmaxf(m, E_s[hf * 64 + r][j]);
+    red[hf][j] = m;
+  }
+  __syncthreads();
+  if (t < MM) colm[t] = fmaxf(red[0][t], red[1][t]);
+  __syncthreads();
+  for (int j = 0; j < MM; ++j) E_s[t][j] = (valid && j < M) ? expf(E_s[t][j] - colm[j]) : 0.f;
+  __syncthreads();
+  float* pb = part + ((size_t)n * nblk + blk) * M * (2 + C);
+  {
+    int j = t & 63, hf = t >> 6;
+    float s = 0.f;
+    for (int r = 0; r < 64; ++r) s += E_s[hf * 64 + r][j];
+    red[hf][j] = s;
+  }
+  __syncthreads();
+  if (t < M) { pb[(size_t)t * (2 + C)] = colm[t]; pb[(size_t)t * (2 + C) + 1] = red[0][t] + red[1][t]; }
+  const int jq = t & 15, cq = t >> 4;  // 4 codes x 4 channels per thread
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    __syncthreads();
+    for (int k = 0; k < 32; ++k) f_s[t][k] = (valid && c0 + k < C) ? Elem<T>::load1(fw, row + c0 + k) : 0.f;
+    __syncthreads();
+    float acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc[u][w] = 0.f;
+    for (int r = 0; r < AT; ++r) {
+      float e[4], f[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { e[u] = E_s[r][jq * 4 + u]; f[u] = f_s[r][cq * 4 + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[u][w] += e[u] * f[w];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int j = jq * 4 + u, c = c0 + cq * 4 + w;
+        if (j < M && c < C) pb[(size_t)j * (2 + C) + 2 + c] = acc[u][w];
+      }
+  }
+}
+
+// map[n][c][j], colstat[n][j] = (max, sum)
+__global__ void __launch_bounds__(NT) k_mappool_merge(const float* __restrict__ part, float* __restrict__ map,
+                                                      float* __restrict__ colstat, int C, int M, int nblk) {
+  const int n = blockIdx.y;
+  const float* base = part + (size_t)n * nblk * M * (2 + C);
+  for (int idx = blockIdx.x * NT + threadIdx.x; idx < C * M; idx += gridDim.x * NT) {
+    int c = idx / M, j = idx % M;
+    float mx = -INFINITY;
+    for (int b = 0; b < nblk; ++b) mx = fmaxf(mx, base[((size_t)b * M + j) * (2 + C)]);
+    float S = 0.f, A = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+      const float* p = base + ((size_t)b * M + j) * (2 + C);
+      float sc = expf(p[0] - mx);
+      S += p[1] * sc;
+      A += p[2 + c] * sc;
+    }
+    map[((size_t)n * C + c) * M + j] = A / S;
+    if (c == 0) { colstat[((size_t)n * M + j) * 2] = mx; colstat[((size_t)n * M + j) * 2 + 1] = S; }
+  }
+}
+
+// dfeat[l,c] = sum_j P[l,j] dmap[c,j];  dlogit[l,j] = P[l,j] (sum_c feat[l,c] dmap[c,j] - <map_j, dmap_j>)
+template <typename T>
+__global__ void __launch_bounds__(AT) k_mappool_bwd(const void* __restrict__ fw, int64_t rs,
+                                                    const float* __restrict__ map, const float* __restrict__ colstat,
+                                                    const float* __restrict__ dmap, void* __restrict__ dfw, int64_t drs,
+                                                    int L, int C, int M) {
+  __shared__ float cj[MM];
+  const int t = threadIdx.x, n = blockIdx.z;
+  const int l = blockIdx.x * AT + t;
+  const bool valid = l < L;
+  if (t < MM) {
+    float c = 0.f;
+    if (t < M)
+      for (int k = 0; k < C; ++k) c += map[((size_t)n * C + k) * M + t] * dmap[((size_t)n * C + k) * M + t];
+    cj[t] = c;
+  }
+  __syncthreads();
+  if (!valid) return;
+  const size_t row = ((size_t)n * L + l) * rs, drow = ((size_t)n * L + l) * drs;
+  float P[MM], tt[MM];
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    P[j] = j < M ? expf(Elem<T>::load1(fw, row + C + j) - colstat[((size_t)n * M + j) * 2]) /
+                       colstat[((size_t)n * M + j) * 2 + 1]
+                 : 0.f;
+    tt[j] = 0.f;
+  }
+  for (int c = 0; c < C; ++c) {
+    float f = Elem<T>::load1(fw, row + c), gsum = 0.f;
+    const float* dm = dmap + ((size_t)n * C + c) * M;
+#pragma unroll
+    for (int j = 0; j < MM; ++j)
+      if (j < M) { tt[j] += f * dm[j]; gsum += P[j] * dm[j]; }
+    Elem<T>::store1(dfw, drow + c, gsum);
+  }
+#pragma unroll
+  for (int j = 0; j < MM; ++j)
+    if (j < M) Elem<T>::store1(dfw, drow + C + j, P[j] * (tt[j] - cj[j]));
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+#define DISPATCH_T(dtype, KERNEL, grid, st, ...)                                        \
+  do {                                                                                  \
+    if ((dtype) == CBIM_BF16)                                                           \
+      CBIM_LAUNCH((KERNEL<bf16_tag>), grid, dim3(NT), 0, st, __VA_ARGS__);              \
+    else                                                                                \
+      CBIM_LAUNCH((KERNEL<float>), grid, dim3(NT), 0, st, __VA_ARGS__);                 \
+  } while (0)
+
+static int launch_ok(const char* what) {
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "%s launch: %s", what, hipGetErrorString(e));
+  return CBIM_OK;
+}
+
+static int check_c(int dtype, int C, const char* what) {
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  CBIM_CHECK(C > 0 && C % cpc == 0, CBIM_EUNSUPPORTED, "%s channel count %d is not a multiple of %d", what, C, cpc);
+  return 0;
+}
+
+static int check_k(int kD, int kH, int kW) {
+  CBIM_CHECK(kD >= 1 && kH >= 1 && kW >= 1 && (kD & 1) && (kH & 1) && (kW & 1) && kD * kH * kW <= NT, CBIM_EUNSUPPORTED,
+             "depthwise kernel %dx%dx%d unsupported (odd extents, <= %d taps)", kD, kH, kW, NT);
+  return 0;
+}
+
+extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const float* in_stats, int act,
+                             const float* bias, const float* w, int flip, void* y, int64_t y_stride, int N, int D,
+                             int H, int W, int C, int kD, int kH, int kW, void* stream) {
+  if (int e = check_c(dtype, C, "dwconv")) return e;
+  if (int e = check_k(kD, kH, kW)) return e;
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * D * H * W * (C / cpc);
+  DISPATCH_T(dtype, k_dwconv, dim3(grid_for(total)), (hipStream_t)stream, x, x_stride, in_stats, act, bias, w, flip, y,
+             y_stride, D, H, W, C, kD, kH, kW, total);
+  return launch_ok("dwconv3d");
+}
+
+static void dw_wgrad_cfg(int64_t vox, int* nblk, int* vpb) {
+  int64_t b = (vox + 255) / 256;  // >= 256 voxels per block
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  *vpb = (int)((vox + b - 1) / b);
+  *nblk = (int)((vox + *vpb - 1) / *vpb);
+}
+
+extern "C" size_t cbim_dwconv3d_wgrad_workspace(int N, int D, int H, int W, int C, int kD, int kH, int kW) {
+  int nblk, vpb;
+  dw_wgrad_cfg((int64_t)N * D * H * W, &nblk, &vpb);
+  return (size_t)nblk * C * kD * kH * kW * sizeof(float);
+}
+
+extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, const float* in_stats, int act,
+                                   const void* dy, int64_t dy_stride, const float* dy_bias, float* dw, int N, int D,
+                                   int H, int W, int C, int kD, int kH, int kW, void* workspace, size_t ws_bytes,
+                                   void* stream) {
+  if (int e = check_c(dtype, C, "dwconv wgrad")) return e;
+  if (int e = check_k(kD, kH, kW)) return e;
+  CBIM_CHECK(workspace && ws_bytes >= cbim_dwconv3d_wgrad_workspace(N, D, H, W, C, kD, kH, kW), CBIM_EWORKSPACE,
+             "dwconv wgrad workspace too small");
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int nblk, vpb;
+  dw_wgrad_cfg((int64_t)N * D * H * W, &nblk, &vpb);
+  int TT = kD * kH * kW, G = NT / TT, cch = C / cpc;
+  dim3 grid(nblk, (cch + G - 1) / G);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, k_dwconv_wgrad, grid, st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias, (float*)workspace, N,
+             D, H, W, C, kD, kH, kW, vpb);
+  if (int e = launch_ok("dwconv3d_wgrad")) return e;
+  CBIM_LAUNCH(k_dwconv_wgrad_reduce, dim3((C * TT + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw, nblk,
+              C * TT);
+  return launch_ok("dwconv3d_wgrad_reduce");
+}
+
+extern "C" int cbim_space_to_depth(int dtype, const void* src, void* dst, int N, int D, int H, int W, int C, int sD,
+                                   int sH, int sW, int inverse, void* stream) {
+  if (int e = check_c(dtype, C, "space_to_depth")) return e;
+  CBIM_CHECK(sD >= 1 && sH >= 1 && sW >= 1 && D % sD == 0 && H % sH == 0 && W % sW == 0, CBIM_EINVAL,
+             "space_to_depth: %dx%dx%d not divisible by %dx%dx%d", D, H, W, sD, sH, sW);
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * D * H * W * (C / cpc);
+  DISPATCH_T(dtype, k_space_to_depth, dim3(grid_for(total)), (hipStream_t)stream, src, dst, D, H, W, C, sD, sH, sW,
+             inverse, total);
+  return launch_ok("space_to_depth");
+}
+
+static int attn_check(int dtype, int L, int heads, int dh, int M) {
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
+  CBIM_CHECK(dh == 8 || dh == 16 || dh == 32, CBIM_EUNSUPPORTED, "attention dim_head %d (supported: 8, 16, 32)", dh);
+  CBIM_CHECK(M >= 1 && M <= MM, CBIM_EUNSUPPORTED, "attention map codes %d (supported: 1..%d)", M, MM);
+  CBIM_CHECK(L >= 1 && heads >= 1 && heads <= 65535, CBIM_EINVAL, "bad attention extents");
+  return 0;
+}
+
+extern "C" size_t cbim_bidir_attn_workspace(int N, int L, int heads, int dh, int M) {
+  size_t nblk = (size_t)(L + AT - 1) / AT;
+  size_t fwd = (size_t)N * heads * nblk * M * (dh + 2), bwd = (size_t)N * heads * nblk * 2 * M * dh;
+  return (fwd > bwd ? fwd : bwd) * sizeof(float);
+}
+
+#define ATTN_DISPATCH(KERNEL, grid, st, ...)                                                           \
+  do {                                                                                                 \
+    if (dtype == CBIM_BF16) {                                                                          \
+      if (dh == 32) CBIM_LAUNCH((KERNEL<bf16_tag, 32>), grid, dim3(AT), 0, st, __VA_ARGS__);           \
+      else if (dh == 16) CBIM_LAUNCH((KERNEL<bf16_tag, 16>), grid, dim3(AT), 0, st, __VA_ARGS__);      \
+      else CBIM_LAUNCH((KERNEL<bf16_tag, 8>), grid, dim3(AT), 0, st, __VA_ARGS__);                     \
+    } else {                                                                                           \
+      if (dh == 32) CBIM_LAUNCH((KERNEL<float, 32>), grid, dim3(AT), 0, st, __VA_ARGS__);              \
+      else if (dh == 16) CBIM_LAUNCH((KERNEL<float, 16>), grid, dim3(AT), 0, st, __VA_ARGS__);         \
+      else CBIM_LAUNCH((KERNEL<float, 8>), grid, dim3(AT), 0, st, __VA_ARGS__);                        \
+    }                                                                                                  \
+  } while (0)
+
+extern "C" int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
+                                   void* feat_out, float* map_out, float* colstat, int N, int L, int heads, int dh,
+                                   int M, float scale, void* workspace, size_t ws_bytes, void* stream) {
+  if (int e = attn_check(dtype, L, heads, dh, M)) return e;
+  CBIM_CHECK(workspace && ws_bytes >= cbim_bidir_attn_workspace(N, L, heads, dh, M), CBIM_EWORKSPACE,
+             "attention workspace too small");
+  int nblk = (L + AT - 1) / AT;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nblk, heads, N);
+  ATTN_DISPATCH(k_attn_fwd, grid, st, qv, qv_stride, mq, mv, feat_out, (float*)workspace, L, heads, M, scale, nblk);
+  if (int e = launch_ok("bidir_attn_fwd")) return e;
+  CBIM_LAUNCH(k_attn_merge, dim3(N * heads), dim3(NT), 0, st, (const float*)workspace, map_out, colstat, heads, M, dh,
+              nblk);
+  return launch_ok("bidir_attn_merge");
+}
+
+extern "C" int cbim_bidir_attn_bwd(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
+                                   const float* colstat, const float* map_out, const void* d_feat_out,
+                                   const float* d_map_out, void* d_qv, float* d_mq, float* d_mv, int N, int L,
+                                   int heads, int dh, int M, float scale, void* workspace, size_t ws_bytes,
+                                   void* stream) {
+  if (int e = attn_check(dtype, L, heads, dh, M)) return e;
+  CBIM_CHECK(workspace && ws_bytes >= cbim_bidir_attn_workspace(N, L, heads, dh, M), CBIM_EWORKSPACE,
+             "attention workspace too small");
+  int nblk = (L + AT - 1) / AT;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nblk, heads, N);
+  ATTN_DISPATCH(k_attn_bwd, grid, st, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out, d_map_out, d_qv,
+                (float*)workspace, L, heads, M, scale, nblk);
+  if (int e = launch_ok("bidir_attn_bwd")) return e;
+  CBIM_LAUNCH(k_attn_bwd_reduce, dim3(N * heads), dim3(NT), 0, st, (const float*)workspace, d_mq, d_mv, heads, M, dh,
+              nblk);
+  return launch_ok("bidir_attn_bwd_reduce");
+}
+
+extern "C" size_t cbim_colsoftmax_pool_workspace(int N, int L, int C, int M) {
+  size_t nblk = (size_t)(L + AT - 1) / AT;
+  return (size_t)N * nblk * M * (2 + C) * sizeof(float);
+}
+
+extern "C" int cbim_colsoftmax_pool_fwd(int dtype, const void* fw, int64_t fw_stride, float* map, float* colstat,
+                                        int N, int L, int C, int M, void* workspace, size_t ws_bytes, void* stream) {
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
+  CBIM_CHECK(M >= 1 && M <= MM && C >= 1 && L >= 1, CBIM_EUNSUPPORTED, "colsoftmax_pool: M=%d C=%d L=%d", M, C, L);
+  CBIM_CHECK(workspace && ws_bytes >= cbim_colsoftmax_pool_workspace(N, L, C, M), CBIM_EWORKSPACE,
+             "colsoftmax_pool workspace too small");
+  int nblk = (L + AT - 1) / AT;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nblk, 1, N);
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_mappool_fwd<bf16_tag>), grid, dim3(AT), 0, st, fw, fw_stride, (float*)workspace, L, C, M, nblk);
+  else
+    CBIM_LAUNCH((k_mappool_fwd<float>), grid, dim3(AT), 0, st, fw, fw_stride, (float*)workspace, L, C, M, nblk);
+  if (int e = launch_ok("colsoftmax_pool_fwd")) return e;
+  int gb = (C * M + NT - 1) / NT;
+  CBIM_LAUNCH(k_mappool_merge, dim3(gb, N), dim3(NT), 0, st, (const float*)workspace, map, colstat, C, M, nblk);
+  return launch_ok("colsoftmax_pool_merge");
+}
+
+extern "C" int cbim_colsoftmax_pool_bwd(int dtype, const void* fw, int64_t fw_stride, const float* map,
+                                        const float* colstat, const float* dmap, void* dfw, int64_t dfw_stride, int N,
+                                        int L, int C, int M, void* stream) {
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
+  CBIM_CHECK(M >= 1 && M <= MM && C >= 1 && L >= 1, CBIM_EUNSUPPORTED, "colsoftmax_pool: M=%d C=%d L=%d", M, C, L);
+  int nblk = (L + AT - 1) / AT;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nblk, 1, N);
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_mappool_bwd<bf16_tag>), grid, dim3(AT), 0, st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, L,
+                C, M);
+  else
+    CBIM_LAUNCH((k_mappool_bwd<float>), grid, dim3(AT), 0, st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, L, C,
+                M);
+  return launch_ok("colsoftmax_pool_bwd");
+}

@@ -228,6 +228,75 @@ __global__ void __launch_bounds__(NT) k_slice_copy(const void* __restrict__ src,
   }
 }
 
+
+// ---- trilinear(align_corners=True) resize of float32 NCDHW planes ---------------------------------
+// MedFormer's auxiliary head: F.interpolate(aux_out, size=x.shape[-3:], 'trilinear', align_corners=True)
+// (/root/reference/model/dim3/medformer.py:91).  One work item = one output (fwd) / input (bwd) element.
+__global__ void __launch_bounds__(NT) k_trilinear_planes_fwd(const float* __restrict__ x, float* __restrict__ y,
+                                                             int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                             int64_t total) {
+  const float sd = lin_scale(Di, Do), sh = lin_scale(Hi, Ho), sw = lin_scale(Wi, Wo);
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int64_t q = i;
+    int w = (int)(q % Wo); q /= Wo;
+    int h = (int)(q % Ho); q /= Ho;
+    int d = (int)(q % Do);
+    int64_t pl = q / Do;
+    Lin ld = lin_src(d, sd, Di), lh = lin_src(h, sh, Hi), lw = lin_src(w, sw, Wi);
+    const float* p = x + (size_t)pl * Di * Hi * Wi;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int dd = a ? ld.i1 : ld.i0;
+      float wa = a ? ld.l1 : ld.l0, pa = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        int hh = b ? lh.i1 : lh.i0;
+        float wb = b ? lh.l1 : lh.l0;
+        const float* r = p + ((size_t)dd * Hi + hh) * Wi;
+        pa += wb * (lw.l0 * r[lw.i0] + lw.l1 * r[lw.i1]);
+      }
+      acc += wa * pa;
+    }
+    y[i] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_trilinear_planes_bwd(const float* __restrict__ dy, float* __restrict__ dx,
+                                                             int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                             int64_t total) {
+  const float sd = lin_scale(Di, Do), sh = lin_scale(Hi, Ho), sw = lin_scale(Wi, Wo);
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int64_t q = i;
+    int wl = (int)(q % Wi); q /= Wi;
+    int hl = (int)(q % Hi); q /= Hi;
+    int dl = (int)(q % Di);
+    int64_t pl = q / Di;
+    int d0, d1, h0, h1, w0, w1;
+    dst_range(dl, sd, Do, d0, d1);
+    dst_range(hl, sh, Ho, h0, h1);
+    dst_range(wl, sw, Wo, w0, w1);
+    const float* p = dy + (size_t)pl * Do * Ho * Wo;
+    float acc = 0.f;
+    for (int d = d0; d <= d1; ++d) {
+      float wd = lin_weight_to(d, sd, Di, dl);
+      if (wd == 0.f) continue;
+      for (int h = h0; h <= h1; ++h) {
+        float wh = lin_weight_to(h, sh, Hi, hl);
+        if (wh == 0.f) continue;
+        const float* r = p + ((size_t)d * Ho + h) * Wo;
+        float rowacc = 0.f;
+        for (int w = w0; w <= w1; ++w) {
+          float ww = lin_weight_to(w, sw, Wi, wl);
+          if (ww != 0.f) rowacc += ww * r[w];
+        }
+        acc += wd * wh * rowacc;
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
 static inline int grid_for(int64_t items) {
   int64_t b = (items + NT - 1) / NT;
   if (b > 256 * 16) b = 256 * 16;
@@ -304,5 +373,25 @@ extern "C" int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dsk
     int64_t t2 = (int64_t)N * D * H * W * (Cs / cpc);
     DISPATCH_T(dtype, k_slice_copy, dim3(grid_for(t2)), st, dout, (int64_t)Ct, skip_lo, dskip, Cs, t2);
   }
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_trilinear_planes_fwd(const float* x, float* y, int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                                         int Wo, void* stream) {
+  CBIM_CHECK(planes >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && Do >= 1 && Ho >= 1 && Wo >= 1, CBIM_EINVAL,
+             "trilinear: empty extent");
+  int64_t total = (int64_t)planes * Do * Ho * Wo;
+  CBIM_LAUNCH(k_trilinear_planes_fwd, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, x, y, Di, Hi, Wi, Do, Ho,
+              Wo, total);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_trilinear_planes_bwd(const float* dy, float* dx, int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                                         int Wo, void* stream) {
+  CBIM_CHECK(planes >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && Do >= 1 && Ho >= 1 && Wo >= 1, CBIM_EINVAL,
+             "trilinear: empty extent");
+  int64_t total = (int64_t)planes * Di * Hi * Wi;
+  CBIM_LAUNCH(k_trilinear_planes_bwd, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, dy, dx, Di, Hi, Wi, Do,
+              Ho, Wo, total);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }

@@ -409,3 +409,127 @@ def ndhwc_to_ncdhw(x: torch.Tensor):
     y = torch.empty((N, Cc) + tuple(x.shape[1:-1]), dtype=torch.float32, device=x.device)
     check(_lib.lib().cbim_ndhwc_to_ncdhw(_dt(x), _p(x), _p(y), N, Cc, S, _stream(x)), "ndhwc_to_ncdhw")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# MedFormer pieces
+# ------------------------------------------------------------------------------------------------
+
+def dwconv(x, w2d, k, in_stats=None, act: int = 0, bias=None, flip: bool = False):
+    """depthwise conv, stride 1, pad k//2; w2d float32 [C, kD*kH*kW]; optional fused IN(+act) on load."""
+    _dev_ok(x, w2d, in_stats, bias)
+    N, D, H, W, Cc = map(int, x.shape)
+    y = torch.empty((N, D, H, W, Cc), dtype=x.dtype, device=x.device)
+    check(_lib.lib().cbim_dwconv3d(_dt(x), _p(x), _rs(x), _p(in_stats), act, _p(bias), _p(w2d), int(flip), _p(y), Cc,
+                                   N, D, H, W, Cc, int(k[0]), int(k[1]), int(k[2]), _stream(x)), "dwconv3d")
+    return y
+
+
+def dwconv_wgrad(x, in_stats, act: int, dy, k, dy_bias=None):
+    _dev_ok(x, in_stats, dy, dy_bias)
+    N, D, H, W, Cc = map(int, x.shape)
+    kD, kH, kW = (int(i) for i in k)
+    L = _lib.lib()
+    nbytes = L.cbim_dwconv3d_wgrad_workspace(N, D, H, W, Cc, kD, kH, kW)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((Cc, kD * kH * kW), dtype=torch.float32, device=x.device)
+    check(L.cbim_dwconv3d_wgrad(_dt(x), _p(x), _rs(x), _p(in_stats), act, _p(dy), _rs(dy), _p(dy_bias), _p(dw),
+                                N, D, H, W, Cc, kD, kH, kW, _p(ws), nbytes, _stream(x)), "dwconv3d_wgrad")
+    return dw
+
+
+def space_to_depth(x, scale):
+    _dev_ok(x)
+    N, D, H, W, Cc = map(int, x.shape)
+    sD, sH, sW = (int(i) for i in scale)
+    y = torch.empty((N, D // sD, H // sH, W // sW, Cc * sD * sH * sW), dtype=x.dtype, device=x.device)
+    check(_lib.lib().cbim_space_to_depth(_dt(x), _p(x), _p(y), N, D, H, W, Cc, sD, sH, sW, 0, _stream(x)),
+          "space_to_depth")
+    return y
+
+
+def depth_to_space(dy, in_shape, scale):
+    _dev_ok(dy)
+    N, D, H, W, Cc = map(int, in_shape)
+    sD, sH, sW = (int(i) for i in scale)
+    dx = torch.empty(tuple(in_shape), dtype=dy.dtype, device=dy.device)
+    check(_lib.lib().cbim_space_to_depth(_dt(dy), _p(dy), _p(dx), N, D, H, W, Cc, sD, sH, sW, 1, _stream(dy)),
+          "space_to_depth(inverse)")
+    return dx
+
+
+def _attn_ws(N, L, heads, dh, M, dev):
+    nbytes = _lib.lib().cbim_bidir_attn_workspace(N, L, heads, dh, M)
+    return torch.empty((nbytes,), dtype=torch.uint8, device=dev), nbytes
+
+
+def bidir_attn_fwd(qv, mq, mv, heads: int, scale: float):
+    """qv [N,D,H,W,2*inner]; mq, mv float32 [N,M,inner] -> feat_out [N,D,H,W,inner], map_out [N,M,inner], colstat."""
+    _dev_ok(qv, mq, mv)
+    N, Lr, inner = int(qv.shape[0]), _spatial(qv), int(qv.shape[-1]) // 2
+    M, dh = int(mq.shape[1]), inner // heads
+    fo = torch.empty(tuple(qv.shape[:-1]) + (inner,), dtype=qv.dtype, device=qv.device)
+    mo = torch.empty((N, M, inner), dtype=torch.float32, device=qv.device)
+    cs = torch.empty((N, heads, M, 2), dtype=torch.float32, device=qv.device)
+    ws, nbytes = _attn_ws(N, Lr, heads, dh, M, qv.device)
+    check(_lib.lib().cbim_bidir_attn_fwd(_dt(qv), _p(qv), _rs(qv), _p(mq), _p(mv), _p(fo), _p(mo), _p(cs), N, Lr, heads,
+                                         dh, M, float(scale), _p(ws), nbytes, _stream(qv)), "bidir_attn_fwd")
+    return fo, mo, cs
+
+
+def bidir_attn_bwd(qv, mq, mv, cs, mo, dfo, dmo, heads: int, scale: float):
+    _dev_ok(qv, mq, mv, cs, mo, dfo, dmo)
+    N, Lr, inner = int(qv.shape[0]), _spatial(qv), int(qv.shape[-1]) // 2
+    M, dh = int(mq.shape[1]), inner // heads
+    dqv = torch.empty(tuple(qv.shape), dtype=qv.dtype, device=qv.device)
+    dmq = torch.empty((N, M, inner), dtype=torch.float32, device=qv.device)
+    dmv = torch.empty((N, M, inner), dtype=torch.float32, device=qv.device)
+    ws, nbytes = _attn_ws(N, Lr, heads, dh, M, qv.device)
+    check(_lib.lib().cbim_bidir_attn_bwd(_dt(qv), _p(qv), _rs(qv), _p(mq), _p(mv), _p(cs), _p(mo), _p(dfo), _p(dmo),
+                                         _p(dqv), _p(dmq), _p(dmv), N, Lr, heads, dh, M, float(scale), _p(ws), nbytes,
+                                         _stream(qv)), "bidir_attn_bwd")
+    return dqv, dmq, dmv
+
+
+def colsoftmax_pool_fwd(fw, Cf: int):
+    """fw [N,D,H,W,Cf+M] -> map float32 [N,Cf,M], colstat float32 [N,M,2]."""
+    _dev_ok(fw)
+    N, Lr, M = int(fw.shape[0]), _spatial(fw), int(fw.shape[-1]) - Cf
+    L = _lib.lib()
+    nbytes = L.cbim_colsoftmax_pool_workspace(N, Lr, Cf, M)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=fw.device)
+    mp = torch.empty((N, Cf, M), dtype=torch.float32, device=fw.device)
+    cs = torch.empty((N, M, 2), dtype=torch.float32, device=fw.device)
+    check(L.cbim_colsoftmax_pool_fwd(_dt(fw), _p(fw), _rs(fw), _p(mp), _p(cs), N, Lr, Cf, M, _p(ws), nbytes, _stream(fw)),
+          "colsoftmax_pool_fwd")
+    return mp, cs
+
+
+def colsoftmax_pool_bwd(fw, Cf: int, mp, cs, dmap):
+    _dev_ok(fw, mp, cs, dmap)
+    N, Lr, M = int(fw.shape[0]), _spatial(fw), int(fw.shape[-1]) - Cf
+    dfw = torch.empty(tuple(fw.shape), dtype=fw.dtype, device=fw.device)
+    check(_lib.lib().cbim_colsoftmax_pool_bwd(_dt(fw), _p(fw), _rs(fw), _p(mp), _p(cs), _p(dmap), _p(dfw), _rs(dfw), N, Lr,
+                                              Cf, M, _stream(fw)), "colsoftmax_pool_bwd")
+    return dfw
+
+
+def trilinear_planes_fwd(x, size):
+    """float32 [N,C,Di,Hi,Wi] -> [N,C,*size], align_corners=True."""
+    _dev_ok(x)
+    N, Cc, Di, Hi, Wi = map(int, x.shape)
+    Do, Ho, Wo = (int(i) for i in size)
+    y = torch.empty((N, Cc, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cbim_trilinear_planes_fwd(_p(x), _p(y), N * Cc, Di, Hi, Wi, Do, Ho, Wo, _stream(x)),
+          "trilinear_planes_fwd")
+    return y
+
+
+def trilinear_planes_bwd(dy, in_shape):
+    _dev_ok(dy)
+    N, Cc, Di, Hi, Wi = map(int, in_shape)
+    _, _, Do, Ho, Wo = map(int, dy.shape)
+    dx = torch.empty(tuple(in_shape), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().cbim_trilinear_planes_bwd(_p(dy), _p(dx), N * Cc, Di, Hi, Wi, Do, Ho, Wo, _stream(dy)),
+          "trilinear_planes_bwd")
+    return dx

@@ -223,6 +223,57 @@ int cbim_intensity(const float* x, float* y, int C, int64_t S, int mode, const f
 int cbim_gaussian_blur3d(const float* x, float* y, float* tmp, int C, int D, int H, int W,
                          const float* g_host, int k, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MedFormer pieces — /root/reference/model/dim3/medformer_utils.py.
+ * ------------------------------------------------------------------------------------------ */
+/* Depthwise k^3 convolution, stride 1, padding k//2 — nn.Conv3d(C, C, k, groups=C, bias=False) of
+ * DepthwiseSeparableConv.depthwise (conv_layers.py:137-145) and the MBConv depthwise ConvNormAct
+ * (conv_layers.py:211).  y = sum_t w[c][t] * a(x)[l+off(t)], a = act((x-mean)*rstd) when in_stats
+ * (float [N][C][2]) is given, zero outside the volume.  bias (float [N][C], optional) is added to every
+ * in-range input; flip=1 indexes the taps in reverse (the data gradient).  w: float [C][kD*kH*kW]. */
+int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const float* in_stats, int act,
+                  const float* bias, const float* w, int flip, void* y, int64_t y_stride, int N, int D,
+                  int H, int W, int C, int kD, int kH, int kW, void* stream);
+/* dw[c][t] = sum_{n,l} a(x)[n,l+off(t),c] * (dy[n,l,c] + dy_bias[n][c]); deterministic two-stage sum. */
+size_t cbim_dwconv3d_wgrad_workspace(int N, int D, int H, int W, int C, int kD, int kH, int kW);
+int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, const float* in_stats, int act,
+                        const void* dy, int64_t dy_stride, const float* dy_bias, float* dw, int N, int D,
+                        int H, int W, int C, int kD, int kH, int kW, void* workspace, size_t ws_bytes,
+                        void* stream);
+/* PatchMerging's strided slices + concat (medformer_utils.py:163-171):
+ * dst[n,d',h',w',((i*sH+j)*sW+k)*C+c] = src[n,d'*sD+i,h'*sH+j,w'*sW+k,c]; inverse=1 is the adjoint copy
+ * (src = merged tensor, dst = [N,D,H,W,C]).  D,H,W are always the UNMERGED extents. */
+int cbim_space_to_depth(int dtype, const void* src, void* dst, int N, int D, int H, int W, int C, int sD,
+                        int sH, int sW, int inverse, void* stream);
+/* BidirectionAttention core (medformer_utils.py:63-97) on qv = [q | v] rows ([N][L][2*inner], row stride
+ * qv_stride), inner = heads*dh, channel c = d*heads + h ("(dim_head heads)", :43-51):
+ *   attn = q_f q_m^T * scale [L x M]; feat_out = softmax_M(attn) v_m; map_out = softmax_L(attn)^T v_f.
+ * mq, mv, map_out, d_*: float [N][M][inner].  colstat: float [N][heads][M][2] column (max, sum) kept
+ * for the backward.  dh in {8,16,32}, M <= 64. */
+size_t cbim_bidir_attn_workspace(int N, int L, int heads, int dh, int M);
+int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
+                        void* feat_out, float* map_out, float* colstat, int N, int L, int heads, int dh,
+                        int M, float scale, void* workspace, size_t ws_bytes, void* stream);
+int cbim_bidir_attn_bwd(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
+                        const float* colstat, const float* map_out, const void* d_feat_out,
+                        const float* d_map_out, void* d_qv, float* d_mq, float* d_mv, int N, int L,
+                        int heads, int dh, int M, float scale, void* workspace, size_t ws_bytes,
+                        void* stream);
+/* SemanticMapGeneration tail (medformer_utils.py:218-228) on fw rows = [feat (C) | weight logits (M)]:
+ * map[n][c][j] = sum_l feat[l,c] * softmax_L(logit[:,j])[l].  colstat: float [N][M][2]. */
+size_t cbim_colsoftmax_pool_workspace(int N, int L, int C, int M);
+int cbim_colsoftmax_pool_fwd(int dtype, const void* fw, int64_t fw_stride, float* map, float* colstat,
+                             int N, int L, int C, int M, void* workspace, size_t ws_bytes, void* stream);
+int cbim_colsoftmax_pool_bwd(int dtype, const void* fw, int64_t fw_stride, const float* map,
+                             const float* colstat, const float* dmap, void* dfw, int64_t dfw_stride, int N,
+                             int L, int C, int M, void* stream);
+/* F.interpolate(aux_out, size, 'trilinear', align_corners=True) on float32 NCDHW planes
+ * (medformer.py:91) and its adjoint. */
+int cbim_trilinear_planes_fwd(const float* x, float* y, int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                              int Wo, void* stream);
+int cbim_trilinear_planes_bwd(const float* dy, float* dx, int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                              int Wo, void* stream);
+
 /* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);

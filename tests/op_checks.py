@@ -83,7 +83,7 @@ def check_upcat(dev, dtype, N=1, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_
     assert torch.equal(from_cl(dskip.cpu()), skr.grad)
 
 
-def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0):
+def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0, act="relu"):
     """conv(relu(IN(x))) forward (+epilogue statistics, +residual), dgrad (+mask, +IN-backward sums,
     +accumulate) and wgrad of one ConvNormAct (reference conv_layers.py:48-49)."""
     torch.manual_seed(seed)
@@ -92,12 +92,12 @@ def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0):
     w = torch.randn(Cout, Cin, *k) * 0.1
     xl = to_cl(x, dtype).to(dev)
     xr = from_cl(xl.cpu())
-    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, 1)
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, ops.ACT[act])
     wdev = w.to(dev)
     wp = ops.pack_weights(wdev, geom, 0)
     st = ops.instnorm_stats(xl)
     xh = F.instance_norm(xr, eps=1e-4)
-    a = F.relu(xh)
+    a = F.relu(xh) if act == "relu" else xh.clone()
     wr = w
     if dtype == torch.bfloat16:
         a = a.bfloat16().float()
@@ -127,7 +127,7 @@ def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0):
     assert e_w < tol(dtype, 5e-5, 1e-3), f"wgrad {e_w:.3e}"
     accl = to_cl(torch.randn_like(a), dtype).to(dev)
     g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=xl, mask_stats=st, accumulate=accl)
-    gm = (a.grad + from_cl(accl.cpu())) * (xh > 0)
+    gm = (a.grad + from_cl(accl.cpu())) * ((xh > 0) if act == "relu" else 1.0)
     assert relerr(from_cl(g2.cpu()), gm) < t, "masked dgrad"
     assert float((sums[..., 0].cpu() - gm.mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
     assert float((sums[..., 1].cpu() - (gm * xh).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
@@ -227,3 +227,120 @@ def check_fused_block(dev, dtype, N=1, Cin=64, Cout=32, dhw=(4, 8, 8)):
     assert relerr(from_cl(f[2]), xr.grad) < t2
     for a_, b_ in zip(f[3], wr):
         assert relerr(a_, b_.grad) < t2
+
+
+# ---- MedFormer pieces -----------------------------------------------------------------------------
+
+def check_dwconv(dev, dtype, N=2, C=16, dhw=(5, 6, 7), k=(3, 3, 3), act="relu", seed=11):
+    """depthwise conv of act(IN(x)) (MBConv.depthwise, conv_layers.py:211) + data/weight gradients."""
+    torch.manual_seed(seed)
+    pad = [i // 2 for i in k]
+    x = torch.randn(N, C, *dhw) + 0.3
+    w = torch.randn(C, 1, *k) * 0.3
+    xl = to_cl(x, dtype).to(dev)
+    xr = from_cl(xl.cpu())
+    st = ops.instnorm_stats(xl, 1e-5)
+    xh = F.instance_norm(xr, eps=1e-5)
+    a = (F.relu(xh) if act == "relu" else xh.clone()).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(a, wr, None, 1, pad, 1, C)
+    w2d = w.reshape(C, -1).contiguous().to(dev)
+    y = ops.dwconv(xl, w2d, k, in_stats=st, act=ops.ACT[act])
+    t = tol(dtype, 2e-5, 1e-2)
+    assert relerr(from_cl(y.cpu()), yr.detach()) < t, "dw fwd"
+    yraw = ops.dwconv(xl, w2d, k)
+    assert relerr(from_cl(yraw.cpu()), F.conv3d(xr, w, None, 1, pad, 1, C)) < t, "dw raw fwd"
+    dy = torch.randn_like(yr)
+    dyl = to_cl(dy, dtype).to(dev)
+    bias = torch.randn(N, C) * 0.1
+    yr.backward(from_cl(dyl.cpu()) + bias[:, :, None, None, None])
+    g = ops.dwconv(dyl, w2d, k, bias=bias.to(dev), flip=True)
+    assert relerr(from_cl(g.cpu()), a.grad) < t, "dw dgrad"
+    dw = ops.dwconv_wgrad(xl, st, ops.ACT[act], dyl, k, dy_bias=bias.to(dev))
+    assert relerr(dw.cpu(), wr.grad.reshape(C, -1)) < tol(dtype, 5e-5, 1e-2), "dw wgrad"
+
+
+def check_space_to_depth(dev, dtype, N=2, C=8, dhw=(4, 6, 8), scale=(2, 2, 2)):
+    torch.manual_seed(12)
+    x = torch.randn(N, C, *dhw)
+    xl = to_cl(x, dtype).to(dev)
+    xr = from_cl(xl.cpu())
+    parts = [xr[:, :, i::scale[0], j::scale[1], k::scale[2]]
+             for i in range(scale[0]) for j in range(scale[1]) for k in range(scale[2])]  # medformer_utils.py:163-171
+    ref = torch.cat(parts, 1)
+    y = ops.space_to_depth(xl, scale)
+    assert torch.equal(from_cl(y.cpu()), ref)
+    back = ops.depth_to_space(y, tuple(xl.shape), scale)
+    assert torch.equal(back.cpu(), xl.cpu())
+
+
+def _attn_ref(q, v, mq, mv, heads, scale):
+    """medformer_utils.py:63-97 on [B, inner, L] / [B, inner, M] tensors, head split '(dim_head heads)'."""
+    B, inner, L = q.shape
+    dh = inner // heads
+    r1 = lambda t: t.view(B, dh, heads, -1).permute(0, 2, 3, 1)       # b heads l dh
+    fq, fv, mq_, mv_ = r1(q), r1(v), r1(mq), r1(mv)
+    attn = torch.einsum('bhid,bhjd->bhij', fq, mq_) * scale
+    p1 = F.softmax(attn, -1)
+    p2 = F.softmax(attn, -2)
+    fo = torch.einsum('bhij,bhjd->bhid', p1, mv_)
+    mo = torch.einsum('bhji,bhjd->bhid', p2, fv)
+    r2 = lambda t: t.permute(0, 3, 1, 2).reshape(B, inner, -1)
+    return r2(fo), r2(mo)
+
+
+def check_attn(dev, dtype, N=2, heads=3, dh=8, dhw=(5, 6, 7), M=8, seed=13):
+    torch.manual_seed(seed)
+    inner = heads * dh
+    L = dhw[0] * dhw[1] * dhw[2]
+    qv = torch.randn(N, 2 * inner, *dhw)
+    qvl = to_cl(qv, dtype).to(dev)
+    qvr = from_cl(qvl.cpu()).reshape(N, 2 * inner, L).clone().requires_grad_(True)
+    mq = torch.randn(N, inner, M).requires_grad_(True)
+    mv = torch.randn(N, inner, M).requires_grad_(True)
+    scale = dh ** -0.5
+    fo_r, mo_r = _attn_ref(qvr[:, :inner], qvr[:, inner:], mq, mv, heads, scale)
+    mql = mq.detach().permute(0, 2, 1).contiguous().to(dev)
+    mvl = mv.detach().permute(0, 2, 1).contiguous().to(dev)
+    fo, mo, cs = ops.bidir_attn_fwd(qvl, mql, mvl, heads, scale)
+    t = tol(dtype, 2e-5, 1e-2)
+    assert relerr(from_cl(fo.cpu()).reshape(N, inner, L), fo_r.detach()) < t, "attn feat_out"
+    assert relerr(mo.cpu().permute(0, 2, 1), mo_r.detach()) < tol(dtype, 2e-5, 2e-5), "attn map_out"
+    dfo = torch.randn(N, inner, *dhw)
+    dfol = to_cl(dfo, dtype).to(dev)
+    dmo = torch.randn(N, inner, M)
+    (fo_r * from_cl(dfol.cpu()).reshape(N, inner, L)).sum().backward(retain_graph=True)
+    (mo_r * dmo).sum().backward()
+    dqv, dmq, dmv = ops.bidir_attn_bwd(qvl, mql, mvl, cs, mo, dfol, dmo.permute(0, 2, 1).contiguous().to(dev), heads, scale)
+    assert relerr(from_cl(dqv.cpu()).reshape(N, 2 * inner, L), qvr.grad) < t, "attn dqv"
+    assert relerr(dmq.cpu().permute(0, 2, 1), mq.grad) < 5e-5, "attn dmq"
+    assert relerr(dmv.cpu().permute(0, 2, 1), mv.grad) < 5e-5, "attn dmv"
+
+
+def check_mappool(dev, dtype, N=2, C=24, M=8, dhw=(5, 6, 7), seed=14):
+    """SemanticMapGeneration tail, medformer_utils.py:218-228."""
+    torch.manual_seed(seed)
+    L = dhw[0] * dhw[1] * dhw[2]
+    fw = torch.randn(N, C + M, *dhw)
+    fwl = to_cl(fw, dtype).to(dev)
+    fwr = from_cl(fwl.cpu()).reshape(N, C + M, L).clone().requires_grad_(True)
+    wm = F.softmax(fwr[:, C:], dim=2)
+    ref = torch.einsum('bij,bkj->bik', fwr[:, :C], wm)
+    mp, cs = ops.colsoftmax_pool_fwd(fwl, C)
+    assert relerr(mp.cpu(), ref.detach()) < 2e-5, "mappool fwd"
+    dmap = torch.randn(N, C, M)
+    ref.backward(dmap)
+    dfw = ops.colsoftmax_pool_bwd(fwl, C, mp, cs, dmap.to(dev))
+    assert relerr(from_cl(dfw.cpu()).reshape(N, C + M, L), fwr.grad) < tol(dtype, 2e-5, 1e-2), "mappool bwd"
+
+
+def check_trilinear_planes(dev, N=1, C=3, lo=(3, 4, 5), hi=(7, 8, 9)):
+    torch.manual_seed(15)
+    x = torch.randn(N, C, *lo, requires_grad=True)
+    ref = F.interpolate(x, size=hi, mode="trilinear", align_corners=True)
+    y = ops.trilinear_planes_fwd(x.detach().to(dev), hi)
+    assert relerr(y.cpu(), ref.detach()) < 2e-6
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    dx = ops.trilinear_planes_bwd(g.to(dev), tuple(x.shape))
+    assert relerr(dx.cpu(), x.grad) < 2e-6

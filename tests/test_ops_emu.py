@@ -42,9 +42,46 @@ def test_upcat(dev, dtype):
     (BF16, 1, 16, 8, (3, 12, 8), (1, 3, 3)),
     (BF16, 1, 8, 8, (33, 16, 16), (3, 3, 3)),   # MT=2 tiles
     (F32, 1, 4, 4, (2, 2, 2), (3, 3, 3)),       # bottom of a 32^3 pyramid
+    (F32, 2, 24, 40, (5, 6, 7), (1, 1, 1)),     # pointwise (MedFormer 1x1 convs)
+    (BF16, 1, 64, 32, (4, 8, 8), (1, 1, 1)),
 ])
 def test_conv(dev, dtype, N, Cin, Cout, dhw, k):
     oc.check_conv(dev, dtype, N, Cin, Cout, dhw, k)
+
+
+def test_conv_norm_no_act(dev):
+    oc.check_conv(dev, F32, 1, 16, 24, (4, 6, 8), (1, 1, 1), act="none")
+    oc.check_conv(dev, BF16, 1, 16, 16, (4, 8, 8), (3, 3, 3), act="none")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_dwconv(dev, dtype):
+    oc.check_dwconv(dev, dtype)
+    oc.check_dwconv(dev, dtype, N=1, C=40, dhw=(2, 2, 2), act="none")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_space_to_depth(dev, dtype):
+    oc.check_space_to_depth(dev, dtype)
+    oc.check_space_to_depth(dev, dtype, C=16, dhw=(2, 4, 6), scale=(1, 2, 2))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attn(dev, dtype):
+    oc.check_attn(dev, dtype)
+    oc.check_attn(dev, dtype, N=1, heads=1, dh=16, dhw=(2, 2, 2), M=8)
+    oc.check_attn(dev, dtype, N=1, heads=2, dh=32, dhw=(4, 6, 6), M=64)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_mappool(dev, dtype):
+    oc.check_mappool(dev, dtype)
+    oc.check_mappool(dev, dtype, N=1, C=72, M=64, dhw=(6, 6, 5))
+
+
+def test_trilinear_planes(dev):
+    oc.check_trilinear_planes(dev)
+    oc.check_trilinear_planes(dev, lo=(1, 2, 2), hi=(4, 4, 4))
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
