@@ -269,3 +269,171 @@ class DiceCEFn(torch.autograd.Function):
         g2 = torch.stack([gout[0] + gout[2], gout[1] + gout[2]]).float().contiguous()
         dz = ops.dice_ce_bwd(logits, labels, weight if ctx.has_w else None, coef, g2)
         return dz, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# MedFormer blocks (reference: /root/reference/model/dim3/medformer_utils.py, conv_layers.py:126-238)
+# ------------------------------------------------------------------------------------------------
+
+def restat(stats: torch.Tensor, eps_from: float, eps_to: float) -> torch.Tensor:
+    """(mean, rstd) computed with one epsilon -> the same moments under another.  The reference's
+    BidirectionAttentionBlock.norm1 / PatchMerging.norm use the InstanceNorm3d default 1e-5 while every
+    ConvNormAct norm is built with 1e-4 (medformer_utils.py:112,158 vs conv_layers.py:40)."""
+    var = (stats[..., 1].double() ** -2 - eps_from).clamp_min(0.0)
+    return torch.stack([stats[..., 0], (var + eps_to).rsqrt().float()], -1).contiguous()
+
+
+class NormConvFn(torch.autograd.Function):
+    """y = conv(act(IN(x))) [+ res]  (pre-activation ConvNormAct, conv_layers.py:48-49); stats=None -> raw
+    conv.  `se` (float [N,Cin], optional; act must be none) folds the SEBlock gate of conv_layers.py:159-175
+    into the normalisation: IN(x*s) = (x-mean) * s*rsqrt(var*s^2+eps), so the gated tensor is never written.
+    Returns (y, InstanceNorm statistics of y [eps 1e-4] or an empty tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, stats, w, act, res, want_stats, se):
+        g = _geom(x, w, act)
+        train = any(ctx.needs_input_grad)
+        wd = w.detach().contiguous()
+        if train:
+            wp, wpd = ops.pack_weights_both(wd, g)
+        else:
+            wp, wpd = ops.pack_weights(wd, g, 0), None
+        st = stats
+        if se is not None:
+            assert act == 0 and stats is not None
+            var = (stats[..., 1].double() ** -2 - IN_EPS).clamp_min(0.0)
+            sd = se.detach().double()
+            rz2 = 1.0 / (var * sd * sd + IN_EPS)
+            st = torch.stack([stats[..., 0], (sd * rz2.sqrt()).float()], -1).contiguous()
+            ctx.rz2 = rz2
+        y, so = ops.conv_fwd(x, wp, g, in_stats=st, res=res, want_stats=want_stats)
+        ctx.save_for_backward(x, st if st is not None else torch.empty(0), se if se is not None else torch.empty(0))
+        ctx.geom, ctx.act, ctx.wpd, ctx.has = g, act, wpd, (stats is not None, res is not None, se is not None)
+        if so is None:
+            so = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(so)
+        return y, so
+
+    @staticmethod
+    def backward(ctx, dy, _dso):
+        x, st, se = ctx.saved_tensors
+        has_stats, has_res, has_se = ctx.has
+        g, act = ctx.geom, ctx.act
+        dy = dy.contiguous()
+        dw = ops.conv_wgrad(x, st if has_stats else None, dy, g) if ctx.needs_input_grad[2] else None
+        dx = ds = None
+        if ctx.needs_input_grad[0]:
+            if has_stats:
+                gx, sums = ops.conv_dgrad(dy, ctx.wpd, g, mask_x=x, mask_stats=st)
+                dx = ops.norm_bwd_apply(gx, x, st, sums, act, masked=False)
+                if has_se:
+                    S = g.in_dhw[0] * g.in_dhw[1] * g.in_dhw[2]
+                    ds = (S * IN_EPS * sums[..., 1].double() * ctx.rz2 / se.double()).float()
+            else:
+                dx, _ = ops.conv_dgrad(dy, ctx.wpd, g)
+        return dx, None, dw, None, (dy if has_res else None), None, ds
+
+
+class DWConvFn(torch.autograd.Function):
+    """Depthwise conv of act(IN(x)) (stats=None: of x) — DepthwiseSeparableConv.depthwise
+    (conv_layers.py:137-145) / MBConv.depthwise (:211).  Also returns the per-(n,c) mean of the output
+    (the SEBlock squeeze, conv_layers.py:163) as a differentiable output and the statistics (eps 1e-4)."""
+
+    @staticmethod
+    def forward(ctx, x, stats, w, act, want_mean):
+        k = tuple(int(i) for i in w.shape[2:])
+        w2d = w.detach().reshape(w.shape[0], -1).contiguous()
+        y = ops.dwconv(x, w2d, k, in_stats=stats, act=act)
+        ctx.save_for_backward(x, stats if stats is not None else torch.empty(0), w2d)
+        ctx.k, ctx.act, ctx.has_stats, ctx.w_shape = k, act, stats is not None, tuple(w.shape)
+        if want_mean:
+            ys = ops.instnorm_stats(y, IN_EPS)
+            mean = ys[..., 0].contiguous()
+        else:
+            ys = torch.empty(0, device=x.device)
+            mean = torch.empty(0, device=x.device)
+        ctx.want_mean = want_mean
+        ctx.S = int(x.shape[1]) * int(x.shape[2]) * int(x.shape[3])
+        ctx.mark_non_differentiable(ys)
+        return y, mean, ys
+
+    @staticmethod
+    def backward(ctx, dy, dmean, _dys):
+        x, stats, w2d = ctx.saved_tensors
+        st = stats if ctx.has_stats else None
+        dy = dy.contiguous()
+        bias = (dmean / ctx.S).float().contiguous() if (ctx.want_mean and dmean is not None) else None
+        dw = ops.dwconv_wgrad(x, st, ctx.act, dy, ctx.k, dy_bias=bias).reshape(ctx.w_shape)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gy = ops.dwconv(dy, w2d, ctx.k, bias=bias, flip=True)
+            if st is not None:
+                sums = ops.norm_bwd_sums(gy, x, st, ctx.act, masked=True)
+                dx = ops.norm_bwd_apply(gy, x, st, sums, ctx.act, masked=True)
+            else:
+                dx = gy
+        return dx, None, dw, None, None
+
+
+class SpaceToDepthFn(torch.autograd.Function):
+    """PatchMerging's 8 strided slices + channel concat (medformer_utils.py:163-171)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.in_shape, ctx.scale = tuple(x.shape), tuple(scale)
+        return ops.space_to_depth(x, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.depth_to_space(dy.contiguous(), ctx.in_shape, ctx.scale), None
+
+
+class BidirAttnFn(torch.autograd.Function):
+    """BidirectionAttention core (medformer_utils.py:63-97): qv [N,D,H,W,2*inner] feature rows,
+    mq / mv float32 [N,M,inner] -> (feat_out [N,D,H,W,inner], map_out float32 [N,M,inner])."""
+
+    @staticmethod
+    def forward(ctx, qv, mq, mv, heads, scale):
+        mq = mq.detach().float().contiguous()
+        mv = mv.detach().float().contiguous()
+        fo, mo, cs = ops.bidir_attn_fwd(qv, mq, mv, heads, scale)
+        ctx.save_for_backward(qv, mq, mv, cs, mo)
+        ctx.heads, ctx.scale = heads, scale
+        return fo, mo
+
+    @staticmethod
+    def backward(ctx, dfo, dmo):
+        qv, mq, mv, cs, mo = ctx.saved_tensors
+        dqv, dmq, dmv = ops.bidir_attn_bwd(qv, mq, mv, cs, mo, dfo.contiguous(), dmo.float().contiguous(),
+                                           ctx.heads, ctx.scale)
+        return dqv, dmq, dmv, None, None
+
+
+class MapPoolFn(torch.autograd.Function):
+    """SemanticMapGeneration tail (medformer_utils.py:218-228): fw = [feat | weight logits] rows ->
+    float32 [N, Cf, M]."""
+
+    @staticmethod
+    def forward(ctx, fw, Cf):
+        mp, cs = ops.colsoftmax_pool_fwd(fw, Cf)
+        ctx.save_for_backward(fw, mp, cs)
+        ctx.Cf = Cf
+        return mp
+
+    @staticmethod
+    def backward(ctx, dmap):
+        fw, mp, cs = ctx.saved_tensors
+        return ops.colsoftmax_pool_bwd(fw, ctx.Cf, mp, cs, dmap.float().contiguous()), None
+
+
+class TrilinearPlanesFn(torch.autograd.Function):
+    """F.interpolate(aux_out, size, 'trilinear', align_corners=True) on NCDHW float32 (medformer.py:91)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_shape = tuple(x.shape)
+        return ops.trilinear_planes_fwd(x.contiguous().float(), size)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.trilinear_planes_bwd(dy.contiguous().float(), ctx.in_shape), None

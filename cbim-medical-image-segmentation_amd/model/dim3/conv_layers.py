@@ -21,12 +21,16 @@ def _k3(k):
 class ConvNormAct(nn.Module):
     """Parameter holder for one conv + (norm, act) description (conv_layers.py:16-53)."""
 
-    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, padding=1, norm="in", act="relu", preact=False):
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, padding=1, groups=1, norm="in", act="relu",
+                 preact=False):
         super().__init__()
         if stride not in (1, [1, 1, 1], (1, 1, 1)):
             raise NotImplementedError("cbim_amd: strided ConvNormAct (pool=False) is not built")
+        if groups not in (1, in_ch):
+            raise NotImplementedError("cbim_amd: grouped convolutions other than depthwise are not built")
         k = _k3(kernel_size)
-        self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=k, stride=1, padding=[i // 2 for i in k], bias=False)
+        self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=k, stride=1, padding=[i // 2 for i in k], groups=groups,
+                              bias=False)
         self.norm = nn.Identity()   # InstanceNorm3d(eps=1e-4): no parameters, fused into the kernels
         self.act = nn.Identity()
         self.act_code = ACT[act]
@@ -66,3 +70,67 @@ class BasicBlock(nn.Module):
         out, so = Fn.BasicBlockFn.apply(f.t, f.stats, self.conv1.conv.weight, self.conv2.conv.weight, wsc,
                                         self.conv1.act_code, want_out_stats)
         return Fn.FMap(out, so if want_out_stats else None)
+
+
+class DepthwiseSeparableConv(nn.Module):
+    """depthwise k^3 (groups=C) then pointwise 1^3, no norm/act in between — conv_layers.py:126-157.
+    forward: y = pointwise(depthwise(a(IN(x)))) [+ res], a given by (stats, act) of the caller's pre-norm."""
+
+    def __init__(self, in_ch, out_ch, stride=1, kernel_size=3, bias=False):
+        super().__init__()
+        if bias or stride != 1:
+            raise NotImplementedError("cbim_amd: DepthwiseSeparableConv with bias/stride is not built")
+        k = _k3(kernel_size)
+        self.depthwise = nn.Conv3d(in_ch, in_ch, kernel_size=k, stride=1, padding=[i // 2 for i in k], groups=in_ch,
+                                   bias=False)
+        self.pointwise = nn.Conv3d(in_ch, out_ch, kernel_size=1, bias=False)
+
+    def forward(self, x, stats=None, act=0, res=None, want_stats=False) -> Fn.FMap:
+        t, _, _ = Fn.DWConvFn.apply(x, stats, self.depthwise.weight, act, False)
+        y, so = Fn.NormConvFn.apply(t, None, self.pointwise.weight, 0, res, want_stats, None)
+        return Fn.FMap(y, so if want_stats else None)
+
+
+class SEBlock(nn.Module):
+    """squeeze (global mean) -> 1x1 conv -> act -> 1x1 conv -> sigmoid — conv_layers.py:159-175.
+    Works on the [N, C] channel means (a few hundred numbers): plain torch ops; the gate is applied
+    inside the next conv's fused normalisation (functional.NormConvFn `se`)."""
+
+    def __init__(self, in_ch, ratio=4, act="relu"):
+        super().__init__()
+        self.squeeze = nn.Identity()
+        self.excitation = nn.Sequential(nn.Conv3d(in_ch, in_ch // ratio, kernel_size=1), nn.ReLU(),
+                                        nn.Conv3d(in_ch // ratio, in_ch, kernel_size=1), nn.Sigmoid())
+        if act != "relu":   # the reference passes no act here, so it is always nn.ReLU (conv_layers.py:223)
+            raise NotImplementedError("cbim_amd: SEBlock activation other than ReLU is not built")
+
+    def gate(self, mean):   # mean: float32 [N, C]
+        return self.excitation(mean[:, :, None, None, None]).flatten(1)
+
+
+class MBConv(nn.Module):
+    """expand 1x1 -> depthwise k^3 -> SE -> project 1x1, every ConvNormAct pre-activated, identity
+    shortcut — conv_layers.py:197-238 (the MedFormer feed-forward, medformer_utils.py:124)."""
+
+    def __init__(self, in_ch, out_ch, expansion=4, kernel_size=3, stride=1, ratio=4, p=0, se=True, norm="in",
+                 act="relu"):
+        super().__init__()
+        if in_ch != out_ch or stride != 1 or p or not se or expansion == 1:
+            raise NotImplementedError("cbim_amd: only the MedFormer MBConv variant (in==out, stride 1, SE, p=0) is built")
+        expanded = expansion * in_ch
+        k = _k3(kernel_size)
+        self.expand_proj = ConvNormAct(in_ch, expanded, kernel_size=1, padding=0, norm=norm, act=act, preact=True)
+        self.depthwise = ConvNormAct(expanded, expanded, kernel_size=k, groups=expanded, norm=norm, act=act, preact=True)
+        self.se = SEBlock(expanded, ratio=ratio)
+        self.pointwise = ConvNormAct(expanded, out_ch, kernel_size=1, padding=0, norm=norm, act=None, preact=True)
+        self.drop_path = nn.Identity()
+        self.shortcut = nn.Sequential()
+
+    def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
+        f = Fn.ensure_stats(f)
+        act = self.expand_proj.act_code
+        e, se_ = Fn.NormConvFn.apply(f.t, f.stats, self.expand_proj.conv.weight, act, None, True, None)
+        d, mean, ds = Fn.DWConvFn.apply(e, se_, self.depthwise.conv.weight, act, True)
+        gate = self.se.gate(mean)
+        y, so = Fn.NormConvFn.apply(d, ds, self.pointwise.conv.weight, 0, f.t, want_out_stats, gate)
+        return Fn.FMap(y, so if want_out_stats else None)

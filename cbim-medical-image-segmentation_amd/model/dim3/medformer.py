@@ -1,0 +1,67 @@
+"""MedFormer behind the reference's constructor signature and parameter names
+(/root/reference/model/dim3/medformer.py:11-101).  forward(x[B,C,D,H,W] fp32 NCDHW) -> logits
+[B,classes,D,H,W] fp32, or [out, aux_out] with aux_loss=True (both full resolution).
+"""
+import torch
+import torch.nn as nn
+
+from ... import functional as Fn
+from .medformer_utils import SemanticMapFusion, down_block, inconv, up_block
+from .utils import get_act, get_block, get_norm
+
+
+class MedFormer(nn.Module):
+    def __init__(self, in_chan, num_classes, base_chan=32, map_size=[4, 8, 8], conv_block="BasicBlock",
+                 conv_num=[2, 1, 0, 0, 0, 1, 2, 2], trans_num=[0, 1, 2, 2, 2, 1, 0, 0],
+                 chan_num=[64, 128, 256, 320, 256, 128, 64, 32], num_heads=[1, 4, 8, 16, 8, 4, 1, 1], fusion_depth=2,
+                 fusion_dim=320, fusion_heads=4, expansion=4, attn_drop=0., proj_drop=0., proj_type="depthwise",
+                 norm="in", act="gelu", kernel_size=[3, 3, 3, 3], scale=[2, 2, 2, 2], aux_loss=False):
+        super().__init__()
+        if conv_block != "BasicBlock":
+            raise NotImplementedError("cbim_amd: MedFormer conv_block must be 'BasicBlock' (as in every shipped config)")
+        dim_head = [chan_num[i] // num_heads[i] for i in range(8)]
+        block, norm, act = get_block(conv_block), get_norm(norm), get_act(act)
+        kw = dict(expansion=expansion, attn_drop=attn_drop, proj_drop=proj_drop, map_size=map_size, proj_type=proj_type,
+                  norm=norm, act=act, conv_block=block)
+        c = chan_num
+        self.inc = inconv(in_chan, base_chan, block=block, kernel_size=kernel_size[0], norm=norm, act=act)
+        self.down1 = down_block(base_chan, c[0], conv_num[0], trans_num[0], conv_block=block, kernel_size=kernel_size[1],
+                                down_scale=scale[0], norm=norm, act=act, map_generate=False)
+        self.down2 = down_block(c[0], c[1], conv_num[1], trans_num[1], kernel_size=kernel_size[2], down_scale=scale[1],
+                                heads=num_heads[1], dim_head=dim_head[1], map_generate=True, **kw)
+        self.down3 = down_block(c[1], c[2], conv_num[2], trans_num[2], kernel_size=kernel_size[3], down_scale=scale[2],
+                                heads=num_heads[2], dim_head=dim_head[2], map_generate=True, **kw)
+        self.down4 = down_block(c[2], c[3], conv_num[3], trans_num[3], kernel_size=kernel_size[4], down_scale=scale[3],
+                                heads=num_heads[3], dim_head=dim_head[3], map_generate=True, **kw)
+        self.map_fusion = SemanticMapFusion(c[1:4], fusion_dim, fusion_heads, depth=fusion_depth, norm=norm)
+        self.up1 = up_block(c[3], c[4], conv_num[4], trans_num[4], kernel_size=kernel_size[3], up_scale=scale[3],
+                            heads=num_heads[4], dim_head=dim_head[4], map_shortcut=True, **kw)
+        self.up2 = up_block(c[4], c[5], conv_num[5], trans_num[5], kernel_size=kernel_size[2], up_scale=scale[2],
+                            heads=num_heads[5], dim_head=dim_head[5], map_shortcut=True, no_map_out=True, **kw)
+        self.up3 = up_block(c[5], c[6], conv_num[6], trans_num[6], conv_block=block, kernel_size=kernel_size[1],
+                            up_scale=scale[1], norm=norm, act=act, map_shortcut=False)
+        self.up4 = up_block(c[6], c[7], conv_num[7], trans_num[7], conv_block=block, kernel_size=kernel_size[0],
+                            up_scale=scale[0], norm=norm, act=act, map_shortcut=False)
+        self.aux_loss = aux_loss
+        if aux_loss:
+            self.aux_out = nn.Conv3d(c[5], num_classes, kernel_size=1)
+        self.outc = nn.Conv3d(c[7], num_classes, kernel_size=1)
+
+    def forward(self, x):
+        dtype = Fn.compute_dtype()
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            x0 = self.inc(x, dtype)
+            x1, _ = self.down1(x0)
+            x2, map2 = self.down2(x1)
+            x3, map3 = self.down3(x2)
+            x4, map4 = self.down4(x3)
+            maps = self.map_fusion([map2, map3, map4])
+            out, smap = self.up1(x4, x3, maps[2], maps[1])
+            out, smap = self.up2(out, x2, smap, maps[0])
+            if self.aux_loss:
+                aux = Fn.HeadFn.apply(out.t, self.aux_out.weight, self.aux_out.bias)
+                aux = Fn.TrilinearPlanesFn.apply(aux, tuple(x.shape[-3:]))
+            out, smap = self.up3(out, x1, smap, None)
+            out, smap = self.up4(out, x0, smap, None)
+            logits = Fn.HeadFn.apply(out.t, self.outc.weight, self.outc.bias)
+            return [logits, aux] if self.aux_loss else logits

@@ -1,0 +1,232 @@
+"""MedFormer building blocks with the reference's module / parameter names
+(/root/reference/model/dim3/medformer_utils.py), executed by the gfx950 kernels behind
+``cbim_amd.functional``.
+
+Feature maps (L = D*H*W voxels) are channels-last ``Fn.FMap``s handled only by HIP kernels.  Semantic
+maps are ``[B, C, m0, m1, m2]`` float32 torch tensors with m0*m1*m2 <= 64 positions: their 1x1
+projections / InstanceNorm / residuals are a few KFLOP each and stay ordinary torch ops (autograd
+differentiates them); everything that touches L voxels is a kernel.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import functional as Fn
+from ...ops import ACT, IN_EPS
+from .conv_layers import BasicBlock, ConvNormAct, DepthwiseSeparableConv, MBConv, _k3
+from .trans_layers import TransformerBlock
+
+_EPS_DEFAULT = 1e-5   # nn.InstanceNorm3d default, used by norm1/norm2 and PatchMerging.norm (:112-113,:158)
+
+
+class BidirectionAttention(nn.Module):
+    """medformer_utils.py:11-97 (proj_type 'depthwise')."""
+
+    def __init__(self, feat_dim, map_dim, out_dim, heads=4, dim_head=64, attn_drop=0., proj_drop=0.,
+                 map_size=(8, 8, 8), proj_type="depthwise", kernel_size=(3, 3, 3), no_map_out=False):
+        super().__init__()
+        if proj_type != "depthwise":
+            raise NotImplementedError("cbim_amd: BidirectionAttention(proj_type='linear') is not built")
+        if attn_drop or proj_drop:
+            raise NotImplementedError("cbim_amd: attention dropout is not built (0 in every shipped config)")
+        self.inner_dim, self.heads, self.dim_head = dim_head * heads, heads, dim_head
+        self.scale = dim_head ** (-0.5)
+        self.feat_qv = DepthwiseSeparableConv(feat_dim, self.inner_dim * 2, kernel_size=kernel_size)
+        self.feat_out = DepthwiseSeparableConv(self.inner_dim, out_dim, kernel_size=kernel_size)
+        self.map_qv = nn.Conv3d(map_dim, self.inner_dim * 2, kernel_size=1, bias=False)
+        self.map_out = nn.Identity() if no_map_out else nn.Conv3d(self.inner_dim, map_dim, kernel_size=1, bias=False)
+
+    def forward(self, x, x_stats, mapp, res, want_stats):
+        """x (raw) with InstanceNorm stats (eps 1e-5) fused into the depthwise load; mapp already normalised.
+        Returns (feat_out + res as FMap, map_out [B, *, m...])."""
+        qv = self.feat_qv(x, x_stats, 0).t
+        B, ms = mapp.shape[0], tuple(mapp.shape[2:])
+        mqv = self.map_qv(mapp).flatten(2).transpose(1, 2)            # [B, M, 2*inner]
+        mq, mv = mqv[..., :self.inner_dim], mqv[..., self.inner_dim:]
+        fo, mo = Fn.BidirAttnFn.apply(qv, mq, mv, self.heads, self.scale)
+        out = self.feat_out(fo, None, 0, res=res, want_stats=want_stats)
+        mo = mo.transpose(1, 2).reshape(B, self.inner_dim, *ms)
+        return out, self.map_out(mo)
+
+
+class BidirectionAttentionBlock(nn.Module):
+    """medformer_utils.py:102-138."""
+
+    def __init__(self, feat_dim, map_dim, out_dim, heads, dim_head, norm="in", act="relu", expansion=4,
+                 attn_drop=0., proj_drop=0., map_size=(8, 8, 8), proj_type="depthwise", kernel_size=(3, 3, 3),
+                 no_map_out=False):
+        super().__init__()
+        self.norm1 = nn.Identity()   # InstanceNorm3d(feat_dim), eps 1e-5: fused into feat_qv's depthwise load
+        self.norm2 = nn.Identity()   # InstanceNorm3d(map_dim) on <= 64 positions: torch op below
+        self.attn = BidirectionAttention(feat_dim, map_dim, out_dim, heads, dim_head, attn_drop=attn_drop,
+                                         proj_drop=proj_drop, map_size=map_size, proj_type=proj_type,
+                                         kernel_size=kernel_size, no_map_out=no_map_out)
+        self.shortcut = nn.Sequential()
+        if feat_dim != out_dim:
+            self.shortcut = ConvNormAct(feat_dim, out_dim, 1, padding=0, norm=norm, act=act, preact=True)
+        self.feedforward = MBConv(out_dim, out_dim, expansion=expansion, kernel_size=kernel_size, act=act, norm=norm)
+
+    def forward(self, f: Fn.FMap, semantic_map, want_out_stats=True):
+        f = Fn.ensure_stats(f)                                   # eps 1e-4 (ConvNormAct convention)
+        s5 = Fn.restat(f.stats, IN_EPS, _EPS_DEFAULT)
+        mapp = F.instance_norm(semantic_map, eps=_EPS_DEFAULT)
+        if isinstance(self.shortcut, ConvNormAct):
+            res, _ = Fn.NormConvFn.apply(f.t, f.stats, self.shortcut.conv.weight, self.shortcut.act_code, None, False,
+                                         None)
+        else:
+            res = f.t
+        out, mapp = self.attn(f.t, s5, mapp, res, True)
+        out = self.feedforward(out, want_out_stats)
+        return out, mapp + semantic_map
+
+
+class PatchMerging(nn.Module):
+    """medformer_utils.py:140-175 (proj_type 'depthwise')."""
+
+    def __init__(self, dim, out_dim, norm="in", proj_type="linear", down_scale=(2, 2, 2), kernel_size=(3, 3, 3)):
+        super().__init__()
+        if proj_type != "depthwise":
+            raise NotImplementedError("cbim_amd: PatchMerging(proj_type='linear') is not built")
+        self.down_scale = _k3(down_scale)
+        merged = 2 ** self.down_scale.count(2) * dim
+        if any(s not in (1, 2) for s in self.down_scale):
+            raise NotImplementedError("cbim_amd: PatchMerging scales other than 1/2 are not built")
+        self.reduction = DepthwiseSeparableConv(merged, out_dim, kernel_size=kernel_size)
+        self.norm = nn.Identity()   # InstanceNorm3d(merged), eps 1e-5: fused into the depthwise load
+
+    def forward(self, f: Fn.FMap) -> Fn.FMap:
+        m = Fn.SpaceToDepthFn.apply(f.t, tuple(self.down_scale))
+        ms = Fn.ensure_stats(Fn.FMap(m, None), _EPS_DEFAULT).stats
+        return self.reduction(m, ms, 0, want_stats=True)
+
+
+class BasicLayer(nn.Module):
+    """medformer_utils.py:177-200."""
+
+    def __init__(self, feat_dim, map_dim, out_dim, num_blocks, heads=4, dim_head=64, expansion=4, attn_drop=0.,
+                 proj_drop=0., map_size=(8, 8, 8), proj_type="depthwise", norm="in", act="gelu",
+                 kernel_size=(3, 3, 3), no_map_out=False):
+        super().__init__()
+        blocks, d1 = [], feat_dim
+        for i in range(num_blocks):
+            blocks.append(BidirectionAttentionBlock(d1, map_dim, out_dim, heads, dim_head, expansion=expansion,
+                                                    attn_drop=attn_drop, proj_drop=proj_drop, map_size=map_size,
+                                                    proj_type=proj_type, norm=norm, act=act, kernel_size=kernel_size,
+                                                    no_map_out=no_map_out if i == num_blocks - 1 else False))
+            d1 = out_dim
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, f, semantic_map):
+        for blk in self.blocks:
+            f, semantic_map = blk(f, semantic_map)
+        return f, semantic_map
+
+
+class SemanticMapGeneration(nn.Module):
+    """medformer_utils.py:203-228: the two 3^3 projections run as ONE Cout-concatenated convolution."""
+
+    def __init__(self, feat_dim, map_dim, map_size):
+        super().__init__()
+        self.map_size, self.map_dim = list(map_size), map_dim
+        self.map_code_num = map_size[0] * map_size[1] * map_size[2]
+        self.base_proj = nn.Conv3d(feat_dim, map_dim, kernel_size=3, padding=1, bias=False)
+        self.semantic_proj = nn.Conv3d(feat_dim, self.map_code_num, kernel_size=3, padding=1, bias=False)
+
+    def forward(self, f: Fn.FMap):
+        w = torch.cat([self.base_proj.weight, self.semantic_proj.weight], 0)
+        fw, _ = Fn.NormConvFn.apply(f.t, None, w, 0, None, False, None)
+        mp = Fn.MapPoolFn.apply(fw, self.map_dim)                       # [B, map_dim, codes]
+        return mp.reshape(mp.shape[0], self.map_dim, *self.map_size)
+
+
+class SemanticMapFusion(nn.Module):
+    """medformer_utils.py:231-261 — 3 x 64 tokens; torch ops (see trans_layers.py)."""
+
+    def __init__(self, in_dim_list, dim, heads, depth=1, norm="in", attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.dim = dim
+        self.in_proj = nn.ModuleList([nn.Conv3d(c, dim, kernel_size=1, bias=False) for c in in_dim_list])
+        self.fusion = TransformerBlock(dim, depth, heads, dim // heads, dim, attn_drop=attn_drop, proj_drop=proj_drop)
+        self.out_proj = nn.ModuleList([nn.Conv3d(dim, c, kernel_size=1, bias=False) for c in in_dim_list])
+
+    def forward(self, map_list):
+        B, _, D, H, W = map_list[0].shape
+        tok = torch.cat([p(m).flatten(2).transpose(1, 2) for p, m in zip(self.in_proj, map_list)], dim=1)
+        tok = self.fusion(tok)
+        return [p(t.transpose(1, 2).reshape(B, self.dim, D, H, W))
+                for p, t in zip(self.out_proj, tok.chunk(len(map_list), dim=1))]
+
+
+class inconv(nn.Module):
+    """medformer_utils.py:264-277."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=(3, 3, 3), block=BasicBlock, norm="in", act="gelu"):
+        super().__init__()
+        k = _k3(kernel_size)
+        self.conv1 = nn.Conv3d(in_ch, out_ch, kernel_size=k, padding=[i // 2 for i in k], bias=False)
+        self.conv2 = block(out_ch, out_ch, kernel_size=k, norm=norm, act=act)
+
+    def forward(self, x, dtype) -> Fn.FMap:
+        return self.conv2(Fn.FMap(Fn.StemFn.apply(x, self.conv1.weight, dtype), None))
+
+
+class down_block(nn.Module):
+    """medformer_utils.py:281-319."""
+
+    def __init__(self, in_ch, out_ch, conv_num, trans_num, down_scale=(2, 2, 2), kernel_size=(3, 3, 3),
+                 conv_block=BasicBlock, heads=4, dim_head=64, expansion=1, attn_drop=0., proj_drop=0.,
+                 map_size=(8, 8, 8), proj_type="depthwise", norm="in", act="gelu", map_generate=False, map_dim=None):
+        super().__init__()
+        map_dim = out_ch if map_dim is None else map_dim
+        self.map_generate = map_generate
+        if map_generate:
+            self.map_gen = SemanticMapGeneration(out_ch, map_dim, map_size)
+        self.patch_merging = PatchMerging(in_ch, out_ch, norm=norm, proj_type=proj_type, down_scale=down_scale,
+                                          kernel_size=kernel_size)
+        self.conv_blocks = nn.Sequential(*[conv_block(out_ch, out_ch, norm=norm, act=act, kernel_size=kernel_size)
+                                           for _ in range(conv_num)])
+        self.trans_blocks = BasicLayer(out_ch, map_dim, out_ch, num_blocks=trans_num, heads=heads, dim_head=dim_head,
+                                       norm=norm, act=act, expansion=expansion, attn_drop=attn_drop,
+                                       proj_drop=proj_drop, map_size=map_size, proj_type=proj_type,
+                                       kernel_size=kernel_size)
+
+    def forward(self, f: Fn.FMap):
+        f = self.patch_merging(f)
+        for blk in self.conv_blocks:
+            f = blk(f)
+        semantic_map = self.map_gen(f) if self.map_generate else None
+        return self.trans_blocks(f, semantic_map)
+
+
+class up_block(nn.Module):
+    """medformer_utils.py:321-372: cat([upsampled, skip]) (note the order), optional map shortcut."""
+
+    def __init__(self, in_ch, out_ch, conv_num, trans_num, up_scale=(2, 2, 2), kernel_size=(3, 3, 3),
+                 conv_block=BasicBlock, heads=4, dim_head=64, expansion=4, attn_drop=0., proj_drop=0.,
+                 map_size=(4, 8, 8), proj_type="depthwise", norm="in", act="gelu", map_dim=None, map_shortcut=False,
+                 no_map_out=False):
+        super().__init__()
+        self.map_shortcut = map_shortcut
+        map_dim = out_ch if map_dim is None else map_dim
+        self.map_reduction = nn.Conv3d(in_ch + out_ch, map_dim, kernel_size=1, bias=False) if map_shortcut else nn.Identity()
+        self.trans_blocks = BasicLayer(in_ch + out_ch, map_dim, out_ch, num_blocks=trans_num, heads=heads,
+                                       dim_head=dim_head, norm=norm, act=act, expansion=expansion, attn_drop=attn_drop,
+                                       proj_drop=proj_drop, map_size=map_size, proj_type=proj_type,
+                                       kernel_size=kernel_size, no_map_out=no_map_out)
+        d1 = in_ch + out_ch if trans_num == 0 else out_ch
+        convs = []
+        for _ in range(conv_num):
+            convs.append(conv_block(d1, out_ch, kernel_size=kernel_size, norm=norm, act=act))
+            d1 = out_ch
+        self.conv_blocks = nn.Sequential(*convs)
+
+    def forward(self, low: Fn.FMap, skip: Fn.FMap, map1, map2=None):
+        f = Fn.FMap(Fn.UpCatFn.apply(low.t, skip.t, False), None)
+        if self.map_shortcut and map2 is not None:
+            semantic_map = self.map_reduction(torch.cat([map1, map2], dim=1))
+        else:
+            semantic_map = map1
+        f, semantic_map = self.trans_blocks(f, semantic_map)
+        for blk in self.conv_blocks:
+            f = blk(f)
+        return f, semantic_map

@@ -14,4 +14,12 @@ def get_model(args, pretrain=False):
             raise ValueError("No pretrain model available")
         return UNet(args.in_chan, args.base_chan, num_classes=args.classes, scale=args.down_scale,
                     norm=args.norm, kernel_size=args.kernel_size, block=args.block)
+    if args.model == "medformer":   # model/utils.py:92-95 of the reference
+        from .dim3 import MedFormer
+        return MedFormer(args.in_chan, args.classes, args.base_chan, map_size=args.map_size,
+                         conv_block=args.conv_block, conv_num=args.conv_num, trans_num=args.trans_num,
+                         num_heads=args.num_heads, fusion_depth=args.fusion_depth, fusion_dim=args.fusion_dim,
+                         fusion_heads=args.fusion_heads, expansion=args.expansion, attn_drop=args.attn_drop,
+                         proj_drop=args.proj_drop, proj_type=args.proj_type, norm=args.norm, act=args.act,
+                         kernel_size=args.kernel_size, scale=args.down_scale, aux_loss=args.aux_loss)
     raise NotImplementedError(f"cbim_amd: 3D model '{args.model}' is not built yet")

@@ -1,0 +1,95 @@
+"""Golden fixtures for MedFormer, produced by EXECUTING THE REAL REFERENCE on CPU (fp32).
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden_medformer.py
+
+Same import shim as make_golden.py.  Cases
+  medformer_tiny_32   reduced widths (dim_head 8, 8 map codes), 32^3, full state_dict + every gradient:
+                      pins oracle/medformer_ref.py and the HIP path (CPU executor and GPU)
+  medformer_amos_64   the shipped AMOS config (config/amos_ct/medformer_3d.yaml) at 64^3; weights are the
+                      reference constructor's under torch.manual_seed(seed) (our module reproduces them
+                      bit for bit — checked through sd_checksum); stores strided logits, losses and
+                      per-parameter gradient norms / sums.  GPU parity test only.
+No reference source is copied; only tensors it produced.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import make_golden as mg  # noqa: E402
+
+TINY = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num=[2, 1, 0, 0, 0, 1, 2, 2],
+            trans_num=[0, 1, 1, 2, 1, 1, 0, 0], chan_num=[16, 16, 32, 40, 32, 16, 16, 8],
+            num_heads=[1, 2, 4, 5, 4, 2, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
+            attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
+            scale=[[2, 2, 2]] * 4, aux_loss=True)
+AMOS = dict(base_chan=32, map_size=[4, 4, 4], conv_block="BasicBlock", conv_num=[2, 1, 0, 0, 0, 1, 2, 2],
+            trans_num=[0, 1, 4, 6, 4, 1, 0, 0], chan_num=[64, 128, 256, 320, 256, 128, 64, 32],
+            num_heads=[1, 4, 8, 10, 8, 4, 1, 1], fusion_depth=2, fusion_dim=320, fusion_heads=10, expansion=4,
+            attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
+            scale=[[2, 2, 2]] * 4, aux_loss=True)
+CASES = {
+    # name: (in_chan, classes, kwargs, spatial, batch, seed, full)
+    "medformer_tiny_32": (1, 4, TINY, (32, 32, 32), 2, 3031, True),
+    "medformer_amos_64": (1, 16, AMOS, (64, 64, 64), 1, 3032, False),
+}
+AUX_WEIGHT = [0.5, 0.5]   # config/amos_ct/medformer_3d.yaml: aux_weight
+
+
+def main():
+    _, DiceLoss = mg.import_reference()
+    MedFormer = importlib.import_module("model.dim3.medformer").MedFormer
+    from oracle.unet_ref import state_dict_checksum
+    torch.set_num_threads(8)
+    for name, (in_ch, classes, kw, shape, batch, seed, full) in CASES.items():
+        torch.manual_seed(seed)
+        net = MedFormer(in_ch, classes, **kw)
+        net.train()
+        gen = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn((batch, in_ch) + shape, generator=gen).clamp_(-7.4, 2.2)
+        lab = mg.make_labels(classes, shape, batch, gen)
+        weight = torch.ones(classes)
+        weight[0] = 0.5
+        outs = net(x)
+        ce_fn, dl_fn = torch.nn.CrossEntropyLoss(weight=weight), DiceLoss()
+        ces = [ce_fn(o, lab.squeeze(1)) for o in outs]
+        dls = [dl_fn(o, lab) for o in outs]
+        loss = sum(w * (c + d) for w, c, d in zip(AUX_WEIGHT, ces, dls))   # train.py:207-210
+        loss.backward()
+        sd = net.state_dict()
+        grads = {k: p.grad for k, p in net.named_parameters()}
+        st = 1 if full else 4
+        out = {
+            "x": x.numpy(), "label": lab.numpy().astype(np.int64), "weight": weight.numpy(),
+            "logits": outs[0].detach().numpy()[..., ::st, ::st, ::st],
+            "aux_logits": outs[1].detach().numpy()[..., ::st, ::st, ::st], "stride": np.int64(st),
+            "ce": np.array([float(c) for c in ces]), "dice": np.array([float(d) for d in dls]),
+            "loss": np.float64(loss.item()),
+            "n_params": np.int64(sum(p.numel() for p in net.parameters())), "n_tensors": np.int64(len(sd)),
+            "n_buffers": np.int64(len(list(net.buffers()))),
+            "keys": np.array(list(sd.keys())), "shapes": np.array([str(tuple(v.shape)) for v in sd.values()]),
+            "grad_norms": np.array([float(grads[k].double().norm()) for k in sd.keys()]),
+            "grad_sums": np.array([float(grads[k].double().sum()) for k in sd.keys()]),
+            "sd_checksum": np.float64(state_dict_checksum(sd)), "seed": np.int64(seed),
+            "g:inc.conv1.weight": grads["inc.conv1.weight"].numpy(),
+            "g:outc.weight": grads["outc.weight"].numpy(), "g:aux_out.weight": grads["aux_out.weight"].numpy(),
+        }
+        if full:
+            for k, v in sd.items():
+                out["p:" + k] = v.numpy()
+                out["g:" + k] = grads[k].numpy()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "logits", tuple(outs[0].shape), "loss", float(loss), "params", int(out["n_params"]), "tensors",
+              int(out["n_tensors"]), "size", os.path.getsize(path) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()

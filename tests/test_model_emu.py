@@ -89,3 +89,22 @@ def test_dice_loss_module_matches_reference_value(dev):
     pred = torch.randn(2, 10, 8, 16, 16)
     target = torch.zeros(2, 1, 8, 16, 16).long()
     assert abs(float(DiceLoss()(pred, target)) - float(f["dice_zero_target"])) < 1e-5
+
+
+def test_medformer_plugin_surface():
+    """get_model(args) with the AMOS yaml keys builds the reference's parameter layout."""
+    from cbim_amd.model.utils import get_model
+    from tests.medformer_checks import AMOS
+    a = dict(AMOS)
+    a["down_scale"] = a.pop("scale")
+    net = get_model(_args(model="medformer", **a))
+    assert sum(p.numel() for p in net.parameters()) == 39594048 and len(net.state_dict()) == 278
+    assert len(list(net.buffers())) == 0
+    sd = net.state_dict()
+    assert tuple(sd["down3.trans_blocks.blocks.0.feedforward.depthwise.conv.weight"].shape) == (1024, 1, 3, 3, 3)
+    assert tuple(sd["up1.trans_blocks.blocks.0.shortcut.conv.weight"].shape) == (256, 576, 1, 1, 1)
+
+
+def test_medformer_fp32_matches_reference_golden(dev):
+    from tests.medformer_checks import assert_fp32_parity
+    assert_fp32_parity("medformer_tiny_32", dev)
