@@ -676,7 +676,8 @@ static int pick_ksplit(const cbim_conv_desc* d, const TileCfg& c) {
   int64_t tiles = (int64_t)d->N * ((d->Do + c.tD - 1) / c.tD) * ((d->Ho + c.tH - 1) / c.tH) * ((d->Wo + 7) / 8);
   int BN = 32 * c.NTL;
   int64_t wgs = tiles * ((d->Cout + BN - 1) / BN);
-  if (wgs >= 96 || n_chunks < 2 || d->Cout > 256 * 8) return 1;
+  // the finish kernel keeps one 16-byte output chunk per thread (FT = 256 threads)
+  if (wgs >= 96 || n_chunks < 2 || d->Cout / (d->dtype == CBIM_BF16 ? 8 : 4) > 256) return 1;
   int64_t s = (192 + wgs - 1) / wgs;
   if (s > n_chunks) s = n_chunks;
   if (s > 16) s = 16;

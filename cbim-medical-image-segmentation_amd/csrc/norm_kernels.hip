@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
                                                      const void* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ stats, int64_t S, int C,
                                                      int P, int act, int masked,
-                                                     float* __restrict__ partials) {
+                                                     float* __restrict__ partials, int Cl, int c_off) {
+  // C = channels handled by this launch (<= NT chunks), starting at channel c_off of a Cl-channel tensor
   constexpr int CPC = Elem<T>::CPC;
   const int cch = C / CPC;
   const int vlc = NT / cch;            // host guarantees cch <= NT
@@ -47,15 +48,15 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
   if (MODE == 1 && active) {
 #pragma unroll
     for (int j = 0; j < CPC; ++j) {
-      mean[j] = stats[((size_t)n * C + cc * CPC + j) * 2 + 0];
-      rstd[j] = stats[((size_t)n * C + cc * CPC + j) * 2 + 1];
+      mean[j] = stats[((size_t)n * Cl + c_off + cc * CPC + j) * 2 + 0];
+      rstd[j] = stats[((size_t)n * Cl + c_off + cc * CPC + j) * 2 + 1];
     }
   }
   if (active) {
     const size_t nb = (size_t)n * S;
     for (int64_t v = v0 + vl; v < v1; v += vlc) {
       float fa[CPC];
-      Elem<T>::unpack(ld_chunk<T>(a, (nb + v) * a_stride + (size_t)cc * CPC), fa);
+      Elem<T>::unpack(ld_chunk<T>(a, (nb + v) * a_stride + c_off + (size_t)cc * CPC), fa);
       if (MODE == 0) {
         if (cnt == 0.f) {
 #pragma unroll
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
         for (int j = 0; j < CPC; ++j) { float d = fa[j] - shift[j]; s0[j] += d; s1[j] += d * d; }
       } else {
         float fx[CPC];
-        Elem<T>::unpack(ld_chunk<T>(x, (nb + v) * x_stride + (size_t)cc * CPC), fx);
+        Elem<T>::unpack(ld_chunk<T>(x, (nb + v) * x_stride + c_off + (size_t)cc * CPC), fx);
 #pragma unroll
         for (int j = 0; j < CPC; ++j) {
           float xh = (fx[j] - mean[j]) * rstd[j];
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
           acc.m2 += r[2];
         }
       }
-      size_t o = (((size_t)n * P + part) * C + cc * CPC + j) * 3;
+      size_t o = (((size_t)n * P + part) * Cl + c_off + cc * CPC + j) * 3;
       partials[o] = acc.n;
       partials[o + 1] = acc.mean;
       partials[o + 2] = acc.m2;
@@ -183,17 +184,18 @@ static constexpr int RU = 4;
 template <typename T>
 __global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ stats, void* __restrict__ y,
-                                                     int64_t y_stride, int64_t S, int C, int act) {
+                                                     int64_t y_stride, int64_t S, int C, int act, int Cl,
+                                                     int c_off) {
   constexpr int CPC = Elem<T>::CPC;
   const int cch = C / CPC, vlc = NT / cch;
-  const int cc = threadIdx.x % cch, vl = threadIdx.x / cch;
+  const int cc = threadIdx.x % cch + c_off / CPC, vl = threadIdx.x / cch;
   if (vl >= vlc) return;
   const int n = blockIdx.y;
   float mean[CPC], rstd[CPC];
 #pragma unroll
   for (int j = 0; j < CPC; ++j) {
-    mean[j] = stats[((size_t)n * C + cc * CPC + j) * 2];
-    rstd[j] = stats[((size_t)n * C + cc * CPC + j) * 2 + 1];
+    mean[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2];
+    rstd[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2 + 1];
   }
   const size_t nb = (size_t)n * S;
   const int64_t step = (int64_t)gridDim.x * vlc;
@@ -223,19 +225,19 @@ __global__ void __launch_bounds__(NT) k_norm_bwd_apply(const void* __restrict__ 
                                                        const float* __restrict__ sums,
                                                        const void* __restrict__ add, int64_t add_stride,
                                                        void* __restrict__ dx, int64_t dx_stride, int64_t S,
-                                                       int C, int act, int masked) {
+                                                       int C, int act, int masked, int Cl, int c_off) {
   constexpr int CPC = Elem<T>::CPC;
   const int cch = C / CPC, vlc = NT / cch;
-  const int cc = threadIdx.x % cch, vl = threadIdx.x / cch;
+  const int cc = threadIdx.x % cch + c_off / CPC, vl = threadIdx.x / cch;
   if (vl >= vlc) return;
   const int n = blockIdx.y;
   float mean[CPC], rstd[CPC], m1[CPC], m2[CPC];
 #pragma unroll
   for (int j = 0; j < CPC; ++j) {
-    mean[j] = stats[((size_t)n * C + cc * CPC + j) * 2];
-    rstd[j] = stats[((size_t)n * C + cc * CPC + j) * 2 + 1];
-    m1[j] = sums[((size_t)n * C + cc * CPC + j) * 2];
-    m2[j] = sums[((size_t)n * C + cc * CPC + j) * 2 + 1];
+    mean[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2];
+    rstd[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2 + 1];
+    m1[j] = sums[((size_t)n * Cl + cc * CPC + j) * 2];
+    m2[j] = sums[((size_t)n * Cl + cc * CPC + j) * 2 + 1];
   }
   const size_t nb = (size_t)n * S;
   const int64_t step = (int64_t)gridDim.x * vlc;
@@ -317,9 +319,13 @@ static int check_c(int dtype, int C) {
   int cpc = dtype == CBIM_BF16 ? 8 : 4;
   CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
   CBIM_CHECK(C > 0 && C % cpc == 0, CBIM_EUNSUPPORTED, "channel count %d is not a multiple of %d", C, cpc);
-  CBIM_CHECK(C / cpc <= NT, CBIM_EUNSUPPORTED, "channel count %d too large", C);
   return 0;
 }
+
+// the kernels keep one channel chunk per thread: wider tensors are processed in groups of <= NT chunks
+#define FOR_CHANNEL_GROUPS(dtype, C)                                             \
+  for (int c_off = 0, cg_max = NT * ((dtype) == CBIM_BF16 ? 8 : 4), Cg = 0;     \
+       c_off < (C) && ((Cg = (C) - c_off > cg_max ? cg_max : (C) - c_off), true); c_off += cg_max)
 
 __global__ void k_noop() {}
 
@@ -347,12 +353,14 @@ extern "C" int cbim_instnorm_stats(int dtype, const void* x, int64_t x_stride, i
   CBIM_CHECK(P >= 1 && N >= 1 && S >= 1, CBIM_EINVAL, "bad sizes");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(P, N);
-  if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_partial_sums<bf16_tag, 0>), grid, dim3(NT), 0, st, x, x_stride, x, x_stride,
-                (const float*)nullptr, S, C, P, 0, 0, partials);
-  else
-    CBIM_LAUNCH((k_partial_sums<float, 0>), grid, dim3(NT), 0, st, x, x_stride, x, x_stride,
-                (const float*)nullptr, S, C, P, 0, 0, partials);
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_partial_sums<bf16_tag, 0>), grid, dim3(NT), 0, st, x, x_stride, x, x_stride,
+                  (const float*)nullptr, S, Cg, P, 0, 0, partials, C, c_off);
+    else
+      CBIM_LAUNCH((k_partial_sums<float, 0>), grid, dim3(NT), 0, st, x, x_stride, x, x_stride,
+                  (const float*)nullptr, S, Cg, P, 0, 0, partials, C, c_off);
+  }
   return cbim_stats_finalize(partials, N, P, C, (double)S, eps, 0, stats, stream);
 }
 
@@ -367,12 +375,16 @@ extern "C" int cbim_stats_finalize(const float* partials, int N, int P, int C, d
 extern "C" int cbim_norm_act_fwd(int dtype, const void* x, int64_t x_stride, const float* stats, void* y,
                                  int64_t y_stride, int N, int64_t S, int C, int act, void* stream) {
   if (int e = check_c(dtype, C)) return e;
-  dim3 grid(row_blocks(dtype, S, C), N);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_norm_act_fwd<bf16_tag>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, C, act);
-  else
-    CBIM_LAUNCH((k_norm_act_fwd<float>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, C, act);
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    dim3 grid(row_blocks(dtype, S, Cg), N);
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_norm_act_fwd<bf16_tag>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, Cg, act, C,
+                  c_off);
+    else
+      CBIM_LAUNCH((k_norm_act_fwd<float>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, Cg, act, C,
+                  c_off);
+  }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
@@ -382,12 +394,14 @@ extern "C" int cbim_norm_bwd_reduce(int dtype, const void* g, int64_t g_stride, 
   if (int e = check_c(dtype, C)) return e;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(P, N);
-  if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_partial_sums<bf16_tag, 1>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, C,
-                P, act, masked, partials);
-  else
-    CBIM_LAUNCH((k_partial_sums<float, 1>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, C, P,
-                act, masked, partials);
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_partial_sums<bf16_tag, 1>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, Cg,
+                  P, act, masked, partials, C, c_off);
+    else
+      CBIM_LAUNCH((k_partial_sums<float, 1>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, Cg, P,
+                  act, masked, partials, C, c_off);
+  }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
@@ -396,14 +410,16 @@ extern "C" int cbim_norm_bwd_apply(int dtype, const void* g, int64_t g_stride, c
                                    int64_t add_stride, void* dx, int64_t dx_stride, int N, int64_t S, int C,
                                    int act, int masked, void* stream) {
   if (int e = check_c(dtype, C)) return e;
-  dim3 grid(row_blocks(dtype, S, C), N);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_norm_bwd_apply<bf16_tag>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
-                add_stride, dx, dx_stride, S, C, act, masked);
-  else
-    CBIM_LAUNCH((k_norm_bwd_apply<float>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
-                add_stride, dx, dx_stride, S, C, act, masked);
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    dim3 grid(row_blocks(dtype, S, Cg), N);
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_norm_bwd_apply<bf16_tag>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
+                  add_stride, dx, dx_stride, S, Cg, act, masked, C, c_off);
+    else
+      CBIM_LAUNCH((k_norm_bwd_apply<float>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
+                  add_stride, dx, dx_stride, S, Cg, act, masked, C, c_off);
+  }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

@@ -18,6 +18,7 @@ def test_instnorm(dev, dtype):
     oc.check_instnorm(dev, dtype)
     oc.check_instnorm(dev, dtype, N=1, C=72, dhw=(2, 3, 3))
     oc.check_instnorm(dev, dtype, N=1, C=32, dhw=(40, 33, 31))
+    oc.check_instnorm(dev, dtype, N=1, C=2056, dhw=(4, 4, 4))
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
@@ -67,3 +68,47 @@ def test_loss(dev):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_fused_conv1_shortcut_block(dev, dtype):
     oc.check_fused_block(dev, dtype)
+
+
+def test_conv_pointwise_and_norm_without_act(dev):
+    oc.check_conv(dev, F32, 2, 24, 40, (5, 6, 7), (1, 1, 1))
+    oc.check_conv(dev, BF16, 1, 64, 32, (4, 8, 8), (1, 1, 1))
+    oc.check_conv(dev, BF16, 1, 2048, 320, (8, 8, 8), (1, 1, 1))      # PatchMerging reduction of down4
+    oc.check_conv(dev, BF16, 1, 128, 512, (32, 32, 32), (1, 1, 1))    # MBConv expand at 32^3
+    oc.check_conv(dev, F32, 1, 16, 24, (4, 6, 8), (1, 1, 1), act="none")
+    oc.check_conv(dev, BF16, 1, 16, 16, (4, 8, 8), (3, 3, 3), act="none")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_dwconv(dev, dtype):
+    oc.check_dwconv(dev, dtype)
+    oc.check_dwconv(dev, dtype, N=1, C=40, dhw=(2, 2, 2), act="none")
+    oc.check_dwconv(dev, dtype, N=1, C=512, dhw=(16, 16, 16))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_space_to_depth(dev, dtype):
+    oc.check_space_to_depth(dev, dtype)
+    oc.check_space_to_depth(dev, dtype, C=16, dhw=(2, 4, 6), scale=(1, 2, 2))
+    oc.check_space_to_depth(dev, dtype, N=1, C=32, dhw=(32, 32, 32))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attn(dev, dtype):
+    oc.check_attn(dev, dtype)
+    oc.check_attn(dev, dtype, N=1, heads=1, dh=16, dhw=(2, 2, 2), M=8)
+    oc.check_attn(dev, dtype, N=1, heads=2, dh=32, dhw=(4, 6, 6), M=64)
+    oc.check_attn(dev, dtype, N=1, heads=4, dh=32, dhw=(16, 16, 16), M=64)   # down3-sized
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_mappool(dev, dtype):
+    oc.check_mappool(dev, dtype)
+    oc.check_mappool(dev, dtype, N=1, C=72, M=64, dhw=(6, 6, 5))
+    oc.check_mappool(dev, dtype, N=1, C=128, M=64, dhw=(16, 16, 16))
+
+
+def test_trilinear_planes(dev):
+    oc.check_trilinear_planes(dev)
+    oc.check_trilinear_planes(dev, lo=(1, 2, 2), hi=(4, 4, 4))
+    oc.check_trilinear_planes(dev, C=16, lo=(16, 16, 16), hi=(64, 64, 64))

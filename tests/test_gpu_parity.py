@@ -133,3 +133,22 @@ def test_training_reduces_loss_and_matches_oracle_at_64(dev):
 def test_smoke_entry(dev):
     import __graft_entry__ as ge
     ge.smoke()
+
+
+# ---- MedFormer -------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["medformer_tiny_32", "medformer_amos_64"])
+def test_medformer_fp32_matches_reference_golden(dev, name):
+    from tests.medformer_checks import assert_fp32_parity as mf_parity
+    print(name, mf_parity(name, dev))
+
+
+def test_medformer_bf16_inside_envelope(dev):
+    """bf16 engine mode of the shipped AMOS config at 64^3 against the reference's fp32 golden: same
+    envelope as the UNet family."""
+    from tests.medformer_checks import run_case as mf_run
+    r, g = mf_run("medformer_amos_64", dev, "bf16")
+    print(r)
+    assert r["logits_err"] < 0.25 and r["aux_err"] < 0.25, r
+    assert max(abs(a - b) for a, b in zip(r["ce"] + r["dice"], list(g["ce"]) + list(g["dice"]))) < 0.05, r
+    assert r["grad_norm_err"] < 0.5, r

@@ -19,6 +19,7 @@ def _need_emu(dev):
 def test_instnorm(dev, dtype):
     oc.check_instnorm(dev, dtype)
     oc.check_instnorm(dev, dtype, N=1, C=72, dhw=(2, 3, 3))
+    oc.check_instnorm(dev, dtype, N=1, C=2056, dhw=(2, 2, 3))   # > 256 chunks: channel groups
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
