@@ -27,6 +27,12 @@ import torch
 import torch.distributed as dist
 
 FWD_FLOPS_128 = 2.592e12          # ResUNet-BasicBlock fwd at 1x1x128^3, 16 classes
+FWD_FLOPS_128_MEDFORMER = 2.34e12  # MedFormer (AMOS yaml) fwd at 1x1x128^3
+MEDFORMER_AMOS = dict(base_chan=32, map_size=[4, 4, 4], conv_block="BasicBlock", conv_num=[2, 1, 0, 0, 0, 1, 2, 2],
+                      trans_num=[0, 1, 4, 6, 4, 1, 0, 0], chan_num=[64, 128, 256, 320, 256, 128, 64, 32],
+                      num_heads=[1, 4, 8, 10, 8, 4, 1, 1], fusion_depth=2, fusion_dim=320, fusion_heads=10,
+                      expansion=4, attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu",
+                      kernel_size=[[3, 3, 3]] * 5, scale=[[2, 2, 2]] * 4, aux_loss=True)  # config/amos_ct/medformer_3d.yaml
 PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_F32_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
@@ -47,6 +53,11 @@ def parse():
     ap.add_argument("--graph", type=int, default=1,
                     help="1: replay the whole step from one hipGraph (captured after warm-up; N=1 only)")
     ap.add_argument("--cpu-size", type=int, default=96, help="edge of the CPU-baseline sample volume")
+    ap.add_argument("--model", default="resunet", choices=["resunet", "medformer"],
+                    help="resunet = BASELINE configs[1] (the headline); medformer = configs[2] (AMOS yaml, aux loss)")
+    ap.add_argument("--aug", type=int, default=0,
+                    help="1: draw each step's volume with the on-device augmentation pipeline (configs[3]): affine "
+                         "scale/rotate + centre crop from a (size+40)^3 source, then the intensity ops")
     return ap.parse_args()
 
 
@@ -60,19 +71,30 @@ def synthetic(batch, classes, size, device, seed):
 
 def cpu_baseline(args):
     """Oracle fwd + loss + bwd on the host cores, one volume (bounded sample)."""
-    from oracle import loss_ref, unet_ref
+    from oracle import loss_ref, medformer_ref, unet_ref
     cores = min(os.cpu_count() or 1, 64)   # one socket's worth; oneDNN conv3d stops scaling beyond
     torch.set_num_threads(cores)
     ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
-    sd = unet_ref.make_unet_state_dict(1, args.base, args.classes, ks, "BasicBlock", seed=2023)
-    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
     s = args.cpu_size
     x, lab = synthetic(1, args.classes, s, "cpu", 2023)
     w = torch.ones(args.classes)
     w[0] = 0.5
-    t0 = time.perf_counter()
-    logits = unet_ref.unet_forward(sd, x, scale=sc, kernel_size=ks, block="BasicBlock")
-    loss = loss_ref.ce_dice_loss(logits, lab, w)
+    if args.model == "medformer":
+        from cbim_amd.model.dim3 import MedFormer   # only as the weight initialiser (reference parameter layout)
+        torch.manual_seed(2023)
+        sd = {k: v.detach().requires_grad_(True) for k, v in MedFormer(1, args.classes, **MEDFORMER_AMOS).state_dict().items()}
+        m = MEDFORMER_AMOS
+        t0 = time.perf_counter()
+        outs = medformer_ref.medformer_forward(sd, x, map_size=m["map_size"], num_heads=m["num_heads"],
+                                               fusion_heads=m["fusion_heads"], fusion_depth=m["fusion_depth"],
+                                               kernel_size=m["kernel_size"], scale=m["scale"], act="relu", aux_loss=True)
+        loss = sum(0.5 * loss_ref.ce_dice_loss(o, lab, w) for o in outs)
+    else:
+        sd = unet_ref.make_unet_state_dict(1, args.base, args.classes, ks, "BasicBlock", seed=2023)
+        sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+        t0 = time.perf_counter()
+        logits = unet_ref.unet_forward(sd, x, scale=sc, kernel_size=ks, block="BasicBlock")
+        loss = loss_ref.ce_dice_loss(logits, lab, w)
     loss.backward()
     dt = time.perf_counter() - t0
     scale = (128.0 / s) ** 3 if s != 128 else 1.0
@@ -94,7 +116,8 @@ def main():
 
     import cbim_amd
     from cbim_amd import _lib, ops
-    from cbim_amd.model.dim3 import UNet
+    from cbim_amd.model.dim3 import MedFormer, UNet
+    from cbim_amd.training import augmentation as aug
     from cbim_amd.parallel import GradAllReduce
     from cbim_amd.training.losses import DiceCELoss
     assert _lib.backend() == "hip-gfx950"
@@ -102,7 +125,10 @@ def main():
 
     torch.manual_seed(2023)
     ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
-    net = UNet(1, args.base, scale=sc, kernel_size=ks, num_classes=args.classes, block="BasicBlock", norm="in").to(dev)
+    if args.model == "medformer":
+        net = MedFormer(1, args.classes, **MEDFORMER_AMOS).to(dev)
+    else:
+        net = UNet(1, args.base, scale=sc, kernel_size=ks, num_classes=args.classes, block="BasicBlock", norm="in").to(dev)
     net.train()
     w = torch.ones(args.classes)
     w[0] = 0.5
@@ -112,11 +138,41 @@ def main():
                             capturable=use_graph)
     ddp = GradAllReduce(net) if world > 1 else None
     x, lab = synthetic(1, args.classes, args.size, dev, 2023 + rank)
+    if args.aug:
+        # source volume with the dataset's affine padding (dataset_amos_ct.py:105-165: affine_pad_size 40)
+        src_x, src_lab = synthetic(1, args.classes, args.size + 40, dev, 2023 + rank)
+        src_lab = src_lab.to(torch.int8)
+        import numpy as np
+        np.random.seed(2023 + rank)
+        use_graph = False   # the pipeline draws host-side random parameters every step
+
+    def draw():
+        """dataset_amos_ct.py:130-153 on the device: affine (scale 0.3, rotate 30) + centre crop, then each
+        intensity op with probability 0.2."""
+        xi, li = aug.random_affine_center_crop_3d(src_x, src_lab, (args.size,) * 3, scale=[0.3] * 3, rotate=[30] * 3,
+                                                   translate=[0] * 3)
+        if np.random.random() < 0.2:
+            xi = aug.brightness_multiply(xi, multiply_range=[0.7, 1.3])
+        if np.random.random() < 0.2:
+            xi = aug.brightness_additive(xi, std=0.1)
+        if np.random.random() < 0.2:
+            xi = aug.gamma(xi, gamma_range=[0.7, 1.5])
+        if np.random.random() < 0.2:
+            xi = aug.contrast(xi, contrast_range=[0.7, 1.3])
+        if np.random.random() < 0.2:
+            xi = aug.gaussian_blur(xi, sigma_range=[0.5, 1.0])
+        if np.random.random() < 0.2:
+            xi = aug.gaussian_noise(xi, std=0.02)
+        return xi, li.long()
 
     def step():
         opt.zero_grad(set_to_none=True)
-        logits = net(x)
-        loss = crit(logits, lab)
+        xs, ls = draw() if args.aug else (x, lab)
+        out = net(xs)
+        if isinstance(out, (list, tuple)):      # deep supervision, train.py:207-210 (aux_weight [0.5, 0.5])
+            loss = sum(0.5 * crit(o, ls) for o in out)
+        else:
+            loss = crit(out, ls)
         loss.backward()
         if ddp is not None:
             ddp.synchronize()
@@ -168,8 +224,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"3D UNet ResBasicBlock (amos_ct/resunet_3d.yaml), 1x1x{args.size}^3 per GPU, "
-                               f"{args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
+        "config": {"workload": ("3D MedFormer (amos_ct/medformer_3d.yaml, aux loss)" if args.model == "medformer"
+                                else "3D UNet ResBasicBlock (amos_ct/resunet_3d.yaml)")
+                               + f", 1x1x{args.size}^3 per GPU, {args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
+                               + (", on-device augmentation (affine+crop+intensity) per step" if args.aug else "")
                                + (" (hipGraph replay)" if use_graph else "")
                                + (", bucketed grad all-reduce (RCCL)" if world > 1 else ""),
                    "global_batch": world, "parallelism": f"dp{world}", "final_loss": loss_val},
@@ -195,7 +253,8 @@ def main():
                      "frac_of_peak": v[0] / v[1] / 1e12 / peak} for k, v in per.items()}
         dom = max((k for k in per if k.startswith("k_conv_igemm")), key=lambda k: per[k][1])
         f, tsec, nl = per[dom]
-        step_flops = 3.0 * FWD_FLOPS_128 * (args.size / 128.0) ** 3 * (args.base / 32.0) ** 2
+        fwd128 = FWD_FLOPS_128_MEDFORMER if args.model == "medformer" else FWD_FLOPS_128 * (args.base / 32.0) ** 2
+        step_flops = 3.0 * fwd128 * (args.size / 128.0) ** 3
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": f / tsec / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": f / tsec / 1e12 / peak, "traffic": None,

@@ -139,6 +139,189 @@ __global__ void __launch_bounds__(NT) k_dwconv_wgrad(const void* __restrict__ x,
   for (int j = 0; j < CPC; ++j) part[((size_t)blockIdx.x * C + c0 + j) * TT + tap] = acc[j];
 }
 
+
+// ---- depthwise convolution, kW == 3 fast path -------------------------------------------------------
+// Thread = (channel chunk, strip of WT consecutive outputs along W): every (kd,kh) input row segment of
+// WT+2 chunks is loaded and normalised ONCE and feeds 3*WT multiply-adds per channel; the weights of the
+// block's chunk group sit in LDS as [tap][channel].  blockIdx.y = chunk group (DG chunks).
+static constexpr int DG = 32;   // channel chunks per block (one 512-byte bf16 row segment per voxel)
+static constexpr int WT = 4;
+template <typename T>
+__global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int64_t xs,
+                                                const float* __restrict__ in_stats, int act,
+                                                const float* __restrict__ bias, const float* __restrict__ w,
+                                                int flip, void* __restrict__ y, int64_t ys, int N, int D, int H, int W,
+                                                int C, int kD, int kH) {
+  constexpr int CPC = Elem<T>::CPC;
+  __shared__ float w_s[27 * DG * CPC];
+  const int cch = C / CPC;
+  const int g0 = blockIdx.y * DG;
+  const int G = cch - g0 < DG ? cch - g0 : DG;
+  const int TT = kD * kH * 3, pD = kD / 2, pH = kH / 2;
+  for (int i = threadIdx.x; i < TT * G * CPC; i += NT) {
+    int tap = i / (G * CPC), ch = i % (G * CPC);
+    w_s[tap * (DG * CPC) + ch] = w[(size_t)(g0 * CPC + ch) * TT + (flip ? TT - 1 - tap : tap)];
+  }
+  __syncthreads();
+  const int cl = threadIdx.x % G, sl = threadIdx.x / G, SL = NT / G;
+  if (sl >= SL) return;
+  const int c0 = (g0 + cl) * CPC;
+  const int strips = (W + WT - 1) / WT;
+  const int64_t total = (int64_t)N * D * H * strips;
+  for (int64_t it = (int64_t)blockIdx.x * SL + sl; it < total; it += (int64_t)gridDim.x * SL) {
+    int64_t r = it;
+    const int w0 = (int)(r % strips) * WT; r /= strips;
+    const int ho = (int)(r % H); r /= H;
+    const int dz = (int)(r % D);
+    const int64_t n = r / D;
+    float mean[CPC], rstd[CPC], bs[CPC], acc[WT][CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      mean[j] = in_stats ? in_stats[((size_t)n * C + c0 + j) * 2] : 0.f;
+      rstd[j] = in_stats ? in_stats[((size_t)n * C + c0 + j) * 2 + 1] : 1.f;
+      bs[j] = bias ? bias[(size_t)n * C + c0 + j] : 0.f;
+#pragma unroll
+      for (int o = 0; o < WT; ++o) acc[o][j] = 0.f;
+    }
+    for (int a = 0; a < kD; ++a) {
+      const int dd = dz + a - pD;
+      if (dd < 0 || dd >= D) continue;
+      for (int b = 0; b < kH; ++b) {
+        const int hh = ho + b - pH;
+        if (hh < 0 || hh >= H) continue;
+        const size_t rbase = (((size_t)n * D + dd) * H + hh) * W;
+        float in[WT + 2][CPC];
+#pragma unroll
+        for (int q = 0; q < WT + 2; ++q) {
+          const int ww = w0 - 1 + q;
+          if (ww >= 0 && ww < W) {
+            Elem<T>::unpack(ld_chunk<T>(x, (rbase + ww) * xs + c0), in[q]);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) {
+              float v = in[q][j];
+              if (in_stats) v = act_fwd((v - mean[j]) * rstd[j], act);
+              in[q][j] = v + bs[j];
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) in[q][j] = 0.f;
+          }
+        }
+        const float* wt = w_s + ((a * kH + b) * 3) * (DG * CPC) + cl * CPC;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float wv[CPC];
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) wv[j] = wt[c * (DG * CPC) + j];
+#pragma unroll
+          for (int o = 0; o < WT; ++o)
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) acc[o][j] += in[o + c][j] * wv[j];
+        }
+      }
+    }
+    const size_t obase = (((size_t)n * D + dz) * H + ho) * W;
+#pragma unroll
+    for (int o = 0; o < WT; ++o)
+      if (w0 + o < W) st_chunk<T>(y, (obase + w0 + o) * ys + c0, Elem<T>::pack(acc[o]));
+  }
+}
+
+// depthwise weight gradient, kW == 3: thread = (channel chunk, row lane); for each (kd,kh) pair it sweeps
+// its rows with a 3-wide sliding window over W (1 new x chunk + 1 dy chunk per voxel, 24 accumulators),
+// then the row lanes are summed through LDS and the block writes its partial [C][T] slab.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_dwconv3_wgrad(const void* __restrict__ x, int64_t xs,
+                                                      const float* __restrict__ in_stats, int act,
+                                                      const void* __restrict__ dy, int64_t dys,
+                                                      const float* __restrict__ dy_bias, float* __restrict__ part,
+                                                      int N, int D, int H, int W, int C, int kD, int kH, int rpb) {
+  constexpr int CPC = Elem<T>::CPC;
+  __shared__ float red[NT * 3 * CPC];
+  const int cch = C / CPC;
+  const int g0 = blockIdx.y * DG;
+  const int G = cch - g0 < DG ? cch - g0 : DG;
+  const int TT = kD * kH * 3, pD = kD / 2, pH = kH / 2;
+  const int cl = threadIdx.x % G, rl = threadIdx.x / G, RL = NT / G;
+  const bool active = rl < RL;
+  const int c0 = (g0 + cl) * CPC;
+  const int64_t rows = (int64_t)N * D * H;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb;
+  if (r1 > rows) r1 = rows;
+  for (int pr = 0; pr < kD * kH; ++pr) {
+    const int a = pr / kH - pD, b = pr % kH - pH;
+    float acc[3][CPC];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) acc[c][j] = 0.f;
+    if (active) {
+      for (int64_t row = r0 + rl; row < r1; row += RL) {
+        int64_t r = row;
+        const int ho = (int)(r % H); r /= H;
+        const int dz = (int)(r % D);
+        const int64_t n = r / D;
+        const int dd = dz + a, hh = ho + b;
+        if (dd < 0 || dd >= D || hh < 0 || hh >= H) continue;
+        float mean[CPC], rstd[CPC], bs[CPC];
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          mean[j] = in_stats ? in_stats[((size_t)n * C + c0 + j) * 2] : 0.f;
+          rstd[j] = in_stats ? in_stats[((size_t)n * C + c0 + j) * 2 + 1] : 1.f;
+          bs[j] = dy_bias ? dy_bias[(size_t)n * C + c0 + j] : 0.f;
+        }
+        const size_t xb = (((size_t)n * D + dd) * H + hh) * W, gb = (size_t)row * W;
+        float xm[CPC], xc[CPC], xp[CPC];   // a(x) at w-1, w, w+1
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) xm[j] = 0.f;
+        Elem<T>::unpack(ld_chunk<T>(x, xb * xs + c0), xc);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j)
+          if (in_stats) xc[j] = act_fwd((xc[j] - mean[j]) * rstd[j], act);
+        for (int wv = 0; wv < W; ++wv) {
+          if (wv + 1 < W) {
+            Elem<T>::unpack(ld_chunk<T>(x, (xb + wv + 1) * xs + c0), xp);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j)
+              if (in_stats) xp[j] = act_fwd((xp[j] - mean[j]) * rstd[j], act);
+          } else {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) xp[j] = 0.f;
+          }
+          float g[CPC];
+          Elem<T>::unpack(ld_chunk<T>(dy, (gb + wv) * dys + c0), g);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) {
+            float gv = g[j] + bs[j];
+            acc[0][j] += xm[j] * gv;
+            acc[1][j] += xc[j] * gv;
+            acc[2][j] += xp[j] * gv;
+            xm[j] = xc[j];
+            xc[j] = xp[j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) red[(threadIdx.x * 3 + c) * CPC + j] = acc[c][j];
+    __syncthreads();
+    if (active && rl == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          float sacc = 0.f;
+          for (int q = 0; q < RL; ++q) sacc += red[((q * G + cl) * 3 + c) * CPC + j];
+          part[((size_t)blockIdx.x * C + c0 + j) * TT + pr * 3 + c] = sacc;
+        }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(NT) k_dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
                                                             int nblk, int CT) {
   int i = blockIdx.x * NT + threadIdx.x;
@@ -273,13 +456,13 @@ __global__ void __launch_bounds__(AT) k_attn_fwd(const void* __restrict__ qv, in
 }
 
 // merge the per-block records: map_out[n][j][d*heads+h], colstat[n][h][j] = (max, sum)
-__global__ void __launch_bounds__(NT) k_attn_merge(const float* __restrict__ part, float* __restrict__ map_out,
+__global__ void __launch_bounds__(64) k_attn_merge(const float* __restrict__ part, float* __restrict__ map_out,
                                                    float* __restrict__ colstat, int heads, int M, int DH, int nblk) {
-  const int h = blockIdx.x % heads, n = blockIdx.x / heads;
+  // one 64-thread block per (n, h, code j): thread d owns one output channel
+  const int j = blockIdx.x % M, h = (blockIdx.x / M) % heads, n = blockIdx.x / (M * heads);
   const int inner = heads * DH;
   const float* base = part + ((size_t)n * heads + h) * nblk * M * (DH + 2);
-  for (int idx = threadIdx.x; idx < M * DH; idx += NT) {
-    int j = idx / DH, d = idx % DH;
+  for (int d = threadIdx.x; d < DH; d += 64) {
     float mx = -INFINITY;
     for (int b = 0; b < nblk; ++b) mx = fmaxf(mx, base[((size_t)b * M + j) * (DH + 2)]);
     float S = 0.f, A = 0.f;
@@ -424,7 +607,7 @@ __global__ void __launch_bounds__(NT) k_attn_bwd_reduce(const float* __restrict_
   const int h = blockIdx.x % heads, n = blockIdx.x / heads;
   const int inner = heads * DH;
   const float* base = part + ((size_t)n * heads + h) * nblk * 2 * M * DH;
-  for (int idx = threadIdx.x; idx < 2 * M * DH; idx += NT) {
+  for (int idx = blockIdx.y * NT + threadIdx.x; idx < 2 * M * DH; idx += gridDim.y * NT) {
     int st = idx / (M * DH), j = (idx / DH) % M, d = idx % DH;
     float s = 0.f;
     for (int b = 0; b < nblk; ++b) s += base[(size_t)b * 2 * M * DH + idx];
@@ -594,10 +777,30 @@ extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const f
   if (int e = check_c(dtype, C, "dwconv")) return e;
   if (int e = check_k(kD, kH, kW)) return e;
   int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  if (kW == 3 && kD <= 3 && kH <= 3) {
+    int cch = C / cpc, groups = (cch + DG - 1) / DG, G = cch < DG ? cch : DG, SL = NT / G;
+    int64_t items = (int64_t)N * D * H * ((W + WT - 1) / WT);
+    int64_t bx = (items + SL - 1) / SL;
+    int64_t cap = 4096 / groups > 1 ? 4096 / groups : 1;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    DISPATCH_T(dtype, k_dwconv3, dim3((unsigned)bx, groups), (hipStream_t)stream, x, x_stride, in_stats, act, bias, w, flip,
+               y, y_stride, N, D, H, W, C, kD, kH);
+    return launch_ok("dwconv3d");
+  }
   int64_t total = (int64_t)N * D * H * W * (C / cpc);
   DISPATCH_T(dtype, k_dwconv, dim3(grid_for(total)), (hipStream_t)stream, x, x_stride, in_stats, act, bias, w, flip, y,
              y_stride, D, H, W, C, kD, kH, kW, total);
   return launch_ok("dwconv3d");
+}
+
+// kW == 3 path: rows (n,d,h) per block so that ~1024 blocks exist, at least 8 rows each
+static void dw3_wgrad_cfg(int64_t rows, int groups, int* nblk, int* rpb) {
+  int64_t want = 1024 / groups > 1 ? 1024 / groups : 1;
+  int64_t r = (rows + want - 1) / want;
+  if (r < 8) r = 8;
+  *rpb = (int)r;
+  *nblk = (int)((rows + r - 1) / r);
 }
 
 static void dw_wgrad_cfg(int64_t vox, int* nblk, int* vpb) {
@@ -611,6 +814,9 @@ static void dw_wgrad_cfg(int64_t vox, int* nblk, int* vpb) {
 extern "C" size_t cbim_dwconv3d_wgrad_workspace(int N, int D, int H, int W, int C, int kD, int kH, int kW) {
   int nblk, vpb;
   dw_wgrad_cfg((int64_t)N * D * H * W, &nblk, &vpb);
+  int nb3, rpb;
+  dw3_wgrad_cfg((int64_t)N * D * H, (C / 4 + DG - 1) / DG, &nb3, &rpb);   // upper bound over both dtypes
+  if (nb3 > nblk) nblk = nb3;
   return (size_t)nblk * C * kD * kH * kW * sizeof(float);
 }
 
@@ -626,10 +832,17 @@ extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, c
   int nblk, vpb;
   dw_wgrad_cfg((int64_t)N * D * H * W, &nblk, &vpb);
   int TT = kD * kH * kW, G = NT / TT, cch = C / cpc;
-  dim3 grid(nblk, (cch + G - 1) / G);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype, k_dwconv_wgrad, grid, st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias, (float*)workspace, N,
-             D, H, W, C, kD, kH, kW, vpb);
+  if (kW == 3 && kD <= 3 && kH <= 3) {
+    int groups = (cch + DG - 1) / DG, rpb;
+    dw3_wgrad_cfg((int64_t)N * D * H, groups, &nblk, &rpb);
+    DISPATCH_T(dtype, k_dwconv3_wgrad, dim3(nblk, groups), st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias,
+               (float*)workspace, N, D, H, W, C, kD, kH, rpb);
+  } else {
+    dim3 grid(nblk, (cch + G - 1) / G);
+    DISPATCH_T(dtype, k_dwconv_wgrad, grid, st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias, (float*)workspace, N,
+               D, H, W, C, kD, kH, kW, vpb);
+  }
   if (int e = launch_ok("dwconv3d_wgrad")) return e;
   CBIM_LAUNCH(k_dwconv_wgrad_reduce, dim3((C * TT + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw, nblk,
               C * TT);
@@ -675,6 +888,7 @@ extern "C" size_t cbim_bidir_attn_workspace(int N, int L, int heads, int dh, int
     }                                                                                                  \
   } while (0)
 
+// (k_attn_merge grid = N*heads*M blocks of 64 threads; k_attn_bwd_reduce grid = (N*heads, ceil(2*M*dh/NT)))
 extern "C" int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
                                    void* feat_out, float* map_out, float* colstat, int N, int L, int heads, int dh,
                                    int M, float scale, void* workspace, size_t ws_bytes, void* stream) {
@@ -686,8 +900,8 @@ extern "C" int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride,
   dim3 grid(nblk, heads, N);
   ATTN_DISPATCH(k_attn_fwd, grid, st, qv, qv_stride, mq, mv, feat_out, (float*)workspace, L, heads, M, scale, nblk);
   if (int e = launch_ok("bidir_attn_fwd")) return e;
-  CBIM_LAUNCH(k_attn_merge, dim3(N * heads), dim3(NT), 0, st, (const float*)workspace, map_out, colstat, heads, M, dh,
-              nblk);
+  CBIM_LAUNCH(k_attn_merge, dim3(N * heads * M), dim3(64), 0, st, (const float*)workspace, map_out, colstat, heads, M,
+              dh, nblk);
   return launch_ok("bidir_attn_merge");
 }
 
@@ -705,8 +919,8 @@ extern "C" int cbim_bidir_attn_bwd(int dtype, const void* qv, int64_t qv_stride,
   ATTN_DISPATCH(k_attn_bwd, grid, st, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out, d_map_out, d_qv,
                 (float*)workspace, L, heads, M, scale, nblk);
   if (int e = launch_ok("bidir_attn_bwd")) return e;
-  CBIM_LAUNCH(k_attn_bwd_reduce, dim3(N * heads), dim3(NT), 0, st, (const float*)workspace, d_mq, d_mv, heads, M, dh,
-              nblk);
+  CBIM_LAUNCH(k_attn_bwd_reduce, dim3(N * heads, (2 * M * dh + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace,
+              d_mq, d_mv, heads, M, dh, nblk);
   return launch_ok("bidir_attn_bwd_reduce");
 }
 

@@ -105,7 +105,11 @@ class SEBlock(nn.Module):
             raise NotImplementedError("cbim_amd: SEBlock activation other than ReLU is not built")
 
     def gate(self, mean):   # mean: float32 [N, C]
-        return self.excitation(mean[:, :, None, None, None]).flatten(1)
+        import torch
+        import torch.nn.functional as F
+        c1, c2 = self.excitation[0], self.excitation[2]
+        h = F.relu(F.linear(mean, c1.weight.flatten(1), c1.bias))
+        return torch.sigmoid(F.linear(h, c2.weight.flatten(1), c2.bias))
 
 
 class MBConv(nn.Module):

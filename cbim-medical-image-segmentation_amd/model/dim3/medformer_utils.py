@@ -9,7 +9,6 @@ differentiates them); everything that touches L voxels is a kernel.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ... import functional as Fn
 from ...ops import ACT, IN_EPS
@@ -17,6 +16,22 @@ from .conv_layers import BasicBlock, ConvNormAct, DepthwiseSeparableConv, MBConv
 from .trans_layers import TransformerBlock
 
 _EPS_DEFAULT = 1e-5   # nn.InstanceNorm3d default, used by norm1/norm2 and PatchMerging.norm (:112-113,:158)
+
+
+def pointwise(conv: nn.Conv3d, x):
+    """1x1x1 nn.Conv3d on a semantic map [B, C, m0, m1, m2] as one matmul over the channel axis (torch's conv3d
+    would pick a generic MIOpen kernel that costs ~0.3 ms for these 64-position tensors)."""
+    y = torch.matmul(conv.weight.flatten(1), x.flatten(2))
+    if conv.bias is not None:
+        y = y + conv.bias[None, :, None]
+    return y.reshape(x.shape[0], -1, *x.shape[2:])
+
+
+def map_instance_norm(x, eps=_EPS_DEFAULT):
+    """nn.InstanceNorm3d (affine=False) over the <= 64 map positions."""
+    f = x.flatten(2)
+    var, mean = torch.var_mean(f, dim=2, unbiased=False, keepdim=True)
+    return ((f - mean) * torch.rsqrt(var + eps)).reshape(x.shape)
 
 
 class BidirectionAttention(nn.Module):
@@ -41,12 +56,12 @@ class BidirectionAttention(nn.Module):
         Returns (feat_out + res as FMap, map_out [B, *, m...])."""
         qv = self.feat_qv(x, x_stats, 0).t
         B, ms = mapp.shape[0], tuple(mapp.shape[2:])
-        mqv = self.map_qv(mapp).flatten(2).transpose(1, 2)            # [B, M, 2*inner]
+        mqv = pointwise(self.map_qv, mapp).flatten(2).transpose(1, 2)   # [B, M, 2*inner]
         mq, mv = mqv[..., :self.inner_dim], mqv[..., self.inner_dim:]
         fo, mo = Fn.BidirAttnFn.apply(qv, mq, mv, self.heads, self.scale)
         out = self.feat_out(fo, None, 0, res=res, want_stats=want_stats)
         mo = mo.transpose(1, 2).reshape(B, self.inner_dim, *ms)
-        return out, self.map_out(mo)
+        return out, (mo if isinstance(self.map_out, nn.Identity) else pointwise(self.map_out, mo))
 
 
 class BidirectionAttentionBlock(nn.Module):
@@ -69,7 +84,7 @@ class BidirectionAttentionBlock(nn.Module):
     def forward(self, f: Fn.FMap, semantic_map, want_out_stats=True):
         f = Fn.ensure_stats(f)                                   # eps 1e-4 (ConvNormAct convention)
         s5 = Fn.restat(f.stats, IN_EPS, _EPS_DEFAULT)
-        mapp = F.instance_norm(semantic_map, eps=_EPS_DEFAULT)
+        mapp = map_instance_norm(semantic_map)
         if isinstance(self.shortcut, ConvNormAct):
             res, _ = Fn.NormConvFn.apply(f.t, f.stats, self.shortcut.conv.weight, self.shortcut.act_code, None, False,
                                          None)
@@ -151,9 +166,9 @@ class SemanticMapFusion(nn.Module):
 
     def forward(self, map_list):
         B, _, D, H, W = map_list[0].shape
-        tok = torch.cat([p(m).flatten(2).transpose(1, 2) for p, m in zip(self.in_proj, map_list)], dim=1)
+        tok = torch.cat([pointwise(p, m).flatten(2).transpose(1, 2) for p, m in zip(self.in_proj, map_list)], dim=1)
         tok = self.fusion(tok)
-        return [p(t.transpose(1, 2).reshape(B, self.dim, D, H, W))
+        return [pointwise(p, t.transpose(1, 2).reshape(B, self.dim, D, H, W))
                 for p, t in zip(self.out_proj, tok.chunk(len(map_list), dim=1))]
 
 
@@ -223,7 +238,7 @@ class up_block(nn.Module):
     def forward(self, low: Fn.FMap, skip: Fn.FMap, map1, map2=None):
         f = Fn.FMap(Fn.UpCatFn.apply(low.t, skip.t, False), None)
         if self.map_shortcut and map2 is not None:
-            semantic_map = self.map_reduction(torch.cat([map1, map2], dim=1))
+            semantic_map = pointwise(self.map_reduction, torch.cat([map1, map2], dim=1))
         else:
             semantic_map = map1
         f, semantic_map = self.trans_blocks(f, semantic_map)

@@ -59,6 +59,9 @@ def test_conv_norm_no_act(dev):
 def test_dwconv(dev, dtype):
     oc.check_dwconv(dev, dtype)
     oc.check_dwconv(dev, dtype, N=1, C=40, dhw=(2, 2, 2), act="none")
+    oc.check_dwconv(dev, dtype, N=1, C=264, dhw=(3, 4, 5))             # two channel-chunk groups
+    oc.check_dwconv(dev, dtype, N=1, C=16, dhw=(3, 6, 9), k=(1, 3, 3))
+    oc.check_dwconv(dev, dtype, N=1, C=16, dhw=(4, 5, 6), k=(3, 3, 1))  # generic path
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
