@@ -61,7 +61,7 @@ def test_unbuilt_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         get_model(_args(norm="bn"))
     with pytest.raises(NotImplementedError):
-        get_model(_args(model="medformer"))
+        get_model(_args(model="swin_unetr"))
     with pytest.raises(KeyError):
         from cbim_amd.model.dim3 import UNet
         UNet(1, 8)                       # the reference's default block name is not a valid key either
