@@ -79,6 +79,13 @@ _SIGS = {
     "cbim_colsoftmax_pool_bwd": (i32, [i32, vp, i64, vp, vp, vp, vp, i64] + [i32] * 4 + [vp]),
     "cbim_trilinear_planes_fwd": (i32, [vp, vp] + [i32] * 7 + [vp]),
     "cbim_trilinear_planes_bwd": (i32, [vp, vp] + [i32] * 7 + [vp]),
+    "cbim_resnorm_fwd": (i32, [i32, vp, i64, vp, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
+    "cbim_resnorm_bwd_reduce": (i32, [i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i64, i32, i32, vp, vp, i32, vp]),
+    "cbim_resnorm_bwd_apply": (i32, [i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "cbim_window_attn3d_num_windows": (i32, [i32] * 4 + [vp]),
+    "cbim_window_attn3d_workspace": (sz, [i32] * 6 + [vp, vp]),
+    "cbim_window_attn3d_fwd": (i32, [i32, vp, vp, vp, vp, vp] + [i32] * 6 + [vp, vp, vp, vp]),
+    "cbim_window_attn3d_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 6 + [vp, vp, vp, vp, sz, vp]),
     "cbim_ncdhw_to_ndhwc": (i32, [i32, vp, vp, i32, i32, i64, vp]),
     "cbim_ndhwc_to_ncdhw": (i32, [i32, vp, vp, i32, i32, i64, vp]),
 }

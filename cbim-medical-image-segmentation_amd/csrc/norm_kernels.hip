@@ -271,6 +271,130 @@ __global__ void __launch_bounds__(NT) k_norm_bwd_apply(const void* __restrict__ 
   }
 }
 
+
+// ---- post-norm residual block tail (monai UnetResBlock): y = act(IN(a) + (IN(b) | b)) ------------------
+// Used by SwinUNETR's UnetrBasicBlock / UnetrUpBlock (swin_unetr.py:129-226): out = lrelu(norm2(conv2(..)) + residual),
+// residual = norm3(conv3(x)) when the channel count changes, else x.  One streaming pass forward; backward =
+// one reduction pass (the InstanceNorm-backward means of both branches, g = dy*act'(pre) with pre recomputed)
+// + one apply pass.
+template <typename T>
+__device__ __forceinline__ void resnorm_pre(const float* fa, const float* fb, const float* sa, const float* sb, float* xa,
+                                            float* xb, float* pre) {
+  constexpr int CPC = Elem<T>::CPC;
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) {
+    xa[j] = (fa[j] - sa[2 * j]) * sa[2 * j + 1];
+    xb[j] = sb ? (fb[j] - sb[2 * j]) * sb[2 * j + 1] : fb[j];
+    pre[j] = xa[j] + xb[j];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_resnorm_fwd(const void* __restrict__ a, int64_t as, const float* __restrict__ sa,
+                                                    const void* __restrict__ b, int64_t bs, const float* __restrict__ sb,
+                                                    void* __restrict__ y, int64_t ys, int64_t S, int C, int act,
+                                                    int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int cc = (int)(i % cch);
+    int64_t row = i / cch, n = row / S;
+    float fa[CPC], fb[CPC], xa[CPC], xb[CPC], pre[CPC];
+    Elem<T>::unpack(ld_chunk<T>(a, (size_t)row * as + (size_t)cc * CPC), fa);
+    Elem<T>::unpack(ld_chunk<T>(b, (size_t)row * bs + (size_t)cc * CPC), fb);
+    resnorm_pre<T>(fa, fb, sa + ((size_t)n * C + cc * CPC) * 2, sb ? sb + ((size_t)n * C + cc * CPC) * 2 : nullptr, xa, xb, pre);
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) pre[j] = act_fwd(pre[j], act);
+    st_chunk<T>(y, (size_t)row * ys + (size_t)cc * CPC, Elem<T>::pack(pre));
+  }
+}
+
+// partial sums per slab: pa = (0, sum g, sum g*xa), pb = (0, sum g, sum g*xb)
+template <typename T>
+__global__ void __launch_bounds__(NT) k_resnorm_partial(const void* __restrict__ dy, int64_t dys,
+                                                        const void* __restrict__ a, int64_t as,
+                                                        const float* __restrict__ sa, const void* __restrict__ b,
+                                                        int64_t bs, const float* __restrict__ sb, int64_t S, int C,
+                                                        int P, int act, float* __restrict__ pa, float* __restrict__ pb,
+                                                        int Cl, int c_off) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC, vlc = NT / cch;
+  const int t = threadIdx.x, cc = t % cch, vl = t / cch;
+  const int part = blockIdx.x, n = blockIdx.y;
+  const int64_t per = (S + P - 1) / P, v0 = (int64_t)part * per;
+  int64_t v1 = v0 + per;
+  if (v1 > S) v1 = S;
+  const bool active = vl < vlc;
+  const int c0 = c_off + cc * CPC;
+  float s0[CPC], s1[CPC], s2[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  if (active) {
+    const float* sap = sa + ((size_t)n * Cl + c0) * 2;
+    const float* sbp = sb ? sb + ((size_t)n * Cl + c0) * 2 : nullptr;
+    const size_t nb = (size_t)n * S;
+    for (int64_t v = v0 + vl; v < v1; v += vlc) {
+      float fa[CPC], fb[CPC], fg[CPC], xa[CPC], xb[CPC], pre[CPC];
+      Elem<T>::unpack(ld_chunk<T>(a, (nb + v) * as + c0), fa);
+      Elem<T>::unpack(ld_chunk<T>(b, (nb + v) * bs + c0), fb);
+      Elem<T>::unpack(ld_chunk<T>(dy, (nb + v) * dys + c0), fg);
+      resnorm_pre<T>(fa, fb, sap, sbp, xa, xb, pre);
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) {
+        float g = fg[j] * act_grad(pre[j], act);
+        s0[j] += g; s1[j] += g * xa[j]; s2[j] += g * xb[j];
+      }
+    }
+  }
+  __shared__ float red[NT * 3 * 8];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) {
+    red[(t * CPC + j) * 3 + 0] = s0[j]; red[(t * CPC + j) * 3 + 1] = s1[j]; red[(t * CPC + j) * 3 + 2] = s2[j];
+  }
+  __syncthreads();
+  if (vl == 0 && active) {
+    for (int j = 0; j < CPC; ++j) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      for (int q = 0; q < vlc; ++q) {
+        const float* r = red + ((q * cch + cc) * CPC + j) * 3;
+        a0 += r[0]; a1 += r[1]; a2 += r[2];
+      }
+      size_t o = (((size_t)n * P + part) * Cl + c0 + j) * 3;
+      pa[o] = 0.f; pa[o + 1] = a0; pa[o + 2] = a1;
+      if (pb) { pb[o] = 0.f; pb[o + 1] = a0; pb[o + 2] = a2; }
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NT) k_resnorm_apply(const void* __restrict__ dy, int64_t dys, const void* __restrict__ a,
+                                                      int64_t as, const float* __restrict__ sa,
+                                                      const float* __restrict__ ma, const void* __restrict__ b, int64_t bs,
+                                                      const float* __restrict__ sb, const float* __restrict__ mb,
+                                                      void* __restrict__ da, void* __restrict__ db, int64_t S, int C,
+                                                      int act, int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int cc = (int)(i % cch);
+    int64_t row = i / cch, n = row / S;
+    const size_t so = ((size_t)n * C + cc * CPC) * 2;
+    float fa[CPC], fb[CPC], fg[CPC], xa[CPC], xb[CPC], pre[CPC], oa[CPC], ob[CPC];
+    Elem<T>::unpack(ld_chunk<T>(a, (size_t)row * as + (size_t)cc * CPC), fa);
+    Elem<T>::unpack(ld_chunk<T>(b, (size_t)row * bs + (size_t)cc * CPC), fb);
+    Elem<T>::unpack(ld_chunk<T>(dy, (size_t)row * dys + (size_t)cc * CPC), fg);
+    resnorm_pre<T>(fa, fb, sa + so, sb ? sb + so : nullptr, xa, xb, pre);
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      float g = fg[j] * act_grad(pre[j], act);
+      oa[j] = sa[so + 2 * j + 1] * (g - ma[so + 2 * j] - xa[j] * ma[so + 2 * j + 1]);
+      ob[j] = sb ? sb[so + 2 * j + 1] * (g - mb[so + 2 * j] - xb[j] * mb[so + 2 * j + 1]) : g;
+    }
+    st_chunk<T>(da, (size_t)row * C + (size_t)cc * CPC, Elem<T>::pack(oa));
+    if (db) st_chunk<T>(db, (size_t)row * C + (size_t)cc * CPC, Elem<T>::pack(ob));
+  }
+}
+
 // ---- layout helpers ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(NT) k_ncdhw_to_ndhwc(const float* __restrict__ x, void* __restrict__ y,
@@ -420,6 +544,61 @@ extern "C" int cbim_norm_bwd_apply(int dtype, const void* g, int64_t g_stride, c
       CBIM_LAUNCH((k_norm_bwd_apply<float>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
                   add_stride, dx, dx_stride, S, Cg, act, masked, C, c_off);
   }
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+
+extern "C" int cbim_resnorm_fwd(int dtype, const void* a, int64_t a_stride, const float* stats_a, const void* b,
+                                int64_t b_stride, const float* stats_b, void* y, int64_t y_stride, int N, int64_t S, int C,
+                                int act, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  CBIM_CHECK(a && b && y && stats_a, CBIM_EINVAL, "null argument");
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * S * (C / cpc);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_resnorm_fwd<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, a, a_stride, stats_a, b, b_stride, stats_b,
+                y, y_stride, S, C, act, total);
+  else
+    CBIM_LAUNCH((k_resnorm_fwd<float>), dim3(grid_for(total)), dim3(NT), 0, st, a, a_stride, stats_a, b, b_stride, stats_b, y,
+                y_stride, S, C, act, total);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_resnorm_bwd_reduce(int dtype, const void* dy, int64_t dy_stride, const void* a, int64_t a_stride,
+                                       const float* stats_a, const void* b, int64_t b_stride, const float* stats_b, int N,
+                                       int64_t S, int C, int act, float* partials_a, float* partials_b, int P,
+                                       void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  CBIM_CHECK(dy && a && b && stats_a && partials_a && (!stats_b || partials_b), CBIM_EINVAL, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(P, N);
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_resnorm_partial<bf16_tag>), grid, dim3(NT), 0, st, dy, dy_stride, a, a_stride, stats_a, b, b_stride,
+                  stats_b, S, Cg, P, act, partials_a, stats_b ? partials_b : (float*)nullptr, C, c_off);
+    else
+      CBIM_LAUNCH((k_resnorm_partial<float>), grid, dim3(NT), 0, st, dy, dy_stride, a, a_stride, stats_a, b, b_stride,
+                  stats_b, S, Cg, P, act, partials_a, stats_b ? partials_b : (float*)nullptr, C, c_off);
+  }
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_resnorm_bwd_apply(int dtype, const void* dy, int64_t dy_stride, const void* a, int64_t a_stride,
+                                      const float* stats_a, const float* sums_a, const void* b, int64_t b_stride,
+                                      const float* stats_b, const float* sums_b, void* da, void* db, int N, int64_t S,
+                                      int C, int act, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  CBIM_CHECK(dy && a && b && stats_a && sums_a && da && (!stats_b || sums_b), CBIM_EINVAL, "null argument");
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * S * (C / cpc);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CBIM_BF16)
+    CBIM_LAUNCH((k_resnorm_apply<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, dy, dy_stride, a, a_stride, stats_a, sums_a,
+                b, b_stride, stats_b, sums_b, da, db, S, C, act, total);
+  else
+    CBIM_LAUNCH((k_resnorm_apply<float>), dim3(grid_for(total)), dim3(NT), 0, st, dy, dy_stride, a, a_stride, stats_a, sums_a, b,
+                b_stride, stats_b, sums_b, da, db, S, C, act, total);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

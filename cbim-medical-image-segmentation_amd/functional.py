@@ -290,7 +290,7 @@ class NormConvFn(torch.autograd.Function):
     Returns (y, InstanceNorm statistics of y [eps 1e-4] or an empty tensor)."""
 
     @staticmethod
-    def forward(ctx, x, stats, w, act, res, want_stats, se):
+    def forward(ctx, x, stats, w, act, res, want_stats, se, eps_out):
         g = _geom(x, w, act)
         train = any(ctx.needs_input_grad)
         wd = w.detach().contiguous()
@@ -306,7 +306,7 @@ class NormConvFn(torch.autograd.Function):
             rz2 = 1.0 / (var * sd * sd + IN_EPS)
             st = torch.stack([stats[..., 0], (sd * rz2.sqrt()).float()], -1).contiguous()
             ctx.rz2 = rz2
-        y, so = ops.conv_fwd(x, wp, g, in_stats=st, res=res, want_stats=want_stats)
+        y, so = ops.conv_fwd(x, wp, g, in_stats=st, res=res, want_stats=want_stats, eps=eps_out)
         ctx.save_for_backward(x, st if st is not None else torch.empty(0), se if se is not None else torch.empty(0))
         ctx.geom, ctx.act, ctx.wpd, ctx.has = g, act, wpd, (stats is not None, res is not None, se is not None)
         if so is None:
@@ -331,7 +331,7 @@ class NormConvFn(torch.autograd.Function):
                     ds = (S * IN_EPS * sums[..., 1].double() * ctx.rz2 / se.double()).float()
             else:
                 dx, _ = ops.conv_dgrad(dy, ctx.wpd, g)
-        return dx, None, dw, None, (dy if has_res else None), None, ds
+        return dx, None, dw, None, (dy if has_res else None), None, ds, None
 
 
 class DWConvFn(torch.autograd.Function):
@@ -437,3 +437,66 @@ class TrilinearPlanesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return ops.trilinear_planes_bwd(dy.contiguous().float(), ctx.in_shape), None
+
+
+# ------------------------------------------------------------------------------------------------
+# SwinUNETR blocks (reference: /root/reference/model/dim3/swin_unetr.py; monai 1.1.0 conv blocks)
+# ------------------------------------------------------------------------------------------------
+
+class WindowAttnFn(torch.autograd.Function):
+    """pad + roll + window_partition + WindowAttention core + window_reverse + roll back + crop
+    (swin_unetr.py:467-490, 554-606) as one kernel.  qkv [B,D,H,W,3C]; returns [B,D,H,W,C].
+    The gradient returned for `qkv_bias` is only the part that flows through window-PADDING tokens (their
+    q/k/v are the bias itself); the part through real tokens reaches the bias via the qkv projection."""
+
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, table, heads, window, shift, table_window):
+        qkv = qkv.contiguous()
+        bias = qkv_bias.detach().float().contiguous() if qkv_bias is not None else None
+        tbl = table.detach().float().contiguous()
+        out, lse = ops.window_attn_fwd(qkv, bias, tbl, heads, window, shift, table_window)
+        ctx.save_for_backward(qkv, bias if bias is not None else torch.empty(0), tbl, out, lse)
+        ctx.cfg = (heads, tuple(window), tuple(shift), tuple(table_window), bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, bias, tbl, out, lse = ctx.saved_tensors
+        heads, window, shift, tw, has_bias = ctx.cfg
+        dqkv, dtable, dbias = ops.window_attn_bwd(qkv, bias if has_bias else None, tbl, out, dout.contiguous(), lse, heads,
+                                                  window, shift, tw)
+        return dqkv, (dbias if has_bias else None), dtable, None, None, None, None
+
+
+class ResNormFn(torch.autograd.Function):
+    """Tail of monai's UnetResBlock: y = act(IN(a) + (IN(b) | b)) with the statistics of a (and b) given
+    (they come out of the producing convolutions' epilogues)."""
+
+    @staticmethod
+    def forward(ctx, a, stats_a, b, stats_b, act):
+        y = ops.resnorm_fwd(a, stats_a, b, stats_b, act)
+        ctx.save_for_backward(a, stats_a, b, stats_b if stats_b is not None else torch.empty(0))
+        ctx.act, ctx.has_b = act, stats_b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, sa, b, sb = ctx.saved_tensors
+        da, db = ops.resnorm_bwd(dy.contiguous(), a, sa, b, sb if ctx.has_b else None, ctx.act,
+                                 need_db=ctx.needs_input_grad[2])
+        return da, None, db, None, None
+
+
+class DepthToSpaceFn(torch.autograd.Function):
+    """[N,D,H,W,8C] -> [N,2D,2H,2W,C]: the scatter half of ConvTranspose3d(k=2,s=2) (monai UnetrUpBlock.transp_conv)."""
+
+    @staticmethod
+    def forward(ctx, t, scale):
+        N, D, H, W, Cm = map(int, t.shape)
+        sD, sH, sW = scale
+        ctx.scale = tuple(scale)
+        return ops.depth_to_space(t, (N, D * sD, H * sH, W * sW, Cm // (sD * sH * sW)), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.space_to_depth(dy.contiguous(), ctx.scale), None

@@ -1,2 +1,3 @@
 from .unet import UNet  # noqa: F401
 from .medformer import MedFormer  # noqa: F401
+from .swin_unetr import SwinUNETR  # noqa: F401

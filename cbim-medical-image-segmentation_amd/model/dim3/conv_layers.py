@@ -11,7 +11,7 @@ the kernels (conv_layers.py:40-43).
 import torch.nn as nn
 
 from ... import functional as Fn
-from ...ops import ACT
+from ...ops import ACT, IN_EPS
 
 
 def _k3(k):
@@ -87,7 +87,7 @@ class DepthwiseSeparableConv(nn.Module):
 
     def forward(self, x, stats=None, act=0, res=None, want_stats=False) -> Fn.FMap:
         t, _, _ = Fn.DWConvFn.apply(x, stats, self.depthwise.weight, act, False)
-        y, so = Fn.NormConvFn.apply(t, None, self.pointwise.weight, 0, res, want_stats, None)
+        y, so = Fn.NormConvFn.apply(t, None, self.pointwise.weight, 0, res, want_stats, None, IN_EPS)
         return Fn.FMap(y, so if want_stats else None)
 
 
@@ -133,8 +133,8 @@ class MBConv(nn.Module):
     def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
         f = Fn.ensure_stats(f)
         act = self.expand_proj.act_code
-        e, se_ = Fn.NormConvFn.apply(f.t, f.stats, self.expand_proj.conv.weight, act, None, True, None)
+        e, se_ = Fn.NormConvFn.apply(f.t, f.stats, self.expand_proj.conv.weight, act, None, True, None, IN_EPS)
         d, mean, ds = Fn.DWConvFn.apply(e, se_, self.depthwise.conv.weight, act, True)
         gate = self.se.gate(mean)
-        y, so = Fn.NormConvFn.apply(d, ds, self.pointwise.conv.weight, 0, f.t, want_out_stats, gate)
+        y, so = Fn.NormConvFn.apply(d, ds, self.pointwise.conv.weight, 0, f.t, want_out_stats, gate, IN_EPS)
         return Fn.FMap(y, so if want_out_stats else None)

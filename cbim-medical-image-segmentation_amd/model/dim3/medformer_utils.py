@@ -87,7 +87,7 @@ class BidirectionAttentionBlock(nn.Module):
         mapp = map_instance_norm(semantic_map)
         if isinstance(self.shortcut, ConvNormAct):
             res, _ = Fn.NormConvFn.apply(f.t, f.stats, self.shortcut.conv.weight, self.shortcut.act_code, None, False,
-                                         None)
+                                         None, IN_EPS)
         else:
             res = f.t
         out, mapp = self.attn(f.t, s5, mapp, res, True)
@@ -149,7 +149,7 @@ class SemanticMapGeneration(nn.Module):
 
     def forward(self, f: Fn.FMap):
         w = torch.cat([self.base_proj.weight, self.semantic_proj.weight], 0)
-        fw, _ = Fn.NormConvFn.apply(f.t, None, w, 0, None, False, None)
+        fw, _ = Fn.NormConvFn.apply(f.t, None, w, 0, None, False, None, IN_EPS)
         mp = Fn.MapPoolFn.apply(fw, self.map_dim)                       # [B, map_dim, codes]
         return mp.reshape(mp.shape[0], self.map_dim, *self.map_size)
 

@@ -1,0 +1,303 @@
+"""SwinUNETR behind the reference's constructor signature and parameter names
+(/root/reference/model/dim3/swin_unetr.py:32-292 and the monai 1.1.0 blocks it imports, :24-27).
+
+Execution split:
+  * conv encoder/decoder (92 % of the FLOPs: UnetrBasicBlock / UnetrUpBlock / UnetOutBlock) — the implicit-GEMM
+    conv kernels with InstanceNorm(eps 1e-5)+LeakyReLU fused on load and statistics in the epilogue, the
+    post-norm residual tail as one streaming kernel (``functional.ResNormFn``), ConvTranspose3d(k=2,s=2) as a
+    1x1 GEMM + depth-to-space scatter;
+  * shifted-window attention — one kernel per block does pad/roll/partition/bias/mask/softmax/AV/reverse/crop
+    (``functional.WindowAttnFn``);
+  * the token-wise Linear layers (qkv, proj, MLP, patch merging/embedding) are plain library GEMMs
+    (torch ``F.linear`` -> hipBLASLt), LayerNorm/GELU/residual adds are torch elementwise ops on the
+    channels-last token tensors.  The transformer trunk runs in fp32 in both engine modes.
+forward(x[B,C,D,H,W] fp32 NCDHW) -> logits[B,classes,D,H,W] fp32.
+"""
+import itertools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import functional as Fn
+from ...ops import ACT
+
+_EPS = 1e-5          # nn.InstanceNorm3d default (monai get_norm_layer("instance"))
+_LRELU = ACT["lrelu"]  # monai UnetResBlock act: LeakyReLU(0.01)
+
+
+def _tup3(v):
+    return tuple(v) if isinstance(v, (list, tuple)) else (v,) * 3
+
+
+# ---- monai conv blocks ---------------------------------------------------------------------------------
+
+class _ConvHolder(nn.Module):
+    """monai ``Convolution(conv_only=True)``: a module whose single child ``conv`` owns the weight."""
+
+    def __init__(self, cin, cout, k, bias=False, transposed=False):
+        super().__init__()
+        if transposed:
+            self.conv = nn.ConvTranspose3d(cin, cout, kernel_size=k, stride=k, bias=bias)
+        else:
+            self.conv = nn.Conv3d(cin, cout, kernel_size=k, stride=1, padding=(k - 1) // 2, bias=bias)
+
+
+class UnetResBlock(nn.Module):
+    """conv3-IN-lrelu-conv3-IN, residual (1x1 conv + IN when the channel count changes), add, lrelu."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3):
+        super().__init__()
+        self.conv1 = _ConvHolder(in_channels, out_channels, kernel_size)
+        self.conv2 = _ConvHolder(out_channels, out_channels, kernel_size)
+        self.lrelu = nn.Identity()
+        self.norm1 = nn.Identity()   # InstanceNorm3d(affine=False): fused into the next conv's load
+        self.norm2 = nn.Identity()   # fused into the residual tail
+        self.downsample = in_channels != out_channels
+        if self.downsample:
+            self.conv3 = _ConvHolder(in_channels, out_channels, 1)
+            self.norm3 = nn.Identity()
+
+    def forward(self, x, stem_dtype=None):
+        """x: channels-last feature map, or (stem_dtype given) the NCDHW fp32 network input."""
+        if stem_dtype is not None:
+            z1 = Fn.StemFn.apply(x, self.conv1.conv.weight, stem_dtype)
+            s1 = Fn.ensure_stats(Fn.FMap(z1, None), _EPS).stats
+        else:
+            z1, s1 = Fn.NormConvFn.apply(x, None, self.conv1.conv.weight, 0, None, True, None, _EPS)
+        z2, s2 = Fn.NormConvFn.apply(z1, s1, self.conv2.conv.weight, _LRELU, None, True, None, _EPS)
+        if self.downsample:
+            if stem_dtype is not None:
+                r = Fn.StemFn.apply(x, self.conv3.conv.weight, stem_dtype)
+                s3 = Fn.ensure_stats(Fn.FMap(r, None), _EPS).stats
+            else:
+                r, s3 = Fn.NormConvFn.apply(x, None, self.conv3.conv.weight, 0, None, True, None, _EPS)
+            return Fn.ResNormFn.apply(z2, s2, r, s3, _LRELU)
+        if stem_dtype is not None:
+            raise NotImplementedError("cbim_amd: identity-residual UnetResBlock on the raw network input is not built")
+        return Fn.ResNormFn.apply(z2, s2, x, None, _LRELU)
+
+
+class UnetrBasicBlock(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, res_block=False):
+        super().__init__()
+        if spatial_dims != 3 or stride != 1 or norm_name != "instance" or not res_block:
+            raise NotImplementedError("cbim_amd: only UnetrBasicBlock(3-D, stride 1, instance norm, res_block) is built")
+        self.layer = UnetResBlock(in_channels, out_channels, kernel_size)
+
+    def forward(self, x, stem_dtype=None):
+        return self.layer(x, stem_dtype)
+
+
+class UnetrUpBlock(nn.Module):
+    """ConvTranspose3d(k=2,s=2,bias=False) -> cat([up, skip]) -> UnetResBlock."""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, upsample_kernel_size, norm_name,
+                 res_block=False):
+        super().__init__()
+        if spatial_dims != 3 or upsample_kernel_size != 2 or norm_name != "instance" or not res_block:
+            raise NotImplementedError("cbim_amd: only UnetrUpBlock(3-D, upsample 2, instance norm, res_block) is built")
+        self.transp_conv = _ConvHolder(in_channels, out_channels, 2, transposed=True)
+        self.conv_block = UnetResBlock(out_channels + out_channels, out_channels, kernel_size)
+
+    def forward(self, x, skip):
+        w = self.transp_conv.conv.weight                               # [Cin, Cout, 2, 2, 2]
+        cout = w.shape[1]
+        w_eq = w.permute(2, 3, 4, 1, 0).reshape(8 * cout, w.shape[0], 1, 1, 1)
+        t, _ = Fn.NormConvFn.apply(x, None, w_eq, 0, None, False, None, _EPS)
+        up = Fn.DepthToSpaceFn.apply(t, (2, 2, 2))
+        return self.conv_block(torch.cat((up, skip), dim=-1))
+
+
+class UnetOutBlock(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels):
+        super().__init__()
+        self.conv = _ConvHolder(in_channels, out_channels, 1, bias=True)
+
+
+# ---- Swin transformer trunk ----------------------------------------------------------------------------
+
+class PatchEmbed(nn.Module):
+    """monai PatchEmbed: Conv3d(k = stride = patch) as one GEMM over the 2x2x2xC patch."""
+
+    def __init__(self, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.patch_size = _tup3(patch_size)
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+
+    def forward(self, x):
+        B, Cc, D, H, W = x.shape
+        p = self.patch_size
+        if D % p[0] or H % p[1] or W % p[2]:
+            x = F.pad(x, (0, (-W) % p[2], 0, (-H) % p[1], 0, (-D) % p[0]))
+            _, _, D, H, W = x.shape
+        x = x.reshape(B, Cc, D // p[0], p[0], H // p[1], p[1], W // p[2], p[2]).permute(0, 2, 4, 6, 1, 3, 5, 7)
+        return F.linear(x.reshape(B, D // p[0], H // p[1], W // p[2], -1), self.proj.weight.flatten(1), self.proj.bias)
+
+
+class MLPBlock(nn.Module):
+    def __init__(self, hidden_size, mlp_dim):
+        super().__init__()
+        self.linear1 = nn.Linear(hidden_size, mlp_dim)
+        self.linear2 = nn.Linear(mlp_dim, hidden_size)
+
+    def forward(self, x):
+        return self.linear2(F.gelu(self.linear1(x)))
+
+
+def _relative_position_index(ws):
+    coords = torch.stack(torch.meshgrid(*[torch.arange(w) for w in ws], indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    for i in range(3):
+        rel[:, :, i] += ws[i] - 1
+    rel[:, :, 0] *= (2 * ws[1] - 1) * (2 * ws[2] - 1)
+    rel[:, :, 1] *= 2 * ws[2] - 1
+    return rel.sum(-1)
+
+
+class WindowAttention(nn.Module):
+    """swin_unetr.py:384-490.  ``relative_position_index`` is kept as a buffer for state_dict compatibility; the
+    kernel derives the same index arithmetically."""
+
+    def __init__(self, dim, num_heads, window_size, qkv_bias=False):
+        super().__init__()
+        self.dim, self.num_heads, self.window_size = dim, num_heads, _tup3(window_size)
+        ws = self.window_size
+        self.relative_position_bias_table = nn.Parameter(
+            torch.zeros((2 * ws[0] - 1) * (2 * ws[1] - 1) * (2 * ws[2] - 1), num_heads))
+        self.register_buffer("relative_position_index", _relative_position_index(ws))
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def forward(self, h, window, shift):
+        qkv = self.qkv(h)
+        o = Fn.WindowAttnFn.apply(qkv, self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
+                                  self.window_size)
+        return self.proj(o)
+
+
+class SwinTransformerBlock(nn.Module):
+    """swin_unetr.py:493-656."""
+
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio=4.0, qkv_bias=True):
+        super().__init__()
+        self.window_size, self.shift_size = _tup3(window_size), _tup3(shift_size)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, num_heads, self.window_size, qkv_bias=qkv_bias)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MLPBlock(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        dims = tuple(x.shape[1:4])
+        ws = tuple(d if d <= w else w for d, w in zip(dims, self.window_size))            # get_window_size (:358-381)
+        ss = tuple(0 if d <= w else s for d, w, s in zip(dims, self.window_size, self.shift_size))
+        x = x + self.attn(self.norm1(x), ws, ss)
+        return x + self.mlp(self.norm2(x))
+
+
+class PatchMerging(nn.Module):
+    """The v0.9 ``PatchMerging`` (swin_unetr.py:707-731): note the slice list repeats three octants."""
+    _SEL = ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0), (0, 0, 1), (1, 1, 1))
+
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = nn.Linear(8 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(8 * dim)
+
+    def forward(self, x):
+        _, d, h, w, _ = x.shape
+        if (d % 2) or (h % 2) or (w % 2):
+            x = F.pad(x, (0, 0, 0, w % 2, 0, h % 2, 0, d % 2))
+        x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self._SEL], -1)
+        return self.reduction(self.norm(x))
+
+
+class BasicLayer(nn.Module):
+    """swin_unetr.py:776-873 (channels-last throughout; the reference's NCDHW<->NDHWC rearranges disappear)."""
+
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio=4.0, qkv_bias=False):
+        super().__init__()
+        ws = _tup3(window_size)
+        shift = tuple(i // 2 for i in ws)
+        self.blocks = nn.ModuleList([SwinTransformerBlock(dim, num_heads, ws, (0, 0, 0) if i % 2 == 0 else shift,
+                                                          mlp_ratio=mlp_ratio, qkv_bias=qkv_bias) for i in range(depth)])
+        self.downsample = PatchMerging(dim)
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return self.downsample(x)
+
+
+class SwinTransformer(nn.Module):
+    """swin_unetr.py:876-997; returns the five channel-LayerNormed hidden states, channels-last."""
+
+    def __init__(self, in_chans, embed_dim, window_size, patch_size, depths, num_heads, mlp_ratio=4.0, qkv_bias=True):
+        super().__init__()
+        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim)
+        self.pos_drop = nn.Identity()
+        for i, name in enumerate(("layers1", "layers2", "layers3", "layers4")):
+            setattr(self, name, nn.ModuleList([BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i], window_size,
+                                                          mlp_ratio=mlp_ratio, qkv_bias=qkv_bias)]))
+
+    def forward(self, x, normalize=True):
+        def out(t):   # proj_out (:970-983): F.layer_norm(x, [ch]) without affine parameters
+            return F.layer_norm(t, (t.shape[-1],)) if normalize else t
+        x = self.patch_embed(x)
+        outs = [out(x)]
+        for layers in (self.layers1, self.layers2, self.layers3, self.layers4):
+            x = layers[0](x)
+            outs.append(out(x))
+        return outs
+
+
+class SwinUNETR(nn.Module):
+    def __init__(self, img_size, in_channels, out_channels, depths=(2, 2, 2, 0), num_heads=(3, 6, 12, 24), feature_size=24,
+                 norm_name="instance", drop_rate=0.0, attn_drop_rate=0.0, dropout_path_rate=0.0, normalize=True,
+                 use_checkpoint=False, spatial_dims=3, downsample="merging"):
+        super().__init__()
+        if spatial_dims != 3 or downsample != "merging" or drop_rate or attn_drop_rate or dropout_path_rate or use_checkpoint:
+            raise NotImplementedError("cbim_amd: SwinUNETR is built for 3-D, 'merging' downsampling, no dropout / checkpointing")
+        img_size = _tup3(img_size)
+        for m in img_size:                       # swin_unetr.py:96-99
+            if m % 32 != 0:
+                raise ValueError("input image size (img_size) should be divisible by stage-wise image resolution.")
+        if feature_size % 12 != 0:
+            raise ValueError("feature_size should be divisible by 12.")
+        self.normalize = normalize
+        f = feature_size
+        self.swinViT = SwinTransformer(in_channels, f, (7, 7, 7), (2, 2, 2), depths, num_heads, mlp_ratio=4.0, qkv_bias=True)
+        kw = dict(spatial_dims=3, kernel_size=3, stride=1, norm_name=norm_name, res_block=True)
+        self.encoder1 = UnetrBasicBlock(in_channels=in_channels, out_channels=f, **kw)
+        self.encoder2 = UnetrBasicBlock(in_channels=f, out_channels=f, **kw)
+        self.encoder3 = UnetrBasicBlock(in_channels=2 * f, out_channels=2 * f, **kw)
+        self.encoder4 = UnetrBasicBlock(in_channels=4 * f, out_channels=4 * f, **kw)
+        self.encoder10 = UnetrBasicBlock(in_channels=16 * f, out_channels=16 * f, **kw)
+        up = dict(spatial_dims=3, kernel_size=3, upsample_kernel_size=2, norm_name=norm_name, res_block=True)
+        self.decoder5 = UnetrUpBlock(in_channels=16 * f, out_channels=8 * f, **up)
+        self.decoder4 = UnetrUpBlock(in_channels=8 * f, out_channels=4 * f, **up)
+        self.decoder3 = UnetrUpBlock(in_channels=4 * f, out_channels=2 * f, **up)
+        self.decoder2 = UnetrUpBlock(in_channels=2 * f, out_channels=f, **up)
+        self.decoder1 = UnetrUpBlock(in_channels=f, out_channels=f, **up)
+        self.out = UnetOutBlock(spatial_dims=3, in_channels=f, out_channels=out_channels)
+
+    def load_from(self, weights):
+        raise NotImplementedError("cbim_amd: loading the external self-supervised Swin-ViT checkpoint is not built")
+
+    def forward(self, x_in):
+        dtype = Fn.compute_dtype()
+        with torch.autocast(device_type=x_in.device.type, enabled=False):
+            x_in = x_in.float()
+            hs = [h.to(dtype) for h in self.swinViT(x_in, self.normalize)]
+            enc0 = self.encoder1(x_in, dtype)
+            enc1 = self.encoder2(hs[0])
+            enc2 = self.encoder3(hs[1])
+            enc3 = self.encoder4(hs[2])
+            dec4 = self.encoder10(hs[4])
+            dec3 = self.decoder5(dec4, hs[3])
+            dec2 = self.decoder4(dec3, enc3)
+            dec1 = self.decoder3(dec2, enc2)
+            dec0 = self.decoder2(dec1, enc1)
+            out = self.decoder1(dec0, enc0)
+            return Fn.HeadFn.apply(out, self.out.conv.conv.weight, self.out.conv.conv.bias)

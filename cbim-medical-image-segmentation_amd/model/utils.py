@@ -22,4 +22,9 @@ def get_model(args, pretrain=False):
                          fusion_heads=args.fusion_heads, expansion=args.expansion, attn_drop=args.attn_drop,
                          proj_drop=args.proj_drop, proj_type=args.proj_type, norm=args.norm, act=args.act,
                          kernel_size=args.kernel_size, scale=args.down_scale, aux_loss=args.aux_loss)
+    if args.model == "swin_unetr":   # model/utils.py:111-119 of the reference (window_size is passed as img_size)
+        from .dim3 import SwinUNETR
+        if pretrain or getattr(args, "pretrain", False):
+            raise NotImplementedError("cbim_amd: the external Swin-ViT pretraining checkpoint (load_from) is not built")
+        return SwinUNETR(args.window_size, args.in_chan, args.classes, feature_size=args.base_chan)
     raise NotImplementedError(f"cbim_amd: 3D model '{args.model}' is not built yet")

@@ -533,3 +533,71 @@ def trilinear_planes_bwd(dy, in_shape):
     check(_lib.lib().cbim_trilinear_planes_bwd(_p(dy), _p(dx), N * Cc, Di, Hi, Wi, Do, Ho, Wo, _stream(dy)),
           "trilinear_planes_bwd")
     return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# SwinUNETR shifted-window attention
+# ------------------------------------------------------------------------------------------------
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(i) for i in v])
+
+
+def window_attn_fwd(qkv, qkv_bias, table, heads: int, window, shift, table_window):
+    """qkv [B,D,H,W,3C]; table float32 [T,heads] -> out [B,D,H,W,C], lse float32 [num_windows, heads, 343]."""
+    _dev_ok(qkv, qkv_bias, table)
+    B, D, H, W, C3 = map(int, qkv.shape)
+    Cc = C3 // 3
+    L = _lib.lib()
+    win = _i3(window)
+    nwin = L.cbim_window_attn3d_num_windows(B, D, H, W, win)
+    out = torch.empty((B, D, H, W, Cc), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((nwin, heads, 343), dtype=torch.float32, device=qkv.device)
+    check(L.cbim_window_attn3d_fwd(_dt(qkv), _p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), B, D, H, W, Cc, heads,
+                                   win, _i3(shift), _i3(table_window), _stream(qkv)), "window_attn3d_fwd")
+    return out, lse
+
+
+def window_attn_bwd(qkv, qkv_bias, table, out, dout, lse, heads: int, window, shift, table_window):
+    _dev_ok(qkv, qkv_bias, table, out, dout, lse)
+    B, D, H, W, C3 = map(int, qkv.shape)
+    Cc = C3 // 3
+    L = _lib.lib()
+    win, tw = _i3(window), _i3(table_window)
+    nbytes = L.cbim_window_attn3d_workspace(B, D, H, W, Cc, heads, win, tw)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=qkv.device)
+    dqkv = torch.empty_like(qkv)
+    dtable = torch.empty(tuple(table.shape), dtype=torch.float32, device=qkv.device)
+    dbias = torch.empty((C3,), dtype=torch.float32, device=qkv.device)
+    check(L.cbim_window_attn3d_bwd(_dt(qkv), _p(qkv), _p(qkv_bias), _p(table), _p(out), _p(dout), _p(lse), _p(dqkv),
+                                   _p(dtable), _p(dbias), B, D, H, W, Cc, heads, win, _i3(shift), tw, _p(ws), nbytes,
+                                   _stream(qkv)), "window_attn3d_bwd")
+    return dqkv, dtable, dbias
+
+
+def resnorm_fwd(a, stats_a, b, stats_b, act: int):
+    """y = act(IN(a) + (IN(b) if stats_b is given else b))."""
+    _dev_ok(a, stats_a, b, stats_b)
+    N, Cc, S = int(a.shape[0]), int(a.shape[-1]), _spatial(a)
+    y = torch.empty(tuple(a.shape), dtype=a.dtype, device=a.device)
+    check(_lib.lib().cbim_resnorm_fwd(_dt(a), _p(a), _rs(a), _p(stats_a), _p(b), _rs(b), _p(stats_b), _p(y), Cc, N, S, Cc, act,
+                                      _stream(a)), "resnorm_fwd")
+    return y
+
+
+def resnorm_bwd(dy, a, stats_a, b, stats_b, act: int, need_db: bool = True):
+    _dev_ok(dy, a, stats_a, b, stats_b)
+    N, Cc, S = int(a.shape[0]), int(a.shape[-1]), _spatial(a)
+    L = _lib.lib()
+    P = L.cbim_stats_parts(S, Cc)
+    pa = torch.empty((N, P, Cc, 3), dtype=torch.float32, device=a.device)
+    pb = torch.empty((N, P, Cc, 3), dtype=torch.float32, device=a.device) if stats_b is not None else None
+    check(L.cbim_resnorm_bwd_reduce(_dt(a), _p(dy), _rs(dy), _p(a), _rs(a), _p(stats_a), _p(b), _rs(b), _p(stats_b), N, S, Cc, act,
+                                    _p(pa), _p(pb), P, _stream(a)), "resnorm_bwd_reduce")
+    ma = stats_finalize(pa, S, 0.0, 1)
+    mb = stats_finalize(pb, S, 0.0, 1) if pb is not None else None
+    da = torch.empty(tuple(a.shape), dtype=a.dtype, device=a.device)
+    db = torch.empty(tuple(a.shape), dtype=a.dtype, device=a.device) if need_db else None
+    check(L.cbim_resnorm_bwd_apply(_dt(a), _p(dy), _rs(dy), _p(a), _rs(a), _p(stats_a), _p(ma), _p(b), _rs(b), _p(stats_b),
+                                   _p(mb), _p(da), _p(db), N, S, Cc, act, _stream(a)), "resnorm_bwd_apply")
+    return da, db

@@ -274,6 +274,45 @@ int cbim_trilinear_planes_fwd(const float* x, float* y, int planes, int Di, int 
 int cbim_trilinear_planes_bwd(const float* dy, float* dx, int planes, int Di, int Hi, int Wi, int Do, int Ho,
                               int Wo, void* stream);
 
+/* Post-norm residual tail of monai's UnetResBlock (SwinUNETR encoder/decoder blocks, swin_unetr.py:129-226):
+ * y = act(IN(a; stats_a) + (stats_b ? IN(b; stats_b) : b)).  Backward: g = dy*act'(pre) (pre recomputed);
+ * reduce -> partial records [N][P][C][3] for cbim_stats_finalize(mode 1) -> sums (mean g, mean g*xhat);
+ * apply -> da = rstd_a*(g - m1 - xhat_a*m2), db likewise or g. */
+int cbim_resnorm_fwd(int dtype, const void* a, int64_t a_stride, const float* stats_a, const void* b,
+                     int64_t b_stride, const float* stats_b, void* y, int64_t y_stride, int N, int64_t S, int C,
+                     int act, void* stream);
+int cbim_resnorm_bwd_reduce(int dtype, const void* dy, int64_t dy_stride, const void* a, int64_t a_stride,
+                            const float* stats_a, const void* b, int64_t b_stride, const float* stats_b, int N,
+                            int64_t S, int C, int act, float* partials_a, float* partials_b, int P, void* stream);
+int cbim_resnorm_bwd_apply(int dtype, const void* dy, int64_t dy_stride, const void* a, int64_t a_stride,
+                           const float* stats_a, const float* sums_a, const void* b, int64_t b_stride,
+                           const float* stats_b, const float* sums_b, void* da, void* db, int N, int64_t S,
+                           int C, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SwinUNETR shifted-window attention — /root/reference/model/dim3/swin_unetr.py.
+ * One call replaces F.pad + torch.roll + window_partition + WindowAttention's q@k^T*scale +
+ * relative_position_bias_table[relative_position_index[:n,:n]] + shift mask + softmax + @v +
+ * window_reverse + roll back + crop (:467-490, :554-606, :737-773).
+ *   qkv  [B][D][H][W][3*C] token rows ([3][heads][dh] inside a row), out/dout [B][D][H][W][C]
+ *   qkv_bias float [3*C] or NULL: the q/k/v of window-padding tokens (the reference pads after norm1)
+ *   table float [(2*tw0-1)*(2*tw1-1)*(2*tw2-1)][heads]; window/shift/table_window: int[3] HOST arrays;
+ *   window/shift are the EFFECTIVE values of get_window_size (:358-381); table_window is the module's (7,7,7)
+ *   lse float [num_windows][heads][343] (log-sum-exp per query, kept for the backward)
+ *   backward also returns d(table) and the gradient reaching qkv.bias through padded keys (float [3*C]).
+ * ------------------------------------------------------------------------------------------ */
+int cbim_window_attn3d_num_windows(int B, int D, int H, int W, const int* window);
+size_t cbim_window_attn3d_workspace(int B, int D, int H, int W, int C, int heads, const int* window,
+                                    const int* table_window);
+int cbim_window_attn3d_fwd(int dtype, const void* qkv, const float* qkv_bias, const float* table, void* out,
+                           float* lse, int B, int D, int H, int W, int C, int heads, const int* window,
+                           const int* shift, const int* table_window, void* stream);
+int cbim_window_attn3d_bwd(int dtype, const void* qkv, const float* qkv_bias, const float* table,
+                           const void* out, const void* dout, const float* lse, void* dqkv, float* dtable,
+                           float* dbias_pad, int B, int D, int H, int W, int C, int heads, const int* window,
+                           const int* shift, const int* table_window, void* workspace, size_t ws_bytes,
+                           void* stream);
+
 /* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);

@@ -344,3 +344,79 @@ def check_trilinear_planes(dev, N=1, C=3, lo=(3, 4, 5), hi=(7, 8, 9)):
     ref.backward(g)
     dx = ops.trilinear_planes_bwd(g.to(dev), tuple(x.shape))
     assert relerr(dx.cpu(), x.grad) < 2e-6
+
+
+# ---- SwinUNETR pieces -----------------------------------------------------------------------------
+
+def check_window_attn(dev, dtype, B=1, dhw=(9, 8, 7), C=24, heads=3, window=(7, 7, 7), shift=(3, 3, 3), seed=21):
+    """pad + roll + partition + WindowAttention core + reverse + roll back + crop (swin_unetr.py:467-490,554-606)
+    against the oracle's stock-torch restatement of the same lines."""
+    from oracle import swin_unetr_ref as R
+    torch.manual_seed(seed)
+    D, H, W = dhw
+    ws, ss = R.effective_window(dhw, window, shift)
+    x = torch.randn(B, D, H, W, C)                                   # plays norm1's output
+    wq = torch.randn(3 * C, C) * 0.3
+    bq = torch.randn(3 * C) * 0.3
+    table = torch.randn((2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1), heads) * 0.5
+    rel = R.relative_position_index(window)
+    # reference: qkv of padded tokens is the bias (linear of zeros)
+    xr = x.clone().requires_grad_(True)
+    bqr = bq.clone().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    pd, ph, pw = (ws[0] - D % ws[0]) % ws[0], (ws[1] - H % ws[1]) % ws[1], (ws[2] - W % ws[2]) % ws[2]
+    xp = F.pad(xr, (0, 0, 0, pw, 0, ph, 0, pd))
+    dims = xp.shape[1:4]
+    shifted = any(s > 0 for s in ss)
+    mask = None
+    if shifted:
+        xp = torch.roll(xp, shifts=tuple(-s for s in ss), dims=(1, 2, 3))
+        mask = R.region_mask(dims, ws, ss, torch.float32)
+    qkv_w = F.linear(R.partition(xp, ws), wq, bqr)
+    o = R.window_attention_core(qkv_w, tr, rel, heads, mask)
+    o = R.unpartition(o, ws, (B,) + tuple(dims))
+    if shifted:
+        o = torch.roll(o, shifts=ss, dims=(1, 2, 3))
+    ref = o[:, :D, :H, :W, :]
+    # kernel: qkv computed on the real tokens only
+    qkv = F.linear(x, wq, bq).to(dtype).to(dev)
+    out, lse = ops.window_attn_fwd(qkv, bq.to(dev), table.to(dev), heads, ws, ss, window)
+    # bf16 I/O variant: q/k/v rounded to bf16 feed softmax logits of magnitude ~10 -> percent-level output changes
+    # (the product runs the transformer trunk in fp32; bf16 here only exercises the 2-byte load/store path)
+    t = tol(dtype, 2e-5, 1e-1)
+    e = relerr(out.float().cpu(), ref.detach())
+    assert e < t, f"window attention fwd {e:.3e}"
+    if dtype != torch.float32:
+        return
+    g = torch.randn_like(ref)
+    qkv_leaf = F.linear(xr, wq, bqr)      # for d(qkv) of real tokens: differentiate through a fresh graph
+    ref.backward(g)
+    dqkv, dtable, dbias = ops.window_attn_bwd(qkv, bq.to(dev), table.to(dev), out, g.to(dev), lse, heads, ws, ss, window)
+    # d x = dqkv @ Wq;  d bias = sum over real tokens of dqkv + gradient through padded keys
+    dx = dqkv.float().cpu() @ wq
+    assert relerr(dx, xr.grad) < 5e-5, "window attention dqkv"
+    assert relerr(dtable.cpu(), tr.grad) < 5e-5, "window attention dtable"
+    db = dqkv.float().cpu().reshape(-1, 3 * C).sum(0) + dbias.cpu()
+    assert relerr(db, bqr.grad) < 5e-5, "window attention dbias"
+
+
+def check_resnorm(dev, dtype, N=2, C=16, dhw=(4, 5, 6), with_b_stats=True, seed=22):
+    """monai UnetResBlock tail: lrelu(IN(a) + (IN(b) | b)), eps 1e-5."""
+    torch.manual_seed(seed)
+    a = torch.randn(N, C, *dhw) * 1.5 + 0.3
+    b = torch.randn(N, C, *dhw)
+    al, bl = to_cl(a, dtype).to(dev), to_cl(b, dtype).to(dev)
+    ar = from_cl(al.cpu()).requires_grad_(True)
+    br = from_cl(bl.cpu()).requires_grad_(True)
+    sa = ops.instnorm_stats(al, 1e-5)
+    sb = ops.instnorm_stats(bl, 1e-5) if with_b_stats else None
+    ref = F.leaky_relu(F.instance_norm(ar, eps=1e-5) + (F.instance_norm(br, eps=1e-5) if with_b_stats else br), 0.01)
+    y = ops.resnorm_fwd(al, sa, bl, sb, ops.ACT["lrelu"])
+    t = tol(dtype, 2e-5, 1e-2)
+    assert relerr(from_cl(y.cpu()), ref.detach()) < t, "resnorm fwd"
+    g = torch.randn_like(ref)
+    gl = to_cl(g, dtype).to(dev)
+    ref.backward(from_cl(gl.cpu()))
+    da, db = ops.resnorm_bwd(gl, al, sa, bl, sb, ops.ACT["lrelu"])
+    assert relerr(from_cl(da.cpu()), ar.grad) < tol(dtype, 5e-5, 2e-2), "resnorm da"
+    assert relerr(from_cl(db.cpu()), br.grad) < tol(dtype, 5e-5, 2e-2), "resnorm db"

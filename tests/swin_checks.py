@@ -1,0 +1,84 @@
+"""Whole-model SwinUNETR parity checks against the goldens of tests/golden/make_golden_swin.py (the reference's
+swin_unetr.py executed unmodified on the torch-only monai stand-in: transformer part pinned, monai conv blocks
+"parity unpinned") — shared by the CPU (host-side executor) and -m gpu suites."""
+import numpy as np
+import torch
+
+import cbim_amd
+from cbim_amd import functional as Fn
+from cbim_amd.model.dim3 import SwinUNETR
+from tests.util import load_golden, rel_err
+
+SW_CASES = {
+    # name: (img_size, in_chan, classes, feature_size)
+    "swin_tiny": ((64, 32, 32), 4, 3, 24),
+    "swin_brats_64": ((64, 64, 64), 4, 4, 48),
+}
+
+
+def build(name, dev):
+    from oracle.unet_ref import state_dict_checksum
+    g = load_golden(name)
+    shape, in_ch, classes, feat = SW_CASES[name]
+    torch.manual_seed(int(g["seed"]))
+    net = SwinUNETR(shape, in_ch, classes, feature_size=feat)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"]) and len(list(net.buffers())) == int(g["n_buffers"])
+    pk = [k for k, _ in net.named_parameters()]
+    assert pk == [str(k) for k in g["param_keys"]]
+    chk = state_dict_checksum({k: sd[k] for k in pk})
+    assert abs(chk - float(g["sd_checksum"])) <= 1e-9 * max(1.0, abs(chk)), (chk, float(g["sd_checksum"]))
+    return net.to(dev), g
+
+
+def run_case(name, dev, mode, backward=True):
+    cbim_amd.set_compute_dtype(mode)
+    try:
+        net, g = build(name, dev)
+        x = torch.from_numpy(g["x"]).to(dev)
+        lab = torch.from_numpy(g["label"]).to(dev)
+        w = torch.from_numpy(g["weight"]).to(dev)
+        res = {}
+        if "hidden0" in g.files:
+            hs = net.swinViT(x)
+            res["hidden_err"] = max(rel_err(h.detach().cpu().permute(0, 4, 1, 2, 3), g[f"hidden{i}"]) for i, h in enumerate(hs))
+        logits = net(x)
+        st = int(g["stride"])
+        mine = logits.detach().cpu()[..., ::st, ::st, ::st]
+        res["logits_err"] = rel_err(mine, g["logits"])
+        ref = torch.from_numpy(g["logits"])
+        top2 = ref.topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        res["argmax_mismatch"] = int(((mine.argmax(1) != ref.argmax(1)) & clear).sum())
+        res["n_vox"] = int(ref.numel() // ref.shape[1])
+        both = Fn.DiceCEFn.apply(logits, lab, w)
+        res["ce"], res["dice"] = float(both[0]), float(both[1])
+        if backward:
+            both[2].backward()
+            params = dict(net.named_parameters())
+            pk = [str(k) for k in g["param_keys"]]
+            gn = np.array([float(params[k].grad.double().norm()) for k in pk])
+            scale = float(np.max(g["grad_norms"]))
+            res["grad_norm_err"] = float(np.max(np.abs(gn - g["grad_norms"]) / np.maximum(g["grad_norms"], 1e-6 * scale)))
+            errs = []
+            for k in g.files:
+                if k.startswith("g:"):
+                    r = torch.from_numpy(g[k]).double()
+                    d = (params[k[2:]].grad.detach().cpu().double() - r).abs()
+                    errs.append(float(d.max()) / max(float(r.abs().max()), 1e-6 * scale))
+            res["grad_max_err"] = max(errs)
+        return res, g
+    finally:
+        cbim_amd.set_compute_dtype(None)
+
+
+def assert_fp32_parity(name, dev, backward=True):
+    r, g = run_case(name, dev, "fp32", backward)
+    assert r.get("hidden_err", 0.0) < 1e-4, r
+    assert r["logits_err"] < 1e-3 and r["argmax_mismatch"] == 0, r
+    assert abs(r["ce"] - float(g["ce"])) < 1e-4 and abs(r["dice"] - float(g["dice"])) < 1e-4, r
+    if backward:
+        assert r["grad_norm_err"] < 1e-2 and r["grad_max_err"] < 2e-2, r
+    return r

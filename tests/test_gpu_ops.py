@@ -112,3 +112,19 @@ def test_trilinear_planes(dev):
     oc.check_trilinear_planes(dev)
     oc.check_trilinear_planes(dev, lo=(1, 2, 2), hi=(4, 4, 4))
     oc.check_trilinear_planes(dev, C=16, lo=(16, 16, 16), hi=(64, 64, 64))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_window_attention(dev, dtype):
+    oc.check_window_attn(dev, dtype)
+    oc.check_window_attn(dev, dtype, dhw=(7, 7, 7), shift=(0, 0, 0), C=16, heads=2)
+    oc.check_window_attn(dev, dtype, dhw=(8, 4, 4), shift=(3, 3, 3), C=16, heads=1)
+    oc.check_window_attn(dev, dtype, dhw=(16, 16, 16), C=48, heads=3)                   # d_head 16, 27 windows
+    oc.check_window_attn(dev, dtype, B=2, dhw=(14, 14, 14), shift=(0, 0, 0), C=96, heads=6)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_resnorm(dev, dtype):
+    oc.check_resnorm(dev, dtype)
+    oc.check_resnorm(dev, dtype, N=1, C=24, dhw=(2, 1, 1), with_b_stats=False)
+    oc.check_resnorm(dev, dtype, N=1, C=768, dhw=(4, 4, 4))

@@ -152,3 +152,20 @@ def test_medformer_bf16_inside_envelope(dev):
     assert r["logits_err"] < 0.25 and r["aux_err"] < 0.25, r
     assert max(abs(a - b) for a, b in zip(r["ce"] + r["dice"], list(g["ce"]) + list(g["dice"]))) < 0.05, r
     assert r["grad_norm_err"] < 0.5, r
+
+
+# ---- SwinUNETR -------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["swin_tiny", "swin_brats_64"])
+def test_swin_unetr_fp32_matches_reference_golden(dev, name):
+    from tests.swin_checks import assert_fp32_parity as sw_parity
+    print(name, sw_parity(name, dev))
+
+
+def test_swin_unetr_bf16_inside_envelope(dev):
+    from tests.swin_checks import run_case as sw_run
+    r, g = sw_run("swin_brats_64", dev, "bf16")
+    print(r)
+    assert r["logits_err"] < 0.25 and r["argmax_mismatch"] < 0.2 * r["n_vox"], r
+    assert abs(r["ce"] - float(g["ce"])) < 0.05 and abs(r["dice"] - float(g["dice"])) < 0.02, r
+    assert r["grad_norm_err"] < 0.5, r

@@ -61,7 +61,7 @@ def test_unbuilt_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         get_model(_args(norm="bn"))
     with pytest.raises(NotImplementedError):
-        get_model(_args(model="swin_unetr"))
+        get_model(_args(model="vtunet"))
     with pytest.raises(KeyError):
         from cbim_amd.model.dim3 import UNet
         UNet(1, 8)                       # the reference's default block name is not a valid key either
@@ -108,3 +108,21 @@ def test_medformer_plugin_surface():
 def test_medformer_fp32_matches_reference_golden(dev):
     from tests.medformer_checks import assert_fp32_parity
     assert_fp32_parity("medformer_tiny_32", dev)
+
+
+def test_swin_unetr_plugin_surface():
+    """get_model(args) builds the reference's SwinUNETR parameter layout (58.54 M parameters / 131 tensors at
+    feature_size 48, in_chan 4 — SURVEY §8a a21)."""
+    from cbim_amd.model.utils import get_model
+    net = get_model(_args(model="swin_unetr", in_chan=4, classes=4, base_chan=48, window_size=[128, 128, 128], pretrain=False))
+    assert sum(p.numel() for p in net.parameters()) == 58537606 and len(net.state_dict()) == 131
+    sd = net.state_dict()
+    assert tuple(sd["swinViT.layers1.0.blocks.0.attn.relative_position_bias_table"].shape) == (2197, 3)
+    assert tuple(sd["decoder5.transp_conv.conv.weight"].shape) == (768, 384, 2, 2, 2)
+    with pytest.raises(NotImplementedError):
+        get_model(_args(model="swin_unetr", in_chan=4, classes=4, base_chan=48, window_size=[128, 128, 128], pretrain=True))
+
+
+def test_swin_unetr_fp32_matches_reference_golden(dev):
+    from tests.swin_checks import assert_fp32_parity
+    print(assert_fp32_parity("swin_tiny", dev))

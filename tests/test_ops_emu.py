@@ -111,3 +111,16 @@ def test_errors_are_loud(dev):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_fused_conv1_shortcut_block(dev, dtype):
     oc.check_fused_block(dev, dtype)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_window_attention(dev, dtype):
+    oc.check_window_attn(dev, dtype)                                                    # padded + shifted
+    oc.check_window_attn(dev, dtype, dhw=(7, 7, 7), shift=(0, 0, 0), C=16, heads=2)     # one full window
+    oc.check_window_attn(dev, dtype, dhw=(8, 4, 4), shift=(3, 3, 3), C=16, heads=1)     # window (7,4,4), shift (3,0,0)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_resnorm(dev, dtype):
+    oc.check_resnorm(dev, dtype)
+    oc.check_resnorm(dev, dtype, N=1, C=24, dhw=(2, 1, 1), with_b_stats=False)

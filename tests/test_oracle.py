@@ -95,3 +95,34 @@ def test_medformer_oracle_matches_reference_golden():
         # bit-identical with the fixture's thread count; other thread counts reorder fp32 sums (the reference's
         # own fp32-vs-fp64 gradient noise on this case is ~1e-3)
         assert float((v.grad - r).abs().max()) <= 1e-3 * float(r.abs().max()) + 1e-7 * scale, k
+
+
+def test_swin_oracle_matches_reference_golden():
+    """oracle/swin_unetr_ref.py against the reference's swin_unetr.py executed on the monai stand-in
+    (transformer part pinned; monai conv blocks parity-unpinned, see the oracle's header)."""
+    from cbim_amd.model.dim3 import SwinUNETR          # only as the seeded weight initialiser (checksum-checked)
+    from oracle.loss_ref import ce_dice_loss
+    from oracle.swin_unetr_ref import swin_transformer, swin_unetr_forward
+    from oracle.unet_ref import state_dict_checksum
+    g = load_golden("swin_tiny")
+    torch.manual_seed(int(g["seed"]))
+    net = SwinUNETR((64, 32, 32), 4, 3, feature_size=24)
+    pk = [k for k, _ in net.named_parameters()]
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    assert abs(state_dict_checksum({k: sd[k] for k in pk}) - float(g["sd_checksum"])) < 1e-6
+    for k in pk:
+        sd[k].requires_grad_(True)
+    x, lab, w = torch.from_numpy(g["x"]), torch.from_numpy(g["label"]), torch.from_numpy(g["weight"])
+    hs = swin_transformer(sd, "swinViT.", x, (2, 2, 2, 0), (3, 6, 12, 24), (7, 7, 7))
+    for i, h in enumerate(hs):
+        assert rel_err(h, g[f"hidden{i}"]) < 1e-5, i
+    logits = swin_unetr_forward(sd, x)
+    assert rel_err(logits, g["logits"]) < 1e-5
+    loss = ce_dice_loss(logits, lab, w)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    scale = float(np.max(g["grad_norms"]))
+    for k in g.files:
+        if k.startswith("g:"):
+            r = torch.from_numpy(g[k])
+            assert float((sd[k[2:]].grad - r).abs().max()) <= 1e-3 * float(r.abs().max()) + 1e-7 * scale, k
