@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 
 FWD_FLOPS_128 = 2.592e12          # ResUNet-BasicBlock fwd at 1x1x128^3, 16 classes
+FWD_FLOPS_128_SWIN = 1.53e12       # SwinUNETR feature 48, 4x128^3 input (conv+linear+attention)
 FWD_FLOPS_128_MEDFORMER = 2.34e12  # MedFormer (AMOS yaml) fwd at 1x1x128^3
 MEDFORMER_AMOS = dict(base_chan=32, map_size=[4, 4, 4], conv_block="BasicBlock", conv_num=[2, 1, 0, 0, 0, 1, 2, 2],
                       trans_num=[0, 1, 4, 6, 4, 1, 0, 0], chan_num=[64, 128, 256, 320, 256, 128, 64, 32],
@@ -53,8 +54,8 @@ def parse():
     ap.add_argument("--graph", type=int, default=1,
                     help="1: replay the whole step from one hipGraph (captured after warm-up; N=1 only)")
     ap.add_argument("--cpu-size", type=int, default=96, help="edge of the CPU-baseline sample volume")
-    ap.add_argument("--model", default="resunet", choices=["resunet", "medformer"],
-                    help="resunet = BASELINE configs[1] (the headline); medformer = configs[2] (AMOS yaml, aux loss)")
+    ap.add_argument("--model", default="resunet", choices=["resunet", "medformer", "swin_unetr"],
+                    help="resunet = BASELINE configs[1] (the headline); medformer = configs[2] (AMOS yaml, aux loss); swin_unetr = configs[4] (4-modality input, feature 48, 4 classes)")
     ap.add_argument("--aug", type=int, default=0,
                     help="1: draw each step's volume with the on-device augmentation pipeline (configs[3]): affine "
                          "scale/rotate + centre crop from a (size+40)^3 source, then the intensity ops")
@@ -79,7 +80,20 @@ def cpu_baseline(args):
     x, lab = synthetic(1, args.classes, s, "cpu", 2023)
     w = torch.ones(args.classes)
     w[0] = 0.5
-    if args.model == "medformer":
+    if args.model == "swin_unetr":
+        from cbim_amd.model.dim3 import SwinUNETR   # only as the weight initialiser (reference parameter layout)
+        from oracle import swin_unetr_ref
+        torch.manual_seed(2023)
+        sd = {k: v.detach() for k, v in SwinUNETR((s,) * 3, 4, 4, feature_size=48).state_dict().items()}
+        for v in sd.values():
+            if v.is_floating_point():
+                v.requires_grad_(True)
+        x = torch.cat([x] + [synthetic(1, 4, s, "cpu", 3000 + i)[0] for i in range(3)], 1)
+        lab = lab.clamp_(max=3)
+        w = w[:4]
+        t0 = time.perf_counter()
+        loss = loss_ref.ce_dice_loss(swin_unetr_ref.swin_unetr_forward(sd, x), lab, w)
+    elif args.model == "medformer":
         from cbim_amd.model.dim3 import MedFormer   # only as the weight initialiser (reference parameter layout)
         torch.manual_seed(2023)
         sd = {k: v.detach().requires_grad_(True) for k, v in MedFormer(1, args.classes, **MEDFORMER_AMOS).state_dict().items()}
@@ -116,7 +130,7 @@ def main():
 
     import cbim_amd
     from cbim_amd import _lib, ops
-    from cbim_amd.model.dim3 import MedFormer, UNet
+    from cbim_amd.model.dim3 import MedFormer, SwinUNETR, UNet
     from cbim_amd.training import augmentation as aug
     from cbim_amd.parallel import GradAllReduce
     from cbim_amd.training.losses import DiceCELoss
@@ -125,8 +139,12 @@ def main():
 
     torch.manual_seed(2023)
     ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
+    in_ch = 1
     if args.model == "medformer":
         net = MedFormer(1, args.classes, **MEDFORMER_AMOS).to(dev)
+    elif args.model == "swin_unetr":
+        in_ch, args.classes = 4, 4
+        net = SwinUNETR((args.size,) * 3, in_ch, args.classes, feature_size=48).to(dev)
     else:
         net = UNet(1, args.base, scale=sc, kernel_size=ks, num_classes=args.classes, block="BasicBlock", norm="in").to(dev)
     net.train()
@@ -138,6 +156,8 @@ def main():
                             capturable=use_graph)
     ddp = GradAllReduce(net) if world > 1 else None
     x, lab = synthetic(1, args.classes, args.size, dev, 2023 + rank)
+    if in_ch > 1:
+        x = torch.cat([x] + [synthetic(1, args.classes, args.size, dev, 3000 + rank + i)[0] for i in range(in_ch - 1)], 1)
     if args.aug:
         # source volume with the dataset's affine padding (dataset_amos_ct.py:105-165: affine_pad_size 40)
         src_x, src_lab = synthetic(1, args.classes, args.size + 40, dev, 2023 + rank)
@@ -224,9 +244,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("3D MedFormer (amos_ct/medformer_3d.yaml, aux loss)" if args.model == "medformer"
-                                else "3D UNet ResBasicBlock (amos_ct/resunet_3d.yaml)")
-                               + f", 1x1x{args.size}^3 per GPU, {args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
+        "config": {"workload": {"medformer": "3D MedFormer (amos_ct/medformer_3d.yaml, aux loss)",
+                                "swin_unetr": "SwinUNETR (feature 48, 4-modality BraTS-style input)",
+                                "resunet": "3D UNet ResBasicBlock (amos_ct/resunet_3d.yaml)"}[args.model]
+                               + f", 1x{in_ch}x{args.size}^3 per GPU, {args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
                                + (", on-device augmentation (affine+crop+intensity) per step" if args.aug else "")
                                + (" (hipGraph replay)" if use_graph else "")
                                + (", bucketed grad all-reduce (RCCL)" if world > 1 else ""),
@@ -253,7 +274,8 @@ def main():
                      "frac_of_peak": v[0] / v[1] / 1e12 / peak} for k, v in per.items()}
         dom = max((k for k in per if k.startswith("k_conv_igemm")), key=lambda k: per[k][1])
         f, tsec, nl = per[dom]
-        fwd128 = FWD_FLOPS_128_MEDFORMER if args.model == "medformer" else FWD_FLOPS_128 * (args.base / 32.0) ** 2
+        fwd128 = {"medformer": FWD_FLOPS_128_MEDFORMER, "swin_unetr": FWD_FLOPS_128_SWIN,
+                  "resunet": FWD_FLOPS_128 * (args.base / 32.0) ** 2}[args.model]
         step_flops = 3.0 * fwd128 * (args.size / 128.0) ** 3
         # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run
         # inside this process); null when no recorded pass covers this kernel / dtype / model
