@@ -86,6 +86,8 @@ _SIGS = {
     "cbim_window_attn3d_workspace": (sz, [i32] * 6 + [vp, vp]),
     "cbim_window_attn3d_fwd": (i32, [i32, vp, vp, vp, vp, vp] + [i32] * 6 + [vp, vp, vp, vp]),
     "cbim_window_attn3d_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 6 + [vp, vp, vp, vp, sz, vp]),
+    "cbim_optim_chunk": (i32, []),
+    "cbim_adamw_ema_step": (i32, [vp, vp, vp, i32, vp, vp]),
     "cbim_ncdhw_to_ndhwc": (i32, [i32, vp, vp, i32, i32, i64, vp]),
     "cbim_ndhwc_to_ncdhw": (i32, [i32, vp, vp, i32, i32, i64, vp]),
 }

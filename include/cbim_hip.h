@@ -313,6 +313,29 @@ int cbim_window_attn3d_bwd(int dtype, const void* qkv, const float* qkv_bias, co
                            const int* shift, const int* table_window, void* workspace, size_t ws_bytes,
                            void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer + EMA step — optim.AdamW(..., eps=1e-5).step() and update_ema_variables
+ * (/root/reference/training/utils.py:14,98-105; train.py:216-218) over ALL parameters in one launch.
+ *   tensors   : DEVICE array of records (fp32 parameter, gradient, exp_avg, exp_avg_sq, ema copy or NULL)
+ *   blk_tensor/blk_chunk : DEVICE int32[nblocks]: workgroup b updates elements [chunk*C, chunk*C + C) of tensor
+ *               blk_tensor[b], C = cbim_optim_chunk()
+ *   hyper     : DEVICE float[10] = {step, lr, beta1, beta2, eps, weight_decay, ema_alpha, 0, 1-beta1, 1-beta2};
+ *               the call first
+ *               increments hyper[0] on the device (graph-capturable), then applies torch's AdamW update with
+ *               bias corrections for that step, then ema = a*ema + (1-a)*p with a = min(1 - 1/step, ema_alpha).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  void* p;
+  const void* g;
+  void* m;
+  void* v;
+  void* ema;
+  int64_t numel;
+} cbim_optim_tensor;
+int cbim_optim_chunk(void);
+int cbim_adamw_ema_step(const cbim_optim_tensor* tensors, const int32_t* blk_tensor, const int32_t* blk_chunk,
+                        int nblocks, float* hyper, void* stream);
+
 /* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);

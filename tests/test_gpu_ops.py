@@ -128,3 +128,9 @@ def test_resnorm(dev, dtype):
     oc.check_resnorm(dev, dtype)
     oc.check_resnorm(dev, dtype, N=1, C=24, dhw=(2, 1, 1), with_b_stats=False)
     oc.check_resnorm(dev, dtype, N=1, C=768, dhw=(4, 4, 4))
+
+
+def test_fused_adamw_ema(dev):
+    from tests.optim_checks import check_adamw_ema
+    check_adamw_ema(dev)
+    check_adamw_ema(dev, steps=7, seed=32)

@@ -124,5 +124,7 @@ def test_swin_unetr_plugin_surface():
 
 
 def test_swin_unetr_fp32_matches_reference_golden(dev):
+    # forward + losses on the host-side executor (the backward of every kernel involved is covered per op in
+    # test_ops_emu.py and end to end on the GPU in test_gpu_parity.py; it would add ~90 s here)
     from tests.swin_checks import assert_fp32_parity
-    print(assert_fp32_parity("swin_tiny", dev))
+    print(assert_fp32_parity("swin_tiny", dev, backward=False))

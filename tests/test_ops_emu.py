@@ -124,3 +124,8 @@ def test_window_attention(dev, dtype):
 def test_resnorm(dev, dtype):
     oc.check_resnorm(dev, dtype)
     oc.check_resnorm(dev, dtype, N=1, C=24, dhw=(2, 1, 1), with_b_stats=False)
+
+
+def test_fused_adamw_ema(dev):
+    from tests.optim_checks import check_adamw_ema
+    check_adamw_ema(dev)
