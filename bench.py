@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--graph", type=int, default=1,
                     help="1: replay the whole step from one hipGraph (captured after warm-up; N=1 only)")
     ap.add_argument("--cpu-size", type=int, default=96, help="edge of the CPU-baseline sample volume")
+    ap.add_argument("--optim", default="fused", choices=["fused", "torch"],
+                    help="fused: cbim_amd FusedAdamW (one multi-tensor launch); torch: torch.optim.AdamW(fused=True)")
     ap.add_argument("--model", default="resunet", choices=["resunet", "medformer", "swin_unetr"],
                     help="resunet = BASELINE configs[1] (the headline); medformer = configs[2] (AMOS yaml, aux loss); swin_unetr = configs[4] (4-modality input, feature 48, 4 classes)")
     ap.add_argument("--aug", type=int, default=0,
@@ -152,8 +154,12 @@ def main():
     w[0] = 0.5
     crit = DiceCELoss(w).to(dev)
     use_graph = bool(args.graph) and world == 1
-    opt = torch.optim.AdamW(net.parameters(), lr=6e-4, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5, fused=True,
-                            capturable=use_graph)
+    if args.optim == "fused":
+        from cbim_amd.training.optim import FusedAdamW
+        opt = FusedAdamW(net.parameters(), lr=6e-4, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5)
+    else:
+        opt = torch.optim.AdamW(net.parameters(), lr=6e-4, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5, fused=True,
+                                capturable=use_graph)
     ddp = GradAllReduce(net) if world > 1 else None
     x, lab = synthetic(1, args.classes, args.size, dev, 2023 + rank)
     if in_ch > 1:

@@ -72,17 +72,20 @@ class FusedAdamW(torch.optim.Optimizer):
                                     self.ema_alpha, 0.0, 1.0 - g["betas"][0], 1.0 - g["betas"][1]], dtype=torch.float32,
                                    device=dev)
         self._lr_pushed = g["lr"]
-        self._hosts = []     # pinned staging buffers stay alive: a captured graph may re-read them on replay
+        # pinned staging buffers, allocated up front (no host allocation may happen while a hipGraph is being
+        # captured) and used round-robin: a captured graph re-reads the buffer it was recorded with on replay
+        nb = len(self._params) * C.sizeof(_Rec)
+        self._hosts = [torch.empty((nb,), dtype=torch.uint8).pin_memory() if dev.type == "cuda"
+                       else torch.empty((nb,), dtype=torch.uint8) for _ in range(8)]
+        self._host_i = 0
         self._table = torch.empty((len(self._params) * C.sizeof(_Rec),), dtype=torch.uint8, device=dev)
 
     def _fill_table(self):
         ptrs = tuple((p.data_ptr(), p.grad.data_ptr()) for p in self._params)
         if ptrs == self._ptrs:
             return
-        host = torch.empty((len(self._params) * C.sizeof(_Rec),), dtype=torch.uint8)
-        if self._table.device.type == "cuda":
-            host = host.pin_memory()
-        self._hosts.append(host)
+        host = self._hosts[self._host_i % len(self._hosts)]
+        self._host_i += 1
         recs = (_Rec * len(self._params)).from_address(host.data_ptr())
         for i, p in enumerate(self._params):
             st = self.state[p]
