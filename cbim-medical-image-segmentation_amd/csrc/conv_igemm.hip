@@ -89,6 +89,12 @@ template <int ACT> __device__ __forceinline__ float actg(float x, int rt) {
 }
 
 #ifdef CBIM_EMU
+#define CBIM_SCHED_FENCE() ((void)0)
+#else
+#define CBIM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+#ifdef CBIM_EMU
 #define CBIM_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
 #else
 #define CBIM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -99,8 +105,13 @@ __device__ __forceinline__ void dma16(const unsigned char* gsrc, unsigned char* 
 #ifdef CBIM_EMU
   emu_global_load_lds16(gsrc, lds_wave_base);
 #else
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  // Issued through inline asm ON PURPOSE: with the builtin the compiler knows an LDS-DMA is in flight, treats the
+  // LGKM counter as out-of-order and turns every `s_waitcnt lgkmcnt(n)` of the fragment pipeline into
+  // lgkmcnt(0) — each MFMA pair then waits a full LDS round trip.  The DMA's completion is covered by the
+  // explicit wait_vm0() + workgroup barrier at the end of every stage.
+  unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+  a = __builtin_amdgcn_readfirstlane(a);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc) : "memory", "m0");
 #endif
 }
 // wave-level rendez-vous for LDS data exchanged between lanes of ONE wave (LDS executes a wave's
@@ -338,10 +349,14 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
               fetch3(f1, kh, kw, 1);
+              CBIM_SCHED_FENCE();
               mma(f0);
+              CBIM_SCHED_FENCE();
               if (kw < 2) fetch3(f0, kh, kw + 1, 0);
               else if (kh < 2) { set_bases(kh + 1); fetch3(f0, kh + 1, 0, 0); }
+              CBIM_SCHED_FENCE();
               mma(f1);
+              CBIM_SCHED_FENCE();
             }
           }
         } else {
@@ -352,9 +367,14 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
           unsigned toff = a_plane;
           set_kh(0);
           fetch(f0, 0, 0, toff, b_buf);
+          // CBIM_SCHED_FENCE pins "issue the next fragments' ds_reads, THEN run the MFMAs on the previous set":
+          // left to itself the scheduler sinks each ds_read next to its use (register pressure) and every
+          // MFMA pair then waits a full LDS round trip (s_waitcnt lgkmcnt(0) right after the reads).
           for (int tp = 0; tp < ptaps; ++tp) {
             fetch(f1, tp, 1, toff, b_buf);
+            CBIM_SCHED_FENCE();
             mma(f0);
+            CBIM_SCHED_FENCE();
             ++kw;
             toff += RB;
             if (kw == p.kW) {   // wave-uniform
@@ -364,7 +384,9 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
               set_kh(kh);
             }
             fetch(f0, tp + 1, 0, toff, b_buf);
+            CBIM_SCHED_FENCE();
             mma(f1);
+            CBIM_SCHED_FENCE();
           }
         }
       }
@@ -852,7 +874,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
     // main kernel writes raw partials; the finish kernel owns residual / mask / statistics / store
     IgemmParams q = p;
     q.res = nullptr; q.mx = nullptr; q.partials = nullptr;
-    static const bool k3s_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : false;
+    static const bool k3s_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : true;
     const bool k3s = k3s_on && d->kH == 3 && d->kW == 3 && c.tH == 8;
     int rc;
     if (d->dtype == CBIM_BF16)
@@ -878,7 +900,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
     }
     return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
   }
-  static const bool k3_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : false;
+  static const bool k3_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : true;
   const bool k3 = k3_on && d->kH == 3 && d->kW == 3 && c.tH == 8;   // hW == hH == 10: compile-time tap offsets
   if (d->dtype == CBIM_BF16) {
     if (relu && k3) return dispatch_tiles<bf16_tag, CBIM_ACT_RELU, true>(c, p, grid, smem, st);
