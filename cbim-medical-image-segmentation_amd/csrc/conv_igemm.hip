@@ -79,11 +79,13 @@ template <> struct Mma<float> {
 // instruction cache); ACT < 0 = runtime switch for the rarely used activations.
 template <int ACT> __device__ __forceinline__ float actf(float x, int rt) {
   if (ACT == CBIM_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (ACT == CBIM_ACT_LRELU) return x > 0.f ? x : 0.01f * x;
   if (ACT == CBIM_ACT_NONE) return x;
   return act_fwd(x, rt);
 }
 template <int ACT> __device__ __forceinline__ float actg(float x, int rt) {
   if (ACT == CBIM_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (ACT == CBIM_ACT_LRELU) return x > 0.f ? 1.f : 0.01f;
   if (ACT == CBIM_ACT_NONE) return 1.f;
   return act_grad(x, rt);
 }
@@ -820,6 +822,22 @@ static int dispatch_tiles(const TileCfg& c, const IgemmParams& p, dim3 grid, siz
   return launch_igemm<T, 1, 2, ACT, K3>(p, grid, smem, st);
 }
 
+// activation -> compile-time instantiation (ReLU: UNet/MedFormer; none: raw and 1x1 projections; LeakyReLU: the
+// monai blocks of SwinUNETR); the rarely used ones share a runtime-switch instantiation
+template <typename T>
+static int dispatch_act(int act, bool k3, const TileCfg& c, const IgemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
+  switch (act) {
+    case CBIM_ACT_RELU:
+      return k3 ? dispatch_tiles<T, CBIM_ACT_RELU, true>(c, p, grid, smem, st) : dispatch_tiles<T, CBIM_ACT_RELU, false>(c, p, grid, smem, st);
+    case CBIM_ACT_NONE:
+      return k3 ? dispatch_tiles<T, CBIM_ACT_NONE, true>(c, p, grid, smem, st) : dispatch_tiles<T, CBIM_ACT_NONE, false>(c, p, grid, smem, st);
+    case CBIM_ACT_LRELU:
+      return k3 ? dispatch_tiles<T, CBIM_ACT_LRELU, true>(c, p, grid, smem, st) : dispatch_tiles<T, CBIM_ACT_LRELU, false>(c, p, grid, smem, st);
+    default:
+      return dispatch_tiles<T, -1, false>(c, p, grid, smem, st);
+  }
+}
+
 extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2,
                                  int64_t x2_stride, int cin_split,
                                  const float* in_stats, const void* w_packed, const void* res,
@@ -876,15 +894,8 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
     q.res = nullptr; q.mx = nullptr; q.partials = nullptr;
     static const bool k3s_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : true;
     const bool k3s = k3s_on && d->kH == 3 && d->kW == 3 && c.tH == 8;
-    int rc;
-    if (d->dtype == CBIM_BF16)
-      rc = (relu && k3s) ? dispatch_tiles<bf16_tag, CBIM_ACT_RELU, true>(c, q, grid, smem, st)
-         : relu ? dispatch_tiles<bf16_tag, CBIM_ACT_RELU, false>(c, q, grid, smem, st)
-                : dispatch_tiles<bf16_tag, -1, false>(c, q, grid, smem, st);
-    else
-      rc = (relu && k3s) ? dispatch_tiles<float, CBIM_ACT_RELU, true>(c, q, grid, smem, st)
-         : relu ? dispatch_tiles<float, CBIM_ACT_RELU, false>(c, q, grid, smem, st)
-                : dispatch_tiles<float, -1, false>(c, q, grid, smem, st);
+    int rc = d->dtype == CBIM_BF16 ? dispatch_act<bf16_tag>(d->act, k3s, c, q, grid, smem, st)
+                                   : dispatch_act<float>(d->act, k3s, c, q, grid, smem, st);
     if (rc) return rc;
     int cpc = d->dtype == CBIM_BF16 ? 8 : 4;
     CBIM_CHECK(d->Cout / cpc <= FT, CBIM_EUNSUPPORTED, "split-K finish: Cout %d too large", d->Cout);
@@ -902,12 +913,6 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   }
   static const bool k3_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : true;
   const bool k3 = k3_on && d->kH == 3 && d->kW == 3 && c.tH == 8;   // hW == hH == 10: compile-time tap offsets
-  if (d->dtype == CBIM_BF16) {
-    if (relu && k3) return dispatch_tiles<bf16_tag, CBIM_ACT_RELU, true>(c, p, grid, smem, st);
-    if (relu) return dispatch_tiles<bf16_tag, CBIM_ACT_RELU, false>(c, p, grid, smem, st);
-    return dispatch_tiles<bf16_tag, -1, false>(c, p, grid, smem, st);
-  }
-  if (relu && k3) return dispatch_tiles<float, CBIM_ACT_RELU, true>(c, p, grid, smem, st);
-  if (relu) return dispatch_tiles<float, CBIM_ACT_RELU, false>(c, p, grid, smem, st);
-  return dispatch_tiles<float, -1, false>(c, p, grid, smem, st);
+  return d->dtype == CBIM_BF16 ? dispatch_act<bf16_tag>(d->act, k3, c, p, grid, smem, st)
+                               : dispatch_act<float>(d->act, k3, c, p, grid, smem, st);
 }
