@@ -336,6 +336,23 @@ int cbim_optim_chunk(void);
 int cbim_adamw_ema_step(const cbim_optim_tensor* tensors, const int32_t* blk_tensor, const int32_t* blk_chunk,
                         int nblocks, float* hyper, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Sliding-window inference + evaluation Dice.
+ *   cbim_softmax_accumulate : prob_sum[window] += softmax(logits, dim 1); counter[window] += 1
+ *                             (/root/reference/inference/inference3d.py:80-86); NCDHW float32
+ *   cbim_prob_finalize      : prob_sum /= counter (:88) (counter NULL: keep), optional argmax labels (int64,
+ *                             first maximum — torch.max(pred, dim=1) of training/validation.py:44)
+ *   cbim_dice_counts        : calculate_dice's mask sums (/root/reference/metric/utils.py:62-82) as exact integers
+ *                             per block of `block` voxels: counts int32 [ceil(N/block)][C][3] =
+ *                             (#pred==c & target==c, #pred==c, #target==c); labels int8 or int64
+ * ------------------------------------------------------------------------------------------ */
+int cbim_softmax_accumulate(const float* logits, float* prob_sum, float* counter, int B, int K, int wd, int wh,
+                            int ww, int D, int H, int W, int d0, int h0, int w0, void* stream);
+int cbim_prob_finalize(float* prob_sum, const float* counter, int64_t* labels, int B, int K, int64_t S,
+                       void* stream);
+int cbim_dice_counts(const void* pred, int pred_bytes, const void* target, int target_bytes, int64_t N,
+                     int64_t block, int C, int32_t* counts, void* stream);
+
 /* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);

@@ -169,3 +169,11 @@ def test_swin_unetr_bf16_inside_envelope(dev):
     assert r["logits_err"] < 0.25 and r["argmax_mismatch"] < 0.2 * r["n_vox"], r
     assert abs(r["ce"] - float(g["ce"])) < 0.05 and abs(r["dice"] - float(g["dice"])) < 0.02, r
     assert r["grad_norm_err"] < 0.5, r
+
+
+# ---- sliding-window inference + evaluation Dice -------------------------------
+
+def test_sliding_window_inference_and_dice(dev):
+    from tests import infer_checks as ic
+    ic.check_dice_exact(dev)
+    ic.check_sliding_window(dev)

@@ -129,3 +129,9 @@ def test_resnorm(dev, dtype):
 def test_fused_adamw_ema(dev):
     from tests.optim_checks import check_adamw_ema
     check_adamw_ema(dev)
+
+
+def test_inference_and_dice(dev):
+    from tests import infer_checks as ic
+    ic.check_dice_exact(dev)
+    ic.check_sliding_window(dev, full=False)      # one 32^3 window on the executor; the 12-window run is a GPU test

@@ -126,3 +126,20 @@ def test_swin_oracle_matches_reference_golden():
         if k.startswith("g:"):
             r = torch.from_numpy(g[k])
             assert float((sd[k[2:]].grad - r).abs().max()) <= 1e-3 * float(r.abs().max()) + 1e-7 * scale, k
+
+
+def test_inference_oracle_matches_reference_golden():
+    """oracle/inference_ref.py (sliding window + Dice) against the real reference's outputs."""
+    from functools import partial
+    from oracle import inference_ref as IR
+    g = load_golden("infer_resunet_b8")
+    sd = unet_ref.make_unet_state_dict(1, 8, 3, [[3, 3, 3]] * 5, "BasicBlock", seed=int(g["seed"]))
+    fwd = partial(unet_ref.unet_forward, sd, scale=[[2, 2, 2]] * 4, kernel_size=[[3, 3, 3]] * 5, block="BasicBlock")
+    with torch.no_grad():
+        prob = IR.sliding_window(fwd, torch.from_numpy(g["x"]), [32, 32, 32], 3)
+    assert rel_err(prob, g["prob"]) < 1e-5
+    lp, lab = torch.from_numpy(g["label_pred"]), torch.from_numpy(g["label"])
+    d, i, s = IR.dice(lp, lab, 3)
+    assert np.array_equal(d.numpy(), g["dice"]) and np.array_equal(s.numpy(), g["summ"])
+    d, i, s = IR.dice_split(lp, lab, 3, block_size=30000)
+    assert np.array_equal(d.numpy(), g["dice_split"]) and np.array_equal(s.numpy(), g["summ_split"])
