@@ -133,6 +133,14 @@ __device__ __forceinline__ void wait_vm0() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
+// wait for everything older than the UH halo prefetch loads issued last (vector-memory loads return in order):
+// the weight DMA of the next stage must have landed, the next tile's halo may stay in flight
+static_assert(UH == 8, "wait_vm_halo hard-codes UH");
+__device__ __forceinline__ void wait_vm_halo() {
+#ifndef CBIM_EMU
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+}
 
 template <int MT, int NTL> struct Frags { u32x4 a[MT]; u32x4 b[NTL]; };   // one k-group of one tap
 
@@ -232,13 +240,15 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
       unsigned hw = r2 - hh * p.hW;
       int id = h_id0 + (int)hd, ih = h_ih0 + (int)hh, iw = h_iw0 + (int)hw;
       bool ld = !(p.dbg & 1) && item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
-      hreg[u] = u32x4{0u, 0u, 0u, 0u};
+      // every thread issues exactly UH loads (out-of-range items read element 0 and are discarded by
+      // halo_store): the stage-end wait can then leave exactly these UH loads in flight (wait_vm_halo)
+      size_t off = 0;
       if (ld) {
         size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
-        hreg[u] = from2 ? ld_chunk<T>(p.x2, row * p.x2_stride + (c0 - p.cin_split))
-                        : ld_chunk<T>(p.x, row * p.x_stride + c0);
+        off = from2 ? row * p.x2_stride + (c0 - p.cin_split) : row * p.x_stride + c0;
         hld |= 1u << u;
       }
+      hreg[u] = ld_chunk<T>(from2 ? p.x2 : p.x, off);
     }
   };
   auto stats_publish = [&]() {   // before a barrier that precedes halo_store
@@ -259,8 +269,9 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
         unsigned hd = (hv * p.mHW) >> 20;
         unsigned r2 = hv - hd * hHW;
         unsigned hh = (r2 * p.mW) >> 20;
-        u32x4 w = hreg[u];
-        if (p.in_stats && ((hld >> u) & 1u)) {
+        const bool loaded = (hld >> u) & 1u;
+        u32x4 w = loaded ? hreg[u] : u32x4{0u, 0u, 0u, 0u};
+        if (p.in_stats && loaded) {
           float f[CPC];
           Elem<T>::unpack(w, f);
 #pragma unroll
@@ -395,7 +406,10 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
       // ---- stage end -------------------------------------------------------------------------------------------
       const bool tile_done = last_plane && q == q_hi - 1;
       if (last_plane && unit + 1 < n_units) stats_publish();
-      wait_vm0();        // this wave's LDS-DMA (next stage's weights) has landed
+      // this wave's LDS-DMA (next stage's weights) has landed; the halo prefetch issued in this stage (kd == 0)
+      // keeps flying through the following stages
+      if (kd == 0 && !last_plane && unit + 1 < n_units) wait_vm_halo();
+      else wait_vm0();
       __syncthreads();   // every wave is done with this stage's A/B reads
       if (tile_done) {
         // ---- epilogue: each wave transposes its own 32x32 accumulator tiles through a private 4 KiB LDS
