@@ -177,3 +177,78 @@ def test_sliding_window_inference_and_dice(dev):
     from tests import infer_checks as ic
     ic.check_dice_exact(dev)
     ic.check_sliding_window(dev)
+
+
+# ---- ragged / non-cubic volumes and batch > 1 against the oracle evaluated on the host ------------------
+
+def _oracle_vs_engine(dev, net, oracle_forward, x, lab, w, aux=False):
+    """fp32 engine mode vs the oracle (stock torch on the CPU) on the same weights: logits, loss, gradient norms."""
+    import cbim_amd
+    from cbim_amd import functional as Fn
+    from oracle.loss_ref import ce_dice_loss
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    outs = oracle_forward(sd, x)
+    outs = outs if isinstance(outs, (list, tuple)) else [outs]
+    loss_ref = sum(ce_dice_loss(o, lab, w) for o in outs) / len(outs)
+    loss_ref.backward()
+    cbim_amd.set_compute_dtype("fp32")
+    try:
+        res = net(x.to(dev))
+        res = res if isinstance(res, (list, tuple)) else [res]
+        loss = sum(Fn.DiceCEFn.apply(o, lab.to(dev), w.to(dev))[2] for o in res) / len(res)
+        loss.backward()
+    finally:
+        cbim_amd.set_compute_dtype(None)
+    for o, r in zip(res, outs):
+        e = float((o.detach().cpu() - r.detach()).abs().max() / r.detach().abs().max())
+        assert e < 1e-3, e
+    assert abs(float(loss) - float(loss_ref)) < 1e-4
+    scale = max(float(v.grad.norm()) for v in sd.values() if v.grad is not None)
+    for k, p in net.named_parameters():
+        a, b = float(p.grad.double().norm()), float(sd[k].grad.double().norm())
+        assert abs(a - b) <= 2e-2 * max(b, 1e-5 * scale), (k, a, b)
+
+
+def _blocky(classes, shape, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    x_shape = (batch,) + shape
+    coarse = torch.randint(0, classes, (batch, 1) + tuple(max(1, s // 4) for s in shape[1:]), generator=g)
+    lab = torch.nn.functional.interpolate(coarse.float(), size=shape[1:], mode="nearest").long()
+    x = torch.randn(x_shape, generator=g).clamp_(-7.4, 2.2)
+    w = torch.ones(classes)
+    w[0] = 0.5
+    return x, lab, w
+
+
+def test_resunet_ragged_batch2_matches_oracle(dev):
+    from functools import partial
+    from cbim_amd.model.dim3 import UNet
+    from oracle.unet_ref import unet_forward
+    torch.manual_seed(11)
+    ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
+    net = UNet(2, 8, scale=sc, kernel_size=ks, num_classes=5, block="BasicBlock", norm="in").to(dev)
+    x, lab, w = _blocky(5, (2, 36, 52, 44), 2, 12)      # odd sizes at every pooling level, ragged 8x8x8 tiles
+    _oracle_vs_engine(dev, net, partial(unet_forward, scale=sc, kernel_size=ks, block="BasicBlock"), x, lab, w)
+
+
+def test_medformer_noncubic_batch2_matches_oracle(dev):
+    from functools import partial
+    from cbim_amd.model.dim3 import MedFormer
+    from oracle.medformer_ref import medformer_forward
+    from tests.medformer_checks import TINY
+    torch.manual_seed(13)
+    net = MedFormer(1, 4, **TINY).to(dev)
+    x, lab, w = _blocky(4, (1, 48, 32, 80), 2, 14)
+    fwd = partial(medformer_forward, map_size=TINY["map_size"], num_heads=TINY["num_heads"], fusion_heads=TINY["fusion_heads"],
+                  fusion_depth=TINY["fusion_depth"], kernel_size=TINY["kernel_size"], scale=TINY["scale"], act="relu",
+                  aux_loss=True)
+    _oracle_vs_engine(dev, net, fwd, x, lab, w)
+
+
+def test_swin_unetr_noncubic_batch2_matches_oracle(dev):
+    from cbim_amd.model.dim3 import SwinUNETR
+    from oracle.swin_unetr_ref import swin_unetr_forward
+    torch.manual_seed(15)
+    net = SwinUNETR((32, 64, 96), 2, 3, feature_size=24).to(dev)
+    x, lab, w = _blocky(3, (2, 32, 64, 96), 2, 16)
+    _oracle_vs_engine(dev, net, swin_unetr_forward, x, lab, w)
