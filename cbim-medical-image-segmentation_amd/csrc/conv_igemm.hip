@@ -135,17 +135,22 @@ __device__ __forceinline__ void wait_vm0() {
 }
 // wait for everything older than the UH halo prefetch loads issued last (vector-memory loads return in order):
 // the weight DMA of the next stage must have landed, the next tile's halo may stay in flight
-static_assert(UH == 8, "wait_vm_halo hard-codes UH");
-__device__ __forceinline__ void wait_vm_halo() {
+template <int N> __device__ __forceinline__ void wait_vm_halo() {
+  static_assert(N == 8 || N == 10, "wait_vm_halo: add the immediate");
 #ifndef CBIM_EMU
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 #endif
 }
 
 template <int MT, int NTL> struct Frags { u32x4 a[MT]; u32x4 b[NTL]; };   // one k-group of one tap
 
-template <typename T, int MT, int NTL, int ACT, bool K3>
-__global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
+// NTH = threads per workgroup: 512 (one persistent workgroup per CU) or 256 (two per CU, 4x8x8 tiles: the two
+// workgroups drift apart, so one's VALU-heavy halo/epilogue phases overlap the other's MFMA k-loop)
+template <typename T, int MT, int NTL, int ACT, bool K3, int NTH = 512>
+__global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
+  constexpr int NT = NTH, NW = NTH / 64;
+  constexpr int UH = NTH == 256 ? 10 : 8;   // halo prefetch quads per thread (6x10x10 rows x 4 slots / 256 threads)
   constexpr int CPC = Elem<T>::CPC;
   constexpr int KC = SLOTS * CPC;  // channels per chunk
   constexpr int BN = 32 * NTL;
@@ -408,7 +413,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
       if (last_plane && unit + 1 < n_units) stats_publish();
       // this wave's LDS-DMA (next stage's weights) has landed; the halo prefetch issued in this stage (kd == 0)
       // keeps flying through the following stages
-      if (kd == 0 && !last_plane && unit + 1 < n_units) wait_vm_halo();
+      if (kd == 0 && !last_plane && unit + 1 < n_units) wait_vm_halo<UH>();
       else wait_vm0();
       __syncthreads();   // every wave is done with this stage's A/B reads
       if (tile_done) {
@@ -424,7 +429,7 @@ __global__ void __launch_bounds__(NT) k_conv_igemm(IgemmParams p) {
         const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
         // scratch: the stage buffer just consumed (NTL=2: 36 KiB) or a dedicated region (NTL=1), so the
         // next halo can be written while other waves are still in their epilogue
-        float* scr = (float*)(smem + ((NTL == 1 || stage_bytes < NW * 4096u) ? scr_base : b_base + (unsigned)(stage & 1) * stage_bytes) +
+        float* scr = (float*)(smem + (((NTL == 1 && NTH == 512) || stage_bytes < NW * 4096u) ? scr_base : b_base + (unsigned)(stage & 1) * stage_bytes) +
                               (unsigned)wave * 4096);
         float* red = (float*)(smem + red_base);
         const int cc = lane % OCH;
@@ -691,7 +696,7 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
   }
 }
 
-struct TileCfg { int MT, NTL, tD, tH, lgH; };
+struct TileCfg { int MT, NTL, tD, tH, lgH, nth; };
 
 static TileCfg pick_cfg(const cbim_conv_desc* d) {
   TileCfg c;
@@ -701,6 +706,14 @@ static TileCfg pick_cfg(const cbim_conv_desc* d) {
   c.MT = (S >= 262144 && d->Do >= 8 && d->Ho >= 8) ? 2 : 1;
   c.tH = 8; c.lgH = 3;
   c.tD = c.MT == 2 ? 8 : 4;
+  c.nth = 512;
+  // two 256-thread workgroups per CU on 4x8x8 tiles (phase overlap): 3x3x3, Cout <= 32 layers at full resolution
+  static const int half_on = getenv("CBIM_IGEMM_HALF") ? atoi(getenv("CBIM_IGEMM_HALF")) : 0;
+  if (half_on && c.MT == 2 && c.NTL == 1 && d->dtype == CBIM_BF16 && d->kD == 3 && d->kH == 3 && d->kW == 3 &&
+      d->act == CBIM_ACT_RELU) {
+    c.nth = 256;
+    c.tD = 4;
+  }
   return c;
 }
 
@@ -811,18 +824,18 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   return ((d->Do + c.tD - 1) / c.tD) * ((d->Ho + c.tH - 1) / c.tH) * ((d->Wo + 7) / 8);
 }
 
-template <typename T, int MT, int NTL, int ACT, bool K3>
+template <typename T, int MT, int NTL, int ACT, bool K3, int NTH = 512>
 static int launch_igemm(const IgemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
 #ifndef CBIM_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_igemm<T, MT, NTL, ACT, K3>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_igemm<T, MT, NTL, ACT, K3, NTH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
 #endif
-  CBIM_LAUNCH((k_conv_igemm<T, MT, NTL, ACT, K3>), grid, dim3(NT), smem, st, p);
+  CBIM_LAUNCH((k_conv_igemm<T, MT, NTL, ACT, K3, NTH>), grid, dim3(NTH), smem, st, p);
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv igemm launch: %s", hipGetErrorString(e));
   return CBIM_OK;
@@ -830,6 +843,11 @@ static int launch_igemm(const IgemmParams& p, dim3 grid, size_t smem, hipStream_
 
 template <typename T, int ACT, bool K3>
 static int dispatch_tiles(const TileCfg& c, const IgemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
+  if (c.nth == 256) {
+    if constexpr (ACT == CBIM_ACT_RELU && K3 && sizeof(typename Elem<T>::type) == 2)
+      return launch_igemm<T, 2, 1, ACT, K3, 256>(p, grid, smem, st);
+    CBIM_CHECK(false, CBIM_EUNSUPPORTED, "256-thread igemm variant not instantiated for this configuration");
+  }
   if (c.MT == 2 && c.NTL == 1) return launch_igemm<T, 2, 1, ACT, K3>(p, grid, smem, st);
   if (c.MT == 2 && c.NTL == 2) return launch_igemm<T, 2, 2, ACT, K3>(p, grid, smem, st);
   if (c.MT == 1 && c.NTL == 1) return launch_igemm<T, 1, 1, ACT, K3>(p, grid, smem, st);
@@ -875,7 +893,8 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   p.tD = c.tD; p.tH = c.tH; p.lgH = c.lgH;
   p.tiles_d = (d->Do + c.tD - 1) / c.tD; p.tiles_h = (d->Ho + c.tH - 1) / c.tH; p.tiles_w = (d->Wo + 7) / 8;
   p.hD = c.tD + d->kD - 1; p.hH = c.tH + d->kH - 1; p.hW = 8 + d->kW - 1;
-  CBIM_CHECK(p.hD * p.hH * p.hW * SLOTS <= UH * NT, CBIM_EUNSUPPORTED, "halo of %d rows too large", p.hD * p.hH * p.hW);
+  const int nw = c.nth / 64, uh = c.nth == 256 ? 10 : UH;
+  CBIM_CHECK(p.hD * p.hH * p.hW * SLOTS <= uh * c.nth, CBIM_EUNSUPPORTED, "halo of %d rows too large", p.hD * p.hH * p.hW);
   p.mHW = ((1u << 20) + (unsigned)(p.hH * p.hW) - 1) / (unsigned)(p.hH * p.hW);
   p.mW = ((1u << 20) + (unsigned)p.hW - 1) / (unsigned)p.hW;
   int KC = kc_of(d->dtype);
@@ -884,13 +903,13 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   { const char* e = getenv("CBIM_IGEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   int BN = 32 * c.NTL;
   size_t smem = (size_t)p.hD * p.hH * p.hW * RB + 2 * (size_t)d->kH * d->kW * KG * 2 * BN * 16 +
-                (size_t)NW * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float) +
-                ((c.NTL == 1 || (size_t)d->kH * d->kW * KG * 2 * BN * 16 < (size_t)NW * 4096) ? (size_t)NW * 4096 : 0);
+                (size_t)nw * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float) +
+                (((c.NTL == 1 && c.nth == 512) || (size_t)d->kH * d->kW * KG * 2 * BN * 16 < (size_t)nw * 4096) ? (size_t)nw * 4096 : 0);
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "conv tile needs %zu B of LDS", smem);
   int64_t n_tiles = (int64_t)d->N * p.tiles_d * p.tiles_h * p.tiles_w;
   int n_nblk = (d->Cout + BN - 1) / BN;
   // persistent grid: about one workgroup per CU (256 CUs), never more workgroups than tiles
-  int64_t G = 256 / n_nblk;
+  int64_t G = (c.nth == 256 ? 512 : 256) / n_nblk;
   if (G < 1) G = 1;
   if (G > n_tiles) G = n_tiles;
   p.ksplit = pick_ksplit(d, c);
