@@ -165,31 +165,21 @@ def main():
     if in_ch > 1:
         x = torch.cat([x] + [synthetic(1, args.classes, args.size, dev, 3000 + rank + i)[0] for i in range(in_ch - 1)], 1)
     if args.aug:
-        # source volume with the dataset's affine padding (dataset_amos_ct.py:105-165: affine_pad_size 40)
-        src_x, src_lab = synthetic(1, args.classes, args.size + 40, dev, 2023 + rank)
-        src_lab = src_lab.to(torch.int8)
+        # HBM-resident source volumes with the dataset's affine padding (dataset_amos_ct.py:105-165: affine_pad_size 40),
+        # samples built by the HIP augmentation kernels on a side stream, one sample ahead of the training step
+        import argparse as _ap
         import numpy as np
+        from cbim_amd.training.dataset.resident import DevicePrefetcher, ResidentVolumeDataset
         np.random.seed(2023 + rank)
+        vols = [synthetic(1, args.classes, args.size + 40, dev, 2023 + 10 * rank + i) for i in range(4)]
+        ds = ResidentVolumeDataset([v[0][0] for v in vols], [v[1][0].to(torch.int8) for v in vols],
+                                   _ap.Namespace(training_size=[args.size] * 3, affine_pad_size=[40] * 3, scale=[0.3] * 3,
+                                                 rotate=[30] * 3, translate=[0] * 3))
+        feeder = DevicePrefetcher(ds)
         use_graph = False   # the pipeline draws host-side random parameters every step
 
     def draw():
-        """dataset_amos_ct.py:130-153 on the device: affine (scale 0.3, rotate 30) + centre crop, then each
-        intensity op with probability 0.2."""
-        xi, li = aug.random_affine_center_crop_3d(src_x, src_lab, (args.size,) * 3, scale=[0.3] * 3, rotate=[30] * 3,
-                                                   translate=[0] * 3)
-        if np.random.random() < 0.2:
-            xi = aug.brightness_multiply(xi, multiply_range=[0.7, 1.3])
-        if np.random.random() < 0.2:
-            xi = aug.brightness_additive(xi, std=0.1)
-        if np.random.random() < 0.2:
-            xi = aug.gamma(xi, gamma_range=[0.7, 1.5])
-        if np.random.random() < 0.2:
-            xi = aug.contrast(xi, contrast_range=[0.7, 1.3])
-        if np.random.random() < 0.2:
-            xi = aug.gaussian_blur(xi, sigma_range=[0.5, 1.0])
-        if np.random.random() < 0.2:
-            xi = aug.gaussian_noise(xi, std=0.02)
-        return xi, li.long()
+        return feeder.next()
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -254,7 +244,7 @@ def main():
                                 "swin_unetr": "SwinUNETR (feature 48, 4-modality BraTS-style input)",
                                 "resunet": "3D UNet ResBasicBlock (amos_ct/resunet_3d.yaml)"}[args.model]
                                + f", 1x{in_ch}x{args.size}^3 per GPU, {args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
-                               + (", on-device augmentation (affine+crop+intensity) per step" if args.aug else "")
+                               + (", HBM-resident volumes + on-device augmentation (crop/affine/intensity, dataset_amos_ct recipe) prefetched on a side stream" if args.aug else "")
                                + (" (hipGraph replay)" if use_graph else "")
                                + (", bucketed grad all-reduce (RCCL)" if world > 1 else ""),
                    "global_batch": world, "parallelism": f"dp{world}", "final_loss": loss_val},

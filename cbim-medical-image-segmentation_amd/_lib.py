@@ -115,6 +115,12 @@ def lib():
             raise RuntimeError(
                 f"cbim_amd: HIP kernel library not found at {path}; build it with "
                 f"`python -c 'import __graft_entry__ as g; g.build()'` (there is no fallback path)")
+        # PyTorch's ROCm wheel bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).
+        # libcbim_hip.so must bind to THAT instance — device pointers and streams are torch's — which the dynamic
+        # loader does by SONAME only if torch's libraries are already mapped.  Loaded the other way round, this
+        # library pulls /opt/rocm's runtime as a second instance and every launch fails with
+        # "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         h = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             try:

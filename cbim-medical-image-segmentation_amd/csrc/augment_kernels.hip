@@ -296,3 +296,5 @@ extern "C" int cbim_gaussian_blur3d(const float* x, float* y, float* tmp, int C,
   CBIM_LAUNCH(k_blur_axis, dim3(grid_for(total)), dim3(NT), 0, st, p);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
+
+CBIM_DEFINE_WARM(augment)

@@ -13,7 +13,7 @@
 #include <utility>
 // Launches go through hipLaunchKernel so that the status checked afterwards is the return code of
 // THIS launch (hipGetLastError() is a sticky per-thread value that unrelated runtime calls of the host
-// process can leave set — seen as a spurious "no ROCm-capable device is detected").
+// process can leave set).
 namespace cbim {
 inline thread_local hipError_t g_launch_err = hipSuccess;
 template <typename... P, size_t... I>
@@ -200,3 +200,29 @@ void cbim_set_error(const char* fmt, ...);
       return (code);                           \
     }                                          \
   } while (0)
+
+// ---- per-code-object warm-up ------------------------------------------------------------------------------
+// Every .hip file is its own code object, loaded lazily at its first launch.  CBIM_DEFINE_WARM(tag) gives the
+// file a no-op kernel and `int cbim_warm_<tag>(void* stream)`, which launches it (re-selecting the device and
+// retrying if that first launch fails); cbim_runtime_warmup() runs all of them once, so module loading is not
+// paid inside a timed or captured region and a broken runtime binding (e.g. this library bound to a second HIP
+// runtime instance, see _lib.py) is reported at start-up with the failing code object named.
+#ifdef CBIM_EMU
+#define CBIM_DEFINE_WARM(tag) extern "C" int cbim_warm_##tag(void*) { return 0; }
+#else
+#define CBIM_DEFINE_WARM(tag)                                                                           \
+  namespace cbim { __global__ void k_warm_##tag() {} }                                                  \
+  extern "C" int cbim_warm_##tag(void* stream) {                                                        \
+    for (int attempt = 0; attempt < 4; ++attempt) {                                                     \
+      cbim::launch(cbim::k_warm_##tag, dim3(1), dim3(64), 0, (hipStream_t)stream);                      \
+      if (cbim::g_launch_err == hipSuccess) return CBIM_OK;                                             \
+      int n = 0, d = 0;                                                                                 \
+      (void)hipGetDeviceCount(&n);                                                                      \
+      (void)hipGetDevice(&d);                                                                           \
+      (void)hipSetDevice(d);                                                                            \
+      (void)hipFree(nullptr);                                                                           \
+    }                                                                                                   \
+    cbim_set_error("first launch from code object '" #tag "': %s", hipGetErrorString(cbim::g_launch_err)); \
+    return CBIM_ELAUNCH;                                                                                \
+  }
+#endif

@@ -949,3 +949,5 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   return d->dtype == CBIM_BF16 ? dispatch_act<bf16_tag>(d->act, k3, c, p, grid, smem, st)
                                : dispatch_act<float>(d->act, k3, c, p, grid, smem, st);
 }
+
+CBIM_DEFINE_WARM(igemm)

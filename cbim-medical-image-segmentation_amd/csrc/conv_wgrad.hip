@@ -407,3 +407,5 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
               d->N * c.strips_per_n, taps, d->Cout, d->Cin, p.Cout_pad, p.Cin_pad, total);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
+
+CBIM_DEFINE_WARM(wgrad)

@@ -127,3 +127,5 @@ extern "C" int cbim_dice_counts(const void* pred, int pred_bytes, const void* ta
     CBIM_LAUNCH((k_dice_counts<int8_t, int8_t>), dim3(nblk), dim3(INT_), sh, st, (const int8_t*)pred, (const int8_t*)target, N, block, C, counts);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
+
+CBIM_DEFINE_WARM(inference)

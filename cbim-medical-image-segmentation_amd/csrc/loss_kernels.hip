@@ -214,3 +214,5 @@ extern "C" int cbim_dice_ce_bwd(const float* logits, const int64_t* labels, cons
               grad_out, dlogits, C, S, total);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
+
+CBIM_DEFINE_WARM(loss)

@@ -964,3 +964,5 @@ extern "C" int cbim_colsoftmax_pool_bwd(int dtype, const void* fw, int64_t fw_st
                 M);
   return launch_ok("colsoftmax_pool_bwd");
 }
+
+CBIM_DEFINE_WARM(medformer)

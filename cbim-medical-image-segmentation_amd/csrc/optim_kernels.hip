@@ -68,3 +68,5 @@ extern "C" int cbim_adamw_ema_step(const cbim_optim_tensor* tensors, const int32
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "adamw_ema_step launch: %s", hipGetErrorString(e));
   return CBIM_OK;
 }
+
+CBIM_DEFINE_WARM(optim)

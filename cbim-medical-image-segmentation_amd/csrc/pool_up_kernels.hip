@@ -395,3 +395,5 @@ extern "C" int cbim_trilinear_planes_bwd(const float* dy, float* dx, int planes,
               Ho, Wo, total);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
+
+CBIM_DEFINE_WARM(pool_up)

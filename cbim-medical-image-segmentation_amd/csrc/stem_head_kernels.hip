@@ -506,3 +506,5 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
               N * nb, Cin, K);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
+
+CBIM_DEFINE_WARM(stem_head)

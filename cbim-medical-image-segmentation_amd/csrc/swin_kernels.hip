@@ -400,3 +400,5 @@ extern "C" int cbim_window_attn3d_bwd(int dtype, const void* qkv, const float* q
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "window_attn3d reduce launch: %s", hipGetErrorString(e));
   return CBIM_OK;
 }
+
+CBIM_DEFINE_WARM(swin)

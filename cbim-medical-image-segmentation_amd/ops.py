@@ -69,7 +69,7 @@ def _stream(t: torch.Tensor):
     if t.device.type == "cuda":
         s = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
         if not _WARM and not torch.cuda.is_current_stream_capturing():
-            _lib.lib().cbim_runtime_warmup(s)
+            check(_lib.lib().cbim_runtime_warmup(s), "runtime_warmup")
             _WARM = True
         return s
     return None

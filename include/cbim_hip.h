@@ -45,7 +45,8 @@ extern "C" {
 int cbim_version(void);
 const char* cbim_backend(void);            /* "hip-gfx950" (product) or "emu" (tests/emu) */
 const char* cbim_last_error_string(void);
-/* One no-op launch (lazy module load) + clears the runtime's sticky error; call once per process. */
+/* One no-op launch from every code object of the library (they load lazily), with a device re-select + retry
+ * if a first launch fails; call once per process before the first real launch. */
 int cbim_runtime_warmup(void* stream);
 
 /* ------------------------------------------------------------------------------------------

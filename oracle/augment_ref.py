@@ -112,3 +112,33 @@ def crop_3d(img, lab, crop_size, mode):                              # :320-343
         z, y, x = dD // 2, dH // 2, dW // 2
     sl = (slice(None), slice(None), slice(z, z + crop_size[0]), slice(y, y + crop_size[1]), slice(x, x + crop_size[2]))
     return img[sl].contiguous(), lab[sl].contiguous()
+
+
+def amos_train_sample(img, lab, training_size, affine_pad_size, scale, rotate, translate):
+    """AMOSDataset.__getitem__, train mode (/root/reference/training/dataset/dim3/dataset_amos_ct.py:105-165) on one
+    volume: img float [C,D,H,W], lab int8 [1,D,H,W]; random draws in the reference's order."""
+    import numpy as np
+    x, y = img.unsqueeze(0), lab.unsqueeze(0)
+    _, _, d, h, w = x.shape
+    if np.random.random() < 0.5:                                                                  # :124
+        crop_size = [min(i + j, k) for i, j, k in zip(training_size, affine_pad_size, [d, h, w])]
+        x, y = crop_3d(x, y, crop_size, mode="random")
+        x, y = random_scale_rotate_translate_3d(x, y, scale, rotate, translate)
+        x, y = crop_3d(x, y, training_size, mode="center")
+    else:
+        x, y = crop_3d(x, y, training_size, mode="random")
+    x, y = x.contiguous(), y.contiguous()
+    if np.random.random() < 0.2:
+        x = brightness_multiply(x, multiply_range=[0.7, 1.3])
+    if np.random.random() < 0.2:
+        x = brightness_additive(x, std=0.1)
+    if np.random.random() < 0.2:
+        x = gamma(x, gamma_range=[0.7, 1.5])
+    if np.random.random() < 0.2:
+        x = contrast(x, contrast_range=[0.7, 1.3])
+    if np.random.random() < 0.2:
+        x = gaussian_blur(x, sigma_range=[0.5, 1.5])
+    if np.random.random() < 0.2:
+        std = np.random.random() * 0.1
+        x = gaussian_noise(x, std=std)
+    return x.squeeze(0), y.squeeze(0)

@@ -59,3 +59,34 @@ def fused_crop(dev):
     oi, ol = _seeded(lambda: A.random_scale_rotate_translate_3d(img, lab, [0.3] * 3, [30] * 3, [0] * 3))
     ci, cl = A.crop_3d(oi, ol, [12, 16, 20], mode="center")
     assert torch.equal(fi, ci) and torch.equal(fl, cl)
+
+
+def resident_pipeline(dev, seeds=(1, 2, 3, 5, 8, 13, 21, 34)):
+    """ResidentVolumeDataset.__getitem__ (HBM-resident volumes, HIP kernels) against the oracle's restatement of
+    dataset_amos_ct.py:105-165 under the same numpy/torch seeds; the seeds cover both crop branches and every
+    intensity op."""
+    import argparse
+    from cbim_amd.training.dataset.resident import DevicePrefetcher, ResidentVolumeDataset
+    from oracle import augment_ref as R
+    g = load_golden("aug_1x1x20x24x28")
+    img = torch.from_numpy(g["img"])[0]            # [1,20,24,28]
+    lab = torch.from_numpy(g["lab"])[0].to(torch.int8)
+    args = argparse.Namespace(training_size=[12, 16, 16], affine_pad_size=[6, 6, 8], scale=[0.3] * 3, rotate=[30] * 3,
+                              translate=[0] * 3)
+    ds = ResidentVolumeDataset([img.to(dev)], [lab.to(dev)], args)
+    branches = set()
+    for seed in seeds:
+        np.random.seed(seed); torch.manual_seed(seed)
+        xi, yi = ds[0]
+        np.random.seed(seed); torch.manual_seed(seed)
+        branches.add(np.random.random() < 0.5)
+        np.random.seed(seed); torch.manual_seed(seed)
+        xr, yr = R.amos_train_sample(img, lab, args.training_size, args.affine_pad_size, args.scale, args.rotate, args.translate)
+        assert tuple(xi.shape) == tuple(xr.shape) and tuple(yi.shape) == tuple(yr.shape)
+        assert _rel(xi.cpu(), xr) < 5e-5, seed
+        assert float((yi.cpu().long() != yr.long()).float().mean()) < 5e-4, seed
+    assert branches == {True, False}
+    pf = DevicePrefetcher(ds)
+    np.random.seed(7); torch.manual_seed(7)
+    a, b = pf.next()
+    assert tuple(a.shape) == (1, 1, 12, 16, 16) and b.dtype == torch.int64 and tuple(b.shape) == (1, 1, 12, 16, 16)

@@ -20,3 +20,10 @@ def test_hip_augmentation_matches_reference_golden(dev):
     print(res)
     aug_checks.check(res)
     aug_checks.fused_crop(dev)
+
+
+def test_resident_dataset_pipeline_matches_oracle(dev):
+    if dev != "cpu":
+        pytest.skip("CPU suite")
+    from tests import aug_checks
+    aug_checks.resident_pipeline(dev)
