@@ -17,6 +17,12 @@
 // channel c = d*heads + h (medformer_utils.py:43-51).  Map-side tensors are float32 [N][M][inner].
 #include "cbim_common.h"
 
+#ifdef CBIM_EMU
+#define CBIM_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
+#else
+#define CBIM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 namespace cbim {
 
 static constexpr int NT = 256;
@@ -320,6 +326,87 @@ __global__ void __launch_bounds__(NT) k_dwconv3_wgrad(const void* __restrict__ x
         }
     }
   }
+}
+
+
+// depthwise weight gradient, 3x3x3, LDS-tiled: a workgroup stages the (transformed) input halo and the output
+// gradient of TH rows x all W of one depth slice for WG_CH channel chunks ONCE, then thread (chunk, tap)
+// accumulates its tap over the tile from LDS — every global byte is read once per tile instead of once per
+// (kd,kh) pair.  Partials [tile][C][27] are summed in tile order by k_dwconv_wgrad_reduce.
+static constexpr int WG_CH = 8;   // channel chunks per workgroup (128 bytes of bf16 / fp32 channels per voxel)
+template <typename T>
+__global__ void __launch_bounds__(NT) k_dwconv3_wgrad_lds(const void* __restrict__ x, int64_t xs,
+                                                          const float* __restrict__ in_stats, int act,
+                                                          const void* __restrict__ dy, int64_t dys,
+                                                          const float* __restrict__ dy_bias, float* __restrict__ part,
+                                                          int N, int D, int H, int W, int C, int TH) {
+  constexpr int CPC = Elem<T>::CPC;
+  CBIM_DYN_SMEM(smem);
+  const int cch = C / CPC;
+  const int g0 = blockIdx.y * WG_CH;
+  const int G = cch - g0 < WG_CH ? cch - g0 : WG_CH;
+  const int htiles = (H + TH - 1) / TH;
+  const int tile = blockIdx.x;
+  const int ht = tile % htiles, dz = (tile / htiles) % D, n = tile / (htiles * D);
+  const int h0 = ht * TH;
+  const int hW = W + 2, hH = TH + 2;
+  // LDS: x_s [3][hH][hW][WG_CH] chunks of float[CPC] ; g_s [TH][W][WG_CH]
+  float* x_s = (float*)smem;
+  float* g_s = x_s + (size_t)3 * hH * hW * WG_CH * CPC;
+  const int xitems = 3 * hH * hW * G, gitems = TH * W * G;
+  for (int i = threadIdx.x; i < xitems; i += NT) {
+    int cl = i % G, v = i / G;
+    int ww = v % hW - 1, hh = (v / hW) % hH - 1 + h0, dd = v / (hW * hH) - 1 + dz;
+    float f[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) f[j] = 0.f;
+    if (dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W) {
+      const int c0 = (g0 + cl) * CPC;
+      Elem<T>::unpack(ld_chunk<T>(x, ((((size_t)n * D + dd) * H + hh) * W + ww) * xs + c0), f);
+      if (in_stats) {
+#pragma unroll
+        for (int j = 0; j < CPC; ++j)
+          f[j] = act_fwd((f[j] - in_stats[((size_t)n * C + c0 + j) * 2]) * in_stats[((size_t)n * C + c0 + j) * 2 + 1], act);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) x_s[((size_t)v * WG_CH + cl) * CPC + j] = f[j];
+  }
+  for (int i = threadIdx.x; i < gitems; i += NT) {
+    int cl = i % G, v = i / G;
+    int ww = v % W, hh = v / W + h0;
+    float f[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) f[j] = 0.f;
+    if (hh < H) {
+      const int c0 = (g0 + cl) * CPC;
+      Elem<T>::unpack(ld_chunk<T>(dy, ((((size_t)n * D + dz) * H + hh) * W + ww) * dys + c0), f);
+      if (dy_bias) {
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) f[j] += dy_bias[(size_t)n * C + c0 + j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) g_s[((size_t)v * WG_CH + cl) * CPC + j] = f[j];
+  }
+  __syncthreads();
+  const int cl = threadIdx.x / 27, tap = threadIdx.x % 27;
+  if (cl >= G) return;
+  const int a = tap / 9, b = (tap / 3) % 3, c = tap % 3;
+  float acc[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
+  for (int r = 0; r < TH; ++r) {
+    const float* xr = x_s + ((size_t)((a * hH + r + b) * hW + c) * WG_CH + cl) * CPC;
+    const float* gr = g_s + ((size_t)(r * W) * WG_CH + cl) * CPC;
+    for (int w = 0; w < W; ++w) {
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) acc[j] += xr[(size_t)w * WG_CH * CPC + j] * gr[(size_t)w * WG_CH * CPC + j];
+    }
+  }
+  const int c0 = (g0 + cl) * CPC;
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) part[((size_t)tile * C + c0 + j) * 27 + tap] = acc[j];
 }
 
 __global__ void __launch_bounds__(NT) k_dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
@@ -794,6 +881,18 @@ extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const f
   return launch_ok("dwconv3d");
 }
 
+// LDS-tiled 3x3x3 path: rows of h per tile so that the fp32 halo + gradient tiles fit ~120 KiB
+static int dw3_lds_th(int H, int W, int cpc) {
+  const size_t per_row_x = (size_t)3 * (W + 2) * WG_CH * cpc * 4, per_row_g = (size_t)W * WG_CH * cpc * 4;
+  int th = (int)((120 * 1024 - 2 * per_row_x) / (per_row_x + per_row_g));
+  if (th > H) th = H;
+  if (th > 8) th = 8;
+  return th;   // < 1: does not fit, use the streaming kernel
+}
+static size_t dw3_lds_bytes(int W, int TH, int cpc) {
+  return ((size_t)3 * (TH + 2) * (W + 2) + (size_t)TH * W) * WG_CH * cpc * 4;
+}
+
 // kW == 3 path: rows (n,d,h) per block so that ~1024 blocks exist, at least 8 rows each
 static void dw3_wgrad_cfg(int64_t rows, int groups, int* nblk, int* rpb) {
   int64_t want = 1024 / groups > 1 ? 1024 / groups : 1;
@@ -817,6 +916,10 @@ extern "C" size_t cbim_dwconv3d_wgrad_workspace(int N, int D, int H, int W, int 
   int nb3, rpb;
   dw3_wgrad_cfg((int64_t)N * D * H, (C / 4 + DG - 1) / DG, &nb3, &rpb);   // upper bound over both dtypes
   if (nb3 > nblk) nblk = nb3;
+  if (kD == 3 && kH == 3 && kW == 3) {   // LDS-tiled path: one partial slab per (n, d, h-tile), TH >= 1
+    int64_t tiles = (int64_t)N * D * H;
+    if (tiles > nblk) nblk = (int)tiles;
+  }
   return (size_t)nblk * C * kD * kH * kW * sizeof(float);
 }
 
@@ -833,7 +936,29 @@ extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, c
   dw_wgrad_cfg((int64_t)N * D * H * W, &nblk, &vpb);
   int TT = kD * kH * kW, G = NT / TT, cch = C / cpc;
   hipStream_t st = (hipStream_t)stream;
-  if (kW == 3 && kD <= 3 && kH <= 3) {
+  const int th_lds = (kD == 3 && kH == 3 && kW == 3) ? dw3_lds_th(H, W, cpc) : 0;
+  if (th_lds >= 1) {
+    const int htiles = (H + th_lds - 1) / th_lds;
+    nblk = N * D * htiles;
+    const size_t smem = dw3_lds_bytes(W, th_lds, cpc);
+    dim3 grid(nblk, (cch + WG_CH - 1) / WG_CH);
+#ifndef CBIM_EMU
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[dtype == CBIM_BF16]) {
+      hipError_t e = dtype == CBIM_BF16
+                         ? hipFuncSetAttribute((const void*)k_dwconv3_wgrad_lds<bf16_tag>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                         : hipFuncSetAttribute((const void*)k_dwconv3_wgrad_lds<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr_done[dtype == CBIM_BF16] = true;
+    }
+#endif
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_dwconv3_wgrad_lds<bf16_tag>), grid, dim3(NT), smem, st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias,
+                  (float*)workspace, N, D, H, W, C, th_lds);
+    else
+      CBIM_LAUNCH((k_dwconv3_wgrad_lds<float>), grid, dim3(NT), smem, st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias,
+                  (float*)workspace, N, D, H, W, C, th_lds);
+  } else if (kW == 3 && kD <= 3 && kH <= 3) {
     int groups = (cch + DG - 1) / DG, rpb;
     dw3_wgrad_cfg((int64_t)N * D * H, groups, &nblk, &rpb);
     DISPATCH_T(dtype, k_dwconv3_wgrad, dim3(nblk, groups), st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias,
