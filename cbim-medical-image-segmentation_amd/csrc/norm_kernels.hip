@@ -481,8 +481,10 @@ extern "C" int cbim_runtime_warmup(void* stream) {
 }
 
 extern "C" int cbim_stats_parts(int64_t S, int C) {
-  (void)C;
-  int64_t p = (S + 255) / 256;
+  // one workgroup per part: >= 64 voxels each, up to 1024 parts (low-resolution layers would otherwise launch
+  // a few dozen workgroups on 256 CUs); wide tensors (few voxel lanes per workgroup) keep parts larger
+  int64_t per = C >= 1024 ? 256 : 64;
+  int64_t p = (S + per - 1) / per;
   if (p < 1) p = 1;
   if (p > 1024) p = 1024;
   return (int)p;
