@@ -146,6 +146,9 @@ def test_data_parallel_training_steps_match_single_process():
         opt.step()
     for a, b, p in zip(got[0], got[1], net.parameters()):
         assert (a == b).all()                                                    # replicas stay bit-identical
-        # Adam normalises by sqrt(v): where a gradient is ~0 its fp32 summation order (2 ranks vs 1 process) moves the
-        # update by a sizeable fraction of lr; 3 steps at lr 1e-2
-        assert torch.allclose(torch.from_numpy(a), p.detach(), rtol=2e-3, atol=3e-3)
+        # Adam's first steps move every weight by ~lr*sign(g): where a gradient is ~0 its fp32 summation order
+        # (2 ranks vs 1 process) can flip the sign, so a few elements differ by up to 2*lr per step — everything
+        # else must agree closely
+        d = (torch.from_numpy(a) - p.detach()).abs()
+        assert float(d.max()) <= 3 * 2 * 1e-2 + 1e-6
+        assert float((d > 1e-3).float().mean()) < 0.02
