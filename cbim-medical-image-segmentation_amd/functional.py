@@ -500,3 +500,20 @@ class DepthToSpaceFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return ops.space_to_depth(dy.contiguous(), ctx.scale), None
+
+
+class NormActFn(torch.autograd.Function):
+    """y = act(IN(z)) with given statistics (post-activation ConvNormAct tail, conv_layers.py:51)."""
+
+    @staticmethod
+    def forward(ctx, z, stats, act):
+        ctx.save_for_backward(z, stats)
+        ctx.act = act
+        return ops.norm_act_fwd(z, stats, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        sums = ops.norm_bwd_sums(dy, z, stats, ctx.act, masked=True)
+        return ops.norm_bwd_apply(dy, z, stats, sums, ctx.act, masked=True), None, None

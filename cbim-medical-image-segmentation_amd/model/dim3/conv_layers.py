@@ -50,6 +50,12 @@ class SingleConv(nn.Module):
         y = Fn.SingleConvFn.apply(f.t, self.conv.conv.weight, self.conv.act_code, need_dx)
         return Fn.FMap(y, None)
 
+    def forward_input(self, x, dtype) -> Fn.FMap:
+        """First layer of a network: x is the NCDHW fp32 input (any channel count <= 16)."""
+        z = Fn.StemFn.apply(x, self.conv.conv.weight, dtype)
+        zs = Fn.ensure_stats(Fn.FMap(z, None)).stats
+        return Fn.FMap(Fn.NormActFn.apply(z, zs, self.conv.act_code), None)
+
 
 class BasicBlock(nn.Module):
     """conv2(conv1(x)) + shortcut(x), every ConvNormAct pre-activated — conv_layers.py:71-94."""
@@ -63,6 +69,22 @@ class BasicBlock(nn.Module):
         self.shortcut = nn.Sequential()
         if in_ch != out_ch:   # a FULL k-sized pre-act ConvNormAct, not 1x1 (conv_layers.py:83-84)
             self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=True)
+
+    def forward_input(self, x, dtype, want_out_stats=True) -> Fn.FMap:
+        """First layer of a network (UNet++ conv0_0): x is the NCDHW fp32 input.  The pre-activation
+        act(IN(x)) of the in_ch-channel input (2 M values at 128^3) is two torch elementwise ops; conv1 and the
+        shortcut conv read it through the stem kernel."""
+        import torch.nn.functional as F
+        if not isinstance(self.shortcut, ConvNormAct):
+            raise NotImplementedError("cbim_amd: identity-shortcut BasicBlock on the raw network input is not built")
+        if self.conv1.act_code != ACT["relu"]:
+            raise NotImplementedError("cbim_amd: first-layer BasicBlock supports ReLU")
+        a = F.relu(F.instance_norm(x.float(), eps=IN_EPS))
+        y1 = Fn.StemFn.apply(a, self.conv1.conv.weight, dtype)
+        s1 = Fn.ensure_stats(Fn.FMap(y1, None)).stats
+        sc = Fn.StemFn.apply(a, self.shortcut.conv.weight, dtype)
+        out, so = Fn.NormConvFn.apply(y1, s1, self.conv2.conv.weight, self.conv1.act_code, sc, want_out_stats, None, IN_EPS)
+        return Fn.FMap(out, so if want_out_stats else None)
 
     def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
         f = Fn.ensure_stats(f)

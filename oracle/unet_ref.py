@@ -188,3 +188,36 @@ def state_dict_checksum(sd) -> float:
         w = torch.arange(1, v.numel() + 1, dtype=torch.float64) / v.numel()
         acc += (i + 1) * float((v * w).sum())
     return acc
+
+
+def unetpp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size, block="BasicBlock") -> torch.Tensor:
+    """UNetPlusPlus.forward (/root/reference/model/dim3/unetpp.py:52-76); layers are nn.Sequential of two blocks
+    (make_layer :79-88), pooling nn.MaxPool3d(scale[i]), upsampling nn.Upsample(scale_factor, trilinear,
+    align_corners=True)."""
+    blk = _BLOCKS[block]
+    ks = [_k3(k) for k in kernel_size]
+    sc = [tuple(_k3(s)) for s in scale]
+
+    def layer(name, t, lvl):
+        t = blk(sd, f"{name}.0.", t, ks[lvl])
+        return blk(sd, f"{name}.1.", t, ks[lvl])
+
+    def up(t, i):
+        return F.interpolate(t, scale_factor=tuple(float(v) for v in sc[i]), mode="trilinear", align_corners=True)
+
+    x0_0 = layer("conv0_0", x, 0)
+    x1_0 = layer("conv1_0", F.max_pool3d(x0_0, sc[0]), 1)
+    x0_1 = layer("conv0_1", torch.cat([x0_0, up(x1_0, 0)], 1), 0)
+    x2_0 = layer("conv2_0", F.max_pool3d(x1_0, sc[1]), 2)
+    x1_1 = layer("conv1_1", torch.cat([x1_0, up(x2_0, 1)], 1), 1)
+    x0_2 = layer("conv0_2", torch.cat([x0_0, x0_1, up(x1_1, 0)], 1), 0)
+    x3_0 = layer("conv3_0", F.max_pool3d(x2_0, sc[2]), 3)
+    x2_1 = layer("conv2_1", torch.cat([x2_0, up(x3_0, 2)], 1), 2)
+    x1_2 = layer("conv1_2", torch.cat([x1_0, x1_1, up(x2_1, 1)], 1), 1)
+    x0_3 = layer("conv0_3", torch.cat([x0_0, x0_1, x0_2, up(x1_2, 0)], 1), 0)
+    x4_0 = layer("conv4_0", F.max_pool3d(x3_0, sc[3]), 4)
+    x3_1 = layer("conv3_1", torch.cat([x3_0, up(x4_0, 3)], 1), 3)
+    x2_2 = layer("conv2_2", torch.cat([x2_0, x2_1, up(x3_1, 2)], 1), 2)
+    x1_3 = layer("conv1_3", torch.cat([x1_0, x1_1, x1_2, up(x2_2, 1)], 1), 1)
+    x0_4 = layer("conv0_4", torch.cat([x0_0, x0_1, x0_2, x0_3, up(x1_3, 0)], 1), 0)
+    return F.conv3d(x0_4, sd["output.weight"], sd["output.bias"])

@@ -252,3 +252,10 @@ def test_swin_unetr_noncubic_batch2_matches_oracle(dev):
     net = SwinUNETR((32, 64, 96), 2, 3, feature_size=24).to(dev)
     x, lab, w = _blocky(3, (2, 32, 64, 96), 2, 16)
     _oracle_vs_engine(dev, net, swin_unetr_forward, x, lab, w)
+
+
+def test_unetpp_matches_reference_golden(dev):
+    from tests.unetpp_checks import assert_fp32, run
+    print(assert_fp32(dev))
+    r = run(dev, "bf16")
+    assert r["logits_err"] < 0.25 and r["ce_err"] < 0.05 and r["dice_err"] < 0.02, r

