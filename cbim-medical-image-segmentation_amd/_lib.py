@@ -91,6 +91,8 @@ _SIGS = {
     "cbim_softmax_accumulate": (i32, [vp, vp, vp] + [i32] * 11 + [vp]),
     "cbim_prob_finalize": (i32, [vp, vp, vp, i32, i32, i64, vp]),
     "cbim_dice_counts": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp]),
+    "cbim_gate_fwd": (i32, [i32, vp, vp, vp, i64, i32, vp]),
+    "cbim_gate_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, vp]),
     "cbim_ncdhw_to_ndhwc": (i32, [i32, vp, vp, i32, i32, i64, vp]),
     "cbim_ndhwc_to_ncdhw": (i32, [i32, vp, vp, i32, i32, i64, vp]),
 }

@@ -396,4 +396,60 @@ extern "C" int cbim_trilinear_planes_bwd(const float* dy, float* dx, int planes,
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
+// ---- attention gate: y = x * psi (AttentionBlock.forward's `x * psi`, /root/reference/model/dim3/
+// attention_unet_utils.py:35; psi is one value per voxel) ---------------------------------------------------
+namespace cbim {
+template <typename T>
+__global__ void __launch_bounds__(NT) k_gate_fwd(const void* __restrict__ x, const float* __restrict__ psi,
+                                                 void* __restrict__ y, int C, int64_t total) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int64_t row = i / cch;
+    float f[CPC];
+    Elem<T>::unpack(ld_chunk<T>(x, (size_t)i * CPC), f);
+    const float s = psi[row];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) f[j] *= s;
+    st_chunk<T>(y, (size_t)i * CPC, Elem<T>::pack(f));
+  }
+}
+// dx = dy * psi; dpsi[row] = sum_c dy[row,c] * x[row,c]   (one thread per voxel row)
+template <typename T>
+__global__ void __launch_bounds__(NT) k_gate_bwd(const void* __restrict__ dy, const void* __restrict__ x,
+                                                 const float* __restrict__ psi, void* __restrict__ dx,
+                                                 float* __restrict__ dpsi, int C, int64_t rows) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int cch = C / CPC;
+  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * NT) {
+    const float s = psi[r];
+    float acc = 0.f;
+    for (int cc = 0; cc < cch; ++cc) {
+      float g[CPC], f[CPC];
+      Elem<T>::unpack(ld_chunk<T>(dy, ((size_t)r * cch + cc) * CPC), g);
+      Elem<T>::unpack(ld_chunk<T>(x, ((size_t)r * cch + cc) * CPC), f);
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) { acc += g[j] * f[j]; g[j] *= s; }
+      st_chunk<T>(dx, ((size_t)r * cch + cc) * CPC, Elem<T>::pack(g));
+    }
+    dpsi[r] = acc;
+  }
+}
+}  // namespace cbim
+
+extern "C" int cbim_gate_fwd(int dtype, const void* x, const float* psi, void* y, int64_t rows, int C, void* stream) {
+  if (int e = check_c(dtype, C, "gate")) return e;
+  int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  int64_t total = rows * (C / cpc);
+  DISPATCH_T(dtype, k_gate_fwd, dim3(grid_for(total)), (hipStream_t)stream, x, psi, y, C, total);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_gate_bwd(int dtype, const void* dy, const void* x, const float* psi, void* dx, float* dpsi,
+                             int64_t rows, int C, void* stream) {
+  if (int e = check_c(dtype, C, "gate")) return e;
+  DISPATCH_T(dtype, k_gate_bwd, dim3(grid_for(rows)), (hipStream_t)stream, dy, x, psi, dx, dpsi, C, rows);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
 CBIM_DEFINE_WARM(pool_up)

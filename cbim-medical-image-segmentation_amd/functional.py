@@ -517,3 +517,18 @@ class NormActFn(torch.autograd.Function):
         dy = dy.contiguous()
         sums = ops.norm_bwd_sums(dy, z, stats, ctx.act, masked=True)
         return ops.norm_bwd_apply(dy, z, stats, sums, ctx.act, masked=True), None, None
+
+
+class GateFn(torch.autograd.Function):
+    """x * psi with one psi per voxel (AttentionBlock.forward, attention_unet_utils.py:35)."""
+
+    @staticmethod
+    def forward(ctx, x, psi):
+        psi = psi.contiguous().float()
+        ctx.save_for_backward(x, psi)
+        return ops.gate_fwd(x, psi)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, psi = ctx.saved_tensors
+        return ops.gate_bwd(dy.contiguous(), x, psi)

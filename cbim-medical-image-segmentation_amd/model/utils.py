@@ -18,6 +18,10 @@ def get_model(args, pretrain=False):
         from .dim3 import UNetPlusPlus
         return UNetPlusPlus(args.in_chan, args.base_chan, num_classes=args.classes, scale=args.down_scale,
                             norm=args.norm, kernel_size=args.kernel_size, block=args.block)
+    if args.model == "attention_unet":   # model/utils.py:88-90 of the reference
+        from .dim3 import AttentionUNet
+        return AttentionUNet(args.in_chan, args.base_chan, num_classes=args.classes, scale=args.down_scale,
+                             norm=args.norm, kernel_size=args.kernel_size, block=args.block)
     if args.model == "medformer":   # model/utils.py:92-95 of the reference
         from .dim3 import MedFormer
         return MedFormer(args.in_chan, args.classes, args.base_chan, map_size=args.map_size,

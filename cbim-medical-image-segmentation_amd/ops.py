@@ -601,3 +601,21 @@ def resnorm_bwd(dy, a, stats_a, b, stats_b, act: int, need_db: bool = True):
     check(L.cbim_resnorm_bwd_apply(_dt(a), _p(dy), _rs(dy), _p(a), _rs(a), _p(stats_a), _p(ma), _p(b), _rs(b), _p(stats_b),
                                    _p(mb), _p(da), _p(db), N, S, Cc, act, _stream(a)), "resnorm_bwd_apply")
     return da, db
+
+
+def gate_fwd(x, psi):
+    """y = x * psi; x [N,D,H,W,C], psi float32 [N,D,H,W] (one value per voxel)."""
+    _dev_ok(x, psi)
+    rows, Cc = x.numel() // int(x.shape[-1]), int(x.shape[-1])
+    y = torch.empty_like(x)
+    check(_lib.lib().cbim_gate_fwd(_dt(x), _p(x), _p(psi), _p(y), rows, Cc, _stream(x)), "gate_fwd")
+    return y
+
+
+def gate_bwd(dy, x, psi):
+    _dev_ok(dy, x, psi)
+    rows, Cc = x.numel() // int(x.shape[-1]), int(x.shape[-1])
+    dx = torch.empty_like(x)
+    dpsi = torch.empty(tuple(psi.shape), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cbim_gate_bwd(_dt(x), _p(dy), _p(x), _p(psi), _p(dx), _p(dpsi), rows, Cc, _stream(x)), "gate_bwd")
+    return dx, dpsi

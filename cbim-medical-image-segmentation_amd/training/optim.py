@@ -41,6 +41,10 @@ class FusedAdamW(torch.optim.Optimizer):
             if len(self._ema_params) != len(list(self.param_groups[0]["params"])):
                 raise ValueError("ema_model must have the same parameters as the optimised model")
             self._ema_params = [e for e, p in zip(self._ema_params, self.param_groups[0]["params"]) if p.requires_grad]
+            self._ema_all = list(self._ema_params)
+            self._ema_active = list(self._ema_params)
+        self._all_params = list(self._params)
+        self._active = None
         self._table = None
         self._ptrs = None
         self._hyper = None
@@ -89,7 +93,7 @@ class FusedAdamW(torch.optim.Optimizer):
         recs = (_Rec * len(self._params)).from_address(host.data_ptr())
         for i, p in enumerate(self._params):
             st = self.state[p]
-            e = self._ema_params[i] if self._ema_params is not None else None
+            e = self._ema_active[i] if self._ema_params is not None else None
             g = p.grad
             if g.dtype != torch.float32 or not g.is_contiguous() or not p.is_contiguous():
                 raise RuntimeError("cbim_amd: FusedAdamW needs contiguous fp32 parameters and gradients")
@@ -104,8 +108,20 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if any(p.grad is None for p in self._params):
-            raise RuntimeError("cbim_amd: FusedAdamW.step(): a parameter has no gradient (unused parameters are not supported)")
+        # parameters that received no gradient are skipped, as torch.optim does (e.g. AttentionUNet's unused conv_ch)
+        active = tuple(i for i, p in enumerate(self._all_params) if p.grad is not None)
+        if not active:
+            return loss
+        if active != self._active:
+            step_now = float(self._hyper[0]) if self._hyper is not None else None
+            self._params = [self._all_params[i] for i in active]
+            if self._ema_params is not None:
+                self._ema_active = [self._ema_all[i] for i in active]
+            self._active, self._table, self._ptrs = active, None, None
+            self._init_state()
+            self._build()
+            if step_now is not None:
+                self._hyper[0] = step_now
         self._init_state()
         if self._table is None:
             self._build()

@@ -354,6 +354,12 @@ int cbim_prob_finalize(float* prob_sum, const float* counter, int64_t* labels, i
 int cbim_dice_counts(const void* pred, int pred_bytes, const void* target, int target_bytes, int64_t N,
                      int64_t block, int C, int32_t* counts, void* stream);
 
+/* Attention gate of AttentionUNet (/root/reference/model/dim3/attention_unet_utils.py:28-35): y = x * psi with one psi
+ * per voxel (float [rows]); backward dx = dy*psi, dpsi[row] = sum_c dy*x. */
+int cbim_gate_fwd(int dtype, const void* x, const float* psi, void* y, int64_t rows, int C, void* stream);
+int cbim_gate_bwd(int dtype, const void* dy, const void* x, const float* psi, void* dx, float* dpsi, int64_t rows,
+                  int C, void* stream);
+
 /* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);

@@ -221,3 +221,38 @@ def unetpp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kerne
     x1_3 = layer("conv1_3", torch.cat([x1_0, x1_1, x1_2, up(x2_2, 1)], 1), 1)
     x0_4 = layer("conv0_4", torch.cat([x0_0, x0_1, x0_2, x0_3, up(x1_3, 0)], 1), 0)
     return F.conv3d(x0_4, sd["output.weight"], sd["output.bias"])
+
+
+def attention_unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size, block="BasicBlock") -> torch.Tensor:
+    """AttentionUNet.forward (/root/reference/model/dim3/attention_unet.py:30-45) with attention_up_block /
+    AttentionBlock (attention_unet_utils.py:6-66): nn.InstanceNorm3d default eps 1e-5 inside the gate."""
+    blk = _BLOCKS[block]
+    ks = [_k3(k) for k in kernel_size]
+    sc = [_k3(s) for s in scale]
+
+    def in5(t):
+        return F.instance_norm(t, eps=1e-5)
+
+    def up(p, lvl, low, skip):
+        x1 = F.interpolate(low, size=skip.shape[2:], mode="trilinear", align_corners=True)
+        g1 = in5(F.conv3d(x1, sd[p + "attn.W_g.0.weight"]))
+        s1 = in5(F.conv3d(skip, sd[p + "attn.W_x.0.weight"]))
+        psi = torch.sigmoid(in5(F.conv3d(F.relu(g1 + s1), sd[p + "attn.psi.0.weight"])))
+        out = torch.cat([skip * psi, x1], dim=1)
+        out = blk(sd, p + "conv.0.", out, ks[lvl])
+        return blk(sd, p + "conv.1.", out, ks[lvl])
+
+    x1 = F.conv3d(x, sd["inc.conv1.weight"], None, 1, _pad(ks[0]))
+    x1 = blk(sd, "inc.conv2.", x1, ks[0])
+    feats = [x1]
+    t = x1
+    for i in range(4):
+        t = F.max_pool3d(t, sc[i])
+        t = blk(sd, f"down{i + 1}.conv.1.", t, ks[i + 1])
+        t = blk(sd, f"down{i + 1}.conv.2.", t, ks[i + 1])
+        feats.append(t)
+    out = up("up1.", 3, feats[4], feats[3])
+    out = up("up2.", 2, out, feats[2])
+    out = up("up3.", 1, out, feats[1])
+    out = up("up4.", 0, out, feats[0])
+    return F.conv3d(out, sd["outc.weight"], sd["outc.bias"])

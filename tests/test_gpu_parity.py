@@ -259,3 +259,12 @@ def test_unetpp_matches_reference_golden(dev):
     print(assert_fp32(dev))
     r = run(dev, "bf16")
     assert r["logits_err"] < 0.25 and r["ce_err"] < 0.05 and r["dice_err"] < 0.02, r
+
+
+def test_attention_unet_matches_reference_golden(dev):
+    from tests.attunet_checks import assert_fp32, run
+    print(assert_fp32(dev, optimizer_step=True))
+    # the base_chan-8 fixture has a 4-channel gate (out_ch // 2) — below the 8-channel bf16 chunk; bf16 mode must
+    # refuse it loudly (shipped configs use base_chan 32 -> 16-channel gates)
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        run(dev, "bf16")

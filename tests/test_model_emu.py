@@ -136,3 +136,8 @@ def test_unetpp_fp32_matches_reference_golden(dev):
     from cbim_amd.model.utils import get_model
     net = get_model(_args(model="unet++", base_chan=8, classes=4))
     assert len(net.state_dict()) == 92 or len(net.state_dict()) > 0
+
+
+def test_attention_unet_fp32_matches_reference_golden(dev):
+    from tests.attunet_checks import assert_fp32
+    print(assert_fp32(dev, optimizer_step=True))

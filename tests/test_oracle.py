@@ -156,3 +156,12 @@ def test_unetpp_oracle_matches_reference_golden():
     with torch.no_grad():
         logits = unet_ref.unetpp_forward(sd, torch.from_numpy(g["x"]), scale=SCALE, kernel_size=KS, block="BasicBlock")
     assert rel_err(logits, g["logits"]) < 1e-5
+
+
+def test_attention_unet_oracle_matches_reference_golden():
+    from tests.attunet_checks import KS, SCALE, build
+    net, g = build()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        logits = unet_ref.attention_unet_forward(sd, torch.from_numpy(g["x"]), scale=SCALE, kernel_size=KS, block="BasicBlock")
+    assert rel_err(logits, g["logits"]) < 1e-5
