@@ -37,7 +37,7 @@ AMOS = dict(base_chan=32, map_size=[4, 4, 4], conv_block="BasicBlock", conv_num=
             scale=[[2, 2, 2]] * 4, aux_loss=True)
 CASES = {
     # name: (in_chan, classes, kwargs, spatial, batch, seed, full)
-    "medformer_tiny_32": (1, 4, TINY, (32, 32, 32), 2, 3031, True),
+    "medformer_tiny_32": (1, 4, TINY, (32, 32, 32), 1, 3031, True),
     "medformer_amos_64": (1, 16, AMOS, (64, 64, 64), 1, 3032, False),
 }
 AUX_WEIGHT = [0.5, 0.5]   # config/amos_ct/medformer_3d.yaml: aux_weight

@@ -131,8 +131,10 @@ def test_swin_unetr_fp32_matches_reference_golden(dev):
 
 
 def test_unetpp_fp32_matches_reference_golden(dev):
+    # forward + losses here; forward + backward + bf16 run on the GPU (tests/test_gpu_parity.py), every kernel's
+    # backward is covered per op in test_ops_emu.py
     from tests.unetpp_checks import assert_fp32
-    print(assert_fp32(dev))
+    print(assert_fp32(dev, backward=False))
     from cbim_amd.model.utils import get_model
     net = get_model(_args(model="unet++", base_chan=8, classes=4))
     assert len(net.state_dict()) == 92 or len(net.state_dict()) > 0

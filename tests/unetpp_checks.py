@@ -11,7 +11,7 @@ SCALE = [[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]]
 KS = [[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]]
 
 
-def run(dev, mode="fp32"):
+def run(dev, mode="fp32", backward=True):
     from oracle.unet_ref import state_dict_checksum
     g = load_golden("unetpp_b8_acdc")
     torch.manual_seed(int(g["seed"]))
@@ -25,9 +25,17 @@ def run(dev, mode="fp32"):
     try:
         logits = net(torch.from_numpy(g["x"]).to(dev))
         both = Fn.DiceCEFn.apply(logits, torch.from_numpy(g["label"]).to(dev), torch.from_numpy(g["weight"]).to(dev))
-        both[2].backward()
+        if backward:
+            both[2].backward()
     finally:
         cbim_amd.set_compute_dtype(None)
+    res = {
+        "logits_err": rel_err(logits.detach().cpu(), g["logits"]),
+        "argmax_mismatch": int((logits.argmax(1).cpu() != torch.from_numpy(g["logits"]).argmax(1)).sum()),
+        "ce_err": abs(float(both[0]) - float(g["ce"])), "dice_err": abs(float(both[1]) - float(g["dice"])),
+    }
+    if not backward:
+        return res
     params = dict(net.named_parameters())
     keys = [str(k) for k in g["keys"]]
     gn = np.array([float(params[k].grad.double().norm()) for k in keys])
@@ -42,9 +50,10 @@ def run(dev, mode="fp32"):
     }
 
 
-def assert_fp32(dev):
-    r = run(dev)
+def assert_fp32(dev, backward=True):
+    r = run(dev, backward=backward)
     assert r["logits_err"] < 1e-3 and r["argmax_mismatch"] == 0, r
     assert r["ce_err"] < 1e-4 and r["dice_err"] < 1e-4, r
-    assert r["grad_norm_err"] < 1e-2 and r["g_first"] < 2e-2 and r["g_head"] < 1e-3, r
+    if backward:
+        assert r["grad_norm_err"] < 1e-2 and r["g_first"] < 2e-2 and r["g_head"] < 1e-3, r
     return r
