@@ -141,6 +141,7 @@ class BasicBlockFn(torch.autograd.Function):
         if so is None:
             so = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(so)
+        ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output
         return out, so
 
     @staticmethod
@@ -312,6 +313,7 @@ class NormConvFn(torch.autograd.Function):
         if so is None:
             so = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(so)
+        ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output
         return y, so
 
     @staticmethod
@@ -355,6 +357,7 @@ class DWConvFn(torch.autograd.Function):
         ctx.want_mean = want_mean
         ctx.S = int(x.shape[1]) * int(x.shape[2]) * int(x.shape[3])
         ctx.mark_non_differentiable(ys)
+        ctx.set_materialize_grads(False)
         return y, mean, ys
 
     @staticmethod
