@@ -39,7 +39,8 @@ class GradAllReduce:
 
         ddp = GradAllReduce(net)              # after net.to(device); broadcasts rank-0 weights
         loss.backward()                       # buckets fire as their gradients complete
-        ddp.synchronize()                     # wait + write the averaged gradients back
+        ddp.synchronize()                     # wait + write the averaged gradients back (parameters that got no
+                                              # gradient are skipped, like find_unused_parameters=True)
         optimizer.step()
     """
 
@@ -87,18 +88,26 @@ class GradAllReduce:
     def synchronize(self):
         """Wait for every bucket and write the averaged gradients back into ``param.grad``."""
         for b in self.buckets:
-            if b.pending != 0:
-                raise RuntimeError("GradAllReduce.synchronize(): a parameter received no gradient "
-                                   "(unused parameters are not supported)")
+            if b.pending != 0 and self.world > 1:
+                # some parameters of this bucket received no gradient in this step (the reference wraps with
+                # DistributedDataParallel(find_unused_parameters=True), train_ddp.py:353; e.g. AttentionUNet's unused
+                # conv_ch): the bucket never fired from the hooks — exchange it now, zeros standing in for the
+                # missing gradients (every rank sees the same graph, so every rank takes this branch)
+                b.flat = torch.cat([p.grad.reshape(-1) if p.grad is not None
+                                    else torch.zeros(p.numel(), dtype=p.dtype, device=p.device) for p in b.params])
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if b.work is not None:
                 b.work.wait()
                 b.flat.div_(self.world)
                 off = 0
-                views = []
+                dst, views = [], []
                 for p in b.params:
-                    views.append(b.flat[off:off + p.numel()].view_as(p.grad))
+                    if p.grad is not None:
+                        dst.append(p.grad)
+                        views.append(b.flat[off:off + p.numel()].view_as(p.grad))
                     off += p.numel()
-                torch._foreach_copy_([p.grad for p in b.params], views)
+                if dst:
+                    torch._foreach_copy_(dst, views)
                 b.work = None
                 b.flat = None
             b.pending = len(b.params)
