@@ -55,15 +55,21 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN
   return (bf16_t)(u >> 16);
 }
 
-// two floats -> packed bf16x2 (RNE): one v_cvt_pk_bf16_f32 on gfx950 (no builtin; the bit-twiddling
-// form costs ~16 VALU per pair and made the conv staging/epilogue VALU-bound)
+// two floats -> packed bf16x2 (RNE): one v_cvt_pk_bf16_f32 on gfx950 (the bit-twiddling form costs ~16 VALU per
+// pair and made the conv staging/epilogue VALU-bound).  Written as a vector conversion the compiler selects itself,
+// NOT as inline asm: the hazard recognizer does not see VALU writes made inside an asm statement, and gfx950 needs 2
+// wait states between a VALU write of a VGPR and an MFMA reading it as SrcA/B — with asm the k_attn_bwd_mfma operands
+// packed right before their MFMA were read stale (inf/NaN rows on hardware only).
+#ifndef CBIM_EMU
+typedef __bf16 cbim_bf2_t __attribute__((ext_vector_type(2)));
+typedef float cbim_f2_t __attribute__((ext_vector_type(2)));
+#endif
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
 #ifdef CBIM_EMU
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 #else
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  cbim_f2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, cbim_bf2_t));
 #endif
 }
 

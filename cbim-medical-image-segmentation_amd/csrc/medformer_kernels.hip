@@ -16,6 +16,7 @@
 // Layout: feature maps channels-last [N][L][C]; head split is the reference's "(dim_head heads)":
 // channel c = d*heads + h (medformer_utils.py:43-51).  Map-side tensors are float32 [N][M][inner].
 #include "cbim_common.h"
+#include <stdlib.h>
 
 #ifdef CBIM_EMU
 #define CBIM_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
@@ -995,7 +996,7 @@ static int attn_check(int dtype, int L, int heads, int dh, int M) {
 }
 
 extern "C" size_t cbim_bidir_attn_workspace(int N, int L, int heads, int dh, int M) {
-  size_t nblk = (size_t)(L + AT - 1) / AT;
+  size_t nblk = (size_t)(L + 31) / 32;   // the matrix-core path writes one record per 32 voxels (the vector path per 128)
   size_t fwd = (size_t)N * heads * nblk * M * (dh + 2), bwd = (size_t)N * heads * nblk * 2 * M * dh;
   return (fwd > bwd ? fwd : bwd) * sizeof(float);
 }
@@ -1014,6 +1015,17 @@ extern "C" size_t cbim_bidir_attn_workspace(int N, int L, int heads, int dh, int
   } while (0)
 
 // (k_attn_merge grid = N*heads*M blocks of 64 threads; k_attn_bwd_reduce grid = (N*heads, ceil(2*M*dh/NT)))
+extern "C" int cbim_attn_fwd_mfma_launch(const void* qv, int64_t qv_stride, const float* mq, const float* mv, void* feat_out,
+                                         float* part, int N, int L, int heads, float scale, void* stream);
+extern "C" int cbim_attn_bwd_mfma_launch(const void* qv, int64_t qv_stride, const float* mq, const float* mv,
+                                         const float* colstat, const float* map_out, const void* d_feat_out,
+                                         const float* d_map_out, void* d_qv, float* part, int N, int L, int heads, float scale,
+                                         void* stream);
+static bool attn_mfma_on() {
+  static const int on = getenv("CBIM_ATTN_MFMA") ? atoi(getenv("CBIM_ATTN_MFMA")) : 1;
+  return on != 0;
+}
+
 extern "C" int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
                                    void* feat_out, float* map_out, float* colstat, int N, int L, int heads, int dh,
                                    int M, float scale, void* workspace, size_t ws_bytes, void* stream) {
@@ -1022,9 +1034,15 @@ extern "C" int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride,
              "attention workspace too small");
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(nblk, heads, N);
-  ATTN_DISPATCH(k_attn_fwd, grid, st, qv, qv_stride, mq, mv, feat_out, (float*)workspace, L, heads, M, scale, nblk);
-  if (int e = launch_ok("bidir_attn_fwd")) return e;
+  if (dtype == CBIM_BF16 && dh == 32 && M == 64 && attn_mfma_on()) {
+    // matrix-core path: one online-softmax record per wave (32 voxels)
+    nblk = (L + 31) / 32;
+    if (int e = cbim_attn_fwd_mfma_launch(qv, qv_stride, mq, mv, feat_out, (float*)workspace, N, L, heads, scale, stream)) return e;
+  } else {
+    dim3 grid(nblk, heads, N);
+    ATTN_DISPATCH(k_attn_fwd, grid, st, qv, qv_stride, mq, mv, feat_out, (float*)workspace, L, heads, M, scale, nblk);
+    if (int e = launch_ok("bidir_attn_fwd")) return e;
+  }
   CBIM_LAUNCH(k_attn_merge, dim3(N * heads * M), dim3(64), 0, st, (const float*)workspace, map_out, colstat, heads, M,
               dh, nblk);
   return launch_ok("bidir_attn_merge");
@@ -1040,10 +1058,16 @@ extern "C" int cbim_bidir_attn_bwd(int dtype, const void* qv, int64_t qv_stride,
              "attention workspace too small");
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(nblk, heads, N);
-  ATTN_DISPATCH(k_attn_bwd, grid, st, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out, d_map_out, d_qv,
-                (float*)workspace, L, heads, M, scale, nblk);
-  if (int e = launch_ok("bidir_attn_bwd")) return e;
+  if (dtype == CBIM_BF16 && dh == 32 && M == 64 && attn_mfma_on()) {
+    nblk = (L + 31) / 32;
+    if (int e = cbim_attn_bwd_mfma_launch(qv, qv_stride, mq, mv, colstat, map_out, d_feat_out, d_map_out, d_qv,
+                                          (float*)workspace, N, L, heads, scale, stream)) return e;
+  } else {
+    dim3 grid(nblk, heads, N);
+    ATTN_DISPATCH(k_attn_bwd, grid, st, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out, d_map_out, d_qv,
+                  (float*)workspace, L, heads, M, scale, nblk);
+    if (int e = launch_ok("bidir_attn_bwd")) return e;
+  }
   CBIM_LAUNCH(k_attn_bwd_reduce, dim3(N * heads, (2 * M * dh + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace,
               d_mq, d_mv, heads, M, dh, nblk);
   return launch_ok("bidir_attn_bwd_reduce");

@@ -305,16 +305,17 @@ def check_attn(dev, dtype, N=2, heads=3, dh=8, dhw=(5, 6, 7), M=8, seed=13):
     fo, mo, cs = ops.bidir_attn_fwd(qvl, mql, mvl, heads, scale)
     t = tol(dtype, 2e-5, 1e-2)
     assert relerr(from_cl(fo.cpu()).reshape(N, inner, L), fo_r.detach()) < t, "attn feat_out"
-    assert relerr(mo.cpu().permute(0, 2, 1), mo_r.detach()) < tol(dtype, 2e-5, 2e-5), "attn map_out"
+    # bf16 with d_head 32 / 64 codes runs on the matrix cores: map operands and probabilities are rounded to bf16
+    assert relerr(mo.cpu().permute(0, 2, 1), mo_r.detach()) < tol(dtype, 2e-5, 1e-2), "attn map_out"
     dfo = torch.randn(N, inner, *dhw)
     dfol = to_cl(dfo, dtype).to(dev)
     dmo = torch.randn(N, inner, M)
     (fo_r * from_cl(dfol.cpu()).reshape(N, inner, L)).sum().backward(retain_graph=True)
     (mo_r * dmo).sum().backward()
     dqv, dmq, dmv = ops.bidir_attn_bwd(qvl, mql, mvl, cs, mo, dfol, dmo.permute(0, 2, 1).contiguous().to(dev), heads, scale)
-    assert relerr(from_cl(dqv.cpu()).reshape(N, 2 * inner, L), qvr.grad) < t, "attn dqv"
-    assert relerr(dmq.cpu().permute(0, 2, 1), mq.grad) < 5e-5, "attn dmq"
-    assert relerr(dmv.cpu().permute(0, 2, 1), mv.grad) < 5e-5, "attn dmv"
+    assert relerr(from_cl(dqv.cpu()).reshape(N, 2 * inner, L), qvr.grad) < tol(dtype, 2e-5, 3e-2), "attn dqv"
+    assert relerr(dmq.cpu().permute(0, 2, 1), mq.grad) < tol(dtype, 5e-5, 3e-2), "attn dmq"
+    assert relerr(dmv.cpu().permute(0, 2, 1), mv.grad) < tol(dtype, 5e-5, 3e-2), "attn dmv"
 
 
 def check_mappool(dev, dtype, N=2, C=24, M=8, dhw=(5, 6, 7), seed=14):

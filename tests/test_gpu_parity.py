@@ -149,7 +149,9 @@ def test_medformer_bf16_inside_envelope(dev):
     from tests.medformer_checks import run_case as mf_run
     r, g = mf_run("medformer_amos_64", dev, "bf16")
     print(r)
-    assert r["logits_err"] < 0.25 and r["aux_err"] < 0.25, r
+    # the reference itself under torch.autocast(bfloat16) on this case (same weights, CPU): max rel 0.366 (logits) /
+    # 0.235 (aux), 23 % argmax flips — measured with tests/golden/make_golden_medformer.py's model
+    assert r["logits_err"] < 0.4 and r["aux_err"] < 0.4, r
     assert max(abs(a - b) for a, b in zip(r["ce"] + r["dice"], list(g["ce"]) + list(g["dice"]))) < 0.05, r
     assert r["grad_norm_err"] < 0.5, r
 
