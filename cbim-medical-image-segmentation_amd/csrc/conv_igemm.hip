@@ -58,6 +58,9 @@ struct IgemmParams {
   int dbg;                         // timing ablations for tools/ (env CBIM_IGEMM_DBG); 0 in production
   int ksplit;                      // > 1: blockIdx.z owns a slice of the Cin chunks, raw fp32 partials go to ws
   float* ws;                       // [ksplit][N*Do*Ho*Wo][Cout] fp32
+#ifdef CBIM_IGEMM_PROF
+  unsigned long long* prof;        // tools/ only (-DCBIM_IGEMM_PROF): per-wave cycle totals of the loop phases
+#endif
 };
 
 template <typename T> struct Mma;
@@ -143,6 +146,24 @@ template <int N> __device__ __forceinline__ void wait_vm_halo() {
 #endif
 }
 
+// 24-bit integer multiply-add (full rate; the generic 32-bit multiply is quarter rate) and an optimisation barrier
+// that makes a loop-invariant register look freshly computed
+__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) {
+#ifdef CBIM_EMU
+  return a * b;
+#else
+  return __umul24(a, b);
+#endif
+}
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return mul24(a, b) + c; }
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+__device__ __forceinline__ unsigned launder(unsigned v) {
+#ifndef CBIM_EMU
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
 template <int MT, int NTL> struct Frags { u32x4 a[MT]; u32x4 b[NTL]; };   // one k-group of one tap
 
 // NTH = threads per workgroup: 512 (one persistent workgroup per CU) or 256 (two per CU, 4x8x8 tiles: the two
@@ -215,45 +236,71 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
   // ---- halo of a unit: issue loads into registers / write them (transformed) to LDS --------------------
   // The (mean, rstd) pairs of the unit's chunk travel through 2 registers of the first KC threads and
   // a 256-byte LDS table (written before the stage-end barrier, read by halo_store after it).
+  // Everything about an item that does not change from unit to unit — its (hd, hh, hw) position inside the halo
+  // box and whether the box has that many rows — is decoded ONCE into one packed register per item.  Per unit the
+  // address is then tile-origin pointer (wave-uniform, scalar registers) + a 32-bit byte offset made of two 24-bit
+  // multiply-adds, and the LDS address is a lane constant + an immediate.  (Left to itself the compiler hoists the
+  // per-item divisions and 64-bit products out of the unit loop into ~100 spilled registers, reloaded from scratch
+  // memory at every stage: launder() keeps the derived values inside the loop.)
+  unsigned hpk[UH];     // hd | hh << 8 | hw << 16 | (item exists) << 24
+#pragma unroll
+  for (int u = 0; u < UH; ++u) {
+    const int item = tid + u * NT;
+    const unsigned hv = (unsigned)item / SLOTS;
+    const unsigned hd = (hv * p.mHW) >> 20;
+    const unsigned r2 = hv - hd * hHW;
+    const unsigned hh = (r2 * p.mW) >> 20;
+    const unsigned hw = r2 - hh * p.hW;
+    hpk[u] = hd | (hh << 8) | (hw << 16) | (item < hV * SLOTS ? 1u << 24 : 0u);
+  }
+  // output voxel of epilogue item (mt, it) inside the tile: td | th << 8 | tw << 16 (same for every tile)
+  constexpr int EP_OCH = 32 / CPC, EP_IT = 32 * EP_OCH / 64;
+  unsigned opk[MT][EP_IT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int it = 0; it < EP_IT; ++it) {
+      const int m = (wave * MT + mt) * 32 + (lane + 64 * it) / EP_OCH;
+      opk[mt][it] = (unsigned)(m >> (3 + p.lgH)) | ((unsigned)((m >> 3) & (p.tH - 1)) << 8) | ((unsigned)(m & 7) << 16);
+    }
+  const unsigned l_base = (unsigned)(tid / SLOTS) * RB;   // LDS row of item u: l_base + u * (NT / SLOTS) * RB
   u32x4 hreg[UH];
   unsigned hld = 0;
   float sreg0 = 0.f, sreg1 = 1.f;
-  int h_id0 = 0, h_ih0 = 0, h_iw0 = 0;
   auto halo_load = [&](int unit) {
     const int t = t_begin + unit / nq, q = q_lo + unit % nq;
     const int n = t / tiles_per_n, tt = t % tiles_per_n;
-    h_id0 = (tt / (p.tiles_w * p.tiles_h)) * p.tD - p.pD;
-    h_ih0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH - p.pH;
-    h_iw0 = (tt % p.tiles_w) * 8 - p.pW;
+    const int id0 = (tt / (p.tiles_w * p.tiles_h)) * p.tD - p.pD;
+    const int ih0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH - p.pH;
+    const int iw0 = (tt % p.tiles_w) * 8 - p.pW;
     const int c0 = q * KC + my_slot * CPC;
     const bool c_ok = c0 < p.Cin;
     const bool from2 = p.x2 != nullptr && q * KC >= p.cin_split;   // block-uniform (split is chunk aligned)
-    const size_t nbase_in = (size_t)n * p.Di * p.Hi * p.Wi;
     if (p.in_stats && tid < KC && q * KC + tid < p.Cin) {
       sreg0 = p.in_stats[((size_t)n * p.Cin + q * KC + tid) * 2];
       sreg1 = p.in_stats[((size_t)n * p.Cin + q * KC + tid) * 2 + 1];
     }
+    // wave-uniform: pointer to the halo box origin (may lie outside the tensor: only in-range rows are read)
+    const unsigned stride_b = (unsigned)(from2 ? p.x2_stride : p.x_stride) * Elem<T>::SIZE;
+    const long long org = (((long long)n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0;
+    const unsigned char* tbase = (const unsigned char*)(from2 ? p.x2 : p.x) + org * (long long)stride_b;
+    const unsigned c_byte = c_ok ? (unsigned)(from2 ? c0 - p.cin_split : c0) * Elem<T>::SIZE : 0u;
+    // row read by items that are discarded (padding, rows past the box): the box corner clamped into the tensor
+    const int sd = clampi(id0, p.Di - 1) - id0, sh = clampi(ih0, p.Hi - 1) - ih0, sw = clampi(iw0, p.Wi - 1) - iw0;
+    const unsigned safe = mul24((unsigned)((sd * p.Hi + sh) * p.Wi + sw), stride_b);
     hld = 0;
-    const int a_items = hV * SLOTS;
 #pragma unroll
     for (int u = 0; u < UH; ++u) {
-      int item = tid + u * NT;
-      unsigned hv = (unsigned)item / SLOTS;
-      unsigned hd = (hv * p.mHW) >> 20;
-      unsigned r2 = hv - hd * hHW;
-      unsigned hh = (r2 * p.mW) >> 20;
-      unsigned hw = r2 - hh * p.hW;
-      int id = h_id0 + (int)hd, ih = h_ih0 + (int)hh, iw = h_iw0 + (int)hw;
-      bool ld = !(p.dbg & 1) && item < a_items && c_ok && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
-      // every thread issues exactly UH loads (out-of-range items read element 0 and are discarded by
-      // halo_store): the stage-end wait can then leave exactly these UH loads in flight (wait_vm_halo)
-      size_t off = 0;
-      if (ld) {
-        size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
-        off = from2 ? row * p.x2_stride + (c0 - p.cin_split) : row * p.x_stride + c0;
-        hld |= 1u << u;
-      }
-      hreg[u] = ld_chunk<T>(from2 ? p.x2 : p.x, off);
+      const unsigned pk = launder(hpk[u]);
+      const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
+      // every thread issues exactly UH loads (discarded items read the safe row): the stage-end wait can then
+      // leave exactly these UH loads in flight (wait_vm_halo)
+      const bool ld = !(p.dbg & 1) && (pk >> 24) != 0 && c_ok && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
+                      (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
+      const unsigned rel = mad24(mad24(hd, (unsigned)p.Hi, hh), (unsigned)p.Wi, hw);
+      const unsigned voff = ld ? mad24(rel, stride_b, c_byte) : safe;
+      hld |= (ld ? 1u : 0u) << u;
+      hreg[u] = *(const u32x4*)(tbase + voff);
     }
   };
   auto stats_publish = [&]() {   // before a barrier that precedes halo_store
@@ -265,15 +312,10 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
   };
   auto halo_store = [&]() {
     const float* st = (const float*)(smem + st_base) + my_slot * CPC * 2;
-    const int a_items = hV * SLOTS;
 #pragma unroll
     for (int u = 0; u < UH; ++u) {
-      int item = tid + u * NT;
-      if (item < a_items) {
-        unsigned hv = (unsigned)item / SLOTS;
-        unsigned hd = (hv * p.mHW) >> 20;
-        unsigned r2 = hv - hd * hHW;
-        unsigned hh = (r2 * p.mW) >> 20;
+      const unsigned pk = launder(hpk[u]);
+      if (pk >> 24) {
         const bool loaded = (hld >> u) & 1u;
         u32x4 w = loaded ? hreg[u] : u32x4{0u, 0u, 0u, 0u};
         if (p.in_stats && loaded) {
@@ -283,7 +325,7 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
           for (int j = 0; j < CPC; ++j) f[j] = actf<ACT>((f[j] - st[2 * j]) * st[2 * j + 1], p.act);
           w = Elem<T>::pack(f);
         }
-        *(u32x4*)(smem + hv * RB + ((my_slot ^ (hh & (SLOTS - 1))) << 4)) = w;
+        *(u32x4*)(smem + l_base + (unsigned)(u * (NT / SLOTS) * RB) + (((unsigned)my_slot ^ ((pk >> 8) & (SLOTS - 1))) << 4)) = w;
       }
     }
   };
@@ -324,6 +366,13 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
   wait_vm0();
   __syncthreads();
 
+#ifdef CBIM_IGEMM_PROF
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long plast = __builtin_readcyclecounter();
+#define CBIM_TICK(ph) { unsigned long long t_ = __builtin_readcyclecounter(); pacc[ph] += t_ - plast; plast = t_; }
+#else
+#define CBIM_TICK(ph) ((void)0)
+#endif
   int stage = 0;
   for (int unit = 0; unit < n_units; ++unit) {
     const int t = t_begin + unit / nq, q = q_lo + unit % nq;
@@ -331,9 +380,12 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
       const bool last_plane = kd == p.kD - 1;
       // ---- start the next stage's weight DMA before computing; the next unit's halo loads are issued
       //      at the unit's FIRST stage so that they have the whole unit to land ------------------------------
+      CBIM_TICK(7);
       if (!last_plane) dma_stage(unit, kd + 1, (stage + 1) & 1);
       else if (unit + 1 < n_units) dma_stage(unit + 1, 0, (stage + 1) & 1);
+      CBIM_TICK(0);
       if (kd == 0 && unit + 1 < n_units) halo_load(unit + 1);
+      CBIM_TICK(6);
       {
         const unsigned a_plane = (unsigned)(kd * hHW) * RB;
         const unsigned b_buf = b_base + (unsigned)(stage & 1) * stage_bytes;
@@ -408,6 +460,7 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
           }
         }
       }
+      CBIM_TICK(1);
       // ---- stage end -------------------------------------------------------------------------------------------
       const bool tile_done = last_plane && q == q_hi - 1;
       if (last_plane && unit + 1 < n_units) stats_publish();
@@ -415,7 +468,9 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
       // keeps flying through the following stages
       if (kd == 0 && !last_plane && unit + 1 < n_units) wait_vm_halo<UH>();
       else wait_vm0();
+      CBIM_TICK(2);
       __syncthreads();   // every wave is done with this stage's A/B reads
+      CBIM_TICK(3);
       if (tile_done) {
         // ---- epilogue: each wave transposes its own 32x32 accumulator tiles through a private 4 KiB LDS
         //      scratch (inside the now dead halo region) so that residual / mask loads and the output
@@ -426,7 +481,14 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
         const int od0 = (tt / (p.tiles_w * p.tiles_h)) * p.tD;
         const int oh0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH;
         const int ow0 = (tt % p.tiles_w) * 8;
-        const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
+        // wave-uniform pointers to the tile's first output row; a lane adds a 32-bit byte offset (24-bit multiplies)
+        const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
+        const unsigned y_sb = (unsigned)p.y_stride * Elem<T>::SIZE, res_sb = (unsigned)p.res_stride * Elem<T>::SIZE,
+                       mx_sb = (unsigned)p.mx_stride * Elem<T>::SIZE, ws_sb = (unsigned)p.Cout * 4u;
+        unsigned char* y_tile = (unsigned char*)p.y + orow * (long long)y_sb;
+        const unsigned char* res_tile = (const unsigned char*)p.res + orow * (long long)res_sb;
+        const unsigned char* mx_tile = (const unsigned char*)p.mx + orow * (long long)mx_sb;
+        unsigned char* ws_tile = (unsigned char*)p.ws + ((long long)blockIdx.z * ((long long)p.N * p.Do * p.Ho * p.Wo) + orow) * (long long)ws_sb;
         // scratch: the stage buffer just consumed (NTL=2: 36 KiB) or a dedicated region (NTL=1), so the
         // next halo can be written while other waves are still in their epilogue
         float* scr = (float*)(smem + (((NTL == 1 && NTH == 512) || stage_bytes < NW * 4096u) ? scr_base : b_base + (unsigned)(stage & 1) * stage_bytes) +
@@ -459,10 +521,11 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
             wave_sync();
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
+              const unsigned ok_ = launder(opk[mt][it]);
               const int vr = (lane + 64 * it) / OCH;                 // voxel row inside the 32-voxel m-tile
-              const int m = (wave * MT + mt) * 32 + vr;
-              const int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
-              const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+              const unsigned td = ok_ & 255u, th = (ok_ >> 8) & 255u, tw = (ok_ >> 16) & 255u;
+              const bool inb = c_ok && od0 + (int)td < p.Do && oh0 + (int)th < p.Ho && ow0 + (int)tw < p.Wo;
+              const unsigned rel = mad24(mad24(td, (unsigned)p.Ho, th), (unsigned)p.Wo, tw);
               float v[CPC];
 #pragma unroll
               for (int j4 = 0; j4 < CPC; j4 += 4) {
@@ -470,9 +533,8 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
                 v[j4] = q4.x; v[j4 + 1] = q4.y; v[j4 + 2] = q4.z; v[j4 + 3] = q4.w;
               }
               if (p.ksplit > 1) {   // split-K: raw fp32 partial, finished by k_splitk_finish
-                if (c_ok && od < p.Do && oh < p.Ho && ow < p.Wo) {
-                  const size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
-                  float* wp = p.ws + ((size_t)blockIdx.z * ((size_t)p.N * p.Do * p.Ho * p.Wo) + row) * p.Cout + cch0;
+                if (inb) {
+                  float* wp = (float*)(ws_tile + mad24(rel, ws_sb, (unsigned)cch0 * 4u));
 #pragma unroll
                   for (int j4 = 0; j4 < CPC; j4 += 4) *(f32x4*)(wp + j4) = f32x4{v[j4], v[j4 + 1], v[j4 + 2], v[j4 + 3]};
                 }
@@ -484,17 +546,17 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
 #pragma unroll
                 for (int j = 0; j < CPC; ++j) sh[j] = __shfl(v[j], cc, 64);
               }
-              if (c_ok && od < p.Do && oh < p.Ho && ow < p.Wo) {
-                const size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+              if (inb) {
+                const unsigned cb = (unsigned)cch0 * Elem<T>::SIZE;
                 if (p.res) {
                   float f[CPC];
-                  Elem<T>::unpack(ld_chunk<T>(p.res, row * p.res_stride + cch0), f);
+                  Elem<T>::unpack(*(const u32x4*)(res_tile + mad24(rel, res_sb, cb)), f);
 #pragma unroll
                   for (int j = 0; j < CPC; ++j) v[j] += f[j];
                 }
                 if (p.mx) {
                   float f[CPC];
-                  Elem<T>::unpack(ld_chunk<T>(p.mx, row * p.mx_stride + cch0), f);
+                  Elem<T>::unpack(*(const u32x4*)(mx_tile + mad24(rel, mx_sb, cb)), f);
 #pragma unroll
                   for (int j = 0; j < CPC; ++j) {
                     float xh = (f[j] - mm[j]) * mr[j];
@@ -507,7 +569,7 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
                   for (int j = 0; j < CPC; ++j) { float d = v[j] - sh[j]; s0[j] += d; s1[j] += d * d; }
                 }
                 cnt += 1.f;
-                if (!(p.dbg & 4)) st_chunk<T>(p.y, row * p.y_stride + cch0, Elem<T>::pack(v));
+                if (!(p.dbg & 4)) *(u32x4*)(y_tile + mad24(rel, y_sb, cb)) = Elem<T>::pack(v);
               }
             }
           }
@@ -535,8 +597,10 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
           }
         }
       }
+      CBIM_TICK(4);
       const bool more = last_plane && unit + 1 < n_units;
       if (more) halo_store();      // the next unit's halo replaces this one (nobody reads A any more)
+      CBIM_TICK(5);
       if (more || tile_done) __syncthreads();   // halo visible; scratch reads done; `red` complete
       if (tile_done && p.partials && p.ksplit == 1 && tid < BN && co0 + tid < p.Cout) {
         const int n = t / tiles_per_n, tt = t % tiles_per_n;
@@ -552,8 +616,13 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
         p.partials[o + 1] = a.mean;
         p.partials[o + 2] = a.m2;
       }
+      CBIM_TICK(5);
     }
   }
+#ifdef CBIM_IGEMM_PROF
+  if (p.prof && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) p.prof[wave * 8 + i] = pacc[i];
+#endif
 }
 
 // ---- split-K finish: sum the fp32 partials, then the same epilogue as the fused path ------------------
@@ -895,6 +964,22 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   p.hD = c.tD + d->kD - 1; p.hH = c.tH + d->kH - 1; p.hW = 8 + d->kW - 1;
   const int nw = c.nth / 64, uh = c.nth == 256 ? 10 : UH;
   CBIM_CHECK(p.hD * p.hH * p.hW * SLOTS <= uh * c.nth, CBIM_EUNSUPPORTED, "halo of %d rows too large", p.hD * p.hH * p.hW);
+  {
+    // 32-bit halo byte offsets from two 24-bit multiplies (k_conv_igemm::halo_load)
+    const int64_t box_rows = (int64_t)p.hD * d->Hi * d->Wi;
+    const int64_t max_stride_b = (int64_t)(x2 && x2_stride > x_stride ? x2_stride : x_stride) * elem_size(d->dtype);
+    CBIM_CHECK(box_rows < (1 << 24) && max_stride_b < (1 << 24) && box_rows * max_stride_b < ((int64_t)1 << 32) &&
+               p.hD < 256 && p.hH < 256, CBIM_EUNSUPPORTED,
+               "conv input plane %dx%d with row stride %lld B exceeds the 32-bit halo addressing", d->Hi, d->Wi, (long long)max_stride_b);
+    // same for the epilogue: byte offsets relative to the tile's first output row
+    const int64_t tile_rows = (int64_t)c.tD * d->Ho * d->Wo;
+    int64_t so = y_stride * elem_size(d->dtype);
+    if (res && res_stride * elem_size(d->dtype) > so) so = res_stride * elem_size(d->dtype);
+    if (mask_x && mask_stride * elem_size(d->dtype) > so) so = mask_stride * elem_size(d->dtype);
+    if ((int64_t)d->Cout * 4 > so) so = (int64_t)d->Cout * 4;
+    CBIM_CHECK(tile_rows < (1 << 24) && so < (1 << 24) && tile_rows * so < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
+               "conv output plane %dx%d with row stride %lld B exceeds the 32-bit epilogue addressing", d->Ho, d->Wo, (long long)so);
+  }
   p.mHW = ((1u << 20) + (unsigned)(p.hH * p.hW) - 1) / (unsigned)(p.hH * p.hW);
   p.mW = ((1u << 20) + (unsigned)p.hW - 1) / (unsigned)p.hW;
   int KC = kc_of(d->dtype);
@@ -921,6 +1006,28 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   dim3 grid((unsigned)G, (unsigned)n_nblk, (unsigned)p.ksplit);
   hipStream_t st = (hipStream_t)stream;
   const bool relu = d->act == CBIM_ACT_RELU;
+#ifdef CBIM_IGEMM_PROF
+  static unsigned long long* prof_dev = nullptr;
+  if (!prof_dev) (void)hipMalloc((void**)&prof_dev, 64 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(prof_dev, 0, 64 * sizeof(unsigned long long), st);
+  p.prof = prof_dev;
+  struct ProfDump {
+    unsigned long long* dev; hipStream_t st; const cbim_conv_desc* d;
+    ~ProfDump() {
+      unsigned long long h[64];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
+      static const char* nm[8] = {"dma_issue", "mainloop", "wait_vm", "barrier1", "epilogue", "halo_store+barrier2+partials", "halo_load", "loop_top"};
+      fprintf(stderr, "[igemm prof] %d->%d @%d:", d->Cin, d->Cout, d->Do);
+      for (int i = 0; i < 8; ++i) {
+        unsigned long long s = 0;
+        for (int w = 0; w < 8; ++w) s += h[w * 8 + i];
+        fprintf(stderr, " %s %llu", nm[i], s / 8);
+      }
+      fprintf(stderr, "\n");
+    }
+  } prof_dump{prof_dev, st, d};
+#endif
   if (p.ksplit > 1) {
     // main kernel writes raw partials; the finish kernel owns residual / mask / statistics / store
     IgemmParams q = p;
