@@ -33,6 +33,9 @@ struct WgradParams {
   int tD, tH, lgH, tiles_d, tiles_h, tiles_w, hD, hH, hW, taps;
   int strips_per_n, tiles_per_strip, ci_blocks, Cout_pad, Cin_pad;
   unsigned mHW, mW;
+#ifdef CBIM_IGEMM_PROF
+  unsigned long long* prof;        // tools/ only: per-wave cycle totals of the tile-loop phases
+#endif
 };
 
 #ifdef CBIM_EMU
@@ -55,6 +58,15 @@ __device__ __forceinline__ u32x2 lds_tr16_b64(const unsigned char* p) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(u32x2, v);
+#endif
+}
+
+// 24-bit multiply-add (full rate): row and byte offsets inside one tile box
+__device__ __forceinline__ unsigned wmad24(unsigned a, unsigned b, unsigned c) {
+#ifdef CBIM_EMU
+  return a * b + c;
+#else
+  return __umul24(a, b) + c;
 #endif
 }
 
@@ -117,8 +129,6 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
       rstd[j] = p.in_stats[((size_t)n * p.Cin + ci0 + j) * 2 + 1];
     }
   }
-  const size_t nbase_in = (size_t)n * p.Di * p.Hi * p.Wi;
-  const size_t nbase_out = (size_t)n * p.Do * p.Ho * p.Wo;
 
   // per-lane constants of the fragment reads
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
@@ -160,74 +170,104 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
     for (int tl = 0; tl < TPW; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a, f.b[tl], acc[tl], 0, 0, 0);
   };
 
+#ifdef CBIM_IGEMM_PROF
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long plast = __builtin_readcyclecounter();
+#define CBIM_TICK(ph) { unsigned long long t_ = __builtin_readcyclecounter(); pacc[ph] += t_ - plast; plast = t_; }
+#else
+#define CBIM_TICK(ph) ((void)0)
+#endif
   for (int t = t_begin; t < t_end; ++t) {
     const int od0 = (t / (p.tiles_w * p.tiles_h)) * p.tD;
     const int oh0 = ((t / p.tiles_w) % p.tiles_h) * p.tH;
     const int ow0 = (t % p.tiles_w) * 8;
     const int id0 = od0 - p.pD, ih0 = oh0 - p.pH, iw0 = ow0 - p.pW;
+    CBIM_TICK(0);
     __syncthreads();
-    // ---- stage dy tile: dense [BMv][32 co]; loads batched (UD/UA in flight per thread) -------------------
-    constexpr int UD = 4, UA = 5;
-    const int d_items = BMv * SLOTS;
-    for (int base = tid; base < d_items; base += NT * UD) {
-      u32x4 v[UD];
+    CBIM_TICK(1);
+    // ---- stage the dy tile (dense [BMv][32 co]) and the transformed input halo ([hV][32 ci]).  ALL global
+    //      loads of the tile (UD + UA 16-byte chunks per thread) are issued before the first LDS store, addressed
+    //      as wave-uniform tile pointer + 32-bit byte offset (24-bit multiply-adds, no 64-bit vector arithmetic) --
+    constexpr int UD = 4, UA = 10;
+    const int d_items = BMv * SLOTS, a_items = hV * SLOTS;
+    const unsigned dy_sb = (unsigned)(dy_from2 ? p.dy2_stride : p.dy_stride) * ES, x_sb = (unsigned)p.x_stride * ES;
+    const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
+    const long long irow = (((long long)n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0;
+    const unsigned char* dy_tile = (const unsigned char*)(dy_from2 ? p.dy2 : p.dy) + orow * (long long)dy_sb;
+    const unsigned char* x_tile = (const unsigned char*)p.x + irow * (long long)x_sb;
+    const unsigned dy_cb = (unsigned)(dy_from2 ? co0 - p.cout_split : co0) * ES, x_cb = (unsigned)ci0 * ES;
+    u32x4 vd[UD], va[UA];
+    unsigned lda = 0;
+    // the item decode below does not depend on the tile; laundering the thread index keeps the compiler from
+    // hoisting ~40 registers of it out of the tile loop (they would spill next to the 112 accumulators)
+    int tidl = tid;
+#ifndef CBIM_EMU
+    asm volatile("" : "+v"(tidl));
+#endif
 #pragma unroll
-      for (int u = 0; u < UD; ++u) {
-        int item = base + u * NT;
-        int m = item / SLOTS;
-        int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
-        int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-        v[u] = u32x4{0u, 0u, 0u, 0u};
-        if (item < d_items && co0 < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo) {
-          size_t row = nbase_out + ((size_t)od * p.Ho + oh) * p.Wo + ow;
-          v[u] = dy_from2 ? ld_chunk<T>(p.dy2, row * p.dy2_stride + (co0 - p.cout_split))
-                          : ld_chunk<T>(p.dy, row * p.dy_stride + co0);
-        }
-      }
+    for (int u = 0; u < UD; ++u) {
+      const int item = tidl + u * NT;
+      const int m = item / SLOTS;
+      const unsigned tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
+      vd[u] = u32x4{0u, 0u, 0u, 0u};
+      if (item < d_items && co0 < p.Cout && od0 + (int)td < p.Do && oh0 + (int)th < p.Ho && ow0 + (int)tw < p.Wo)
+        vd[u] = *(const u32x4*)(dy_tile + wmad24(wmad24(wmad24(td, (unsigned)p.Ho, th), (unsigned)p.Wo, tw), dy_sb, dy_cb));
+    }
 #pragma unroll
-      for (int u = 0; u < UD; ++u) {
-        int item = base + u * NT;
-        if (item < d_items) *(u32x4*)(smem + (unsigned)(item / SLOTS) * ROWB + my_slot * 16) = v[u];
+    for (int u = 0; u < UA; ++u) {
+      const int item = tidl + u * NT;
+      const unsigned hv = (unsigned)item / SLOTS;
+      const unsigned hd = (hv * p.mHW) >> 20;
+      const unsigned r2 = hv - hd * hHW;
+      const unsigned hh = (r2 * p.mW) >> 20;
+      const unsigned hw = r2 - hh * p.hW;
+      const bool ld = item < a_items && ci0 < p.Cin && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
+                      (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
+      va[u] = u32x4{0u, 0u, 0u, 0u};
+      if (ld) va[u] = *(const u32x4*)(x_tile + wmad24(wmad24(wmad24(hd, (unsigned)p.Hi, hh), (unsigned)p.Wi, hw), x_sb, x_cb));
+      lda |= (ld ? 1u : 0u) << u;
+    }
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const int item = tid + u * NT;
+      if (item < d_items) *(u32x4*)(smem + (unsigned)item * 16) = vd[u];
+    }
+    CBIM_TICK(2);
+    auto xform = [&](u32x4 w) -> u32x4 {
+      float f[CPC];
+      Elem<T>::unpack(w, f);
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) f[j] = wg_actf<ACT>((f[j] - mean[j]) * rstd[j], p.act);
+      return Elem<T>::pack(f);
+    };
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int item = tid + u * NT;
+      if (item < a_items) {
+        u32x4 w = va[u];
+        if (p.in_stats && ((lda >> u) & 1u)) w = xform(w);
+        *(u32x4*)(smem + aL + (unsigned)item * 16) = w;
       }
     }
-    // ---- stage the transformed input halo: [hV][32 ci] --------------------------------------------------
-    const int a_items = hV * SLOTS;
-    for (int base = tid; base < a_items; base += NT * UA) {
-      u32x4 v[UA];
-      bool ld[UA];
-#pragma unroll
-      for (int u = 0; u < UA; ++u) {
-        int item = base + u * NT;
-        unsigned hv = (unsigned)item / SLOTS;
-        unsigned hd = (hv * p.mHW) >> 20;
-        unsigned r2 = hv - hd * hHW;
-        unsigned hh = (r2 * p.mW) >> 20;
-        unsigned hw = r2 - hh * p.hW;
-        int id = id0 + (int)hd, ih = ih0 + (int)hh, iw = iw0 + (int)hw;
-        ld[u] = item < a_items && ci0 < p.Cin && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
-        v[u] = u32x4{0u, 0u, 0u, 0u};
-        if (ld[u]) {
-          size_t row = nbase_in + ((size_t)id * p.Hi + ih) * p.Wi + iw;
-          v[u] = ld_chunk<T>(p.x, row * p.x_stride + ci0);
-        }
+    // halos larger than NT * UA chunks (kernels beyond 3x3x3 on the 4x8x8 tile): remaining items, same scheme
+    for (int base = tid + NT * UA; base < a_items; base += NT) {
+      const unsigned hv = (unsigned)base / SLOTS;
+      const unsigned hd = (hv * p.mHW) >> 20;
+      const unsigned r2 = hv - hd * hHW;
+      const unsigned hh = (r2 * p.mW) >> 20;
+      const unsigned hw = r2 - hh * p.hW;
+      const bool ld = ci0 < p.Cin && (unsigned)(id0 + (int)hd) < (unsigned)p.Di && (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi &&
+                      (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
+      u32x4 w = u32x4{0u, 0u, 0u, 0u};
+      if (ld) {
+        w = *(const u32x4*)(x_tile + wmad24(wmad24(wmad24(hd, (unsigned)p.Hi, hh), (unsigned)p.Wi, hw), x_sb, x_cb));
+        if (p.in_stats) w = xform(w);
       }
-#pragma unroll
-      for (int u = 0; u < UA; ++u) {
-        int item = base + u * NT;
-        if (item < a_items) {
-          u32x4 w = v[u];
-          if (p.in_stats && ld[u]) {
-            float f[CPC];
-            Elem<T>::unpack(w, f);
-#pragma unroll
-            for (int j = 0; j < CPC; ++j) f[j] = wg_actf<ACT>((f[j] - mean[j]) * rstd[j], p.act);
-            w = Elem<T>::pack(f);
-          }
-          *(u32x4*)(smem + aL + (unsigned)(item / SLOTS) * ROWB + my_slot * 16) = w;
-        }
-      }
+      *(u32x4*)(smem + aL + (unsigned)base * 16) = w;
     }
+    CBIM_TICK(3);
     __syncthreads();
+    CBIM_TICK(4);
     // ---- contraction over the tile's voxels, two k-steps per trip through static register sets --------------
     if (IS_BF16) {
       const int nks = BMv / 16;   // even (BMv is 128 or 256)
@@ -252,6 +292,11 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
     }
   }
 
+  CBIM_TICK(5);
+#ifdef CBIM_IGEMM_PROF
+  if (p.prof && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) p.prof[wave * 8 + i] = pacc[i];
+#endif
   // ---- write this strip's slab: ws[(n*strips+strip)][tap][Cout_pad][Cin_pad] -------------------------------------
   const size_t slab = (size_t)p.taps * p.Cout_pad * p.Cin_pad;
   float* wsb = p.ws + (size_t)blockIdx.x * slab;
@@ -384,6 +429,15 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   p.tD = c.tD; p.tH = c.tH; p.lgH = c.lgH; p.tiles_d = c.tiles_d; p.tiles_h = c.tiles_h; p.tiles_w = c.tiles_w;
   p.hD = c.tD + d->kD - 1; p.hH = c.tH + d->kH - 1; p.hW = 8 + d->kW - 1;
   CBIM_CHECK(p.hD * p.hH * p.hW <= 2048, CBIM_EUNSUPPORTED, "halo too large");
+  {
+    // 32-bit byte offsets inside one tile box, built from 24-bit multiplies (k_conv_wgrad staging)
+    const int es_ = d->dtype == CBIM_BF16 ? 2 : 4;
+    const int64_t in_rows = (int64_t)p.hD * d->Hi * d->Wi, out_rows = (int64_t)c.tD * d->Ho * d->Wo;
+    const int64_t xs = x_stride * es_, ds = (dy2 && dy2_stride > dy_stride ? dy2_stride : dy_stride) * es_;
+    CBIM_CHECK(in_rows < (1 << 24) && out_rows < (1 << 24) && xs < (1 << 24) && ds < (1 << 24) &&
+               in_rows * xs < ((int64_t)1 << 32) && out_rows * ds < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
+               "wgrad planes %dx%d with row strides %lld/%lld B exceed the 32-bit tile addressing", d->Hi, d->Wi, (long long)xs, (long long)ds);
+  }
   p.mHW = ((1u << 20) + (unsigned)(p.hH * p.hW) - 1) / (unsigned)(p.hH * p.hW);
   p.mW = ((1u << 20) + (unsigned)p.hW - 1) / (unsigned)p.hW;
   p.taps = taps; p.strips_per_n = c.strips_per_n; p.tiles_per_strip = c.tiles_per_strip;
@@ -393,6 +447,28 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "wgrad tile needs %zu B of LDS", smem);
   dim3 grid((unsigned)(d->N * c.strips_per_n), (unsigned)(c.co_blocks * c.ci_blocks));
   hipStream_t st = (hipStream_t)stream;
+#ifdef CBIM_IGEMM_PROF
+  static unsigned long long* prof_dev = nullptr;
+  if (!prof_dev) (void)hipMalloc((void**)&prof_dev, 64 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(prof_dev, 0, 64 * sizeof(unsigned long long), st);
+  p.prof = prof_dev;
+  struct ProfDump {
+    unsigned long long* dev; hipStream_t st; const cbim_conv_desc* d; int tps;
+    ~ProfDump() {
+      unsigned long long h[64];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
+      static const char* nm[6] = {"loop_top", "barrier0", "stage_dy", "stage_halo", "barrier1", "contraction"};
+      fprintf(stderr, "[wgrad prof] %d->%d @%d (%d tiles/strip):", d->Cin, d->Cout, d->Do, tps);
+      for (int i = 0; i < 6; ++i) {
+        unsigned long long s = 0;
+        for (int w = 0; w < 4; ++w) s += h[w * 8 + i];
+        fprintf(stderr, " %s %llu", nm[i], s / 4);
+      }
+      fprintf(stderr, "\n");
+    }
+  } prof_dump{prof_dev, st, d, c.tiles_per_strip};
+#endif
   const bool relu = d->act == CBIM_ACT_RELU || !in_stats;
   int rc;
   if (d->dtype == CBIM_BF16)
