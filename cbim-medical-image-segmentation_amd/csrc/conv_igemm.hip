@@ -222,10 +222,33 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
 
   const int my_slot = tid & (SLOTS - 1);  // NT % SLOTS == 0: a thread always stages the same slot
 
+  // ---- position of a unit: (image, tile coordinates, Cin chunk), advanced incrementally — the divisions that
+  //      decode a linear unit index cost ~150 scalar cycles each and ran ten times per unit ----------------------
+  struct UnitPos { int n, td, th, tw, q; };
+  auto advance = [&](UnitPos& u) {
+    if (++u.q == q_hi) {
+      u.q = q_lo;
+      if (++u.tw == p.tiles_w) {
+        u.tw = 0;
+        if (++u.th == p.tiles_h) {
+          u.th = 0;
+          if (++u.td == p.tiles_d) { u.td = 0; ++u.n; }
+        }
+      }
+    }
+  };
+  UnitPos cur, nxt;
+  {
+    const int n0 = t_begin / tiles_per_n, tt = t_begin % tiles_per_n;
+    cur.n = n0; cur.td = tt / (p.tiles_w * p.tiles_h); cur.th = (tt / p.tiles_w) % p.tiles_h; cur.tw = tt % p.tiles_w;
+    cur.q = q_lo;
+    nxt = cur;
+    advance(nxt);
+  }
+
   // ---- weight stage s -> LDS buffer (s & 1) by LDS-DMA ------------------------------------------------
-  auto dma_stage = [&](int unit, int kd, int buf) {
+  auto dma_stage = [&](int q, int kd, int buf) {
     if (p.dbg & 2) return;
-    const int q = q_lo + unit % nq;
     const unsigned char* src = (const unsigned char*)p.w +
         ((size_t)nb * p.n_chunks + q) * ((size_t)p.kD * stage_bytes) + (size_t)kd * stage_bytes;
     unsigned char* dst = smem + b_base + (unsigned)buf * stage_bytes;
@@ -267,12 +290,11 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
   u32x4 hreg[UH];
   unsigned hld = 0;
   float sreg0 = 0.f, sreg1 = 1.f;
-  auto halo_load = [&](int unit) {
-    const int t = t_begin + unit / nq, q = q_lo + unit % nq;
-    const int n = t / tiles_per_n, tt = t % tiles_per_n;
-    const int id0 = (tt / (p.tiles_w * p.tiles_h)) * p.tD - p.pD;
-    const int ih0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH - p.pH;
-    const int iw0 = (tt % p.tiles_w) * 8 - p.pW;
+  auto halo_load = [&](const UnitPos& up) {
+    const int n = up.n, q = up.q;
+    const int id0 = up.td * p.tD - p.pD;
+    const int ih0 = up.th * p.tH - p.pH;
+    const int iw0 = up.tw * 8 - p.pW;
     const int c0 = q * KC + my_slot * CPC;
     const bool c_ok = c0 < p.Cin;
     const bool from2 = p.x2 != nullptr && q * KC >= p.cin_split;   // block-uniform (split is chunk aligned)
@@ -358,8 +380,8 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
   (void)0;
 
   // ---- prologue: first unit's halo and first stage of weights -----------------------------------------
-  dma_stage(0, 0, 0);
-  halo_load(0);
+  dma_stage(cur.q, 0, 0);
+  halo_load(cur);
   stats_publish();
   __syncthreads();
   halo_store();
@@ -375,16 +397,16 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
 #endif
   int stage = 0;
   for (int unit = 0; unit < n_units; ++unit) {
-    const int t = t_begin + unit / nq, q = q_lo + unit % nq;
+    const int q = cur.q;
     for (int kd = 0; kd < p.kD; ++kd, ++stage) {
       const bool last_plane = kd == p.kD - 1;
       // ---- start the next stage's weight DMA before computing; the next unit's halo loads are issued
       //      at the unit's FIRST stage so that they have the whole unit to land ------------------------------
       CBIM_TICK(7);
-      if (!last_plane) dma_stage(unit, kd + 1, (stage + 1) & 1);
-      else if (unit + 1 < n_units) dma_stage(unit + 1, 0, (stage + 1) & 1);
+      if (!last_plane) dma_stage(cur.q, kd + 1, (stage + 1) & 1);
+      else if (unit + 1 < n_units) dma_stage(nxt.q, 0, (stage + 1) & 1);
       CBIM_TICK(0);
-      if (kd == 0 && unit + 1 < n_units) halo_load(unit + 1);
+      if (kd == 0 && unit + 1 < n_units) halo_load(nxt);
       CBIM_TICK(6);
       {
         const unsigned a_plane = (unsigned)(kd * hHW) * RB;
@@ -477,10 +499,8 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
         //      stores are whole 16-byte channel chunks; no workgroup barrier inside -----------------------------
         constexpr int OCH = 32 / CPC;            // 16-byte chunks per 32-cout row
         constexpr int IT = 32 * OCH / 64;        // chunk items per lane per 32x32 tile
-        const int n = t / tiles_per_n, tt = t % tiles_per_n;
-        const int od0 = (tt / (p.tiles_w * p.tiles_h)) * p.tD;
-        const int oh0 = ((tt / p.tiles_w) % p.tiles_h) * p.tH;
-        const int ow0 = (tt % p.tiles_w) * 8;
+        const int n = cur.n;
+        const int od0 = cur.td * p.tD, oh0 = cur.th * p.tH, ow0 = cur.tw * 8;
         // wave-uniform pointers to the tile's first output row; a lane adds a 32-bit byte offset (24-bit multiplies)
         const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
         const unsigned y_sb = (unsigned)p.y_stride * Elem<T>::SIZE, res_sb = (unsigned)p.res_stride * Elem<T>::SIZE,
@@ -603,7 +623,7 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
       CBIM_TICK(5);
       if (more || tile_done) __syncthreads();   // halo visible; scratch reads done; `red` complete
       if (tile_done && p.partials && p.ksplit == 1 && tid < BN && co0 + tid < p.Cout) {
-        const int n = t / tiles_per_n, tt = t % tiles_per_n;
+        const int n = cur.n, tt = (cur.td * p.tiles_h + cur.th) * p.tiles_w + cur.tw;
         const float* red = (const float*)(smem + red_base);
         Moments a = {0.f, 0.f, 0.f};
         for (int g = 0; g < NW; ++g) {
@@ -618,6 +638,8 @@ __global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
       }
       CBIM_TICK(5);
     }
+    cur = nxt;
+    advance(nxt);
   }
 #ifdef CBIM_IGEMM_PROF
   if (p.prof && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
