@@ -136,8 +136,8 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
   const int mq = 8 * half + (i16 >> 2);                             // bf16: voxel of the lane inside a k-step
 
   auto halo_row = [&](int m) -> unsigned {   // LDS row (bytes) of tile voxel m at tap (0,0,0)
-    int tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
-    return (unsigned)((td * p.hH + th) * p.hW + tw) * ROWB;
+    unsigned tw = m & 7, th = (m >> 3) & (p.tH - 1), td = m >> (3 + p.lgH);
+    return wmad24(wmad24(td, (unsigned)p.hH, th), (unsigned)p.hW, tw) * ROWB;
   };
   auto fetch16 = [&](WFrag<TPW>& f, int ks) {
     int m0 = ks * 16 + mq, m1 = m0 + 4;
@@ -177,10 +177,11 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
 #else
 #define CBIM_TICK(ph) ((void)0)
 #endif
+  // tile coordinates advanced incrementally (three scalar divisions per tile otherwise)
+  int ttd = t_begin / (p.tiles_w * p.tiles_h), tth = (t_begin / p.tiles_w) % p.tiles_h, ttw = t_begin % p.tiles_w;
   for (int t = t_begin; t < t_end; ++t) {
-    const int od0 = (t / (p.tiles_w * p.tiles_h)) * p.tD;
-    const int oh0 = ((t / p.tiles_w) % p.tiles_h) * p.tH;
-    const int ow0 = (t % p.tiles_w) * 8;
+    const int od0 = ttd * p.tD, oh0 = tth * p.tH, ow0 = ttw * 8;
+    if (++ttw == p.tiles_w) { ttw = 0; if (++tth == p.tiles_h) { tth = 0; ++ttd; } }
     const int id0 = od0 - p.pD, ih0 = oh0 - p.pH, iw0 = ow0 - p.pW;
     CBIM_TICK(0);
     __syncthreads();
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
     // ---- stage the dy tile (dense [BMv][32 co]) and the transformed input halo ([hV][32 ci]).  ALL global
     //      loads of the tile (UD + UA 16-byte chunks per thread) are issued before the first LDS store, addressed
     //      as wave-uniform tile pointer + 32-bit byte offset (24-bit multiply-adds, no 64-bit vector arithmetic) --
-    constexpr int UD = 4, UA = 10;
+    constexpr int UD = SLOTS * 256 / NT, UA = 10;   // dy tile: at most 256 voxels x SLOTS chunks, all prefetched
     const int d_items = BMv * SLOTS, a_items = hV * SLOTS;
     const unsigned dy_sb = (unsigned)(dy_from2 ? p.dy2_stride : p.dy_stride) * ES, x_sb = (unsigned)p.x_stride * ES;
     const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;

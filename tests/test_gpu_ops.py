@@ -49,6 +49,7 @@ def test_upcat(dev, dtype):
     (BF16, 1, 64, 128, (16, 16, 16), (3, 3, 3)),
     (BF16, 1, 320, 320, (8, 8, 8), (3, 3, 3)),
     (F32, 1, 32, 64, (16, 16, 16), (3, 3, 3)),
+    (F32, 1, 8, 16, (32, 32, 32), (3, 3, 3)),     # fp32 on the 4x8x8 wgrad tile (8 chunks per dy row)
 ])
 def test_conv(dev, dtype, N, Cin, Cout, dhw, k):
     oc.check_conv(dev, dtype, N, Cin, Cout, dhw, k)
