@@ -70,6 +70,12 @@ __device__ __forceinline__ unsigned wmad24(unsigned a, unsigned b, unsigned c) {
 #endif
 }
 
+#ifdef CBIM_EMU
+#define WG_SCHED_FENCE() ((void)0)
+#else
+#define WG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 template <int ACT> __device__ __forceinline__ float wg_actf(float x, int rt) {
   if (ACT == CBIM_ACT_RELU) return x > 0.f ? x : 0.f;
   if (ACT == CBIM_ACT_NONE) return x;
@@ -79,7 +85,9 @@ template <int ACT> __device__ __forceinline__ float wg_actf(float x, int rt) {
 template <int TPW> struct WFrag { u32x4 a; u32x4 b[TPW]; };   // bf16: 8 voxels x 1 channel per operand
 template <int TPW> struct WFragF { float a; float b[TPW]; };  // f32 : 1 voxel per operand
 
-template <typename T, int TPW, int ACT>
+// K3T: 3x3 taps per plane on the 4x8x8 tile (halo rows 10x10, bf16): every fragment address of the voxel loop is
+// a per-tile lane constant + an immediate, the 16 k-steps are unrolled and carry no vector-ALU address arithmetic
+template <typename T, int TPW, int ACT, bool K3T>
 __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int ES = Elem<T>::SIZE;
@@ -270,7 +278,41 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
     __syncthreads();
     CBIM_TICK(4);
     // ---- contraction over the tile's voxels, two k-steps per trip through static register sets --------------
-    if (IS_BF16) {
+    if (IS_BF16 && K3T) {
+      // lane bases: dy row mq, halo row (half, i16 >> 2) of the tile's first plane pair; k-step ks adds
+      // 16 dy rows and ((ks >> 2) * 10 + 2 * (ks & 3)) * 10 halo rows — compile-time immediates of the ds_read
+      const unsigned dyb = (unsigned)mq * ROWB + colb;
+      unsigned tb[TPW];
+#pragma unroll
+      for (int tl = 0; tl < TPW; ++tl) tb[tl] = aL + (unsigned)(half * 10 + (i16 >> 2)) * ROWB + colb + tapoff[tl];
+      auto fetchk = [&](WFrag<TPW>& f, int ks) {
+        const unsigned kc = (unsigned)(((ks >> 2) * 10 + 2 * (ks & 3)) * 10) * ROWB;
+        u32x2 a0 = lds_tr16_b64(smem + dyb + (unsigned)ks * 16 * ROWB);
+        u32x2 a1 = lds_tr16_b64(smem + dyb + (unsigned)ks * 16 * ROWB + 4 * ROWB);
+        f.a = u32x4{a0.x, a0.y, a1.x, a1.y};
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+          u32x2 b0 = lds_tr16_b64(smem + tb[tl] + kc);
+          u32x2 b1 = lds_tr16_b64(smem + tb[tl] + kc + 4 * ROWB);
+          f.b[tl] = u32x4{b0.x, b0.y, b1.x, b1.y};
+        }
+      };
+      // the fences pin "issue the next step's 16 transposed reads, THEN run this step's MFMAs": left alone the
+      // scheduler re-uses one B register set and every second MFMA waits for a read issued just before it
+      WFrag<TPW> f0, f1;
+      fetchk(f0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 16; ks += 2) {
+        fetchk(f1, ks + 1);
+        WG_SCHED_FENCE();
+        mma16(f0);
+        WG_SCHED_FENCE();
+        if (ks + 2 < 16) fetchk(f0, ks + 2);
+        WG_SCHED_FENCE();
+        mma16(f1);
+        WG_SCHED_FENCE();
+      }
+    } else if (IS_BF16) {
       const int nks = BMv / 16;   // even (BMv is 128 or 256)
       WFrag<TPW> f0, f1;
       fetch16(f0, 0);
@@ -378,18 +420,18 @@ extern "C" size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* d) {
   return (size_t)d->N * c.strips_per_n * taps * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
 }
 
-template <typename T, int TPW, int ACT>
+template <typename T, int TPW, int ACT, bool K3T = false>
 static int launch_wgrad(const WgradParams& p, dim3 grid, size_t smem, hipStream_t st) {
 #ifndef CBIM_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_wgrad<T, TPW, ACT>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_wgrad<T, TPW, ACT, K3T>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
 #endif
-  CBIM_LAUNCH((k_conv_wgrad<T, TPW, ACT>), grid, dim3(NT), smem, st, p);
+  CBIM_LAUNCH((k_conv_wgrad<T, TPW, ACT, K3T>), grid, dim3(NT), smem, st, p);
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv wgrad launch: %s", hipGetErrorString(e));
   return CBIM_OK;
@@ -401,6 +443,8 @@ static int dispatch_tpw(int taps, const WgradParams& p, dim3 grid, size_t smem, 
   if (tpw <= 1) return launch_wgrad<T, 1, ACT>(p, grid, smem, st);
   if (tpw <= 3) return launch_wgrad<T, 3, ACT>(p, grid, smem, st);
   if (tpw <= 5) return launch_wgrad<T, 5, ACT>(p, grid, smem, st);
+  if (sizeof(typename Elem<T>::type) == 2 && p.kH == 3 && p.kW == 3 && p.tD == 4 && p.tH == 8)
+    return launch_wgrad<T, 7, ACT, true>(p, grid, smem, st);
   return launch_wgrad<T, 7, ACT>(p, grid, smem, st);
 }
 
