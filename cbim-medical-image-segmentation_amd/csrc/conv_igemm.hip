@@ -169,7 +169,7 @@ template <int MT, int NTL> struct Frags { u32x4 a[MT]; u32x4 b[NTL]; };   // one
 // NTH = threads per workgroup: 512 (one persistent workgroup per CU) or 256 (two per CU, 4x8x8 tiles: the two
 // workgroups drift apart, so one's VALU-heavy halo/epilogue phases overlap the other's MFMA k-loop)
 template <typename T, int MT, int NTL, int ACT, bool K3, int NTH = 512>
-__global__ void __launch_bounds__(NTH) k_conv_igemm(IgemmParams p) {
+__global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmParams p) {
   constexpr int NT = NTH, NW = NTH / 64;
   constexpr int UH = NTH == 256 ? 10 : 8;   // halo prefetch quads per thread (6x10x10 rows x 4 slots / 256 threads)
   constexpr int CPC = Elem<T>::CPC;
