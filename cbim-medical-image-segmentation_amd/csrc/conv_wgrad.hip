@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
   int t_end = t_begin + p.tiles_per_strip;
   if (t_end > tiles_per_n) t_end = tiles_per_n;
 
+  const bool ksplit = TPW == 1 && p.taps == 1;   // wave-uniform
   // taps of this wave: tap = wave + 4*tl (clamped: out-of-range slots redo the last tap and are dropped)
   unsigned tapoff[TPW];
 #pragma unroll
@@ -313,23 +314,27 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
         WG_SCHED_FENCE();
       }
     } else if (IS_BF16) {
-      const int nks = BMv / 16;   // even (BMv is 128 or 256)
+      // a single tap (1x1x1 convs): the 4 waves split the voxel steps instead of repeating the tap, each writes
+      // its own slab (ksplit); otherwise every wave walks all steps for its own taps
+      const int nks = BMv / 16;   // multiple of 8 (BMv is 128 or 256)
+      const int k_lo = ksplit ? wave * (nks / 4) : 0, k_hi = ksplit ? k_lo + nks / 4 : nks;
       WFrag<TPW> f0, f1;
-      fetch16(f0, 0);
-      for (int ks = 0; ks < nks; ks += 2) {
+      fetch16(f0, k_lo);
+      for (int ks = k_lo; ks < k_hi; ks += 2) {
         fetch16(f1, ks + 1);
         mma16(f0);
-        if (ks + 2 < nks) fetch16(f0, ks + 2);
+        if (ks + 2 < k_hi) fetch16(f0, ks + 2);
         mma16(f1);
       }
     } else {
       const int nks = BMv / 2;
+      const int k_lo = ksplit ? wave * (nks / 4) : 0, k_hi = ksplit ? k_lo + nks / 4 : nks;
       WFragF<TPW> f0, f1;
-      fetch32(f0, 0);
-      for (int ks = 0; ks < nks; ks += 2) {
+      fetch32(f0, k_lo);
+      for (int ks = k_lo; ks < k_hi; ks += 2) {
         fetch32(f1, ks + 1);
         mma32(f0);
-        if (ks + 2 < nks) fetch32(f0, ks + 2);
+        if (ks + 2 < k_hi) fetch32(f0, ks + 2);
         mma32(f1);
       }
     }
@@ -342,10 +347,10 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
 #endif
   // ---- write this strip's slab: ws[(n*strips+strip)][tap][Cout_pad][Cin_pad] -------------------------------------
   const size_t slab = (size_t)p.taps * p.Cout_pad * p.Cin_pad;
-  float* wsb = p.ws + (size_t)blockIdx.x * slab;
+  float* wsb = p.ws + (ksplit ? (size_t)blockIdx.x * 4 + wave : (size_t)blockIdx.x) * slab;
 #pragma unroll
   for (int tl = 0; tl < TPW; ++tl) {
-    int tap = wave + 4 * tl;
+    int tap = ksplit ? 0 : wave + 4 * tl;
     if (tap < p.taps) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -400,7 +405,7 @@ static WgCfg wg_cfg(const cbim_conv_desc* d) {
   if (want < 1) want = 1;
   if (want > tiles_per_n) want = tiles_per_n;
   int taps = d->kD * d->kH * d->kW;
-  size_t slab = (size_t)taps * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
+  size_t slab = (size_t)(taps == 1 ? 4 : taps) * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
   int64_t cap = (int64_t)((64ull << 20) / (slab * d->N));   // cap the slab workspace at ~64 MiB
   if (cap < 1) cap = 1;
   if (want > cap) want = cap;
@@ -417,7 +422,8 @@ extern "C" size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* d) {
   if (!d) return 0;
   WgCfg c = wg_cfg(d);
   int taps = d->kD * d->kH * d->kW;
-  return (size_t)d->N * c.strips_per_n * taps * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
+  // one tap: each of the 4 waves writes its own slab (they split the voxel loop)
+  return (size_t)d->N * c.strips_per_n * (taps == 1 ? 4 : taps) * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
 }
 
 template <typename T, int TPW, int ACT, bool K3T = false>
@@ -525,7 +531,7 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   int64_t blocks = (total + NT - 1) / NT;
   if (blocks > 4096) blocks = 4096;
   CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, st, (const float*)workspace, dw,
-              d->N * c.strips_per_n, taps, d->Cout, d->Cin, p.Cout_pad, p.Cin_pad, total);
+              d->N * c.strips_per_n * (taps == 1 ? 4 : 1), taps, d->Cout, d->Cin, p.Cout_pad, p.Cin_pad, total);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
