@@ -276,13 +276,14 @@ def main():
         # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run
         # inside this process); null when no recorded pass covers this kernel / dtype / model
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in ("r01_j_traffic.json", "r01_c_traffic.json"))
+                      if os.path.isfile(q)), "")
         if args.model == "resunet" and args.size == 128 and os.path.isfile(tpath):
             traffic = (json.load(open(tpath)).get(dom) or {}).get("hbm_bytes_per_launch")
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": f / tsec / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": f / tsec / 1e12 / peak, "traffic": traffic,
-            "traffic_source": "profiles/r01_c_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)"
+            "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)" % os.path.basename(tpath)
                               if traffic else None,
             "alg_flops_per_launch": f / nl, "avg_launch_ms": tsec / nl * 1e3,
             "step_flops": step_flops, "step_achieved": step_flops / (ms * 1e-3) / 1e12,
