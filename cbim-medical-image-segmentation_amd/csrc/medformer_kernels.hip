@@ -544,23 +544,38 @@ __global__ void __launch_bounds__(AT) k_attn_fwd(const void* __restrict__ qv, in
 }
 
 // merge the per-block records: map_out[n][j][d*heads+h], colstat[n][h][j] = (max, sum)
-__global__ void __launch_bounds__(64) k_attn_merge(const float* __restrict__ part, float* __restrict__ map_out,
-                                                   float* __restrict__ colstat, int heads, int M, int DH, int nblk) {
-  // one 64-thread block per (n, h, code j): thread d owns one output channel
+__global__ void __launch_bounds__(256) k_attn_merge(const float* __restrict__ part, float* __restrict__ map_out,
+                                                    float* __restrict__ colstat, int heads, int M, int DH, int nblk) {
+  // one 256-thread block per (n, h, code j): thread (g, d) = (record group, output channel).  The 8 groups walk
+  // interleaved records (the matrix-core path writes one record per 32 voxels: 1024 of them at 32^3), partial
+  // results are combined through LDS in group order — deterministic.
+  __shared__ float mx_s[8], S_s[8], A_s[8][33];
   const int j = blockIdx.x % M, h = (blockIdx.x / M) % heads, n = blockIdx.x / (M * heads);
   const int inner = heads * DH;
+  const int d = threadIdx.x & 31, g = threadIdx.x >> 5;
   const float* base = part + ((size_t)n * heads + h) * nblk * M * (DH + 2);
-  for (int d = threadIdx.x; d < DH; d += 64) {
-    float mx = -INFINITY;
-    for (int b = 0; b < nblk; ++b) mx = fmaxf(mx, base[((size_t)b * M + j) * (DH + 2)]);
-    float S = 0.f, A = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-      const float* p = base + ((size_t)b * M + j) * (DH + 2);
-      float sc = expf(p[0] - mx);
-      S += p[1] * sc;
-      A += p[2 + d] * sc;
-    }
-    map_out[((size_t)n * M + j) * inner + d * heads + h] = A / S;
+  float mx = -INFINITY;
+  for (int b = g; b < nblk; b += 8) mx = fmaxf(mx, base[((size_t)b * M + j) * (DH + 2)]);
+  if (d == 0) mx_s[g] = mx;
+  __syncthreads();
+  mx = mx_s[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) mx = fmaxf(mx, mx_s[i]);
+  float S = 0.f, A = 0.f;
+  for (int b = g; b < nblk; b += 8) {
+    const float* p = base + ((size_t)b * M + j) * (DH + 2);
+    float sc = expf(p[0] - mx);
+    S += p[1] * sc;
+    if (d < DH) A += p[2 + d] * sc;
+  }
+  if (d == 0) S_s[g] = S;
+  A_s[g][d] = A;
+  __syncthreads();
+  if (g == 0) {
+    S = S_s[0]; A = A_s[0][d];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { S += S_s[i]; A += A_s[i][d]; }
+    if (d < DH) map_out[((size_t)n * M + j) * inner + d * heads + h] = A / S;
     if (d == 0) {
       colstat[(((size_t)n * heads + h) * M + j) * 2] = mx;
       colstat[(((size_t)n * heads + h) * M + j) * 2 + 1] = S;
@@ -697,8 +712,15 @@ __global__ void __launch_bounds__(NT) k_attn_bwd_reduce(const float* __restrict_
   const float* base = part + ((size_t)n * heads + h) * nblk * 2 * M * DH;
   for (int idx = blockIdx.y * NT + threadIdx.x; idx < 2 * M * DH; idx += gridDim.y * NT) {
     int st = idx / (M * DH), j = (idx / DH) % M, d = idx % DH;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += base[(size_t)b * 2 * M * DH + idx];
+    // 8 independent chains keep 8 loads in flight (a single chain pays the full memory latency per record);
+    // fixed association -> deterministic
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 7 < nblk; b += 8)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s8[i] += base[(size_t)(b + i) * 2 * M * DH + idx];
+    for (; b < nblk; ++b) s8[0] += base[(size_t)b * 2 * M * DH + idx];
+    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     (st == 0 ? dmv : dmq)[((size_t)n * M + j) * inner + d * heads + h] = s;
   }
 }
@@ -808,6 +830,45 @@ __global__ void __launch_bounds__(AT) k_mappool_bwd(const void* __restrict__ fw,
   if (!valid) return;
   const size_t row = ((size_t)n * L + l) * rs, drow = ((size_t)n * L + l) * drs;
   float P[MM], tt[MM];
+  constexpr int CPC = Elem<T>::CPC;
+  // whole 16-byte channel chunks in and out (2-byte element stores are read-modify-write in the memory system and
+  // made this kernel 5x slower); element-wise only for code counts that are not a multiple of the chunk
+  const bool chunked = (M % CPC) == 0 && (C % CPC) == 0 && (rs % CPC) == 0 && (drs % CPC) == 0;
+  if (chunked) {
+#pragma unroll
+    for (int j0 = 0; j0 < MM; j0 += CPC) {
+      float f[CPC];
+      if (j0 < M) Elem<T>::unpack(ld_chunk<T>(fw, row + C + j0), f);
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) {
+        P[j0 + j] = j0 < M ? expf(f[j] - colstat[((size_t)n * M + j0 + j) * 2]) / colstat[((size_t)n * M + j0 + j) * 2 + 1] : 0.f;
+        tt[j0 + j] = 0.f;
+      }
+    }
+    for (int c0 = 0; c0 < C; c0 += CPC) {
+      float f[CPC], g[CPC];
+      Elem<T>::unpack(ld_chunk<T>(fw, row + c0), f);
+#pragma unroll
+      for (int k = 0; k < CPC; ++k) {
+        const float* dm = dmap + ((size_t)n * C + c0 + k) * M;
+        float gsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < MM; ++j)
+          if (j < M) { tt[j] += f[k] * dm[j]; gsum += P[j] * dm[j]; }
+        g[k] = gsum;
+      }
+      st_chunk<T>(dfw, drow + c0, Elem<T>::pack(g));
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < MM; j0 += CPC)
+      if (j0 < M) {
+        float g[CPC];
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) g[j] = P[j0 + j] * (tt[j0 + j] - cj[j0 + j]);
+        st_chunk<T>(dfw, drow + C + j0, Elem<T>::pack(g));
+      }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MM; ++j) {
     P[j] = j < M ? expf(Elem<T>::load1(fw, row + C + j) - colstat[((size_t)n * M + j) * 2]) /
@@ -1043,7 +1104,7 @@ extern "C" int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride,
     ATTN_DISPATCH(k_attn_fwd, grid, st, qv, qv_stride, mq, mv, feat_out, (float*)workspace, L, heads, M, scale, nblk);
     if (int e = launch_ok("bidir_attn_fwd")) return e;
   }
-  CBIM_LAUNCH(k_attn_merge, dim3(N * heads * M), dim3(64), 0, st, (const float*)workspace, map_out, colstat, heads, M,
+  CBIM_LAUNCH(k_attn_merge, dim3(N * heads * M), dim3(256), 0, st, (const float*)workspace, map_out, colstat, heads, M,
               dh, nblk);
   return launch_ok("bidir_attn_merge");
 }
