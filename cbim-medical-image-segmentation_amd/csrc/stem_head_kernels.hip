@@ -82,12 +82,15 @@ __global__ void __launch_bounds__(NT) k_stem_fwd(StemParams p) {
 // dw[co][ci][tap] = sum_v dy[v][co] * x[v+tap-p][ci]; thread = (co lane, row group); a thread walks whole
 // 8-voxel W rows so each halo value it reads from LDS feeds up to kW FMAs (LDS reads per FMA ~0.4);
 // strip of tiles per workgroup; per-strip slab [Cin][taps][Cout] then a fixed-order reduce.
-template <typename T>
+// CG input channels share one pass over dy (multi-modal inputs: dy is 48 bf16 channels x 128^3 = 201 MB, read once
+// instead of once per input channel).
+template <typename T, int CG>
 __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
   CBIM_DYN_SMEM(smem);
   const int hV = p.hD * p.hH * p.hW;
-  float* xL = (float*)smem;                           // [hV]
-  float* red = xL + ((hV + 3) & ~3);                  // [NT/32 groups][MAXTAPS][32]
+  const int hVp = (hV + 3) & ~3;
+  float* xL = (float*)smem;                           // [CG][hVp]
+  float* red = xL + CG * hVp;                         // [NT/32 groups][MAXTAPS][32]
   const int tid = threadIdx.x, col = tid & 31, vg = tid >> 5;   // 8 row groups
   const int n = blockIdx.x / p.strips_per_n, strip = blockIdx.x % p.strips_per_n;
   const int cob = blockIdx.y;   // block of 32 couts
@@ -98,20 +101,23 @@ __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
   if (t_end > tiles_per_n) t_end = tiles_per_n;
   const size_t Sin = (size_t)p.Di * p.Hi * p.Wi;
   const size_t slab = (size_t)p.Cin * p.taps * p.Cout;
-  for (int ci = 0; ci < p.Cin; ++ci) {
-    float acc[MAXTAPS];
+  for (int ci0 = 0; ci0 < p.Cin; ci0 += CG) {
+    float acc[CG][MAXTAPS];
 #pragma unroll
-    for (int k = 0; k < MAXTAPS; ++k) acc[k] = 0.f;
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+      for (int k = 0; k < MAXTAPS; ++k) acc[c][k] = 0.f;
     for (int t = t_begin; t < t_end; ++t) {
       const int od0 = (t / (p.tiles_w * p.tiles_h)) * 4, oh0 = ((t / p.tiles_w) % p.tiles_h) * 8, ow0 = (t % p.tiles_w) * 8;
       __syncthreads();
       for (int hv = tid; hv < hV; hv += NT) {
         int hw = hv % p.hW, r = hv / p.hW, hh = r % p.hH, hd = r / p.hH;
         int id = od0 - p.pD + hd, ih = oh0 - p.pH + hh, iw = ow0 - p.pW + hw;
-        float v = 0.f;
-        if (id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi)
-          v = p.x[((size_t)n * p.Cin + ci) * Sin + ((size_t)id * p.Hi + ih) * p.Wi + iw];
-        xL[hv] = v;
+        const bool in = id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+          xL[c * hVp + hv] = (in && ci0 + c < p.Cin)
+                                 ? p.x[((size_t)n * p.Cin + ci0 + c) * Sin + ((size_t)id * p.Hi + ih) * p.Wi + iw] : 0.f;
       }
       __syncthreads();
       for (int rowi = vg; rowi < 32; rowi += 8) {      // rows (td, th) of the 4x8x8 tile
@@ -128,22 +134,25 @@ __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
         }
         // static 3x3x3 tap lattice (extents <= 3 per axis, guarded): accumulator indices stay compile-time
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd) {
-          if (kd < p.kD) {
+        for (int c = 0; c < CG; ++c) {
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-              if (kh < p.kH) {
-                const float* xr = xL + ((td + kd) * p.hH + th + kh) * p.hW;
-                float xv[10];
+          for (int kd = 0; kd < 3; ++kd) {
+            if (kd < p.kD) {
 #pragma unroll
-                for (int i = 0; i < 10; ++i) xv[i] = i < 8 + p.kW - 1 ? xr[i] : 0.f;
+              for (int kh = 0; kh < 3; ++kh) {
+                if (kh < p.kH) {
+                  const float* xr = xL + c * hVp + ((td + kd) * p.hH + th + kh) * p.hW;
+                  float xv[10];
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                  if (kw < p.kW) {
-                    float a = acc[(kd * 3 + kh) * 3 + kw];
+                  for (int i = 0; i < 10; ++i) xv[i] = i < 8 + p.kW - 1 ? xr[i] : 0.f;
 #pragma unroll
-                    for (int w8 = 0; w8 < 8; ++w8) a = fmaf(g[w8], xv[w8 + kw], a);
-                    acc[(kd * 3 + kh) * 3 + kw] = a;
+                  for (int kw = 0; kw < 3; ++kw) {
+                    if (kw < p.kW) {
+                      float a = acc[c][(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+                      for (int w8 = 0; w8 < 8; ++w8) a = fmaf(g[w8], xv[w8 + kw], a);
+                      acc[c][(kd * 3 + kh) * 3 + kw] = a;
+                    }
                   }
                 }
               }
@@ -152,15 +161,20 @@ __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
         }
       }
     }
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < MAXTAPS; ++k) red[(vg * MAXTAPS + k) * 32 + col] = acc[k];
-    __syncthreads();
-    for (int i = tid; i < p.taps * 32; i += NT) {
-      int c = i & 31, k = i >> 5;
-      float a = 0.f;
-      for (int g = 0; g < 8; ++g) a += red[(g * MAXTAPS + k) * 32 + c];
-      if (cob * 32 + c < p.Cout) p.ws[(size_t)blockIdx.x * slab + ((size_t)ci * p.taps + k) * p.Cout + cob * 32 + c] = a;
+    for (int c = 0; c < CG; ++c) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < MAXTAPS; ++k) red[(vg * MAXTAPS + k) * 32 + col] = acc[c][k];
+      __syncthreads();
+      if (ci0 + c < p.Cin)
+        for (int i = tid; i < p.taps * 32; i += NT) {
+          int cc = i & 31, k = i >> 5;
+          float a = 0.f;
+          for (int g = 0; g < 8; ++g) a += red[(g * MAXTAPS + k) * 32 + cc];
+          if (cob * 32 + cc < p.Cout)
+            p.ws[(size_t)blockIdx.x * slab + ((size_t)(ci0 + c) * p.taps + k) * p.Cout + cob * 32 + cc] = a;
+        }
     }
   }
 }
@@ -431,11 +445,18 @@ extern "C" int cbim_stem_conv_wgrad(int dtype, const float* x, const void* dy, f
   StemParams p;
   p.x = x; p.w = nullptr; p.y = nullptr; p.dy = dy; p.ws = (float*)workspace;
   stem_fill(p, N, Cin, Di, Hi, Wi, Cout, kD, kH, kW, pD, pH, pW, Do, Ho, Wo);
-  size_t smem = ((((size_t)p.hD * p.hH * p.hW + 3) & ~(size_t)3) + (size_t)(NT / 32) * MAXTAPS * 32) * sizeof(float);
+  const int cg = Cin >= 2 ? 4 : 1;   // input channels sharing one pass over dy
+  size_t smem = ((((size_t)p.hD * p.hH * p.hW + 3) & ~(size_t)3) * cg + (size_t)(NT / 32) * MAXTAPS * 32) * sizeof(float);
+  CBIM_CHECK(smem <= 64 * 1024, CBIM_EUNSUPPORTED, "stem wgrad needs %zu B of LDS", smem);
   dim3 grid((unsigned)(N * p.strips_per_n), (unsigned)((Cout + 31) / 32));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CBIM_BF16) CBIM_LAUNCH((k_stem_wgrad<bf16_tag>), grid, dim3(NT), smem, st, p);
-  else CBIM_LAUNCH((k_stem_wgrad<float>), grid, dim3(NT), smem, st, p);
+  if (dtype == CBIM_BF16) {
+    if (cg == 4) CBIM_LAUNCH((k_stem_wgrad<bf16_tag, 4>), grid, dim3(NT), smem, st, p);
+    else CBIM_LAUNCH((k_stem_wgrad<bf16_tag, 1>), grid, dim3(NT), smem, st, p);
+  } else {
+    if (cg == 4) CBIM_LAUNCH((k_stem_wgrad<float, 4>), grid, dim3(NT), smem, st, p);
+    else CBIM_LAUNCH((k_stem_wgrad<float, 1>), grid, dim3(NT), smem, st, p);
+  }
   int total = Cin * p.taps * Cout;
   CBIM_LAUNCH(k_stem_wgrad_reduce, dim3((total + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw,
               N * p.strips_per_n, Cin, p.taps, Cout);

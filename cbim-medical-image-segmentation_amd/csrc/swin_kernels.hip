@@ -278,15 +278,26 @@ __global__ void __launch_bounds__(256) k_winattn_reduce(const float* __restrict_
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i < TS * heads) {
     int h = i % heads, e = i / heads;
-    float acc = 0.f;
-    for (int w = 0; w < nwin; ++w) acc += part_tbl[((size_t)w * heads + h) * TS + e];
-    dtable[i] = acc;
+    // 8 independent chains in fixed association (a single chain pays one memory latency per window)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = 0;
+    for (; w + 7 < nwin; w += 8)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a8[q] += part_tbl[((size_t)(w + q) * heads + h) * TS + e];
+    for (; w < nwin; ++w) a8[0] += part_tbl[((size_t)w * heads + h) * TS + e];
+    dtable[i] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   }
   if (i < 3 * C) {
     float acc = 0.f;
     if (i >= C) {
       int kv = i / C - 1, h = (i % C) / DH, d = i % DH;
-      for (int w = 0; w < nwin; ++w) acc += part_pad[(((size_t)w * heads + h) * 2 + kv) * DH + d];
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};
+      int w = 0;
+      for (; w + 3 < nwin; w += 4)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] += part_pad[(((size_t)(w + q) * heads + h) * 2 + kv) * DH + d];
+      for (; w < nwin; ++w) a4[0] += part_pad[(((size_t)w * heads + h) * 2 + kv) * DH + d];
+      acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     dbias[i] = acc;
   }

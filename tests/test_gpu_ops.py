@@ -59,6 +59,7 @@ def test_conv(dev, dtype, N, Cin, Cout, dhw, k):
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
     oc.check_stem_head(dev, dtype, Cin=1, base=32, K=16, dhw=(16, 32, 32))
+    oc.check_stem_head(dev, dtype, Cin=5, base=8, K=3, dhw=(4, 8, 9))     # two channel groups in the stem wgrad
 
 
 def test_loss(dev):

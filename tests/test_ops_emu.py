@@ -92,6 +92,7 @@ def test_trilinear_planes(dev):
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
     oc.check_stem_head(dev, dtype, Cin=1, base=16, K=3, dhw=(4, 8, 8), k=(1, 3, 3))
+    oc.check_stem_head(dev, dtype, Cin=5, base=8, K=3, dhw=(4, 8, 9))     # two channel groups in the stem wgrad
 
 
 def test_loss(dev):
