@@ -10,7 +10,8 @@ Execution split:
     (``functional.WindowAttnFn``);
   * the token-wise Linear layers (qkv, proj, MLP, patch merging/embedding) are plain library GEMMs
     (torch ``F.linear`` -> hipBLASLt), LayerNorm/GELU/residual adds are torch elementwise ops on the
-    channels-last token tensors.  The transformer trunk runs in fp32 in both engine modes.
+    channels-last token tensors.  The residual stream and LayerNorm of the trunk stay fp32; in the bf16 engine mode the
+    Linears, GELU and the window-attention kernel of each block run in bf16 (torch.autocast, as the reference under AMP).
 forward(x[B,C,D,H,W] fp32 NCDHW) -> logits[B,classes,D,H,W] fp32.
 """
 import itertools
@@ -18,6 +19,8 @@ import itertools
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+import os
 
 from ... import functional as Fn
 from ...ops import ACT
@@ -135,6 +138,9 @@ class PatchEmbed(nn.Module):
         return F.linear(x.reshape(B, D // p[0], H // p[1], W // p[2], -1), self.proj.weight.flatten(1), self.proj.bias)
 
 
+_TRUNK_AMP = os.environ.get("CBIM_SWIN_TRUNK_AMP", "1") != "0"
+
+
 class MLPBlock(nn.Module):
     def __init__(self, hidden_size, mlp_dim):
         super().__init__()
@@ -192,8 +198,12 @@ class SwinTransformerBlock(nn.Module):
         dims = tuple(x.shape[1:4])
         ws = tuple(d if d <= w else w for d, w in zip(dims, self.window_size))            # get_window_size (:358-381)
         ss = tuple(0 if d <= w else s for d, w, s in zip(dims, self.window_size, self.shift_size))
-        x = x + self.attn(self.norm1(x), ws, ss)
-        return x + self.mlp(self.norm2(x))
+        # bf16 engine mode: the token Linears (qkv, proj, MLP), GELU and the window-attention kernel run in bf16 like
+        # the reference under AMP (LayerNorm and the residual stream stay fp32); fp32 mode is untouched
+        amp = x.is_cuda and Fn.compute_dtype() == torch.bfloat16 and _TRUNK_AMP
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            x = x + self.attn(self.norm1(x), ws, ss)
+            return x + self.mlp(self.norm2(x))
 
 
 class PatchMerging(nn.Module):
