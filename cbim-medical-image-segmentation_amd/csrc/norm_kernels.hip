@@ -54,9 +54,11 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
   }
   if (active) {
     const size_t nb = (size_t)n * S;
-    for (int64_t v = v0 + vl; v < v1; v += vlc) {
+    // two rows per trip: both rows' loads are issued before either is consumed (one load pair in flight per trip
+    // left this streaming kernel latency bound); rows are accumulated in the same order as a one-row loop
+    auto accumulate = [&](const u32x4& ra, const u32x4& rx) {
       float fa[CPC];
-      Elem<T>::unpack(ld_chunk<T>(a, (nb + v) * a_stride + c_off + (size_t)cc * CPC), fa);
+      Elem<T>::unpack(ra, fa);
       if (MODE == 0) {
         if (cnt == 0.f) {
 #pragma unroll
@@ -67,7 +69,7 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
         for (int j = 0; j < CPC; ++j) { float d = fa[j] - shift[j]; s0[j] += d; s1[j] += d * d; }
       } else {
         float fx[CPC];
-        Elem<T>::unpack(ld_chunk<T>(x, (nb + v) * x_stride + c_off + (size_t)cc * CPC), fx);
+        Elem<T>::unpack(rx, fx);
 #pragma unroll
         for (int j = 0; j < CPC; ++j) {
           float xh = (fx[j] - mean[j]) * rstd[j];
@@ -76,6 +78,19 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
           s1[j] += g * xh;
         }
       }
+    };
+    for (int64_t v = v0 + vl; v < v1; v += 2 * vlc) {
+      const bool two = v + vlc < v1;
+      const int64_t vb = two ? v + vlc : v;
+      const u32x4 a0 = ld_chunk<T>(a, (nb + v) * a_stride + c_off + (size_t)cc * CPC);
+      const u32x4 a1 = ld_chunk<T>(a, (nb + vb) * a_stride + c_off + (size_t)cc * CPC);
+      u32x4 x0 = a0, x1 = a1;
+      if (MODE == 1) {
+        x0 = ld_chunk<T>(x, (nb + v) * x_stride + c_off + (size_t)cc * CPC);
+        x1 = ld_chunk<T>(x, (nb + vb) * x_stride + c_off + (size_t)cc * CPC);
+      }
+      accumulate(a0, x0);
+      if (two) accumulate(a1, x1);
     }
   }
   // reduce over the voxel lanes through LDS (fixed order -> deterministic)
@@ -483,12 +498,22 @@ extern "C" int cbim_runtime_warmup(void* stream) {
 }
 
 extern "C" int cbim_stats_parts(int64_t S, int C) {
-  // one workgroup per part: >= 64 voxels each, up to 1024 parts (low-resolution layers would otherwise launch
-  // a few dozen workgroups on 256 CUs); wide tensors (few voxel lanes per workgroup) keep parts larger
-  int64_t per = C >= 1024 ? 256 : 64;
+  // one workgroup per part.  A workgroup has 256 / (C/8) voxel lanes: a wide tensor (C = 1024 -> 2 lanes) with
+  // 256-voxel parts ran 128 dependent trips in 128 workgroups — 253 GB/s.  Parts are sized for ~16 trips per
+  // lane and at least ~1024 workgroups where the volume allows, at most 4096 parts (12 bytes per part and channel)
+  if (C < 512) {   // many voxel lanes per workgroup: 64-voxel parts, up to 1024 of them
+    int64_t q = (S + 63) / 64;
+    return (int)(q < 1 ? 1 : (q > 1024 ? 1024 : q));
+  }
+  int64_t lanes = 256 / (C / 8 > 0 ? (C / 8 < 256 ? C / 8 : 256) : 1);
+  if (lanes < 1) lanes = 1;
+  int64_t per = lanes * 16;
+  if (per < 16) per = 16;
+  if (per > 256) per = 256;
+  while (per > 16 && (S + per - 1) / per < 1024) per /= 2;
   int64_t p = (S + per - 1) / per;
   if (p < 1) p = 1;
-  if (p > 1024) p = 1024;
+  if (p > 4096) p = 4096;
   return (int)p;
 }
 
