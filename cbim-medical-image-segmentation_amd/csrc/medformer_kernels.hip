@@ -391,32 +391,75 @@ __global__ void __launch_bounds__(NT) k_dwconv3_wgrad_lds(const void* __restrict
     for (int j = 0; j < CPC; ++j) g_s[((size_t)v * WG_CH + cl) * CPC + j] = f[j];
   }
   __syncthreads();
-  const int cl = threadIdx.x / 27, tap = threadIdx.x % 27;
-  if (cl >= G) return;
-  const int a = tap / 9, b = (tap / 3) % 3, c = tap % 3;
-  float acc[CPC];
+  // thread = (channel chunk, (kd,kh) pair, row third): the three kw taps of a pair share every dy value and slide
+  // over the same x row — one x chunk and one dy chunk are read from LDS per 24 multiply-adds (one read pair per 8
+  // before: the kernel was LDS-bandwidth bound at 253 GB/s of HBM traffic); the three row thirds are added at the end
+  const int cl = threadIdx.x / 27, rem = threadIdx.x % 27;
+  const int ab = rem / 3, rs = rem % 3;
+  const int ka = ab / 3, kb = ab % 3;
+  const bool active = cl < G;
+  float acc[3][CPC];
 #pragma unroll
-  for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
-  for (int r = 0; r < TH; ++r) {
-    const float* xr = x_s + ((size_t)((a * hH + r + b) * hW + c) * WG_CH + cl) * CPC;
-    const float* gr = g_s + ((size_t)(r * W) * WG_CH + cl) * CPC;
-    for (int w = 0; w < W; ++w) {
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int j = 0; j < CPC; ++j) acc[j] += xr[(size_t)w * WG_CH * CPC + j] * gr[(size_t)w * WG_CH * CPC + j];
+    for (int j = 0; j < CPC; ++j) acc[c][j] = 0.f;
+  if (active) {
+    for (int r = rs; r < TH; r += 3) {
+      const float* xr = x_s + ((size_t)((ka * hH + r + kb) * hW) * WG_CH + cl) * CPC;
+      const float* gr = g_s + ((size_t)(r * W) * WG_CH + cl) * CPC;
+      float x0[CPC], x1[CPC];
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) { x0[j] = xr[j]; x1[j] = xr[(size_t)WG_CH * CPC + j]; }
+      for (int w = 0; w < W; ++w) {
+        float x2[CPC], g[CPC];
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          x2[j] = xr[(size_t)(w + 2) * WG_CH * CPC + j];
+          g[j] = gr[(size_t)w * WG_CH * CPC + j];
+        }
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          acc[0][j] += x0[j] * g[j];
+          acc[1][j] += x1[j] * g[j];
+          acc[2][j] += x2[j] * g[j];
+          x0[j] = x1[j];
+          x1[j] = x2[j];
+        }
+      }
     }
   }
-  const int c0 = (g0 + cl) * CPC;
+  __syncthreads();                       // x_s is dead: reuse it for the row-third partials [NT][3][CPC]
+  float* red = x_s;
 #pragma unroll
-  for (int j = 0; j < CPC; ++j) part[((size_t)tile * C + c0 + j) * 27 + tap] = acc[j];
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) red[((size_t)threadIdx.x * 3 + c) * CPC + j] = acc[c][j];
+  __syncthreads();
+  if (active && rs == 0) {
+    const int c0 = (g0 + cl) * CPC;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) {
+        const float v = (red[((size_t)threadIdx.x * 3 + c) * CPC + j] + red[((size_t)(threadIdx.x + 1) * 3 + c) * CPC + j]) +
+                        red[((size_t)(threadIdx.x + 2) * 3 + c) * CPC + j];
+        part[((size_t)tile * C + c0 + j) * 27 + ab * 3 + c] = v;
+      }
+  }
 }
 
 __global__ void __launch_bounds__(NT) k_dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
                                                             int nblk, int CT) {
   int i = blockIdx.x * NT + threadIdx.x;
   if (i >= CT) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * CT + i];
-  dw[i] = s;
+  // 8 independent chains, fixed association (one chain = one memory latency per slab)
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 7 < nblk; b += 8)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s8[q] += part[(size_t)(b + q) * CT + i];
+  for (; b < nblk; ++b) s8[0] += part[(size_t)b * CT + i];
+  dw[i] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
 }
 
 // ---- PatchMerging gather ---------------------------------------------------------------------------
@@ -952,7 +995,9 @@ static int dw3_lds_th(int H, int W, int cpc) {
   return th;   // < 1: does not fit, use the streaming kernel
 }
 static size_t dw3_lds_bytes(int W, int TH, int cpc) {
-  return ((size_t)3 * (TH + 2) * (W + 2) + (size_t)TH * W) * WG_CH * cpc * 4;
+  size_t b = ((size_t)3 * (TH + 2) * (W + 2) + (size_t)TH * W) * WG_CH * cpc * 4;
+  const size_t red = (size_t)NT * 3 * cpc * 4;     // row-third partials re-use the front of the buffer
+  return b > red ? b : red;
 }
 
 // kW == 3 path: rows (n,d,h) per block so that ~1024 blocks exist, at least 8 rows each
