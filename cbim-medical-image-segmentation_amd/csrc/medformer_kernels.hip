@@ -176,11 +176,13 @@ __global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int6
   const int strips = (W + WT - 1) / WT;
   const int64_t total = (int64_t)N * D * H * strips;
   for (int64_t it = (int64_t)blockIdx.x * SL + sl; it < total; it += (int64_t)gridDim.x * SL) {
-    int64_t r = it;
-    const int w0 = (int)(r % strips) * WT; r /= strips;
-    const int ho = (int)(r % H); r /= H;
-    const int dz = (int)(r % D);
-    const int64_t n = r / D;
+    // 32-bit index decode (the host checks total < 2^31; 64-bit divisions by run-time values cost ~150
+    // instructions each, four of them per 864 multiply-adds)
+    unsigned r = (unsigned)it;
+    const int w0 = (int)(r % (unsigned)strips) * WT; r /= (unsigned)strips;
+    const int ho = (int)(r % (unsigned)H); r /= (unsigned)H;
+    const int dz = (int)(r % (unsigned)D);
+    const int64_t n = r / (unsigned)D;
     float mean[CPC], rstd[CPC], bs[CPC], acc[WT][CPC];
 #pragma unroll
     for (int j = 0; j < CPC; ++j) {
@@ -197,12 +199,15 @@ __global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int6
         const int hh = ho + b - pH;
         if (hh < 0 || hh >= H) continue;
         const size_t rbase = (((size_t)n * D + dd) * H + hh) * W;
+        // one 64-bit row pointer per (kd,kh); the WT+2 chunks are xs elements apart
+        const unsigned char* rp = (const unsigned char*)x + ((int64_t)(rbase + w0 - 1) * xs + c0) * (int64_t)Elem<T>::SIZE;
+        const unsigned xsb = (unsigned)xs * Elem<T>::SIZE;
         float in[WT + 2][CPC];
 #pragma unroll
         for (int q = 0; q < WT + 2; ++q) {
           const int ww = w0 - 1 + q;
           if (ww >= 0 && ww < W) {
-            Elem<T>::unpack(ld_chunk<T>(x, (rbase + ww) * xs + c0), in[q]);
+            Elem<T>::unpack(*(const u32x4*)(rp + (size_t)q * xsb), in[q]);
 #pragma unroll
             for (int j = 0; j < CPC; ++j) {
               float v = in[q][j];
@@ -870,8 +875,7 @@ __global__ void __launch_bounds__(AT) k_mappool_bwd(const void* __restrict__ fw,
     cj[t] = c;
   }
   __syncthreads();
-  if (!valid) return;
-  const size_t row = ((size_t)n * L + l) * rs, drow = ((size_t)n * L + l) * drs;
+  const size_t row = ((size_t)n * L + (valid ? l : 0)) * rs, drow = ((size_t)n * L + (valid ? l : 0)) * drs;
   float P[MM], tt[MM];
   constexpr int CPC = Elem<T>::CPC;
   // whole 16-byte channel chunks in and out (2-byte element stores are read-modify-write in the memory system and
@@ -888,20 +892,23 @@ __global__ void __launch_bounds__(AT) k_mappool_bwd(const void* __restrict__ fw,
         tt[j0 + j] = 0.f;
       }
     }
-    for (int c0 = 0; c0 < C; c0 += CPC) {
-      float f[CPC], g[CPC];
-      Elem<T>::unpack(ld_chunk<T>(fw, row + c0), f);
+    if (valid) {
+      for (int c0 = 0; c0 < C; c0 += CPC) {
+        float f[CPC], g[CPC];
+        Elem<T>::unpack(ld_chunk<T>(fw, row + c0), f);
 #pragma unroll
-      for (int k = 0; k < CPC; ++k) {
-        const float* dm = dmap + ((size_t)n * C + c0 + k) * M;
-        float gsum = 0.f;
+        for (int k = 0; k < CPC; ++k) {
+          const float* dm = dmap + ((size_t)n * C + c0 + k) * M;
+          float gsum = 0.f;
 #pragma unroll
-        for (int j = 0; j < MM; ++j)
-          if (j < M) { tt[j] += f[k] * dm[j]; gsum += P[j] * dm[j]; }
-        g[k] = gsum;
+          for (int j = 0; j < MM; ++j)
+            if (j < M) { tt[j] += f[k] * dm[j]; gsum += P[j] * dm[j]; }
+          g[k] = gsum;
+        }
+        st_chunk<T>(dfw, drow + c0, Elem<T>::pack(g));
       }
-      st_chunk<T>(dfw, drow + c0, Elem<T>::pack(g));
     }
+    if (!valid) return;
 #pragma unroll
     for (int j0 = 0; j0 < MM; j0 += CPC)
       if (j0 < M) {
@@ -912,6 +919,7 @@ __global__ void __launch_bounds__(AT) k_mappool_bwd(const void* __restrict__ fw,
       }
     return;
   }
+  if (!valid) return;
 #pragma unroll
   for (int j = 0; j < MM; ++j) {
     P[j] = j < M ? expf(Elem<T>::load1(fw, row + C + j) - colstat[((size_t)n * M + j) * 2]) /
@@ -972,6 +980,8 @@ extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const f
   if (kW == 3 && kD <= 3 && kH <= 3) {
     int cch = C / cpc, groups = (cch + DG - 1) / DG, G = cch < DG ? cch : DG, SL = NT / G;
     int64_t items = (int64_t)N * D * H * ((W + WT - 1) / WT);
+    CBIM_CHECK(items < ((int64_t)1 << 31) && x_stride * 4 < ((int64_t)1 << 28), CBIM_EUNSUPPORTED,
+               "dwconv3d: %lld strips / row stride %lld exceed the 32-bit index arithmetic", (long long)items, (long long)x_stride);
     int64_t bx = (items + SL - 1) / SL;
     int64_t cap = 4096 / groups > 1 ? 4096 / groups : 1;
     if (bx > cap) bx = cap;
