@@ -139,6 +139,46 @@ class PatchEmbed(nn.Module):
 
 
 _TRUNK_AMP = os.environ.get("CBIM_SWIN_TRUNK_AMP", "1") != "0"
+_SPLITK_DW = os.environ.get("CBIM_SWIN_SPLITK_DW", "1") != "0"
+
+
+class _TokenLinearFn(torch.autograd.Function):
+    """``F.linear`` on [tokens, C] rows whose weight gradient is a split-K batched GEMM.  At the first stage there
+    are 262 144 tokens and 48..192 features: dW = dY^T X is then a (192 x 262144) x (262144 x 48) product for which
+    the library picks a 64x64 output tiling = 3 workgroups on 256 CUs (567 us per layer).  64 K-slices as one bmm
+    plus an fp32 sum of the partials fill the chip."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=None)
+    def forward(ctx, x, w, b):
+        y = F.linear(x, w, b)
+        # tensors as the GEMM saw them (under autocast: the bf16 casts), so that backward runs in the same dtype
+        xs, ws = (x.to(y.dtype), w.to(y.dtype)) if y.dtype != x.dtype else (x, w)
+        ctx.save_for_backward(xs, ws)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.to(x.dtype)
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        x2, g2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
+        T = int(x2.shape[0])
+        S = 64 if (T >= 32768 and T % 64 == 0) else 1
+        if S > 1:
+            gw = torch.bmm(g2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1)).float().sum(0)
+        else:
+            gw = (g2.t() @ x2).float()
+        gb = g2.float().sum(0) if ctx.has_b else None
+        return gx, gw, gb
+
+
+def _token_linear(lin, x):
+    if _SPLITK_DW and x.is_cuda and torch.is_grad_enabled() and lin.weight.requires_grad:
+        return _TokenLinearFn.apply(x, lin.weight, lin.bias)
+    return lin(x)
 
 
 class MLPBlock(nn.Module):
@@ -148,7 +188,7 @@ class MLPBlock(nn.Module):
         self.linear2 = nn.Linear(mlp_dim, hidden_size)
 
     def forward(self, x):
-        return self.linear2(F.gelu(self.linear1(x)))
+        return _token_linear(self.linear2, F.gelu(_token_linear(self.linear1, x)))
 
 
 def _relative_position_index(ws):
@@ -177,10 +217,10 @@ class WindowAttention(nn.Module):
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
     def forward(self, h, window, shift):
-        qkv = self.qkv(h)
+        qkv = _token_linear(self.qkv, h)
         o = Fn.WindowAttnFn.apply(qkv, self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
                                   self.window_size)
-        return self.proj(o)
+        return _token_linear(self.proj, o)
 
 
 class SwinTransformerBlock(nn.Module):
