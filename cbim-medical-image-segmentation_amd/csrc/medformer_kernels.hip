@@ -783,10 +783,11 @@ __global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw,
   __shared__ float red[2][MM];
   __shared__ float colm[MM];
   const int t = threadIdx.x, blk = blockIdx.x, n = blockIdx.z;
+  const int j0 = blockIdx.y * MM;   // code group (column softmaxes of different codes are independent)
   const int l = blk * AT + t;
   const bool valid = l < L;
   const size_t row = ((size_t)n * L + (valid ? l : 0)) * rs;
-  for (int j = 0; j < MM; ++j) E_s[t][j] = (valid && j < M) ? Elem<T>::load1(fw, row + C + j) : -INFINITY;
+  for (int j = 0; j < MM; ++j) E_s[t][j] = (valid && j0 + j < M) ? Elem<T>::load1(fw, row + C + j0 + j) : -INFINITY;
   __syncthreads();
   {
     int j = t & 63, hf = t >> 6;
@@ -797,7 +798,7 @@ __global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw,
   __syncthreads();
   if (t < MM) colm[t] = fmaxf(red[0][t], red[1][t]);
   __syncthreads();
-  for (int j = 0; j < MM; ++j) E_s[t][j] = (valid && j < M) ? expf(E_s[t][j] - colm[j]) : 0.f;
+  for (int j = 0; j < MM; ++j) E_s[t][j] = (valid && j0 + j < M) ? expf(E_s[t][j] - colm[j]) : 0.f;
   __syncthreads();
   float* pb = part + ((size_t)n * nblk + blk) * M * (2 + C);
   {
@@ -807,7 +808,7 @@ __global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw,
     red[hf][j] = s;
   }
   __syncthreads();
-  if (t < M) { pb[(size_t)t * (2 + C)] = colm[t]; pb[(size_t)t * (2 + C) + 1] = red[0][t] + red[1][t]; }
+  if (t < MM && j0 + t < M) { pb[(size_t)(j0 + t) * (2 + C)] = colm[t]; pb[(size_t)(j0 + t) * (2 + C) + 1] = red[0][t] + red[1][t]; }
   const int jq = t & 15, cq = t >> 4;  // 4 codes x 4 channels per thread
   for (int c0 = 0; c0 < C; c0 += 32) {
     __syncthreads();
@@ -831,7 +832,7 @@ __global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw,
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        int j = jq * 4 + u, c = c0 + cq * 4 + w;
+        int j = j0 + jq * 4 + u, c = c0 + cq * 4 + w;
         if (j < M && c < C) pb[(size_t)j * (2 + C) + 2 + c] = acc[u][w];
       }
   }
@@ -1103,10 +1104,11 @@ extern "C" int cbim_space_to_depth(int dtype, const void* src, void* dst, int N,
   return launch_ok("space_to_depth");
 }
 
+static constexpr int MWIDE_CODES = 128;   // attn_wide.hip
 static int attn_check(int dtype, int L, int heads, int dh, int M) {
   CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
-  CBIM_CHECK(dh == 8 || dh == 16 || dh == 32, CBIM_EUNSUPPORTED, "attention dim_head %d (supported: 8, 16, 32)", dh);
-  CBIM_CHECK(M >= 1 && M <= MM, CBIM_EUNSUPPORTED, "attention map codes %d (supported: 1..%d)", M, MM);
+  CBIM_CHECK(dh >= 1 && dh <= 4096, CBIM_EUNSUPPORTED, "attention dim_head %d (supported: 1..4096)", dh);
+  CBIM_CHECK(M >= 1 && M <= MWIDE_CODES, CBIM_EUNSUPPORTED, "attention map codes %d (supported: 1..%d)", M, MWIDE_CODES);
   CBIM_CHECK(L >= 1 && heads >= 1 && heads <= 65535, CBIM_EINVAL, "bad attention extents");
   return 0;
 }
@@ -1137,6 +1139,18 @@ extern "C" int cbim_attn_bwd_mfma_launch(const void* qv, int64_t qv_stride, cons
                                          const float* colstat, const float* map_out, const void* d_feat_out,
                                          const float* d_map_out, void* d_qv, float* part, int N, int L, int heads, float scale,
                                          void* stream);
+// attn_wide.hip: any d_head, up to MWIDE codes (one record per 64 voxels)
+extern "C" int cbim_attn_fwd_wide_launch(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
+                                         void* feat_out, float* map_out, float* colstat, float* part, int N, int L,
+                                         int heads, int dh, int M, float scale, void* stream);
+extern "C" int cbim_attn_bwd_wide_launch(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
+                                         const float* colstat, const float* map_out, const void* d_feat_out,
+                                         const float* d_map_out, void* d_qv, float* part, int N, int L, int heads, int dh,
+                                         int M, float scale, void* stream);
+extern "C" int cbim_mappool_bwd_wide_launch(int dtype, const void* fw, int64_t fw_stride, const float* map,
+                                            const float* colstat, const float* dmap, void* dfw, int64_t dfw_stride, int N,
+                                            int L, int C, int M, void* stream);
+static bool attn_wide(int dh, int M) { return !(dh == 8 || dh == 16 || dh == 32) || M > MM; }
 static bool attn_mfma_on() {
   static const int on = getenv("CBIM_ATTN_MFMA") ? atoi(getenv("CBIM_ATTN_MFMA")) : 1;
   return on != 0;
@@ -1148,6 +1162,9 @@ extern "C" int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride,
   if (int e = attn_check(dtype, L, heads, dh, M)) return e;
   CBIM_CHECK(workspace && ws_bytes >= cbim_bidir_attn_workspace(N, L, heads, dh, M), CBIM_EWORKSPACE,
              "attention workspace too small");
+  if (attn_wide(dh, M))
+    return cbim_attn_fwd_wide_launch(dtype, qv, qv_stride, mq, mv, feat_out, map_out, colstat, (float*)workspace, N, L,
+                                     heads, dh, M, scale, stream);
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CBIM_BF16 && dh == 32 && M == 64 && attn_mfma_on()) {
@@ -1174,7 +1191,11 @@ extern "C" int cbim_bidir_attn_bwd(int dtype, const void* qv, int64_t qv_stride,
              "attention workspace too small");
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CBIM_BF16 && dh == 32 && M == 64 && attn_mfma_on()) {
+  if (attn_wide(dh, M)) {
+    nblk = (L + 63) / 64;
+    if (int e = cbim_attn_bwd_wide_launch(dtype, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out, d_map_out, d_qv,
+                                          (float*)workspace, N, L, heads, dh, M, scale, stream)) return e;
+  } else if (dtype == CBIM_BF16 && dh == 32 && M == 64 && attn_mfma_on()) {
     nblk = (L + 31) / 32;
     if (int e = cbim_attn_bwd_mfma_launch(qv, qv_stride, mq, mv, colstat, map_out, d_feat_out, d_map_out, d_qv,
                                           (float*)workspace, N, L, heads, scale, stream)) return e;
@@ -1197,12 +1218,12 @@ extern "C" size_t cbim_colsoftmax_pool_workspace(int N, int L, int C, int M) {
 extern "C" int cbim_colsoftmax_pool_fwd(int dtype, const void* fw, int64_t fw_stride, float* map, float* colstat,
                                         int N, int L, int C, int M, void* workspace, size_t ws_bytes, void* stream) {
   CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
-  CBIM_CHECK(M >= 1 && M <= MM && C >= 1 && L >= 1, CBIM_EUNSUPPORTED, "colsoftmax_pool: M=%d C=%d L=%d", M, C, L);
+  CBIM_CHECK(M >= 1 && M <= MWIDE_CODES && C >= 1 && L >= 1, CBIM_EUNSUPPORTED, "colsoftmax_pool: M=%d C=%d L=%d", M, C, L);
   CBIM_CHECK(workspace && ws_bytes >= cbim_colsoftmax_pool_workspace(N, L, C, M), CBIM_EWORKSPACE,
              "colsoftmax_pool workspace too small");
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(nblk, 1, N);
+  dim3 grid(nblk, (M + MM - 1) / MM, N);   // y = group of 64 codes
   if (dtype == CBIM_BF16)
     CBIM_LAUNCH((k_mappool_fwd<bf16_tag>), grid, dim3(AT), 0, st, fw, fw_stride, (float*)workspace, L, C, M, nblk);
   else
@@ -1217,7 +1238,9 @@ extern "C" int cbim_colsoftmax_pool_bwd(int dtype, const void* fw, int64_t fw_st
                                         const float* colstat, const float* dmap, void* dfw, int64_t dfw_stride, int N,
                                         int L, int C, int M, void* stream) {
   CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
-  CBIM_CHECK(M >= 1 && M <= MM && C >= 1 && L >= 1, CBIM_EUNSUPPORTED, "colsoftmax_pool: M=%d C=%d L=%d", M, C, L);
+  CBIM_CHECK(M >= 1 && M <= MWIDE_CODES && C >= 1 && L >= 1, CBIM_EUNSUPPORTED, "colsoftmax_pool: M=%d C=%d L=%d", M, C, L);
+  if (M > MM)
+    return cbim_mappool_bwd_wide_launch(dtype, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, N, L, C, M, stream);
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nblk, 1, N);

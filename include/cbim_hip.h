@@ -250,7 +250,11 @@ int cbim_space_to_depth(int dtype, const void* src, void* dst, int N, int D, int
  * qv_stride), inner = heads*dh, channel c = d*heads + h ("(dim_head heads)", :43-51):
  *   attn = q_f q_m^T * scale [L x M]; feat_out = softmax_M(attn) v_m; map_out = softmax_L(attn)^T v_f.
  * mq, mv, map_out, d_*: float [N][M][inner].  colstat: float [N][heads][M][2] column (max, sum) kept
- * for the backward.  dh in {8,16,32}, M <= 64. */
+ * for the backward.  Any dh >= 1 and M <= cbim_attn_wide_max_codes() (= 128): dh in {8,16,32} with M <= 64 runs the
+ * register-resident kernels (bf16, dh 32, M 64: the MFMA kernel), every other size — e.g. config/acdc/medformer_3d.yaml
+ * (72 codes, dh 64|80) and config/lits/medformer_3d.yaml (num_heads 1: dh up to 320) — the LDS-tiled kernels of
+ * attn_wide.hip. */
+int cbim_attn_wide_max_codes(void);
 size_t cbim_bidir_attn_workspace(int N, int L, int heads, int dh, int M);
 int cbim_bidir_attn_fwd(int dtype, const void* qv, int64_t qv_stride, const float* mq, const float* mv,
                         void* feat_out, float* map_out, float* colstat, int N, int L, int heads, int dh,
@@ -261,7 +265,8 @@ int cbim_bidir_attn_bwd(int dtype, const void* qv, int64_t qv_stride, const floa
                         int heads, int dh, int M, float scale, void* workspace, size_t ws_bytes,
                         void* stream);
 /* SemanticMapGeneration tail (medformer_utils.py:218-228) on fw rows = [feat (C) | weight logits (M)]:
- * map[n][c][j] = sum_l feat[l,c] * softmax_L(logit[:,j])[l].  colstat: float [N][M][2]. */
+ * map[n][c][j] = sum_l feat[l,c] * softmax_L(logit[:,j])[l].  colstat: float [N][M][2].
+ * M <= cbim_attn_wide_max_codes(). */
 size_t cbim_colsoftmax_pool_workspace(int N, int L, int C, int M);
 int cbim_colsoftmax_pool_fwd(int dtype, const void* fw, int64_t fw_stride, float* map, float* colstat,
                              int N, int L, int C, int M, void* workspace, size_t ws_bytes, void* stream);

@@ -11,6 +11,11 @@ Same import shim as make_golden.py.  Cases
                       reference constructor's under torch.manual_seed(seed) (our module reproduces them
                       bit for bit — checked through sd_checksum); stores strided logits, losses and
                       per-parameter gradient norms / sums.  GPU parity test only.
+  medformer_acdc_tiny the STRUCTURE of config/acdc/medformer_3d.yaml at reduced widths: anisotropic kernels/scales,
+                      map_size [2,6,6] = 72 codes, 4 heads everywhere (d_head 8 | 16 | 20), transformer blocks at
+                      every inner level — exercises attn_wide.hip and the >64-code map pooling
+  medformer_lits_tiny the STRUCTURE of config/lits/medformer_3d.yaml: num_heads all 1 (d_head = channels: 32, 64,
+                      80), aux_loss False (forward returns one tensor)
 No reference source is copied; only tensors it produced.
 """
 import importlib
@@ -35,10 +40,25 @@ AMOS = dict(base_chan=32, map_size=[4, 4, 4], conv_block="BasicBlock", conv_num=
             num_heads=[1, 4, 8, 10, 8, 4, 1, 1], fusion_depth=2, fusion_dim=320, fusion_heads=10, expansion=4,
             attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
             scale=[[2, 2, 2]] * 4, aux_loss=True)
+ACDC_T = dict(base_chan=8, map_size=[2, 6, 6], conv_block="BasicBlock", conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
+              trans_num=[0, 2, 1, 1, 1, 1, 0, 0], chan_num=[16, 32, 64, 80, 64, 32, 16, 8],
+              num_heads=[1, 4, 4, 4, 4, 4, 1, 1], fusion_depth=2, fusion_dim=32, fusion_heads=4, expansion=4,
+              attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu",
+              kernel_size=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+              scale=[[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]], aux_loss=True)
+LITS_T = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
+              trans_num=[0, 1, 1, 2, 1, 1, 0, 0], chan_num=[16, 32, 64, 80, 64, 32, 16, 8],
+              num_heads=[1, 1, 1, 1, 1, 1, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
+              attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
+              scale=[[2, 2, 2]] * 4, aux_loss=False)
 CASES = {
     # name: (in_chan, classes, kwargs, spatial, batch, seed, full)
     "medformer_tiny_32": (1, 4, TINY, (32, 32, 32), 1, 3031, True),
     "medformer_amos_64": (1, 16, AMOS, (64, 64, 64), 1, 3032, False),
+    # full = 20000: full gradients of every tensor with at most that many elements (all attention / map-side tensors),
+    # weights come from the seed (sd_checksum)
+    "medformer_acdc_tiny": (1, 4, ACDC_T, (8, 32, 32), 1, 3033, 20000),
+    "medformer_lits_tiny": (1, 3, LITS_T, (32, 32, 32), 1, 3034, 20000),
 }
 AUX_WEIGHT = [0.5, 0.5]   # config/amos_ct/medformer_3d.yaml: aux_weight
 
@@ -48,7 +68,10 @@ def main():
     MedFormer = importlib.import_module("model.dim3.medformer").MedFormer
     from oracle.unet_ref import state_dict_checksum
     torch.set_num_threads(8)
+    only = sys.argv[1:]
     for name, (in_ch, classes, kw, shape, batch, seed, full) in CASES.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(seed)
         net = MedFormer(in_ch, classes, **kw)
         net.train()
@@ -58,18 +81,25 @@ def main():
         weight = torch.ones(classes)
         weight[0] = 0.5
         outs = net(x)
+        if not kw["aux_loss"]:
+            outs = [outs]                      # medformer.py:98-101: a single tensor without aux_loss
         ce_fn, dl_fn = torch.nn.CrossEntropyLoss(weight=weight), DiceLoss()
         ces = [ce_fn(o, lab.squeeze(1)) for o in outs]
         dls = [dl_fn(o, lab) for o in outs]
-        loss = sum(w * (c + d) for w, c, d in zip(AUX_WEIGHT, ces, dls))   # train.py:207-210
+        if kw["aux_loss"]:
+            loss = sum(w * (c + d) for w, c, d in zip(AUX_WEIGHT, ces, dls))   # train.py:207-210
+        else:
+            loss = ces[0] + dls[0]                                             # train.py:212-213
         loss.backward()
         sd = net.state_dict()
         grads = {k: p.grad for k, p in net.named_parameters()}
         st = 1 if full else 4
+        if st == 1 and full is not True:
+            st = 2
         out = {
             "x": x.numpy(), "label": lab.numpy().astype(np.int64), "weight": weight.numpy(),
             "logits": outs[0].detach().numpy()[..., ::st, ::st, ::st],
-            "aux_logits": outs[1].detach().numpy()[..., ::st, ::st, ::st], "stride": np.int64(st),
+            "aux_logits": outs[-1].detach().numpy()[..., ::st, ::st, ::st], "stride": np.int64(st),
             "ce": np.array([float(c) for c in ces]), "dice": np.array([float(d) for d in dls]),
             "loss": np.float64(loss.item()),
             "n_params": np.int64(sum(p.numel() for p in net.parameters())), "n_tensors": np.int64(len(sd)),
@@ -79,12 +109,18 @@ def main():
             "grad_sums": np.array([float(grads[k].double().sum()) for k in sd.keys()]),
             "sd_checksum": np.float64(state_dict_checksum(sd)), "seed": np.int64(seed),
             "g:inc.conv1.weight": grads["inc.conv1.weight"].numpy(),
-            "g:outc.weight": grads["outc.weight"].numpy(), "g:aux_out.weight": grads["aux_out.weight"].numpy(),
+            "g:outc.weight": grads["outc.weight"].numpy(),
         }
-        if full:
+        if kw["aux_loss"]:
+            out["g:aux_out.weight"] = grads["aux_out.weight"].numpy()
+        if full is True:
             for k, v in sd.items():
                 out["p:" + k] = v.numpy()
                 out["g:" + k] = grads[k].numpy()
+        elif full:
+            for k, v in sd.items():
+                if v.numel() <= full:
+                    out["g:" + k] = grads[k].numpy()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(name, "logits", tuple(outs[0].shape), "loss", float(loss), "params", int(out["n_params"]), "tensors",

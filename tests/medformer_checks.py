@@ -18,7 +18,21 @@ AMOS = dict(base_chan=32, map_size=[4, 4, 4], conv_block="BasicBlock", conv_num=
             num_heads=[1, 4, 8, 10, 8, 4, 1, 1], fusion_depth=2, fusion_dim=320, fusion_heads=10, expansion=4,
             attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
             scale=[[2, 2, 2]] * 4, aux_loss=True)
-MF_CASES = {"medformer_tiny_32": (1, 4, TINY), "medformer_amos_64": (1, 16, AMOS)}
+# the structure of config/acdc/medformer_3d.yaml (72 map codes, anisotropic stem, 4 heads: d_head 8|16|20) and of
+# config/lits/medformer_3d.yaml (one head per block: d_head = channels, no auxiliary head) at reduced widths
+ACDC_T = dict(base_chan=8, map_size=[2, 6, 6], conv_block="BasicBlock", conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
+              trans_num=[0, 2, 1, 1, 1, 1, 0, 0], chan_num=[16, 32, 64, 80, 64, 32, 16, 8],
+              num_heads=[1, 4, 4, 4, 4, 4, 1, 1], fusion_depth=2, fusion_dim=32, fusion_heads=4, expansion=4,
+              attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu",
+              kernel_size=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+              scale=[[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]], aux_loss=True)
+LITS_T = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
+              trans_num=[0, 1, 1, 2, 1, 1, 0, 0], chan_num=[16, 32, 64, 80, 64, 32, 16, 8],
+              num_heads=[1, 1, 1, 1, 1, 1, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
+              attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
+              scale=[[2, 2, 2]] * 4, aux_loss=False)
+MF_CASES = {"medformer_tiny_32": (1, 4, TINY), "medformer_amos_64": (1, 16, AMOS),
+            "medformer_acdc_tiny": (1, 4, ACDC_T), "medformer_lits_tiny": (1, 3, LITS_T)}
 AUX_WEIGHT = (0.5, 0.5)
 
 
@@ -46,8 +60,10 @@ def run_case(name, dev, mode):
         lab = torch.from_numpy(g["label"]).to(dev)
         w = torch.from_numpy(g["weight"]).to(dev)
         outs = net(x)
+        aux_on = isinstance(outs, (list, tuple))                 # medformer.py:98-101
+        outs = list(outs) if aux_on else [outs]
         losses = [Fn.DiceCEFn.apply(o, lab, w) for o in outs]
-        loss = sum(a * l[2] for a, l in zip(AUX_WEIGHT, losses))
+        loss = sum(a * l[2] for a, l in zip(AUX_WEIGHT, losses)) if aux_on else losses[0][2]   # train.py:206-212
         loss.backward()
         st = int(g["stride"])
         params = dict(net.named_parameters())
@@ -56,25 +72,27 @@ def run_case(name, dev, mode):
         scale = float(np.max(g["grad_norms"]))
         res = {
             "logits_err": rel_err(outs[0].detach().cpu()[..., ::st, ::st, ::st], g["logits"]),
-            "aux_err": rel_err(outs[1].detach().cpu()[..., ::st, ::st, ::st], g["aux_logits"]),
+            "aux_err": rel_err(outs[-1].detach().cpu()[..., ::st, ::st, ::st], g["aux_logits"]),
             "ce": [float(l[0]) for l in losses], "dice": [float(l[1]) for l in losses], "loss": float(loss),
-            # norms below 1e-6 of the largest are analytically-zero gradients (e.g. a bias in front of InstanceNorm)
-            "grad_norm_err": float(np.max(np.abs(gn - g["grad_norms"]) / np.maximum(g["grad_norms"], 1e-6 * scale))),
+            # norms below 1e-5 of the largest are analytically-zero gradients (a bias in front of a normalisation:
+            # 4e-8 of pure fp32 rounding noise in both implementations for map_fusion...fc2.bias of the ACDC case)
+            "grad_norm_err": float(np.max(np.abs(gn - g["grad_norms"]) / np.maximum(g["grad_norms"], 1e-5 * scale))),
             "g_stem": rel_err(params["inc.conv1.weight"].grad.cpu(), g["g:inc.conv1.weight"]),
             "g_head": rel_err(params["outc.weight"].grad.cpu(), g["g:outc.weight"]),
-            "g_aux": rel_err(params["aux_out.weight"].grad.cpu(), g["g:aux_out.weight"]),
+            "g_aux": rel_err(params["aux_out.weight"].grad.cpu(), g["g:aux_out.weight"]) if aux_on else 0.0,
         }
         ref = torch.from_numpy(g["logits"])
         top2 = ref.topk(2, dim=1).values
         clear = (top2[:, 0] - top2[:, 1]) > 1e-4          # ties below the fp32 noise floor are masked
         mine = outs[0].detach().cpu()[..., ::st, ::st, ::st].argmax(1)
         res["argmax_mismatch"] = int(((mine != ref.argmax(1)) & clear).sum())
-        if "p:" + keys[0] in g.files:                     # full-gradient fixture
+        stored = [k for k in keys if "g:" + k in g.files]
+        if len(stored) > 3:                               # fixture with full gradients (all, or all small tensors)
             errs, meds = [], []
-            for k in keys:
+            for k in stored:
                 r = torch.from_numpy(g["g:" + k]).double()
                 d = (params[k].grad.detach().cpu().double() - r).abs()
-                floor = max(float(r.abs().max()), 1e-6 * scale)
+                floor = max(float(r.abs().max()), 1e-5 * scale)
                 errs.append(float(d.max()) / floor)
                 meds.append(float(d.median()) / floor)
             res["grad_max_err"], res["grad_med_err"] = max(errs), max(meds)

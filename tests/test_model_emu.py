@@ -110,6 +110,22 @@ def test_medformer_fp32_matches_reference_golden(dev):
     assert_fp32_parity("medformer_tiny_32", dev)
 
 
+def test_medformer_acdc_structure_fp32_matches_reference_golden(dev):
+    """config/acdc/medformer_3d.yaml's structure (72 map codes, anisotropic stem, d_head 8|16|20) at reduced widths
+    against the real reference: attn_wide.hip + the >64-code map pooling, forward and backward."""
+    from tests.medformer_checks import assert_fp32_parity
+    print(assert_fp32_parity("medformer_acdc_tiny", dev))
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not __import__("os").environ.get("CBIM_SLOW"), reason="66 s on the host-side executor; set CBIM_SLOW=1 "
+                    "(the same case runs in the -m gpu suite, its attention shapes in test_ops_emu.py)")
+def test_medformer_lits_structure_fp32_matches_reference_golden(dev):
+    """config/lits/medformer_3d.yaml's structure: one head per block (d_head = channels), no auxiliary head."""
+    from tests.medformer_checks import assert_fp32_parity
+    print(assert_fp32_parity("medformer_lits_tiny", dev))
+
+
 def test_swin_unetr_plugin_surface():
     """get_model(args) builds the reference's SwinUNETR parameter layout (58.54 M parameters / 131 tensors at
     feature_size 48, in_chan 4 — SURVEY §8a a21)."""

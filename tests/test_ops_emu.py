@@ -83,6 +83,22 @@ def test_mappool(dev, dtype):
     oc.check_mappool(dev, dtype, N=1, C=72, M=64, dhw=(6, 6, 5))
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attn_wide_heads_and_maps(dev, dtype):
+    """d_head / map sizes of the shipped ACDC (72 codes, d_head 64 | 80) and LiTS (one head: d_head = channels)
+    MedFormer configurations — attn_wide.hip."""
+    oc.check_attn(dev, dtype, N=1, heads=4, dh=80, dhw=(2, 6, 6), M=72)       # acdc down4: 320 channels, 4 heads
+    oc.check_attn(dev, dtype, N=2, heads=1, dh=64, dhw=(3, 5, 7), M=64)       # lits down1-sized head
+    oc.check_attn(dev, dtype, N=1, heads=2, dh=24, dhw=(4, 4, 5), M=27)       # bcv map [3,3,3], odd d_head
+    oc.check_attn(dev, dtype, N=1, heads=1, dh=40, dhw=(1, 1, 3), M=128)      # more codes than voxels, code limit
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_mappool_more_than_64_codes(dev, dtype):
+    oc.check_mappool(dev, dtype, N=1, C=40, M=72, dhw=(4, 6, 6))              # acdc map_size [2,6,6]
+    oc.check_mappool(dev, dtype, N=2, C=24, M=128, dhw=(3, 7, 5))
+
+
 def test_trilinear_planes(dev):
     oc.check_trilinear_planes(dev)
     oc.check_trilinear_planes(dev, lo=(1, 2, 2), hi=(4, 4, 4))
