@@ -8,6 +8,7 @@ installed here, so they come from the torch-only stand-in in tests/golden/monai_
 MONAI conv blocks are "parity unpinned" (SURVEY.md §8c).  Cases
   swin_tiny        feature_size 24, in_chan 4, 3 classes, 64x32x32 (anisotropic windows, one shifted stage with a
                    window smaller than 7 in two dims), seeded weights, every gradient tensor of <= 20000 elements in full, norms/sums of all, the 5 hidden states
+  swin_c1_tiny     in_chan 1 / 14 classes as in config/bcv/swin_unetr_3d.yaml, feature_size 24, 64x32x32
   swin_brats_64    feature_size 48, in_chan 4, 4 classes (BASELINE config 5 shape) at 64^3; seeded weights,
                    strided logits, losses, per-parameter gradient norms
 """
@@ -29,6 +30,8 @@ CASES = {
     # name: (img_size, in_chan, classes, feature_size, batch, seed, full)
     "swin_tiny": ((64, 32, 32), 4, 3, 24, 1, 4041, True),
     "swin_brats_64": ((64, 64, 64), 4, 4, 48, 1, 4042, False),
+    # the shipped configs (config/{bcv,kits,lits}/swin_unetr_3d.yaml) are single-modality: in_chan 1, 14 classes (bcv)
+    "swin_c1_tiny": ((64, 32, 32), 1, 14, 24, 1, 4043, True),
 }
 
 
@@ -37,7 +40,10 @@ def main():
     SwinUNETR = importlib.import_module("model.dim3.swin_unetr").SwinUNETR
     from oracle.unet_ref import state_dict_checksum
     torch.set_num_threads(8)
+    only = sys.argv[1:]
     for name, (shape, in_ch, classes, feat, batch, seed, full) in CASES.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(seed)
         net = SwinUNETR(shape, in_ch, classes, feature_size=feat)     # model/utils.py:113 call shape
         net.train()
@@ -55,7 +61,7 @@ def main():
         sd = {k: v for k, v in net.state_dict().items()}
         grads = {k: p.grad for k, p in net.named_parameters()}
         pkeys = [k for k, _ in net.named_parameters()]
-        st = 1 if full else 4
+        st = (2 if classes > 8 else 1) if full else 4    # keep the fixture small
         out = {
             "x": x.numpy(), "label": lab.numpy().astype(np.int64), "weight": weight.numpy(),
             "logits": logits.detach().numpy()[..., ::st, ::st, ::st], "stride": np.int64(st),

@@ -13,6 +13,7 @@ SW_CASES = {
     # name: (img_size, in_chan, classes, feature_size)
     "swin_tiny": ((64, 32, 32), 4, 3, 24),
     "swin_brats_64": ((64, 64, 64), 4, 4, 48),
+    "swin_c1_tiny": ((64, 32, 32), 1, 14, 24),       # single modality, 14 classes: config/bcv/swin_unetr_3d.yaml
 }
 
 

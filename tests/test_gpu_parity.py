@@ -171,7 +171,7 @@ def test_medformer_wide_heads_bf16_inside_envelope(dev, name):
 
 # ---- SwinUNETR -------------------------------------------------------------
 
-@pytest.mark.parametrize("name", ["swin_tiny", "swin_brats_64"])
+@pytest.mark.parametrize("name", ["swin_tiny", "swin_brats_64", "swin_c1_tiny"])
 def test_swin_unetr_fp32_matches_reference_golden(dev, name):
     from tests.swin_checks import assert_fp32_parity as sw_parity
     print(name, sw_parity(name, dev))
