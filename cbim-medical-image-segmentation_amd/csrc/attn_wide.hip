@@ -7,7 +7,7 @@
 // Python side are shared.
 //
 // One wave (64 voxels) per workgroup, thread = voxel.  The [voxel][code] logit matrix lives in LDS (each thread owns
-// a row, pitch 129 floats: conflict-free both for "own row" walks and for column walks), the head dimension is
+// a row, odd pitch >= M: conflict-free both for "own row" walks and for column walks), the head dimension is
 // streamed in chunks of 32: the map-side chunk [code][32] is staged once per workgroup and read as 16-byte
 // broadcasts, the voxel-side chunk sits in registers.  Products that sum over the voxels of the block (column-softmax
 // records, dq_m / dv_m partials) stage the voxel-side chunk in LDS and give each thread one or two codes.
@@ -25,7 +25,9 @@ namespace cbim {
 static constexpr int WT = 64;        // voxels (= threads) per workgroup
 static constexpr int MWC = 128;      // max map codes
 static constexpr int DC = 32;        // head-dimension chunk
-static constexpr int EP = MWC + 1;   // pitch of the [voxel][code] matrices
+// pitch of the [voxel][code] matrices: the first odd number >= M (conflict-free own-row and column walks).  LDS is
+// sized per launch from M, so 64 codes leave room for three workgroups per CU (one was resident with a fixed 129).
+__host__ __device__ __forceinline__ int code_pitch(int M) { return M | 1; }
 static constexpr int XQ = DC + 4;    // pitch of the staged voxel-side chunk (16-byte aligned rows)
 
 // map-side chunk: Wc[j][k] = src[j*inner + (d0+k)*heads] for j < M, k < DC (zero past dh)
@@ -91,8 +93,8 @@ __device__ __forceinline__ void block_logits(float* Et, float* Wc, const void* _
 }
 
 // partial[j][d0..] = sum over the block's voxels r of Mx[r][j] * X[r][k] for this thread's codes j = t, t + 64
-__device__ __forceinline__ void code_times_voxels(const float* Mx, const float* X, float* dst, int64_t dst_pitch, int dh,
-                                                  int M, int d0, int t, float mul) {
+__device__ __forceinline__ void code_times_voxels(const float* Mx, int EP, const float* X, float* dst, int64_t dst_pitch,
+                                                  int dh, int M, int d0, int t, float mul) {
   for (int j = t; j < M; j += WT) {
     float acc[DC];
 #pragma unroll
@@ -111,10 +113,11 @@ __global__ void __launch_bounds__(WT) k_attnw_fwd(const void* __restrict__ qv, i
                                                   float* __restrict__ part, int L, int heads, int dh, int M, float scale,
                                                   int nblk) {
   CBIM_DYN_SMEM(smem);
+  const int EP = code_pitch(M);
   float* E = (float*)smem;       // [WT][EP]
   float* X = E + WT * EP;        // [WT][XQ]
-  float* Wc = X + WT * XQ;       // [MWC][DC]
-  float* colm = Wc + MWC * DC;   // [MWC]
+  float* Wc = X + WT * XQ;       // [M][DC]
+  float* colm = Wc + M * DC;     // [M]
   const int t = threadIdx.x, blk = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const int inner = heads * dh;
   const int l = blk * WT + t;
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(WT) k_attnw_fwd(const void* __restrict__ qv, i
 #pragma unroll
     for (int k = 0; k < DC; ++k) X[t * XQ + k] = v[k];
     __syncthreads();
-    code_times_voxels(E, X, pb + 2, dh + 2, dh, M, d0, t, 1.f);
+    code_times_voxels(E, EP, X, pb + 2, dh + 2, dh, M, d0, t, 1.f);
   }
 }
 
@@ -210,13 +213,14 @@ __global__ void __launch_bounds__(WT) k_attnw_bwd(const void* __restrict__ qv, i
                                                   float* __restrict__ part, int L, int heads, int dh, int M, float scale,
                                                   int nblk) {
   CBIM_DYN_SMEM(smem);
+  const int EP = code_pitch(M);
   float* A = (float*)smem;      // [WT][EP] logits, later P1
   float* B = A + WT * EP;       // [WT][EP] g.mv_j, later dA
   float* X = B + WT * EP;       // [WT][XQ]
-  float* Wc = X + WT * XQ;      // [MWC][DC]
-  float* cj = Wc + MWC * DC;    // <map_out_j, dmap_out_j>
-  float* cM = cj + MWC;         // column max
-  float* cIS = cM + MWC;        // 1 / column sum
+  float* Wc = X + WT * XQ;      // [M][DC]
+  float* cj = Wc + M * DC;      // <map_out_j, dmap_out_j>
+  float* cM = cj + M;           // column max
+  float* cIS = cM + M;          // 1 / column sum
   const int t = threadIdx.x, blk = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const int inner = heads * dh;
   const int l = blk * WT + t;
@@ -309,7 +313,7 @@ __global__ void __launch_bounds__(WT) k_attnw_bwd(const void* __restrict__ qv, i
 #pragma unroll
       for (int k = 0; k < DC; ++k) X[t * XQ + k] = x[k];
       __syncthreads();
-      code_times_voxels(stage == 0 ? A : B, X, pbase + (size_t)stage * M * dh, dh, dh, M, d0, t, stage == 0 ? 1.f : scale);
+      code_times_voxels(stage == 0 ? A : B, EP, X, pbase + (size_t)stage * M * dh, dh, dh, M, d0, t, stage == 0 ? 1.f : scale);
     }
 }
 
@@ -320,10 +324,11 @@ __global__ void __launch_bounds__(WT) k_mappoolw_bwd(const void* __restrict__ fw
                                                      const float* __restrict__ colstat, const float* __restrict__ dmap,
                                                      void* __restrict__ dfw, int64_t drs, int L, int C, int M) {
   CBIM_DYN_SMEM(smem);
+  const int EP = code_pitch(M);
   float* P = (float*)smem;      // [WT][EP]
   float* TT = P + WT * EP;      // [WT][EP]
-  float* Wc = TT + WT * EP;     // [MWC][DC]: dmap[c0+k][j]
-  float* cj = Wc + MWC * DC;
+  float* Wc = TT + WT * EP;     // [M][DC]: dmap[c0+k][j]
+  float* cj = Wc + M * DC;
   const int t = threadIdx.x, n = blockIdx.z;
   const int l = blockIdx.x * WT + t;
   const bool valid = l < L;
@@ -372,9 +377,9 @@ __global__ void __launch_bounds__(WT) k_mappoolw_bwd(const void* __restrict__ fw
 
 using namespace cbim;
 
-static constexpr size_t FWD_SMEM = (size_t)(WT * EP + WT * XQ + MWC * DC + MWC) * sizeof(float);
-static constexpr size_t BWD_SMEM = (size_t)(2 * WT * EP + WT * XQ + MWC * DC + 3 * MWC) * sizeof(float);
-static constexpr size_t POOL_SMEM = (size_t)(2 * WT * EP + MWC * DC + MWC) * sizeof(float);
+static size_t fwd_smem(int M) { return (size_t)(WT * code_pitch(M) + WT * XQ + M * DC + M) * sizeof(float); }
+static size_t bwd_smem(int M) { return (size_t)(2 * WT * code_pitch(M) + WT * XQ + M * DC + 3 * M) * sizeof(float); }
+static size_t pool_smem(int M) { return (size_t)(2 * WT * code_pitch(M) + M * DC + M) * sizeof(float); }
 
 // kernels that ask for more than 64 KiB of LDS need the attribute once per process
 template <typename K>
@@ -402,18 +407,18 @@ extern "C" int cbim_attn_fwd_wide_launch(int dtype, const void* qv, int64_t qv_s
                                          int heads, int dh, int M, float scale, void* stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (int e = allow_lds(k_attnw_fwd<bf16_tag>, FWD_SMEM, "bidir_attn_fwd (wide)")) return e;
-    if (int e = allow_lds(k_attnw_fwd<float>, FWD_SMEM, "bidir_attn_fwd (wide)")) return e;
+    if (int e = allow_lds(k_attnw_fwd<bf16_tag>, fwd_smem(MWC), "bidir_attn_fwd (wide)")) return e;
+    if (int e = allow_lds(k_attnw_fwd<float>, fwd_smem(MWC), "bidir_attn_fwd (wide)")) return e;
     attr_done = true;
   }
   const int nblk = (L + WT - 1) / WT;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nblk, heads, N);
   if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_attnw_fwd<bf16_tag>), grid, dim3(WT), FWD_SMEM, st, qv, qv_stride, mq, mv, feat_out, part, L, heads, dh, M,
+    CBIM_LAUNCH((k_attnw_fwd<bf16_tag>), grid, dim3(WT), fwd_smem(M), st, qv, qv_stride, mq, mv, feat_out, part, L, heads, dh, M,
                 scale, nblk);
   else
-    CBIM_LAUNCH((k_attnw_fwd<float>), grid, dim3(WT), FWD_SMEM, st, qv, qv_stride, mq, mv, feat_out, part, L, heads, dh, M,
+    CBIM_LAUNCH((k_attnw_fwd<float>), grid, dim3(WT), fwd_smem(M), st, qv, qv_stride, mq, mv, feat_out, part, L, heads, dh, M,
                 scale, nblk);
   if (int e = wide_launch_ok("bidir_attn_fwd (wide)")) return e;
   CBIM_LAUNCH(k_attnw_merge, dim3(N * heads * M), dim3(WT), 0, st, (const float*)part, map_out, colstat, heads, M, dh, nblk);
@@ -428,18 +433,18 @@ extern "C" int cbim_attn_bwd_wide_launch(int dtype, const void* qv, int64_t qv_s
                                          int M, float scale, void* stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (int e = allow_lds(k_attnw_bwd<bf16_tag>, BWD_SMEM, "bidir_attn_bwd (wide)")) return e;
-    if (int e = allow_lds(k_attnw_bwd<float>, BWD_SMEM, "bidir_attn_bwd (wide)")) return e;
+    if (int e = allow_lds(k_attnw_bwd<bf16_tag>, bwd_smem(MWC), "bidir_attn_bwd (wide)")) return e;
+    if (int e = allow_lds(k_attnw_bwd<float>, bwd_smem(MWC), "bidir_attn_bwd (wide)")) return e;
     attr_done = true;
   }
   const int nblk = (L + WT - 1) / WT;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nblk, heads, N);
   if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_attnw_bwd<bf16_tag>), grid, dim3(WT), BWD_SMEM, st, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out,
+    CBIM_LAUNCH((k_attnw_bwd<bf16_tag>), grid, dim3(WT), bwd_smem(M), st, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out,
                 d_map_out, d_qv, part, L, heads, dh, M, scale, nblk);
   else
-    CBIM_LAUNCH((k_attnw_bwd<float>), grid, dim3(WT), BWD_SMEM, st, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out,
+    CBIM_LAUNCH((k_attnw_bwd<float>), grid, dim3(WT), bwd_smem(M), st, qv, qv_stride, mq, mv, colstat, map_out, d_feat_out,
                 d_map_out, d_qv, part, L, heads, dh, M, scale, nblk);
   return wide_launch_ok("bidir_attn_bwd (wide)");
 }
@@ -449,17 +454,17 @@ extern "C" int cbim_mappool_bwd_wide_launch(int dtype, const void* fw, int64_t f
                                             int L, int C, int M, void* stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (int e = allow_lds(k_mappoolw_bwd<bf16_tag>, POOL_SMEM, "colsoftmax_pool_bwd (wide)")) return e;
-    if (int e = allow_lds(k_mappoolw_bwd<float>, POOL_SMEM, "colsoftmax_pool_bwd (wide)")) return e;
+    if (int e = allow_lds(k_mappoolw_bwd<bf16_tag>, pool_smem(MWC), "colsoftmax_pool_bwd (wide)")) return e;
+    if (int e = allow_lds(k_mappoolw_bwd<float>, pool_smem(MWC), "colsoftmax_pool_bwd (wide)")) return e;
     attr_done = true;
   }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((L + WT - 1) / WT, 1, N);
   if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_mappoolw_bwd<bf16_tag>), grid, dim3(WT), POOL_SMEM, st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride,
+    CBIM_LAUNCH((k_mappoolw_bwd<bf16_tag>), grid, dim3(WT), pool_smem(M), st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride,
                 L, C, M);
   else
-    CBIM_LAUNCH((k_mappoolw_bwd<float>), grid, dim3(WT), POOL_SMEM, st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, L,
+    CBIM_LAUNCH((k_mappoolw_bwd<float>), grid, dim3(WT), pool_smem(M), st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, L,
                 C, M);
   return wide_launch_ok("colsoftmax_pool_bwd (wide)");
 }
