@@ -68,7 +68,7 @@ def main():
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         print(json.dumps({"config": name, "model": cfg["model"], "training_size": size, "dtype": a.dtype,
                           "ms_per_step": round(ms, 2), "volumes_per_s": round(1e3 / ms, 2), "steps": a.steps,
-                          "final_loss": round(float(loss), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}),
+                          "final_loss": round(float(loss.detach()), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}),
               flush=True)
         del net, opt, x, lab
         torch.cuda.empty_cache()
