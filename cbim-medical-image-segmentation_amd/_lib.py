@@ -89,6 +89,7 @@ _SIGS = {
     "cbim_window_attn3d_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 6 + [vp, vp, vp, vp, sz, vp]),
     "cbim_optim_chunk": (i32, []),
     "cbim_adamw_ema_step": (i32, [vp, vp, vp, i32, vp, vp]),
+    "cbim_ema_step": (i32, [vp, vp, vp, i32, f32, f32, vp]),
     "cbim_softmax_accumulate": (i32, [vp, vp, vp] + [i32] * 11 + [vp]),
     "cbim_prob_finalize": (i32, [vp, vp, vp, i32, i32, i64, vp]),
     "cbim_dice_counts": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp]),

@@ -52,6 +52,21 @@ __global__ void __launch_bounds__(ONT) k_adamw_ema(const cbim_optim_tensor* __re
   }
 }
 
+// update_ema_variables alone (training/utils.py:98-102), for callers that keep torch's optimizer:
+// ema = a*ema + (1-a)*p over every tensor of the table in one launch (records use .p and .ema only).
+__global__ void __launch_bounds__(ONT) k_ema(const cbim_optim_tensor* __restrict__ tab, const int32_t* __restrict__ blk_tensor,
+                                             const int32_t* __restrict__ blk_chunk, float a, float oma) {
+  const cbim_optim_tensor t = tab[blk_tensor[blockIdx.x]];
+  const int64_t base = (int64_t)blk_chunk[blockIdx.x] * OCHUNK;
+  const float* p = (const float*)t.p;
+  float* e = (float*)t.ema;
+  for (int i = threadIdx.x; i < OCHUNK; i += ONT) {
+    int64_t k = base + i;
+    if (k >= t.numel) break;
+    e[k] = fmaf(oma, p[k], e[k] * a);   // ema.mul_(alpha) rounds, .add_(param, alpha=1-alpha) is a fused multiply-add in ATen
+  }
+}
+
 }  // namespace cbim
 
 using namespace cbim;
@@ -66,6 +81,15 @@ extern "C" int cbim_adamw_ema_step(const cbim_optim_tensor* tensors, const int32
   CBIM_LAUNCH(k_adamw_ema, dim3(nblocks), dim3(ONT), 0, st, tensors, blk_tensor, blk_chunk, (const float*)hyper);
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "adamw_ema_step launch: %s", hipGetErrorString(e));
+  return CBIM_OK;
+}
+
+extern "C" int cbim_ema_step(const cbim_optim_tensor* tensors, const int32_t* blk_tensor, const int32_t* blk_chunk,
+                             int nblocks, float alpha, float one_minus_alpha, void* stream) {
+  CBIM_CHECK(tensors && blk_tensor && blk_chunk && nblocks >= 1, CBIM_EINVAL, "ema_step: bad arguments");
+  CBIM_LAUNCH(k_ema, dim3(nblocks), dim3(ONT), 0, (hipStream_t)stream, tensors, blk_tensor, blk_chunk, alpha, one_minus_alpha);
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "ema_step launch: %s", hipGetErrorString(e));
   return CBIM_OK;
 }
 

@@ -341,6 +341,12 @@ typedef struct {
 int cbim_optim_chunk(void);
 int cbim_adamw_ema_step(const cbim_optim_tensor* tensors, const int32_t* blk_tensor, const int32_t* blk_chunk,
                         int nblocks, float* hyper, void* stream);
+/* update_ema_variables alone (/root/reference/training/utils.py:98-102, called at train.py:218) for callers that keep
+ * another optimizer: ema = alpha*ema + (1-alpha)*p over every record (.p, .ema, .numel used) in one launch; alpha is
+ * the already clamped min(1 - 1/(global_step+1), ema_alpha), one_minus_alpha = (float)(1 - (double)alpha) as torch
+ * rounds the scalar of add_(param, alpha=1-alpha); the result is bit-identical to the reference's loop. */
+int cbim_ema_step(const cbim_optim_tensor* tensors, const int32_t* blk_tensor, const int32_t* blk_chunk, int nblocks,
+                  float alpha, float one_minus_alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sliding-window inference + evaluation Dice.

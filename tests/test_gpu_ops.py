@@ -150,6 +150,11 @@ def test_resnorm(dev, dtype):
     oc.check_resnorm(dev, dtype, N=1, C=768, dhw=(4, 4, 4))
 
 
+def test_training_utils_surface(dev):
+    from tests.optim_checks import check_training_utils_surface
+    check_training_utils_surface(dev)
+
+
 def test_fused_adamw_ema(dev):
     from tests.optim_checks import check_adamw_ema
     check_adamw_ema(dev)

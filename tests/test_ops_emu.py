@@ -148,6 +148,11 @@ def test_fused_adamw_ema(dev):
     check_adamw_ema(dev)
 
 
+def test_training_utils_surface(dev):
+    from tests.optim_checks import check_training_utils_surface
+    check_training_utils_surface(dev)
+
+
 def test_inference_and_dice(dev):
     from tests import infer_checks as ic
     ic.check_dice_exact(dev)
