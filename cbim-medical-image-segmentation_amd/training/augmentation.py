@@ -245,9 +245,35 @@ def crop_3d(tensor_img, tensor_lab, crop_size, mode):
         rand_x = np.random.randint(0, max(diff_W, 1))
     else:
         rand_z, rand_y, rand_x = diff_D // 2, diff_H // 2, diff_W // 2
+    return _crop_at(tensor_img, tensor_lab, crop_size, rand_z, rand_y, rand_x)
+
+
+def _crop_at(tensor_img, tensor_lab, crop_size, z0, y0, x0):
+    _, Cc, D, H, W = tensor_img.shape
+    if min(z0, y0, x0) < 0 or z0 + crop_size[0] > D or y0 + crop_size[1] > H or x0 + crop_size[2] > W:
+        raise ValueError(f"cbim_amd: crop window {(z0, y0, x0)}+{tuple(crop_size)} leaves the {(D, H, W)} volume")
     img, lab = tensor_img.contiguous(), tensor_lab.contiguous()
     oimg = torch.empty((1, Cc) + tuple(crop_size), dtype=torch.float32, device=img.device)
     olab = torch.empty((1, 1) + tuple(crop_size), dtype=lab.dtype, device=img.device)
     check(_lib.lib().cbim_crop3d(_p(img), _p(lab), _lab_bytes(lab), _p(oimg), _p(olab), Cc, D, H, W, *crop_size,
-                                 rand_z, rand_y, rand_x, _stream(img)), "crop3d")
+                                 z0, y0, x0, _stream(img)), "crop3d")
     return oimg, olab
+
+
+def crop_around_coordinate_3d(tensor_img, tensor_lab, crop_size, coordinate, mode):
+    """augmentation.py:346-382: a window of crop_size near (z, y, x) — "random": origin drawn (np.random.randint, z then y
+    then x) from [max(0, c - size), min(dim - size, c + size)); "center": origin max(0, c - ceil(size/2)) clamped to the
+    volume."""
+    assert mode in ["random", "center"], "Invalid Mode, should be 'random' or 'center'"
+    if isinstance(crop_size, int):
+        crop_size = [crop_size] * 3
+    _need5(tensor_img)
+    _dev_ok(tensor_img, tensor_lab)
+    z, y, x = (int(c) for c in coordinate)
+    _, _, D, H, W = tensor_img.shape
+    dims, cs = (D, H, W), tuple(int(c) for c in crop_size)
+    if mode == "random":
+        org = [np.random.randint(max(0, c - s), min(d - s, c + s)) for c, s, d in zip((z, y, x), cs, dims)]
+    else:
+        org = [min(max(0, c - math.ceil(s / 2)), d - s) for c, s, d in zip((z, y, x), cs, dims)]
+    return _crop_at(tensor_img, tensor_lab, list(cs), *org)

@@ -114,6 +114,24 @@ def crop_3d(img, lab, crop_size, mode):                              # :320-343
     return img[sl].contiguous(), lab[sl].contiguous()
 
 
+def crop_around_coordinate_3d(img, lab, crop_size, coordinate, mode):   # :346-382
+    if isinstance(crop_size, int):
+        crop_size = [crop_size] * 3
+    z, y, x = coordinate
+    _, _, D, H, W = img.shape
+    dD, dH, dW = D - crop_size[0], H - crop_size[1], W - crop_size[2]
+    if mode == "random":
+        rz = np.random.randint(max(0, z - crop_size[0]), min(dD, z + crop_size[0]))
+        ry = np.random.randint(max(0, y - crop_size[1]), min(dH, y + crop_size[1]))
+        rx = np.random.randint(max(0, x - crop_size[2]), min(dW, x + crop_size[2]))
+    else:
+        rz = min(max(0, z - math.ceil(crop_size[0] / 2)), D - crop_size[0])
+        ry = min(max(0, y - math.ceil(crop_size[1] / 2)), H - crop_size[1])
+        rx = min(max(0, x - math.ceil(crop_size[2] / 2)), W - crop_size[2])
+    sl = (slice(None), slice(None), slice(rz, rz + crop_size[0]), slice(ry, ry + crop_size[1]), slice(rx, rx + crop_size[2]))
+    return img[sl].contiguous(), lab[sl].contiguous()
+
+
 def amos_train_sample(img, lab, training_size, affine_pad_size, scale, rotate, translate):
     """AMOSDataset.__getitem__, train mode (/root/reference/training/dataset/dim3/dataset_amos_ct.py:105-165) on one
     volume: img float [C,D,H,W], lab int8 [1,D,H,W]; random draws in the reference's order."""

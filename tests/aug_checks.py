@@ -41,6 +41,33 @@ def run(dev, A=None):
     return res
 
 
+def coordinate_crop(dev):
+    """crop_around_coordinate_3d (augmentation.py:346-382) against the oracle restatement under the same numpy seed, and
+    against the reference itself when its tree is mounted (build container)."""
+    import os
+    from cbim_amd.training import augmentation as A
+    from oracle import augment_ref as R
+    g = load_golden("aug_1x1x20x24x28")
+    img, lab = torch.from_numpy(g["img"]), torch.from_numpy(g["lab"])
+    fns = [R.crop_around_coordinate_3d]
+    if os.path.isfile("/root/reference/training/augmentation.py"):
+        import importlib.util
+        import sys
+        import types
+        for missing in ("torchvision", "torchvision.transforms"):
+            sys.modules.setdefault(missing, types.ModuleType(missing))
+        spec = importlib.util.spec_from_file_location("ref_aug_live", "/root/reference/training/augmentation.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        fns.append(mod.crop_around_coordinate_3d)
+    for mode in ("random", "center"):
+        for coord in ((10, 12, 14), (0, 0, 0), (19, 23, 27), (3, 20, 9)):
+            mine = _seeded(lambda: A.crop_around_coordinate_3d(img.to(dev), lab.to(dev), [8, 10, 12], coord, mode))
+            for fn in fns:
+                want = _seeded(lambda: fn(img, lab, [8, 10, 12], coord, mode))
+                assert torch.equal(mine[0].cpu(), want[0]) and torch.equal(mine[1].cpu(), want[1]), (mode, coord)
+
+
 def check(res, fused=None):
     assert res["affine_img"] < 2e-5, res
     assert res["affine_lab_mismatch"] < 2e-4, res     # nearest-neighbour ties at x.5 under fp32 coordinate rounding

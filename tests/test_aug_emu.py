@@ -20,6 +20,7 @@ def test_hip_augmentation_matches_reference_golden(dev):
     print(res)
     aug_checks.check(res)
     aug_checks.fused_crop(dev)
+    aug_checks.coordinate_crop(dev)
 
 
 def test_resident_dataset_pipeline_matches_oracle(dev):
