@@ -47,17 +47,30 @@ __device__ __forceinline__ void load_row_chunk(float* x, const void* __restrict_
   for (int k = 0; k < DC; ++k) x[k] = (valid && d0 + k < dh) ? Elem<T>::load1(p, base + (size_t)(d0 + k) * heads) : 0.f;
 }
 
-__device__ __forceinline__ float dot_chunk(const float* x, const float* w) {
-  const f32x4* w4 = (const f32x4*)w;
-  float s = 0.f;
+// The library is built with -ffp-contract=off (bit-identical results between builds), so a*b+c written with
+// operators costs a multiply AND an add, and `s += ...` over a chunk is one 64-deep dependent chain; the helpers below
+// use fmaf explicitly and keep U independent sums (U codes at a time) so that the LDS reads of U rows are in flight
+// together.
+template <int U>
+__device__ __forceinline__ void dot_rows(const float* x, const float* w, float* s) {   // s[u] = <x, w[u][:]>
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = 0.f;
 #pragma unroll
   for (int k4 = 0; k4 < DC / 4; ++k4) {
-    const f32x4 v = w4[k4];
-    s += x[4 * k4] * v.x;
-    s += x[4 * k4 + 1] * v.y;
-    s += x[4 * k4 + 2] * v.z;
-    s += x[4 * k4 + 3] * v.w;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f32x4 v = ((const f32x4*)(w + u * DC))[k4];
+      s[u] = fmaf(x[4 * k4], v.x, s[u]);
+      s[u] = fmaf(x[4 * k4 + 1], v.y, s[u]);
+      s[u] = fmaf(x[4 * k4 + 2], v.z, s[u]);
+      s[u] = fmaf(x[4 * k4 + 3], v.w, s[u]);
+    }
   }
+}
+
+__device__ __forceinline__ float dot_chunk(const float* x, const float* w) {
+  float s;
+  dot_rows<1>(x, w, &s);
   return s;
 }
 
@@ -66,12 +79,14 @@ __device__ __forceinline__ void axpy_chunk(float* o, float e, const float* w) {
 #pragma unroll
   for (int k4 = 0; k4 < DC / 4; ++k4) {
     const f32x4 v = w4[k4];
-    o[4 * k4] += e * v.x;
-    o[4 * k4 + 1] += e * v.y;
-    o[4 * k4 + 2] += e * v.z;
-    o[4 * k4 + 3] += e * v.w;
+    o[4 * k4] = fmaf(e, v.x, o[4 * k4]);
+    o[4 * k4 + 1] = fmaf(e, v.y, o[4 * k4 + 1]);
+    o[4 * k4 + 2] = fmaf(e, v.z, o[4 * k4 + 2]);
+    o[4 * k4 + 3] = fmaf(e, v.w, o[4 * k4 + 3]);
   }
 }
+
+static constexpr int JU = 4;   // codes per trip of the per-voxel loops
 
 // logits of this block: Et[j] = scale * sum_d q[d] mq[j][d]  (own row of E)
 template <typename T>
@@ -84,7 +99,14 @@ __device__ __forceinline__ void block_logits(float* Et, float* Wc, const void* _
     float q[DC];
     load_row_chunk<T>(q, qv, qbase, heads, dh, d0, valid);
     __syncthreads();
-    for (int j = 0; j < M; ++j) {
+    int j = 0;
+    for (; j + JU <= M; j += JU) {
+      float s[JU];
+      dot_rows<JU>(q, Wc + j * DC, s);
+#pragma unroll
+      for (int u = 0; u < JU; ++u) Et[j + u] = d0 == 0 ? s[u] : Et[j + u] + s[u];
+    }
+    for (; j < M; ++j) {
       const float s = dot_chunk(q, Wc + j * DC);
       Et[j] = d0 == 0 ? s : Et[j] + s;
     }
@@ -254,7 +276,14 @@ __global__ void __launch_bounds__(WT) k_attnw_bwd(const void* __restrict__ qv, i
     float g[DC];
     load_row_chunk<T>(g, dfo, grow, heads, dh, d0, valid);
     __syncthreads();
-    for (int j = 0; j < M; ++j) {
+    int j = 0;
+    for (; j + JU <= M; j += JU) {
+      float s[JU];
+      dot_rows<JU>(g, Wc + j * DC, s);
+#pragma unroll
+      for (int u = 0; u < JU; ++u) Bt[j + u] = d0 == 0 ? s[u] : Bt[j + u] + s[u];
+    }
+    for (; j < M; ++j) {
       const float s = dot_chunk(g, Wc + j * DC);
       Bt[j] = d0 == 0 ? s : Bt[j] + s;
     }
@@ -271,7 +300,19 @@ __global__ void __launch_bounds__(WT) k_attnw_bwd(const void* __restrict__ qv, i
 #pragma unroll
     for (int k = 0; k < DC; ++k) dv[k] = 0.f;
     __syncthreads();
-    for (int j = 0; j < M; ++j) {
+    int j = 0;
+    for (; j + JU <= M; j += JU) {
+      float s[JU], p2[JU];
+      dot_rows<JU>(v, Wc + j * DC, s);
+#pragma unroll
+      for (int u = 0; u < JU; ++u) {
+        p2[u] = expf(At[j + u] - cM[j + u]) * cIS[j + u];
+        Bt[j + u] += p2[u] * (d0 == 0 ? s[u] - cj[j + u] : s[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < JU; ++u) axpy_chunk(dv, p2[u], Wc + (j + u) * DC);
+    }
+    for (; j < M; ++j) {
       const float p2 = expf(At[j] - cM[j]) * cIS[j];
       const float s = dot_chunk(v, Wc + j * DC);
       Bt[j] += p2 * (d0 == 0 ? s - cj[j] : s);
@@ -358,7 +399,17 @@ __global__ void __launch_bounds__(WT) k_mappoolw_bwd(const void* __restrict__ fw
       g[k] = 0.f;
     }
     __syncthreads();
-    for (int j = 0; j < M; ++j) {
+    int j = 0;
+    for (; j + JU <= M; j += JU) {
+      float s[JU];
+      dot_rows<JU>(f, Wc + j * DC, s);
+#pragma unroll
+      for (int u = 0; u < JU; ++u) {
+        Tt[j + u] += s[u];
+        axpy_chunk(g, Pt[j + u], Wc + (j + u) * DC);
+      }
+    }
+    for (; j < M; ++j) {
       Tt[j] += dot_chunk(f, Wc + j * DC);
       axpy_chunk(g, Pt[j], Wc + j * DC);
     }

@@ -55,3 +55,75 @@ def test_medformer_attention_shapes_are_supported(cfg):
             assert chan[i] % a["num_heads"][i] == 0
             dh = chan[i] // a["num_heads"][i]
             assert L.cbim_bidir_attn_workspace(1, 4096, a["num_heads"][i], dh, codes) > 0
+
+
+def _step_properties(cfg, dev, size=None, dtype="bf16"):
+    import torch
+    import cbim_amd
+    from cbim_amd.model.utils import get_model
+    from cbim_amd.training.losses import DiceCELoss
+    from cbim_amd.training.utils import get_optimizer
+    a = dict(SHIPPED[cfg]["args"])
+    cbim_amd.set_compute_dtype(dtype)
+    try:
+        torch.manual_seed(2023)
+        net = get_model(argparse.Namespace(**a)).to(dev).train()
+        size = list(size or a["training_size"])
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn((1, a["in_chan"], *size), generator=g).clamp_(-7.4, 2.2).to(dev)
+        lab = torch.randint(0, a["classes"], (1, 1, *size), generator=g).to(dev)
+        w = torch.tensor(a.get("weight", [1.0] * a["classes"]), dtype=torch.float32)
+        crit = DiceCELoss(w).to(dev)
+        opt = get_optimizer(argparse.Namespace(optimizer="adamw", base_lr=6e-4, betas=[0.9, 0.999], weight_decay=0.05), net)
+
+        def loss_of(out):
+            if isinstance(out, (list, tuple)):                 # train.py:206-210
+                return sum(aw * crit(o, lab) for aw, o in zip(a.get("aux_weight", [0.5, 0.5]), out))
+            return crit(out, lab)
+
+        first = float(loss_of(net(x)).detach())
+        out = net(x)
+        main = out[0] if isinstance(out, (list, tuple)) else out
+        assert tuple(main.shape) == (1, a["classes"], *size), (cfg, tuple(main.shape))
+        loss = loss_of(out)
+        second = float(loss.detach())
+        assert first == first and abs(first) < 1e4, (cfg, first)
+        # fixed-order reductions in every hand-written kernel: bit-identical; SwinUNETR's token GEMMs are library calls
+        tol = 1e-6 * abs(first) if a["model"] == "swin_unetr" else 0.0
+        assert abs(second - first) <= tol, (cfg, first, second)
+        loss.backward()
+        params = list(net.parameters())
+        with_grad = [p for p in params if p.grad is not None]
+        assert len(with_grad) >= 0.8 * len(params), (cfg, len(with_grad), len(params))
+        assert all(bool(torch.isfinite(p.grad).all()) for p in with_grad), cfg
+        opt.step()
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(p).all()) for p in params), cfg
+        return first
+    finally:
+        cbim_amd.set_compute_dtype(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", sorted(SHIPPED))
+def test_training_step_at_shipped_training_size(cfg):
+    """Full-size property check (no oracle at these sizes): every shipped configuration runs one bf16 training step
+    (forward, CE+Dice with the yaml's class / aux weights, backward, fused AdamW) at ITS OWN training_size on the GPU — the
+    loss is finite and identical when the forward is repeated (fixed-order reductions), every gradient and updated
+    parameter is finite, the logits have the input's spatial shape."""
+    import torch
+    try:
+        print(cfg, _step_properties(cfg, torch.device("cuda", 0)))
+    finally:
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("CBIM_SLOW"), reason="minutes on the host-side executor; set CBIM_SLOW=1")
+@pytest.mark.parametrize("cfg,size", [("acdc/unet_3d.yaml", (8, 32, 32)), ("acdc/medformer_3d.yaml", (8, 32, 32))])
+def test_training_step_properties_on_executor(cfg, size, dev):
+    """The same check at a reduced spatial size on the host-side executor (full channel widths)."""
+    if dev != "cpu":
+        pytest.skip("CPU suite")
+    print(cfg, _step_properties(cfg, "cpu", size=size))
