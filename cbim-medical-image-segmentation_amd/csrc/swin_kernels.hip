@@ -136,14 +136,14 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_fwd(WinGeom g, const voi
   for (int j = 0; j < n; ++j) {
     float sc = 0.f;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) sc += q[d] * s.A[j * DH + d];
+    for (int d = 0; d < DH; ++d) sc = fmaf(q[d], s.A[j * DH + d], sc);   // explicit: the build has -ffp-contract=off
     sc += s.tbl[myb - s.bco[j] + off0];
     if (g.masked && s.lab[j] != mylab) sc += -100.f;
     float mn = fmaxf(m, sc);
     float corr = expf(m - mn), p = expf(sc - mn);
     l = l * corr + p;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) o[d] = o[d] * corr + p * s.Bv[j * DH + d];
+    for (int d = 0; d < DH; ++d) o[d] = fmaf(p, s.Bv[j * DH + d], o[d] * corr);
     m = mn;
   }
   lse_out[((size_t)win * g.heads + h) * WMAX + t] = m + logf(l);
@@ -208,14 +208,14 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_bwd(WinGeom g, const voi
     if (act) {
       float sc = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) { sc += q[d] * s.A[j * DH + d]; dp += go[d] * s.Bv[j * DH + d]; }
+      for (int d = 0; d < DH; ++d) { sc = fmaf(q[d], s.A[j * DH + d], sc); dp = fmaf(go[d], s.Bv[j * DH + d], dp); }
       int idx = myb - s.bco[j] + off0;
       sc += s.tbl[idx];
       if (g.masked && s.lab[j] != mylab) sc += -100.f;
       float p = expf(sc - mylse);
       float ds = p * (dp - myD);
 #pragma unroll
-      for (int d = 0; d < DH; ++d) dq[d] += ds * s.A[j * DH + d];
+      for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, s.A[j * DH + d], dq[d]);
       s.hist[idx] += ds;                // distinct idx for distinct queries at a fixed j
     }
     __syncthreads();
@@ -239,13 +239,13 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_bwd(WinGeom g, const voi
     for (int i = 0; i < n; ++i) {
       float sc = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) { sc += s.A[i * DH + d] * kk[d]; dp += s.Bv[i * DH + d] * vv[d]; }
+      for (int d = 0; d < DH; ++d) { sc = fmaf(s.A[i * DH + d], kk[d], sc); dp = fmaf(s.Bv[i * DH + d], vv[d], dp); }
       sc += s.tbl[s.bco[i] - myb + off0];
       if (g.masked && s.lab[i] != mylab) sc += -100.f;
       float p = expf(sc - s.lse[i]);
       float ds = p * (dp - s.dsum[i]);
 #pragma unroll
-      for (int d = 0; d < DH; ++d) { dv[d] += p * s.Bv[i * DH + d]; dk[d] += ds * s.A[i * DH + d]; }
+      for (int d = 0; d < DH; ++d) { dv[d] = fmaf(p, s.Bv[i * DH + d], dv[d]); dk[d] = fmaf(ds, s.A[i * DH + d], dk[d]); }
     }
     if (myrow >= 0) {
 #pragma unroll
