@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(AT) k_attn_fwd(const void* __restrict__ qv, in
     if (j < M) {
       s = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) s += q[d] * mqh[(size_t)j * inner + d * heads];
+      for (int d = 0; d < DH; ++d) s = fmaf(q[d], mqh[(size_t)j * inner + d * heads], s);   // -ffp-contract=off build
       s *= scale;
     }
     a[j] = s;
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(AT) k_attn_fwd(const void* __restrict__ qv, in
       float e = expf(a[j] - mx);
       sum += e;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) o[d] += e * mvh[(size_t)j * inner + d * heads];
+      for (int d = 0; d < DH; ++d) o[d] = fmaf(e, mvh[(size_t)j * inner + d * heads], o[d]);
     }
   }
   if (valid) {
@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(AT) k_attn_fwd(const void* __restrict__ qv, in
       float e = E_s[r][j];
       s += e;
 #pragma unroll
-      for (int k = 0; k < HD; ++k) acc[k] += e * v_s[r][d0 + k];
+      for (int k = 0; k < HD; ++k) acc[k] = fmaf(e, v_s[r][d0 + k], acc[k]);
     }
     if (j < M) {
       float* p = part + ((((size_t)n * heads + h) * nblk + blk) * M + j) * (DH + 2);
@@ -678,15 +678,15 @@ __global__ void __launch_bounds__(AT) k_attn_bwd(const void* __restrict__ qv, in
     if (j < M) {
       s = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) s += q[d] * mqh[(size_t)j * inner + d * heads];
+      for (int d = 0; d < DH; ++d) s = fmaf(q[d], mqh[(size_t)j * inner + d * heads], s);
       s *= scale;
       // map side: P2 = exp(a - colmax)/colsum; dA2 = P2*(v.dmo_j - <map_out_j, dmo_j>)
       float p2 = expf(s - cM[j]) * cIS[j], dp2 = 0.f;
 #pragma unroll
       for (int d = 0; d < DH; ++d) {
         float w = dmh[(size_t)j * inner + d * heads];
-        dp2 += v[d] * w;
-        dv[d] += p2 * w;
+        dp2 = fmaf(v[d], w, dp2);
+        dv[d] = fmaf(p2, w, dv[d]);
       }
       da = p2 * (dp2 - cj[j]);
     }
@@ -707,7 +707,7 @@ __global__ void __launch_bounds__(AT) k_attn_bwd(const void* __restrict__ qv, in
     float dp = 0.f;
     if (j < M) {
 #pragma unroll
-      for (int d = 0; d < DH; ++d) dp += g[d] * mvh[(size_t)j * inner + d * heads];
+      for (int d = 0; d < DH; ++d) dp = fmaf(g[d], mvh[(size_t)j * inner + d * heads], dp);
     }
     A_s[t][j] = dp;  // own row only
     rr += a[j] * dp;
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(AT) k_attn_bwd(const void* __restrict__ qv, in
     dA[j] += a[j] * (A_s[t][j] - rr);
     if (j < M) {
 #pragma unroll
-      for (int d = 0; d < DH; ++d) dq[d] += dA[j] * mqh[(size_t)j * inner + d * heads];
+      for (int d = 0; d < DH; ++d) dq[d] = fmaf(dA[j], mqh[(size_t)j * inner + d * heads], dq[d]);
     }
   }
   if (valid) {
@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(AT) k_attn_bwd(const void* __restrict__ qv, in
     for (int r = 0; r < AT; ++r) {
       float e = A_s[r][j];
 #pragma unroll
-      for (int k = 0; k < HD; ++k) acc[k] += e * B_s[r][d0 + k];
+      for (int k = 0; k < HD; ++k) acc[k] = fmaf(e, B_s[r][d0 + k], acc[k]);
     }
     if (j < M) {
 #pragma unroll
@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw,
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc[u][w] += e[u] * f[w];
+        for (int w = 0; w < 4; ++w) acc[u][w] = fmaf(e[u], f[w], acc[u][w]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(AT) k_mappool_bwd(const void* __restrict__ fw,
           float gsum = 0.f;
 #pragma unroll
           for (int j = 0; j < MM; ++j)
-            if (j < M) { tt[j] += f[k] * dm[j]; gsum += P[j] * dm[j]; }
+            if (j < M) { tt[j] = fmaf(f[k], dm[j], tt[j]); gsum = fmaf(P[j], dm[j], gsum); }
           g[k] = gsum;
         }
         st_chunk<T>(dfw, drow + c0, Elem<T>::pack(g));
@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(AT) k_mappool_bwd(const void* __restrict__ fw,
     const float* dm = dmap + ((size_t)n * C + c) * M;
 #pragma unroll
     for (int j = 0; j < MM; ++j)
-      if (j < M) { tt[j] += f * dm[j]; gsum += P[j] * dm[j]; }
+      if (j < M) { tt[j] = fmaf(f, dm[j], tt[j]); gsum = fmaf(P[j], dm[j], gsum); }
     Elem<T>::store1(dfw, drow + c, gsum);
   }
 #pragma unroll
