@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(NT) k_dwconv(const void* __restrict__ x, int64
             float v = f[j];
             if (in_stats) v = act_fwd((v - mean[j]) * rstd[j], act);
             v += bs[j];
-            acc[j] += v * w[(size_t)(c0 + j) * TT + wt];
+            acc[j] = fmaf(v, w[(size_t)(c0 + j) * TT + wt], acc[j]);   // explicit: -ffp-contract=off build
           }
         }
       }
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(NT) k_dwconv_wgrad(const void* __restrict__ x,
         xv = act_fwd((xv - mean) * rstd, act);
       }
       float gv = g[j] + (dy_bias ? dy_bias[(size_t)n * C + c0 + j] : 0.f);
-      acc[j] += xv * gv;
+      acc[j] = fmaf(xv, gv, acc[j]);
     }
   }
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int6
 #pragma unroll
           for (int o = 0; o < WT; ++o)
 #pragma unroll
-            for (int j = 0; j < CPC; ++j) acc[o][j] += in[o + c][j] * wv[j];
+            for (int j = 0; j < CPC; ++j) acc[o][j] = fmaf(in[o + c][j], wv[j], acc[o][j]);   // 27 taps x 8 channels per output: VALU-bound, mul+add would double it
         }
       }
     }
@@ -306,9 +306,9 @@ __global__ void __launch_bounds__(NT) k_dwconv3_wgrad(const void* __restrict__ x
 #pragma unroll
           for (int j = 0; j < CPC; ++j) {
             float gv = g[j] + bs[j];
-            acc[0][j] += xm[j] * gv;
-            acc[1][j] += xc[j] * gv;
-            acc[2][j] += xp[j] * gv;
+            acc[0][j] = fmaf(xm[j], gv, acc[0][j]);
+            acc[1][j] = fmaf(xc[j], gv, acc[1][j]);
+            acc[2][j] = fmaf(xp[j], gv, acc[2][j]);
             xm[j] = xc[j];
             xc[j] = xp[j];
           }
@@ -424,9 +424,9 @@ __global__ void __launch_bounds__(NT) k_dwconv3_wgrad_lds(const void* __restrict
         }
 #pragma unroll
         for (int j = 0; j < CPC; ++j) {
-          acc[0][j] += x0[j] * g[j];
-          acc[1][j] += x1[j] * g[j];
-          acc[2][j] += x2[j] * g[j];
+          acc[0][j] = fmaf(x0[j], g[j], acc[0][j]);
+          acc[1][j] = fmaf(x1[j], g[j], acc[1][j]);
+          acc[2][j] = fmaf(x2[j], g[j], acc[2][j]);
           x0[j] = x1[j];
           x1[j] = x2[j];
         }
