@@ -133,17 +133,36 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_fwd(WinGeom g, const voi
   float m = -INFINITY, l = 0.f, o[DH];
 #pragma unroll
   for (int d = 0; d < DH; ++d) o[d] = 0.f;
-  for (int j = 0; j < n; ++j) {
-    float sc = 0.f;
+  // online softmax over tiles of KT keys: one running-maximum update and one rescale of (l, o) per tile instead of per
+  // key (the per-key form spent DH multiplies and a second expf on the rescale alone)
+  constexpr int KT = 4;
+  for (int j0 = 0; j0 < n; j0 += KT) {
+    float sc[KT];
 #pragma unroll
-    for (int d = 0; d < DH; ++d) sc = fmaf(q[d], s.A[j * DH + d], sc);   // explicit: the build has -ffp-contract=off
-    sc += s.tbl[myb - s.bco[j] + off0];
-    if (g.masked && s.lab[j] != mylab) sc += -100.f;
-    float mn = fmaxf(m, sc);
-    float corr = expf(m - mn), p = expf(sc - mn);
-    l = l * corr + p;
+    for (int u = 0; u < KT; ++u) {
+      const int j = j0 + u < n ? j0 + u : n - 1;
+      float a = 0.f;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) o[d] = fmaf(p, s.Bv[j * DH + d], o[d] * corr);
+      for (int d = 0; d < DH; ++d) a = fmaf(q[d], s.A[j * DH + d], a);   // explicit: the build has -ffp-contract=off
+      a += s.tbl[myb - s.bco[j] + off0];
+      if (g.masked && s.lab[j] != mylab) a += -100.f;
+      sc[u] = j0 + u < n ? a : -INFINITY;
+    }
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < KT; ++u) mn = fmaxf(mn, sc[u]);
+    const float corr = expf(m - mn);      // 0 on the first tile (m = -inf, mn finite: key j0 always exists)
+    l *= corr;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] *= corr;
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int j = j0 + u < n ? j0 + u : n - 1;
+      const float p = expf(sc[u] - mn);   // 0 past the last key
+      l += p;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) o[d] = fmaf(p, s.Bv[j * DH + d], o[d]);
+    }
     m = mn;
   }
   lse_out[((size_t)win * g.heads + h) * WMAX + t] = m + logf(l);
