@@ -19,7 +19,8 @@
 // K,V (then Q,dO) of the window live in LDS, read with broadcast; online softmax in registers.  The work is
 // ~61 GFLOP per forward at 128^3 (d_head 16): latency/LDS-bound, not MFMA-shaped at 343x343x16.
 // Every reduction has a fixed order: d(bias table) is accumulated per workgroup in an LDS histogram — at
-// key step j all queries i address distinct entries (i -> B_i - B_j is injective), one barrier per step —
+// key step j all queries i address distinct entries (i -> B_i - B_j is injective), one barrier per two keys
+// (even / odd keys own separate histograms) —
 // and the per-workgroup histograms are summed over windows in launch order.
 #include "cbim_common.h"
 
@@ -68,7 +69,7 @@ struct WinSmem {
   float* A;       // [n][DH]  K   (pass B: scaled Q)
   float* Bv;      // [n][DH]  V   (pass B: dO)
   float* tbl;     // [TS]     bias table column of this head
-  float* hist;    // [TS]     backward only
+  float* hist;    // [2][TS]  backward only: even / odd key steps
   float* lse;     // [n]
   float* dsum;    // [n]
   int* bco;       // [n]
@@ -83,7 +84,7 @@ __device__ __forceinline__ WinSmem win_smem(unsigned char* smem, int TS) {
   s.A = (float*)(smem + o); o += WMAX * DH * 4;
   s.Bv = (float*)(smem + o); o += WMAX * DH * 4;
   s.tbl = (float*)(smem + o); o += TS * 4;
-  s.hist = (float*)(smem + o); o += TS * 4;
+  s.hist = (float*)(smem + o); o += 2 * TS * 4;
   s.lse = (float*)(smem + o); o += WMAX * 4;
   s.dsum = (float*)(smem + o); o += WMAX * 4;
   s.bco = (int*)(smem + o); o += WMAX * 4;
@@ -92,7 +93,7 @@ __device__ __forceinline__ WinSmem win_smem(unsigned char* smem, int TS) {
   s.row = (int64_t*)(smem + o);
   return s;
 }
-static size_t win_smem_bytes(int dh, int TS) { return (size_t)2 * WMAX * dh * 4 + 2 * (size_t)TS * 4 + 4 * WMAX * 4 + 8 + WMAX * 8; }
+static size_t win_smem_bytes(int dh, int TS) { return (size_t)2 * WMAX * dh * 4 + 3 * (size_t)TS * 4 + 4 * WMAX * 4 + 8 + WMAX * 8; }
 
 template <typename T, int DH>
 __global__ void __launch_bounds__(WT_THREADS) k_winattn_fwd(WinGeom g, const void* __restrict__ qkv,
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_bwd(WinGeom g, const voi
   const int win = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
   const int C = g.C;
   const bool act = t < n;
-  for (int i = t; i < TS; i += WT_THREADS) { s.tbl[i] = table[(size_t)i * g.heads + h]; s.hist[i] = 0.f; }
+  for (int i = t; i < TS; i += WT_THREADS) { s.tbl[i] = table[(size_t)i * g.heads + h]; s.hist[i] = 0.f; s.hist[TS + i] = 0.f; }
   float q[DH], kk[DH], vv[DH], go[DH];
   int64_t myrow = -1;
   int mylab = 0, myb = 0;
@@ -219,23 +220,31 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_bwd(WinGeom g, const voi
     s.lse[t] = mylse; s.dsum[t] = myD;
   }
   __syncthreads();
-  // ---- pass A: thread = query i.  dq_i, and the bias-table histogram (one barrier per key step)
+  // ---- pass A: thread = query i.  dq_i, and the bias-table histogram.  At one key j all queries address distinct
+  // entries; two keys per step go to two histograms (even / odd), so there is one barrier per TWO keys and still no
+  // two threads ever touch the same word between barriers.  hist[0] + hist[1] at the end: fixed order.
   float dq[DH];
 #pragma unroll
   for (int d = 0; d < DH; ++d) dq[d] = 0.f;
-  for (int j = 0; j < n; ++j) {
+  for (int j0 = 0; j0 < n; j0 += 2) {
     if (act) {
-      float sc = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) { sc = fmaf(q[d], s.A[j * DH + d], sc); dp = fmaf(go[d], s.Bv[j * DH + d], dp); }
-      int idx = myb - s.bco[j] + off0;
-      sc += s.tbl[idx];
-      if (g.masked && s.lab[j] != mylab) sc += -100.f;
-      float p = expf(sc - mylse);
-      float ds = p * (dp - myD);
+      for (int u = 0; u < 2; ++u) {
+        const int j = j0 + u;
+        if (j < n) {
+          float sc = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, s.A[j * DH + d], dq[d]);
-      s.hist[idx] += ds;                // distinct idx for distinct queries at a fixed j
+          for (int d = 0; d < DH; ++d) { sc = fmaf(q[d], s.A[j * DH + d], sc); dp = fmaf(go[d], s.Bv[j * DH + d], dp); }
+          int idx = myb - s.bco[j] + off0;
+          sc += s.tbl[idx];
+          if (g.masked && s.lab[j] != mylab) sc += -100.f;
+          float p = expf(sc - mylse);
+          float ds = p * (dp - myD);
+#pragma unroll
+          for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, s.A[j * DH + d], dq[d]);
+          s.hist[u * TS + idx] += ds;     // distinct idx for distinct queries at a fixed j
+        }
+      }
     }
     __syncthreads();
   }
@@ -243,7 +252,7 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_bwd(WinGeom g, const voi
 #pragma unroll
     for (int d = 0; d < DH; ++d) Elem<T>::store1(dqkv, (size_t)myrow * 3 * C + h * DH + d, dq[d] * g.scale);
   }
-  for (int i = t; i < TS; i += WT_THREADS) part_tbl[((size_t)win * g.heads + h) * TS + i] = s.hist[i];
+  for (int i = t; i < TS; i += WT_THREADS) part_tbl[((size_t)win * g.heads + h) * TS + i] = s.hist[i] + s.hist[TS + i];
   __syncthreads();
   // ---- pass B: thread = key j.  LDS now holds scaled Q and dO
   if (act) {
