@@ -941,6 +941,83 @@ __global__ void __launch_bounds__(AT) k_mappool_bwd(const void* __restrict__ fw,
     if (j < M) Elem<T>::store1(dfw, drow + C + j, P[j] * (tt[j] - cj[j]));
 }
 
+
+// Same contract as k_mappool_bwd for the all-chunked case (M, C and both row strides multiples of the 16-byte chunk,
+// M <= 64), with FOUR waves per 64 voxels: wave w takes the channel chunks c0 = (w + 4i)*CPC — dfeat chunks are
+// independent, dmap rows stay wave-uniform (scalar loads) — and holds a partial tt over its channels; the partials
+// meet once in LDS and thread (w, voxel) finishes codes 16w..16w+15.  k_mappool_bwd had one thread per voxel: 512 waves
+// for the 32^3 level of the AMOS configuration, two SIMDs of every CU idle and nothing to hide latency with
+// (729 us per call, ~3 % of the vector-ALU peak).
+static constexpr int MP4_T = 256;
+template <typename T>
+__global__ void __launch_bounds__(MP4_T) k_mappool_bwd4(const void* __restrict__ fw, int64_t rs,
+                                                        const float* __restrict__ map, const float* __restrict__ colstat,
+                                                        const float* __restrict__ dmap, void* __restrict__ dfw, int64_t drs,
+                                                        int L, int C, int M) {
+  CBIM_DYN_SMEM(smem);
+  float* TTs = (float*)smem;                 // [4][64][MM + 1]
+  float* cj = TTs + 4 * 64 * (MM + 1);       // [MM]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, n = blockIdx.z;
+  const int l = blockIdx.x * 64 + lane;
+  const bool valid = l < L;
+  if (t < MM) {
+    float c = 0.f;
+    if (t < M)
+      for (int k = 0; k < C; ++k) c = fmaf(map[((size_t)n * C + k) * M + t], dmap[((size_t)n * C + k) * M + t], c);
+    cj[t] = c;
+  }
+  const size_t row = ((size_t)n * L + (valid ? l : 0)) * rs, drow = ((size_t)n * L + (valid ? l : 0)) * drs;
+  constexpr int CPC = Elem<T>::CPC;
+  float P[MM], tt[MM];
+#pragma unroll
+  for (int j0 = 0; j0 < MM; j0 += CPC) {
+    float f[CPC];
+    if (j0 < M) Elem<T>::unpack(ld_chunk<T>(fw, row + C + j0), f);
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      P[j0 + j] = j0 < M ? expf(f[j] - colstat[((size_t)n * M + j0 + j) * 2]) / colstat[((size_t)n * M + j0 + j) * 2 + 1] : 0.f;
+      tt[j0 + j] = 0.f;
+    }
+  }
+  if (valid) {
+    for (int c0 = w * CPC; c0 < C; c0 += 4 * CPC) {
+      float f[CPC], g[CPC];
+      Elem<T>::unpack(ld_chunk<T>(fw, row + c0), f);
+#pragma unroll
+      for (int k = 0; k < CPC; ++k) {
+        const float* dm = dmap + ((size_t)n * C + c0 + k) * M;
+        float gsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < MM; ++j)
+          if (j < M) { tt[j] = fmaf(f[k], dm[j], tt[j]); gsum = fmaf(P[j], dm[j], gsum); }
+        g[k] = gsum;
+      }
+      st_chunk<T>(dfw, drow + c0, Elem<T>::pack(g));
+    }
+  }
+  float* mine = TTs + (size_t)(w * 64 + lane) * (MM + 1);
+#pragma unroll
+  for (int j = 0; j < MM; ++j) mine[j] = tt[j];
+  __syncthreads();
+  if (!valid) return;
+#pragma unroll
+  for (int jj = 0; jj < 16; jj += CPC) {
+    const int j0 = 16 * w + jj;
+    if (j0 < M) {
+      float f[CPC], g[CPC];
+      Elem<T>::unpack(ld_chunk<T>(fw, row + C + j0), f);
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) {
+        const float p = expf(f[j] - colstat[((size_t)n * M + j0 + j) * 2]) / colstat[((size_t)n * M + j0 + j) * 2 + 1];
+        const float* col = TTs + (size_t)lane * (MM + 1) + j0 + j;
+        const float s = ((col[0] + col[64 * (MM + 1)]) + col[2 * 64 * (MM + 1)]) + col[3 * 64 * (MM + 1)];   // wave order
+        g[j] = p * (s - cj[j0 + j]);
+      }
+      st_chunk<T>(dfw, drow + C + j0, Elem<T>::pack(g));
+    }
+  }
+}
+
 }  // namespace cbim
 
 using namespace cbim;
@@ -1243,6 +1320,28 @@ extern "C" int cbim_colsoftmax_pool_bwd(int dtype, const void* fw, int64_t fw_st
     return cbim_mappool_bwd_wide_launch(dtype, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, N, L, C, M, stream);
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
+  const int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  static const int four = getenv("CBIM_MAPPOOL_BWD4") ? atoi(getenv("CBIM_MAPPOOL_BWD4")) : 1;
+  if (four && M % cpc == 0 && C % cpc == 0 && fw_stride % cpc == 0 && dfw_stride % cpc == 0) {
+    const size_t smem = (size_t)(4 * 64 * (MM + 1) + MM) * sizeof(float);
+#ifndef CBIM_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)k_mappool_bwd4<bf16_tag>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipError_t e2 = hipFuncSetAttribute((const void*)k_mappool_bwd4<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      CBIM_CHECK(e1 == hipSuccess && e2 == hipSuccess, CBIM_ELAUNCH, "colsoftmax_pool_bwd: hipFuncSetAttribute failed");
+      attr_done = true;
+    }
+#endif
+    dim3 grid4((L + 63) / 64, 1, N);
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_mappool_bwd4<bf16_tag>), grid4, dim3(MP4_T), smem, st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, L,
+                  C, M);
+    else
+      CBIM_LAUNCH((k_mappool_bwd4<float>), grid4, dim3(MP4_T), smem, st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, L, C,
+                  M);
+    return launch_ok("colsoftmax_pool_bwd (4 waves per 64 voxels)");
+  }
   dim3 grid(nblk, 1, N);
   if (dtype == CBIM_BF16)
     CBIM_LAUNCH((k_mappool_bwd<bf16_tag>), grid, dim3(AT), 0, st, fw, fw_stride, map, colstat, dmap, dfw, dfw_stride, L,

@@ -107,6 +107,7 @@ def test_attn(dev, dtype):
 def test_mappool(dev, dtype):
     oc.check_mappool(dev, dtype)
     oc.check_mappool(dev, dtype, N=1, C=72, M=64, dhw=(6, 6, 5))
+    oc.check_mappool(dev, dtype, N=1, C=40, M=27, dhw=(4, 5, 6))     # bcv map_size [3,3,3]: element-wise (one-wave) backward
     oc.check_mappool(dev, dtype, N=1, C=128, M=64, dhw=(16, 16, 16))
 
 
