@@ -1,0 +1,38 @@
+"""examples/train_synthetic.py — the reference's train.py loop on this package's drop-in surfaces — executed end to end:
+get_model from a shipped yaml record, HBM-resident dataset + on-device augmentation, CE+Dice, fused AdamW, lr schedule,
+EMA update, sliding-window validation + Dice.  CPU: tiny ResUNet on the host-side executor; -m gpu: the same loop on
+the device, where the loss must also fall."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _example():
+    spec = importlib.util.spec_from_file_location("train_synthetic", os.path.join(ROOT, "examples", "train_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_training_loop_runs_on_executor(dev):
+    if dev != "cpu":
+        pytest.skip("CPU suite")
+    r = _example().run("amos_ct/resunet_3d.yaml", iters=1, epochs=1, base=8, size=(16, 16, 16), device="cpu", dtype="fp32",
+                       n_volumes=1, verbose=False, sliding_window=False)   # whole-image validation here; the 8-window pass runs in the gpu test
+    assert r["steps"] == 1 and all(np.isfinite(r["losses"])) and len(r["dice"]) == 16
+    assert all(0.0 <= d <= 1.0 for d in r["dice"])
+
+
+@pytest.mark.gpu
+def test_training_loop_reduces_loss_on_gpu(dev):
+    import torch
+    # train.py:94 hard-codes a 5-epoch exponential warm-up (lr 2.7e-8 at epoch 0): learning starts at epoch ~4
+    r = _example().run("amos_ct/resunet_3d.yaml", iters=8, epochs=8, base=16, size=(64, 64, 64), device=torch.device("cuda", 0),
+                       dtype="bf16", verbose=False)
+    first, last = float(np.mean(r["losses"][:8])), float(np.mean(r["losses"][-8:]))
+    print(first, last, r["dice"])
+    assert all(np.isfinite(r["losses"])) and last < first, (first, last)
