@@ -148,9 +148,18 @@ class SemanticMapGeneration(nn.Module):
         self.semantic_proj = nn.Conv3d(feat_dim, self.map_code_num, kernel_size=3, padding=1, bias=False)
 
     def forward(self, f: Fn.FMap):
-        w = torch.cat([self.base_proj.weight, self.semantic_proj.weight], 0)
+        # the conv kernels move whole 16-byte channel chunks: a code count that is not a multiple of 8 (config/bcv:
+        # map_size [3,3,3] = 27) is padded with zero-weight codes — their logits are 0, their pooled columns are cut
+        # off below and receive no gradient, so the 27 real codes are untouched
+        pad = (-self.map_code_num) % 8
+        parts = [self.base_proj.weight, self.semantic_proj.weight]
+        if pad:
+            parts.append(self.semantic_proj.weight.new_zeros((pad,) + tuple(self.semantic_proj.weight.shape[1:])))
+        w = torch.cat(parts, 0)
         fw, _ = Fn.NormConvFn.apply(f.t, None, w, 0, None, False, None, IN_EPS)
-        mp = Fn.MapPoolFn.apply(fw, self.map_dim)                       # [B, map_dim, codes]
+        mp = Fn.MapPoolFn.apply(fw, self.map_dim)                       # [B, map_dim, codes (+pad)]
+        if pad:
+            mp = mp[..., :self.map_code_num]
         return mp.reshape(mp.shape[0], self.map_dim, *self.map_size)
 
 

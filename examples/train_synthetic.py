@@ -10,7 +10,7 @@ step through this package's drop-in surfaces — on synthetic volumes, because t
     python examples/train_synthetic.py --config amos_ct/resunet_3d.yaml --iters 50          # on an MI355X
 
 The YAML keys come from tests/golden/shipped_configs.json (the values of the reference's own config files); --base /
---size shrink the model and the crop for a quick run.  tests/test_example_loop.py runs it on the host-side executor.
+--size shrink the model and the crop for a quick run.  tests/test_train_loop_example.py runs it on the host-side executor.
 """
 import argparse
 import copy

@@ -14,6 +14,7 @@ Same import shim as make_golden.py.  Cases
   medformer_acdc_tiny the STRUCTURE of config/acdc/medformer_3d.yaml at reduced widths: anisotropic kernels/scales,
                       map_size [2,6,6] = 72 codes, 4 heads everywhere (d_head 8 | 16 | 20), transformer blocks at
                       every inner level — exercises attn_wide.hip and the >64-code map pooling
+  medformer_bcv_tiny  the STRUCTURE of config/bcv/medformer_3d.yaml: 27 map codes (odd: padded code rows), 14 classes
   medformer_lits_tiny the STRUCTURE of config/lits/medformer_3d.yaml: num_heads all 1 (d_head = channels: 32, 64,
                       80), aux_loss False (forward returns one tensor)
 No reference source is copied; only tensors it produced.
@@ -46,6 +47,14 @@ ACDC_T = dict(base_chan=8, map_size=[2, 6, 6], conv_block="BasicBlock", conv_num
               attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu",
               kernel_size=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
               scale=[[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]], aux_loss=True)
+# config/bcv/medformer_3d.yaml's structure: map_size [3,3,3] = 27 codes (not a multiple of the 8-channel chunk: padded with
+# zero-weight codes in SemanticMapGeneration), anisotropic stem, trans_num [0,2,4,6,4,2,0,0] cut to one block per level
+BCV_T = dict(base_chan=8, map_size=[3, 3, 3], conv_block="BasicBlock", conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
+             trans_num=[0, 1, 1, 1, 1, 1, 0, 0], chan_num=[16, 32, 64, 80, 64, 32, 16, 8],
+             num_heads=[1, 2, 4, 5, 4, 2, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
+             attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu",
+             kernel_size=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+             scale=[[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]], aux_loss=True)
 LITS_T = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
               trans_num=[0, 1, 1, 2, 1, 1, 0, 0], chan_num=[16, 32, 64, 80, 64, 32, 16, 8],
               num_heads=[1, 1, 1, 1, 1, 1, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
@@ -59,6 +68,7 @@ CASES = {
     # weights come from the seed (sd_checksum)
     "medformer_acdc_tiny": (1, 4, ACDC_T, (8, 32, 32), 1, 3033, 20000),
     "medformer_lits_tiny": (1, 3, LITS_T, (32, 32, 32), 1, 3034, 20000),
+    "medformer_bcv_tiny": (1, 14, BCV_T, (8, 32, 32), 1, 3041, 20000),   # seed chosen so that the reference fp32 run has no ReLU-mask flip (fp32 vs fp64 gradients 5e-3; seed 3035: 0.29)
 }
 AUX_WEIGHT = [0.5, 0.5]   # config/amos_ct/medformer_3d.yaml: aux_weight
 

@@ -26,13 +26,22 @@ ACDC_T = dict(base_chan=8, map_size=[2, 6, 6], conv_block="BasicBlock", conv_num
               attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu",
               kernel_size=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
               scale=[[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]], aux_loss=True)
+# config/bcv/medformer_3d.yaml's structure: map_size [3,3,3] = 27 codes (not a multiple of the 8-channel chunk: padded with
+# zero-weight codes in SemanticMapGeneration), anisotropic stem, trans_num [0,2,4,6,4,2,0,0] cut to one block per level
+BCV_T = dict(base_chan=8, map_size=[3, 3, 3], conv_block="BasicBlock", conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
+             trans_num=[0, 1, 1, 1, 1, 1, 0, 0], chan_num=[16, 32, 64, 80, 64, 32, 16, 8],
+             num_heads=[1, 2, 4, 5, 4, 2, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
+             attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu",
+             kernel_size=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+             scale=[[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]], aux_loss=True)
 LITS_T = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
               trans_num=[0, 1, 1, 2, 1, 1, 0, 0], chan_num=[16, 32, 64, 80, 64, 32, 16, 8],
               num_heads=[1, 1, 1, 1, 1, 1, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
               attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
               scale=[[2, 2, 2]] * 4, aux_loss=False)
 MF_CASES = {"medformer_tiny_32": (1, 4, TINY), "medformer_amos_64": (1, 16, AMOS),
-            "medformer_acdc_tiny": (1, 4, ACDC_T), "medformer_lits_tiny": (1, 3, LITS_T)}
+            "medformer_acdc_tiny": (1, 4, ACDC_T), "medformer_lits_tiny": (1, 3, LITS_T),
+            "medformer_bcv_tiny": (1, 14, BCV_T)}
 AUX_WEIGHT = (0.5, 0.5)
 
 

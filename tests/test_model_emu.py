@@ -117,6 +117,13 @@ def test_medformer_acdc_structure_fp32_matches_reference_golden(dev):
     print(assert_fp32_parity("medformer_acdc_tiny", dev))
 
 
+def test_medformer_bcv_structure_fp32_matches_reference_golden(dev):
+    """config/bcv/medformer_3d.yaml's structure: 27 map codes — not a multiple of the 8-channel chunk, padded with
+    zero-weight codes in SemanticMapGeneration; the element-wise map-pooling backward and the <=64-code generic attention."""
+    from tests.medformer_checks import assert_fp32_parity
+    print(assert_fp32_parity("medformer_bcv_tiny", dev))
+
+
 @pytest.mark.slow
 @pytest.mark.skipif(not __import__("os").environ.get("CBIM_SLOW"), reason="66 s on the host-side executor; set CBIM_SLOW=1 "
                     "(the same case runs in the -m gpu suite, its attention shapes in test_ops_emu.py)")
