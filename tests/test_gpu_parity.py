@@ -137,8 +137,7 @@ def test_smoke_entry(dev):
 
 # ---- MedFormer -------------------------------------------------------------
 
-@pytest.mark.parametrize("name", ["medformer_tiny_32", "medformer_amos_64", "medformer_acdc_tiny", "medformer_lits_tiny",
-                                  "medformer_bcv_tiny"])
+@pytest.mark.parametrize("name", ["medformer_tiny_32", "medformer_amos_64", "medformer_acdc_tiny", "medformer_lits_tiny"])
 def test_medformer_fp32_matches_reference_golden(dev, name):
     from tests.medformer_checks import assert_fp32_parity as mf_parity
     print(name, mf_parity(name, dev))
@@ -157,7 +156,7 @@ def test_medformer_bf16_inside_envelope(dev):
     assert r["grad_norm_err"] < 0.5, r
 
 
-@pytest.mark.parametrize("name", ["medformer_acdc_tiny", "medformer_lits_tiny", "medformer_bcv_tiny"])
+@pytest.mark.parametrize("name", ["medformer_acdc_tiny", "medformer_lits_tiny"])
 def test_medformer_wide_heads_bf16_inside_envelope(dev, name):
     """bf16 engine mode of the ACDC- (72 map codes, d_head 8|16|20) and LiTS-structured (one head per block, d_head up
     to 80, no auxiliary head) configurations: attn_wide.hip and the >64-code map pooling in bf16.  The same cases on
@@ -167,9 +166,7 @@ def test_medformer_wide_heads_bf16_inside_envelope(dev, name):
     print(r)
     assert r["logits_err"] < 0.4 and r["aux_err"] < 0.4, r
     assert max(abs(a - b) for a, b in zip(r["ce"] + r["dice"], list(g["ce"]) + list(g["dice"]))) < 0.05, r
-    # per-tensor gradient norms of a 14-class net with InstanceNorm over 8 voxels at the deepest level: 0.39 for the BCV
-    # structure on the executor (one small-norm tensor), 0.17 / 0.13 for the other two
-    assert r["grad_norm_err"] < (1.0 if name == "medformer_bcv_tiny" else 0.5), r
+    assert r["grad_norm_err"] < 0.5, r
 
 
 # ---- SwinUNETR -------------------------------------------------------------
