@@ -94,6 +94,38 @@ class BasicBlock(nn.Module):
         return Fn.FMap(out, so if want_out_stats else None)
 
 
+class Bottleneck(nn.Module):
+    """conv3(conv2(conv1(x))) + shortcut(x): pre-activated 1x1x1 -> k^3 -> 1x1x1 with expansion 2, shortcut = identity or
+    a FULL k-sized pre-act ConvNormAct — conv_layers.py:96-125.  Four launches of the implicit-GEMM kernel (InstanceNorm+act
+    of the producer on load, statistics / residual add in the epilogue)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=(3, 3, 3), stride=1, groups=1, dilation=1, norm="in", act="relu",
+                 preact=True):
+        super().__init__()
+        if not preact or groups != 1 or dilation != 1:
+            raise NotImplementedError("cbim_amd: Bottleneck(preact=False / groups / dilation) is not built")
+        self.expansion = 2
+        mid = out_ch // self.expansion
+        self.conv1 = ConvNormAct(in_ch, mid, 1, stride=1, padding=0, norm=norm, act=act, preact=True)
+        self.conv2 = ConvNormAct(mid, mid, kernel_size, stride=stride, norm=norm, act=act, preact=True)
+        self.conv3 = ConvNormAct(mid, out_ch, 1, stride=1, padding=0, norm=norm, act=act, preact=True)
+        self.shortcut = nn.Sequential()
+        if in_ch != out_ch:
+            self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=True)
+
+    def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
+        f = Fn.ensure_stats(f)
+        a = self.conv1.act_code
+        y1, s1 = Fn.NormConvFn.apply(f.t, f.stats, self.conv1.conv.weight, a, None, True, None, IN_EPS)
+        y2, s2 = Fn.NormConvFn.apply(y1, s1, self.conv2.conv.weight, a, None, True, None, IN_EPS)
+        if isinstance(self.shortcut, ConvNormAct):
+            sc, _ = Fn.NormConvFn.apply(f.t, f.stats, self.shortcut.conv.weight, a, None, False, None, IN_EPS)
+        else:
+            sc = f.t
+        out, so = Fn.NormConvFn.apply(y2, s2, self.conv3.conv.weight, a, sc, want_out_stats, None, IN_EPS)
+        return Fn.FMap(out, so if want_out_stats else None)
+
+
 class DepthwiseSeparableConv(nn.Module):
     """depthwise k^3 (groups=C) then pointwise 1^3, no norm/act in between — conv_layers.py:126-157.
     forward: y = pointwise(depthwise(a(IN(x)))) [+ res], a given by (stats, act) of the caller's pre-norm."""

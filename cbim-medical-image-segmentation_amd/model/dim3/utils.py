@@ -1,14 +1,12 @@
 """Name -> class maps with the reference's keys (/root/reference/model/dim3/utils.py:7-30)."""
-from .conv_layers import BasicBlock, SingleConv
+from .conv_layers import BasicBlock, Bottleneck, SingleConv
 
 _NORMS = ("in",)           # every shipped 3D config uses `norm: in`
 _ACTS = ("relu", "lrelu", "gelu", "swish")
 
 
 def get_block(name):
-    blocks = {"SingleConv": SingleConv, "BasicBlock": BasicBlock}
-    if name == "Bottleneck":
-        raise NotImplementedError("cbim_amd: Bottleneck blocks are not built yet (no shipped 3D config uses them)")
+    blocks = {"SingleConv": SingleConv, "BasicBlock": BasicBlock, "Bottleneck": Bottleneck}
     return blocks[name]  # KeyError for unknown names, like the reference
 
 

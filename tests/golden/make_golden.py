@@ -47,6 +47,8 @@ CASES = {
     "unet_single_acdc": (1, 8, 4, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]],
                          [[1, 3, 3], [2, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]], "SingleConv",
                          (16, 32, 32), 1, 2026, False),
+    # UNet(block='Bottleneck') (conv_layers.py:96-125): 1x1 -> 3^3 -> 1x1 with expansion 2, full-size conv shortcuts
+    "resunet_bottleneck_b16": (1, 16, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "Bottleneck", (32, 32, 32), 1, 2027, False),
 }
 
 
@@ -60,7 +62,10 @@ def make_labels(classes, shape, batch, gen):
 def main():
     UNet, DiceLoss = import_reference()
     torch.set_num_threads(8)
+    only = sys.argv[1:]
     for name, (in_ch, base, classes, scale, ks, block, shape, batch, seed, full_sd) in CASES.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(seed)
         net = UNet(in_ch, base, scale=scale, kernel_size=ks, num_classes=classes, block=block, norm="in")
         net.train()

@@ -61,6 +61,8 @@ def test_unbuilt_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         get_model(_args(norm="bn"))
     with pytest.raises(NotImplementedError):
+        get_model(_args(block="Bottleneck", norm="ln"))
+    with pytest.raises(NotImplementedError):
         get_model(_args(model="vtunet"))
     with pytest.raises(KeyError):
         from cbim_amd.model.dim3 import UNet
@@ -80,6 +82,16 @@ def test_unet_singleconv_acdc_fp32_matches_reference_golden(dev):
     from tests.model_checks import assert_fp32_parity
     r = assert_fp32_parity("unet_single_acdc", dev)
     print(r)
+
+
+def test_resunet_bottleneck_fp32_matches_reference_golden(dev):
+    """UNet(block='Bottleneck') (conv_layers.py:96-125) against the real reference, inside the reference's own
+    fp32-vs-fp64 envelope on this fixture (see tests/model_checks.py)."""
+    from tests.model_checks import assert_fp32_parity
+    from cbim_amd.model.utils import get_model
+    print(assert_fp32_parity("resunet_bottleneck_b16", dev, max_flips=2, g_stem_tol=5e-2))
+    net = get_model(_args(block="Bottleneck"))
+    assert "down1.conv.1.conv3.conv.weight" in net.state_dict()
 
 
 def test_dice_loss_module_matches_reference_value(dev):

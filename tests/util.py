@@ -15,6 +15,7 @@ CASES = {
     "unet_single_acdc": (1, 8, 4, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]],
                          [[1, 3, 3], [2, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]], "SingleConv",
                          (16, 32, 32), 1, 2026),
+    "resunet_bottleneck_b16": (1, 16, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "Bottleneck", (32, 32, 32), 1, 2027),
 }
 
 
