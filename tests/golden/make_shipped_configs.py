@@ -65,8 +65,8 @@ def main():
             "n_buffers": len(list(net.buffers())), "layout_sha256": layout_digest(sd),
         }
         print(rel, out[rel]["n_params"], out[rel]["n_tensors"], out[rel]["n_buffers"])
-    with open(os.path.join(HERE, "shipped_configs.json"), "w") as f:
-        json.dump(out, f, indent=1, sort_keys=True)
+    with open(os.path.join(HERE, "shipped_configs.json"), "w") as f:      # one line per configuration file
+        f.write("{\n" + ",\n".join(f" {json.dumps(k)}: {json.dumps(out[k], sort_keys=True)}" for k in sorted(out)) + "\n}\n")
     print(len(out), "configurations")
 
 
