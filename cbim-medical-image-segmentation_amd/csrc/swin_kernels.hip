@@ -23,6 +23,7 @@
 // (even / odd keys own separate histograms) —
 // and the per-workgroup histograms are summed over windows in launch order.
 #include "cbim_common.h"
+#include <stdlib.h>
 
 namespace cbim {
 
@@ -171,6 +172,118 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_fwd(WinGeom g, const voi
     float inv = 1.f / l;
 #pragma unroll
     for (int d = 0; d < DH; ++d) Elem<T>::store1(out, (size_t)myrow * C + h * DH + d, o[d] * inv);
+  }
+}
+
+// ---- experimental (CBIM_WINATTN_FWD2=1, default off, not yet timed): TWO queries per thread -------------------------
+// Per key and CU the one-query kernels issue as many LDS clocks (broadcast ds_read_b128 of the K and V rows) as VALU
+// clocks, so neither alone can be sped up.  Here a thread owns queries t and t + 192: every K / V row read from LDS
+// feeds two queries (half the LDS traffic per FMA), and the dot products keep an even and an odd partial sum so that
+// the compiler can pair them into v_pk_fma_f32.  Same LDS layout, same tiled online softmax, same outputs.
+static constexpr int W2_THREADS = 192;
+template <typename T, int DH>
+__global__ void __launch_bounds__(W2_THREADS) k_winattn_fwd2(WinGeom g, const void* __restrict__ qkv,
+                                                             const float* __restrict__ qkv_bias,
+                                                             const float* __restrict__ table, void* __restrict__ out,
+                                                             float* __restrict__ lse_out) {
+  CBIM_DYN_SMEM(smem);
+  const int n = g.w0 * g.w1 * g.w2, TS = (2 * g.tw0 - 1) * (2 * g.tw1 - 1) * (2 * g.tw2 - 1);
+  const int off0 = ((g.tw0 - 1) * (2 * g.tw1 - 1) + (g.tw1 - 1)) * (2 * g.tw2 - 1) + (g.tw2 - 1);
+  WinSmem s = win_smem<DH>(smem, TS);
+  const int win = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
+  const int C = g.C;
+  for (int i = t; i < TS; i += W2_THREADS) s.tbl[i] = table[(size_t)i * g.heads + h];
+  float q[2][DH];
+  int64_t myrow[2] = {-1, -1};
+  int mylab[2] = {0, 0}, myb[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int tok = t + u * W2_THREADS;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) q[u][d] = 0.f;
+    if (tok < n) {
+      win_token(g, win, tok, myrow[u], mylab[u], myb[u]);
+      s.bco[tok] = myb[u]; s.lab[tok] = mylab[u];
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        float qv, kv, vv;
+        if (myrow[u] >= 0) {
+          size_t base = (size_t)myrow[u] * 3 * C + h * DH + d;
+          qv = Elem<T>::load1(qkv, base); kv = Elem<T>::load1(qkv, base + C); vv = Elem<T>::load1(qkv, base + 2 * C);
+        } else {
+          qv = qkv_bias ? qkv_bias[h * DH + d] : 0.f;
+          kv = qkv_bias ? qkv_bias[C + h * DH + d] : 0.f;
+          vv = qkv_bias ? qkv_bias[2 * C + h * DH + d] : 0.f;
+        }
+        q[u][d] = qv * g.scale;
+        s.A[tok * DH + d] = kv;
+        s.Bv[tok * DH + d] = vv;
+      }
+    }
+  }
+  __syncthreads();
+  if (t >= n) return;                       // t + 192 >= n as well
+  const bool two = t + W2_THREADS < n;
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f}, o[2][DH];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[u][d] = 0.f;
+  constexpr int KT = 4;
+  for (int j0 = 0; j0 < n; j0 += KT) {
+    float sc[2][KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int j = j0 + k < n ? j0 + k : n - 1;
+      float ae[2] = {0.f, 0.f}, ao[2] = {0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < DH; d += 2) {
+        const float k0 = s.A[j * DH + d], k1 = s.A[j * DH + d + 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { ae[u] = fmaf(q[u][d], k0, ae[u]); ao[u] = fmaf(q[u][d + 1], k1, ao[u]); }
+      }
+      const int bj = s.bco[j], lj = s.lab[j];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float a = (ae[u] + ao[u]) + s.tbl[myb[u] - bj + off0];
+        if (g.masked && lj != mylab[u]) a += -100.f;
+        sc[u][k] = j0 + k < n ? a : -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float mn = m[u];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) mn = fmaxf(mn, sc[u][k]);
+      const float corr = expf(m[u] - mn);
+      l[u] *= corr;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) o[u][d] *= corr;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) { sc[u][k] = expf(sc[u][k] - mn); l[u] += sc[u][k]; }
+      m[u] = mn;
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int j = j0 + k < n ? j0 + k : n - 1;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        const float v = s.Bv[j * DH + d];
+        o[0][d] = fmaf(sc[0][k], v, o[0][d]);
+        o[1][d] = fmaf(sc[1][k], v, o[1][d]);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (u == 1 && !two) break;
+    const int tok = t + u * W2_THREADS;
+    lse_out[((size_t)win * g.heads + h) * WMAX + tok] = m[u] + logf(l[u]);
+    if (myrow[u] >= 0) {
+      const float inv = 1.f / l[u];
+#pragma unroll
+      for (int d = 0; d < DH; ++d) Elem<T>::store1(out, (size_t)myrow[u] * C + h * DH + d, o[u][d] * inv);
+    }
   }
 }
 
@@ -403,7 +516,19 @@ extern "C" int cbim_window_attn3d_fwd(int dtype, const void* qkv, const float* q
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "window attention needs %zu B of LDS", smem);
   dim3 grid(B * g.nw0 * g.nw1 * g.nw2, heads);
   hipStream_t st = (hipStream_t)stream;
-  WIN_DISPATCH(k_winattn_fwd, g, qkv, qkv_bias, table, out, lse);
+  static const int fwd2 = getenv("CBIM_WINATTN_FWD2") ? atoi(getenv("CBIM_WINATTN_FWD2")) : 0;
+  if (fwd2 && g.dh == 16 && g.w0 * g.w1 * g.w2 <= 2 * W2_THREADS) {   // experimental two-queries-per-thread variant
+    static bool once = false;
+    if (!once) {
+      if (int e = set_smem(k_winattn_fwd2<bf16_tag, 16>, smem)) return e;
+      if (int e = set_smem(k_winattn_fwd2<float, 16>, smem)) return e;
+      once = true;
+    }
+    if (dtype == CBIM_BF16) CBIM_LAUNCH((k_winattn_fwd2<bf16_tag, 16>), grid, dim3(W2_THREADS), smem, st, g, qkv, qkv_bias, table, out, lse);
+    else CBIM_LAUNCH((k_winattn_fwd2<float, 16>), grid, dim3(W2_THREADS), smem, st, g, qkv, qkv_bias, table, out, lse);
+  } else {
+    WIN_DISPATCH(k_winattn_fwd, g, qkv, qkv_bias, table, out, lse);
+  }
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "window_attn3d_fwd launch: %s", hipGetErrorString(e));
   return CBIM_OK;

@@ -421,3 +421,25 @@ def check_resnorm(dev, dtype, N=2, C=16, dhw=(4, 5, 6), with_b_stats=True, seed=
     da, db = ops.resnorm_bwd(gl, al, sa, bl, sb, ops.ACT["lrelu"])
     assert relerr(from_cl(da.cpu()), ar.grad) < tol(dtype, 5e-5, 2e-2), "resnorm da"
     assert relerr(from_cl(db.cpu()), br.grad) < tol(dtype, 5e-5, 2e-2), "resnorm db"
+
+
+def check_window_attn_fwd2_variant(dev_name):
+    """The experimental two-queries-per-thread forward (CBIM_WINATTN_FWD2=1; the switch is read once per process, hence a
+    child process): d_head 16 windows with 343 tokens (both queries of a thread live), padding + shift, and a 112-token
+    window (one query per thread)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "from tests import op_checks as oc\n"
+        f"dev = {dev_name!r}\n"
+        "for dt in (torch.float32, torch.bfloat16):\n"
+        "    oc.check_window_attn(dev, dt, dhw=(7, 7, 7), shift=(0, 0, 0), C=16, heads=1)\n"
+        "    oc.check_window_attn(dev, dt, dhw=(9, 8, 7), C=48, heads=3)\n"
+        "    oc.check_window_attn(dev, dt, dhw=(8, 4, 4), shift=(3, 3, 3), C=16, heads=1)\n"
+        "print('fwd2-ok')\n")
+    env = dict(os.environ, CBIM_WINATTN_FWD2="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fwd2-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -44,3 +44,8 @@ def test_resunet_bottleneck_matches_reference_golden(dev):
     # bf16 on untrained weights with three convs per block and InstanceNorm over 8 voxels at the deepest level: logits 0.73
     # (max-abs / max-abs) on the executor, yet CE 1.5315 vs 1.5256 and Dice 0.7636 vs 0.7615 — the losses are the criterion
     assert r["logits_err"] < 2.0 and abs(r["ce"] - float(g["ce"])) < 0.05 and abs(r["dice"] - float(g["dice"])) < 0.05, r
+
+
+def test_window_attention_two_queries_per_thread_variant(dev):
+    """Experimental forward (default off); correctness only — tools/run_round2_first.sh times it."""
+    oc.check_window_attn_fwd2_variant(dev)

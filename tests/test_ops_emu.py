@@ -149,6 +149,10 @@ def test_fused_adamw_ema(dev):
     check_adamw_ema(dev)
 
 
+def test_window_attention_two_queries_per_thread_variant(dev):
+    oc.check_window_attn_fwd2_variant(dev)
+
+
 def test_training_utils_surface(dev):
     from tests.optim_checks import check_training_utils_surface
     check_training_utils_surface(dev)
