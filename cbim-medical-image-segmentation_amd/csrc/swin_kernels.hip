@@ -444,6 +444,179 @@ __global__ void __launch_bounds__(256) k_winattn_reduce(const float* __restrict_
   }
 }
 
+// ---- experimental (CBIM_WINATTN_BWD2=1, default off, not yet timed): the backward with two tokens per thread ----------
+// Same idea as k_winattn_fwd2: pass A owns queries t and t + 192 (each K / V row read from LDS feeds both), pass B owns
+// keys t and t + 192 (each Q / dO row feeds both); dot products keep even / odd partial sums.  Histogram discipline
+// unchanged: at one key all queries address distinct entries, even / odd keys have their own histogram, one barrier per
+// two keys; results match k_winattn_bwd up to the summation order inside the dot products.
+template <typename T, int DH>
+__global__ void __launch_bounds__(W2_THREADS) k_winattn_bwd2(WinGeom g, const void* __restrict__ qkv,
+                                                             const float* __restrict__ qkv_bias,
+                                                             const float* __restrict__ table,
+                                                             const void* __restrict__ out, const void* __restrict__ dout,
+                                                             const float* __restrict__ lse_in, void* __restrict__ dqkv,
+                                                             float* __restrict__ part_tbl, float* __restrict__ part_pad) {
+  CBIM_DYN_SMEM(smem);
+  const int n = g.w0 * g.w1 * g.w2, TS = (2 * g.tw0 - 1) * (2 * g.tw1 - 1) * (2 * g.tw2 - 1);
+  const int off0 = ((g.tw0 - 1) * (2 * g.tw1 - 1) + (g.tw1 - 1)) * (2 * g.tw2 - 1) + (g.tw2 - 1);
+  WinSmem s = win_smem<DH>(smem, TS);
+  const int win = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
+  const int C = g.C;
+  for (int i = t; i < TS; i += W2_THREADS) { s.tbl[i] = table[(size_t)i * g.heads + h]; s.hist[i] = 0.f; s.hist[TS + i] = 0.f; }
+  float q[2][DH], kk[2][DH], vv[2][DH], go[2][DH];
+  int64_t myrow[2] = {-1, -1};
+  int mylab[2] = {0, 0}, myb[2] = {0, 0};
+  float mylse[2] = {0.f, 0.f}, myD[2] = {0.f, 0.f};
+  bool act[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int tok = t + u * W2_THREADS;
+    act[u] = tok < n;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { q[u][d] = 0.f; kk[u][d] = 0.f; vv[u][d] = 0.f; go[u][d] = 0.f; }
+    if (act[u]) {
+      win_token(g, win, tok, myrow[u], mylab[u], myb[u]);
+      s.bco[tok] = myb[u]; s.lab[tok] = mylab[u]; s.row[tok] = myrow[u];
+      mylse[u] = lse_in[((size_t)win * g.heads + h) * WMAX + tok];
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        float qv, ov = 0.f, gv = 0.f;
+        if (myrow[u] >= 0) {
+          size_t base = (size_t)myrow[u] * 3 * C + h * DH + d;
+          qv = Elem<T>::load1(qkv, base); kk[u][d] = Elem<T>::load1(qkv, base + C); vv[u][d] = Elem<T>::load1(qkv, base + 2 * C);
+          ov = Elem<T>::load1(out, (size_t)myrow[u] * C + h * DH + d);
+          gv = Elem<T>::load1(dout, (size_t)myrow[u] * C + h * DH + d);
+        } else {
+          qv = qkv_bias ? qkv_bias[h * DH + d] : 0.f;
+          kk[u][d] = qkv_bias ? qkv_bias[C + h * DH + d] : 0.f;
+          vv[u][d] = qkv_bias ? qkv_bias[2 * C + h * DH + d] : 0.f;
+        }
+        q[u][d] = qv * g.scale;
+        go[u][d] = gv;
+        myD[u] = fmaf(gv, ov, myD[u]);
+        s.A[tok * DH + d] = kk[u][d];
+        s.Bv[tok * DH + d] = vv[u][d];
+      }
+      s.lse[tok] = mylse[u]; s.dsum[tok] = myD[u];
+    }
+  }
+  __syncthreads();
+  // ---- pass A: thread = queries t, t + 192
+  float dq[2][DH];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[u][d] = 0.f;
+  for (int j0 = 0; j0 < n; j0 += 2) {
+#pragma unroll
+    for (int uk = 0; uk < 2; ++uk) {
+      const int j = j0 + uk;
+      if (j < n && act[0]) {
+        float se[2] = {0.f, 0.f}, so[2] = {0.f, 0.f}, pe[2] = {0.f, 0.f}, po[2] = {0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < DH; d += 2) {
+          const float k0 = s.A[j * DH + d], k1 = s.A[j * DH + d + 1], v0 = s.Bv[j * DH + d], v1 = s.Bv[j * DH + d + 1];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            se[u] = fmaf(q[u][d], k0, se[u]); so[u] = fmaf(q[u][d + 1], k1, so[u]);
+            pe[u] = fmaf(go[u][d], v0, pe[u]); po[u] = fmaf(go[u][d + 1], v1, po[u]);
+          }
+        }
+        const int bj = s.bco[j], lj = s.lab[j];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (act[u]) {
+            const int idx = myb[u] - bj + off0;
+            float sc = (se[u] + so[u]) + s.tbl[idx];
+            if (g.masked && lj != mylab[u]) sc += -100.f;
+            const float p = expf(sc - mylse[u]);
+            const float ds = p * ((pe[u] + po[u]) - myD[u]);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) dq[u][d] = fmaf(ds, s.A[j * DH + d], dq[u][d]);
+            s.hist[uk * TS + idx] += ds;     // distinct idx for distinct queries at a fixed key
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (act[u] && myrow[u] >= 0) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) Elem<T>::store1(dqkv, (size_t)myrow[u] * 3 * C + h * DH + d, dq[u][d] * g.scale);
+    }
+  for (int i = t; i < TS; i += W2_THREADS) part_tbl[((size_t)win * g.heads + h) * TS + i] = s.hist[i] + s.hist[TS + i];
+  __syncthreads();
+  // ---- pass B: thread = keys t, t + 192.  LDS now holds scaled Q and dO
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (act[u]) {
+      const int tok = t + u * W2_THREADS;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) { s.A[tok * DH + d] = q[u][d]; s.Bv[tok * DH + d] = go[u][d]; }
+    }
+  __syncthreads();
+  float dk[2][DH], dv[2][DH];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { dk[u][d] = 0.f; dv[u][d] = 0.f; }
+  if (act[0]) {
+    for (int i = 0; i < n; ++i) {
+      float se[2] = {0.f, 0.f}, so[2] = {0.f, 0.f}, pe[2] = {0.f, 0.f}, po[2] = {0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < DH; d += 2) {
+        const float q0 = s.A[i * DH + d], q1 = s.A[i * DH + d + 1], g0 = s.Bv[i * DH + d], g1 = s.Bv[i * DH + d + 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          se[u] = fmaf(q0, kk[u][d], se[u]); so[u] = fmaf(q1, kk[u][d + 1], so[u]);
+          pe[u] = fmaf(g0, vv[u][d], pe[u]); po[u] = fmaf(g1, vv[u][d + 1], po[u]);
+        }
+      }
+      const int bi = s.bco[i], li = s.lab[i];
+      const float lsei = s.lse[i], dsi = s.dsum[i];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (act[u]) {
+          float sc = (se[u] + so[u]) + s.tbl[bi - myb[u] + off0];
+          if (g.masked && li != mylab[u]) sc += -100.f;
+          const float p = expf(sc - lsei);
+          const float ds = p * ((pe[u] + po[u]) - dsi);
+#pragma unroll
+          for (int d = 0; d < DH; ++d) { dv[u][d] = fmaf(p, s.Bv[i * DH + d], dv[u][d]); dk[u][d] = fmaf(ds, s.A[i * DH + d], dk[u][d]); }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (act[u] && myrow[u] >= 0) {
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+          Elem<T>::store1(dqkv, (size_t)myrow[u] * 3 * C + C + h * DH + d, dk[u][d]);
+          Elem<T>::store1(dqkv, (size_t)myrow[u] * 3 * C + 2 * C + h * DH + d, dv[u][d]);
+        }
+      }
+  }
+  __syncthreads();
+  // gradient of qkv.bias through the padded keys: fixed-order sum over this window's padded tokens
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (act[u]) {
+      const int tok = t + u * W2_THREADS;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) { s.A[tok * DH + d] = myrow[u] < 0 ? dk[u][d] : 0.f; s.Bv[tok * DH + d] = myrow[u] < 0 ? dv[u][d] : 0.f; }
+    }
+  __syncthreads();
+  if (t < 2 * DH) {
+    const float* src = t < DH ? s.A : s.Bv;
+    int d = t % DH;
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += src[i * DH + d];
+    part_pad[(((size_t)win * g.heads + h) * 2 + t / DH) * DH + d] = acc;
+  }
+}
+
 }  // namespace cbim
 
 using namespace cbim;
@@ -554,7 +727,23 @@ extern "C" int cbim_window_attn3d_bwd(int dtype, const void* qkv, const float* q
   hipStream_t st = (hipStream_t)stream;
   float* part_tbl = (float*)workspace;
   float* part_pad = part_tbl + (size_t)nwin * heads * TS;
-  WIN_DISPATCH(k_winattn_bwd, g, qkv, qkv_bias, table, out, dout, lse, dqkv, part_tbl, part_pad);
+  static const int bwd2 = getenv("CBIM_WINATTN_BWD2") ? atoi(getenv("CBIM_WINATTN_BWD2")) : 0;
+  if (bwd2 && g.dh == 16 && g.w0 * g.w1 * g.w2 <= 2 * W2_THREADS) {   // experimental two-tokens-per-thread variant
+    static bool once = false;
+    if (!once) {
+      if (int e = set_smem(k_winattn_bwd2<bf16_tag, 16>, smem)) return e;
+      if (int e = set_smem(k_winattn_bwd2<float, 16>, smem)) return e;
+      once = true;
+    }
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_winattn_bwd2<bf16_tag, 16>), grid, dim3(W2_THREADS), smem, st, g, qkv, qkv_bias, table, out, dout, lse, dqkv,
+                  part_tbl, part_pad);
+    else
+      CBIM_LAUNCH((k_winattn_bwd2<float, 16>), grid, dim3(W2_THREADS), smem, st, g, qkv, qkv_bias, table, out, dout, lse, dqkv,
+                  part_tbl, part_pad);
+  } else {
+    WIN_DISPATCH(k_winattn_bwd, g, qkv, qkv_bias, table, out, dout, lse, dqkv, part_tbl, part_pad);
+  }
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "window_attn3d_bwd launch: %s", hipGetErrorString(e));
   int items = TS * heads > 3 * C ? TS * heads : 3 * C;

@@ -424,7 +424,7 @@ def check_resnorm(dev, dtype, N=2, C=16, dhw=(4, 5, 6), with_b_stats=True, seed=
 
 
 def check_window_attn_fwd2_variant(dev_name):
-    """The experimental two-queries-per-thread forward (CBIM_WINATTN_FWD2=1; the switch is read once per process, hence a
+    """The experimental two-tokens-per-thread forward and backward (CBIM_WINATTN_FWD2=1, CBIM_WINATTN_BWD2=1; read once per process, hence a
     child process): d_head 16 windows with 343 tokens (both queries of a thread live), padding + shift, and a 112-token
     window (one query per thread)."""
     import os
@@ -439,7 +439,7 @@ def check_window_attn_fwd2_variant(dev_name):
         "    oc.check_window_attn(dev, dt, dhw=(9, 8, 7), C=48, heads=3)\n"
         "    oc.check_window_attn(dev, dt, dhw=(8, 4, 4), shift=(3, 3, 3), C=16, heads=1)\n"
         "print('fwd2-ok')\n")
-    env = dict(os.environ, CBIM_WINATTN_FWD2="1")
+    env = dict(os.environ, CBIM_WINATTN_FWD2="1", CBIM_WINATTN_BWD2="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fwd2-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -47,5 +47,5 @@ def test_resunet_bottleneck_matches_reference_golden(dev):
 
 
 def test_window_attention_two_queries_per_thread_variant(dev):
-    """Experimental forward (default off); correctness only — tools/run_round2_first.sh times it."""
+    """Experimental forward + backward (default off); correctness only — tools/run_round2_first.sh times it."""
     oc.check_window_attn_fwd2_variant(dev)
