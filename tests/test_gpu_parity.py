@@ -16,7 +16,7 @@ from tests.util import CASES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", [n for n in CASES if "bottleneck" not in n])   # Bottleneck: tests/test_late_gpu_cases.py
+@pytest.mark.parametrize("name", [n for n in CASES if "bottleneck" not in n])   # Bottleneck: tests/test_u_late_gpu_cases.py
 def test_fp32_mode_matches_reference_golden(dev, name):
     if CASES[name][1] % 4:
         pytest.skip("base_chan must be a multiple of 4 for whole 16-byte channel chunks")
