@@ -6,7 +6,7 @@
 #pragma once
 #ifdef CBIM_EMU
 #include "hip_emu.h"   // tests/emu: host-side executor used only by the CPU test-suite
-#define CBIM_LAST_LAUNCH() 0
+#define CBIM_LAST_LAUNCH() (cbim_emu::last_launch_err())
 #else
 #include <hip/hip_runtime.h>
 #include <tuple>

@@ -1075,17 +1075,22 @@ extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const f
 }
 
 // LDS-tiled 3x3x3 path: rows of h per tile so that the fp32 halo + gradient tiles fit ~120 KiB
-static int dw3_lds_th(int H, int W, int cpc) {
-  const size_t per_row_x = (size_t)3 * (W + 2) * WG_CH * cpc * 4, per_row_g = (size_t)W * WG_CH * cpc * 4;
-  int th = (int)((120 * 1024 - 2 * per_row_x) / (per_row_x + per_row_g));
-  if (th > H) th = H;
-  if (th > 8) th = 8;
-  return th;   // < 1: does not fit, use the streaming kernel
-}
 static size_t dw3_lds_bytes(int W, int TH, int cpc) {
   size_t b = ((size_t)3 * (TH + 2) * (W + 2) + (size_t)TH * W) * WG_CH * cpc * 4;
   const size_t red = (size_t)NT * 3 * cpc * 4;     // row-third partials re-use the front of the buffer
   return b > red ? b : red;
+}
+static constexpr int64_t DW3_LDS_BUDGET = 120 * 1024;   // of 160 KiB per CU
+static int dw3_lds_th(int H, int W, int cpc) {
+  // signed: two halo rows alone exceed the budget for W >= 79 (bf16) / W >= 159 (fp32) -> 0 -> streaming kernel
+  const int64_t per_row_x = (int64_t)3 * (W + 2) * WG_CH * cpc * 4, per_row_g = (int64_t)W * WG_CH * cpc * 4;
+  const int64_t room = DW3_LDS_BUDGET - 2 * per_row_x;
+  if (room < per_row_x + per_row_g) return 0;
+  int64_t th = room / (per_row_x + per_row_g);
+  if (th > H) th = H;
+  if (th > 8) th = 8;
+  if (th < 1 || (int64_t)dw3_lds_bytes(W, (int)th, cpc) > 160 * 1024) return 0;
+  return (int)th;   // 0: does not fit, use the streaming kernel
 }
 
 // kW == 3 path: rows (n,d,h) per block so that ~1024 blocks exist, at least 8 rows each

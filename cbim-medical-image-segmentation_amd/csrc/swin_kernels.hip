@@ -656,7 +656,9 @@ extern "C" size_t cbim_window_attn3d_workspace(int B, int D, int H, int W, int C
 template <typename K>
 static int set_smem(K kernel, size_t bytes) {
 #ifndef CBIM_EMU
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  // set once per kernel: ask for the CU maximum, the first caller's window need not be the largest one
+  (void)bytes;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
 #else
   (void)kernel; (void)bytes;

@@ -138,7 +138,13 @@ static void run_block(BlockCtx* c) {
   }
 }
 
+int g_last_launch_err = 0;
+int last_launch_err() { return g_last_launch_err; }
+
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+  // like the hardware: a workgroup cannot have more than 160 KiB of LDS (gfx950) -> "invalid argument", nothing runs
+  g_last_launch_err = shmem > 160 * 1024 ? 1 : 0;
+  if (g_last_launch_err) return;
   int nthreads = block.x * block.y * block.z;
   if (nthreads > kMaxThreads) { fprintf(stderr, "emu: block too large\n"); abort(); }
   long nblocks = (long)grid.x * grid.y * grid.z;

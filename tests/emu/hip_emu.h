@@ -32,7 +32,7 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 inline hipError_t hipGetLastError() { return 0; }
-inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline const char* hipGetErrorString(hipError_t e) { return e ? "invalid argument (emu: LDS request over 160 KiB)" : "emu"; }
 
 namespace cbim_emu {
 struct Lane {
@@ -50,6 +50,7 @@ void sync_block();
 // exchange buffer (stride `bytes`) valid until this lane's next collective.
 const unsigned char* wave_exchange(const void* mine, size_t bytes);
 unsigned char* dyn_smem();
+int last_launch_err();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 }  // namespace cbim_emu
 

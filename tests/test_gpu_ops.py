@@ -88,6 +88,15 @@ def test_dwconv(dev, dtype):
     oc.check_dwconv(dev, dtype, N=1, C=512, dhw=(16, 16, 16))
 
 
+@pytest.mark.parametrize("dtype,W", [(BF16, 78), (BF16, 79), (BF16, 80), (BF16, 112), (BF16, 128), (BF16, 224),
+                                     (F32, 112), (F32, 158), (F32, 160), (F32, 224)])
+def test_dwconv_wide_rows(dev, dtype, W):
+    """3x3x3 depthwise wgrad picks the LDS-tiled or the streaming kernel from the row width: two halo rows stop
+    fitting the LDS budget at W >= 79 (bf16) / W >= 159 (fp32) -- config/amos_mr/medformer_3d.yaml:33 runs W = 112."""
+    oc.check_dwconv(dev, dtype, N=1, C=16, dhw=(3, 5, W))
+    oc.check_dwconv(dev, dtype, N=1, C=256, dhw=(2, 3, W), act="none")
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_space_to_depth(dev, dtype):
     oc.check_space_to_depth(dev, dtype)
