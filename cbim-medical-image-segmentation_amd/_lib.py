@@ -27,6 +27,14 @@ class ConvDesc(C.Structure):
 
 _dp = C.POINTER(ConvDesc)
 
+class PackItem(C.Structure):
+    """cbim_pack_item of include/cbim_hip.h (one weight tensor of the one-launch weight re-layout)."""
+    _fields_ = [("w0", C.c_void_p), ("w1", C.c_void_p), ("p0", C.c_void_p), ("p1", C.c_void_p),
+                ("total0", C.c_int64), ("total1", C.c_int64)] + \
+               [(n, C.c_int) for n in ("rows0", "Cout", "Cin", "taps", "BN0", "nch0", "BN1", "nch1", "block_begin",
+                                       "n_blocks", "dtype", "_pad")]
+
+
 # name -> (restype, argtypes)   (mirrors include/cbim_hip.h one to one)
 _SIGS = {
     "cbim_version": (i32, []),
@@ -46,6 +54,8 @@ _SIGS = {
     "cbim_conv3d_packed_bytes": (sz, [_dp, i32]),
     "cbim_conv3d_pack_weights": (i32, [_dp, i32, vp, vp, vp]),
     "cbim_conv3d_pack_weights_both": (i32, [_dp, vp, vp, vp, vp]),
+    "cbim_conv3d_pack_item_fill": (i32, [_dp, vp, vp, i32, vp, vp, i32, vp]),
+    "cbim_conv3d_pack_weights_table": (i32, [vp, i32, i32, vp]),
     "cbim_conv3d_num_tiles": (i32, [_dp]),
     "cbim_conv3d_tile_config": (i32, [_dp, C.POINTER(C.c_int * 4)]),
     "cbim_conv3d_igemm": (i32, [_dp, vp, i64, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, sz, vp]),

@@ -749,8 +749,11 @@ __global__ void __launch_bounds__(FT) k_splitk_finish(const float* __restrict__ 
 // packed[nb][chunk][tap][kg][half][BN][CPC];  channel = chunk*KC + (2kg+half)*CPC + j, cout = nb*BN + nn.
 // mode 0: K = Cin, N = Cout, value w[cout][cin][tap]; mode 1 (dgrad): K = Cout_fwd, N = Cin_fwd,
 // value w[k_ch][n_ch][taps-1-tap]  (w is always the forward [Cout][Cin][taps] tensor).
+// `w` rows (forward output channels) >= rows0 come from `w1` (row r - rows0): a Cout-concatenated convolution
+// (conv1 | shortcut) is packed straight from its two parameter tensors; w1 == nullptr: everything is in `w`.
 template <typename T>
-__device__ __forceinline__ void pack_one(const float* __restrict__ w, void* __restrict__ packed, int Cout_f,
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, const float* __restrict__ w1, int rows0,
+                                         void* __restrict__ packed, int Cout_f,
                                          int Cin_f, int taps, int mode, int BN, int n_chunks, int64_t i) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int KC = SLOTS * CPC;
@@ -768,8 +771,9 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, void* __re
   int nc = nb * BN + nn;
   float v = 0.f;
   if (kc < Kdim && nc < Ndim) {
-    if (mode == 0) v = w[((size_t)nc * Cin_f + kc) * taps + tap];
-    else v = w[((size_t)kc * Cin_f + nc) * taps + (taps - 1 - tap)];
+    const int row = mode == 0 ? nc : kc, col = mode == 0 ? kc : nc, tp = mode == 0 ? tap : taps - 1 - tap;
+    const float* src = (w1 && row >= rows0) ? w1 + (size_t)(row - rows0) * Cin_f * taps : w + (size_t)row * Cin_f * taps;
+    v = src[(size_t)col * taps + tp];
   }
   Elem<T>::store1(packed, (size_t)i, v);
 }
@@ -782,9 +786,32 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
                                                       int64_t total1) {
   const int64_t tmax = total0 > total1 ? total0 : total1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tmax; i += (int64_t)gridDim.x * 256) {
-    if (p0 && i < total0) pack_one<T>(w, p0, Cout_f, Cin_f, taps, 0, BN0, nch0, i);
-    if (p1 && i < total1) pack_one<T>(w, p1, Cout_f, Cin_f, taps, 1, BN1, nch1, i);
+    if (p0 && i < total0) pack_one<T>(w, nullptr, 0, p0, Cout_f, Cin_f, taps, 0, BN0, nch0, i);
+    if (p1 && i < total1) pack_one<T>(w, nullptr, 0, p1, Cout_f, Cin_f, taps, 1, BN1, nch1, i);
   }
+}
+
+// Every convolution weight of a model in ONE launch (the weights change once per optimizer step: 34 pack launches +
+// the torch.cat of each conv1|shortcut pair were 0.5 ms of a 19 ms ResUNet step).  The table lives in device memory;
+// blockIdx.x -> item by binary search over the items' first block.
+template <typename T>
+__device__ __forceinline__ void pack_item(const cbim_pack_item& it, int64_t first, int64_t step) {
+  const int64_t tmax = it.total0 > it.total1 ? it.total0 : it.total1;
+  for (int64_t i = first; i < tmax; i += step) {
+    if (it.p0 && i < it.total0) pack_one<T>(it.w0, it.w1, it.rows0, it.p0, it.Cout, it.Cin, it.taps, 0, it.BN0, it.nch0, i);
+    if (it.p1 && i < it.total1) pack_one<T>(it.w0, it.w1, it.rows0, it.p1, it.Cout, it.Cin, it.taps, 1, it.BN1, it.nch1, i);
+  }
+}
+__global__ void __launch_bounds__(256) k_pack_weights_table(const cbim_pack_item* __restrict__ items, int n_items) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {   // last item whose block_begin <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const cbim_pack_item it = items[lo];
+  const int64_t first = (int64_t)((int)blockIdx.x - it.block_begin) * 256 + threadIdx.x, step = (int64_t)it.n_blocks * 256;
+  if (it.dtype == CBIM_BF16) pack_item<bf16_tag>(it, first, step);
+  else pack_item<float>(it, first, step);
 }
 
 struct TileCfg { int MT, NTL, tD, tH, lgH, nth; };
@@ -891,6 +918,33 @@ extern "C" int cbim_conv3d_pack_weights_both(const cbim_conv_desc* d, const floa
                                              void* packed_dgrad, void* stream) {
   CBIM_CHECK(w && packed_fwd && packed_dgrad, CBIM_EINVAL, "null argument");
   return pack_launch(d, w, packed_fwd, packed_dgrad, stream);
+}
+
+extern "C" int cbim_conv3d_pack_item_fill(const cbim_conv_desc* d, const float* w0, const float* w1, int rows0,
+                                          void* packed_fwd, void* packed_dgrad, int block_begin, cbim_pack_item* out) {
+  if (int e = validate(d)) return e;
+  CBIM_CHECK(w0 && out && (packed_fwd || packed_dgrad), CBIM_EINVAL, "null argument");
+  CBIM_CHECK(!w1 || (rows0 > 0 && rows0 < d->Cout), CBIM_EINVAL, "second weight tensor: bad split %d", rows0);
+  const int KC = kc_of(d->dtype), es = elem_size(d->dtype);
+  out->w0 = w0; out->w1 = w1; out->p0 = packed_fwd; out->p1 = packed_dgrad;
+  out->rows0 = w1 ? rows0 : d->Cout; out->Cout = d->Cout; out->Cin = d->Cin; out->taps = d->kD * d->kH * d->kW;
+  out->BN0 = d->Cout <= 32 ? 32 : 64; out->BN1 = d->Cin <= 32 ? 32 : 64;
+  out->nch0 = (d->Cin + KC - 1) / KC; out->nch1 = (d->Cout + KC - 1) / KC;
+  out->total0 = packed_fwd ? (int64_t)(cbim_conv3d_packed_bytes(d, 0) / es) : 0;
+  out->total1 = packed_dgrad ? (int64_t)(cbim_conv3d_packed_bytes(d, 1) / es) : 0;
+  const int64_t tmax = out->total0 > out->total1 ? out->total0 : out->total1;
+  int64_t nb = (tmax + 256 * 8 - 1) / (256 * 8);   // ~8 elements per thread
+  if (nb < 1) nb = 1;
+  if (nb > 1024) nb = 1024;
+  out->block_begin = block_begin; out->n_blocks = (int)nb; out->dtype = d->dtype;
+  return CBIM_OK;
+}
+
+extern "C" int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, int n_items, int total_blocks,
+                                              void* stream) {
+  CBIM_CHECK(items_dev && n_items > 0 && total_blocks > 0, CBIM_EINVAL, "empty pack table");
+  CBIM_LAUNCH(k_pack_weights_table, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 extern "C" int cbim_conv3d_tile_config(const cbim_conv_desc* d, int out[4]) {

@@ -18,57 +18,108 @@ static constexpr int NT = 256;
 static constexpr int CMAX = 32;
 static constexpr float SMOOTH = 1e-5f;
 
-// partial layout per workgroup: [3*C + 2] = TP[C], SP[C], CNT[C], ce_num, ce_den
+// V consecutive voxels per thread: every class plane is read with one V*4-byte load per lane (16 B for V = 4, a
+// wave instruction then covers 1 KiB of one plane), labels as V int64.  CT = compile-time class bound (C <= CT) so
+// the per-class arrays live in registers without predicated dead work (C = 16 ran the CT = 32 loops before).
+template <int V> struct VecF;
+template <> struct VecF<4> { typedef f32x4 type; };
+template <> struct VecF<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecF<1> { typedef float type; };
+template <int V> __device__ __forceinline__ void ldv(const float* p, float* o) {
+  typename VecF<V>::type q = *(const typename VecF<V>::type*)p;
+  if constexpr (V == 1) o[0] = q;
+  else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = q[i];
+  }
+}
+template <int V> __device__ __forceinline__ void stv(float* p, const float* o) {
+  typename VecF<V>::type q;
+  if constexpr (V == 1) q = o[0];
+  else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) q[i] = o[i];
+  }
+  *(typename VecF<V>::type*)p = q;
+}
+
+// partial layout per workgroup: [3*C + 3] = TP[C], SP[C], CNT[C], ce_num, ce_den, #labels outside [0, C)
+// A label outside [0, C) (the reference raises in scatter_ / CrossEntropyLoss) is never used as an index: the voxel
+// is left out of CE, TP and CNT and counted, the count comes back in out[3].
+template <int CT, int V>
 __global__ void __launch_bounds__(NT) k_dice_ce_fwd(const float* __restrict__ z, const int64_t* __restrict__ y,
                                                     const float* __restrict__ wgt, int C, int64_t S,
-                                                    int64_t total, float* __restrict__ partials) {
-  float tp[CMAX], sp[CMAX], cnt[CMAX];
+                                                    int64_t groups, float* __restrict__ partials) {
+  float tp[CT], sp[CT], cnt[CT];
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) { tp[c] = 0.f; sp[c] = 0.f; cnt[c] = 0.f; }
-  float ce_num = 0.f, ce_den = 0.f;
-  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < total; r += (int64_t)gridDim.x * NT) {
-    int64_t n = r / S, v = r % S;
+  for (int c = 0; c < CT; ++c) { tp[c] = 0.f; sp[c] = 0.f; cnt[c] = 0.f; }
+  float ce_num = 0.f, ce_den = 0.f, bad = 0.f;
+  for (int64_t g = (int64_t)blockIdx.x * NT + threadIdx.x; g < groups; g += (int64_t)gridDim.x * NT) {
+    const int64_t r = g * V;
+    const int64_t n = r / S, v = r % S;
     const float* zp = z + (size_t)n * C * S + v;
-    int lab = (int)y[r];
-    float l[CMAX];
-    float mx = -INFINITY, zy = 0.f;
+    int lab[V];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < C) { l[c] = zp[(size_t)c * S]; mx = fmaxf(mx, l[c]); if (c == lab) zy = l[c]; }
-    float se = 0.f;
+    for (int i = 0; i < V; ++i) lab[i] = (int)y[r + i];
+    float l[CT][V];
+    float mx[V], zy[V], se[V];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < C) { l[c] = __expf(l[c] - mx); se += l[c]; }
-    float inv = 1.f / se;
+    for (int i = 0; i < V; ++i) { mx[i] = -INFINITY; zy[i] = 0.f; se[i] = 0.f; }
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
+    for (int c = 0; c < CT; ++c)
+      if (c < C) ldv<V>(zp + (size_t)c * S, l[c]);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
       if (c < C) {
-        float pc = l[c] * inv;
-        sp[c] += pc;
-        if (c == lab) { tp[c] += pc; cnt[c] += 1.f; }
+#pragma unroll
+        for (int i = 0; i < V; ++i) { mx[i] = fmaxf(mx[i], l[c][i]); if (c == lab[i]) zy[i] = l[c][i]; }
       }
-    float wy = wgt ? wgt[lab] : 1.f;
-    ce_num += wy * (__logf(se) + mx - zy);
-    ce_den += wy;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) { l[c][i] = __expf(l[c][i] - mx[i]); se[i] += l[c][i]; }
+      }
+    float inv[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) inv[i] = 1.f / se[i];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          float pc = l[c][i] * inv[i];
+          sp[c] += pc;
+          if (c == lab[i]) { tp[c] += pc; cnt[c] += 1.f; }
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const bool ok = (unsigned)lab[i] < (unsigned)C;
+      float wy = ok ? (wgt ? wgt[lab[i]] : 1.f) : 0.f;
+      ce_num += wy * (__logf(se[i]) + mx[i] - zy[i]);
+      ce_den += wy;
+      bad += ok ? 0.f : 1.f;
+    }
   }
   // workgroup reduction (fixed order): wave shuffles then 4 waves through LDS
-  __shared__ float red[4][3 * CMAX + 2];
+  __shared__ float red[4][3 * CT + 3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) {
+  for (int c = 0; c < CT; ++c) {
     if (c < C) {
       float a = wave_sum(tp[c]), b = wave_sum(sp[c]), d = wave_sum(cnt[c]);
-      if (lane == 0) { red[wave][c] = a; red[wave][CMAX + c] = b; red[wave][2 * CMAX + c] = d; }
+      if (lane == 0) { red[wave][c] = a; red[wave][CT + c] = b; red[wave][2 * CT + c] = d; }
     }
   }
   {
-    float a = wave_sum(ce_num), b = wave_sum(ce_den);
-    if (lane == 0) { red[wave][3 * CMAX] = a; red[wave][3 * CMAX + 1] = b; }
+    float a = wave_sum(ce_num), b = wave_sum(ce_den), e = wave_sum(bad);
+    if (lane == 0) { red[wave][3 * CT] = a; red[wave][3 * CT + 1] = b; red[wave][3 * CT + 2] = e; }
   }
   __syncthreads();
-  float* out = partials + (size_t)blockIdx.x * (3 * C + 2);
-  for (int i = threadIdx.x; i < 3 * C + 2; i += NT) {
-    int src = i < 3 * C ? (i / C) * CMAX + (i % C) : 3 * CMAX + (i - 3 * C);
+  float* out = partials + (size_t)blockIdx.x * (3 * C + 3);
+  for (int i = threadIdx.x; i < 3 * C + 3; i += NT) {
+    int src = i < 3 * C ? (i / C) * CT + (i % C) : 3 * CT + (i - 3 * C);
     out[i] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
   }
 }
@@ -76,10 +127,10 @@ __global__ void __launch_bounds__(NT) k_dice_ce_fwd(const float* __restrict__ z,
 // single workgroup: reduce partials in fp64, evaluate the loss and its class-level derivatives.
 __global__ void __launch_bounds__(NT) k_dice_ce_finalize(const float* __restrict__ partials, int nblk, int C,
                                                          float* __restrict__ out, float* __restrict__ coef) {
-  __shared__ double tot[3 * CMAX + 2];
-  __shared__ double part[4][3 * CMAX + 2];
+  __shared__ double tot[3 * CMAX + 3];
+  __shared__ double part[4][3 * CMAX + 3];
   __shared__ double dice_term[CMAX];
-  const int nv = 3 * C + 2;
+  const int nv = 3 * C + 3;
   {   // 4 thread groups stride over the workgroup partials (independent loads in flight), fixed-order merge
     const int li = threadIdx.x & 63, pg = threadIdx.x >> 6;
     for (int i = li; i < nv; i += 64) {
@@ -123,60 +174,95 @@ __global__ void __launch_bounds__(NT) k_dice_ce_finalize(const float* __restrict
     out[0] = (float)ce;
     out[1] = (float)dl;
     out[2] = (float)(ce + dl);
+    out[3] = (float)tot[3 * C + 2];   // labels outside [0, C)
     coef[2 * C] = (float)(1.0 / tot[3 * C + 1]);
   }
 }
 
 // dlogits = g_ce * dCE/dz + g_dice * dDice/dz   (grad_out = {g_ce, g_dice} on the device)
+template <int CT, int V>
 __global__ void __launch_bounds__(NT) k_dice_ce_bwd(const float* __restrict__ z, const int64_t* __restrict__ y,
                                                     const float* __restrict__ wgt, const float* __restrict__ coef,
                                                     const float* __restrict__ grad_out, float* __restrict__ dz,
-                                                    int C, int64_t S, int64_t total) {
+                                                    int C, int64_t S, int64_t groups) {
   __shared__ float cf[2 * CMAX + 1];
   if ((int)threadIdx.x < 2 * C + 1) cf[threadIdx.x] = coef[threadIdx.x];
   __syncthreads();
   const float g_ce = grad_out[0], g_dice = grad_out[1];
   const float inv_w = cf[2 * C];
-  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < total; r += (int64_t)gridDim.x * NT) {
-    int64_t n = r / S, v = r % S;
+  for (int64_t g = (int64_t)blockIdx.x * NT + threadIdx.x; g < groups; g += (int64_t)gridDim.x * NT) {
+    const int64_t r = g * V;
+    const int64_t n = r / S, v = r % S;
     const float* zp = z + (size_t)n * C * S + v;
     float* dp = dz + (size_t)n * C * S + v;
-    int lab = (int)y[r];
-    float l[CMAX];
-    float mx = -INFINITY;
+    int lab[V];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < C) { l[c] = zp[(size_t)c * S]; mx = fmaxf(mx, l[c]); }
-    float se = 0.f;
+    for (int i = 0; i < V; ++i) lab[i] = (int)y[r + i];
+    float l[CT][V];
+    float mx[V], se[V], dot[V], wy[V];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < C) { l[c] = __expf(l[c] - mx); se += l[c]; }
-    float inv = 1.f / se;
-    float dot = 0.f;  // sum_k p_k G_k
+    for (int i = 0; i < V; ++i) { mx[i] = -INFINITY; se[i] = 0.f; dot[i] = 0.f; }
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
+    for (int c = 0; c < CT; ++c)
+      if (c < C) ldv<V>(zp + (size_t)c * S, l[c]);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
       if (c < C) {
-        l[c] *= inv;
-        float G = cf[C + c] + (c == lab ? cf[c] : 0.f);
-        dot += l[c] * G;
+#pragma unroll
+        for (int i = 0; i < V; ++i) mx[i] = fmaxf(mx[i], l[c][i]);
       }
-    float wy = (wgt ? wgt[lab] : 1.f) * inv_w;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
+    for (int c = 0; c < CT; ++c)
       if (c < C) {
-        float G = cf[C + c] + (c == lab ? cf[c] : 0.f);
-        float d_dice = l[c] * (G - dot);
-        float d_ce = wy * (l[c] - (c == lab ? 1.f : 0.f));
-        dp[(size_t)c * S] = g_ce * d_ce + g_dice * d_dice;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { l[c][i] = __expf(l[c][i] - mx[i]); se[i] += l[c][i]; }
+      }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      se[i] = 1.f / se[i];
+      const bool ok = (unsigned)lab[i] < (unsigned)C;     // see k_dice_ce_fwd: such a voxel only feeds SP
+      wy[i] = ok ? (wgt ? wgt[lab[i]] : 1.f) * inv_w : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+        const float gs = cf[C + c], gt = cf[c];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          l[c][i] *= se[i];
+          dot[i] += l[c][i] * (gs + (c == lab[i] ? gt : 0.f));   // sum_k p_k G_k
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+        const float gs = cf[C + c], gt = cf[c];
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          float G = gs + (c == lab[i] ? gt : 0.f);
+          float d_dice = l[c][i] * (G - dot[i]);
+          float d_ce = wy[i] * (l[c][i] - (c == lab[i] ? 1.f : 0.f));
+          o[i] = g_ce * d_ce + g_dice * d_dice;
+        }
+        stv<V>(dp + (size_t)c * S, o);
       }
   }
 }
 
 static int loss_blocks(int64_t total) {
-  int64_t b = (total + NT * 8 - 1) / (NT * 8);
+  int64_t b = (total + NT * 8 - 1) / (NT * 8);   // upper bound over the vector widths (groups <= total)
   if (b > 1024) b = 1024;   // the finalize kernel walks these partials with 4 thread groups
   if (b < 1) b = 1;
   return (int)b;
+}
+
+// voxels per thread: 4 (C <= 16) / 2 (C <= 32) consecutive voxels when every class plane stays aligned for the
+// vector load (S a multiple of V, base pointer aligned); otherwise one voxel per thread
+static int loss_vec(const void* logits, int64_t S, int C) {
+  const int V = C <= 16 ? 4 : 2;
+  if (S % V != 0 || ((size_t)logits % (V * 4)) != 0) return 1;
+  return V;
 }
 
 }  // namespace cbim
@@ -184,7 +270,7 @@ static int loss_blocks(int64_t total) {
 using namespace cbim;
 
 extern "C" size_t cbim_dice_ce_workspace(int N, int C, int64_t S) {
-  return (size_t)loss_blocks((int64_t)N * S) * (3 * C + 2) * sizeof(float);
+  return (size_t)loss_blocks((int64_t)N * S) * (3 * C + 3) * sizeof(float);
 }
 
 extern "C" int cbim_dice_ce_fwd(const float* logits, const int64_t* labels, const float* weight, int N, int C,
@@ -195,9 +281,21 @@ extern "C" int cbim_dice_ce_fwd(const float* logits, const int64_t* labels, cons
   size_t need = cbim_dice_ce_workspace(N, C, S);
   CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "loss workspace %zu < %zu", ws_bytes, need);
   int64_t total = (int64_t)N * S;
-  int nb = loss_blocks(total);
   hipStream_t st = (hipStream_t)stream;
-  CBIM_LAUNCH(k_dice_ce_fwd, dim3(nb), dim3(NT), 0, st, logits, labels, weight, C, S, total, (float*)workspace);
+  const int V = loss_vec(logits, S, C);
+  const int64_t groups = total / V;
+  int nb = loss_blocks(total);
+  if ((int64_t)nb * NT > groups) nb = (int)((groups + NT - 1) / NT);
+  if (nb < 1) nb = 1;
+  float* ws = (float*)workspace;
+  if (C <= 16) {
+    if (V == 4) CBIM_LAUNCH((k_dice_ce_fwd<16, 4>), dim3(nb), dim3(NT), 0, st, logits, labels, weight, C, S, groups, ws);
+    else CBIM_LAUNCH((k_dice_ce_fwd<16, 1>), dim3(nb), dim3(NT), 0, st, logits, labels, weight, C, S, groups, ws);
+  } else {
+    if (V == 2) CBIM_LAUNCH((k_dice_ce_fwd<CMAX, 2>), dim3(nb), dim3(NT), 0, st, logits, labels, weight, C, S, groups, ws);
+    else CBIM_LAUNCH((k_dice_ce_fwd<CMAX, 1>), dim3(nb), dim3(NT), 0, st, logits, labels, weight, C, S, groups, ws);
+  }
+  if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
   CBIM_LAUNCH(k_dice_ce_finalize, dim3(1), dim3(NT), 0, st, (const float*)workspace, nb, C, out, coef);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
@@ -208,10 +306,21 @@ extern "C" int cbim_dice_ce_bwd(const float* logits, const int64_t* labels, cons
   CBIM_CHECK(logits && labels && coef && grad_out && dlogits, CBIM_EINVAL, "null argument");
   CBIM_CHECK(C >= 1 && C <= CMAX, CBIM_EUNSUPPORTED, "loss supports up to %d classes (got %d)", CMAX, C);
   int64_t total = (int64_t)N * S;
-  int64_t b = (total + NT - 1) / NT;
+  int V = loss_vec(logits, S, C);
+  if (V > 1 && ((size_t)dlogits % (V * 4)) != 0) V = 1;
+  const int64_t groups = total / V;
+  int64_t b = (groups + NT - 1) / NT;
   if (b > 256 * 16) b = 256 * 16;
-  CBIM_LAUNCH(k_dice_ce_bwd, dim3((unsigned)b), dim3(NT), 0, (hipStream_t)stream, logits, labels, weight, coef,
-              grad_out, dlogits, C, S, total);
+  if (b < 1) b = 1;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)b);
+  if (C <= 16) {
+    if (V == 4) CBIM_LAUNCH((k_dice_ce_bwd<16, 4>), grid, dim3(NT), 0, st, logits, labels, weight, coef, grad_out, dlogits, C, S, groups);
+    else CBIM_LAUNCH((k_dice_ce_bwd<16, 1>), grid, dim3(NT), 0, st, logits, labels, weight, coef, grad_out, dlogits, C, S, groups);
+  } else {
+    if (V == 2) CBIM_LAUNCH((k_dice_ce_bwd<CMAX, 2>), grid, dim3(NT), 0, st, logits, labels, weight, coef, grad_out, dlogits, C, S, groups);
+    else CBIM_LAUNCH((k_dice_ce_bwd<CMAX, 1>), grid, dim3(NT), 0, st, logits, labels, weight, coef, grad_out, dlogits, C, S, groups);
+  }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

@@ -370,6 +370,161 @@ __global__ void __launch_bounds__(NT) k_head_bwd_reduce(const float* __restrict_
   }
 }
 
+// ---- head, K <= 16 classes (every shipped config): compile-time class count ------------------------------------
+// forward: one thread per voxel, grid.y = image (no 64-bit divisions in the loop), weights zero-padded to KT classes
+// in LDS so the FMA loop carries no predicates.
+template <typename T, int KT>
+__global__ void __launch_bounds__(NT) k_head_fwd_k(const void* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float* __restrict__ logits,
+                                                   int64_t S, int Cin, int K) {
+  constexpr int CPC = Elem<T>::CPC;
+  CBIM_DYN_SMEM(smem);
+  float* wL = (float*)smem;  // [Cin][KT]
+  for (int i = threadIdx.x; i < Cin * KT; i += NT) {
+    int k = i % KT, c = i / KT;
+    wL[i] = k < K ? w[(size_t)k * Cin + c] : 0.f;
+  }
+  __syncthreads();
+  const int n = blockIdx.y;
+  float bias[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) bias[k] = k < K ? b[k] : 0.f;
+  const char* xn = (const char*)x + (size_t)n * S * Cin * Elem<T>::SIZE;
+  float* ln = logits + (size_t)n * K * S;
+  for (int64_t v = (int64_t)blockIdx.x * NT + threadIdx.x; v < S; v += (int64_t)gridDim.x * NT) {
+    float out[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) out[k] = bias[k];
+    const char* xr = xn + (size_t)v * Cin * Elem<T>::SIZE;
+    for (int cb = 0; cb < Cin; cb += 4 * CPC) {   // 4 chunk loads in flight before any is used
+      u32x4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (cb + u * CPC < Cin) raw[u] = *(const u32x4*)(xr + (size_t)(cb + u * CPC) * Elem<T>::SIZE);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c0 = cb + u * CPC;
+        if (c0 < Cin) {
+          float f[CPC];
+          Elem<T>::unpack(raw[u], f);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) {
+            const f32x4* wr = (const f32x4*)(wL + (size_t)(c0 + j) * KT);
+#pragma unroll
+            for (int k4 = 0; k4 < KT / 4; ++k4) {
+              const f32x4 wv = wr[k4];
+              out[4 * k4] = fmaf(f[j], wv.x, out[4 * k4]);
+              out[4 * k4 + 1] = fmaf(f[j], wv.y, out[4 * k4 + 1]);
+              out[4 * k4 + 2] = fmaf(f[j], wv.z, out[4 * k4 + 2]);
+              out[4 * k4 + 3] = fmaf(f[j], wv.w, out[4 * k4 + 3]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k < K) ln[(size_t)k * S + v] = out[k];
+  }
+}
+
+// backward, one pass over dz and x: dx (optional), dw and db.  Wave w of the workgroup owns the 16-byte channel
+// chunks w, w+4, .. (CHW of them) of every voxel row; a lane = one voxel.  dz[k][v] is a coalesced plane read (the four
+// waves read the same values: L1), dx_chunk = sum_k dz[k] * W[k][chunk] (weights: LDS broadcasts), and the wave keeps
+// dw[k][chunk] as per-lane partial sums over its voxels (16 x CPC x CHW registers), summed over lanes once at the
+// end.  Slab per workgroup [K][Cin+1] (last column = db), fixed-order reduce by k_head_bwd_reduce.
+template <typename T, int CHW>
+__global__ void __launch_bounds__(NT) k_head_bwd_k(const void* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ dz, void* __restrict__ dx,
+                                                   float* __restrict__ ws, int64_t S, int Cin, int K,
+                                                   int64_t vox_per_block) {
+  constexpr int CPC = Elem<T>::CPC, KT = 16;
+  CBIM_DYN_SMEM(smem);
+  float* wL = (float*)smem;   // [KT][Cin] zero rows for k >= K
+  for (int i = threadIdx.x; i < KT * Cin; i += NT) wL[i] = i < K * Cin ? w[i] : 0.f;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.y, cch = Cin / CPC;
+  float acc[CHW][KT][CPC];
+  float dbv[KT];
+#pragma unroll
+  for (int h = 0; h < CHW; ++h)
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) acc[h][k][j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) dbv[k] = 0.f;
+  const int64_t v_begin = (int64_t)blockIdx.x * vox_per_block;
+  int64_t v_end = v_begin + vox_per_block;
+  if (v_end > S) v_end = S;
+  const float* dzn = dz + (size_t)n * K * S;
+  const char* xn = (const char*)x + (size_t)n * S * Cin * Elem<T>::SIZE;
+  char* dxn = dx ? (char*)dx + (size_t)n * S * Cin * Elem<T>::SIZE : nullptr;
+  for (int64_t v = v_begin + lane; v < v_end; v += 64) {
+    float g[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) g[k] = k < K ? dzn[(size_t)k * S + v] : 0.f;
+    u32x4 raw[CHW];
+#pragma unroll
+    for (int h = 0; h < CHW; ++h) {
+      const int q = wave + 4 * h;
+      if (q < cch) raw[h] = *(const u32x4*)(xn + ((size_t)v * Cin + (size_t)q * CPC) * Elem<T>::SIZE);
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) dbv[k] += g[k];
+#pragma unroll
+    for (int h = 0; h < CHW; ++h) {
+      const int q = wave + 4 * h;
+      if (q < cch) {
+        float xf[CPC];
+        Elem<T>::unpack(raw[h], xf);
+        if (dxn) {
+          float f[CPC];
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) f[j] = 0.f;
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            const float* wr = wL + (size_t)k * Cin + q * CPC;
+#pragma unroll
+            for (int j4 = 0; j4 < CPC; j4 += 4) {
+              const f32x4 wv = *(const f32x4*)(wr + j4);
+              f[j4] = fmaf(g[k], wv.x, f[j4]);
+              f[j4 + 1] = fmaf(g[k], wv.y, f[j4 + 1]);
+              f[j4 + 2] = fmaf(g[k], wv.z, f[j4 + 2]);
+              f[j4 + 3] = fmaf(g[k], wv.w, f[j4 + 3]);
+            }
+          }
+          *(u32x4*)(dxn + ((size_t)v * Cin + (size_t)q * CPC) * Elem<T>::SIZE) = Elem<T>::pack(f);
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) acc[h][k][j] = fmaf(g[k], xf[j], acc[h][k][j]);
+      }
+    }
+  }
+  // lanes -> one value (xor butterfly: every lane ends with the same, order-fixed sum)
+  const int npairs = K * (Cin + 1);
+  float* slab = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * npairs;
+#pragma unroll
+  for (int h = 0; h < CHW; ++h) {
+    const int q = wave + 4 * h;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) {
+        const float a = wave_sum(acc[h][k][j]);
+        if (lane == 0 && q < cch && k < K) slab[(size_t)k * (Cin + 1) + q * CPC + j] = a;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const float a = wave_sum(dbv[k]);
+    if (wave == 0 && lane == 0 && k < K) slab[(size_t)k * (Cin + 1) + Cin] = a;
+  }
+}
+
 static inline int grid_for(int64_t items) {
   int64_t b = (items + NT - 1) / NT;
   if (b > 256 * 8) b = 256 * 8;
@@ -477,6 +632,16 @@ extern "C" int cbim_head_fwd(int dtype, const void* x, const float* w, const flo
   int64_t total = (int64_t)N * S;
   size_t smem = (size_t)Cin * K * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  if (K <= 16 && (size_t)Cin * 16 * sizeof(float) <= 64 * 1024) {   // compile-time class count (k_head_fwd_k)
+    const size_t sm = (size_t)Cin * 16 * sizeof(float);
+    int64_t bx = (S + NT - 1) / NT;
+    const int64_t cap = 2048 / N > 1 ? 2048 / N : 1;
+    if (bx > cap) bx = cap;
+    dim3 grid((unsigned)bx, (unsigned)N);
+    if (dtype == CBIM_BF16) CBIM_LAUNCH((k_head_fwd_k<bf16_tag, 16>), grid, dim3(NT), sm, st, x, w, b, logits, S, Cin, K);
+    else CBIM_LAUNCH((k_head_fwd_k<float, 16>), grid, dim3(NT), sm, st, x, w, b, logits, S, Cin, K);
+    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  }
   if (dtype == CBIM_BF16)
     CBIM_LAUNCH((k_head_fwd<bf16_tag>), dim3(grid_for(total)), dim3(NT), smem, st, x, w, b, logits, S, Cin, K, total);
   else
@@ -504,6 +669,30 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
   hipStream_t st = (hipStream_t)stream;
   int64_t total = (int64_t)N * S;
   size_t smem = (size_t)Cin * K * sizeof(float);
+  {
+    // one fused pass (dx, dw, db) when the channel chunks of a row fit the 4 waves x CHW layout of k_head_bwd_k
+    const int cpc = dtype == CBIM_BF16 ? 8 : 4, cch = Cin / cpc;
+    if (K <= 16 && cch <= 8 && (size_t)Cin * 16 * sizeof(float) <= 64 * 1024) {
+      const int nb = head_bwd_blocks(S);
+      int64_t vpb = (S + nb - 1) / nb;
+      vpb = (vpb + 63) / 64 * 64;
+      const size_t sm = (size_t)Cin * 16 * sizeof(float);
+      dim3 grid((unsigned)nb, (unsigned)N);
+      float* wsf = (float*)workspace;
+      if (dtype == CBIM_BF16) {
+        if (cch <= 4) CBIM_LAUNCH((k_head_bwd_k<bf16_tag, 1>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
+        else CBIM_LAUNCH((k_head_bwd_k<bf16_tag, 2>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
+      } else {
+        if (cch <= 4) CBIM_LAUNCH((k_head_bwd_k<float, 1>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
+        else CBIM_LAUNCH((k_head_bwd_k<float, 2>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
+      }
+      if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+      const int npairs = K * (Cin + 1);
+      CBIM_LAUNCH(k_head_bwd_reduce, dim3((npairs + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw, db,
+                  N * nb, Cin, K);
+      return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+    }
+  }
   if (dx) {
     if (dtype == CBIM_BF16)
       CBIM_LAUNCH((k_head_bwd_dx<bf16_tag>), dim3(grid_for(total)), dim3(NT), smem, st, w, dlogits, dx, S, Cin, K, total);

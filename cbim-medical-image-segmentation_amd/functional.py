@@ -14,6 +14,7 @@ Fusion map (reference: /root/reference/model/dim3/conv_layers.py):
 """
 from __future__ import annotations
 
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -22,6 +23,7 @@ from . import ops
 from .ops import ACT, IN_EPS, ConvGeom
 
 _COMPUTE_DTYPE: Optional[torch.dtype] = None
+_CHECK_LABELS = os.environ.get("CBIM_CHECK_LABELS", "0") not in ("", "0")
 
 
 def set_compute_dtype(dtype):
@@ -55,6 +57,13 @@ def ensure_stats(f: FMap, eps: float = IN_EPS) -> FMap:
         return f
     with torch.no_grad():
         return FMap(f.t, ops.instnorm_stats(f.t.detach(), eps))
+
+
+def _geom_c(x: torch.Tensor, cout: int, w: torch.Tensor, act: int) -> ConvGeom:
+    """geometry of a convolution whose weight is `w` with `cout` output channels (Cout-concatenated pairs)"""
+    k = tuple(int(i) for i in w.shape[2:])
+    pad = tuple(i // 2 for i in k)
+    return ConvGeom(x.dtype, int(x.shape[0]), tuple(x.shape[1:4]), int(w.shape[1]), int(cout), k, pad, act)
 
 
 def _geom(x: torch.Tensor, w: torch.Tensor, act: int) -> ConvGeom:
@@ -105,16 +114,13 @@ class BasicBlockFn(torch.autograd.Function):
     def forward(ctx, x, x_stats, w1, w2, wsc, act, want_out_stats):
         cout = int(w1.shape[0])
         fused = wsc is not None and _fusable(x, cout)
-        w2d = w2.detach().contiguous()
         train = any(ctx.needs_input_grad)
-        # weights are re-laid into MFMA fragment order once per step; when a backward will follow, the
-        # dgrad layout comes out of the same launch and is kept for it
-        pk = (lambda w, g: ops.pack_weights_both(w, g)) if train else (lambda w, g: (ops.pack_weights(w, g, 0), None))
+        # weights live in MFMA fragment order in a cache that one launch per optimizer step refreshes
+        # (ops.PackedWeights); the dgrad layout comes out of the same launch
         wdsc = None
         if fused:
-            wcat = torch.cat([w1.detach(), wsc.detach()], 0).contiguous()
-            gc = _geom(x, wcat, act)
-            wp, wd1 = pk(wcat, gc)
+            gc = _geom_c(x, 2 * cout, w1, act)
+            wp, wd1 = ops.packed_weights((w1, wsc), gc, train)
             ycat, scat = ops.conv_fwd(x, wp, gc, in_stats=x_stats, want_stats=True)
             y1, res = ycat[..., :cout], ycat[..., cout:]
             s1 = scat[:, :cout].contiguous()
@@ -122,17 +128,17 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             gc = None
             g1 = _geom(x, w1, act)
-            wp, wd1 = pk(w1.detach().contiguous(), g1)
+            wp, wd1 = ops.packed_weights((w1,), g1, train)
             y1, s1 = ops.conv_fwd(x, wp, g1, in_stats=x_stats, want_stats=True)
             if wsc is not None:
                 gsc = _geom(x, wsc, act)
-                wpsc, wdsc = pk(wsc.detach().contiguous(), gsc)
+                wpsc, wdsc = ops.packed_weights((wsc,), gsc, train)
                 res, _ = ops.conv_fwd(x, wpsc, gsc, in_stats=x_stats)
             else:
                 gsc = None
                 res = x
         g2 = _geom(y1, w2, act)
-        wp2, wd2 = pk(w2d, g2)
+        wp2, wd2 = ops.packed_weights((w2,), g2, train)
         out, so = ops.conv_fwd(y1, wp2, g2, in_stats=s1, res=res, want_stats=want_out_stats)
         ctx.save_for_backward(x, x_stats, y1, s1, w1, w2, wsc if wsc is not None else torch.empty(0))
         ctx.packed = (wd1, wd2, wdsc)
@@ -183,7 +189,9 @@ class SingleConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, act, need_dx):
         g = _geom(x, w, act)
-        z, sz = ops.conv_fwd(x, ops.pack_weights(w.detach().contiguous(), g, 0), g, want_stats=True)
+        wp, wpd = ops.packed_weights((w,), g, bool(need_dx))
+        z, sz = ops.conv_fwd(x, wp, g, want_stats=True)
+        ctx.wpd = wpd
         y = ops.norm_act_fwd(z, sz, act)
         ctx.save_for_backward(x, z, sz, w)
         ctx.geom, ctx.act, ctx.need_dx = g, act, need_dx
@@ -199,7 +207,7 @@ class SingleConvFn(torch.autograd.Function):
         dw = ops.conv_wgrad(x, None, dz, g)
         dx = None
         if ctx.need_dx:
-            dx, _ = ops.conv_dgrad(dz, ops.pack_weights(w.detach().contiguous(), g, 1), g)
+            dx, _ = ops.conv_dgrad(dz, ctx.wpd, g)
         return dx, dw, None, None
 
 
@@ -260,6 +268,12 @@ class DiceCEFn(torch.autograd.Function):
         if labels.dtype != torch.int64:
             labels = labels.long()
         out, coef = ops.dice_ce_fwd(logits, labels, weight)
+        # out[3] = number of labels outside [0, C): the reference raises (scatter_ / CrossEntropyLoss); reading the
+        # count is a device synchronisation, so it is only checked on request
+        if _CHECK_LABELS and not (logits.is_cuda and torch.cuda.is_current_stream_capturing()):
+            bad = int(out[3].item())
+            if bad:
+                raise IndexError(f"cbim_amd: {bad} label(s) outside [0, {int(logits.shape[1])}) (Target out of bounds)")
         ctx.save_for_backward(logits, labels, coef, weight if weight is not None else torch.empty(0))
         ctx.has_w = weight is not None
         return out
@@ -293,12 +307,7 @@ class NormConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stats, w, act, res, want_stats, se, eps_out):
         g = _geom(x, w, act)
-        train = any(ctx.needs_input_grad)
-        wd = w.detach().contiguous()
-        if train:
-            wp, wpd = ops.pack_weights_both(wd, g)
-        else:
-            wp, wpd = ops.pack_weights(wd, g, 0), None
+        wp, wpd = ops.packed_weights((w,), g, bool(ctx.needs_input_grad[0]))
         st = stats
         if se is not None:
             assert act == 0 and stats is not None

@@ -226,6 +226,106 @@ def pack_weights_both(w: torch.Tensor, geom: ConvGeom):
     return p0, p1
 
 
+class _PackEntry:
+    __slots__ = ("w0", "w1", "rows0", "geom", "p0", "p1", "versions", "last")
+
+
+class PackedWeights:
+    """Packed (MFMA fragment order) copies of every convolution weight seen so far, re-laid by ONE kernel launch
+    when any of them changed (`Tensor._version` moves with the optimizer's in-place update): the first convolution
+    of a step finds its weight stale and re-packs the whole table, the others hit.  Replaces one pack launch per
+    convolution and the torch.cat of each conv1|shortcut pair (0.5 ms of the 19 ms ResUNet step).  Under hipGraph
+    capture the table launch is captured where it happens and replays with the step."""
+
+    def __init__(self):
+        self.entries = {}
+        self.tick = 0          # number of table launches so far
+        self.table = None      # device copy of the cbim_pack_item array
+        self.n_blocks = 0
+        self.dirty_table = True
+
+    @staticmethod
+    def _key(ws, geom: ConvGeom):
+        return tuple((w.data_ptr(), tuple(w.shape)) for w in ws) + (geom.dtype,)
+
+    def get(self, ws, geom: ConvGeom, need_dgrad: bool):
+        """ws: (w,) or (w_conv1, w_shortcut) fp32 [Cout_i, Cin, kD, kH, kW] -> (packed fwd, packed dgrad | None)."""
+        key = self._key(ws, geom)
+        e = self.entries.get(key)
+        if e is None or (need_dgrad and e.p1 is None):
+            e = self._add(key, ws, geom, need_dgrad or (e is not None and e.p1 is not None))
+        e.last = self.tick
+        vers = tuple(w._version for w in ws)
+        if e.versions != vers:
+            self._repack_all()
+        return e.p0, (e.p1 if need_dgrad else None)
+
+    def _add(self, key, ws, geom, with_dgrad):
+        L = _lib.lib()
+        dev = ws[0].device
+        e = _PackEntry()
+        e.w0 = ws[0].detach()
+        e.w1 = ws[1].detach() if len(ws) > 1 else None
+        for w in ws:
+            _dev_ok(w)
+            if w.dtype != torch.float32:
+                raise TypeError("cbim_amd: convolution weights must be float32 master copies")
+        e.rows0 = int(ws[0].shape[0])
+        e.geom = geom
+        e.p0 = torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 0),), dtype=torch.uint8, device=dev)
+        e.p1 = torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 1),), dtype=torch.uint8, device=dev) \
+            if with_dgrad else None
+        e.versions = None
+        e.last = self.tick
+        self.entries[key] = e
+        self.dirty_table = True
+        return e
+
+    def _build_table(self):
+        L = _lib.lib()
+        items = (_lib.PackItem * len(self.entries))()
+        blk = 0
+        for i, e in enumerate(self.entries.values()):
+            check(L.cbim_conv3d_pack_item_fill(C.byref(e.geom.fwd), _p(e.w0), _p(e.w1), e.rows0, _p(e.p0), _p(e.p1), blk,
+                                               C.byref(items[i])), "pack_item_fill")
+            blk += items[i].n_blocks
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        dev = next(iter(self.entries.values())).p0.device
+        self.table = raw.to(dev)       # (outside graph capture: see _repack_all)
+        self.n_blocks = blk
+        self.dirty_table = False
+
+    def _repack_all(self):
+        capturing = self.table is not None and self.table.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            # weights that no convolution asked for during the last 8 table launches belong to models that are gone
+            dead = [k for k, e in self.entries.items() if self.tick - e.last > 8]
+            for k in dead:
+                del self.entries[k]
+            self.dirty_table = self.dirty_table or bool(dead)
+        self.tick += 1
+        if self.dirty_table:
+            if self.table is not None and self.table.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("cbim_amd: a new convolution weight appeared during hipGraph capture; run one "
+                                   "eager step first so that the pack table is complete")
+            self._build_table()
+        t = self.table
+        check(_lib.lib().cbim_conv3d_pack_weights_table(_p(t), len(self.entries), self.n_blocks, _stream(t)),
+              "pack_weights_table")
+        for e in self.entries.values():
+            e.versions = tuple(w._version for w in ((e.w0,) if e.w1 is None else (e.w0, e.w1)))
+
+    def clear(self):
+        self.__init__()
+
+
+PACKED = PackedWeights()
+
+
+def packed_weights(ws, geom: ConvGeom, need_dgrad: bool):
+    return PACKED.get(tuple(ws), geom, need_dgrad)
+
+
 def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, mask_x=None, mask_stats=None,
                want_partials: bool = False, x2=None):
     """x2: second input tensor; the conv's input is the channel concatenation [x | x2] (never
@@ -369,14 +469,14 @@ def head_bwd(x, w2d, dlogits, need_dx=True):
 # ------------------------------------------------------------------------------------------------
 
 def dice_ce_fwd(logits, labels, weight=None):
-    """-> out float32[3] = (CE, Dice, CE+Dice), coef float32[2C+1] (for the backward)."""
+    """-> out float32[4] = (CE, Dice, CE+Dice, #labels outside [0,C)), coef float32[2C+1] (for the backward)."""
     _dev_ok(logits, labels, weight)
     N, Cc = int(logits.shape[0]), int(logits.shape[1])
     S = logits.numel() // (N * Cc)
     L = _lib.lib()
     nbytes = L.cbim_dice_ce_workspace(N, Cc, S)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=logits.device)
-    out = torch.empty((3,), dtype=torch.float32, device=logits.device)
+    out = torch.empty((4,), dtype=torch.float32, device=logits.device)
     coef = torch.empty((2 * Cc + 1,), dtype=torch.float32, device=logits.device)
     check(L.cbim_dice_ce_fwd(_p(logits), _p(labels), _p(weight), N, Cc, S, _p(out), _p(coef), _p(ws), nbytes,
                              _stream(logits)), "dice_ce_fwd")

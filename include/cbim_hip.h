@@ -122,6 +122,18 @@ int cbim_conv3d_pack_weights(const cbim_conv_desc* fwd_desc, int mode, const flo
 /* Both layouts in one launch (training: the dgrad layout is needed in the backward of the same step). */
 int cbim_conv3d_pack_weights_both(const cbim_conv_desc* fwd_desc, const float* w, void* packed_fwd,
                                   void* packed_dgrad, void* stream);
+/* All convolution weights of a model in one launch.  The host fills one cbim_pack_item per weight with
+ * cbim_conv3d_pack_item_fill (w1 != NULL: forward output channels >= rows0 come from w1 — the Cout-concatenated
+ * conv1|shortcut pair of BasicBlock, conv_layers.py:86-94, packed without a torch.cat; block_begin = running sum of the
+ * previous items' n_blocks), copies the array to the device and launches it once per optimizer step. */
+typedef struct cbim_pack_item {
+  const float* w0; const float* w1; void* p0; void* p1;
+  int64_t total0, total1;
+  int rows0, Cout, Cin, taps, BN0, nch0, BN1, nch1, block_begin, n_blocks, dtype, _pad;
+} cbim_pack_item;
+int cbim_conv3d_pack_item_fill(const cbim_conv_desc* fwd_desc, const float* w0, const float* w1, int rows0,
+                               void* packed_fwd, void* packed_dgrad, int block_begin, cbim_pack_item* out);
+int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, int n_items, int total_blocks, void* stream);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);
@@ -183,7 +195,9 @@ int cbim_head_bwd(int dtype, const void* x, const float* w, const float* dlogits
  * Loss: nn.CrossEntropyLoss(weight)(logits, label) + DiceLoss()(logits, label)
  * (train.py:80-81,212; training/losses.py:18-58) in one read of the logits.
  * logits float [N][C][S] (NCDHW), labels int64 [N][S].
- * fwd: out[0]=CE, out[1]=Dice, out[2]=CE+Dice; coef float [2][C] = (dL/dTP_c, dL/dSP_c) and
+ * fwd: out float[4]: out[0]=CE, out[1]=Dice, out[2]=CE+Dice, out[3]=number of labels outside [0,C) (the reference
+ *      raises for those in scatter_/CrossEntropyLoss; here such a voxel is excluded from CE / TP / CNT, never used
+ *      as an index, and counted so the host can raise); coef float [2][C] = (dL/dTP_c, dL/dSP_c) and
  *      coef[2C] = 1/sum_i w[y_i] for the backward.  workspace: cbim_dice_ce_workspace(N,C,S).
  * bwd: dlogits = grad_out[0] * d(CE+Dice)/dlogits  (grad_out is a DEVICE scalar).
  * ------------------------------------------------------------------------------------------ */

@@ -155,7 +155,7 @@ def check_stem_head(dev, dtype, N=1, Cin=2, base=8, K=5, dhw=(6, 9, 10), k=(3, 3
     zr = F.conv3d(hr, wh, bh)
     z = ops.head_fwd(hl, wh.detach().reshape(K, base).contiguous().to(dev), bh.detach().to(dev))
     assert relerr(z.cpu(), zr.detach()) < 5e-6
-    dz = torch.randn_like(zr)
+    dz = torch.randn(zr.shape)
     zr.backward(dz)
     dx, dwh, dbh = ops.head_bwd(hl, wh.detach().reshape(K, base).contiguous().to(dev), dz.to(dev))
     assert relerr(from_cl(dx.cpu()), hr.grad) < tol(dtype, 5e-6, 8e-3)
@@ -179,6 +179,16 @@ def check_loss(dev, N=2, C=6, dhw=(6, 7, 8), weighted=True, seed=5):
     g2 = torch.tensor([0.7, 1.3], device=dev)
     dz = ops.dice_ce_bwd(z.detach().to(dev), lab.to(dev), None if w is None else w.to(dev), coef, g2)
     assert relerr(dz.cpu(), z.grad) < 2e-5
+    assert float(out[3]) == 0.0
+    # a label outside [0, C) is counted (out[3]) and never used as an index: same result as dropping those voxels
+    # from CE / the one-hot target (the reference raises instead)
+    lab2 = lab.clone()
+    lab2[0, 0, -1, -1, -3:] = C + 5
+    lab2[-1, 0, 0, 0, 0] = -1
+    out2, coef2 = ops.dice_ce_fwd(z.detach().to(dev), lab2.to(dev), None if w is None else w.to(dev))
+    assert float(out2[3]) == 4.0 and all(bool(torch.isfinite(t).all()) for t in (out2, coef2))
+    dz2 = ops.dice_ce_bwd(z.detach().to(dev), lab2.to(dev), None if w is None else w.to(dev), coef2, g2)
+    assert bool(torch.isfinite(dz2).all())
 
 
 def check_fused_block(dev, dtype, N=1, Cin=64, Cout=32, dhw=(4, 8, 8)):

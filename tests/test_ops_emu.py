@@ -117,11 +117,17 @@ def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
     oc.check_stem_head(dev, dtype, Cin=1, base=16, K=3, dhw=(4, 8, 8), k=(1, 3, 3))
     oc.check_stem_head(dev, dtype, Cin=5, base=8, K=3, dhw=(4, 8, 9))     # two channel groups in the stem wgrad
+    oc.check_stem_head(dev, dtype, N=2, Cin=1, base=32, K=16, dhw=(5, 7, 9))   # head: 4 (bf16) / 8 (fp32) chunks per row
+    oc.check_stem_head(dev, dtype, Cin=1, base=64, K=2, dhw=(3, 5, 20))        # head: two chunks per wave (bf16) / generic kernels (fp32)
+    oc.check_stem_head(dev, dtype, Cin=1, base=16, K=19, dhw=(3, 4, 5))        # head: more than 16 classes -> generic kernels
 
 
 def test_loss(dev):
     oc.check_loss(dev)
     oc.check_loss(dev, N=1, C=3, dhw=(4, 4, 4), weighted=False, seed=9)
+    oc.check_loss(dev, N=2, C=20, dhw=(3, 5, 6))     # C > 16: two voxels per thread
+    oc.check_loss(dev, N=2, C=20, dhw=(3, 5, 7))     # odd plane size: one voxel per thread
+    oc.check_loss(dev, N=2, C=5, dhw=(3, 3, 5))
 
 
 def test_errors_are_loud(dev):
