@@ -379,6 +379,20 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
   };
   (void)0;
 
+  // ---- statistics record of this workgroup: partials[n][lb][Cout][3], P = gridDim.x records per image; images the
+  //      strip does not touch get an empty record (n = 0 merges as the identity) ----------------------------------
+  Moments run = {0.f, 0.f, 0.f};
+  int run_n = cur.n;
+  auto flush_partial = [&](int n, const Moments& m) {
+    const size_t o = (((size_t)n * gridDim.x + lb) * p.Cout + co0 + tid) * 3;
+    p.partials[o] = m.n; p.partials[o + 1] = m.mean; p.partials[o + 2] = m.m2;
+  };
+  if (p.partials && p.ksplit == 1 && tid < BN && co0 + tid < p.Cout) {
+    const int n_first = t_begin / tiles_per_n, n_last = (t_end - 1) / tiles_per_n;
+    for (int n = 0; n < p.N; ++n)
+      if (n < n_first || n > n_last) flush_partial(n, Moments{0.f, 0.f, 0.f});
+  }
+
   // ---- prologue: first unit's halo and first stage of weights -----------------------------------------
   dma_stage(cur.q, 0, 0);
   halo_load(cur);
@@ -623,7 +637,8 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
       CBIM_TICK(5);
       if (more || tile_done) __syncthreads();   // halo visible; scratch reads done; `red` complete
       if (tile_done && p.partials && p.ksplit == 1 && tid < BN && co0 + tid < p.Cout) {
-        const int n = cur.n, tt = (cur.td * p.tiles_h + cur.th) * p.tiles_w + cur.tw;
+        // one record per (image, workgroup): the tile's moments join the workgroup's running record (a record per
+        // TILE made the finalize kernel walk 4096 scattered 12-byte rows per channel at 128^3)
         const float* red = (const float*)(smem + red_base);
         Moments a = {0.f, 0.f, 0.f};
         for (int g = 0; g < NW; ++g) {
@@ -631,16 +646,16 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
           if (p.mx) { a.mean += rr[1]; a.m2 += rr[2]; }
           else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
         }
-        size_t o = (((size_t)n * tiles_per_n + tt) * p.Cout + co0 + tid) * 3;
-        p.partials[o] = a.n;
-        p.partials[o + 1] = a.mean;
-        p.partials[o + 2] = a.m2;
+        if (cur.n != run_n) { flush_partial(run_n, run); run = Moments{0.f, 0.f, 0.f}; run_n = cur.n; }
+        if (p.mx) { run.mean += a.mean; run.m2 += a.m2; }
+        else run = moments_merge(run, a);
       }
       CBIM_TICK(5);
     }
     cur = nxt;
     advance(nxt);
   }
+  if (p.partials && p.ksplit == 1 && tid < BN && co0 + tid < p.Cout) flush_partial(run_n, run);
 #ifdef CBIM_IGEMM_PROF
   if (p.prof && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
     for (int i = 0; i < 8; ++i) p.prof[wave * 8 + i] = pacc[i];
@@ -859,6 +874,15 @@ static int finish_parts(int64_t S) {
   return (int)p;
 }
 static int kc_of(int dtype) { return RB / elem_size(dtype); }
+// persistent grid: about one workgroup per CU (256 CUs), never more workgroups than tiles
+static int64_t igemm_grid_x(const cbim_conv_desc* d, const TileCfg& c) {
+  const int64_t n_tiles = (int64_t)d->N * ((d->Do + c.tD - 1) / c.tD) * ((d->Ho + c.tH - 1) / c.tH) * ((d->Wo + 7) / 8);
+  const int BN = 32 * c.NTL, n_nblk = (d->Cout + BN - 1) / BN;
+  int64_t G = (c.nth == 256 ? 512 : 256) / n_nblk;
+  if (G < 1) G = 1;
+  if (G > n_tiles) G = n_tiles;
+  return G;
+}
 
 }  // namespace cbim
 
@@ -966,7 +990,7 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   if (!d) return 0;
   TileCfg c = pick_cfg(d);
   if (pick_ksplit(d, c) > 1) return finish_parts((int64_t)d->Do * d->Ho * d->Wo);
-  return ((d->Do + c.tD - 1) / c.tD) * ((d->Ho + c.tH - 1) / c.tH) * ((d->Wo + 7) / 8);
+  return (int)igemm_grid_x(d, c);   // one record per (image, persistent workgroup)
 }
 
 template <typename T, int MT, int NTL, int ACT, bool K3, int NTH = 512>
@@ -1069,10 +1093,8 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "conv tile needs %zu B of LDS", smem);
   int64_t n_tiles = (int64_t)d->N * p.tiles_d * p.tiles_h * p.tiles_w;
   int n_nblk = (d->Cout + BN - 1) / BN;
-  // persistent grid: about one workgroup per CU (256 CUs), never more workgroups than tiles
-  int64_t G = (c.nth == 256 ? 512 : 256) / n_nblk;
-  if (G < 1) G = 1;
-  if (G > n_tiles) G = n_tiles;
+  const int64_t G = igemm_grid_x(d, c);
+  (void)n_tiles;
   p.ksplit = pick_ksplit(d, c);
   p.ws = (float*)workspace;
   if (p.ksplit > 1) {

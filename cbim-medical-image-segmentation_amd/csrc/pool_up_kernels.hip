@@ -153,6 +153,102 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd(const void* __restrict__ low, 
   }
 }
 
+// Same output as k_upcat_fwd plus the InstanceNorm statistics partials of the concatenated tensor (the first block of
+// the decoder level normalises it: a separate statistics pass re-read the 403 MB concat of the 128^3 level).
+// grid = (parts, N); thread = (fixed channel chunk, voxel lane) so per-channel sums stay in registers; 32-bit index
+// arithmetic.  partials: float [N][P][Ct][3] = (n, mean, M2) records merged by k_stats_finalize.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_upcat_fwd_stats(const void* __restrict__ low, const void* __restrict__ skip,
+                                                        void* __restrict__ out, int Dl, int Hl, int Wl, int Cl,
+                                                        int D, int H, int W, int Cs, int skip_first, int P,
+                                                        float* __restrict__ partials) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int Ct = Cs + Cl;
+  const int cch = Ct / CPC, vlc = NT / cch;       // host guarantees cch <= NT
+  const int t = threadIdx.x, cc = t % cch, vl = t / cch;
+  const int part = blockIdx.x, n = blockIdx.y;
+  const int S = D * H * W, per = (S + P - 1) / P;
+  const int v0 = part * per, v1 = v0 + per < S ? v0 + per : S;
+  const float sd = lin_scale(Dl, D), sh = lin_scale(Hl, H), sw = lin_scale(Wl, W);
+  const int skip_lo = skip_first ? 0 : Cl, low_lo = skip_first ? Cs : 0;
+  const int c0 = cc * CPC;
+  const bool is_skip = c0 >= skip_lo && c0 < skip_lo + Cs;
+  const bool active = vl < vlc;
+  float s0[CPC], s1[CPC], shift[CPC];
+  float cnt = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) { s0[j] = 0.f; s1[j] = 0.f; shift[j] = 0.f; }
+  if (active) {
+    const size_t nrow = (size_t)n * S;
+    for (int v = v0 + vl; v < v1; v += vlc) {
+      u32x4 o;
+      if (is_skip) {
+        o = ld_chunk<T>(skip, (nrow + v) * Cs + (c0 - skip_lo));
+      } else {
+        const int w = v % W, q = v / W, h = q % H, d = q / H;
+        const Lin ld = lin_src(d, sd, Dl), lh = lin_src(h, sh, Hl), lw = lin_src(w, sw, Wl);
+        const int cl = c0 - low_lo;
+        float acc[CPC];
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int dd = a ? ld.i1 : ld.i0;
+          const float wa = a ? ld.l1 : ld.l0;
+          float pa[CPC];
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) pa[j] = 0.f;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int hh = b ? lh.i1 : lh.i0;
+            const float wb = b ? lh.l1 : lh.l0;
+            const size_t rbase = (((size_t)n * Dl + dd) * Hl + hh) * Wl;
+            float f0[CPC], f1[CPC];
+            Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl), f0);
+            Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl), f1);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) pa[j] += wb * (lw.l0 * f0[j] + lw.l1 * f1[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) acc[j] += wa * pa[j];
+        }
+        o = Elem<T>::pack(acc);
+      }
+      st_chunk<T>(out, (nrow + v) * Ct + c0, o);
+      float f[CPC];
+      Elem<T>::unpack(o, f);   // statistics of the STORED (rounded) values, like a pass over the tensor
+      if (cnt == 0.f) {
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) shift[j] = f[j];
+      }
+      cnt += 1.f;
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) { const float dlt = f[j] - shift[j]; s0[j] += dlt; s1[j] += dlt * dlt; }
+    }
+  }
+  __shared__ float red[NT * 3 * 8];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) {
+    const Moments m = moments_from_shifted(cnt, shift[j], s0[j], s1[j]);
+    red[(t * CPC + j) * 3 + 0] = m.n;
+    red[(t * CPC + j) * 3 + 1] = m.mean;
+    red[(t * CPC + j) * 3 + 2] = m.m2;
+  }
+  __syncthreads();
+  if (vl == 0 && active) {
+    for (int j = 0; j < CPC; ++j) {
+      Moments acc = {0.f, 0.f, 0.f};
+      for (int q = 0; q < vlc; ++q) {
+        const float* r = red + ((q * cch + cc) * CPC + j) * 3;
+        const Moments b = {r[0], r[1], r[2]};
+        acc = moments_merge(acc, b);
+      }
+      const size_t o = (((size_t)n * P + part) * Ct + c0 + j) * 3;
+      partials[o] = acc.n; partials[o + 1] = acc.mean; partials[o + 2] = acc.m2;
+    }
+  }
+}
+
 // candidate range of destination indices whose interpolation footprint can touch source index l
 __device__ __forceinline__ void dst_range(int l, float scale, int out, int& lo, int& hi) {
   if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
@@ -356,6 +452,26 @@ extern "C" int cbim_upcat_fwd(int dtype, const void* low, const void* skip, void
   DISPATCH_T(dtype, k_upcat_fwd, dim3(grid_for(total)), (hipStream_t)stream, low, skip, out, Dl, Hl, Wl, Cl,
              D, H, W, Cs, skip_first, total);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_stats_parts(int64_t S, int C);
+extern "C" int cbim_stats_finalize(const float* partials, int N, int P, int C, double count, float eps, int mode,
+                                   float* out, void* stream);
+
+extern "C" int cbim_upcat_fwd_stats(int dtype, const void* low, const void* skip, void* out, int N, int Dl, int Hl,
+                                    int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, float eps,
+                                    float* partials, int P, float* stats, void* stream) {
+  if (int e = check_c(dtype, Cl, "upcat low")) return e;
+  if (Cs > 0) if (int e = check_c(dtype, Cs, "upcat skip")) return e;
+  const int cpc = dtype == CBIM_BF16 ? 8 : 4, Ct = Cs + Cl;
+  const int64_t S = (int64_t)D * H * W;
+  CBIM_CHECK(partials && stats && P == cbim_stats_parts(S, Ct), CBIM_EINVAL, "upcat_fwd_stats: partials must have cbim_stats_parts(S, Cs+Cl) records");
+  CBIM_CHECK(Ct / cpc <= NT && S < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "upcat_fwd_stats: %d channels / %lld voxels unsupported", Ct, (long long)S);
+  dim3 grid((unsigned)P, (unsigned)N);
+  DISPATCH_T(dtype, k_upcat_fwd_stats, grid, (hipStream_t)stream, low, skip, out, Dl, Hl, Wl, Cl, D, H, W, Cs, skip_first, P,
+             partials);
+  if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+  return cbim_stats_finalize(partials, N, P, Ct, (double)S, eps, 0, stats, stream);
 }
 
 extern "C" int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dskip, int N, int Dl, int Hl,

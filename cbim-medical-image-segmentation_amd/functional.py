@@ -231,14 +231,19 @@ class UpCatFn(torch.autograd.Function):
     """F.interpolate(low, size=skip size, trilinear, align_corners=True) + cat (unet_utils.py:69-71)."""
 
     @staticmethod
-    def forward(ctx, low, skip, skip_first):
+    def forward(ctx, low, skip, skip_first, want_stats=False):
         ctx.low_shape, ctx.Cs, ctx.skip_first = tuple(low.shape), int(skip.shape[-1]), skip_first
+        if want_stats:   # statistics of the concatenated tensor from the same pass (non-differentiable output)
+            out, st = ops.upcat_fwd_stats(low, skip, skip_first)
+            ctx.mark_non_differentiable(st)
+            ctx.set_materialize_grads(False)
+            return out, st
         return ops.upcat_fwd(low, skip, skip_first)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dst=None):
         dlow, dskip = ops.upcat_bwd(dout.contiguous(), ctx.low_shape, ctx.Cs, ctx.skip_first)
-        return dlow, dskip, None
+        return dlow, dskip, None, None
 
 
 class HeadFn(torch.autograd.Function):

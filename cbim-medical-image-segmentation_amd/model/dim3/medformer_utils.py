@@ -245,7 +245,7 @@ class up_block(nn.Module):
         self.conv_blocks = nn.Sequential(*convs)
 
     def forward(self, low: Fn.FMap, skip: Fn.FMap, map1, map2=None):
-        f = Fn.FMap(Fn.UpCatFn.apply(low.t, skip.t, False), None)
+        f = Fn.FMap(*Fn.UpCatFn.apply(low.t, skip.t, False, True))   # concat + InstanceNorm statistics in one pass
         if self.map_shortcut and map2 is not None:
             semantic_map = pointwise(self.map_reduction, torch.cat([map1, map2], dim=1))
         else:

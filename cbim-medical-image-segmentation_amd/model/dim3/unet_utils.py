@@ -70,7 +70,7 @@ class up_block(nn.Module):
         self.conv = nn.Sequential(*mods)
 
     def forward(self, low: Fn.FMap, skip: Fn.FMap) -> Fn.FMap:
-        f = Fn.FMap(Fn.UpCatFn.apply(low.t, skip.t, True), None)
+        f = Fn.FMap(*Fn.UpCatFn.apply(low.t, skip.t, True, True))   # concat + its InstanceNorm statistics in one pass
         for m in self.conv:
             f = m(f)
         return f

@@ -58,7 +58,7 @@ class UNetPlusPlus(nn.Module):
         """conv(cat([*skips, up(low)], 1)) — unetpp.py:54-73 (nn.Upsample(scale_factor, trilinear, align_corners=True)
         lands exactly on the skip's size for the even extents the reference supports)."""
         sk = skips[0].t if len(skips) == 1 else torch.cat([s.t for s in skips], dim=-1)
-        return self._run(layer, Fn.FMap(Fn.UpCatFn.apply(low.t, sk, True), None))
+        return self._run(layer, Fn.FMap(*Fn.UpCatFn.apply(low.t, sk, True, True)))   # concat + statistics in one pass
 
     def forward(self, x):
         dtype = Fn.compute_dtype()

@@ -173,6 +173,26 @@ def upcat_fwd(low, skip, skip_first: bool = True):
     return out
 
 
+def upcat_fwd_stats(low, skip, skip_first: bool = True, eps: float = IN_EPS):
+    """upcat_fwd plus the InstanceNorm statistics of the concatenated tensor from the same pass."""
+    _dev_ok(low, skip)
+    N, Dl, Hl, Wl, Cl = map(int, low.shape)
+    _, D, H, W, Cs = map(int, skip.shape)
+    L = _lib.lib()
+    Ct, S = Cs + Cl, D * H * W
+    cpc = 8 if low.dtype == torch.bfloat16 else 4
+    if Ct // cpc > 256 or S >= 2 ** 31:
+        out = upcat_fwd(low, skip, skip_first)
+        return out, instnorm_stats(out, eps)
+    out = torch.empty((N, D, H, W, Ct), dtype=low.dtype, device=low.device)
+    P = L.cbim_stats_parts(S, Ct)
+    part = torch.empty((N, P, Ct, 3), dtype=torch.float32, device=low.device)
+    stats = torch.empty((N, Ct, 2), dtype=torch.float32, device=low.device)
+    check(L.cbim_upcat_fwd_stats(_dt(low), _p(low), _p(skip), _p(out), N, Dl, Hl, Wl, Cl, D, H, W, Cs, int(skip_first),
+                                 eps, _p(part), P, _p(stats), _stream(low)), "upcat_fwd_stats")
+    return out, stats
+
+
 def upcat_bwd(dout, low_shape, Cs: int, skip_first: bool = True):
     _dev_ok(dout)
     N, Dl, Hl, Wl, Cl = map(int, low_shape)
@@ -227,7 +247,7 @@ def pack_weights_both(w: torch.Tensor, geom: ConvGeom):
 
 
 class _PackEntry:
-    __slots__ = ("w0", "w1", "rows0", "geom", "p0", "p1", "versions", "last")
+    __slots__ = ("w0", "w1", "rows0", "geom", "p0", "p1", "versions", "used", "idle")
 
 
 class PackedWeights:
@@ -237,9 +257,11 @@ class PackedWeights:
     convolution and the torch.cat of each conv1|shortcut pair (0.5 ms of the 19 ms ResUNet step).  Under hipGraph
     capture the table launch is captured where it happens and replays with the step."""
 
+    MAX_IDLE = 8   # weight-change epochs an entry may go unused before it is dropped
+
     def __init__(self):
         self.entries = {}
-        self.tick = 0          # number of table launches so far
+        self.stale = False     # set after a hipGraph replay (the captured optimizer moved the weights unseen)
         self.table = None      # device copy of the cbim_pack_item array
         self.n_blocks = 0
         self.dirty_table = True
@@ -254,10 +276,9 @@ class PackedWeights:
         e = self.entries.get(key)
         if e is None or (need_dgrad and e.p1 is None):
             e = self._add(key, ws, geom, need_dgrad or (e is not None and e.p1 is not None))
-        e.last = self.tick
-        vers = tuple(w._version for w in ws)
-        if e.versions != vers:
-            self._repack_all()
+        e.used = True
+        if self.stale or e.versions != tuple(w._version for w in ws):
+            self._repack_all(new_only=e.versions is None and not self.stale)
         return e.p0, (e.p1 if need_dgrad else None)
 
     def _add(self, key, ws, geom, with_dgrad):
@@ -276,7 +297,7 @@ class PackedWeights:
         e.p1 = torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 1),), dtype=torch.uint8, device=dev) \
             if with_dgrad else None
         e.versions = None
-        e.last = self.tick
+        e.used, e.idle = True, 0
         self.entries[key] = e
         self.dirty_table = True
         return e
@@ -295,15 +316,24 @@ class PackedWeights:
         self.n_blocks = blk
         self.dirty_table = False
 
-    def _repack_all(self):
-        capturing = self.table is not None and self.table.is_cuda and torch.cuda.is_current_stream_capturing()
-        if not capturing:
-            # weights that no convolution asked for during the last 8 table launches belong to models that are gone
-            dead = [k for k, e in self.entries.items() if self.tick - e.last > 8]
+    def _repack_all(self, new_only=False):
+        dev0 = next(iter(self.entries.values())).p0
+        capturing = dev0.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing and not new_only:
+            # a weight CHANGED (optimizer step): entries no convolution asked for during the last 8 such epochs
+            # belong to models that are gone
+            dead = []
+            for k, e in self.entries.items():
+                e.idle = 0 if e.used else e.idle + 1
+                e.used = False
+                if e.idle > self.MAX_IDLE:
+                    dead.append(k)
             for k in dead:
                 del self.entries[k]
             self.dirty_table = self.dirty_table or bool(dead)
-        self.tick += 1
+        if capturing:
+            _hook_graph_replay()
+        self.stale = False
         if self.dirty_table:
             if self.table is not None and self.table.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("cbim_amd: a new convolution weight appeared during hipGraph capture; run one "
@@ -320,6 +350,25 @@ class PackedWeights:
 
 
 PACKED = PackedWeights()
+_REPLAY_HOOKED = False
+
+
+def _hook_graph_replay():
+    """Once a table launch has been captured into a hipGraph, every replay moves the weights (captured optimizer) and
+    re-packs them (captured table launch) without this module seeing a `_version` change: an EAGER convolution after a
+    replay (validation between graph-replayed epochs) must not trust the host-side versions.  torch offers no replay
+    callback, so CUDAGraph.replay is wrapped to flag the cache stale; the next eager lookup then re-packs once."""
+    global _REPLAY_HOOKED
+    if _REPLAY_HOOKED:
+        return
+    _REPLAY_HOOKED = True
+    orig = torch.cuda.CUDAGraph.replay
+
+    def replay(self):
+        orig(self)
+        PACKED.stale = True
+
+    torch.cuda.CUDAGraph.replay = replay
 
 
 def packed_weights(ws, geom: ConvGeom, need_dgrad: bool):

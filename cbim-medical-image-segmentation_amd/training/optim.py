@@ -132,6 +132,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self._fill_table()
         _lib.check(_lib.lib().cbim_adamw_ema_step(_p(self._table), _p(self._blk_tensor), _p(self._blk_chunk), self._nblocks,
                                                   _p(self._hyper), _stream(self._params[0])), "adamw_ema_step")
+        # the kernel wrote the parameters (and the EMA copies) through raw pointers: tell autograd / every cache keyed on
+        # Tensor._version (ops.PackedWeights: packed convolution weights) that they changed
+        torch.autograd.graph.increment_version(self._params)
+        if self._ema_params is not None:
+            torch.autograd.graph.increment_version([e for e in self._ema_active if e is not None])
         if self.ema_model is not None:          # training/utils.py:104-105 (no-op for the shipped nets: 0 buffers)
             for eb, mb in zip(self.ema_model.buffers(), self._model_buffers()):
                 eb.copy_(mb)

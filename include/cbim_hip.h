@@ -95,6 +95,11 @@ int cbim_maxpool3d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, 
  * ------------------------------------------------------------------------------------------ */
 int cbim_upcat_fwd(int dtype, const void* low, const void* skip, void* out, int N, int Dl, int Hl,
                    int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
+/* cbim_upcat_fwd + the InstanceNorm statistics (mean, rstd; eps) of its output in the same pass: partials float
+ * [N][P][Cs+Cl][3] with P = cbim_stats_parts(D*H*W, Cs+Cl), stats float [N][Cs+Cl][2]. */
+int cbim_upcat_fwd_stats(int dtype, const void* low, const void* skip, void* out, int N, int Dl, int Hl, int Wl,
+                         int Cl, int D, int H, int W, int Cs, int skip_first, float eps, float* partials, int P,
+                         float* stats, void* stream);
 int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dskip, int N, int Dl, int Hl,
                    int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
 
@@ -137,7 +142,8 @@ int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, int n_items,
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);
-/* Number of spatial tiles per sample = rows of the per-tile partial-sum buffer. */
+/* Records per sample of the partial-sum buffer `partials` (one per persistent workgroup, or per finish part when the
+ * launcher splits K). */
 int cbim_conv3d_num_tiles(const cbim_conv_desc* desc);
 /* y = conv(xform(x), w) [+ res];  xform(x) = act((x-mean)*rstd) when in_stats != NULL (zero
  * padding is applied AFTER the transform, conv_layers.py:48-49).  Optional epilogue:

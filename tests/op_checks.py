@@ -75,6 +75,11 @@ def check_upcat(dev, dtype, N=1, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_
     ref = torch.cat([skr, up] if skip_first else [up, skr], 1)
     out = ops.upcat_fwd(lol, skl, skip_first)
     assert relerr(from_cl(out.cpu()), ref.detach()) < tol(dtype, 2e-6, 8e-3)
+    # the fused variant: same tensor bit for bit + the InstanceNorm statistics of what was stored
+    out2, st2 = ops.upcat_fwd_stats(lol, skl, skip_first)
+    assert torch.equal(out2.cpu(), out.cpu())
+    st = ops.instnorm_stats(out)
+    assert relerr(st2.cpu()[..., 0], st.cpu()[..., 0]) < 1e-5 and relerr(st2.cpu()[..., 1], st.cpu()[..., 1]) < 1e-5
     g = torch.randn_like(ref)
     gl = to_cl(g, dtype).to(dev)
     ref.backward(from_cl(gl.cpu()))
