@@ -28,6 +28,7 @@
 // Replaces aten::convolution / convolution_backward(input) for nn.Conv3d in ConvNormAct
 // (conv_layers.py:29-38), stride 1, groups 1, bias-free; padding k//2 (unet_utils.py:13).
 #include "cbim_common.h"
+#include "conv_r32.h"
 #include <stdlib.h>
 
 namespace cbim {
@@ -56,6 +57,7 @@ struct IgemmParams {
   int n_chunks, taps;
   unsigned mHW, mW;                // ceil(2^20 / (hH*hW)), ceil(2^20 / hW): division by multiply
   int dbg;                         // timing ablations for tools/ (env CBIM_IGEMM_DBG); 0 in production
+  int P;                           // records per image of `partials` (cbim_conv3d_num_tiles)
   int ksplit;                      // > 1: blockIdx.z owns a slice of the Cin chunks, raw fp32 partials go to ws
   float* ws;                       // [ksplit][N*Do*Ho*Wo][Cout] fp32
 #ifdef CBIM_IGEMM_PROF
@@ -384,13 +386,18 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
   Moments run = {0.f, 0.f, 0.f};
   int run_n = cur.n;
   auto flush_partial = [&](int n, const Moments& m) {
-    const size_t o = (((size_t)n * gridDim.x + lb) * p.Cout + co0 + tid) * 3;
+    const size_t o = (((size_t)n * p.P + lb) * p.Cout + co0 + tid) * 3;
     p.partials[o] = m.n; p.partials[o + 1] = m.mean; p.partials[o + 2] = m.m2;
   };
   if (p.partials && p.ksplit == 1 && tid < BN && co0 + tid < p.Cout) {
     const int n_first = t_begin / tiles_per_n, n_last = (t_end - 1) / tiles_per_n;
-    for (int n = 0; n < p.N; ++n)
+    for (int n = 0; n < p.N; ++n) {
       if (n < n_first || n > n_last) flush_partial(n, Moments{0.f, 0.f, 0.f});
+      for (unsigned r = lb + gridDim.x; r < (unsigned)p.P; r += gridDim.x) {   // buffer sized for a larger grid
+        const size_t o = (((size_t)n * p.P + r) * p.Cout + co0 + tid) * 3;
+        p.partials[o] = 0.f; p.partials[o + 1] = 0.f; p.partials[o + 2] = 0.f;
+      }
+    }
   }
 
   // ---- prologue: first unit's halo and first stage of weights -----------------------------------------
@@ -973,6 +980,10 @@ extern "C" int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, i
 
 extern "C" int cbim_conv3d_tile_config(const cbim_conv_desc* d, int out[4]) {
   CBIM_CHECK(d && out, CBIM_EINVAL, "null argument");
+  if (cbim_conv_r32_eligible(d, nullptr, nullptr, nullptr, nullptr)) {   // (when the call has one input tensor) conv_r32.hip: 4 m-tiles per wave
+    out[0] = 4; out[1] = 1; out[2] = 8; out[3] = 8;
+    return CBIM_OK;
+  }
   TileCfg c = pick_cfg(d);
   out[0] = c.MT; out[1] = c.NTL; out[2] = c.tD; out[3] = c.tH;
   return CBIM_OK;
@@ -990,7 +1001,10 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   if (!d) return 0;
   TileCfg c = pick_cfg(d);
   if (pick_ksplit(d, c) > 1) return finish_parts((int64_t)d->Do * d->Ho * d->Wo);
-  return (int)igemm_grid_x(d, c);   // one record per (image, persistent workgroup)
+  int64_t g = igemm_grid_x(d, c);   // one record per (image, persistent workgroup)
+  // the same layer may run on conv_r32.hip (8x8x8 tiles whatever pick_cfg says): room for either grid
+  if (cbim_conv_r32_eligible(d, nullptr, nullptr, nullptr, nullptr) && cbim_conv_r32_grid(d) > g) g = cbim_conv_r32_grid(d);
+  return (int)g;
 }
 
 template <typename T, int MT, int NTL, int ACT, bool K3, int NTH = 512>
@@ -1048,6 +1062,9 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   if (int e = validate(d)) return e;
   CBIM_CHECK(x && w_packed && y, CBIM_EINVAL, "null tensor");
   CBIM_CHECK(!mask_x || mask_stats, CBIM_EINVAL, "mask_x needs mask_stats");
+  if (cbim_conv_r32_eligible(d, x2, in_stats, res, mask_x))   // Cin = 32 -> Cout <= 32 at full resolution: weights in registers
+    return cbim_conv_r32_launch(d, x, x_stride, in_stats, w_packed, res, res_stride, mask_x, mask_stride, mask_stats, y,
+                                y_stride, partials, stream);
   TileCfg c = pick_cfg(d);
   IgemmParams p;
   p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.w = w_packed;
@@ -1095,6 +1112,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   int n_nblk = (d->Cout + BN - 1) / BN;
   const int64_t G = igemm_grid_x(d, c);
   (void)n_tiles;
+  p.P = cbim_conv3d_num_tiles(d);
   p.ksplit = pick_ksplit(d, c);
   p.ws = (float*)workspace;
   if (p.ksplit > 1) {

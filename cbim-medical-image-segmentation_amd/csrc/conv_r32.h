@@ -1,0 +1,31 @@
+// conv_r32.h — internal interface of the "weights in registers" 3x3x3 kernel (conv_r32.hip), used by the
+// cbim_conv3d_igemm launcher (conv_igemm.hip).  Not part of the C ABI.
+#pragma once
+#include <stdint.h>
+#include "../../include/cbim_hip.h"
+
+namespace cbim {
+struct R32Params {
+  const void* x; int64_t x_stride; const float* in_stats;
+  const void* w;
+  const void* res; int64_t res_stride;
+  const void* mx; int64_t mx_stride; const float* m_stats;
+  void* y; int64_t y_stride;
+  float* partials;
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cout;
+  int pD, pH, pW, act;
+  int tiles_d, tiles_h, tiles_w;
+  int dbg; // timing ablations for tools/ (env CBIM_R32_DBG); 0 in production
+  int P;   // records per image of `partials` (cbim_conv3d_num_tiles)
+};
+}  // namespace cbim
+
+// bf16, 3x3x3, Cin == 32 (one input tensor), Cout <= 32, >= 64^3 output voxels
+bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, const float* in_stats, const void* res,
+                            const void* mask_x);
+// persistent grid = records per image of the statistics partials (equals the k_conv_igemm count for these shapes)
+int64_t cbim_conv_r32_grid(const cbim_conv_desc* d);
+int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats,
+                         const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
+                         int64_t mask_stride, const float* mask_stats, void* y, int64_t y_stride, float* partials,
+                         void* stream);

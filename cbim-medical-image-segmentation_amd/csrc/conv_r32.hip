@@ -1,0 +1,537 @@
+// conv_r32.hip — 3x3x3 convolution (forward and dgrad) for the single-chunk layers Cin = 32 -> Cout <= 32 (bf16),
+// the layers that own half of the ResUNet's FLOPs at full resolution (32 -> 32 @ 128^3, conv_layers.py:71-94 with
+// base_ch 32, unet.py:22,44): "weights in registers".
+//
+// Why a second kernel: k_conv_igemm<2,1> ran these layers at 19 % of the MFMA peak.  With N = 32 every A fragment
+// feeds ONE MFMA, so the LDS fragment traffic (3 ds_read_b128 per 2 MFMAs) plus halo stores and the transposing
+// epilogue saturate the LDS pipe, and every phase (halo load, transform, weight stage, epilogue) is serialised by
+// workgroup barriers.  Here
+//   * the layer's weights stay in REGISTERS for the life of the persistent workgroup — no weight staging, no stage
+//     barriers, ONE barrier per tile.  To fit two waves per SIMD (256 VGPRs each; a first version with one 512-register
+//     wave per SIMD was instruction-issue bound: 2 700 vector-ALU instructions per 216 MFMAs) the matrix product runs
+//     on v_mfma_f32_16x16x32_bf16: a wave owns 16 of the 32 output channels, its 27 weight fragments (K = all 32 input
+//     channels in one instruction) are 108 VGPRs;
+//   * a wave owns 8 n-tiles STACKED ALONG D (a 2x8 (h,w) patch of 16 voxels on each of the tile's 8 planes): the
+//     fragment of input plane i serves (n-tile i, kd 0), (n-tile i-1, kd 1) and (n-tile i-2, kd 2), so per (kh,kw)
+//     10 fragment reads feed 24 MFMAs; reads stream through a small register ring, plane-major;
+//   * the halo (10x10x10 rows x 64 B) is DOUBLE buffered in LDS (2 x 64 KiB): the next tile's halo is fetched while
+//     this tile computes — by LDS-DMA (global_load_lds_dwordx4, no registers, no VALU) when the input is used as
+//     it is (dgrad, or a raw convolution), through registers with InstanceNorm + activation applied on the way
+//     (pre-activation ConvNormAct, conv_layers.py:48-49; zero padding after the transform) otherwise; the per-item
+//     work is spread over the (kh,kw) steps of the MFMA loop;
+//   * the MFMA operands are swapped (A = weights, B = voxels), so an accumulator holds 4 output channels of ONE voxel
+//     per lane: one v_permlane16_swap per register between two n-tiles leaves every lane with a whole 16-byte
+//     channel chunk of one voxel — residual add, act' mask, statistics and the store need no LDS transpose; the
+//     per-channel statistics are per-lane running sums, combined across lanes once per workgroup.
+// Same C ABI entry (cbim_conv3d_igemm picks this kernel when the layer qualifies), same packed-weight layout, same
+// partial-record format as conv_igemm.hip.
+#include "cbim_common.h"
+#include "conv_r32.h"
+#include <stdlib.h>
+
+namespace cbim {
+
+static constexpr int R_NT = 512;
+static constexpr int R_NW = 8;
+static constexpr int R_RB = 64;                 // bytes per halo row (32 bf16 channels)
+static constexpr int R_HROWS = 1000;            // 10 x 10 x 10
+static constexpr unsigned R_HBUF = 65536;       // one halo buffer (64000 B used; items 4000..4095 are padding)
+static constexpr int R_UH = 8;                  // 16-byte halo items per thread (4096 / 512)
+
+__device__ __attribute__((aligned(64))) unsigned int g_r32_zero[16];   // source of padding rows for the LDS-DMA
+
+typedef __attribute__((ext_vector_type(4))) float r_f32x4;
+
+#ifdef CBIM_EMU
+#define R_SCHED_FENCE() ((void)0)
+#define R_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
+#else
+#define R_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define R_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+__device__ __forceinline__ void r_dma16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
+#ifdef CBIM_EMU
+  emu_global_load_lds16(gsrc, lds_wave_base);
+#else
+  // inline asm on purpose (conv_igemm.hip dma16): the compiler must not treat LGKM as out of order
+  unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+  a = __builtin_amdgcn_readfirstlane(a);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc) : "memory", "m0");
+#endif
+}
+__device__ __forceinline__ void r_wait_vm0() {
+#ifndef CBIM_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ unsigned r_launder(unsigned v) {
+#ifndef CBIM_EMU
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+__device__ __forceinline__ unsigned r_mul24(unsigned a, unsigned b) {
+#ifdef CBIM_EMU
+  return a * b;
+#else
+  return __umul24(a, b);
+#endif
+}
+// XOR key of the 16-byte slot inside halo row (hd, hh, hw): a ds_read_b128 lane group of the B-fragment read covers the
+// two h rows of the wave's patch and two k-groups; keys 0 / 2 on alternating rows give it 16 distinct cells of the
+// 256-byte bank window (key hh & 3, right for the 4-row patches of conv_igemm.hip, measured 37 % conflict cycles here)
+__device__ __forceinline__ unsigned r_swz(unsigned hh) { return (hh & 1u) << 1; }
+// exchange between 16-lane rows: a's odd rows (lanes 16..31, 48..63) <-> b's even rows (lanes 0..15, 32..47)
+// (v_permlane16_swap_b32)
+__device__ __forceinline__ void r_swap16(float& a, float& b) {
+#ifdef CBIM_EMU
+  struct P { float a, b; } mine = {a, b};
+  const P* buf = (const P*)cbim_emu::wave_exchange(&mine, sizeof(P));
+  const int l = CBIM_EMU_LANE_ID();
+  if (l & 16) a = buf[l - 16].b;
+  else b = buf[l + 16].a;
+#else
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x);
+  b = __uint_as_float(r.y);
+#endif
+}
+
+// TR: the input is transformed (InstanceNorm + ACT) on its way into LDS (register path); !TR: LDS-DMA
+// MX: dgrad epilogue (x act'(xh) mask + the two InstanceNorm-backward sums); !MX: forward epilogue (moments)
+template <int ACT, bool TR, bool MX>
+__global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
+  R_DYN_SMEM(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lv = lane & 15, lq = lane >> 4;
+  const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+  const int n_tiles = p.N * tiles_per_n;
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int t_begin = (int)(((long long)lb * n_tiles) / gridDim.x);
+  const int t_end = (int)(((long long)(lb + 1) * n_tiles) / gridDim.x);
+  if (t_begin >= t_end) return;
+  const unsigned red_base = 2 * R_HBUF;                     // [R_NW][16][3] floats
+  const unsigned mst_base = red_base + R_NW * 16 * 3 * 4;   // MX: (mean, rstd) of the 32 mask channels, 256 B
+  const unsigned ist_base = mst_base + 256;                 // TR: (mean, rstd) of the 32 input channels, 256 B
+
+  // ---- wave = (cout half ch, voxel group vg); lane = (voxel lv of a 2x8 patch, k-group / row-group lq) -----------
+  const int ch = wave & 1, vg = wave >> 1;
+  const int tw = lv & 7, th = 2 * vg + (lv >> 3);
+  // weights: fragment of tap tp = A operand [16 couts][32 channels]: lane (cout lv, channels 8*lq..+7) = 16 bytes of
+  // the packed image [tap][kg = lq>>1][half = lq&1][32 couts][8]
+  u32x4 wf[27];
+  {
+    const unsigned char* wp = (const unsigned char*)p.w + (unsigned)((lq * 32) + 16 * ch + lv) * 16;
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) wf[tp] = *(const u32x4*)(wp + (unsigned)(tp * 4 * 32) * 16);
+#ifndef CBIM_EMU
+    // The compiler tracks these loads as possibly pending at the loop back-edge and guards the first MFMA of every tile
+    // with s_waitcnt vmcnt(1) — which, with the LDS-DMA pieces it cannot see in flight, waits for the DMA to land.
+    // Passing the registers through an empty asm makes it wait once, here, and forget the loads.
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) asm volatile("" : "+v"(wf[tp]));
+#endif
+  }
+  // B operand (voxels): fragment of plane i at tap (kh, kw) = 16 bytes at row (i, th + kh, tw + kw), slot
+  // lq ^ r_swz(th + kh); base per kh, plane and kw are immediates (i * 6400 + kw * 64)
+  unsigned fb[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+    fb[kh] = (unsigned)((th + kh) * 10 + tw) * R_RB + (((unsigned)lq ^ r_swz((unsigned)(th + kh))) << 4);
+
+  // ---- halo items of this thread (the same for every tile): position inside the 10x10x10 box --------------------
+  // LDS-DMA item q = tid + 512 u is PHYSICAL (LDS byte q*16 = row q>>2, slot q&3), source slot = (q&3) ^ r_swz(hh);
+  // the in-place transform of the TR path takes item q as LOGICAL (row q>>2, channel chunk q&3 = tid&3)
+  // The position is decoded per tile from the laundered thread index (~10 VALU per item) instead of living in
+  // registers next to the weights.
+  auto item_pos = [&](unsigned tl, int u) -> unsigned {   // hd | hh << 8 | hw << 16 | exists << 24
+    const unsigned row = (tl + 512u * (unsigned)u) >> 2;
+    const unsigned hd = (row * 5243u) >> 19;              // row / 100 for row < 1024
+    const unsigned r2 = row - hd * 100u;
+    const unsigned hh = (r2 * 205u) >> 11;                // r2 / 10 for r2 < 100
+    const unsigned hw = r2 - hh * 10u;
+    return hd | (hh << 8) | (hw << 16) | (row < (unsigned)R_HROWS ? 1u << 24 : 0u);
+  };
+  const unsigned my_slot = (unsigned)tid & 3u;
+
+  struct TilePos { int n, td, th, tw; };
+  auto advance = [&](TilePos& u) {
+    if (++u.tw == p.tiles_w) { u.tw = 0; if (++u.th == p.tiles_h) { u.th = 0; if (++u.td == p.tiles_d) { u.td = 0; ++u.n; } } }
+  };
+  TilePos cur, nxt;
+  {
+    const int tt = t_begin % tiles_per_n;
+    cur.n = t_begin / tiles_per_n; cur.td = tt / (p.tiles_w * p.tiles_h); cur.th = (tt / p.tiles_w) % p.tiles_h; cur.tw = tt % p.tiles_w;
+    nxt = cur;
+    advance(nxt);
+  }
+
+  const unsigned x_sb = (unsigned)p.x_stride * 2u;
+  // source address of halo item u of tile `tp` (in range: the tensor; padding: 64 zero bytes) ---------------------
+  struct Src { const unsigned char* ptr; bool ld; unsigned pk; };
+  auto item_src = [&](const TilePos& tp, int u) -> Src {
+    const int id0 = tp.td * 8 - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
+    const long long org = (((long long)tp.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0;
+    const unsigned char* tbase = (const unsigned char*)p.x + org * (long long)x_sb;   // wave-uniform
+    const unsigned pk = item_pos(r_launder((unsigned)tid), u);
+    const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
+    const bool ld = !(p.dbg & 1) && (pk >> 24) != 0 && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
+                    (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
+    const unsigned rel = r_mul24(r_mul24(hd, (unsigned)p.Hi) + hh, (unsigned)p.Wi) + hw;
+    const unsigned slot = my_slot ^ r_swz(hh);
+    const unsigned off = ld ? r_mul24(rel, x_sb) + slot * 16u : 0u;
+    Src r;
+    r.ptr = (ld ? tbase : (const unsigned char*)g_r32_zero) + off;
+    r.ld = ld;
+    r.pk = pk;
+    return r;
+  };
+  // DMA path: item u of tile `tp` into LDS buffer `buf` (an asynchronous 1 KiB piece per wave)
+  auto dma_item = [&](const TilePos& tp, int u, unsigned buf) {
+    const Src sr = item_src(tp, u);
+    r_dma16(sr.ptr, smem + buf + (unsigned)(wave * 64 + 512 * u) * 16);
+  };
+  // TR path: the raw halo arrives by the same LDS-DMA; once it has landed (workgroup barrier) every thread transforms
+  // its 8 items IN PLACE (ds_read_b128 -> InstanceNorm + activation -> ds_write_b128), item = (row, logical channel
+  // chunk tid & 3) so the chunk's statistics are one 64-byte row of a 256-byte LDS table.  Padding rows stay zero.
+  auto tr_xform = [&](const TilePos& tp, int u, unsigned buf) {
+    const int id0 = tp.td * 8 - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
+    const unsigned pk = item_pos(r_launder((unsigned)tid), u);
+    const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
+    const bool ld = (pk >> 24) != 0 && (unsigned)(id0 + (int)hd) < (unsigned)p.Di && (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi &&
+                    (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
+    if (ld) {
+      const unsigned row = ((unsigned)tid + 512u * (unsigned)u) >> 2;
+      unsigned char* cell = smem + buf + row * R_RB + ((my_slot ^ r_swz(hh)) << 4);
+      float f[8];
+      Elem<bf16_tag>::unpack(*(const u32x4*)cell, f);
+      const float* is = (const float*)(smem + ist_base) + my_slot * 16;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const f32x4 q4 = *(const f32x4*)(is + 2 * j);   // (mean, rstd) of channels j, j+1
+        const float x0 = (f[j] - q4.x) * q4.y, x1 = (f[j + 1] - q4.z) * q4.w;
+        f[j] = ACT == CBIM_ACT_RELU ? (x0 > 0.f ? x0 : 0.f) : (ACT == CBIM_ACT_NONE ? x0 : act_fwd(x0, p.act));
+        f[j + 1] = ACT == CBIM_ACT_RELU ? (x1 > 0.f ? x1 : 0.f) : (ACT == CBIM_ACT_NONE ? x1 : act_fwd(x1, p.act));
+      }
+      *(u32x4*)cell = Elem<bf16_tag>::pack(f);
+    }
+  };
+
+  // ---- per-lane statistics: after the epilogue exchange a lane owns channel chunk cidx = 2*ch + (lq >> 1) -------
+  const int cidx = 2 * ch + (lq >> 1);
+  const bool c_ok = cidx * 8 < p.Cout;
+  float s0[8], s1[8], sh[MX ? 1 : 8];
+  float cnt = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; sh[MX ? 0 : j] = 0.f; }
+  int run_n = cur.n;
+  const bool want_part = p.partials != nullptr;
+  // combine the lanes' sums of image n into this workgroup's record and reset them (all threads call it)
+  auto flush_stats = [&](int n) {
+    __syncthreads();
+    float* red = (float*)(smem + red_base);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      Moments a;
+      if (MX) { a.n = 0.f; a.mean = s0[j]; a.m2 = s1[j]; }
+      else a = moments_from_shifted(cnt, sh[MX ? 0 : j], s0[j], s1[j]);
+#pragma unroll
+      for (int msk = 1; msk < 32; msk <<= 1) {   // lanes differing in bits 0..4 (voxel, lq & 1) hold the same channels
+        Moments b;
+        b.n = __shfl_xor(a.n, msk, 64); b.mean = __shfl_xor(a.mean, msk, 64); b.m2 = __shfl_xor(a.m2, msk, 64);
+        if (MX) { a.mean += b.mean; a.m2 += b.m2; }
+        else a = (lane & msk) == 0 ? moments_merge(a, b) : moments_merge(b, a);   // same operand order in both lanes
+      }
+      if ((lane & 31) == 0) {
+        float* rr = red + ((wave * 16) + (lq >> 1) * 8 + j) * 3;
+        rr[0] = a.n; rr[1] = a.mean; rr[2] = a.m2;
+      }
+      s0[j] = 0.f; s1[j] = 0.f; sh[MX ? 0 : j] = 0.f;
+    }
+    cnt = 0.f;
+    __syncthreads();
+    if (tid < 32 && tid < p.Cout) {
+      Moments a = {0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) {   // the four voxel groups of this channel's cout half
+        const float* rr = red + (((2 * g + (tid >> 4)) * 16) + (tid & 15)) * 3;
+        if (MX) { a.mean += rr[1]; a.m2 += rr[2]; }
+        else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
+      }
+      const size_t o = (((size_t)n * p.P + lb) * p.Cout + tid) * 3;
+      p.partials[o] = a.n; p.partials[o + 1] = a.mean; p.partials[o + 2] = a.m2;
+    }
+  };
+  if (want_part && tid < 32 && tid < p.Cout) {
+    // empty records (n = 0 merges as the identity): images this strip does not touch, and the records lb + k * grid
+    // of a buffer sized for more workgroups than this launch has (p.P = cbim_conv3d_num_tiles records per image)
+    const int n_first = t_begin / tiles_per_n, n_last = (t_end - 1) / tiles_per_n;
+    for (int n = 0; n < p.N; ++n)
+      for (unsigned r = lb; r < (unsigned)p.P; r += gridDim.x)
+        if (r != lb || n < n_first || n > n_last) {
+          const size_t o = (((size_t)n * p.P + r) * p.Cout + tid) * 3;
+          p.partials[o] = 0.f; p.partials[o + 1] = 0.f; p.partials[o + 2] = 0.f;
+        }
+  }
+  // (mean, rstd) tables in LDS: the mask tensor's channels (MX) / the input's channels (TR); refreshed at an image
+  // change, always followed by a workgroup barrier before they are read
+  int mst_n = -1, ist_n = -1;
+  auto load_mstats = [&](int n) {
+    if (MX && n != mst_n) {
+      if (tid < 64) {
+        const int c = tid >> 1;
+        ((float*)(smem + mst_base))[tid] = c < p.Cout ? p.m_stats[((size_t)n * p.Cout + c) * 2 + (tid & 1)] : (float)(tid & 1);
+      }
+      mst_n = n;
+    }
+  };
+  auto load_istats = [&](int n) {
+    if (TR && n != ist_n) {
+      if (tid < 64) ((float*)(smem + ist_base))[tid] = p.in_stats[(size_t)n * 64 + tid];
+      ist_n = n;
+    }
+  };
+
+  // ---- prologue: first tile's halo ---------------------------------------------------------------------------------
+  load_mstats(cur.n);
+  load_istats(cur.n);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < R_UH; ++u) dma_item(cur, u, 0);
+  r_wait_vm0();
+  __syncthreads();
+  if (TR) {
+#pragma unroll
+    for (int u = 0; u < R_UH; ++u) tr_xform(cur, u, 0);
+    __syncthreads();
+  }
+
+  r_f32x4 acc[8];
+  const int n_my = t_end - t_begin;
+  for (int t = 0; t < n_my; ++t) {
+    const unsigned buf = (unsigned)(t & 1) * R_HBUF, obuf = R_HBUF - buf;
+    const bool more = t + 1 < n_my;
+    // the next tile's transforms run during THIS tile: at an image change the statistics table is rewritten first (no
+    // reader is active here: the previous tile's transforms ended before its barrier)
+    if (TR && more && nxt.n != ist_n) { load_istats(nxt.n); __syncthreads(); }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) acc[nt] = r_f32x4{0.f, 0.f, 0.f, 0.f};
+    // (B) 9 (kh, kw) steps: the 10 plane fragments stream through a ring of 5 registers, plane i feeds the MFMAs
+    //     (n-tile i, kd 0), (i-1, kd 1), (i-2, kd 2).  One halo item of the next tile is handled per step: DMA item
+    //     s is issued at step s; TR item s is loaded at step s and transformed + stored at step s+1.
+    if (!(p.dbg & 2)) {
+      constexpr int RING = 5;
+      u32x4 xr[RING];
+#pragma unroll
+      for (int i = 0; i < RING - 1; ++i) xr[i] = *(const u32x4*)(smem + buf + fb[0] + (unsigned)(i * 100 * R_RB));
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        const int kh = s / 3, kw = s % 3;
+        const unsigned base = buf + fb[kh] + (unsigned)(kw * R_RB);
+        const unsigned base_n = buf + fb[(s + 1) / 3 % 3] + (unsigned)(((s + 1) % 3) * R_RB);
+        // the next tile's halo: LDS-DMA pieces during the first steps; TR: after a mid-tile barrier (all pieces
+        // landed) the in-place transform runs under the MFMAs of the last three steps
+        if (more) {
+          if (TR) {
+            if (s < 4) { dma_item(nxt, 2 * s, obuf); dma_item(nxt, 2 * s + 1, obuf); }
+            if (s == 6) { r_wait_vm0(); __syncthreads(); }
+            if (s >= 6) {
+#pragma unroll
+              for (int u = 3 * (s - 6); u < 3 * (s - 6) + 3; ++u)
+                if (u < R_UH) tr_xform(nxt, u, obuf);
+            }
+          } else if (s < R_UH) {
+            dma_item(nxt, s, obuf);
+          }
+        }
+        // plane i+4 (of this step, or of the next one: the ring runs across steps) is requested before the MFMAs of
+        // plane i issue; the fences keep the compiler from sinking the read next to its use (it then waits a full LDS
+        // round trip every third MFMA: measured 57 % of the MFMA rate)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          const int j = i + RING - 1;
+          if (j < 10) xr[j % RING] = *(const u32x4*)(smem + base + (unsigned)(j * 100 * R_RB));
+          else if (s + 1 < 9) xr[j % RING] = *(const u32x4*)(smem + base_n + (unsigned)((j - 10) * 100 * R_RB));
+          R_SCHED_FENCE();
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd) {
+            const int nt = i - kd;
+            if (nt >= 0 && nt < 8)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[(kd * 3 + kh) * 3 + kw]),
+                                                                __builtin_bit_cast(bf16x8, xr[i % RING]), acc[nt], 0, 0, 0);
+          }
+          R_SCHED_FENCE();
+        }
+      }
+    }
+    // (D) ONE barrier per tile: every wave is done with `buf`, the other buffer is complete (own LDS-DMA waited for,
+    //     LDS stores drained)
+    load_mstats(cur.n);
+    r_wait_vm0();
+    __syncthreads();
+    // (C) epilogue of this tile — no barrier inside (except at an image change); its stores drain under the next
+    //     tile's MFMAs
+    if (!(p.dbg & 4)) {
+      const int n = cur.n;
+      if (want_part && n != run_n) { flush_stats(run_n); run_n = n; }
+      const int od0 = cur.td * 8, oh0 = cur.th * 8, ow0 = cur.tw * 8;
+      const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
+      const unsigned y_sb = (unsigned)p.y_stride * 2u, res_sb = (unsigned)p.res_stride * 2u, mx_sb = (unsigned)p.mx_stride * 2u;
+      unsigned char* y_tile = (unsigned char*)p.y + orow * (long long)y_sb;
+      const unsigned char* res_tile = (const unsigned char*)p.res + orow * (long long)res_sb;
+      const unsigned char* mx_tile = (const unsigned char*)p.mx + orow * (long long)mx_sb;
+      const bool hw_ok = oh0 + th < p.Ho && ow0 + tw < p.Wo;
+      // after the exchange this lane owns, for the plane pair (2pp, 2pp+1), chunk cidx of voxel (2pp + (lq&1), th, tw)
+      const unsigned rel0 = r_mul24(r_mul24((unsigned)(lq & 1), (unsigned)p.Ho) + (unsigned)th, (unsigned)p.Wo) + (unsigned)tw;
+      const unsigned plane2 = 2u * r_mul24((unsigned)p.Ho, (unsigned)p.Wo);
+      const unsigned cb = (unsigned)cidx * 16u;
+      u32x4 rq[2];
+      auto ep_load = [&](int pp, u32x4& q) {
+        const bool in = hw_ok && od0 + 2 * pp + (lq & 1) < p.Do && c_ok && !(p.dbg & 8);
+        const unsigned rel = rel0 + (unsigned)pp * plane2;
+        q = u32x4{0u, 0u, 0u, 0u};
+        if (in) {
+          if (MX) q = *(const u32x4*)(mx_tile + (r_mul24(rel, mx_sb) + cb));
+          else if (p.res) q = *(const u32x4*)(res_tile + (r_mul24(rel, res_sb) + cb));
+        }
+      };
+      ep_load(0, rq[0]);
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        if (pp + 1 < 4) ep_load(pp + 1, rq[(pp + 1) & 1]);
+        const bool in = hw_ok && od0 + 2 * pp + (lq & 1) < p.Do;
+        const unsigned rel = rel0 + (unsigned)pp * plane2;
+        // accumulator register r of n-tile nt = channel 16*ch + 4*lq + r of voxel (plane nt, th, tw).  Swapping the
+        // registers of n-tile 2pp in the odd 16-lane rows with those of n-tile 2pp+1 in the even rows leaves the lane
+        // with 8 consecutive channels (chunk cidx) of ONE voxel: plane 2pp (lq even) / 2pp+1 (lq odd)
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = acc[2 * pp][r], b = acc[2 * pp + 1][r];
+          r_swap16(a, b);
+          v[r] = a;
+          v[4 + r] = b;
+        }
+        float f[8];
+        Elem<bf16_tag>::unpack(rq[pp & 1], f);
+        if (MX) {
+          const float* ms = (const float*)(smem + mst_base) + cidx * 16;
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const f32x4 q4 = *(const f32x4*)(ms + 2 * j);   // (mean, rstd) of channels j, j+1
+            const float xh0 = (f[j] - q4.x) * q4.y, xh1 = (f[j + 1] - q4.z) * q4.w;
+            const float g0 = ACT == CBIM_ACT_RELU ? (xh0 > 0.f ? 1.f : 0.f) : (ACT == CBIM_ACT_NONE ? 1.f : act_grad(xh0, p.act));
+            const float g1 = ACT == CBIM_ACT_RELU ? (xh1 > 0.f ? 1.f : 0.f) : (ACT == CBIM_ACT_NONE ? 1.f : act_grad(xh1, p.act));
+            v[j] *= g0;
+            v[j + 1] *= g1;
+            if (in && c_ok) {
+              s0[j] += v[j]; s1[j] += v[j] * xh0;
+              s0[j + 1] += v[j + 1]; s1[j + 1] += v[j + 1] * xh1;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += f[j];     // residual (zeros when there is none)
+          if (in && c_ok && want_part) {
+            if (cnt == 0.f) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) sh[MX ? 0 : j] = v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[j] - sh[MX ? 0 : j]; s0[j] += d; s1[j] += d * d; }
+          }
+        }
+        if (in && c_ok && !(p.dbg & 16)) *(u32x4*)(y_tile + (r_mul24(rel, y_sb) + cb)) = Elem<bf16_tag>::pack(v);
+        if (in) cnt += 1.f;
+      }
+    }
+    cur = nxt;
+    advance(nxt);
+  }
+  if (want_part) flush_stats(run_n);
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+static int64_t g_r32_min_voxels = 262144;   // same threshold as the 8x8x8 tile configuration of k_conv_igemm
+
+bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, const float* in_stats, const void* res,
+                            const void* mask_x) {
+  static const int on = getenv("CBIM_CONV_R32") ? atoi(getenv("CBIM_CONV_R32")) : 1;
+  if (!on || d->dtype != CBIM_BF16 || x2) return false;
+  if (d->kD != 3 || d->kH != 3 || d->kW != 3 || d->Cin != 32 || d->Cout > 32) return false;
+  if (d->Do < 8 || d->Ho < 8 || d->Wo < 8) return false;
+  if (!(d->act == CBIM_ACT_RELU || d->act == CBIM_ACT_NONE)) return false;
+  if (mask_x && (in_stats || res)) return false;   // masked epilogue: raw input, no accumulate tensor
+  // at least ~2 tiles per CU, like the 8x8x8 configuration of k_conv_igemm
+  const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
+  return S >= g_r32_min_voxels;
+}
+
+extern "C" int64_t cbim_conv_r32_min_voxels(int64_t v) {
+  const int64_t old = g_r32_min_voxels;
+  if (v >= 0) g_r32_min_voxels = v;
+  return old;
+}
+
+int64_t cbim_conv_r32_grid(const cbim_conv_desc* d) {
+  const int64_t n_tiles = (int64_t)d->N * ((d->Do + 7) / 8) * ((d->Ho + 7) / 8) * ((d->Wo + 7) / 8);
+  return n_tiles < 256 ? n_tiles : 256;
+}
+
+template <int ACT, bool TR, bool MX>
+static int r32_launch(const R32Params& p, dim3 grid, size_t smem, hipStream_t st) {
+#ifndef CBIM_EMU
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv3_r32<ACT, TR, MX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+#endif
+  CBIM_LAUNCH((k_conv3_r32<ACT, TR, MX>), grid, dim3(R_NT), smem, st, p);
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv r32 launch: %s", hipGetErrorString(e));
+  return CBIM_OK;
+}
+
+int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats,
+                         const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
+                         int64_t mask_stride, const float* mask_stats, void* y, int64_t y_stride, float* partials,
+                         void* stream) {
+  R32Params p;
+  p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.w = w_packed;
+  p.res = res; p.res_stride = res_stride; p.mx = mask_x; p.mx_stride = mask_stride; p.m_stats = mask_stats;
+  p.y = y; p.y_stride = y_stride; p.partials = partials;
+  p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.pD = d->pD; p.pH = d->pH; p.pW = d->pW; p.act = d->act;
+  p.tiles_d = (d->Do + 7) / 8; p.tiles_h = (d->Ho + 7) / 8; p.tiles_w = (d->Wo + 7) / 8;
+  { const char* e = getenv("CBIM_R32_DBG"); p.dbg = e ? atoi(e) : 0; }   // tools/r32_ablate.py timing ablations; 0 in production
+  p.P = cbim_conv3d_num_tiles(d);
+  CBIM_CHECK(!partials || p.P >= (int)cbim_conv_r32_grid(d), CBIM_EINVAL, "conv r32: %d partial records < grid", p.P);
+  {
+    // 32-bit byte offsets inside one halo box / one output tile, built from 24-bit multiplies
+    const int64_t box_rows = (int64_t)10 * d->Hi * d->Wi, xs = x_stride * 2;
+    CBIM_CHECK(box_rows < (1 << 24) && xs < (1 << 24) && box_rows * xs < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
+               "conv r32: input plane %dx%d with row stride %lld B exceeds the 32-bit halo addressing", d->Hi, d->Wi, (long long)xs);
+    const int64_t tile_rows = (int64_t)8 * d->Ho * d->Wo;
+    int64_t so = y_stride * 2;
+    if (res && res_stride * 2 > so) so = res_stride * 2;
+    if (mask_x && mask_stride * 2 > so) so = mask_stride * 2;
+    CBIM_CHECK(tile_rows < (1 << 24) && so < (1 << 24) && tile_rows * so < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
+               "conv r32: output plane %dx%d with row stride %lld B exceeds the 32-bit epilogue addressing", d->Ho, d->Wo, (long long)so);
+  }
+  const size_t smem = 2 * (size_t)R_HBUF + (size_t)R_NW * 16 * 3 * sizeof(float) + 256 + 256;
+  dim3 grid((unsigned)cbim_conv_r32_grid(d));
+  hipStream_t st = (hipStream_t)stream;
+  const bool relu = d->act == CBIM_ACT_RELU;
+  // (eligibility: act is ReLU or none; a transformed input comes with the forward epilogue, a mask with an input
+  //  that is used as it is — the four combinations the pre-activation blocks produce)
+  if (in_stats) return relu ? r32_launch<CBIM_ACT_RELU, true, false>(p, grid, smem, st) : r32_launch<CBIM_ACT_NONE, true, false>(p, grid, smem, st);
+  if (mask_x) return relu ? r32_launch<CBIM_ACT_RELU, false, true>(p, grid, smem, st) : r32_launch<CBIM_ACT_NONE, false, true>(p, grid, smem, st);
+  return r32_launch<CBIM_ACT_NONE, false, false>(p, grid, smem, st);
+}
+
+CBIM_DEFINE_WARM(r32)

@@ -134,9 +134,16 @@ __global__ void __launch_bounds__(NT) k_dice_ce_finalize(const float* __restrict
   {   // 4 thread groups stride over the workgroup partials (independent loads in flight), fixed-order merge
     const int li = threadIdx.x & 63, pg = threadIdx.x >> 6;
     for (int i = li; i < nv; i += 64) {
-      double a = 0.0;
-      for (int b = pg; b < nblk; b += 4) a += (double)partials[(size_t)b * nv + i];
-      part[pg][i] = a;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // 4 loads in flight per trip
+      int b = pg;
+      for (; b + 12 < nblk; b += 16) {
+        a0 += (double)partials[(size_t)b * nv + i];
+        a1 += (double)partials[(size_t)(b + 4) * nv + i];
+        a2 += (double)partials[(size_t)(b + 8) * nv + i];
+        a3 += (double)partials[(size_t)(b + 12) * nv + i];
+      }
+      for (; b < nblk; b += 4) a0 += (double)partials[(size_t)b * nv + i];
+      part[pg][i] = (a0 + a1) + (a2 + a3);
     }
   }
   __syncthreads();
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(NT) k_dice_ce_bwd(const float* __restrict__ z,
 
 static int loss_blocks(int64_t total) {
   int64_t b = (total + NT * 8 - 1) / (NT * 8);   // upper bound over the vector widths (groups <= total)
-  if (b > 1024) b = 1024;   // the finalize kernel walks these partials with 4 thread groups
+  if (b > 256) b = 256;     // one workgroup per CU; the single-workgroup finalize kernel walks these records
   if (b < 1) b = 1;
   return (int)b;
 }

@@ -479,6 +479,7 @@ extern "C" int cbim_warm_optim(void* stream);
 extern "C" int cbim_warm_inference(void* stream);
 extern "C" int cbim_warm_attn_mfma(void* stream);
 extern "C" int cbim_warm_attn_wide(void* stream);
+extern "C" int cbim_warm_r32(void* stream);
 
 // One successful no-op launch from every code object of the library (see CBIM_DEFINE_WARM); the binding calls
 // this once per process before the first real launch.
@@ -496,6 +497,7 @@ extern "C" int cbim_runtime_warmup(void* stream) {
   if (int e = cbim_warm_inference(stream)) return e;
   if (int e = cbim_warm_attn_mfma(stream)) return e;
   if (int e = cbim_warm_attn_wide(stream)) return e;
+  if (int e = cbim_warm_r32(stream)) return e;
   return CBIM_OK;
 }
 

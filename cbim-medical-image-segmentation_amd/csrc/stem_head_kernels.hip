@@ -434,25 +434,30 @@ __global__ void __launch_bounds__(NT) k_head_fwd_k(const void* __restrict__ x, c
 // dw[k][chunk] as per-lane partial sums over its voxels (16 x CPC x CHW registers), summed over lanes once at the
 // end.  Slab per workgroup [K][Cin+1] (last column = db), fixed-order reduce by k_head_bwd_reduce.
 template <typename T, int CHW>
-__global__ void __launch_bounds__(NT) k_head_bwd_k(const void* __restrict__ x, const float* __restrict__ w,
-                                                   const float* __restrict__ dz, void* __restrict__ dx,
-                                                   float* __restrict__ ws, int64_t S, int Cin, int K,
-                                                   int64_t vox_per_block) {
-  constexpr int CPC = Elem<T>::CPC, KT = 16;
-  CBIM_DYN_SMEM(smem);
-  float* wL = (float*)smem;   // [KT][Cin] zero rows for k >= K
-  for (int i = threadIdx.x; i < KT * Cin; i += NT) wL[i] = i < K * Cin ? w[i] : 0.f;
-  __syncthreads();
+__global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ dz, void* __restrict__ dx,
+                                                      float* __restrict__ ws, int64_t S, int Cin, int K,
+                                                      int64_t vox_per_block) {
+  // One wave per SIMD (16 x CPC x CHW accumulators + the wave's weight columns live in registers: ~300 VGPRs), so
+  // memory latency is hidden by the wave itself: the loads of the next two voxel batches are in flight while a batch
+  // is computed (ring of three register sets, loop unrolled by three).
+  constexpr int CPC = Elem<T>::CPC, KT = 16, RING = 3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.y, cch = Cin / CPC;
+  float wr[CHW][KT][CPC];     // W[k][chunk channels] of this wave's chunks (zero rows for k >= K)
   float acc[CHW][KT][CPC];
   float dbv[KT];
 #pragma unroll
-  for (int h = 0; h < CHW; ++h)
+  for (int h = 0; h < CHW; ++h) {
+    const int q = wave + 4 * h;
 #pragma unroll
     for (int k = 0; k < KT; ++k)
 #pragma unroll
-      for (int j = 0; j < CPC; ++j) acc[h][k][j] = 0.f;
+      for (int j = 0; j < CPC; ++j) {
+        acc[h][k][j] = 0.f;
+        wr[h][k][j] = (k < K && q < cch) ? w[(size_t)k * Cin + q * CPC + j] : 0.f;
+      }
+  }
 #pragma unroll
   for (int k = 0; k < KT; ++k) dbv[k] = 0.f;
   const int64_t v_begin = (int64_t)blockIdx.x * vox_per_block;
@@ -461,48 +466,56 @@ __global__ void __launch_bounds__(NT) k_head_bwd_k(const void* __restrict__ x, c
   const float* dzn = dz + (size_t)n * K * S;
   const char* xn = (const char*)x + (size_t)n * S * Cin * Elem<T>::SIZE;
   char* dxn = dx ? (char*)dx + (size_t)n * S * Cin * Elem<T>::SIZE : nullptr;
-  for (int64_t v = v_begin + lane; v < v_end; v += 64) {
-    float g[KT];
+  float g[RING][KT];
+  u32x4 raw[RING][CHW];
+  auto load = [&](int slot, int64_t v) {
+    if (v < v_end) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) g[k] = k < K ? dzn[(size_t)k * S + v] : 0.f;
-    u32x4 raw[CHW];
+      for (int k = 0; k < KT; ++k) g[slot][k] = k < K ? dzn[(size_t)k * S + v] : 0.f;
 #pragma unroll
-    for (int h = 0; h < CHW; ++h) {
-      const int q = wave + 4 * h;
-      if (q < cch) raw[h] = *(const u32x4*)(xn + ((size_t)v * Cin + (size_t)q * CPC) * Elem<T>::SIZE);
+      for (int h = 0; h < CHW; ++h) {
+        const int q = wave + 4 * h;
+        if (q < cch) raw[slot][h] = *(const u32x4*)(xn + ((size_t)v * Cin + (size_t)q * CPC) * Elem<T>::SIZE);
+      }
     }
+  };
+  auto compute = [&](int slot, int64_t v) {
+    if (v >= v_end) return;
 #pragma unroll
-    for (int k = 0; k < KT; ++k) dbv[k] += g[k];
+    for (int k = 0; k < KT; ++k) dbv[k] += g[slot][k];
 #pragma unroll
     for (int h = 0; h < CHW; ++h) {
       const int q = wave + 4 * h;
       if (q < cch) {
         float xf[CPC];
-        Elem<T>::unpack(raw[h], xf);
+        Elem<T>::unpack(raw[slot][h], xf);
         if (dxn) {
           float f[CPC];
 #pragma unroll
           for (int j = 0; j < CPC; ++j) f[j] = 0.f;
 #pragma unroll
-          for (int k = 0; k < KT; ++k) {
-            const float* wr = wL + (size_t)k * Cin + q * CPC;
+          for (int k = 0; k < KT; ++k)
 #pragma unroll
-            for (int j4 = 0; j4 < CPC; j4 += 4) {
-              const f32x4 wv = *(const f32x4*)(wr + j4);
-              f[j4] = fmaf(g[k], wv.x, f[j4]);
-              f[j4 + 1] = fmaf(g[k], wv.y, f[j4 + 1]);
-              f[j4 + 2] = fmaf(g[k], wv.z, f[j4 + 2]);
-              f[j4 + 3] = fmaf(g[k], wv.w, f[j4 + 3]);
-            }
-          }
+            for (int j = 0; j < CPC; ++j) f[j] = fmaf(g[slot][k], wr[h][k][j], f[j]);
           *(u32x4*)(dxn + ((size_t)v * Cin + (size_t)q * CPC) * Elem<T>::SIZE) = Elem<T>::pack(f);
         }
 #pragma unroll
         for (int k = 0; k < KT; ++k)
 #pragma unroll
-          for (int j = 0; j < CPC; ++j) acc[h][k][j] = fmaf(g[k], xf[j], acc[h][k][j]);
+          for (int j = 0; j < CPC; ++j) acc[h][k][j] = fmaf(g[slot][k], xf[j], acc[h][k][j]);
       }
     }
+  };
+  int64_t v = v_begin + lane;
+  load(0, v);
+  load(1, v + 64);
+  for (; v < v_end; v += 3 * 64) {
+    load(2, v + 128);
+    compute(0, v);
+    load(0, v + 192);
+    compute(1, v + 64);
+    load(1, v + 256);
+    compute(2, v + 128);
   }
   // lanes -> one value (xor butterfly: every lane ends with the same, order-fixed sum)
   const int npairs = K * (Cin + 1);
@@ -522,6 +535,29 @@ __global__ void __launch_bounds__(NT) k_head_bwd_k(const void* __restrict__ x, c
   for (int k = 0; k < KT; ++k) {
     const float a = wave_sum(dbv[k]);
     if (wave == 0 && lane == 0 && k < K) slab[(size_t)k * (Cin + 1) + Cin] = a;
+  }
+}
+
+// slabs -> dw, db: 64 outputs x 4 slab phases per workgroup, fixed order
+__global__ void __launch_bounds__(NT) k_head_bwd_reduce4(const float* __restrict__ ws, float* __restrict__ dw,
+                                                         float* __restrict__ db, int n_slabs, int Cin, int K) {
+  __shared__ float red[4][64];
+  const int npairs = K * (Cin + 1);
+  const int o = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < npairs) {
+    int s = ph;
+    for (; s + 4 < n_slabs; s += 8) { a0 += ws[(size_t)s * npairs + i]; a1 += ws[(size_t)(s + 4) * npairs + i]; }
+    if (s < n_slabs) a0 += ws[(size_t)s * npairs + i];
+  }
+  red[ph][o] = a0 + a1;
+  __syncthreads();
+  if (ph == 0 && i < npairs) {
+    const float a = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    const int c = i % (Cin + 1), k = i / (Cin + 1);
+    if (c < Cin) dw[(size_t)k * Cin + c] = a;
+    else db[k] = a;
   }
 }
 
@@ -673,10 +709,11 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
     // one fused pass (dx, dw, db) when the channel chunks of a row fit the 4 waves x CHW layout of k_head_bwd_k
     const int cpc = dtype == CBIM_BF16 ? 8 : 4, cch = Cin / cpc;
     if (K <= 16 && cch <= 8 && (size_t)Cin * 16 * sizeof(float) <= 64 * 1024) {
-      const int nb = head_bwd_blocks(S);
+      int nb = head_bwd_blocks(S);      // (the workspace is sized for head_bwd_blocks(S) slabs)
+      if (nb > 256) nb = 256;           // one workgroup per CU: fewer slabs for the reduce
       int64_t vpb = (S + nb - 1) / nb;
       vpb = (vpb + 63) / 64 * 64;
-      const size_t sm = (size_t)Cin * 16 * sizeof(float);
+      const size_t sm = 0;
       dim3 grid((unsigned)nb, (unsigned)N);
       float* wsf = (float*)workspace;
       if (dtype == CBIM_BF16) {
@@ -688,7 +725,7 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
       }
       if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
       const int npairs = K * (Cin + 1);
-      CBIM_LAUNCH(k_head_bwd_reduce, dim3((npairs + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw, db,
+      CBIM_LAUNCH(k_head_bwd_reduce4, dim3((npairs + 63) / 64), dim3(NT), 0, st, (const float*)workspace, dw, db,
                   N * nb, Cin, K);
       return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
     }

@@ -401,7 +401,12 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
         e1.record()
         cfg = (C.c_int * 4)()
         L.cbim_conv3d_tile_config(C.byref(desc), C.byref(cfg))
-        name = "k_conv_igemm<%s,%d,%d>" % ("bf16" if desc.dtype == 1 else "f32", cfg[0], cfg[1])
+        if cfg[0] == 4 and x2 is None:
+            name = "k_conv3_r32<bf16>"
+        else:
+            if cfg[0] == 4:
+                cfg[0] = 2
+            name = "k_conv_igemm<%s,%d,%d>" % ("bf16" if desc.dtype == 1 else "f32", cfg[0], cfg[1])
         flops = 2.0 * desc.N * desc.Do * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.kD * desc.kH * desc.kW
         PROFILE.append((name, flops, e0, e1, (desc.Cin, desc.Cout, desc.Do, desc.Ho, desc.Wo)))
     return y, part

@@ -139,6 +139,10 @@ typedef struct cbim_pack_item {
 int cbim_conv3d_pack_item_fill(const cbim_conv_desc* fwd_desc, const float* w0, const float* w1, int rows0,
                                void* packed_fwd, void* packed_dgrad, int block_begin, cbim_pack_item* out);
 int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, int n_items, int total_blocks, void* stream);
+/* Tuning knob: output voxels per image from which the Cin = 32 -> Cout <= 32 3x3x3 layers (bf16) run on the
+ * "weights in registers" kernel (conv_r32.hip) instead of k_conv_igemm; v < 0 only queries.  Returns the previous
+ * value (default 262144 = 64^3).  The two kernels compute the same function (tests lower it to cover small shapes). */
+int64_t cbim_conv_r32_min_voxels(int64_t v);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);

@@ -153,6 +153,27 @@ inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16
   }
   return d;
 }
+// 16x16x32 bf16: A lane l: row l&15, k = 8*(l>>4)+j ; B lane l: col l&15, same k; C/D lane l: col l&15, row 4*(l>>4)+r.
+inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c, int, int, int) {
+  struct P { unsigned short a[8], b[8]; } mine;
+  memcpy(mine.a, &a, 16);
+  memcpy(mine.b, &b, 16);
+  const P* buf = (const P*)cbim_emu::wave_exchange(&mine, sizeof(P));
+  int l = CBIM_EMU_LANE_ID();
+  int col = l & 15;
+  emu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (l >> 4) + r;
+    float acc = d[r];
+    for (int k = 0; k < 32; ++k) {
+      float av = emu_bf2f(buf[row + 16 * (k >> 3)].a[k & 7]);
+      float bv = emu_bf2f(buf[col + 16 * (k >> 3)].b[k & 7]);
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
 // f32 32x32x2: A lane l: A[i=l&31][k=l>>5]; B lane l: B[k=l>>5][j=l&31].
 inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
   struct P { float a, b; } mine = {a, b};

@@ -138,6 +138,74 @@ def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0, act="relu"):
     assert float((sums[..., 1].cpu() - (gm * xh).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
 
 
+def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21):
+    """The 'weights in registers' kernel for Cin = 32 -> Cout <= 32, 3x3x3, bf16 (conv_r32.hip) against torch AND against
+    k_conv_igemm on the same inputs: transformed input + residual + statistics (forward), raw input (LDS-DMA path),
+    plain dgrad, masked dgrad with the two InstanceNorm-backward sums."""
+    from cbim_amd import _lib
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    torch.manual_seed(seed)
+    k, pad, Cin = (3, 3, 3), (1, 1, 1), 32
+    x = torch.randn(N, Cin, *dhw) + 0.5
+    w = torch.randn(Cout, Cin, *k) * 0.1
+    xl = to_cl(x, dtype).to(dev)
+    xr = from_cl(xl.cpu())
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, ops.ACT[act])
+    wdev = w.to(dev)
+    wp, wpd = ops.pack_weights(wdev, geom, 0), ops.pack_weights(wdev, geom, 1)
+    st = ops.instnorm_stats(xl)
+    xh = F.instance_norm(xr, eps=1e-4)
+    a = (F.relu(xh) if act == "relu" else xh.clone()).bfloat16().float()
+    wr = w.bfloat16().float()
+    res = torch.randn(N, Cout, *dhw)
+    resl = to_cl(res, dtype).to(dev)
+    dy = torch.randn(N, Cout, *dhw)
+    dyl = to_cl(dy, dtype).to(dev)
+    # dgrad geometry of this layer: Cout_dgrad = Cin = 32, Cin_dgrad = Cout -> only Cout == 32 is the r32 shape
+    mk = torch.randn(N, Cin, *dhw) * 1.3 + 0.2
+    mkl = to_cl(mk, dtype).to(dev)
+    mst = ops.instnorm_stats(mkl)
+
+    def run():
+        y, ys = ops.conv_fwd(xl, wp, geom, in_stats=st, res=resl, want_stats=True)
+        y0, ys0 = ops.conv_fwd(xl, wp, geom, want_stats=True)
+        y1, _ = ops.conv_fwd(xl, wp, geom)
+        out = [y, ys, y0, ys0, y1]
+        if Cout == 32:
+            g, _ = ops.conv_dgrad(dyl, wpd, geom)
+            g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=mkl, mask_stats=mst)
+            out += [g, g2, sums]
+        return [o.float().cpu() for o in out]
+
+    old = L.cbim_conv_r32_min_voxels(-1)
+    try:
+        L.cbim_conv_r32_min_voxels(1 << 40)
+        ref = run()                       # k_conv_igemm
+        L.cbim_conv_r32_min_voxels(0)
+        got = run()                       # k_conv3_r32
+    finally:
+        L.cbim_conv_r32_min_voxels(old)
+    names = ["fwd+res", "fwd stats", "raw fwd", "raw stats", "raw fwd (no stats)", "dgrad", "masked dgrad", "bwd sums"]
+    for nm, r, g_ in zip(names, ref, got):
+        lim = 2e-3 if nm in ("fwd stats", "raw stats", "bwd sums") else 1e-2
+        assert relerr(g_, r) < lim, f"r32 vs igemm: {nm} {relerr(g_, r):.3e}"
+    # and against torch
+    yr = F.conv3d(a, wr, None, 1, pad) + from_cl(resl.cpu())
+    assert relerr(from_cl(got[0]), yr) < 1e-2, "fwd vs torch"
+    assert relerr(got[1][..., 0], yr.mean((2, 3, 4))) < 1e-2 + 1e-4
+    assert relerr(from_cl(got[2]), F.conv3d(xr, wr, None, 1, pad)) < 1e-2, "raw fwd vs torch"
+    if Cout == 32:
+        dyr = from_cl(dyl.cpu())
+        gr = F.conv_transpose3d(dyr, wr, None, 1, pad)
+        assert relerr(from_cl(got[5]), gr) < 1e-2, "dgrad vs torch"
+        mh = F.instance_norm(from_cl(mkl.cpu()), eps=1e-4)
+        gm = gr * ((mh > 0) if act == "relu" else 1.0)
+        assert relerr(from_cl(got[6]), gm) < 1e-2, "masked dgrad vs torch"
+        assert float((got[7][..., 0] - gm.mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
+        assert float((got[7][..., 1] - (gm * mh).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
+
+
 def check_stem_head(dev, dtype, N=1, Cin=2, base=8, K=5, dhw=(6, 9, 10), k=(3, 3, 3)):
     torch.manual_seed(4)
     pad = [i // 2 for i in k]

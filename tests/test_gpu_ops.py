@@ -55,6 +55,12 @@ def test_conv(dev, dtype, N, Cin, Cout, dhw, k):
     oc.check_conv(dev, dtype, N, Cin, Cout, dhw, k)
 
 
+def test_conv_r32_weights_in_registers(dev):
+    oc.check_conv_r32(dev)                                          # ragged tiles, two images
+    oc.check_conv_r32(dev, N=1, Cout=16, dhw=(8, 8, 16), act="none")
+    oc.check_conv_r32(dev, N=1, Cout=32, dhw=(64, 64, 64))          # the default threshold: picked without the knob
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)

@@ -112,6 +112,11 @@ def test_trilinear_planes(dev):
     oc.check_trilinear_planes(dev, lo=(1, 2, 2), hi=(4, 4, 4))
 
 
+def test_conv_r32_weights_in_registers(dev):
+    oc.check_conv_r32(dev)                                          # ragged tiles, two images
+    oc.check_conv_r32(dev, N=1, Cout=16, dhw=(8, 8, 16), act="none")
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
