@@ -773,31 +773,37 @@ __global__ void __launch_bounds__(FT) k_splitk_finish(const float* __restrict__ 
 // value w[k_ch][n_ch][taps-1-tap]  (w is always the forward [Cout][Cin][taps] tensor).
 // `w` rows (forward output channels) >= rows0 come from `w1` (row r - rows0): a Cout-concatenated convolution
 // (conv1 | shortcut) is packed straight from its two parameter tensors; w1 == nullptr: everything is in `w`.
+// One call produces one 16-byte chunk (CPC consecutive K channels of one (tap, cout)): index `ic` counts chunks.
 template <typename T>
 __device__ __forceinline__ void pack_one(const float* __restrict__ w, const float* __restrict__ w1, int rows0,
                                          void* __restrict__ packed, int Cout_f,
-                                         int Cin_f, int taps, int mode, int BN, int n_chunks, int64_t i) {
+                                         int Cin_f, int taps, int mode, int BN, int n_chunks, int64_t ic) {
   constexpr int CPC = Elem<T>::CPC;
   constexpr int KC = SLOTS * CPC;
   const int Kdim = mode == 0 ? Cin_f : Cout_f;
   const int Ndim = mode == 0 ? Cout_f : Cin_f;
-  int64_t r = i;
-  int j = (int)(r % CPC); r /= CPC;
-  int nn = (int)(r % BN); r /= BN;
-  int half = (int)(r % 2); r /= 2;
-  int kg = (int)(r % KG); r /= KG;
-  int tap = (int)(r % taps); r /= taps;
-  int q = (int)(r % n_chunks);
-  int nb = (int)(r / n_chunks);
-  int kc = q * KC + (2 * kg + half) * CPC + j;
-  int nc = nb * BN + nn;
-  float v = 0.f;
-  if (kc < Kdim && nc < Ndim) {
-    const int row = mode == 0 ? nc : kc, col = mode == 0 ? kc : nc, tp = mode == 0 ? tap : taps - 1 - tap;
-    const float* src = (w1 && row >= rows0) ? w1 + (size_t)(row - rows0) * Cin_f * taps : w + (size_t)row * Cin_f * taps;
-    v = src[(size_t)col * taps + tp];
+  // 32-bit decode (a packed image has < 2^31 chunks); BN (32 | 64), 2 and KG are powers of two
+  unsigned r = (unsigned)ic;
+  const int nn = (int)(r & (unsigned)(BN - 1)); r >>= (BN == 64 ? 6 : 5);
+  const int half = (int)(r & 1u); r >>= 1;
+  const int kg = (int)(r % KG); r /= KG;
+  const int tap = (int)(r % (unsigned)taps); r /= (unsigned)taps;
+  const int q = (int)(r % (unsigned)n_chunks);
+  const int nb = (int)(r / (unsigned)n_chunks);
+  const int kc0 = q * KC + (2 * kg + half) * CPC;
+  const int nc = nb * BN + nn;
+  float v[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) {
+    const int kc = kc0 + j;
+    v[j] = 0.f;
+    if (kc < Kdim && nc < Ndim) {
+      const int row = mode == 0 ? nc : kc, col = mode == 0 ? kc : nc, tp = mode == 0 ? tap : taps - 1 - tap;
+      const float* src = (w1 && row >= rows0) ? w1 + (size_t)(row - rows0) * Cin_f * taps : w + (size_t)row * Cin_f * taps;
+      v[j] = src[(size_t)col * taps + tp];
+    }
   }
-  Elem<T>::store1(packed, (size_t)i, v);
+  st_chunk<T>(packed, (size_t)ic * CPC, Elem<T>::pack(v));
 }
 
 // One launch packs the forward layout, the dgrad layout, or both (p0/p1 may be null).
@@ -806,10 +812,12 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
                                                       void* __restrict__ p1, int Cout_f, int Cin_f, int taps,
                                                       int BN0, int nch0, int64_t total0, int BN1, int nch1,
                                                       int64_t total1) {
-  const int64_t tmax = total0 > total1 ? total0 : total1;
+  constexpr int CPC = Elem<T>::CPC;
+  const int64_t c0 = total0 / CPC, c1 = total1 / CPC;
+  const int64_t tmax = c0 > c1 ? c0 : c1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tmax; i += (int64_t)gridDim.x * 256) {
-    if (p0 && i < total0) pack_one<T>(w, nullptr, 0, p0, Cout_f, Cin_f, taps, 0, BN0, nch0, i);
-    if (p1 && i < total1) pack_one<T>(w, nullptr, 0, p1, Cout_f, Cin_f, taps, 1, BN1, nch1, i);
+    if (p0 && i < c0) pack_one<T>(w, nullptr, 0, p0, Cout_f, Cin_f, taps, 0, BN0, nch0, i);
+    if (p1 && i < c1) pack_one<T>(w, nullptr, 0, p1, Cout_f, Cin_f, taps, 1, BN1, nch1, i);
   }
 }
 
@@ -818,10 +826,12 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
 // blockIdx.x -> item by binary search over the items' first block.
 template <typename T>
 __device__ __forceinline__ void pack_item(const cbim_pack_item& it, int64_t first, int64_t step) {
-  const int64_t tmax = it.total0 > it.total1 ? it.total0 : it.total1;
+  constexpr int CPC = Elem<T>::CPC;
+  const int64_t c0 = it.total0 / CPC, c1 = it.total1 / CPC;
+  const int64_t tmax = c0 > c1 ? c0 : c1;
   for (int64_t i = first; i < tmax; i += step) {
-    if (it.p0 && i < it.total0) pack_one<T>(it.w0, it.w1, it.rows0, it.p0, it.Cout, it.Cin, it.taps, 0, it.BN0, it.nch0, i);
-    if (it.p1 && i < it.total1) pack_one<T>(it.w0, it.w1, it.rows0, it.p1, it.Cout, it.Cin, it.taps, 1, it.BN1, it.nch1, i);
+    if (it.p0 && i < c0) pack_one<T>(it.w0, it.w1, it.rows0, it.p0, it.Cout, it.Cin, it.taps, 0, it.BN0, it.nch0, i);
+    if (it.p1 && i < c1) pack_one<T>(it.w0, it.w1, it.rows0, it.p1, it.Cout, it.Cin, it.taps, 1, it.BN1, it.nch1, i);
   }
 }
 __global__ void __launch_bounds__(256) k_pack_weights_table(const cbim_pack_item* __restrict__ items, int n_items) {
@@ -924,7 +934,7 @@ static int pack_launch(const cbim_conv_desc* d, const float* w, void* p0, void* 
   int nch0 = (d->Cin + KC - 1) / KC, nch1 = (d->Cout + KC - 1) / KC;
   int64_t t0 = p0 ? (int64_t)(cbim_conv3d_packed_bytes(d, 0) / es) : 0;
   int64_t t1 = p1 ? (int64_t)(cbim_conv3d_packed_bytes(d, 1) / es) : 0;
-  int64_t tmax = t0 > t1 ? t0 : t1;
+  int64_t tmax = (t0 > t1 ? t0 : t1) / (d->dtype == CBIM_BF16 ? 8 : 4);   // one 16-byte chunk per thread trip
   int64_t blocks = (tmax + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
@@ -964,7 +974,7 @@ extern "C" int cbim_conv3d_pack_item_fill(const cbim_conv_desc* d, const float* 
   out->total0 = packed_fwd ? (int64_t)(cbim_conv3d_packed_bytes(d, 0) / es) : 0;
   out->total1 = packed_dgrad ? (int64_t)(cbim_conv3d_packed_bytes(d, 1) / es) : 0;
   const int64_t tmax = out->total0 > out->total1 ? out->total0 : out->total1;
-  int64_t nb = (tmax + 256 * 8 - 1) / (256 * 8);   // ~8 elements per thread
+  int64_t nb = (tmax + 256 * 16 - 1) / (256 * 16);   // ~2 sixteen-byte chunks per thread
   if (nb < 1) nb = 1;
   if (nb > 1024) nb = 1024;
   out->block_begin = block_begin; out->n_blocks = (int)nb; out->dtype = d->dtype;

@@ -43,9 +43,13 @@ __device__ __attribute__((aligned(64))) unsigned int g_r32_zero[16];   // source
 typedef __attribute__((ext_vector_type(4))) float r_f32x4;
 
 #ifdef CBIM_EMU
+#define R_SCHED_GROUP(mask, n) ((void)0)
 #define R_SCHED_FENCE() ((void)0)
 #define R_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
 #else
+// one group of the instruction-interleave pattern of a scheduling region: `n` instructions of class `mask`
+// (0x2 VALU, 0x4 SALU, 0x8 MFMA, 0x100 DS read, 0x200 DS write) come next
+#define R_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define R_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define R_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
@@ -141,8 +145,7 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
     fb[kh] = (unsigned)((th + kh) * 10 + tw) * R_RB + (((unsigned)lq ^ r_swz((unsigned)(th + kh))) << 4);
 
   // ---- halo items of this thread (the same for every tile): position inside the 10x10x10 box --------------------
-  // LDS-DMA item q = tid + 512 u is PHYSICAL (LDS byte q*16 = row q>>2, slot q&3), source slot = (q&3) ^ r_swz(hh);
-  // the in-place transform of the TR path takes item q as LOGICAL (row q>>2, channel chunk q&3 = tid&3)
+  // LDS-DMA item q = tid + 512 u is PHYSICAL (LDS byte q*16 = row q>>2, slot q&3), source slot = (q&3) ^ r_swz(hh)
   // The position is decoded per tile from the laundered thread index (~10 VALU per item) instead of living in
   // registers next to the weights.
   auto item_pos = [&](unsigned tl, int u) -> unsigned {   // hd | hh << 8 | hw << 16 | exists << 24
@@ -192,30 +195,52 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
     const Src sr = item_src(tp, u);
     r_dma16(sr.ptr, smem + buf + (unsigned)(wave * 64 + 512 * u) * 16);
   };
-  // TR path: the raw halo arrives by the same LDS-DMA; once it has landed (workgroup barrier) every thread transforms
-  // its 8 items IN PLACE (ds_read_b128 -> InstanceNorm + activation -> ds_write_b128), item = (row, logical channel
-  // chunk tid & 3) so the chunk's statistics are one 64-byte row of a 256-byte LDS table.  Padding rows stay zero.
+  // TR path: the raw halo arrives by the same LDS-DMA; a wave transforms IN PLACE exactly the 1 KiB pieces it has
+  // fetched itself (lane = the piece's 16-byte item), so the only ordering needed is the wave's own counted vmcnt —
+  // no workgroup barrier between the fetch and the transform.  ds_read_b128 -> (x - mean) * rstd as packed f32 pairs
+  // -> bf16 pairs -> ReLU as v_pk_max_i16 against 0 -> ds_write_b128.  The statistics of the item's channel chunk
+  // are one 64-byte row of a 256-byte LDS table.  Padding rows stay zero.
   auto tr_xform = [&](const TilePos& tp, int u, unsigned buf) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef short s2_t __attribute__((ext_vector_type(2)));
     const int id0 = tp.td * 8 - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
     const unsigned pk = item_pos(r_launder((unsigned)tid), u);
     const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
     const bool ld = (pk >> 24) != 0 && (unsigned)(id0 + (int)hd) < (unsigned)p.Di && (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi &&
                     (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
-    if (ld) {
-      const unsigned row = ((unsigned)tid + 512u * (unsigned)u) >> 2;
-      unsigned char* cell = smem + buf + row * R_RB + ((my_slot ^ r_swz(hh)) << 4);
-      float f[8];
-      Elem<bf16_tag>::unpack(*(const u32x4*)cell, f);
-      const float* is = (const float*)(smem + ist_base) + my_slot * 16;
+    {
+      unsigned char* cell = smem + buf + ((unsigned)tid + 512u * (unsigned)u) * 16u;
+      const float* is = (const float*)(smem + ist_base) + ((my_slot ^ r_swz(hh)) << 4);   // logical chunk of this cell
+      const u32x4 raw = *(const u32x4*)cell;
+      const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w};
+      unsigned ow[4];
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        const f32x4 q4 = *(const f32x4*)(is + 2 * j);   // (mean, rstd) of channels j, j+1
-        const float x0 = (f[j] - q4.x) * q4.y, x1 = (f[j + 1] - q4.z) * q4.w;
-        f[j] = ACT == CBIM_ACT_RELU ? (x0 > 0.f ? x0 : 0.f) : (ACT == CBIM_ACT_NONE ? x0 : act_fwd(x0, p.act));
-        f[j + 1] = ACT == CBIM_ACT_RELU ? (x1 > 0.f ? x1 : 0.f) : (ACT == CBIM_ACT_NONE ? x1 : act_fwd(x1, p.act));
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 q4 = *(const f32x4*)(is + 4 * j);   // (mean, rstd) of channels 2j, 2j+1
+        const f2_t x = {__uint_as_float(rw[j] << 16), __uint_as_float(rw[j] & 0xffff0000u)};
+        const f2_t m = {q4.x, q4.z}, r = {q4.y, q4.w};
+        const f2_t y = (x - m) * r;
+        unsigned o = pk_bf16(y.x, y.y);
+        if (ACT == CBIM_ACT_RELU) {
+          s2_t h = __builtin_bit_cast(s2_t, o);
+          const s2_t z = {0, 0};
+          h = __builtin_elementwise_max(h, z);      // a negative bf16 is a negative int16
+          o = __builtin_bit_cast(unsigned, h);
+        }
+        ow[j] = ld ? o : 0u;                        // padding cells (zeros from the DMA) stay zero: no branch
       }
-      *(u32x4*)cell = Elem<bf16_tag>::pack(f);
+      *(u32x4*)cell = u32x4{ow[0], ow[1], ow[2], ow[3]};
     }
+  };
+  auto wait_vm = [&](int n) {   // at most n vector-memory operations of this wave still in flight
+#ifndef CBIM_EMU
+    if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    (void)n;
+#endif
   };
 
   // ---- per-lane statistics: after the epilogue exchange a lane owns channel chunk cidx = 2*ch + (lq >> 1) -------
@@ -226,30 +251,38 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; sh[MX ? 0 : j] = 0.f; }
   int run_n = cur.n;
+  bool shift_set = false;     // workgroup-uniform
   const bool want_part = p.partials != nullptr;
-  // combine the lanes' sums of image n into this workgroup's record and reset them (all threads call it)
+  // combine the lanes' sums of image n into this workgroup's record and reset them (all threads call it).  The 32 lanes
+  // that hold a channel chunk share ONE shift (taken from the group's first lane when the sums start), so their sums
+  // simply add: 5 butterfly rounds over 17 independent values, one conversion to (n, mean, M2) per channel and wave.
   auto flush_stats = [&](int n) {
     __syncthreads();
     float* red = (float*)(smem + red_base);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      Moments a;
-      if (MX) { a.n = 0.f; a.mean = s0[j]; a.m2 = s1[j]; }
-      else a = moments_from_shifted(cnt, sh[MX ? 0 : j], s0[j], s1[j]);
+    for (int msk = 1; msk < 32; msk <<= 1) {   // lanes differing in bits 0..4 (voxel, lq & 1) hold the same channels
+      float t0[8], t1[8];
 #pragma unroll
-      for (int msk = 1; msk < 32; msk <<= 1) {   // lanes differing in bits 0..4 (voxel, lq & 1) hold the same channels
-        Moments b;
-        b.n = __shfl_xor(a.n, msk, 64); b.mean = __shfl_xor(a.mean, msk, 64); b.m2 = __shfl_xor(a.m2, msk, 64);
-        if (MX) { a.mean += b.mean; a.m2 += b.m2; }
-        else a = (lane & msk) == 0 ? moments_merge(a, b) : moments_merge(b, a);   // same operand order in both lanes
-      }
-      if ((lane & 31) == 0) {
+      for (int j = 0; j < 8; ++j) { t0[j] = __shfl_xor(s0[j], msk, 64); t1[j] = __shfl_xor(s1[j], msk, 64); }
+      const float tc = __shfl_xor(cnt, msk, 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s0[j] += t0[j]; s1[j] += t1[j]; }
+      cnt += tc;
+    }
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        Moments a;
+        if (MX) { a.n = 0.f; a.mean = s0[j]; a.m2 = s1[j]; }
+        else a = moments_from_shifted(cnt, sh[MX ? 0 : j], s0[j], s1[j]);
         float* rr = red + ((wave * 16) + (lq >> 1) * 8 + j) * 3;
         rr[0] = a.n; rr[1] = a.mean; rr[2] = a.m2;
       }
-      s0[j] = 0.f; s1[j] = 0.f; sh[MX ? 0 : j] = 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
     cnt = 0.f;
+    shift_set = false;
     __syncthreads();
     if (tid < 32 && tid < p.Cout) {
       Moments a = {0.f, 0.f, 0.f};
@@ -314,6 +347,8 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
     // the next tile's transforms run during THIS tile: at an image change the statistics table is rewritten first (no
     // reader is active here: the previous tile's transforms ended before its barrier)
     if (TR && more && nxt.n != ist_n) { load_istats(nxt.n); __syncthreads(); }
+    TilePos nx;
+    nx.n = more ? nxt.n : cur.n; nx.td = more ? nxt.td : cur.td; nx.th = more ? nxt.th : cur.th; nx.tw = more ? nxt.tw : cur.tw;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) acc[nt] = r_f32x4{0.f, 0.f, 0.f, 0.f};
     // (B) 9 (kh, kw) steps: the 10 plane fragments stream through a ring of 5 registers, plane i feeds the MFMAs
@@ -329,24 +364,28 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
         const int kh = s / 3, kw = s % 3;
         const unsigned base = buf + fb[kh] + (unsigned)(kw * R_RB);
         const unsigned base_n = buf + fb[(s + 1) / 3 % 3] + (unsigned)(((s + 1) % 3) * R_RB);
-        // the next tile's halo: LDS-DMA pieces during the first steps; TR: after a mid-tile barrier (all pieces
-        // landed) the in-place transform runs under the MFMAs of the last three steps
-        if (more) {
+        // the next tile's halo: LDS-DMA pieces during the first steps (TR: transformed in place four steps later).
+        // Branch-free (the strip's last tile re-fetches itself into the idle buffer) so that this code sits in the same
+        // basic block as the step's MFMAs and can be interleaved with them.
+        {
           if (TR) {
-            if (s < 4) { dma_item(nxt, 2 * s, obuf); dma_item(nxt, 2 * s + 1, obuf); }
-            if (s == 6) { r_wait_vm0(); __syncthreads(); }
-            if (s >= 6) {
-#pragma unroll
-              for (int u = 3 * (s - 6); u < 3 * (s - 6) + 3; ++u)
-                if (u < R_UH) tr_xform(nxt, u, obuf);
+            // pieces 2s, 2s+1 are fetched at step s < 4 and transformed at step s + 4 (own pieces only: the wave's
+            // counted vmcnt — 6, 4, 2, 0 younger pieces may still be in flight — is the whole synchronisation)
+            if (s < 4) { dma_item(nx, 2 * s, obuf); dma_item(nx, 2 * s + 1, obuf); }
+            if (s >= 4 && s < 8) {
+              wait_vm(6 - 2 * (s - 4));
+              tr_xform(nx, 2 * (s - 4), obuf);
+              tr_xform(nx, 2 * (s - 4) + 1, obuf);
             }
           } else if (s < R_UH) {
-            dma_item(nxt, s, obuf);
+            dma_item(nx, s, obuf);
           }
         }
         // plane i+4 (of this step, or of the next one: the ring runs across steps) is requested before the MFMAs of
         // plane i issue; the fences keep the compiler from sinking the read next to its use (it then waits a full LDS
-        // round trip every third MFMA: measured 57 % of the MFMA rate)
+        // round trip every third MFMA: measured 57 % of the MFMA rate).  (A sched_group_barrier pattern over the whole
+        // step was tried instead of the fences: the inline-asm LDS-DMA splits the scheduling region and the reads
+        // sink again.)
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
           const int j = i + RING - 1;
@@ -412,43 +451,62 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
           v[r] = a;
           v[4 + r] = b;
         }
-        float f[8];
-        Elem<bf16_tag>::unpack(rq[pp & 1], f);
+        // packed f32 pairs from here on (v_pk_add / v_pk_mul / v_pk_fma); lanes outside the tensor or beyond Cout
+        // contribute with weight 0 instead of branching
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        const float live = (in && c_ok) ? 1.f : 0.f;
+        const f2_t live2 = {live, live};
+        const unsigned rw[4] = {rq[pp & 1].x, rq[pp & 1].y, rq[pp & 1].z, rq[pp & 1].w};
         if (MX) {
           const float* ms = (const float*)(smem + mst_base) + cidx * 16;
 #pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            const f32x4 q4 = *(const f32x4*)(ms + 2 * j);   // (mean, rstd) of channels j, j+1
-            const float xh0 = (f[j] - q4.x) * q4.y, xh1 = (f[j + 1] - q4.z) * q4.w;
-            const float g0 = ACT == CBIM_ACT_RELU ? (xh0 > 0.f ? 1.f : 0.f) : (ACT == CBIM_ACT_NONE ? 1.f : act_grad(xh0, p.act));
-            const float g1 = ACT == CBIM_ACT_RELU ? (xh1 > 0.f ? 1.f : 0.f) : (ACT == CBIM_ACT_NONE ? 1.f : act_grad(xh1, p.act));
-            v[j] *= g0;
-            v[j + 1] *= g1;
-            if (in && c_ok) {
-              s0[j] += v[j]; s1[j] += v[j] * xh0;
-              s0[j + 1] += v[j + 1]; s1[j + 1] += v[j + 1] * xh1;
-            }
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 q4 = *(const f32x4*)(ms + 4 * j);   // (mean, rstd) of channels 2j, 2j+1
+            const f2_t x = {__uint_as_float(rw[j] << 16), __uint_as_float(rw[j] & 0xffff0000u)};
+            const f2_t m = {q4.x, q4.z}, r = {q4.y, q4.w};
+            const f2_t xh = (x - m) * r;
+            f2_t g;
+            if (ACT == CBIM_ACT_RELU) { g.x = xh.x > 0.f ? v[2 * j] : 0.f; g.y = xh.y > 0.f ? v[2 * j + 1] : 0.f; }
+            else { g.x = v[2 * j]; g.y = v[2 * j + 1]; }
+            v[2 * j] = g.x;
+            v[2 * j + 1] = g.y;
+            const f2_t gl = g * live2;
+            f2_t a0 = {s0[2 * j], s0[2 * j + 1]}, a1 = {s1[2 * j], s1[2 * j + 1]};
+            a0 = a0 + gl;
+            a1 = __builtin_elementwise_fma(gl, xh, a1);
+            s0[2 * j] = a0.x; s0[2 * j + 1] = a0.y; s1[2 * j] = a1.x; s1[2 * j + 1] = a1.y;
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += f[j];     // residual (zeros when there is none)
-          if (in && c_ok && want_part) {
-            if (cnt == 0.f) {
+          for (int j = 0; j < 4; ++j) {   // residual (zeros when there is none)
+            v[2 * j] += __uint_as_float(rw[j] << 16);
+            v[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u);
+          }
+          if (want_part && !(p.dbg & 32)) {
+            if (!shift_set) {            // common shift of the 32 lanes that hold this chunk: any finite value near
+              shift_set = true;          // the data works (shifted moments); taken from the group's first lane
 #pragma unroll
-              for (int j = 0; j < 8; ++j) sh[MX ? 0 : j] = v[j];
+              for (int j = 0; j < 8; ++j) sh[MX ? 0 : j] = __shfl(v[j], lane & 32, 64);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[j] - sh[MX ? 0 : j]; s0[j] += d; s1[j] += d * d; }
+            for (int j = 0; j < 4; ++j) {
+              const f2_t x = {v[2 * j], v[2 * j + 1]}, hs = {sh[MX ? 0 : 2 * j], sh[MX ? 0 : 2 * j + 1]};
+              const f2_t d = (x - hs) * live2;
+              f2_t a0 = {s0[2 * j], s0[2 * j + 1]}, a1 = {s1[2 * j], s1[2 * j + 1]};
+              a0 = a0 + d;
+              a1 = __builtin_elementwise_fma(d, d, a1);
+              s0[2 * j] = a0.x; s0[2 * j + 1] = a0.y; s1[2 * j] = a1.x; s1[2 * j + 1] = a1.y;
+            }
           }
         }
         if (in && c_ok && !(p.dbg & 16)) *(u32x4*)(y_tile + (r_mul24(rel, y_sb) + cb)) = Elem<bf16_tag>::pack(v);
-        if (in) cnt += 1.f;
+        cnt += live;
       }
     }
     cur = nxt;
     advance(nxt);
   }
-  if (want_part) flush_stats(run_n);
+  if (want_part && !(p.dbg & 64)) flush_stats(run_n);
 }
 
 }  // namespace cbim

@@ -278,7 +278,13 @@ class PackedWeights:
             e = self._add(key, ws, geom, need_dgrad or (e is not None and e.p1 is not None))
         e.used = True
         if self.stale or e.versions != tuple(w._version for w in ws):
-            self._repack_all(new_only=e.versions is None and not self.stale)
+            try:
+                self._repack_all(new_only=e.versions is None and not self.stale)
+            except Exception:
+                if e.versions is None:        # an unsupported weight (e.g. Cout not a multiple of the channel chunk)
+                    self.entries.pop(key, None)   # must not stay in the table and fail every later launch
+                    self.dirty_table = True
+                raise
         return e.p0, (e.p1 if need_dgrad else None)
 
     def _add(self, key, ws, geom, with_dgrad):

@@ -61,7 +61,7 @@ def test_dead_models_leave_the_table(dev, monkeypatch):
         del old
         net = _net().to(dev)
         with torch.no_grad():
-            for _ in range(4):       # 4 "optimizer steps" (version bumps) during which only `net` is used
+            for _ in range(5):       # 5 "optimizer steps" (version bumps) during which only `net` is used
                 torch.autograd.graph.increment_version(list(net.parameters()))
                 net(x)
         assert len(ops.PACKED.entries) == n_one                 # the first model's weights were evicted
