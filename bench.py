@@ -52,8 +52,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=1,
-                    help="1: replay the whole step from one hipGraph (captured after warm-up; N=1 only)")
-    ap.add_argument("--cpu-size", type=int, default=96, help="edge of the CPU-baseline sample volume")
+                    help="1: replay the whole step (incl. the RCCL gradient all-reduce for N > 1) from one hipGraph, "
+                         "captured after warm-up; falls back to eager launches if the capture fails")
+    ap.add_argument("--ddp1", type=int, default=0,
+                    help="1 (with --gpus 1): run the data-parallel path on a ONE-rank RCCL group — the bucketed gradient "
+                         "all-reduce and its hipGraph capture exercised on a single GPU (tests/, not a bench line)")
+    ap.add_argument("--cpu-size", type=int, default=128,
+                    help="edge of the CPU-baseline sample volume (default: the real 1x1x128^3 volume, no extrapolation)")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch"],
                     help="fused: cbim_amd FusedAdamW (one multi-tensor launch); torch: torch.optim.AdamW(fused=True)")
     ap.add_argument("--model", default="resunet", choices=["resunet", "medformer", "swin_unetr"],
@@ -73,10 +78,16 @@ def synthetic(batch, classes, size, device, seed):
 
 
 def cpu_baseline(args):
-    """Oracle fwd + loss + bwd on the host cores, one volume (bounded sample)."""
+    """fwd + loss + bwd of ONE 1x1x128^3 volume on the host cores (bounded sample: ~20-30 s).  When the reference
+    checkout is mounted (the build container) its own modules are timed (kind "reference"); on the GPU box, where
+    /root/reference does not exist, the oracle — the restatement pinned to it by tests/golden — is (kind "port")."""
     from oracle import loss_ref, medformer_ref, unet_ref
-    cores = min(os.cpu_count() or 1, 64)   # one socket's worth; oneDNN conv3d stops scaling beyond
+    cores = min(os.cpu_count() or 1, 128)
     torch.set_num_threads(cores)
+    if args.model == "resunet" and os.path.isdir("/root/reference/model"):
+        r = _reference_cpu_baseline(args, cores)
+        if r is not None:
+            return r
     ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
     s = args.cpu_size
     x, lab = synthetic(1, args.classes, s, "cpu", 2023)
@@ -119,6 +130,36 @@ def cpu_baseline(args):
                       + ("" if s == 128 else f" (scaled x{scale:.2f} to 128^3)")}
 
 
+def _reference_cpu_baseline(args, cores):
+    """The reference's own UNet + CrossEntropyLoss + DiceLoss on the host cores."""
+    try:
+        sys.path.insert(0, "/root/reference")
+        from model.dim3.unet import UNet as RefUNet
+        from training.losses import DiceLoss as RefDice
+    except Exception:
+        return None
+    finally:
+        if sys.path and sys.path[0] == "/root/reference":
+            sys.path.pop(0)
+    torch.manual_seed(2023)
+    s = args.cpu_size
+    net = RefUNet(1, args.base, scale=[[2, 2, 2]] * 4, kernel_size=[[3, 3, 3]] * 5, num_classes=args.classes,
+                  block="BasicBlock", norm="in")
+    x, lab = synthetic(1, args.classes, s, "cpu", 2023)
+    w = torch.ones(args.classes)
+    w[0] = 0.5
+    ce, dl = torch.nn.CrossEntropyLoss(weight=w), RefDice()
+    t0 = time.perf_counter()
+    out = net(x)
+    loss = ce(out, lab.squeeze(1)) + dl(out, lab)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    scale = (128.0 / s) ** 3 if s != 128 else 1.0
+    return {"value": 1.0 / (dt * scale), "unit": "volumes/s", "cores": cores, "kind": "reference",
+            "sample": f"1 volume 1x1x{s}^3 fwd+loss+bwd, /root/reference model.dim3.unet.UNet + CE + DiceLoss, fp32, "
+                      f"torch {torch.__version__} CPU, {dt:.1f} s" + ("" if s == 128 else f" (scaled x{scale:.2f} to 128^3)")}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,6 +170,12 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+    elif args.ddp1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     import cbim_amd
     from cbim_amd import _lib, ops
@@ -153,14 +200,14 @@ def main():
     w = torch.ones(args.classes)
     w[0] = 0.5
     crit = DiceCELoss(w).to(dev)
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph)
     if args.optim == "fused":
         from cbim_amd.training.optim import FusedAdamW
         opt = FusedAdamW(net.parameters(), lr=6e-4, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5)
     else:
         opt = torch.optim.AdamW(net.parameters(), lr=6e-4, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5, fused=True,
                                 capturable=use_graph)
-    ddp = GradAllReduce(net) if world > 1 else None
+    ddp = GradAllReduce(net) if dist.is_initialized() else None
     x, lab = synthetic(1, args.classes, args.size, dev, 2023 + rank)
     if in_ch > 1:
         x = torch.cat([x] + [synthetic(1, args.classes, args.size, dev, 3000 + rank + i)[0] for i in range(in_ch - 1)], 1)
@@ -205,18 +252,28 @@ def main():
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-            opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph, stream=side):
-                static_loss = eager_step()
-        torch.cuda.current_stream().wait_stream(side)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+                opt.zero_grad(set_to_none=True)
+                # the RCCL collectives of the gradient exchange are captured with the kernels (N > 1): every rank
+                # captures and replays the same sequence
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if ddp is not None else "global"):
+                    static_loss = eager_step()
+            torch.cuda.current_stream().wait_stream(side)
 
-        def step():
-            graph.replay()
-            return static_loss
-        step()
+            def step():
+                graph.replay()
+                return static_loss
+            step()
+        except Exception as e:   # capture refused (e.g. an RCCL build without graph support): eager launches
+            if rank == 0:
+                print(f"bench.py: hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            torch.cuda.synchronize()
+            use_graph = False
+            step = eager_step
+            step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -246,7 +303,7 @@ def main():
                                + f", 1x{in_ch}x{args.size}^3 per GPU, {args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
                                + (", HBM-resident volumes + on-device augmentation (crop/affine/intensity, dataset_amos_ct recipe) prefetched on a side stream" if args.aug else "")
                                + (" (hipGraph replay)" if use_graph else "")
-                               + (", bucketed grad all-reduce (RCCL)" if world > 1 else ""),
+                               + (", bucketed in-place grad all-reduce (RCCL)" if ddp is not None else ""),
                    "global_batch": world, "parallelism": f"dp{world}", "final_loss": loss_val},
     }
 
@@ -295,7 +352,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

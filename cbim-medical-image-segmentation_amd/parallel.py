@@ -5,10 +5,15 @@ The reference's only parallelism is ``torch.nn.parallel.DistributedDataParallel`
 ``/root/reference/train_ddp.py:353`` (one replica per GPU, gradient all-reduce(mean) per step,
 ``find_unused_parameters=True``).  The models here have no unused parameters, so
 the exchange is static: parameters are grouped into fixed buckets in REVERSE registration order
-(the order the backward produces them: decoder first); when the last gradient of a bucket has
-been accumulated its flat buffer is all-reduced asynchronously on the process group's own
-stream while the backward of the earlier layers keeps the compute stream busy.
-``backend="nccl"`` is RCCL on ROCm; the same code runs on ``gloo`` for the CPU tests.
+(the order the backward produces them: decoder first); every bucket owns ONE flat fp32 buffer and
+``param.grad`` IS a view into it: a gradient that arrives from autograd is copied once into its slot
+(no ``torch.cat``, no copy back), and when the last gradient of a bucket has landed the flat buffer
+is all-reduced IN PLACE, asynchronously, on the process group's own stream while the backward of
+the earlier layers keeps the compute stream busy.  The optimizer then reads the averaged
+gradients straight from the views.  ``backend="nccl"`` is RCCL on ROCm; the same code runs on
+``gloo`` for the CPU tests.  Everything here is stream-ordered device work (copies, RCCL
+collectives, stream waits), so a whole training step including the exchange can be captured in
+one hipGraph (bench.py does that for N > 1 as it does for N = 1).
 
 Sizing for xGMI (7 links x ~153 GB/s per GPU, point to point): a 162 MB fp32 gradient set in
 ~6 buckets of 32 MB keeps each ring transfer per-link bound at >= 4 MB per step of the ring,
@@ -17,6 +22,7 @@ only one not hidden behind compute.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import List
 
 import torch
@@ -24,14 +30,16 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("params", "numel", "pending", "flat", "work")
+    __slots__ = ("params", "offsets", "numel", "pending", "flat", "work", "fired")
 
     def __init__(self):
         self.params: List[torch.nn.Parameter] = []
+        self.offsets: List[int] = []
         self.numel = 0
         self.pending = 0
         self.flat = None
         self.work = None
+        self.fired = False
 
 
 class GradAllReduce:
@@ -39,9 +47,19 @@ class GradAllReduce:
 
         ddp = GradAllReduce(net)              # after net.to(device); broadcasts rank-0 weights
         loss.backward()                       # buckets fire as their gradients complete
-        ddp.synchronize()                     # wait + write the averaged gradients back (parameters that got no
-                                              # gradient are skipped, like find_unused_parameters=True)
+        ddp.synchronize()                     # wait; param.grad (views of the flat buffers) now hold the averages
+                                              # (parameters that got no gradient keep grad None, like
+                                              # find_unused_parameters=True)
         optimizer.step()
+
+    Gradient accumulation over several backward passes (DistributedDataParallel.no_sync semantics)::
+
+        with ddp.no_sync():
+            loss_a.backward()                 # accumulates locally, nothing is exchanged
+        loss_b.backward()                     # the exchange happens in the last backward
+        ddp.synchronize()
+
+    Every backward outside ``no_sync`` must be followed by ``synchronize()`` before the next one.
     """
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 32.0, process_group=None,
@@ -49,6 +67,9 @@ class GradAllReduce:
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._exchange = dist.is_initialized()      # a 1-rank group still runs the collective (tests, graph capture)
+        self._sync = True
+        self._accumulated = False                   # a no_sync backward has left partial sums in the views
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast_parameters and self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
@@ -57,60 +78,87 @@ class GradAllReduce:
         self.buckets: List[_Bucket] = []
         cur = _Bucket()
         for p in reversed(params):
+            if p.dtype != torch.float32:
+                raise TypeError("cbim_amd: GradAllReduce expects float32 master parameters")
             if cur.params and cur.numel + p.numel() > cap:
                 self.buckets.append(cur)
                 cur = _Bucket()
             cur.params.append(p)
-            cur.numel += p.numel()
+            cur.offsets.append(cur.numel)
+            cur.numel += (p.numel() + 3) // 4 * 4          # 16-byte aligned slots
         if cur.params:
             self.buckets.append(cur)
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None    # gloo has no AVG: SUM, then scale
         self._owner = {}
+        self._views = {}
         self._handles = []
         for b in self.buckets:
+            dev = b.params[0].device
+            b.flat = torch.zeros((b.numel,), dtype=torch.float32, device=dev)
             b.pending = len(b.params)
-            for p in b.params:
+            for p, off in zip(b.params, b.offsets):
                 self._owner[p] = b
+                self._views[p] = b.flat[off:off + p.numel()].view_as(p)
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     # -- hooks ------------------------------------------------------------------------------------------
     def _on_grad(self, p: torch.nn.Parameter):
         b = self._owner[p]
+        view = self._views[p]
+        g = p.grad
+        if g is not view:                       # fresh tensor from autograd (grad was None): move it into its slot
+            if self._accumulated:
+                view.add_(g)
+            else:
+                view.copy_(g)
+            p.grad = view
+        # else: autograd accumulated in place into the view (grad was already the view)
+        if not self._sync:
+            return
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
 
     def _launch(self, b: _Bucket):
-        if self.world == 1:
+        b.fired = True
+        b.pending = len(b.params)
+        if not self._exchange:
             return
-        b.flat = torch.cat([p.grad.reshape(-1) for p in b.params])
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        op = self._avg_op if self._avg_op is not None else dist.ReduceOp.SUM
+        b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside accumulate gradients locally; the first backward after the block exchanges the sums."""
+        old = self._sync
+        self._sync = False
+        try:
+            yield
+        finally:
+            self._sync = old
+            self._accumulated = True
 
     def synchronize(self):
-        """Wait for every bucket and write the averaged gradients back into ``param.grad``."""
+        """Wait for every bucket; ``param.grad`` (a view of the bucket's flat buffer) then holds the average."""
         for b in self.buckets:
-            if b.pending != 0 and self.world > 1:
+            if not b.fired:
                 # some parameters of this bucket received no gradient in this step (the reference wraps with
                 # DistributedDataParallel(find_unused_parameters=True), train_ddp.py:353; e.g. AttentionUNet's unused
                 # conv_ch): the bucket never fired from the hooks — exchange it now, zeros standing in for the
                 # missing gradients (every rank sees the same graph, so every rank takes this branch)
-                b.flat = torch.cat([p.grad.reshape(-1) if p.grad is not None
-                                    else torch.zeros(p.numel(), dtype=p.dtype, device=p.device) for p in b.params])
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                for p in b.params:
+                    if p.grad is None:
+                        self._views[p].zero_()
+                self._launch(b)
             if b.work is not None:
                 b.work.wait()
-                b.flat.div_(self.world)
-                off = 0
-                dst, views = [], []
-                for p in b.params:
-                    if p.grad is not None:
-                        dst.append(p.grad)
-                        views.append(b.flat[off:off + p.numel()].view_as(p.grad))
-                    off += p.numel()
-                if dst:
-                    torch._foreach_copy_(dst, views)
                 b.work = None
-                b.flat = None
+                if self._avg_op is None and self.world > 1:
+                    b.flat.div_(self.world)
+            b.fired = False
             b.pending = len(b.params)
+        self._accumulated = False
 
     def remove(self):
         for h in self._handles:

@@ -154,3 +154,97 @@ def test_data_parallel_training_steps_match_single_process():
         d = (torch.from_numpy(a) - p.detach()).abs()
         assert float(d.max()) <= 3 * 2 * 1e-2 + 1e-6
         assert float((d > 1e-3).float().mean()) < 0.02
+
+
+# ---- replicas that run the ENGINE (the kernel sources on the host-side executor), not the oracle ------------------
+
+def _engine_net():
+    import cbim_amd
+    from cbim_amd.model.dim3 import UNet
+    cbim_amd.set_compute_dtype("fp32")
+    torch.manual_seed(9)
+    return UNet(1, 4, scale=[[1, 2, 2]] * 4, kernel_size=[[3, 3, 3]] * 5, num_classes=3, block="BasicBlock", norm="in")
+
+
+def _engine_data(rank):
+    g = torch.Generator().manual_seed(200 + rank)
+    return torch.randn(1, 1, 2, 16, 16, generator=g), torch.randint(0, 3, (1, 1, 2, 16, 16), generator=g)
+
+
+def _worker_engine(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cbim_amd.parallel import GradAllReduce
+    from cbim_amd.training.losses import DiceCELoss
+    from cbim_amd.training.optim import FusedAdamW
+    net = _engine_net()
+    ddp = GradAllReduce(net, bucket_mb=0.002)     # several buckets
+    assert len(ddp.buckets) > 3
+    opt = FusedAdamW(net.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5)
+    crit = DiceCELoss(torch.tensor([0.5, 1.0, 1.0]))
+    x, lab = _engine_data(rank)
+    grads = None
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        crit(net(x), lab).backward()
+        ddp.synchronize()
+        if it == 0:
+            grads = [p.grad.clone().numpy() for p in net.parameters()]
+            # param.grad IS a view of the bucket's flat buffer: no copy back after the exchange
+            assert all(p.grad.data_ptr() == ddp._views[p].data_ptr() for p in net.parameters())
+        opt.step()
+    # gradient accumulation: the no_sync backward stays local, the next one exchanges the SUM of both
+    opt.zero_grad(set_to_none=True)
+    with ddp.no_sync():
+        crit(net(x), lab).backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    crit(net(x), lab).backward()
+    ddp.synchronize()
+    acc = [p.grad.clone().numpy() for p in net.parameters()]
+    q.put((rank, grads, [p.detach().numpy() for p in net.parameters()], [l.numpy() for l in local], acc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_engine_replicas_exchange_gradients_in_place():
+    """world_size 2, gloo: both replicas run the HIP kernel sources (host-side executor) end to end — forward, fused
+    Dice+CE, backward, bucketed in-place all-reduce, fused AdamW — and must agree with one process that averages the two
+    volumes' gradients itself."""
+    if not os.environ.get("CBIM_HIP_LIBRARY"):
+        pytest.skip("needs the host-side kernel executor (CPU suite)")
+    from cbim_amd.training.losses import DiceCELoss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_engine, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, g, w, loc, acc = q.get(timeout=900)
+        got[r] = (g, w, loc, acc)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    # single process: mean of the two volumes' gradients at the initial weights
+    crit = DiceCELoss(torch.tensor([0.5, 1.0, 1.0]))
+    ref = None
+    for r in range(2):
+        net = _engine_net()
+        x, lab = _engine_data(r)
+        crit(net(x), lab).backward()
+        gs = [p.grad.clone() for p in net.parameters()]
+        ref = gs if ref is None else [a + b for a, b in zip(ref, gs)]
+    for a, b, g in zip(got[0][0], got[1][0], ref):
+        assert (a == b).all()                                   # both ranks hold the same averaged gradient
+        assert torch.allclose(torch.from_numpy(a), g / 2, rtol=1e-5, atol=1e-7)
+    for a, b in zip(got[0][1], got[1][1]):
+        assert (a == b).all()                                   # replicas stay bit-identical after the optimizer steps
+    # no_sync: averaged (local sum over the two backward passes) == 2 x the per-pass mean gradient over ranks
+    for r in range(2):
+        assert all(np_l.any() for np_l in got[r][2][:3])
+    mean_local = [(torch.from_numpy(a) + torch.from_numpy(b)) / 2 for a, b in zip(got[0][2], got[1][2])]
+    for acc, ml in zip(got[0][3], mean_local):
+        assert torch.allclose(torch.from_numpy(acc), 2 * ml, rtol=1e-4, atol=1e-6)
