@@ -132,15 +132,33 @@ def cpu_baseline(args):
 
 def _reference_cpu_baseline(args, cores):
     """The reference's own UNet + CrossEntropyLoss + DiceLoss on the host cores."""
+    # the reference's package __init__ files import the whole model zoo (monai, torchvision: not installed): the
+    # import shim of SURVEY.md §8c (also used by tests/golden/make_golden.py) registers the two packages as bare
+    # namespaces, so only model/dim3/unet.py and its own imports are executed — unmodified reference code
+    import importlib
+    import types
+    ref = "/root/reference"
+    saved = {k: sys.modules.get(k) for k in ("model", "model.dim3", "training", "training.losses")}
     try:
-        sys.path.insert(0, "/root/reference")
-        from model.dim3.unet import UNet as RefUNet
-        from training.losses import DiceLoss as RefDice
+        sys.path.insert(0, ref)
+        for name, path in (("model", f"{ref}/model"), ("model.dim3", f"{ref}/model/dim3")):
+            pkg = types.ModuleType(name)
+            pkg.__path__ = [path]
+            sys.modules[name] = pkg
+        for missing in ("torchvision", "torchvision.transforms"):
+            sys.modules.setdefault(missing, types.ModuleType(missing))
+        RefUNet = importlib.import_module("model.dim3.unet").UNet
+        RefDice = importlib.import_module("training.losses").DiceLoss
     except Exception:
         return None
     finally:
-        if sys.path and sys.path[0] == "/root/reference":
-            sys.path.pop(0)
+        if ref in sys.path:
+            sys.path.remove(ref)
+        for k, v in saved.items():           # this repository has packages of the same names: leave no trace
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
     torch.manual_seed(2023)
     s = args.cpu_size
     net = RefUNet(1, args.base, scale=[[2, 2, 2]] * 4, kernel_size=[[3, 3, 3]] * 5, num_classes=args.classes,
