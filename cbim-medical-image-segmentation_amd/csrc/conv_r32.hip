@@ -31,12 +31,32 @@
 
 namespace cbim {
 
-static constexpr int R_NT = 512;
-static constexpr int R_NW = 8;
 static constexpr int R_RB = 64;                 // bytes per halo row (32 bf16 channels)
-static constexpr int R_HROWS = 1000;            // 10 x 10 x 10
-static constexpr unsigned R_HBUF = 65536;       // one halo buffer (64000 B used; items 4000..4095 are padding)
-static constexpr int R_UH = 8;                  // 16-byte halo items per thread (4096 / 512)
+// Geometry by tile depth TD.  TD = 8: 8x8x8 tile, 512 threads, ONE workgroup per CU (2 x 64 KiB of halo).
+// TD = 4: 4x8x8 tile, 256 threads, TWO workgroups per CU (2 x 40 KiB of halo each, 80 KiB per workgroup): each SIMD then
+// hosts one wave of each workgroup, the two workgroups drift apart, and one's epilogue / halo transform (vector ALU
+// and memory) overlaps the other's MFMA loop — with one workgroup per CU all eight waves leave the MFMA loop together
+// at the tile barrier and the matrix pipes idle through every epilogue.
+template <int TD> struct RGeom {
+  static constexpr int NT = TD == 8 ? 512 : 256;
+  static constexpr int NW = NT / 64;
+  static constexpr int HP = TD == 8 ? 1 : 2;                 // (h-pair) patches of 2x8 voxels per wave and plane
+  static constexpr int HROWS = (TD + 2) * 100;               // halo rows: (TD+2) x 10 x 10
+  static constexpr int ITEMS = HROWS * 4;                    // 16-byte items
+  static constexpr int UH = (ITEMS + NT - 1) / NT;           // items per thread: 8 / 10
+  static constexpr int PIECES = (ITEMS + 63) / 64;           // 1 KiB LDS-DMA pieces: 63 / 38
+  static constexpr unsigned HBUF = (unsigned)UH * NT * 16;   // bytes reserved per halo buffer: 65536 / 40960
+  static constexpr unsigned TAB = 1536 + 256 + 256;          // statistics scratch + two (mean, rstd) tables
+  // TD = 8: tables after the two buffers; TD = 4: in the tail of buffer 1 that no LDS-DMA piece touches
+  static constexpr unsigned TAB_BASE = TD == 8 ? 2 * HBUF : 2 * HBUF - TAB;
+  // TD = 8 only (there is no LDS left with two workgroups per CU): per halo item its byte offset from the halo box
+  // origin (u32) and its position (hd | hh << 4 | hw << 8 | exists << 12, u16), filled once per workgroup
+  static constexpr bool ITAB = TD == 8;
+  static constexpr unsigned ITAB_BASE = 2 * HBUF + TAB;
+  static constexpr unsigned SMEM = TD == 8 ? 2 * HBUF + TAB + (unsigned)UH * NT * 6 : 2 * HBUF;
+  static_assert((unsigned)PIECES * 1024 + 1024 <= HBUF, "no room for the 1 KiB dump behind the pieces of buffer 0");
+  static_assert((unsigned)PIECES * 1024 <= HBUF - (TD == 8 ? 0 : TAB), "LDS-DMA pieces overlap the tables");
+};
 
 __device__ __attribute__((aligned(64))) unsigned int g_r32_zero[16];   // source of padding rows for the LDS-DMA
 
@@ -103,10 +123,14 @@ __device__ __forceinline__ void r_swap16(float& a, float& b) {
 #endif
 }
 
-// TR: the input is transformed (InstanceNorm + ACT) on its way into LDS (register path); !TR: LDS-DMA
+// TR: the input is transformed (InstanceNorm + ACT) in place in LDS after the LDS-DMA; !TR: used as it is
 // MX: dgrad epilogue (x act'(xh) mask + the two InstanceNorm-backward sums); !MX: forward epilogue (moments)
-template <int ACT, bool TR, bool MX>
-__global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
+// TD: tile depth 8 (one 512-thread workgroup per CU) or 4 (two 256-thread workgroups per CU), see RGeom
+template <int ACT, bool TR, bool MX, int TD>
+__global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R32Params p) {
+  typedef RGeom<TD> G;
+  constexpr int NT = G::NT, NW = G::NW, HP = G::HP, UH = G::UH;
+  constexpr unsigned HBUF = G::HBUF;
   R_DYN_SMEM(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lv = lane & 15, lq = lane >> 4;
   const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
@@ -115,13 +139,14 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
   const int t_begin = (int)(((long long)lb * n_tiles) / gridDim.x);
   const int t_end = (int)(((long long)(lb + 1) * n_tiles) / gridDim.x);
   if (t_begin >= t_end) return;
-  const unsigned red_base = 2 * R_HBUF;                     // [R_NW][16][3] floats
-  const unsigned mst_base = red_base + R_NW * 16 * 3 * 4;   // MX: (mean, rstd) of the 32 mask channels, 256 B
-  const unsigned ist_base = mst_base + 256;                 // TR: (mean, rstd) of the 32 input channels, 256 B
+  const unsigned red_base = G::TAB_BASE;              // [NW][16][3] floats
+  const unsigned mst_base = red_base + 1536;          // MX: (mean, rstd) of the 32 mask channels, 256 B
+  const unsigned ist_base = mst_base + 256;           // TR: (mean, rstd) of the 32 input channels, 256 B
 
   // ---- wave = (cout half ch, voxel group vg); lane = (voxel lv of a 2x8 patch, k-group / row-group lq) -----------
+  // TD = 8: 4 voxel groups of one h-pair; TD = 4: 2 voxel groups of two h-pairs.  n-tile nt = hp * TD + plane.
   const int ch = wave & 1, vg = wave >> 1;
-  const int tw = lv & 7, th = 2 * vg + (lv >> 3);
+  const int tw = lv & 7;
   // weights: fragment of tap tp = A operand [16 couts][32 channels]: lane (cout lv, channels 8*lq..+7) = 16 bytes of
   // the packed image [tap][kg = lq>>1][half = lq&1][32 couts][8]
   u32x4 wf[27];
@@ -138,23 +163,28 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
 #endif
   }
   // B operand (voxels): fragment of plane i at tap (kh, kw) = 16 bytes at row (i, th + kh, tw + kw), slot
-  // lq ^ r_swz(th + kh); base per kh, plane and kw are immediates (i * 6400 + kw * 64)
-  unsigned fb[3];
+  // lq ^ r_swz(th + kh); base per (h-pair, kh); plane and kw are immediates (i * 6400 + kw * 64)
+  int thp[HP];
+  unsigned fb[HP][3];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
-    fb[kh] = (unsigned)((th + kh) * 10 + tw) * R_RB + (((unsigned)lq ^ r_swz((unsigned)(th + kh))) << 4);
+  for (int hp = 0; hp < HP; ++hp) {
+    thp[hp] = 2 * (vg * HP + hp) + (lv >> 3);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+      fb[hp][kh] = (unsigned)((thp[hp] + kh) * 10 + tw) * R_RB + (((unsigned)lq ^ r_swz((unsigned)(thp[hp] + kh))) << 4);
+  }
 
-  // ---- halo items of this thread (the same for every tile): position inside the 10x10x10 box --------------------
-  // LDS-DMA item q = tid + 512 u is PHYSICAL (LDS byte q*16 = row q>>2, slot q&3), source slot = (q&3) ^ r_swz(hh)
+  // ---- halo items of this thread (the same for every tile): position inside the (TD+2)x10x10 box ---------------
+  // LDS-DMA item q = tid + NT u is PHYSICAL (LDS byte q*16 = row q>>2, slot q&3), source slot = (q&3) ^ r_swz(hh).
   // The position is decoded per tile from the laundered thread index (~10 VALU per item) instead of living in
   // registers next to the weights.
   auto item_pos = [&](unsigned tl, int u) -> unsigned {   // hd | hh << 8 | hw << 16 | exists << 24
-    const unsigned row = (tl + 512u * (unsigned)u) >> 2;
+    const unsigned row = (tl + (unsigned)NT * (unsigned)u) >> 2;
     const unsigned hd = (row * 5243u) >> 19;              // row / 100 for row < 1024
     const unsigned r2 = row - hd * 100u;
     const unsigned hh = (r2 * 205u) >> 11;                // r2 / 10 for r2 < 100
     const unsigned hw = r2 - hh * 10u;
-    return hd | (hh << 8) | (hw << 16) | (row < (unsigned)R_HROWS ? 1u << 24 : 0u);
+    return hd | (hh << 8) | (hw << 16) | (row < (unsigned)G::HROWS ? 1u << 24 : 0u);
   };
   const unsigned my_slot = (unsigned)tid & 3u;
 
@@ -171,29 +201,54 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
   }
 
   const unsigned x_sb = (unsigned)p.x_stride * 2u;
+  // per-item constants in LDS (TD = 8): decoding the position and multiplying out the offset for every item of every
+  // tile was ~50 vector/scalar instructions per item in which the wave issues no MFMA; with the table an item costs two
+  // LDS reads, the range test and a 64-bit add
+  unsigned* const tab_off = (unsigned*)(smem + G::ITAB_BASE);
+  unsigned short* const tab_pos = (unsigned short*)(smem + G::ITAB_BASE + (unsigned)UH * NT * 4);
+  if (G::ITAB) {
+#pragma unroll
+    for (int u = 0; u < UH; ++u) {
+      const unsigned pk = item_pos((unsigned)tid, u);
+      const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
+      const unsigned rel = r_mul24(r_mul24(hd, (unsigned)p.Hi) + hh, (unsigned)p.Wi) + hw;
+      tab_off[tid + NT * u] = r_mul24(rel, x_sb) + ((my_slot ^ r_swz(hh)) << 4);
+      tab_pos[tid + NT * u] = (unsigned short)(hd | (hh << 4) | (hw << 8) | ((pk >> 24) << 12));
+    }
+    // (read back by the same thread only: no barrier needed, the prologue has one anyway)
+  }
+  // position (hd, hh, hw, exists) and source offset of item u
+  auto item_get = [&](int u, unsigned& hd, unsigned& hh, unsigned& hw, bool& exists, unsigned& off) {
+    if (G::ITAB) {
+      const unsigned tl = r_launder((unsigned)tid);      // (keeps the loop-invariant reads inside the tile loop)
+      const unsigned ps = tab_pos[tl + NT * u];
+      off = tab_off[tl + NT * u];
+      hd = ps & 15u; hh = (ps >> 4) & 15u; hw = (ps >> 8) & 15u; exists = (ps >> 12) != 0;
+    } else {
+      const unsigned pk = item_pos(r_launder((unsigned)tid), u);
+      hd = pk & 255u; hh = (pk >> 8) & 255u; hw = (pk >> 16) & 255u; exists = (pk >> 24) != 0;
+      off = r_mul24(r_mul24(r_mul24(hd, (unsigned)p.Hi) + hh, (unsigned)p.Wi) + hw, x_sb) + ((my_slot ^ r_swz(hh)) << 4);
+    }
+  };
   // source address of halo item u of tile `tp` (in range: the tensor; padding: 64 zero bytes) ---------------------
-  struct Src { const unsigned char* ptr; bool ld; unsigned pk; };
-  auto item_src = [&](const TilePos& tp, int u) -> Src {
-    const int id0 = tp.td * 8 - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
+  auto item_src = [&](const TilePos& tp, int u) -> const unsigned char* {
+    const int id0 = tp.td * TD - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
     const long long org = (((long long)tp.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0;
     const unsigned char* tbase = (const unsigned char*)p.x + org * (long long)x_sb;   // wave-uniform
-    const unsigned pk = item_pos(r_launder((unsigned)tid), u);
-    const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
-    const bool ld = !(p.dbg & 1) && (pk >> 24) != 0 && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
+    unsigned hd, hh, hw, off;
+    bool exists;
+    item_get(u, hd, hh, hw, exists, off);
+    const bool ld = !(p.dbg & 1) && exists && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
                     (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
-    const unsigned rel = r_mul24(r_mul24(hd, (unsigned)p.Hi) + hh, (unsigned)p.Wi) + hw;
-    const unsigned slot = my_slot ^ r_swz(hh);
-    const unsigned off = ld ? r_mul24(rel, x_sb) + slot * 16u : 0u;
-    Src r;
-    r.ptr = (ld ? tbase : (const unsigned char*)g_r32_zero) + off;
-    r.ld = ld;
-    r.pk = pk;
-    return r;
+    return (ld ? tbase : (const unsigned char*)g_r32_zero) + (ld ? off : 0u);
   };
-  // DMA path: item u of tile `tp` into LDS buffer `buf` (an asynchronous 1 KiB piece per wave)
+  // item u of tile `tp` into LDS buffer `buf` (an asynchronous 1 KiB piece per wave).  A piece that lies wholly past
+  // the box (last u of the upper waves) copies zeros into a 1 KiB dump at the end of buffer 0 that nothing reads:
+  // no branch, and every wave has the same number of pieces in flight (the TR path counts them).
   auto dma_item = [&](const TilePos& tp, int u, unsigned buf) {
-    const Src sr = item_src(tp, u);
-    r_dma16(sr.ptr, smem + buf + (unsigned)(wave * 64 + 512 * u) * 16);
+    const bool past = (wave * 64 + NT * u) >= G::PIECES * 64;     // wave-uniform
+    const unsigned char* src = item_src(tp, u);                   // (items past the box: the zero page)
+    r_dma16(src, smem + (past ? (unsigned)G::PIECES * 1024u : buf + (unsigned)(wave * 64 + NT * u) * 16));
   };
   // TR path: the raw halo arrives by the same LDS-DMA; a wave transforms IN PLACE exactly the 1 KiB pieces it has
   // fetched itself (lane = the piece's 16-byte item), so the only ordering needed is the wave's own counted vmcnt —
@@ -203,13 +258,14 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
   auto tr_xform = [&](const TilePos& tp, int u, unsigned buf) {
     typedef float f2_t __attribute__((ext_vector_type(2)));
     typedef short s2_t __attribute__((ext_vector_type(2)));
-    const int id0 = tp.td * 8 - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
-    const unsigned pk = item_pos(r_launder((unsigned)tid), u);
-    const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
-    const bool ld = (pk >> 24) != 0 && (unsigned)(id0 + (int)hd) < (unsigned)p.Di && (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi &&
+    const int id0 = tp.td * TD - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
+    unsigned hd, hh, hw, off;
+    bool exists;
+    item_get(u, hd, hh, hw, exists, off);
+    const bool ld = exists && (unsigned)(id0 + (int)hd) < (unsigned)p.Di && (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi &&
                     (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
-    {
-      unsigned char* cell = smem + buf + ((unsigned)tid + 512u * (unsigned)u) * 16u;
+    if (exists) {                                     // (items past the box do not exist in LDS)
+      unsigned char* cell = smem + buf + ((unsigned)tid + (unsigned)NT * (unsigned)u) * 16u;
       const float* is = (const float*)(smem + ist_base) + ((my_slot ^ r_swz(hh)) << 4);   // logical chunk of this cell
       const u32x4 raw = *(const u32x4*)cell;
       const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -227,14 +283,15 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
           h = __builtin_elementwise_max(h, z);      // a negative bf16 is a negative int16
           o = __builtin_bit_cast(unsigned, h);
         }
-        ow[j] = ld ? o : 0u;                        // padding cells (zeros from the DMA) stay zero: no branch
+        ow[j] = ld ? o : 0u;                        // padding cells (zeros from the DMA) stay zero
       }
       *(u32x4*)cell = u32x4{ow[0], ow[1], ow[2], ow[3]};
     }
   };
   auto wait_vm = [&](int n) {   // at most n vector-memory operations of this wave still in flight
 #ifndef CBIM_EMU
-    if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -286,7 +343,7 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
     __syncthreads();
     if (tid < 32 && tid < p.Cout) {
       Moments a = {0.f, 0.f, 0.f};
-      for (int g = 0; g < 4; ++g) {   // the four voxel groups of this channel's cout half
+      for (int g = 0; g < NW / 2; ++g) {   // the voxel groups of this channel's cout half
         const float* rr = red + (((2 * g + (tid >> 4)) * 16) + (tid & 15)) * 3;
         if (MX) { a.mean += rr[1]; a.m2 += rr[2]; }
         else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
@@ -330,19 +387,19 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
   load_istats(cur.n);
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < R_UH; ++u) dma_item(cur, u, 0);
+  for (int u = 0; u < UH; ++u) dma_item(cur, u, 0);
   r_wait_vm0();
   __syncthreads();
   if (TR) {
 #pragma unroll
-    for (int u = 0; u < R_UH; ++u) tr_xform(cur, u, 0);
+    for (int u = 0; u < UH; ++u) tr_xform(cur, u, 0);
     __syncthreads();
   }
 
   r_f32x4 acc[8];
   const int n_my = t_end - t_begin;
   for (int t = 0; t < n_my; ++t) {
-    const unsigned buf = (unsigned)(t & 1) * R_HBUF, obuf = R_HBUF - buf;
+    const unsigned buf = (unsigned)(t & 1) * HBUF, obuf = HBUF - buf;
     const bool more = t + 1 < n_my;
     // the next tile's transforms run during THIS tile: at an image change the statistics table is rewritten first (no
     // reader is active here: the previous tile's transforms ended before its barrier)
@@ -351,56 +408,89 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
     nx.n = more ? nxt.n : cur.n; nx.td = more ? nxt.td : cur.td; nx.th = more ? nxt.th : cur.th; nx.tw = more ? nxt.tw : cur.tw;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) acc[nt] = r_f32x4{0.f, 0.f, 0.f, 0.f};
-    // (B) 9 (kh, kw) steps: the 10 plane fragments stream through a ring of 5 registers, plane i feeds the MFMAs
-    //     (n-tile i, kd 0), (i-1, kd 1), (i-2, kd 2).  One halo item of the next tile is handled per step: DMA item
-    //     s is issued at step s; TR item s is loaded at step s and transformed + stored at step s+1.
+    // (B) 9 (kh, kw) steps x HP patches: the TD+2 plane fragments of a patch stream through a ring of 5 registers,
+    //     plane i feeds the MFMAs (n-tile i, kd 0), (i-1, kd 1), (i-2, kd 2).  The halo of the next tile is fetched by
+    //     LDS-DMA during the first steps; TR: a piece is transformed in place four steps after its fetch.
+    //     Branch-free (the strip's last tile re-fetches itself into the idle buffer).
     if (!(p.dbg & 2)) {
-      constexpr int RING = 5;
+      constexpr int RING = 5, PLN = TD + 2, SEQ = 9 * HP * PLN;   // fragment reads of a tile, in order
       u32x4 xr[RING];
+      auto frag_addr = [&](int e) -> unsigned {                   // e = ((kh*3 + kw) * HP + hp) * PLN + plane
+        const int i = e % PLN, hp = (e / PLN) % HP, s = e / (PLN * HP);
+        return buf + fb[hp][s / 3] + (unsigned)((s % 3) * R_RB) + (unsigned)(i * 100 * R_RB);
+      };
 #pragma unroll
-      for (int i = 0; i < RING - 1; ++i) xr[i] = *(const u32x4*)(smem + buf + fb[0] + (unsigned)(i * 100 * R_RB));
+      for (int e = 0; e < RING - 1; ++e) xr[e] = *(const u32x4*)(smem + frag_addr(e));
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
         const int kh = s / 3, kw = s % 3;
-        const unsigned base = buf + fb[kh] + (unsigned)(kw * R_RB);
-        const unsigned base_n = buf + fb[(s + 1) / 3 % 3] + (unsigned)(((s + 1) % 3) * R_RB);
-        // the next tile's halo: LDS-DMA pieces during the first steps (TR: transformed in place four steps later).
-        // Branch-free (the strip's last tile re-fetches itself into the idle buffer) so that this code sits in the same
-        // basic block as the step's MFMAs and can be interleaved with them.
         {
-          if (TR) {
-            // pieces 2s, 2s+1 are fetched at step s < 4 and transformed at step s + 4 (own pieces only: the wave's
-            // counted vmcnt — 6, 4, 2, 0 younger pieces may still be in flight — is the whole synchronisation)
-            if (s < 4) { dma_item(nx, 2 * s, obuf); dma_item(nx, 2 * s + 1, obuf); }
-            if (s >= 4 && s < 8) {
-              wait_vm(6 - 2 * (s - 4));
-              tr_xform(nx, 2 * (s - 4), obuf);
-              tr_xform(nx, 2 * (s - 4) + 1, obuf);
+          // per-step share of the next tile's halo work: UH items over 9 steps.  DMA: items 2s, 2s+1 in the first
+          // steps; TR: transform of items 2(s-4).. four steps later (own pieces: counted vmcnt is the whole sync)
+          constexpr int FS = (UH + 1) / 2;                   // fetch steps: 4 / 5
+          if (s < FS) {
+            dma_item(nx, 2 * s, obuf);
+            if (2 * s + 1 < UH) dma_item(nx, 2 * s + 1, obuf);
+          }
+          if (TR && s >= 9 - FS) {
+            const int k = s - (9 - FS);                      // 0 .. FS-1: transforms items 2k, 2k+1
+            wait_vm(UH - 2 * k - 2 > 0 ? UH - 2 * k - 2 : 0);
+            tr_xform(nx, 2 * k, obuf);
+            if (2 * k + 1 < UH) tr_xform(nx, 2 * k + 1, obuf);
+          }
+        }
+#pragma unroll
+        for (int hp = 0; hp < HP; ++hp) {
+#pragma unroll
+          for (int i = 0; i < PLN; ++i) {
+            const int e = (s * HP + hp) * PLN + i;
+            // read RING-1 entries ahead; the fences keep the compiler from sinking the read next to its use (it then
+            // waits a full LDS round trip every third MFMA: measured 57 % of the MFMA rate)
+            if (e + RING - 1 < SEQ && !(p.dbg & 128)) xr[(e + RING - 1) % RING] = *(const u32x4*)(smem + frag_addr(e + RING - 1));
+            R_SCHED_FENCE();
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+              const int pl = i - kd;
+              if (pl >= 0 && pl < TD)
+                acc[hp * TD + pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[(kd * 3 + kh) * 3 + kw]),
+                                                                            __builtin_bit_cast(bf16x8, xr[e % RING]), acc[hp * TD + pl], 0, 0, 0);
             }
-          } else if (s < R_UH) {
-            dma_item(nx, s, obuf);
+            R_SCHED_FENCE();
           }
         }
-        // plane i+4 (of this step, or of the next one: the ring runs across steps) is requested before the MFMAs of
-        // plane i issue; the fences keep the compiler from sinking the read next to its use (it then waits a full LDS
-        // round trip every third MFMA: measured 57 % of the MFMA rate).  (A sched_group_barrier pattern over the whole
-        // step was tried instead of the fences: the inline-asm LDS-DMA splits the scheduling region and the reads
-        // sink again.)
+      }
+    }
+    // epilogue operands (mask / residual rows of the lane's four output voxels): requested BEFORE the tile barrier, so
+    // their memory latency overlaps the barrier and the wait for the LDS-DMA (requested inside the epilogue, one pair
+    // ahead, every pair paid most of a global-memory round trip: the epilogue was 38 % of the masked dgrad)
+    const int n = cur.n;
+    const int od0 = cur.td * TD, oh0 = cur.th * 8, ow0 = cur.tw * 8;
+    const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
+    const unsigned y_sb = (unsigned)p.y_stride * 2u, res_sb = (unsigned)p.res_stride * 2u, mx_sb = (unsigned)p.mx_stride * 2u;
+    unsigned char* y_tile = (unsigned char*)p.y + orow * (long long)y_sb;
+    const unsigned char* res_tile = (const unsigned char*)p.res + orow * (long long)res_sb;
+    const unsigned char* mx_tile = (const unsigned char*)p.mx + orow * (long long)mx_sb;
+    const unsigned plane2 = 2u * r_mul24((unsigned)p.Ho, (unsigned)p.Wo);
+    const unsigned cb = (unsigned)cidx * 16u;
+    // after the exchange this lane owns, for pair pr = (hp, pp): chunk cidx of voxel (2pp + (lq&1), th(hp), tw)
+    constexpr int NPAIR = 4;                               // 8 n-tiles
+    auto pair_rel = [&](int pr) -> unsigned {
+      const int hp = pr / (TD / 2), pp = pr % (TD / 2);
+      return r_mul24(r_mul24((unsigned)(lq & 1), (unsigned)p.Ho) + (unsigned)thp[hp], (unsigned)p.Wo) + (unsigned)tw + (unsigned)pp * plane2;
+    };
+    auto pair_in = [&](int pr) -> bool {
+      const int hp = pr / (TD / 2), pp = pr % (TD / 2);
+      return oh0 + thp[hp] < p.Ho && ow0 + tw < p.Wo && od0 + 2 * pp + (lq & 1) < p.Do;
+    };
+    u32x4 rq[NPAIR];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-          const int j = i + RING - 1;
-          if (j < 10) xr[j % RING] = *(const u32x4*)(smem + base + (unsigned)(j * 100 * R_RB));
-          else if (s + 1 < 9) xr[j % RING] = *(const u32x4*)(smem + base_n + (unsigned)((j - 10) * 100 * R_RB));
-          R_SCHED_FENCE();
-#pragma unroll
-          for (int kd = 0; kd < 3; ++kd) {
-            const int nt = i - kd;
-            if (nt >= 0 && nt < 8)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[(kd * 3 + kh) * 3 + kw]),
-                                                                __builtin_bit_cast(bf16x8, xr[i % RING]), acc[nt], 0, 0, 0);
-          }
-          R_SCHED_FENCE();
-        }
+    for (int pr = 0; pr < NPAIR; ++pr) {
+      const bool in = pair_in(pr) && c_ok && !(p.dbg & (4 | 8));
+      const unsigned rel = pair_rel(pr);
+      rq[pr] = u32x4{0u, 0u, 0u, 0u};
+      if (in) {
+        if (MX) rq[pr] = *(const u32x4*)(mx_tile + (r_mul24(rel, mx_sb) + cb));
+        else if (p.res) rq[pr] = *(const u32x4*)(res_tile + (r_mul24(rel, res_sb) + cb));
       }
     }
     // (D) ONE barrier per tile: every wave is done with `buf`, the other buffer is complete (own LDS-DMA waited for,
@@ -411,42 +501,18 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
     // (C) epilogue of this tile — no barrier inside (except at an image change); its stores drain under the next
     //     tile's MFMAs
     if (!(p.dbg & 4)) {
-      const int n = cur.n;
       if (want_part && n != run_n) { flush_stats(run_n); run_n = n; }
-      const int od0 = cur.td * 8, oh0 = cur.th * 8, ow0 = cur.tw * 8;
-      const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
-      const unsigned y_sb = (unsigned)p.y_stride * 2u, res_sb = (unsigned)p.res_stride * 2u, mx_sb = (unsigned)p.mx_stride * 2u;
-      unsigned char* y_tile = (unsigned char*)p.y + orow * (long long)y_sb;
-      const unsigned char* res_tile = (const unsigned char*)p.res + orow * (long long)res_sb;
-      const unsigned char* mx_tile = (const unsigned char*)p.mx + orow * (long long)mx_sb;
-      const bool hw_ok = oh0 + th < p.Ho && ow0 + tw < p.Wo;
-      // after the exchange this lane owns, for the plane pair (2pp, 2pp+1), chunk cidx of voxel (2pp + (lq&1), th, tw)
-      const unsigned rel0 = r_mul24(r_mul24((unsigned)(lq & 1), (unsigned)p.Ho) + (unsigned)th, (unsigned)p.Wo) + (unsigned)tw;
-      const unsigned plane2 = 2u * r_mul24((unsigned)p.Ho, (unsigned)p.Wo);
-      const unsigned cb = (unsigned)cidx * 16u;
-      u32x4 rq[2];
-      auto ep_load = [&](int pp, u32x4& q) {
-        const bool in = hw_ok && od0 + 2 * pp + (lq & 1) < p.Do && c_ok && !(p.dbg & 8);
-        const unsigned rel = rel0 + (unsigned)pp * plane2;
-        q = u32x4{0u, 0u, 0u, 0u};
-        if (in) {
-          if (MX) q = *(const u32x4*)(mx_tile + (r_mul24(rel, mx_sb) + cb));
-          else if (p.res) q = *(const u32x4*)(res_tile + (r_mul24(rel, res_sb) + cb));
-        }
-      };
-      ep_load(0, rq[0]);
 #pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {
-        if (pp + 1 < 4) ep_load(pp + 1, rq[(pp + 1) & 1]);
-        const bool in = hw_ok && od0 + 2 * pp + (lq & 1) < p.Do;
-        const unsigned rel = rel0 + (unsigned)pp * plane2;
-        // accumulator register r of n-tile nt = channel 16*ch + 4*lq + r of voxel (plane nt, th, tw).  Swapping the
-        // registers of n-tile 2pp in the odd 16-lane rows with those of n-tile 2pp+1 in the even rows leaves the lane
-        // with 8 consecutive channels (chunk cidx) of ONE voxel: plane 2pp (lq even) / 2pp+1 (lq odd)
+      for (int pr = 0; pr < NPAIR; ++pr) {
+        const bool in = pair_in(pr);
+        const unsigned rel = pair_rel(pr);
+        // accumulator register r of n-tile nt = channel 16*ch + 4*lq + r of voxel (plane, th, tw).  Swapping the
+        // registers of the pair's first n-tile in the odd 16-lane rows with those of its second n-tile in the even
+        // rows leaves the lane with 8 consecutive channels (chunk cidx) of ONE voxel: plane 2pp (lq even) / 2pp+1 (odd)
         float v[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float a = acc[2 * pp][r], b = acc[2 * pp + 1][r];
+          float a = acc[2 * pr][r], b = acc[2 * pr + 1][r];
           r_swap16(a, b);
           v[r] = a;
           v[4 + r] = b;
@@ -456,7 +522,7 @@ __global__ void __launch_bounds__(R_NT, 1) k_conv3_r32(R32Params p) {
         typedef float f2_t __attribute__((ext_vector_type(2)));
         const float live = (in && c_ok) ? 1.f : 0.f;
         const f2_t live2 = {live, live};
-        const unsigned rw[4] = {rq[pp & 1].x, rq[pp & 1].y, rq[pp & 1].z, rq[pp & 1].w};
+        const unsigned rw[4] = {rq[pr].x, rq[pr].y, rq[pr].z, rq[pr].w};
         if (MX) {
           const float* ms = (const float*)(smem + mst_base) + cidx * 16;
 #pragma unroll
@@ -534,25 +600,41 @@ extern "C" int64_t cbim_conv_r32_min_voxels(int64_t v) {
   return old;
 }
 
-int64_t cbim_conv_r32_grid(const cbim_conv_desc* d) {
-  const int64_t n_tiles = (int64_t)d->N * ((d->Do + 7) / 8) * ((d->Ho + 7) / 8) * ((d->Wo + 7) / 8);
-  return n_tiles < 256 ? n_tiles : 256;
+// 8: one 512-thread workgroup per CU on 8x8x8 tiles (default); 4: two 256-thread workgroups per CU on 4x8x8 tiles —
+// measured 5-15 % slower on 32->32 @128^3 (more halo per voxel, and the MFMA phase, not the overlap, is what limits)
+static int g_r32_td = getenv("CBIM_CONV_R32_TD") && atoi(getenv("CBIM_CONV_R32_TD")) == 4 ? 4 : 8;
+static int r32_tile_depth() { return g_r32_td; }
+extern "C" int cbim_conv_r32_tile_depth(int td) {
+  const int old = g_r32_td;
+  if (td == 4 || td == 8) g_r32_td = td;
+  return old;
 }
 
-template <int ACT, bool TR, bool MX>
-static int r32_launch(const R32Params& p, dim3 grid, size_t smem, hipStream_t st) {
+int64_t cbim_conv_r32_grid(const cbim_conv_desc* d) {
+  const int td = r32_tile_depth();
+  const int64_t n_tiles = (int64_t)d->N * ((d->Do + td - 1) / td) * ((d->Ho + 7) / 8) * ((d->Wo + 7) / 8);
+  const int64_t cap = td == 8 ? 256 : 512;
+  return n_tiles < cap ? n_tiles : cap;
+}
+
+template <int ACT, bool TR, bool MX, int TD>
+static int r32_launch_td(const R32Params& p, dim3 grid, hipStream_t st) {
 #ifndef CBIM_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv3_r32<ACT, TR, MX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv3_r32<ACT, TR, MX, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
 #endif
-  CBIM_LAUNCH((k_conv3_r32<ACT, TR, MX>), grid, dim3(R_NT), smem, st, p);
+  CBIM_LAUNCH((k_conv3_r32<ACT, TR, MX, TD>), grid, dim3(RGeom<TD>::NT), (size_t)RGeom<TD>::SMEM, st, p);
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv r32 launch: %s", hipGetErrorString(e));
   return CBIM_OK;
+}
+template <int ACT, bool TR, bool MX>
+static int r32_launch(const R32Params& p, dim3 grid, hipStream_t st) {
+  return r32_tile_depth() == 8 ? r32_launch_td<ACT, TR, MX, 8>(p, grid, st) : r32_launch_td<ACT, TR, MX, 4>(p, grid, st);
 }
 
 int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats,
@@ -565,31 +647,31 @@ int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_strid
   p.y = y; p.y_stride = y_stride; p.partials = partials;
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
   p.pD = d->pD; p.pH = d->pH; p.pW = d->pW; p.act = d->act;
-  p.tiles_d = (d->Do + 7) / 8; p.tiles_h = (d->Ho + 7) / 8; p.tiles_w = (d->Wo + 7) / 8;
+  const int td = r32_tile_depth();
+  p.tiles_d = (d->Do + td - 1) / td; p.tiles_h = (d->Ho + 7) / 8; p.tiles_w = (d->Wo + 7) / 8;
   { const char* e = getenv("CBIM_R32_DBG"); p.dbg = e ? atoi(e) : 0; }   // tools/r32_ablate.py timing ablations; 0 in production
   p.P = cbim_conv3d_num_tiles(d);
   CBIM_CHECK(!partials || p.P >= (int)cbim_conv_r32_grid(d), CBIM_EINVAL, "conv r32: %d partial records < grid", p.P);
   {
     // 32-bit byte offsets inside one halo box / one output tile, built from 24-bit multiplies
-    const int64_t box_rows = (int64_t)10 * d->Hi * d->Wi, xs = x_stride * 2;
+    const int64_t box_rows = (int64_t)(td + 2) * d->Hi * d->Wi, xs = x_stride * 2;
     CBIM_CHECK(box_rows < (1 << 24) && xs < (1 << 24) && box_rows * xs < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
                "conv r32: input plane %dx%d with row stride %lld B exceeds the 32-bit halo addressing", d->Hi, d->Wi, (long long)xs);
-    const int64_t tile_rows = (int64_t)8 * d->Ho * d->Wo;
+    const int64_t tile_rows = (int64_t)td * d->Ho * d->Wo;
     int64_t so = y_stride * 2;
     if (res && res_stride * 2 > so) so = res_stride * 2;
     if (mask_x && mask_stride * 2 > so) so = mask_stride * 2;
     CBIM_CHECK(tile_rows < (1 << 24) && so < (1 << 24) && tile_rows * so < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
                "conv r32: output plane %dx%d with row stride %lld B exceeds the 32-bit epilogue addressing", d->Ho, d->Wo, (long long)so);
   }
-  const size_t smem = 2 * (size_t)R_HBUF + (size_t)R_NW * 16 * 3 * sizeof(float) + 256 + 256;
   dim3 grid((unsigned)cbim_conv_r32_grid(d));
   hipStream_t st = (hipStream_t)stream;
   const bool relu = d->act == CBIM_ACT_RELU;
   // (eligibility: act is ReLU or none; a transformed input comes with the forward epilogue, a mask with an input
   //  that is used as it is — the four combinations the pre-activation blocks produce)
-  if (in_stats) return relu ? r32_launch<CBIM_ACT_RELU, true, false>(p, grid, smem, st) : r32_launch<CBIM_ACT_NONE, true, false>(p, grid, smem, st);
-  if (mask_x) return relu ? r32_launch<CBIM_ACT_RELU, false, true>(p, grid, smem, st) : r32_launch<CBIM_ACT_NONE, false, true>(p, grid, smem, st);
-  return r32_launch<CBIM_ACT_NONE, false, false>(p, grid, smem, st);
+  if (in_stats) return relu ? r32_launch<CBIM_ACT_RELU, true, false>(p, grid, st) : r32_launch<CBIM_ACT_NONE, true, false>(p, grid, st);
+  if (mask_x) return relu ? r32_launch<CBIM_ACT_RELU, false, true>(p, grid, st) : r32_launch<CBIM_ACT_NONE, false, true>(p, grid, st);
+  return r32_launch<CBIM_ACT_NONE, false, false>(p, grid, st);
 }
 
 CBIM_DEFINE_WARM(r32)

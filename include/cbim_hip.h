@@ -143,6 +143,9 @@ int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, int n_items,
  * "weights in registers" kernel (conv_r32.hip) instead of k_conv_igemm; v < 0 only queries.  Returns the previous
  * value (default 262144 = 64^3).  The two kernels compute the same function (tests lower it to cover small shapes). */
 int64_t cbim_conv_r32_min_voxels(int64_t v);
+/* Tile depth of that kernel: 8 = one 512-thread workgroup per CU on 8x8x8 tiles (default), 4 = two 256-thread workgroups
+ * per CU on 4x8x8 tiles; any other value only queries.  Returns the previous value. */
+int cbim_conv_r32_tile_depth(int td);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);

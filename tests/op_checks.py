@@ -138,7 +138,7 @@ def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0, act="relu"):
     assert float((sums[..., 1].cpu() - (gm * xh).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
 
 
-def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21):
+def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21, tile_depth=8):
     """The 'weights in registers' kernel for Cin = 32 -> Cout <= 32, 3x3x3, bf16 (conv_r32.hip) against torch AND against
     k_conv_igemm on the same inputs: transformed input + residual + statistics (forward), raw input (LDS-DMA path),
     plain dgrad, masked dgrad with the two InstanceNorm-backward sums."""
@@ -178,7 +178,7 @@ def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21):
             out += [g, g2, sums]
         return [o.float().cpu() for o in out]
 
-    old = L.cbim_conv_r32_min_voxels(-1)
+    old, old_td = L.cbim_conv_r32_min_voxels(-1), L.cbim_conv_r32_tile_depth(tile_depth)
     try:
         L.cbim_conv_r32_min_voxels(1 << 40)
         ref = run()                       # k_conv_igemm
@@ -186,6 +186,7 @@ def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21):
         got = run()                       # k_conv3_r32
     finally:
         L.cbim_conv_r32_min_voxels(old)
+        L.cbim_conv_r32_tile_depth(old_td)
     names = ["fwd+res", "fwd stats", "raw fwd", "raw stats", "raw fwd (no stats)", "dgrad", "masked dgrad", "bwd sums"]
     for nm, r, g_ in zip(names, ref, got):
         lim = 2e-3 if nm in ("fwd stats", "raw stats", "bwd sums") else 1e-2

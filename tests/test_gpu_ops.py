@@ -58,6 +58,8 @@ def test_conv(dev, dtype, N, Cin, Cout, dhw, k):
 def test_conv_r32_weights_in_registers(dev):
     oc.check_conv_r32(dev)                                          # ragged tiles, two images
     oc.check_conv_r32(dev, N=1, Cout=16, dhw=(8, 8, 16), act="none")
+    oc.check_conv_r32(dev, tile_depth=4)                            # two 256-thread workgroups per CU, 4x8x8 tiles
+    oc.check_conv_r32(dev, N=1, Cout=32, dhw=(13, 8, 24), tile_depth=4, act="none")
     oc.check_conv_r32(dev, N=1, Cout=32, dhw=(64, 64, 64))          # the default threshold: picked without the knob
 
 

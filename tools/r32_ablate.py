@@ -36,6 +36,7 @@ L = _lib.lib()
 L.cbim_conv_r32_min_voxels(1 << 40)
 print("k_conv_igemm :", "  ".join(f"{k} {timeit(f):.0f}us" for k, f in calls.items()), flush=True)
 L.cbim_conv_r32_min_voxels(262144)
-for dbg in (0, 1, 2, 4, 8, 16, 24, 32, 64, 96, 6):
+for td, dbg in [(4, d) for d in (0, 1, 2, 4, 8, 16, 6)] + [(8, d) for d in (0, 4, 6, 132, 133)]:
+    L.cbim_conv_r32_tile_depth(td)
     os.environ["CBIM_R32_DBG"] = str(dbg)
-    print(f"r32 dbg={dbg:2d}  :", "  ".join(f"{k} {timeit(f):.0f}us ({gf/timeit(f)*1e3:.0f}TF)" for k, f in calls.items()), flush=True)
+    print(f"r32 td={td} dbg={dbg:2d}  :", "  ".join(f"{k} {timeit(f):.0f}us ({gf/timeit(f)*1e3:.0f}TF)" for k, f in calls.items()), flush=True)
