@@ -708,7 +708,9 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
   {
     // one fused pass (dx, dw, db) when the channel chunks of a row fit the 4 waves x CHW layout of k_head_bwd_k
     const int cpc = dtype == CBIM_BF16 ? 8 : 4, cch = Cin / cpc;
-    if (K <= 16 && cch <= 8 && (size_t)Cin * 16 * sizeof(float) <= 64 * 1024) {
+    // (bf16 rows of more than 4 chunks would need 2 x 16 x 8 accumulators + as many weight registers per lane: spills;
+    //  they keep the two-kernel path below)
+    if (K <= 16 && cch <= (dtype == CBIM_BF16 ? 4 : 8) && (size_t)Cin * 16 * sizeof(float) <= 64 * 1024) {
       int nb = head_bwd_blocks(S);      // (the workspace is sized for head_bwd_blocks(S) slabs)
       if (nb > 256) nb = 256;           // one workgroup per CU: fewer slabs for the reduce
       int64_t vpb = (S + nb - 1) / nb;

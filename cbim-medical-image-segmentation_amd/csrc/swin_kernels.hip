@@ -22,49 +22,16 @@
 // key step j all queries i address distinct entries (i -> B_i - B_j is injective), one barrier per two keys
 // (even / odd keys own separate histograms) —
 // and the per-workgroup histograms are summed over windows in launch order.
-#include "cbim_common.h"
+#include "swin_common.h"
 #include <stdlib.h>
 
 namespace cbim {
-
-static constexpr int WT_THREADS = 384;   // >= 343 = 7^3 tokens
-static constexpr int WMAX = 343;
-
-struct WinGeom {
-  int B, D, H, W, C, heads, dh;
-  int w0, w1, w2;        // window extents actually used (get_window_size, :358-381)
-  int s0, s1, s2;        // shift (0 where the window covers the dimension)
-  int Dp, Hp, Wp;        // padded extents
-  int nw0, nw1, nw2;     // windows per dimension
-  int tw0, tw1, tw2;     // extents of the module's bias table window (7,7,7)
-  int masked;            // any shift > 0
-  float scale;
-};
 
 #ifdef CBIM_EMU
 #define CBIM_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
 #else
 #define CBIM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
-
-// token t of window `win` -> source row in the [B][D][H][W] tensor (or -1 for a padded token), region label,
-// bias-table coordinate B_t
-__device__ __forceinline__ void win_token(const WinGeom& g, int win, int t, int64_t& row, int& label, int& bcoord) {
-  int ww = win % g.nw2, wh = (win / g.nw2) % g.nw1, wd = (win / (g.nw2 * g.nw1)) % g.nw0, b = win / (g.nw2 * g.nw1 * g.nw0);
-  int c = t % g.w2, bb = (t / g.w2) % g.w1, a = t / (g.w2 * g.w1);
-  int pd = wd * g.w0 + a, ph = wh * g.w1 + bb, pw = ww * g.w2 + c;          // shifted frame
-  int sd = pd + g.s0, sh = ph + g.s1, sw = pw + g.s2;                         // torch.roll(x, -shift)
-  if (sd >= g.Dp) sd -= g.Dp;
-  if (sh >= g.Hp) sh -= g.Hp;
-  if (sw >= g.Wp) sw -= g.Wp;
-  row = (sd < g.D && sh < g.H && sw < g.W) ? (((int64_t)b * g.D + sd) * g.H + sh) * g.W + sw : -1;
-  int ld = g.s0 == 0 ? 2 : (pd < g.Dp - g.w0 ? 0 : (pd < g.Dp - g.s0 ? 1 : 2));
-  int lh = g.s1 == 0 ? 2 : (ph < g.Hp - g.w1 ? 0 : (ph < g.Hp - g.s1 ? 1 : 2));
-  int lw = g.s2 == 0 ? 2 : (pw < g.Wp - g.w2 ? 0 : (pw < g.Wp - g.s2 ? 1 : 2));
-  label = (ld * 3 + lh) * 3 + lw;
-  int t0 = t / (g.tw1 * g.tw2), t1 = (t / g.tw2) % g.tw1, t2 = t % g.tw2;    // coordinates by token number
-  bcoord = (t0 * (2 * g.tw1 - 1) + t1) * (2 * g.tw2 - 1) + t2;
-}
 
 struct WinSmem {
   float* A;       // [n][DH]  K   (pass B: scaled Q)
@@ -172,118 +139,6 @@ __global__ void __launch_bounds__(WT_THREADS) k_winattn_fwd(WinGeom g, const voi
     float inv = 1.f / l;
 #pragma unroll
     for (int d = 0; d < DH; ++d) Elem<T>::store1(out, (size_t)myrow * C + h * DH + d, o[d] * inv);
-  }
-}
-
-// ---- experimental (CBIM_WINATTN_FWD2=1, default off, not yet timed): TWO queries per thread -------------------------
-// Per key and CU the one-query kernels issue as many LDS clocks (broadcast ds_read_b128 of the K and V rows) as VALU
-// clocks, so neither alone can be sped up.  Here a thread owns queries t and t + 192: every K / V row read from LDS
-// feeds two queries (half the LDS traffic per FMA), and the dot products keep an even and an odd partial sum so that
-// the compiler can pair them into v_pk_fma_f32.  Same LDS layout, same tiled online softmax, same outputs.
-static constexpr int W2_THREADS = 192;
-template <typename T, int DH>
-__global__ void __launch_bounds__(W2_THREADS) k_winattn_fwd2(WinGeom g, const void* __restrict__ qkv,
-                                                             const float* __restrict__ qkv_bias,
-                                                             const float* __restrict__ table, void* __restrict__ out,
-                                                             float* __restrict__ lse_out) {
-  CBIM_DYN_SMEM(smem);
-  const int n = g.w0 * g.w1 * g.w2, TS = (2 * g.tw0 - 1) * (2 * g.tw1 - 1) * (2 * g.tw2 - 1);
-  const int off0 = ((g.tw0 - 1) * (2 * g.tw1 - 1) + (g.tw1 - 1)) * (2 * g.tw2 - 1) + (g.tw2 - 1);
-  WinSmem s = win_smem<DH>(smem, TS);
-  const int win = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
-  const int C = g.C;
-  for (int i = t; i < TS; i += W2_THREADS) s.tbl[i] = table[(size_t)i * g.heads + h];
-  float q[2][DH];
-  int64_t myrow[2] = {-1, -1};
-  int mylab[2] = {0, 0}, myb[2] = {0, 0};
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int tok = t + u * W2_THREADS;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) q[u][d] = 0.f;
-    if (tok < n) {
-      win_token(g, win, tok, myrow[u], mylab[u], myb[u]);
-      s.bco[tok] = myb[u]; s.lab[tok] = mylab[u];
-#pragma unroll
-      for (int d = 0; d < DH; ++d) {
-        float qv, kv, vv;
-        if (myrow[u] >= 0) {
-          size_t base = (size_t)myrow[u] * 3 * C + h * DH + d;
-          qv = Elem<T>::load1(qkv, base); kv = Elem<T>::load1(qkv, base + C); vv = Elem<T>::load1(qkv, base + 2 * C);
-        } else {
-          qv = qkv_bias ? qkv_bias[h * DH + d] : 0.f;
-          kv = qkv_bias ? qkv_bias[C + h * DH + d] : 0.f;
-          vv = qkv_bias ? qkv_bias[2 * C + h * DH + d] : 0.f;
-        }
-        q[u][d] = qv * g.scale;
-        s.A[tok * DH + d] = kv;
-        s.Bv[tok * DH + d] = vv;
-      }
-    }
-  }
-  __syncthreads();
-  if (t >= n) return;                       // t + 192 >= n as well
-  const bool two = t + W2_THREADS < n;
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f}, o[2][DH];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int d = 0; d < DH; ++d) o[u][d] = 0.f;
-  constexpr int KT = 4;
-  for (int j0 = 0; j0 < n; j0 += KT) {
-    float sc[2][KT];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const int j = j0 + k < n ? j0 + k : n - 1;
-      float ae[2] = {0.f, 0.f}, ao[2] = {0.f, 0.f};
-#pragma unroll
-      for (int d = 0; d < DH; d += 2) {
-        const float k0 = s.A[j * DH + d], k1 = s.A[j * DH + d + 1];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { ae[u] = fmaf(q[u][d], k0, ae[u]); ao[u] = fmaf(q[u][d + 1], k1, ao[u]); }
-      }
-      const int bj = s.bco[j], lj = s.lab[j];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        float a = (ae[u] + ao[u]) + s.tbl[myb[u] - bj + off0];
-        if (g.masked && lj != mylab[u]) a += -100.f;
-        sc[u][k] = j0 + k < n ? a : -INFINITY;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float mn = m[u];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) mn = fmaxf(mn, sc[u][k]);
-      const float corr = expf(m[u] - mn);
-      l[u] *= corr;
-#pragma unroll
-      for (int d = 0; d < DH; ++d) o[u][d] *= corr;
-#pragma unroll
-      for (int k = 0; k < KT; ++k) { sc[u][k] = expf(sc[u][k] - mn); l[u] += sc[u][k]; }
-      m[u] = mn;
-    }
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const int j = j0 + k < n ? j0 + k : n - 1;
-#pragma unroll
-      for (int d = 0; d < DH; ++d) {
-        const float v = s.Bv[j * DH + d];
-        o[0][d] = fmaf(sc[0][k], v, o[0][d]);
-        o[1][d] = fmaf(sc[1][k], v, o[1][d]);
-      }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (u == 1 && !two) break;
-    const int tok = t + u * W2_THREADS;
-    lse_out[((size_t)win * g.heads + h) * WMAX + tok] = m[u] + logf(l[u]);
-    if (myrow[u] >= 0) {
-      const float inv = 1.f / l[u];
-#pragma unroll
-      for (int d = 0; d < DH; ++d) Elem<T>::store1(out, (size_t)myrow[u] * C + h * DH + d, o[u][d] * inv);
-    }
   }
 }
 
@@ -444,179 +299,6 @@ __global__ void __launch_bounds__(256) k_winattn_reduce(const float* __restrict_
   }
 }
 
-// ---- experimental (CBIM_WINATTN_BWD2=1, default off, not yet timed): the backward with two tokens per thread ----------
-// Same idea as k_winattn_fwd2: pass A owns queries t and t + 192 (each K / V row read from LDS feeds both), pass B owns
-// keys t and t + 192 (each Q / dO row feeds both); dot products keep even / odd partial sums.  Histogram discipline
-// unchanged: at one key all queries address distinct entries, even / odd keys have their own histogram, one barrier per
-// two keys; results match k_winattn_bwd up to the summation order inside the dot products.
-template <typename T, int DH>
-__global__ void __launch_bounds__(W2_THREADS) k_winattn_bwd2(WinGeom g, const void* __restrict__ qkv,
-                                                             const float* __restrict__ qkv_bias,
-                                                             const float* __restrict__ table,
-                                                             const void* __restrict__ out, const void* __restrict__ dout,
-                                                             const float* __restrict__ lse_in, void* __restrict__ dqkv,
-                                                             float* __restrict__ part_tbl, float* __restrict__ part_pad) {
-  CBIM_DYN_SMEM(smem);
-  const int n = g.w0 * g.w1 * g.w2, TS = (2 * g.tw0 - 1) * (2 * g.tw1 - 1) * (2 * g.tw2 - 1);
-  const int off0 = ((g.tw0 - 1) * (2 * g.tw1 - 1) + (g.tw1 - 1)) * (2 * g.tw2 - 1) + (g.tw2 - 1);
-  WinSmem s = win_smem<DH>(smem, TS);
-  const int win = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
-  const int C = g.C;
-  for (int i = t; i < TS; i += W2_THREADS) { s.tbl[i] = table[(size_t)i * g.heads + h]; s.hist[i] = 0.f; s.hist[TS + i] = 0.f; }
-  float q[2][DH], kk[2][DH], vv[2][DH], go[2][DH];
-  int64_t myrow[2] = {-1, -1};
-  int mylab[2] = {0, 0}, myb[2] = {0, 0};
-  float mylse[2] = {0.f, 0.f}, myD[2] = {0.f, 0.f};
-  bool act[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int tok = t + u * W2_THREADS;
-    act[u] = tok < n;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) { q[u][d] = 0.f; kk[u][d] = 0.f; vv[u][d] = 0.f; go[u][d] = 0.f; }
-    if (act[u]) {
-      win_token(g, win, tok, myrow[u], mylab[u], myb[u]);
-      s.bco[tok] = myb[u]; s.lab[tok] = mylab[u]; s.row[tok] = myrow[u];
-      mylse[u] = lse_in[((size_t)win * g.heads + h) * WMAX + tok];
-#pragma unroll
-      for (int d = 0; d < DH; ++d) {
-        float qv, ov = 0.f, gv = 0.f;
-        if (myrow[u] >= 0) {
-          size_t base = (size_t)myrow[u] * 3 * C + h * DH + d;
-          qv = Elem<T>::load1(qkv, base); kk[u][d] = Elem<T>::load1(qkv, base + C); vv[u][d] = Elem<T>::load1(qkv, base + 2 * C);
-          ov = Elem<T>::load1(out, (size_t)myrow[u] * C + h * DH + d);
-          gv = Elem<T>::load1(dout, (size_t)myrow[u] * C + h * DH + d);
-        } else {
-          qv = qkv_bias ? qkv_bias[h * DH + d] : 0.f;
-          kk[u][d] = qkv_bias ? qkv_bias[C + h * DH + d] : 0.f;
-          vv[u][d] = qkv_bias ? qkv_bias[2 * C + h * DH + d] : 0.f;
-        }
-        q[u][d] = qv * g.scale;
-        go[u][d] = gv;
-        myD[u] = fmaf(gv, ov, myD[u]);
-        s.A[tok * DH + d] = kk[u][d];
-        s.Bv[tok * DH + d] = vv[u][d];
-      }
-      s.lse[tok] = mylse[u]; s.dsum[tok] = myD[u];
-    }
-  }
-  __syncthreads();
-  // ---- pass A: thread = queries t, t + 192
-  float dq[2][DH];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int d = 0; d < DH; ++d) dq[u][d] = 0.f;
-  for (int j0 = 0; j0 < n; j0 += 2) {
-#pragma unroll
-    for (int uk = 0; uk < 2; ++uk) {
-      const int j = j0 + uk;
-      if (j < n && act[0]) {
-        float se[2] = {0.f, 0.f}, so[2] = {0.f, 0.f}, pe[2] = {0.f, 0.f}, po[2] = {0.f, 0.f};
-#pragma unroll
-        for (int d = 0; d < DH; d += 2) {
-          const float k0 = s.A[j * DH + d], k1 = s.A[j * DH + d + 1], v0 = s.Bv[j * DH + d], v1 = s.Bv[j * DH + d + 1];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            se[u] = fmaf(q[u][d], k0, se[u]); so[u] = fmaf(q[u][d + 1], k1, so[u]);
-            pe[u] = fmaf(go[u][d], v0, pe[u]); po[u] = fmaf(go[u][d + 1], v1, po[u]);
-          }
-        }
-        const int bj = s.bco[j], lj = s.lab[j];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (act[u]) {
-            const int idx = myb[u] - bj + off0;
-            float sc = (se[u] + so[u]) + s.tbl[idx];
-            if (g.masked && lj != mylab[u]) sc += -100.f;
-            const float p = expf(sc - mylse[u]);
-            const float ds = p * ((pe[u] + po[u]) - myD[u]);
-#pragma unroll
-            for (int d = 0; d < DH; ++d) dq[u][d] = fmaf(ds, s.A[j * DH + d], dq[u][d]);
-            s.hist[uk * TS + idx] += ds;     // distinct idx for distinct queries at a fixed key
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-    if (act[u] && myrow[u] >= 0) {
-#pragma unroll
-      for (int d = 0; d < DH; ++d) Elem<T>::store1(dqkv, (size_t)myrow[u] * 3 * C + h * DH + d, dq[u][d] * g.scale);
-    }
-  for (int i = t; i < TS; i += W2_THREADS) part_tbl[((size_t)win * g.heads + h) * TS + i] = s.hist[i] + s.hist[TS + i];
-  __syncthreads();
-  // ---- pass B: thread = keys t, t + 192.  LDS now holds scaled Q and dO
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-    if (act[u]) {
-      const int tok = t + u * W2_THREADS;
-#pragma unroll
-      for (int d = 0; d < DH; ++d) { s.A[tok * DH + d] = q[u][d]; s.Bv[tok * DH + d] = go[u][d]; }
-    }
-  __syncthreads();
-  float dk[2][DH], dv[2][DH];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int d = 0; d < DH; ++d) { dk[u][d] = 0.f; dv[u][d] = 0.f; }
-  if (act[0]) {
-    for (int i = 0; i < n; ++i) {
-      float se[2] = {0.f, 0.f}, so[2] = {0.f, 0.f}, pe[2] = {0.f, 0.f}, po[2] = {0.f, 0.f};
-#pragma unroll
-      for (int d = 0; d < DH; d += 2) {
-        const float q0 = s.A[i * DH + d], q1 = s.A[i * DH + d + 1], g0 = s.Bv[i * DH + d], g1 = s.Bv[i * DH + d + 1];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          se[u] = fmaf(q0, kk[u][d], se[u]); so[u] = fmaf(q1, kk[u][d + 1], so[u]);
-          pe[u] = fmaf(g0, vv[u][d], pe[u]); po[u] = fmaf(g1, vv[u][d + 1], po[u]);
-        }
-      }
-      const int bi = s.bco[i], li = s.lab[i];
-      const float lsei = s.lse[i], dsi = s.dsum[i];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (act[u]) {
-          float sc = (se[u] + so[u]) + s.tbl[bi - myb[u] + off0];
-          if (g.masked && li != mylab[u]) sc += -100.f;
-          const float p = expf(sc - lsei);
-          const float ds = p * ((pe[u] + po[u]) - dsi);
-#pragma unroll
-          for (int d = 0; d < DH; ++d) { dv[u][d] = fmaf(p, s.Bv[i * DH + d], dv[u][d]); dk[u][d] = fmaf(ds, s.A[i * DH + d], dk[u][d]); }
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (act[u] && myrow[u] >= 0) {
-#pragma unroll
-        for (int d = 0; d < DH; ++d) {
-          Elem<T>::store1(dqkv, (size_t)myrow[u] * 3 * C + C + h * DH + d, dk[u][d]);
-          Elem<T>::store1(dqkv, (size_t)myrow[u] * 3 * C + 2 * C + h * DH + d, dv[u][d]);
-        }
-      }
-  }
-  __syncthreads();
-  // gradient of qkv.bias through the padded keys: fixed-order sum over this window's padded tokens
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-    if (act[u]) {
-      const int tok = t + u * W2_THREADS;
-#pragma unroll
-      for (int d = 0; d < DH; ++d) { s.A[tok * DH + d] = myrow[u] < 0 ? dk[u][d] : 0.f; s.Bv[tok * DH + d] = myrow[u] < 0 ? dv[u][d] : 0.f; }
-    }
-  __syncthreads();
-  if (t < 2 * DH) {
-    const float* src = t < DH ? s.A : s.Bv;
-    int d = t % DH;
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc += src[i * DH + d];
-    part_pad[(((size_t)win * g.heads + h) * 2 + t / DH) * DH + d] = acc;
-  }
-}
-
 }  // namespace cbim
 
 using namespace cbim;
@@ -691,19 +373,9 @@ extern "C" int cbim_window_attn3d_fwd(int dtype, const void* qkv, const float* q
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "window attention needs %zu B of LDS", smem);
   dim3 grid(B * g.nw0 * g.nw1 * g.nw2, heads);
   hipStream_t st = (hipStream_t)stream;
-  static const int fwd2 = getenv("CBIM_WINATTN_FWD2") ? atoi(getenv("CBIM_WINATTN_FWD2")) : 0;
-  if (fwd2 && g.dh == 16 && g.w0 * g.w1 * g.w2 <= 2 * W2_THREADS) {   // experimental two-queries-per-thread variant
-    static bool once = false;
-    if (!once) {
-      if (int e = set_smem(k_winattn_fwd2<bf16_tag, 16>, smem)) return e;
-      if (int e = set_smem(k_winattn_fwd2<float, 16>, smem)) return e;
-      once = true;
-    }
-    if (dtype == CBIM_BF16) CBIM_LAUNCH((k_winattn_fwd2<bf16_tag, 16>), grid, dim3(W2_THREADS), smem, st, g, qkv, qkv_bias, table, out, lse);
-    else CBIM_LAUNCH((k_winattn_fwd2<float, 16>), grid, dim3(W2_THREADS), smem, st, g, qkv, qkv_bias, table, out, lse);
-  } else {
-    WIN_DISPATCH(k_winattn_fwd, g, qkv, qkv_bias, table, out, lse);
-  }
+  if (cbim_winattn_mfma_eligible(dtype, g))   // bf16, d_head 16: QK^T and PV on the matrix cores (swin_mfma.hip)
+    return cbim_winattn_mfma_fwd(g, qkv, qkv_bias, table, out, lse, stream);
+  WIN_DISPATCH(k_winattn_fwd, g, qkv, qkv_bias, table, out, lse);
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "window_attn3d_fwd launch: %s", hipGetErrorString(e));
   return CBIM_OK;
@@ -729,20 +401,8 @@ extern "C" int cbim_window_attn3d_bwd(int dtype, const void* qkv, const float* q
   hipStream_t st = (hipStream_t)stream;
   float* part_tbl = (float*)workspace;
   float* part_pad = part_tbl + (size_t)nwin * heads * TS;
-  static const int bwd2 = getenv("CBIM_WINATTN_BWD2") ? atoi(getenv("CBIM_WINATTN_BWD2")) : 0;
-  if (bwd2 && g.dh == 16 && g.w0 * g.w1 * g.w2 <= 2 * W2_THREADS) {   // experimental two-tokens-per-thread variant
-    static bool once = false;
-    if (!once) {
-      if (int e = set_smem(k_winattn_bwd2<bf16_tag, 16>, smem)) return e;
-      if (int e = set_smem(k_winattn_bwd2<float, 16>, smem)) return e;
-      once = true;
-    }
-    if (dtype == CBIM_BF16)
-      CBIM_LAUNCH((k_winattn_bwd2<bf16_tag, 16>), grid, dim3(W2_THREADS), smem, st, g, qkv, qkv_bias, table, out, dout, lse, dqkv,
-                  part_tbl, part_pad);
-    else
-      CBIM_LAUNCH((k_winattn_bwd2<float, 16>), grid, dim3(W2_THREADS), smem, st, g, qkv, qkv_bias, table, out, dout, lse, dqkv,
-                  part_tbl, part_pad);
+  if (cbim_winattn_mfma_bwd_eligible(dtype, g)) {
+    if (int e = cbim_winattn_mfma_bwd(g, qkv, qkv_bias, table, out, dout, lse, dqkv, part_tbl, part_pad, stream)) return e;
   } else {
     WIN_DISPATCH(k_winattn_bwd, g, qkv, qkv_bias, table, out, dout, lse, dqkv, part_tbl, part_pad);
   }

@@ -279,7 +279,10 @@ class PackedWeights:
         e.used = True
         if self.stale or e.versions != tuple(w._version for w in ws):
             try:
-                self._repack_all(new_only=e.versions is None and not self.stale)
+                if e.versions is None and not self.stale:
+                    self._pack_one(e)
+                else:
+                    self._repack_all()
             except Exception:
                 if e.versions is None:        # an unsupported weight (e.g. Cout not a multiple of the channel chunk)
                     self.entries.pop(key, None)   # must not stay in the table and fail every later launch
@@ -322,10 +325,23 @@ class PackedWeights:
         self.n_blocks = blk
         self.dirty_table = False
 
-    def _repack_all(self, new_only=False):
+    def _pack_one(self, e):
+        """a weight seen for the first time: its own launch (the table launch would re-pack every weight)"""
+        if e.w1 is None:
+            w = e.w0.contiguous()
+        else:
+            w = torch.cat([e.w0, e.w1], 0).contiguous()
+        L = _lib.lib()
+        if e.p1 is not None:
+            check(L.cbim_conv3d_pack_weights_both(C.byref(e.geom.fwd), _p(w), _p(e.p0), _p(e.p1), _stream(w)), "pack_weights_both")
+        else:
+            check(L.cbim_conv3d_pack_weights(C.byref(e.geom.fwd), 0, _p(w), _p(e.p0), _stream(w)), "pack_weights")
+        e.versions = tuple(t._version for t in ((e.w0,) if e.w1 is None else (e.w0, e.w1)))
+
+    def _repack_all(self):
         dev0 = next(iter(self.entries.values())).p0
         capturing = dev0.is_cuda and torch.cuda.is_current_stream_capturing()
-        if not capturing and not new_only:
+        if not capturing:
             # a weight CHANGED (optimizer step): entries no convolution asked for during the last 8 such epochs
             # belong to models that are gone
             dead = []
@@ -378,7 +394,17 @@ def _hook_graph_replay():
 
 
 def packed_weights(ws, geom: ConvGeom, need_dgrad: bool):
-    return PACKED.get(tuple(ws), geom, need_dgrad)
+    """(packed forward layout, packed dgrad layout | None) of a convolution weight (or conv1 | shortcut pair).
+    nn.Parameters are served from the one-launch-per-optimizer-step table; any other tensor (e.g. the permuted
+    ConvTranspose3d weight of monai's UnetrUpBlock, a new allocation every forward pass, with or without grad mode) is
+    packed on the spot and never enters the table — entries keep their weight alive, temporaries would pile up."""
+    ws = tuple(ws)
+    if all(isinstance(w, torch.nn.Parameter) for w in ws):
+        return PACKED.get(ws, geom, need_dgrad)
+    w = ws[0].detach().contiguous() if len(ws) == 1 else torch.cat([t.detach() for t in ws], 0).contiguous()
+    if need_dgrad:
+        return pack_weights_both(w, geom)
+    return pack_weights(w, geom, 0), None
 
 
 def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, mask_x=None, mask_stats=None,

@@ -95,6 +95,14 @@ inline T __shfl_down(T v, unsigned delta, int width = 64) {
   return r;
 }
 
+inline int __any(int pred) {
+  const int mine = pred != 0;
+  const unsigned char* buf = cbim_emu::wave_exchange(&mine, sizeof(int));
+  int r = 0;
+  for (int i = 0; i < 64; ++i) { int v; memcpy(&v, buf + (size_t)i * sizeof(int), sizeof(int)); r |= v; }
+  return r;
+}
+
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __expf(float x) { return expf(x); }
@@ -123,6 +131,12 @@ inline double atomicAdd(double* p, double v) {
 }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+  unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
 
 // ---- MFMA models (lane<->element maps: cdna_hip_programming.md §3) -------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 emu_bf16x8;

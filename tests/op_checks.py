@@ -507,23 +507,27 @@ def check_resnorm(dev, dtype, N=2, C=16, dhw=(4, 5, 6), with_b_stats=True, seed=
     assert relerr(from_cl(db.cpu()), br.grad) < tol(dtype, 5e-5, 2e-2), "resnorm db"
 
 
-def check_window_attn_fwd2_variant(dev_name):
-    """The experimental two-tokens-per-thread forward and backward (CBIM_WINATTN_FWD2=1, CBIM_WINATTN_BWD2=1; read once per process, hence a
-    child process): d_head 16 windows with 343 tokens (both queries of a thread live), padding + shift, and a 112-token
-    window (one query per thread)."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import torch\n"
-        "from tests import op_checks as oc\n"
-        f"dev = {dev_name!r}\n"
-        "for dt in (torch.float32, torch.bfloat16):\n"
-        "    oc.check_window_attn(dev, dt, dhw=(7, 7, 7), shift=(0, 0, 0), C=16, heads=1)\n"
-        "    oc.check_window_attn(dev, dt, dhw=(9, 8, 7), C=48, heads=3)\n"
-        "    oc.check_window_attn(dev, dt, dhw=(8, 4, 4), shift=(3, 3, 3), C=16, heads=1)\n"
-        "print('fwd2-ok')\n")
-    env = dict(os.environ, CBIM_WINATTN_FWD2="1", CBIM_WINATTN_BWD2="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "fwd2-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+def check_window_attn_mfma(dev, B=1, dhw=(9, 8, 7), C=48, heads=3, window=(7, 7, 7), shift=(3, 3, 3), seed=23):
+    """The matrix-core window attention (swin_mfma.hip: bf16, d_head 16) against the vector-ALU fp32 kernels of
+    swin_kernels.hip fed with the SAME bf16-rounded q/k/v (and, for the backward, the same bf16-rounded upstream gradient):
+    the only differences left are the bf16 rounding of the probabilities / score gradients that feed the second GEMMs."""
+    from oracle import swin_unetr_ref as R
+    torch.manual_seed(seed)
+    D, H, W = dhw
+    ws, ss = R.effective_window(dhw, window, shift)
+    bq = (torch.randn(3 * C) * 0.3).to(dev)
+    table = (torch.randn((2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1), heads) * 0.5).to(dev)
+    qkv16 = (torch.randn(B, D, H, W, 3 * C) * 0.7).bfloat16().to(dev)
+    qkv32 = qkv16.float()
+    o32, lse32 = ops.window_attn_fwd(qkv32, bq, table, heads, ws, ss, window)
+    o16, lse16 = ops.window_attn_fwd(qkv16, bq, table, heads, ws, ss, window)
+    e = relerr(o16.float().cpu(), o32.cpu())
+    assert e < 1.5e-2, f"window attention (mfma) fwd {e:.3e}"
+    n = ws[0] * ws[1] * ws[2]
+    assert relerr(lse16.cpu()[..., :n], lse32.cpu()[..., :n]) < 1e-3, "window attention (mfma) lse"
+    g16 = torch.randn(B, D, H, W, C).bfloat16().to(dev)
+    dq32, dt32, db32 = ops.window_attn_bwd(qkv32, bq, table, o32, g16.float(), lse32, heads, ws, ss, window)
+    dq16, dt16, db16 = ops.window_attn_bwd(qkv16, bq, table, o16, g16, lse16, heads, ws, ss, window)
+    assert relerr(dq16.float().cpu(), dq32.cpu()) < 3e-2, f"window attention (mfma) dqkv {relerr(dq16.float().cpu(), dq32.cpu()):.3e}"
+    assert relerr(dt16.cpu(), dt32.cpu()) < 3e-2, f"window attention (mfma) dtable {relerr(dt16.cpu(), dt32.cpu()):.3e}"
+    assert relerr(db16.cpu(), db32.cpu()) < 3e-2 + 1e-6, f"window attention (mfma) dbias {relerr(db16.cpu(), db32.cpu()):.3e}"

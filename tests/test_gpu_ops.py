@@ -166,6 +166,12 @@ def test_window_attention(dev, dtype):
     oc.check_window_attn(dev, dtype, B=2, dhw=(14, 14, 14), shift=(0, 0, 0), C=96, heads=6)
 
 
+def test_window_attention_matrix_core_path(dev):
+    oc.check_window_attn_mfma(dev)                                                  # padded + shifted, 3 heads
+    oc.check_window_attn_mfma(dev, dhw=(8, 4, 4), shift=(3, 3, 3), C=16, heads=1)   # window (7,4,4): 112 tokens
+    oc.check_window_attn_mfma(dev, B=2, dhw=(14, 14, 14), C=96, heads=6, shift=(0, 0, 0))
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_resnorm(dev, dtype):
     oc.check_resnorm(dev, dtype)

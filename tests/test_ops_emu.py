@@ -169,8 +169,9 @@ def test_fused_adamw_ema(dev):
     check_adamw_ema(dev)
 
 
-def test_window_attention_two_queries_per_thread_variant(dev):
-    oc.check_window_attn_fwd2_variant(dev)
+def test_window_attention_matrix_core_path(dev):
+    oc.check_window_attn_mfma(dev)                                                  # padded + shifted, 3 heads
+    oc.check_window_attn_mfma(dev, dhw=(8, 4, 4), shift=(3, 3, 3), C=16, heads=1)   # window (7,4,4): 112 tokens
 
 
 def test_training_utils_surface(dev):

@@ -20,9 +20,9 @@ def test_one_table_launch_per_optimizer_step_and_fresh_weights(dev, monkeypatch)
         net = _net().to(dev)
         x = torch.randn(1, 1, 2, 16, 16, generator=torch.Generator().manual_seed(1)).to(dev)
         launches = []
-        orig = ops.PackedWeights._repack_all
-        monkeypatch.setattr(ops.PackedWeights, "_repack_all",
-                            lambda self, new_only=False: (launches.append(new_only), orig(self, new_only))[1])
+        orig, orig_one = ops.PackedWeights._repack_all, ops.PackedWeights._pack_one
+        monkeypatch.setattr(ops.PackedWeights, "_repack_all", lambda self: (launches.append(False), orig(self))[1])
+        monkeypatch.setattr(ops.PackedWeights, "_pack_one", lambda self, e: (launches.append(True), orig_one(self, e))[1])
         opt = FusedAdamW(net.parameters(), lr=1e-2)
         net(x).sum().backward()
         n_first = len(launches)

@@ -13,9 +13,6 @@ done
 python $R/tools/bench_shipped_config.py acdc/medformer_3d.yaml lits/medformer_3d.yaml bcv/medformer_3d.yaml bcv/swin_unetr_3d.yaml \
   --steps 5 --warmup 2 2>/dev/null | grep config > $O/${T}_shipped_bench.txt
 CBIM_MAPPOOL_BWD4=0 python $R/bench.py --model medformer --no-cpu-baseline --no-roofline 2>/dev/null | head -c 300 > $O/${T}_medformer_mappool_old.json
-CBIM_WINATTN_FWD2=1 python $R/bench.py --model swin_unetr --no-cpu-baseline --no-roofline 2>/dev/null | head -c 300 > $O/${T}_swin_fwd2.json
-CBIM_WINATTN_FWD2=1 CBIM_WINATTN_BWD2=1 python $R/bench.py --model swin_unetr --no-cpu-baseline --no-roofline 2>/dev/null | head -c 300 > $O/${T}_swin_fwd2_bwd2.json
-cat $O/${T}_swin_fwd2.json; echo; cat $O/${T}_swin_fwd2_bwd2.json; echo
 cat $O/${T}_shipped_bench.txt; cat $O/${T}_medformer_mappool_old.json; echo
 cd /tmp; export TMPDIR=/tmp
 for m in medformer swin_unetr; do
