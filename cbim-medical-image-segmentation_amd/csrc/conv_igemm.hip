@@ -990,7 +990,7 @@ extern "C" int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, i
 
 extern "C" int cbim_conv3d_tile_config(const cbim_conv_desc* d, int out[4]) {
   CBIM_CHECK(d && out, CBIM_EINVAL, "null argument");
-  if (cbim_conv_r32_eligible(d, nullptr, nullptr, nullptr, nullptr)) {   // (when the call has one input tensor) conv_r32.hip: 4 m-tiles per wave
+  if (cbim_conv_r32_eligible(d, nullptr, 0, nullptr, nullptr, nullptr)) {   // (when the call has one input tensor) conv_r32.hip: 4 m-tiles per wave
     out[0] = 4; out[1] = 1; out[2] = 8; out[3] = 8;
     return CBIM_OK;
   }
@@ -1013,7 +1013,7 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   if (pick_ksplit(d, c) > 1) return finish_parts((int64_t)d->Do * d->Ho * d->Wo);
   int64_t g = igemm_grid_x(d, c);   // one record per (image, persistent workgroup)
   // the same layer may run on conv_r32.hip (8x8x8 tiles whatever pick_cfg says): room for either grid
-  if (cbim_conv_r32_eligible(d, nullptr, nullptr, nullptr, nullptr) && cbim_conv_r32_grid(d) > g) g = cbim_conv_r32_grid(d);
+  if (cbim_conv_r32_eligible(d, nullptr, 0, nullptr, nullptr, nullptr) && cbim_conv_r32_grid(d) > g) g = cbim_conv_r32_grid(d);
   return (int)g;
 }
 
@@ -1072,8 +1072,8 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   if (int e = validate(d)) return e;
   CBIM_CHECK(x && w_packed && y, CBIM_EINVAL, "null tensor");
   CBIM_CHECK(!mask_x || mask_stats, CBIM_EINVAL, "mask_x needs mask_stats");
-  if (cbim_conv_r32_eligible(d, x2, in_stats, res, mask_x))   // Cin = 32 -> Cout <= 32 at full resolution: weights in registers
-    return cbim_conv_r32_launch(d, x, x_stride, in_stats, w_packed, res, res_stride, mask_x, mask_stride, mask_stats, y,
+  if (cbim_conv_r32_eligible(d, x2, cin_split, in_stats, res, mask_x))   // channels in multiples of 32 at high resolution: weights in registers
+    return cbim_conv_r32_launch(d, x, x_stride, x2, x2_stride, cin_split, in_stats, w_packed, res, res_stride, mask_x, mask_stride, mask_stats, y,
                                 y_stride, partials, stream);
   TileCfg c = pick_cfg(d);
   IgemmParams p;

@@ -7,6 +7,9 @@
 namespace cbim {
 struct R32Params {
   const void* x; int64_t x_stride; const float* in_stats;
+  const void* x2; int64_t x2_stride; int c_split;   // Cin chunks >= c_split come from x2 (virtual concatenation)
+  int NC;                                           // 32-channel chunks of Cin
+  int BN;                                           // cout block of the packed weight image: 32 (Cout <= 32) or 64
   const void* w;
   const void* res; int64_t res_stride;
   const void* mx; int64_t mx_stride; const float* m_stats;
@@ -20,12 +23,14 @@ struct R32Params {
 };
 }  // namespace cbim
 
-// bf16, 3x3x3, Cin == 32 (one input tensor), Cout <= 32, >= 64^3 output voxels
-bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, const float* in_stats, const void* res,
+// bf16, 3x3x3, Cin a multiple of 32 (a second input tensor splits it at a multiple of 32), Cout <= 32 or a multiple of
+// 32, enough 8x8x8 output tiles to give every CU a (tile strip, Cout chunk) pair
+bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, int cin_split, const float* in_stats, const void* res,
                             const void* mask_x);
-// persistent grid = records per image of the statistics partials (equals the k_conv_igemm count for these shapes)
+// persistent grid.x = records per image of the statistics partials; grid.y = 32-channel chunks of Cout
 int64_t cbim_conv_r32_grid(const cbim_conv_desc* d);
-int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats,
+int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                         int cin_split, const float* in_stats,
                          const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
                          int64_t mask_stride, const float* mask_stats, void* y, int64_t y_stride, float* partials,
                          void* stream);

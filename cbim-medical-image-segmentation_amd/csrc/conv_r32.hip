@@ -1,6 +1,10 @@
-// conv_r32.hip — 3x3x3 convolution (forward and dgrad) for the single-chunk layers Cin = 32 -> Cout <= 32 (bf16),
-// the layers that own half of the ResUNet's FLOPs at full resolution (32 -> 32 @ 128^3, conv_layers.py:71-94 with
-// base_ch 32, unet.py:22,44): "weights in registers".
+// conv_r32.hip — 3x3x3 convolution (forward and dgrad), bf16, channel counts in multiples of 32: "weights in registers".
+// Written for the single-chunk layers 32 -> 32 @ 128^3 that own half of the ResUNet's FLOPs at full resolution
+// (conv_layers.py:71-94 with base_ch 32, unet.py:22,44), then generalised: blockIdx.y = 32-channel chunk of Cout, and a
+// workgroup walks the 32-channel chunks of Cin (one "unit" = one (tile, Cin chunk)) with the accumulators kept across
+// the chunks.  The 27 weight fragments of the NEXT unit stream from L2 into the registers of the CURRENT unit as they
+// fall dead: a (kh, kw) step is the only user of its three fragments, so right after step s they are reloaded for the
+// next unit, which needs them one whole unit later — no second register set, no exposed latency.
 //
 // Why a second kernel: k_conv_igemm<2,1> ran these layers at 19 % of the MFMA peak.  With N = 32 every A fragment
 // feeds ONE MFMA, so the LDS fragment traffic (3 ds_read_b128 per 2 MFMAs) plus halo stores and the transposing
@@ -53,7 +57,11 @@ template <int TD> struct RGeom {
   // origin (u32) and its position (hd | hh << 4 | hw << 8 | exists << 12, u16), filled once per workgroup
   static constexpr bool ITAB = TD == 8;
   static constexpr unsigned ITAB_BASE = 2 * HBUF + TAB;
-  static constexpr unsigned SMEM = TD == 8 ? 2 * HBUF + TAB + (unsigned)UH * NT * 6 : 2 * HBUF;
+  // TD = 8: (mean, rstd) of every input channel, one 256-byte row per 32-channel chunk (Cin <= 32 * MAXC)
+  static constexpr int MAXC = TD == 8 ? 18 : 1;
+  static constexpr unsigned IST_BASE = TD == 8 ? ITAB_BASE + (unsigned)UH * NT * 6 : TAB_BASE + 1536 + 256;
+  static constexpr unsigned SMEM = TD == 8 ? IST_BASE + MAXC * 256 : 2 * HBUF;
+  static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert((unsigned)PIECES * 1024 + 1024 <= HBUF, "no room for the 1 KiB dump behind the pieces of buffer 0");
   static_assert((unsigned)PIECES * 1024 <= HBUF - (TD == 8 ? 0 : TAB), "LDS-DMA pieces overlap the tables");
 };
@@ -126,7 +134,8 @@ __device__ __forceinline__ void r_swap16(float& a, float& b) {
 // TR: the input is transformed (InstanceNorm + ACT) in place in LDS after the LDS-DMA; !TR: used as it is
 // MX: dgrad epilogue (x act'(xh) mask + the two InstanceNorm-backward sums); !MX: forward epilogue (moments)
 // TD: tile depth 8 (one 512-thread workgroup per CU) or 4 (two 256-thread workgroups per CU), see RGeom
-template <int ACT, bool TR, bool MX, int TD>
+// MC: several 32-channel chunks of Cin (units = (tile, chunk), streamed weights, optional second input tensor)
+template <int ACT, bool TR, bool MX, int TD, bool MC>
 __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R32Params p) {
   typedef RGeom<TD> G;
   constexpr int NT = G::NT, NW = G::NW, HP = G::HP, UH = G::UH;
@@ -141,7 +150,10 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   if (t_begin >= t_end) return;
   const unsigned red_base = G::TAB_BASE;              // [NW][16][3] floats
   const unsigned mst_base = red_base + 1536;          // MX: (mean, rstd) of the 32 mask channels, 256 B
-  const unsigned ist_base = mst_base + 256;           // TR: (mean, rstd) of the 32 input channels, 256 B
+  const unsigned ist_base = G::IST_BASE;              // TR: (mean, rstd) of the input channels, 256 B per 32-channel chunk
+  const int oc = blockIdx.y;                          // this workgroup's 32-channel chunk of Cout
+  const int NC = MC ? p.NC : 1;                       // 32-channel chunks of Cin; a unit = (tile, chunk)
+  constexpr bool stream_w = MC;                       // weights of the next unit replace this unit's as they fall dead
 
   // ---- wave = (cout half ch, voxel group vg); lane = (voxel lv of a 2x8 patch, k-group / row-group lq) -----------
   // TD = 8: 4 voxel groups of one h-pair; TD = 4: 2 voxel groups of two h-pairs.  n-tile nt = hp * TD + plane.
@@ -149,11 +161,16 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   const int tw = lv & 7;
   // weights: fragment of tap tp = A operand [16 couts][32 channels]: lane (cout lv, channels 8*lq..+7) = 16 bytes of
   // the packed image [tap][kg = lq>>1][half = lq&1][32 couts][8]
+  // packed image (conv_igemm.hip): [cout block of BN][Cin chunk][tap][kg = lq>>1][half = lq&1][BN couts][8], BN = 32 / 64
   u32x4 wf[27];
+  const unsigned w_tap = 4u * (unsigned)p.BN * 16u;    // bytes per tap
+  const unsigned char* const w_lane = (const unsigned char*)p.w +
+      (size_t)(p.BN == 64 ? oc >> 1 : oc) * (size_t)NC * 27u * w_tap +
+      (unsigned)((lq * p.BN) + (p.BN == 64 ? (oc & 1) * 32 : 0) + 16 * ch + lv) * 16;
   {
-    const unsigned char* wp = (const unsigned char*)p.w + (unsigned)((lq * 32) + 16 * ch + lv) * 16;
+    const unsigned char* wp = w_lane;
 #pragma unroll
-    for (int tp = 0; tp < 27; ++tp) wf[tp] = *(const u32x4*)(wp + (unsigned)(tp * 4 * 32) * 16);
+    for (int tp = 0; tp < 27; ++tp) wf[tp] = *(const u32x4*)(wp + (size_t)tp * w_tap);
 #ifndef CBIM_EMU
     // The compiler tracks these loads as possibly pending at the loop back-edge and guards the first MFMA of every tile
     // with s_waitcnt vmcnt(1) — which, with the LDS-DMA pieces it cannot see in flight, waits for the DMA to land.
@@ -188,19 +205,22 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   };
   const unsigned my_slot = (unsigned)tid & 3u;
 
-  struct TilePos { int n, td, th, tw; };
+  struct TilePos { int n, td, th, tw, cc; };            // a unit: tile + Cin chunk
   auto advance = [&](TilePos& u) {
+    if (++u.cc < NC) return;
+    u.cc = 0;
     if (++u.tw == p.tiles_w) { u.tw = 0; if (++u.th == p.tiles_h) { u.th = 0; if (++u.td == p.tiles_d) { u.td = 0; ++u.n; } } }
   };
   TilePos cur, nxt;
   {
     const int tt = t_begin % tiles_per_n;
     cur.n = t_begin / tiles_per_n; cur.td = tt / (p.tiles_w * p.tiles_h); cur.th = (tt / p.tiles_w) % p.tiles_h; cur.tw = tt % p.tiles_w;
+    cur.cc = 0;
     nxt = cur;
     advance(nxt);
   }
 
-  const unsigned x_sb = (unsigned)p.x_stride * 2u;
+  const unsigned x_sb = (unsigned)p.x_stride * 2u, x2_sb = (unsigned)p.x2_stride * 2u;
   // per-item constants in LDS (TD = 8): decoding the position and multiplying out the offset for every item of every
   // tile was ~50 vector/scalar instructions per item in which the wave issues no MFMA; with the table an item costs two
   // LDS reads, the range test and a 64-bit add
@@ -212,32 +232,39 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
       const unsigned pk = item_pos((unsigned)tid, u);
       const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
       const unsigned rel = r_mul24(r_mul24(hd, (unsigned)p.Hi) + hh, (unsigned)p.Wi) + hw;
-      tab_off[tid + NT * u] = r_mul24(rel, x_sb) + ((my_slot ^ r_swz(hh)) << 4);
+      // MC: row of the box (bytes = rel * row stride of the chunk's tensor); else the byte offset itself
+      tab_off[tid + NT * u] = MC ? rel : r_mul24(rel, x_sb) + ((my_slot ^ r_swz(hh)) << 4);
       tab_pos[tid + NT * u] = (unsigned short)(hd | (hh << 4) | (hw << 8) | ((pk >> 24) << 12));
     }
     // (read back by the same thread only: no barrier needed, the prologue has one anyway)
   }
   // position (hd, hh, hw, exists) and source offset of item u
-  auto item_get = [&](int u, unsigned& hd, unsigned& hh, unsigned& hw, bool& exists, unsigned& off) {
+  auto item_get = [&](int u, unsigned sb, unsigned& hd, unsigned& hh, unsigned& hw, bool& exists, unsigned& off) {
+    unsigned rel;
     if (G::ITAB) {
       const unsigned tl = r_launder((unsigned)tid);      // (keeps the loop-invariant reads inside the tile loop)
       const unsigned ps = tab_pos[tl + NT * u];
-      off = tab_off[tl + NT * u];
+      rel = tab_off[tl + NT * u];
       hd = ps & 15u; hh = (ps >> 4) & 15u; hw = (ps >> 8) & 15u; exists = (ps >> 12) != 0;
     } else {
       const unsigned pk = item_pos(r_launder((unsigned)tid), u);
       hd = pk & 255u; hh = (pk >> 8) & 255u; hw = (pk >> 16) & 255u; exists = (pk >> 24) != 0;
-      off = r_mul24(r_mul24(r_mul24(hd, (unsigned)p.Hi) + hh, (unsigned)p.Wi) + hw, x_sb) + ((my_slot ^ r_swz(hh)) << 4);
+      rel = r_mul24(r_mul24(hd, (unsigned)p.Hi) + hh, (unsigned)p.Wi) + hw;
     }
+    off = (G::ITAB && !MC) ? rel : r_mul24(rel, sb) + ((my_slot ^ r_swz(hh)) << 4);
   };
   // source address of halo item u of tile `tp` (in range: the tensor; padding: 64 zero bytes) ---------------------
   auto item_src = [&](const TilePos& tp, int u) -> const unsigned char* {
     const int id0 = tp.td * TD - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
     const long long org = (((long long)tp.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0;
-    const unsigned char* tbase = (const unsigned char*)p.x + org * (long long)x_sb;   // wave-uniform
+    // chunk cc of the (virtually concatenated) input: chunks below c_split come from x, the others from x2
+    const bool second = MC && tp.cc >= p.c_split;
+    const unsigned sb = second ? x2_sb : x_sb;
+    const unsigned char* tbase = (second ? (const unsigned char*)p.x2 + (tp.cc - p.c_split) * R_RB
+                                         : (const unsigned char*)p.x + tp.cc * R_RB) + org * (long long)sb;   // wave-uniform
     unsigned hd, hh, hw, off;
     bool exists;
-    item_get(u, hd, hh, hw, exists, off);
+    item_get(u, sb, hd, hh, hw, exists, off);
     const bool ld = !(p.dbg & 1) && exists && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
                     (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
     return (ld ? tbase : (const unsigned char*)g_r32_zero) + (ld ? off : 0u);
@@ -261,12 +288,12 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     const int id0 = tp.td * TD - p.pD, ih0 = tp.th * 8 - p.pH, iw0 = tp.tw * 8 - p.pW;
     unsigned hd, hh, hw, off;
     bool exists;
-    item_get(u, hd, hh, hw, exists, off);
+    item_get(u, x_sb, hd, hh, hw, exists, off);
     const bool ld = exists && (unsigned)(id0 + (int)hd) < (unsigned)p.Di && (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi &&
                     (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
     if (exists) {                                     // (items past the box do not exist in LDS)
       unsigned char* cell = smem + buf + ((unsigned)tid + (unsigned)NT * (unsigned)u) * 16u;
-      const float* is = (const float*)(smem + ist_base) + ((my_slot ^ r_swz(hh)) << 4);   // logical chunk of this cell
+      const float* is = (const float*)(smem + ist_base) + tp.cc * 64 + ((my_slot ^ r_swz(hh)) << 4);   // logical chunk of this cell
       const u32x4 raw = *(const u32x4*)cell;
       const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w};
       unsigned ow[4];
@@ -290,7 +317,15 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   };
   auto wait_vm = [&](int n) {   // at most n vector-memory operations of this wave still in flight
 #ifndef CBIM_EMU
-    if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (n >= 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -302,7 +337,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
 
   // ---- per-lane statistics: after the epilogue exchange a lane owns channel chunk cidx = 2*ch + (lq >> 1) -------
   const int cidx = 2 * ch + (lq >> 1);
-  const bool c_ok = cidx * 8 < p.Cout;
+  const bool c_ok = oc * 32 + cidx * 8 < p.Cout;
   float s0[8], s1[8], sh[MX ? 1 : 8];
   float cnt = 0.f;
 #pragma unroll
@@ -341,25 +376,25 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     cnt = 0.f;
     shift_set = false;
     __syncthreads();
-    if (tid < 32 && tid < p.Cout) {
+    if (tid < 32 && oc * 32 + tid < p.Cout) {
       Moments a = {0.f, 0.f, 0.f};
       for (int g = 0; g < NW / 2; ++g) {   // the voxel groups of this channel's cout half
         const float* rr = red + (((2 * g + (tid >> 4)) * 16) + (tid & 15)) * 3;
         if (MX) { a.mean += rr[1]; a.m2 += rr[2]; }
         else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
       }
-      const size_t o = (((size_t)n * p.P + lb) * p.Cout + tid) * 3;
+      const size_t o = (((size_t)n * p.P + lb) * p.Cout + oc * 32 + tid) * 3;
       p.partials[o] = a.n; p.partials[o + 1] = a.mean; p.partials[o + 2] = a.m2;
     }
   };
-  if (want_part && tid < 32 && tid < p.Cout) {
+  if (want_part && tid < 32 && oc * 32 + tid < p.Cout) {
     // empty records (n = 0 merges as the identity): images this strip does not touch, and the records lb + k * grid
     // of a buffer sized for more workgroups than this launch has (p.P = cbim_conv3d_num_tiles records per image)
     const int n_first = t_begin / tiles_per_n, n_last = (t_end - 1) / tiles_per_n;
     for (int n = 0; n < p.N; ++n)
       for (unsigned r = lb; r < (unsigned)p.P; r += gridDim.x)
         if (r != lb || n < n_first || n > n_last) {
-          const size_t o = (((size_t)n * p.P + r) * p.Cout + tid) * 3;
+          const size_t o = (((size_t)n * p.P + r) * p.Cout + oc * 32 + tid) * 3;
           p.partials[o] = 0.f; p.partials[o + 1] = 0.f; p.partials[o + 2] = 0.f;
         }
   }
@@ -370,14 +405,14 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     if (MX && n != mst_n) {
       if (tid < 64) {
         const int c = tid >> 1;
-        ((float*)(smem + mst_base))[tid] = c < p.Cout ? p.m_stats[((size_t)n * p.Cout + c) * 2 + (tid & 1)] : (float)(tid & 1);
+        ((float*)(smem + mst_base))[tid] = oc * 32 + c < p.Cout ? p.m_stats[((size_t)n * p.Cout + oc * 32 + c) * 2 + (tid & 1)] : (float)(tid & 1);
       }
       mst_n = n;
     }
   };
   auto load_istats = [&](int n) {
     if (TR && n != ist_n) {
-      if (tid < 64) ((float*)(smem + ist_base))[tid] = p.in_stats[(size_t)n * 64 + tid];
+      for (int i = tid; i < NC * 64; i += NT) ((float*)(smem + ist_base))[i] = p.in_stats[(size_t)n * (NC * 64) + i];
       ist_n = n;
     }
   };
@@ -397,17 +432,22 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   }
 
   r_f32x4 acc[8];
-  const int n_my = t_end - t_begin;
+  const int n_my = (t_end - t_begin) * NC;              // units
   for (int t = 0; t < n_my; ++t) {
     const unsigned buf = (unsigned)(t & 1) * HBUF, obuf = HBUF - buf;
     const bool more = t + 1 < n_my;
+    const bool first_cc = cur.cc == 0, last_cc = cur.cc == NC - 1;
     // the next tile's transforms run during THIS tile: at an image change the statistics table is rewritten first (no
     // reader is active here: the previous tile's transforms ended before its barrier)
     if (TR && more && nxt.n != ist_n) { load_istats(nxt.n); __syncthreads(); }
     TilePos nx;
     nx.n = more ? nxt.n : cur.n; nx.td = more ? nxt.td : cur.td; nx.th = more ? nxt.th : cur.th; nx.tw = more ? nxt.tw : cur.tw;
+    nx.cc = more ? nxt.cc : cur.cc;
+    if (first_cc) {
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) acc[nt] = r_f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < 8; ++nt) acc[nt] = r_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned char* const w_next = w_lane + (size_t)nx.cc * 27u * w_tap;
     // (B) 9 (kh, kw) steps x HP patches: the TD+2 plane fragments of a patch stream through a ring of 5 registers,
     //     plane i feeds the MFMAs (n-tile i, kd 0), (i-1, kd 1), (i-2, kd 2).  The halo of the next tile is fetched by
     //     LDS-DMA during the first steps; TR: a piece is transformed in place four steps after its fetch.
@@ -434,7 +474,8 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
           }
           if (TR && s >= 9 - FS) {
             const int k = s - (9 - FS);                      // 0 .. FS-1: transforms items 2k, 2k+1
-            wait_vm(UH - 2 * k - 2 > 0 ? UH - 2 * k - 2 : 0);
+            // own pieces younger than item 2k+1, plus (streamed weights) the 3 fragment loads of each step since
+            wait_vm((UH - 2 * k - 2 > 0 ? UH - 2 * k - 2 : 0) + (stream_w ? 3 * (9 - FS) : 0));
             tr_xform(nx, 2 * k, obuf);
             if (2 * k + 1 < UH) tr_xform(nx, 2 * k + 1, obuf);
           }
@@ -458,6 +499,12 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
             R_SCHED_FENCE();
           }
         }
+        // the three fragments of this (kh, kw) are dead until step s of the next unit: reload them for it now
+        if (stream_w) {
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd)
+            wf[(kd * 3 + kh) * 3 + kw] = *(const u32x4*)(w_next + (size_t)((kd * 3 + kh) * 3 + kw) * w_tap);
+        }
       }
     }
     // epilogue operands (mask / residual rows of the lane's four output voxels): requested BEFORE the tile barrier, so
@@ -471,7 +518,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     const unsigned char* res_tile = (const unsigned char*)p.res + orow * (long long)res_sb;
     const unsigned char* mx_tile = (const unsigned char*)p.mx + orow * (long long)mx_sb;
     const unsigned plane2 = 2u * r_mul24((unsigned)p.Ho, (unsigned)p.Wo);
-    const unsigned cb = (unsigned)cidx * 16u;
+    const unsigned cb = (unsigned)(oc * 4 + cidx) * 16u;
     // after the exchange this lane owns, for pair pr = (hp, pp): chunk cidx of voxel (2pp + (lq&1), th(hp), tw)
     constexpr int NPAIR = 4;                               // 8 n-tiles
     auto pair_rel = [&](int pr) -> unsigned {
@@ -485,7 +532,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     u32x4 rq[NPAIR];
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) {
-      const bool in = pair_in(pr) && c_ok && !(p.dbg & (4 | 8));
+      const bool in = last_cc && pair_in(pr) && c_ok && !(p.dbg & (4 | 8));
       const unsigned rel = pair_rel(pr);
       rq[pr] = u32x4{0u, 0u, 0u, 0u};
       if (in) {
@@ -496,11 +543,14 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     // (D) ONE barrier per tile: every wave is done with `buf`, the other buffer is complete (own LDS-DMA waited for,
     //     LDS stores drained)
     load_mstats(cur.n);
-    r_wait_vm0();
+    // own LDS-DMA pieces landed.  Streamed weights: the fragment loads issued after the last piece (steps FS-1 .. 8) may
+    // stay in flight (vector-memory operations complete in order)
+    if (stream_w) wait_vm(3 * (10 - (UH + 1) / 2));
+    else r_wait_vm0();
     __syncthreads();
     // (C) epilogue of this tile — no barrier inside (except at an image change); its stores drain under the next
     //     tile's MFMAs
-    if (!(p.dbg & 4)) {
+    if (last_cc && !(p.dbg & 4)) {
       if (want_part && n != run_n) { flush_stats(run_n); run_n = n; }
 #pragma unroll
       for (int pr = 0; pr < NPAIR; ++pr) {
@@ -580,18 +630,34 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
 using namespace cbim;
 
 static int64_t g_r32_min_voxels = 262144;   // same threshold as the 8x8x8 tile configuration of k_conv_igemm
+static int r32_tile_depth();
 
-bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, const float* in_stats, const void* res,
+// CBIM_CONV_R32: 0 off, 1 the single-chunk layers only (Cin = 32, Cout <= 32), 2 (default) every multiple of 32
+static int r32_mode() {
+  static const int m = getenv("CBIM_CONV_R32") ? atoi(getenv("CBIM_CONV_R32")) : 2;
+  return m;
+}
+bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, int cin_split, const float* in_stats, const void* res,
                             const void* mask_x) {
-  static const int on = getenv("CBIM_CONV_R32") ? atoi(getenv("CBIM_CONV_R32")) : 1;
-  if (!on || d->dtype != CBIM_BF16 || x2) return false;
-  if (d->kD != 3 || d->kH != 3 || d->kW != 3 || d->Cin != 32 || d->Cout > 32) return false;
+  const int mode = r32_mode();
+  if (!mode || d->dtype != CBIM_BF16) return false;
+  if (d->kD != 3 || d->kH != 3 || d->kW != 3 || d->Cin % 32 != 0 || !(d->Cout <= 32 || d->Cout % 32 == 0)) return false;
+  if (mode == 1 && (d->Cin != 32 || d->Cout > 32 || x2)) return false;
+  if (d->Cin > 32 * RGeom<8>::MAXC || (d->Cin > 32 && r32_tile_depth() != 8)) return false;
+  if (x2 && (cin_split <= 0 || cin_split >= d->Cin || cin_split % 32 != 0)) return false;
   if (d->Do < 8 || d->Ho < 8 || d->Wo < 8) return false;
   if (!(d->act == CBIM_ACT_RELU || d->act == CBIM_ACT_NONE)) return false;
   if (mask_x && (in_stats || res)) return false;   // masked epilogue: raw input, no accumulate tensor
-  // at least ~2 tiles per CU, like the 8x8x8 configuration of k_conv_igemm
   const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
-  return S >= g_r32_min_voxels;
+  if (g_r32_min_voxels == 0) return true;            // forced (tests, tools)
+  if (d->Cin == 32 && d->Cout <= 32) return S >= g_r32_min_voxels;   // at least ~2 tiles per CU
+  // several chunks.  Measured against k_conv_igemm<2,2> (profiles/r02_m_conv_bench_ab.txt): ahead where the 64-wide
+  // n-blocks of that kernel are half empty (Cout = 32, 96, ...), for single-chunk inputs, and at 32^3 where its tiles
+  // are too few; behind (the per-unit input transform is not amortised over two Cout chunks) on 64-multiples at >= 64^3
+  const int64_t tiles = (int64_t)d->N * ((d->Do + 7) / 8) * ((d->Ho + 7) / 8) * ((d->Wo + 7) / 8);
+  const int n_oc = (d->Cout + 31) / 32;
+  if (S >= g_r32_min_voxels) return d->Cin == 32 || d->Cout % 64 != 0;
+  return S >= g_r32_min_voxels / 8 && tiles * n_oc >= 192;
 }
 
 extern "C" int64_t cbim_conv_r32_min_voxels(int64_t v) {
@@ -613,36 +679,42 @@ extern "C" int cbim_conv_r32_tile_depth(int td) {
 int64_t cbim_conv_r32_grid(const cbim_conv_desc* d) {
   const int td = r32_tile_depth();
   const int64_t n_tiles = (int64_t)d->N * ((d->Do + td - 1) / td) * ((d->Ho + 7) / 8) * ((d->Wo + 7) / 8);
-  const int64_t cap = td == 8 ? 256 : 512;
+  const int n_oc = (d->Cout + 31) / 32;
+  int64_t cap = (td == 8 ? 256 : 512) / n_oc;      // about one workgroup per CU over all Cout chunks
+  if (cap < 1) cap = 1;
   return n_tiles < cap ? n_tiles : cap;
 }
 
-template <int ACT, bool TR, bool MX, int TD>
-static int r32_launch_td(const R32Params& p, dim3 grid, hipStream_t st) {
+template <int ACT, bool TR, bool MX, int TD, bool MC>
+static int r32_launch_mc(const R32Params& p, dim3 grid, hipStream_t st) {
 #ifndef CBIM_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv3_r32<ACT, TR, MX, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv3_r32<ACT, TR, MX, TD, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
 #endif
-  CBIM_LAUNCH((k_conv3_r32<ACT, TR, MX, TD>), grid, dim3(RGeom<TD>::NT), (size_t)RGeom<TD>::SMEM, st, p);
+  CBIM_LAUNCH((k_conv3_r32<ACT, TR, MX, TD, MC>), grid, dim3(RGeom<TD>::NT), (size_t)RGeom<TD>::SMEM, st, p);
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv r32 launch: %s", hipGetErrorString(e));
   return CBIM_OK;
 }
 template <int ACT, bool TR, bool MX>
 static int r32_launch(const R32Params& p, dim3 grid, hipStream_t st) {
-  return r32_tile_depth() == 8 ? r32_launch_td<ACT, TR, MX, 8>(p, grid, st) : r32_launch_td<ACT, TR, MX, 4>(p, grid, st);
+  if (p.NC > 1) return r32_launch_mc<ACT, TR, MX, 8, true>(p, grid, st);     // (eligibility: tile depth 8 only)
+  return r32_tile_depth() == 8 ? r32_launch_mc<ACT, TR, MX, 8, false>(p, grid, st) : r32_launch_mc<ACT, TR, MX, 4, false>(p, grid, st);
 }
 
-int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats,
-                         const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
+int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                         int cin_split, const float* in_stats, const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
                          int64_t mask_stride, const float* mask_stats, void* y, int64_t y_stride, float* partials,
                          void* stream) {
   R32Params p;
   p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.w = w_packed;
+  p.NC = d->Cin / 32;
+  p.x2 = x2; p.x2_stride = x2 ? x2_stride : x_stride; p.c_split = x2 ? cin_split / 32 : p.NC;
+  p.BN = d->Cout <= 32 ? 32 : 64;
   p.res = res; p.res_stride = res_stride; p.mx = mask_x; p.mx_stride = mask_stride; p.m_stats = mask_stats;
   p.y = y; p.y_stride = y_stride; p.partials = partials;
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
@@ -654,7 +726,7 @@ int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_strid
   CBIM_CHECK(!partials || p.P >= (int)cbim_conv_r32_grid(d), CBIM_EINVAL, "conv r32: %d partial records < grid", p.P);
   {
     // 32-bit byte offsets inside one halo box / one output tile, built from 24-bit multiplies
-    const int64_t box_rows = (int64_t)(td + 2) * d->Hi * d->Wi, xs = x_stride * 2;
+    const int64_t box_rows = (int64_t)(td + 2) * d->Hi * d->Wi, xs = (x2 && x2_stride > x_stride ? x2_stride : x_stride) * 2;
     CBIM_CHECK(box_rows < (1 << 24) && xs < (1 << 24) && box_rows * xs < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
                "conv r32: input plane %dx%d with row stride %lld B exceeds the 32-bit halo addressing", d->Hi, d->Wi, (long long)xs);
     const int64_t tile_rows = (int64_t)td * d->Ho * d->Wo;
@@ -664,7 +736,7 @@ int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_strid
     CBIM_CHECK(tile_rows < (1 << 24) && so < (1 << 24) && tile_rows * so < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
                "conv r32: output plane %dx%d with row stride %lld B exceeds the 32-bit epilogue addressing", d->Ho, d->Wo, (long long)so);
   }
-  dim3 grid((unsigned)cbim_conv_r32_grid(d));
+  dim3 grid((unsigned)cbim_conv_r32_grid(d), (unsigned)((d->Cout + 31) / 32));
   hipStream_t st = (hipStream_t)stream;
   const bool relu = d->act == CBIM_ACT_RELU;
   // (eligibility: act is ReLU or none; a transformed input comes with the forward epilogue, a mask with an input

@@ -433,7 +433,7 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
         e1.record()
         cfg = (C.c_int * 4)()
         L.cbim_conv3d_tile_config(C.byref(desc), C.byref(cfg))
-        if cfg[0] == 4 and x2 is None:
+        if cfg[0] == 4:
             name = "k_conv3_r32<bf16>"
         else:
             if cfg[0] == 4:

@@ -138,15 +138,17 @@ def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0, act="relu"):
     assert float((sums[..., 1].cpu() - (gm * xh).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
 
 
-def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21, tile_depth=8):
-    """The 'weights in registers' kernel for Cin = 32 -> Cout <= 32, 3x3x3, bf16 (conv_r32.hip) against torch AND against
-    k_conv_igemm on the same inputs: transformed input + residual + statistics (forward), raw input (LDS-DMA path),
-    plain dgrad, masked dgrad with the two InstanceNorm-backward sums."""
+def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21, tile_depth=8, Cin=32, dy_split=0):
+    """The 'weights in registers' kernel (conv_r32.hip: bf16, 3x3x3, channels in multiples of 32, Cout <= 32 or a multiple
+    of 32) against torch AND against k_conv_igemm on the same inputs: transformed input + residual + statistics
+    (forward), raw input (LDS-DMA path), plain dgrad, masked dgrad with the two InstanceNorm-backward sums.
+    dy_split > 0: the dgrad input is the virtual concatenation [dy[..., :dy_split] | dy[..., dy_split:]] (conv1 +
+    shortcut as one GEMM)."""
     from cbim_amd import _lib
     L = _lib.lib()
     dtype = torch.bfloat16
     torch.manual_seed(seed)
-    k, pad, Cin = (3, 3, 3), (1, 1, 1), 32
+    k, pad = (3, 3, 3), (1, 1, 1)
     x = torch.randn(N, Cin, *dhw) + 0.5
     w = torch.randn(Cout, Cin, *k) * 0.1
     xl = to_cl(x, dtype).to(dev)
@@ -162,19 +164,25 @@ def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21, tile
     resl = to_cl(res, dtype).to(dev)
     dy = torch.randn(N, Cout, *dhw)
     dyl = to_cl(dy, dtype).to(dev)
-    # dgrad geometry of this layer: Cout_dgrad = Cin = 32, Cin_dgrad = Cout -> only Cout == 32 is the r32 shape
+    # dgrad of this layer = a convolution Cout -> Cin: the r32 shape when Cout is a multiple of 32
+    dgrad_r32 = Cout % 32 == 0
     mk = torch.randn(N, Cin, *dhw) * 1.3 + 0.2
     mkl = to_cl(mk, dtype).to(dev)
     mst = ops.instnorm_stats(mkl)
+    if dy_split:
+        dya, dyb = dyl[..., :dy_split].contiguous(), dyl[..., dy_split:].contiguous()
 
     def run():
         y, ys = ops.conv_fwd(xl, wp, geom, in_stats=st, res=resl, want_stats=True)
         y0, ys0 = ops.conv_fwd(xl, wp, geom, want_stats=True)
         y1, _ = ops.conv_fwd(xl, wp, geom)
         out = [y, ys, y0, ys0, y1]
-        if Cout == 32:
+        if dgrad_r32:
             g, _ = ops.conv_dgrad(dyl, wpd, geom)
-            g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=mkl, mask_stats=mst)
+            if dy_split:
+                g2, sums = ops.conv_dgrad(dya, wpd, geom, mask_x=mkl, mask_stats=mst, dy2=dyb)
+            else:
+                g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=mkl, mask_stats=mst)
             out += [g, g2, sums]
         return [o.float().cpu() for o in out]
 
@@ -196,7 +204,7 @@ def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21, tile
     assert relerr(from_cl(got[0]), yr) < 1e-2, "fwd vs torch"
     assert relerr(got[1][..., 0], yr.mean((2, 3, 4))) < 1e-2 + 1e-4
     assert relerr(from_cl(got[2]), F.conv3d(xr, wr, None, 1, pad)) < 1e-2, "raw fwd vs torch"
-    if Cout == 32:
+    if dgrad_r32:
         dyr = from_cl(dyl.cpu())
         gr = F.conv_transpose3d(dyr, wr, None, 1, pad)
         assert relerr(from_cl(got[5]), gr) < 1e-2, "dgrad vs torch"

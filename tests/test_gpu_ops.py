@@ -60,6 +60,10 @@ def test_conv_r32_weights_in_registers(dev):
     oc.check_conv_r32(dev, N=1, Cout=16, dhw=(8, 8, 16), act="none")
     oc.check_conv_r32(dev, tile_depth=4)                            # two 256-thread workgroups per CU, 4x8x8 tiles
     oc.check_conv_r32(dev, N=1, Cout=32, dhw=(13, 8, 24), tile_depth=4, act="none")
+    # several 32-channel chunks: Cin chunks walked with streamed weights, Cout chunks on blockIdx.y
+    oc.check_conv_r32(dev, N=1, Cin=64, Cout=32, dhw=(9, 8, 16))
+    oc.check_conv_r32(dev, N=2, Cin=96, Cout=64, dhw=(8, 9, 8), dy_split=32)     # 64-cout weight blocks; dgrad over [dy1 | dout]
+    oc.check_conv_r32(dev, N=1, Cin=32, Cout=96, dhw=(8, 8, 8), act="none")     # Cout 96: the last 64-block is half empty
     oc.check_conv_r32(dev, N=1, Cout=32, dhw=(64, 64, 64))          # the default threshold: picked without the knob
 
 

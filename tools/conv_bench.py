@@ -32,7 +32,10 @@ def timeit(fn):
     return e0.elapsed_time(e1) / reps
 
 
-print(f"dtype={dtype} reps={reps} dbg={os.environ.get('CBIM_IGEMM_DBG', '0')}")
+if os.environ.get("CB_R32_MINVOX"):
+    from cbim_amd import _lib
+    _lib.lib().cbim_conv_r32_min_voxels(int(os.environ["CB_R32_MINVOX"]))
+print(f"dtype={dtype} reps={reps} dbg={os.environ.get('CBIM_IGEMM_DBG', '0')} r32={os.environ.get('CBIM_CONV_R32', '2')} minvox={os.environ.get('CB_R32_MINVOX', '-')}")
 for cin, cout, s in SHAPES:
     x = torch.randn(1, s, s, s, cin, device=dev).to(dtype)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
