@@ -348,9 +348,39 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   // combine the lanes' sums of image n into this workgroup's record and reset them (all threads call it).  The 32 lanes
   // that hold a channel chunk share ONE shift (taken from the group's first lane when the sums start), so their sums
   // simply add: 5 butterfly rounds over 17 independent values, one conversion to (n, mean, M2) per channel and wave.
+  // MC: the per-lane sums would be ~25 more registers alive through the MFMA phase (measured: 21-29 spilled VGPRs whose
+  // reloads next to the unit barrier drain the weight stream).  The statistics of a tile are reduced over the lanes in its
+  // epilogue — once per NC units — and merged into the wave's running record in LDS (red, wave-private).
+  auto tile_stats = [&](float (&t0)[8], float (&t1)[8], const float (&tsh)[MX ? 1 : 8], float tcnt) {
+    float* red = (float*)(smem + red_base);
+#pragma unroll
+    for (int msk = 1; msk < 32; msk <<= 1) {
+      float u0[8], u1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { u0[j] = __shfl_xor(t0[j], msk, 64); u1[j] = __shfl_xor(t1[j], msk, 64); }
+      const float tc = __shfl_xor(tcnt, msk, 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { t0[j] += u0[j]; t1[j] += u1[j]; }
+      tcnt += tc;
+    }
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float* rr = red + ((wave * 16) + (lq >> 1) * 8 + j) * 3;
+        if (MX) { rr[1] += t0[j]; rr[2] += t1[j]; }
+        else {
+          const Moments a = {rr[0], rr[1], rr[2]};
+          const Moments b = moments_from_shifted(tcnt, tsh[MX ? 0 : j], t0[j], t1[j]);
+          const Moments m = moments_merge(a, b);
+          rr[0] = m.n; rr[1] = m.mean; rr[2] = m.m2;
+        }
+      }
+    }
+  };
   auto flush_stats = [&](int n) {
     __syncthreads();
     float* red = (float*)(smem + red_base);
+    if (!MC) {
 #pragma unroll
     for (int msk = 1; msk < 32; msk <<= 1) {   // lanes differing in bits 0..4 (voxel, lq & 1) hold the same channels
       float t0[8], t1[8];
@@ -375,6 +405,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
     cnt = 0.f;
     shift_set = false;
+    }
     __syncthreads();
     if (tid < 32 && oc * 32 + tid < p.Cout) {
       Moments a = {0.f, 0.f, 0.f};
@@ -386,7 +417,14 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
       const size_t o = (((size_t)n * p.P + lb) * p.Cout + oc * 32 + tid) * 3;
       p.partials[o] = a.n; p.partials[o + 1] = a.mean; p.partials[o + 2] = a.m2;
     }
+    if (MC) {                                 // the next image starts from empty records
+      __syncthreads();
+      for (int i = tid; i < NW * 16 * 3; i += NT) red[i] = 0.f;
+    }
   };
+  if (MC) {
+    for (int i = tid; i < NW * 16 * 3; i += NT) ((float*)(smem + red_base))[i] = 0.f;   // (the prologue barriers follow)
+  }
   if (want_part && tid < 32 && oc * 32 + tid < p.Cout) {
     // empty records (n = 0 merges as the identity): images this strip does not touch, and the records lb + k * grid
     // of a buffer sized for more workgroups than this launch has (p.P = cbim_conv3d_num_tiles records per image)
@@ -531,18 +569,21 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     };
     u32x4 rq[NPAIR];
 #pragma unroll
-    for (int pr = 0; pr < NPAIR; ++pr) {
-      const bool in = last_cc && pair_in(pr) && c_ok && !(p.dbg & (4 | 8));
-      const unsigned rel = pair_rel(pr);
-      rq[pr] = u32x4{0u, 0u, 0u, 0u};
-      if (in) {
-        if (MX) rq[pr] = *(const u32x4*)(mx_tile + (r_mul24(rel, mx_sb) + cb));
-        else if (p.res) rq[pr] = *(const u32x4*)(res_tile + (r_mul24(rel, res_sb) + cb));
+    for (int pr = 0; pr < NPAIR; ++pr) rq[pr] = u32x4{0u, 0u, 0u, 0u};
+    if (last_cc) {      // (a branch, not a predicate: the units in between must not touch — reload — any of this)
+#pragma unroll
+      for (int pr = 0; pr < NPAIR; ++pr) {
+        const bool in = pair_in(pr) && c_ok && !(p.dbg & (4 | 8));
+        const unsigned rel = pair_rel(pr);
+        if (in) {
+          if (MX) rq[pr] = *(const u32x4*)(mx_tile + (r_mul24(rel, mx_sb) + cb));
+          else if (p.res) rq[pr] = *(const u32x4*)(res_tile + (r_mul24(rel, res_sb) + cb));
+        }
       }
+      load_mstats(cur.n);
     }
     // (D) ONE barrier per tile: every wave is done with `buf`, the other buffer is complete (own LDS-DMA waited for,
     //     LDS stores drained)
-    load_mstats(cur.n);
     // own LDS-DMA pieces landed.  Streamed weights: the fragment loads issued after the last piece (steps FS-1 .. 8) may
     // stay in flight (vector-memory operations complete in order)
     if (stream_w) wait_vm(3 * (10 - (UH + 1) / 2));
@@ -552,6 +593,17 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     //     tile's MFMAs
     if (last_cc && !(p.dbg & 4)) {
       if (want_part && n != run_n) { flush_stats(run_n); run_n = n; }
+      // statistics of this tile: running per-lane sums (single chunk) or tile-local sums reduced below (MC)
+      float l0[8], l1[8], lsh[MX ? 1 : 8];
+      float lcnt = 0.f;
+      bool lset = false;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { l0[j] = 0.f; l1[j] = 0.f; lsh[MX ? 0 : j] = 0.f; }
+      float (&S0)[8] = MC ? l0 : s0;
+      float (&S1)[8] = MC ? l1 : s1;
+      float (&SH)[MX ? 1 : 8] = MC ? lsh : sh;
+      float& CNT = MC ? lcnt : cnt;
+      bool& SHSET = MC ? lset : shift_set;
 #pragma unroll
       for (int pr = 0; pr < NPAIR; ++pr) {
         const bool in = pair_in(pr);
@@ -587,10 +639,10 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
             v[2 * j] = g.x;
             v[2 * j + 1] = g.y;
             const f2_t gl = g * live2;
-            f2_t a0 = {s0[2 * j], s0[2 * j + 1]}, a1 = {s1[2 * j], s1[2 * j + 1]};
+            f2_t a0 = {S0[2 * j], S0[2 * j + 1]}, a1 = {S1[2 * j], S1[2 * j + 1]};
             a0 = a0 + gl;
             a1 = __builtin_elementwise_fma(gl, xh, a1);
-            s0[2 * j] = a0.x; s0[2 * j + 1] = a0.y; s1[2 * j] = a1.x; s1[2 * j + 1] = a1.y;
+            S0[2 * j] = a0.x; S0[2 * j + 1] = a0.y; S1[2 * j] = a1.x; S1[2 * j + 1] = a1.y;
           }
         } else {
 #pragma unroll
@@ -599,25 +651,26 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
             v[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u);
           }
           if (want_part && !(p.dbg & 32)) {
-            if (!shift_set) {            // common shift of the 32 lanes that hold this chunk: any finite value near
-              shift_set = true;          // the data works (shifted moments); taken from the group's first lane
+            if (!SHSET) {            // common shift of the 32 lanes that hold this chunk: any finite value near
+              SHSET = true;             // the data works (shifted moments); taken from the group's first lane
 #pragma unroll
-              for (int j = 0; j < 8; ++j) sh[MX ? 0 : j] = __shfl(v[j], lane & 32, 64);
+              for (int j = 0; j < 8; ++j) SH[MX ? 0 : j] = __shfl(v[j], lane & 32, 64);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const f2_t x = {v[2 * j], v[2 * j + 1]}, hs = {sh[MX ? 0 : 2 * j], sh[MX ? 0 : 2 * j + 1]};
+              const f2_t x = {v[2 * j], v[2 * j + 1]}, hs = {SH[MX ? 0 : 2 * j], SH[MX ? 0 : 2 * j + 1]};
               const f2_t d = (x - hs) * live2;
-              f2_t a0 = {s0[2 * j], s0[2 * j + 1]}, a1 = {s1[2 * j], s1[2 * j + 1]};
+              f2_t a0 = {S0[2 * j], S0[2 * j + 1]}, a1 = {S1[2 * j], S1[2 * j + 1]};
               a0 = a0 + d;
               a1 = __builtin_elementwise_fma(d, d, a1);
-              s0[2 * j] = a0.x; s0[2 * j + 1] = a0.y; s1[2 * j] = a1.x; s1[2 * j + 1] = a1.y;
+              S0[2 * j] = a0.x; S0[2 * j + 1] = a0.y; S1[2 * j] = a1.x; S1[2 * j + 1] = a1.y;
             }
           }
         }
         if (in && c_ok && !(p.dbg & 16)) *(u32x4*)(y_tile + (r_mul24(rel, y_sb) + cb)) = Elem<bf16_tag>::pack(v);
-        cnt += live;
+        CNT += live;
       }
+      if (MC && want_part && !(p.dbg & 32)) tile_stats(l0, l1, lsh, lcnt);
     }
     cur = nxt;
     advance(nxt);
@@ -651,12 +704,13 @@ bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, int cin_spl
   const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
   if (g_r32_min_voxels == 0) return true;            // forced (tests, tools)
   if (d->Cin == 32 && d->Cout <= 32) return S >= g_r32_min_voxels;   // at least ~2 tiles per CU
-  // several chunks.  Measured against k_conv_igemm<2,2> (profiles/r02_m_conv_bench_ab.txt): ahead where the 64-wide
-  // n-blocks of that kernel are half empty (Cout = 32, 96, ...), for single-chunk inputs, and at 32^3 where its tiles
-  // are too few; behind (the per-unit input transform is not amortised over two Cout chunks) on 64-multiples at >= 64^3
+  // several chunks, measured against k_conv_igemm (profiles/r02_p_conv_bench_ab.txt).  Raw input (dgrad, LDS-DMA only):
+  // ahead on every shape, 2-24 %.  Transformed input (forward: InstanceNorm + activation applied in LDS once per unit
+  // and per Cout chunk): ahead for single-chunk inputs, where the 64-wide n-blocks of k_conv_igemm are half empty
+  // (Cout = 32, 96, ...) and at 32^3 where its tiles are too few; 10-15 % behind on 64-multiples at >= 64^3.
   const int64_t tiles = (int64_t)d->N * ((d->Do + 7) / 8) * ((d->Ho + 7) / 8) * ((d->Wo + 7) / 8);
   const int n_oc = (d->Cout + 31) / 32;
-  if (S >= g_r32_min_voxels) return d->Cin == 32 || d->Cout % 64 != 0;
+  if (S >= g_r32_min_voxels) return !in_stats || d->Cin == 32 || d->Cout % 64 != 0;
   return S >= g_r32_min_voxels / 8 && tiles * n_oc >= 192;
 }
 

@@ -18,7 +18,10 @@ from cbim_amd import ops
 
 which = sys.argv[1] if len(sys.argv) > 1 else "igemm"
 dtype = torch.bfloat16
-for cin, cout, s in [(32, 32, 128), (64, 64, 64), (192, 64, 64)]:
+SH = [(32, 32, 128), (64, 64, 64), (192, 64, 64)]
+if os.environ.get("CB_SHAPES"):
+    SH = [tuple(int(v) for v in t.split("x")) for t in os.environ["CB_SHAPES"].split(",")]
+for cin, cout, s in SH:
     x = torch.randn(1, s, s, s, cin, device="cuda").to(dtype)
     w = torch.randn(cout, cin, 3, 3, 3, device="cuda") * 0.05
     geom = ops.ConvGeom(dtype, 1, (s, s, s), cin, cout, (3, 3, 3), (1, 1, 1), 1)
