@@ -215,6 +215,35 @@ def check_conv_r32(dev, N=2, Cout=32, dhw=(9, 16, 11), act="relu", seed=21, tile
         assert float((got[7][..., 1] - (gm * mh).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
 
 
+def check_wgrad_large(dev, N=2, Cin=64, Cout=32, dhw=(8, 64, 64), act="relu", raw=False, split=0, seed=5):
+    """Weight gradient of a bf16 3x3x3 convolution at >= 32768 voxels (the 4x8x8-tile, fully unrolled path of
+    k_conv_wgrad) against torch.  raw: no input transform (SingleConv's wgrad); split > 0: dy as two tensors (conv1 +
+    shortcut as one GEMM)."""
+    dtype = torch.bfloat16
+    torch.manual_seed(seed)
+    k, pad = (3, 3, 3), (1, 1, 1)
+    x = torch.randn(N, Cin, *dhw) * 1.2 + 0.3
+    xl = to_cl(x, dtype).to(dev)
+    xr = from_cl(xl.cpu())
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, ops.ACT[act])
+    st = None if raw else ops.instnorm_stats(xl)
+    if raw:
+        a = xr
+    else:
+        xh = F.instance_norm(xr, eps=1e-4)
+        a = (F.relu(xh) if act == "relu" else xh).bfloat16().float()
+    dy = torch.randn(N, Cout, *dhw)
+    dyl = to_cl(dy, dtype).to(dev)
+    if split:
+        dw = ops.conv_wgrad(xl, st, dyl[..., :split].contiguous(), geom, dy2=dyl[..., split:].contiguous())
+    else:
+        dw = ops.conv_wgrad(xl, st, dyl, geom)
+    w = torch.zeros(Cout, Cin, *k, requires_grad=True)
+    F.conv3d(a, w, None, 1, pad).backward(from_cl(dyl.cpu()))
+    e = relerr(dw.cpu(), w.grad)
+    assert e < 1e-3, f"wgrad vs torch {e:.3e}"
+
+
 def check_stem_head(dev, dtype, N=1, Cin=2, base=8, K=5, dhw=(6, 9, 10), k=(3, 3, 3)):
     torch.manual_seed(4)
     pad = [i // 2 for i in k]

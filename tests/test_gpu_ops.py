@@ -187,3 +187,10 @@ def test_fused_adamw_ema(dev):
     from tests.optim_checks import check_adamw_ema
     check_adamw_ema(dev)
     check_adamw_ema(dev, steps=7, seed=32)
+
+
+@pytest.mark.gpu
+def test_wgrad_unrolled_plane_path_at_32k_voxels(dev):
+    oc.check_wgrad_large(dev)                                # 8x64x64 = 2 x 8 x 8 tiles of 4x8x8
+    oc.check_wgrad_large(dev, N=1, Cin=32, Cout=64, dhw=(30, 36, 41), act="none", split=32)
+    oc.check_wgrad_large(dev, N=1, Cin=32, Cout=32, dhw=(33, 32, 40), raw=True)

@@ -187,3 +187,9 @@ def test_inference_and_dice(dev):
     from tests import infer_checks as ic
     ic.check_dice_exact(dev)
     ic.check_sliding_window(dev, full=False)      # one 32^3 window on the executor; the 12-window run is a GPU test
+
+
+def test_wgrad_unrolled_plane_path_at_32k_voxels(dev):
+    oc.check_wgrad_large(dev, N=1, Cin=32)                                # 8x64x64 = 2 x 8 x 8 tiles of 4x8x8
+    oc.check_wgrad_large(dev, N=1, Cin=32, Cout=64, dhw=(8, 64, 64), act="none", split=32)
+    oc.check_wgrad_large(dev, N=1, Cin=32, Cout=32, dhw=(8, 64, 64), raw=True)
