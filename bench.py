@@ -8,7 +8,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline     : matrix-core roofline of the dominant kernel (all k_conv_igemm launches of a step),
+  roofline     : matrix-core roofline of the dominant kernel (all launches of that conv kernel in a step),
                  algorithmic FLOPs / HIP-event time measured live on the launch stream
   cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/) timed on this box's
                  host cores on one 1x1x128^3 volume (rank 0, N=1 only)
@@ -325,7 +325,7 @@ def main():
                    "global_batch": world, "parallelism": f"dp{world}", "final_loss": loss_val},
     }
 
-    # ---- roofline of the dominant kernel: every k_conv_igemm launch of one step, HIP events on the launch stream
+    # ---- roofline of the dominant kernel: every launch of the conv kernels in one step, HIP events on the launch stream
     if not args.no_roofline and rank == 0:
         per = {}
         reps = 3
@@ -343,7 +343,9 @@ def main():
         table = {k: {"launches_per_step": v[2] // reps, "avg_launch_ms": v[1] / v[2] * 1e3,
                      "alg_tflop_per_step": v[0] / reps / 1e12, "achieved_tflops": v[0] / v[1] / 1e12,
                      "frac_of_peak": v[0] / v[1] / 1e12 / peak} for k, v in per.items()}
-        dom = max((k for k in per if k.startswith("k_conv_igemm")), key=lambda k: per[k][1])
+        # the dominant kernel = the MFMA conv kernel with the largest share of the step (forward/dgrad kernels; the wgrad
+        # entry sums k_conv_wgrad and its reduce)
+        dom = max((k for k in per if k.startswith(("k_conv_igemm", "k_conv3_r32"))), key=lambda k: per[k][1])
         f, tsec, nl = per[dom]
         fwd128 = {"medformer": FWD_FLOPS_128_MEDFORMER, "swin_unetr": FWD_FLOPS_128_SWIN,
                   "resunet": FWD_FLOPS_128 * (args.base / 32.0) ** 2}[args.model]
@@ -351,7 +353,7 @@ def main():
         # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run
         # inside this process); null when no recorded pass covers this kernel / dtype / model
         traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in ("r01_j_traffic.json", "r01_c_traffic.json"))
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in ("r02_traffic.json", "r01_j_traffic.json", "r01_c_traffic.json"))
                       if os.path.isfile(q)), "")
         if args.model == "resunet" and args.size == 128 and os.path.isfile(tpath):
             traffic = (json.load(open(tpath)).get(dom) or {}).get("hbm_bytes_per_launch")

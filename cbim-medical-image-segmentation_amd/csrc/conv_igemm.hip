@@ -773,77 +773,131 @@ __global__ void __launch_bounds__(FT) k_splitk_finish(const float* __restrict__ 
 // value w[k_ch][n_ch][taps-1-tap]  (w is always the forward [Cout][Cin][taps] tensor).
 // `w` rows (forward output channels) >= rows0 come from `w1` (row r - rows0): a Cout-concatenated convolution
 // (conv1 | shortcut) is packed straight from its two parameter tensors; w1 == nullptr: everything is in `w`.
-// One call produces one 16-byte chunk (CPC consecutive K channels of one (tap, cout)): index `ic` counts chunks.
+//
+// One workgroup = one block of 32 forward output channels x KC input channels x all taps, transposed through LDS:
+// the block is read as 32 contiguous runs of KC*taps floats (a thread-per-chunk version gathered every float at a
+// stride of `taps` floats and re-fetched each cache line ~27 times: 778 us for the ResUNet's 19 M weights, 0.1 TB/s,
+// 4.5 % of the training step) and leaves as runs of 32 (KC) sixteen-byte chunks = 512 contiguous bytes per (tap, k-slot),
+// in BOTH layouts from the one staged copy.
+struct PackGeom { const float* w0; const float* w1; void* p0; void* p1; int rows0, Cout, Cin, taps, BN0, nch0, BN1, nch1; };
+
 template <typename T>
-__device__ __forceinline__ void pack_one(const float* __restrict__ w, const float* __restrict__ w1, int rows0,
-                                         void* __restrict__ packed, int Cout_f,
-                                         int Cin_f, int taps, int mode, int BN, int n_chunks, int64_t ic) {
-  constexpr int CPC = Elem<T>::CPC;
-  constexpr int KC = SLOTS * CPC;
-  const int Kdim = mode == 0 ? Cin_f : Cout_f;
-  const int Ndim = mode == 0 ? Cout_f : Cin_f;
-  // 32-bit decode (a packed image has < 2^31 chunks); BN (32 | 64), 2 and KG are powers of two
-  unsigned r = (unsigned)ic;
-  const int nn = (int)(r & (unsigned)(BN - 1)); r >>= (BN == 64 ? 6 : 5);
-  const int half = (int)(r & 1u); r >>= 1;
-  const int kg = (int)(r % KG); r /= KG;
-  const int tap = (int)(r % (unsigned)taps); r /= (unsigned)taps;
-  const int q = (int)(r % (unsigned)n_chunks);
-  const int nb = (int)(r / (unsigned)n_chunks);
-  const int kc0 = q * KC + (2 * kg + half) * CPC;
-  const int nc = nb * BN + nn;
-  float v[CPC];
+__device__ __forceinline__ void pack_block(const PackGeom& g, int blk, unsigned char* smem) {
+  constexpr int CPC = Elem<T>::CPC, ES = Elem<T>::SIZE;
+  constexpr int KC = SLOTS * CPC;                 // input channels per block (32 bf16 / 16 f32): 64-byte LDS rows
+  constexpr int G = 32 / CPC;                     // groups of CPC output channels in the block
+  const int tid = threadIdx.x, taps = g.taps;
+  const int n_nblk0 = (g.Cout + g.BN0 - 1) / g.BN0, n_nblk1 = (g.Cin + g.BN1 - 1) / g.BN1;
+  const int ci_blks = n_nblk1 * g.BN1 / KC;
+  const int co_b = blk / ci_blks, ci_b = blk - co_b * ci_blks;
+  const int co0 = co_b * 32, ci0 = ci_b * KC;
+  // ---- load: row co = one contiguous, 16-byte aligned run of KC*taps floats (Cin % 4 == 0); eight float4 per thread
+  //      in flight per trip (one load per trip left the kernel latency bound); LDS element (tap, co_l, ci_l) ----------
+  const int seg = KC * taps, seg4 = seg / 4;
+  const unsigned mdiv = ((1u << 20) + (unsigned)taps - 1) / (unsigned)taps;    // idx / taps for idx < 2048, taps <= 64
+  const unsigned mseg = ((1u << 22) + (unsigned)seg4 - 1) / (unsigned)seg4;    // e4 / seg4 for e4 < 32 * seg4 <= 16384
+  const int n_ci = g.Cin - ci0 < KC ? g.Cin - ci0 : KC;                          // valid input channels of the block (<= 0: none)
+  const int total4 = 32 * seg4;
+  constexpr int UL = 8;
+  for (int base = 0; base < total4; base += 256 * UL) {
+    f32x4 v4[UL];
+    int rowv[UL], idxv[UL];
 #pragma unroll
-  for (int j = 0; j < CPC; ++j) {
-    const int kc = kc0 + j;
-    v[j] = 0.f;
-    if (kc < Kdim && nc < Ndim) {
-      const int row = mode == 0 ? nc : kc, col = mode == 0 ? kc : nc, tp = mode == 0 ? tap : taps - 1 - tap;
-      const float* src = (w1 && row >= rows0) ? w1 + (size_t)(row - rows0) * Cin_f * taps : w + (size_t)row * Cin_f * taps;
-      v[j] = src[(size_t)col * taps + tp];
+    for (int u = 0; u < UL; ++u) {
+      const int e4 = base + u * 256 + tid;
+      const int co_l = (int)(((unsigned)e4 * mseg) >> 22);
+      const int idx = (e4 - co_l * seg4) * 4;
+      rowv[u] = co_l; idxv[u] = idx;
+      const int co = co0 + co_l;
+      v4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e4 < total4 && co < g.Cout && n_ci > 0 && idx < n_ci * taps) {   // (n_ci * taps is a multiple of 4)
+        const float* src = ((g.w1 && co >= g.rows0) ? g.w1 + (size_t)(co - g.rows0) * g.Cin * taps : g.w0 + (size_t)co * g.Cin * taps) +
+                           (size_t)ci0 * taps;
+        v4[u] = *(const f32x4*)(src + idx);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      if (base + u * 256 + tid < total4) {
+        const float vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = idxv[u] + j;
+          const int ci_l = (int)(((unsigned)idx * mdiv) >> 20), tap = idx - ci_l * taps;
+          unsigned char* cell = smem + (size_t)((tap * 32 + rowv[u]) * KC + ci_l) * ES;
+          if (ES == 2) *(bf16_t*)cell = (bf16_t)pk_bf16(vv[j], 0.f);
+          else *(float*)cell = vv[j];
+        }
+      }
     }
   }
-  st_chunk<T>(packed, (size_t)ic * CPC, Elem<T>::pack(v));
+  __syncthreads();
+  // ---- forward layout: chunk (tap, k-slot, cout) = 16 contiguous LDS bytes ------------------------------------------
+  if (g.p0 && ci_b < g.nch0) {
+    const int nb = co0 / g.BN0, nn0 = co0 - nb * g.BN0;
+    for (int c = tid; c < taps * 128; c += 256) {
+      const int co_l = c & 31, slot = (c >> 5) & 3, tap = c >> 7;
+      const u32x4 v = *(const u32x4*)(smem + (size_t)(tap * 32 + co_l) * 64 + slot * 16);
+      const size_t ic = ((((size_t)(nb * g.nch0 + ci_b) * taps + tap) * KG + (slot >> 1)) * 2 + (slot & 1)) * g.BN0 + nn0 + co_l;
+      *(u32x4*)((unsigned char*)g.p0 + ic * 16) = v;
+    }
+  }
+  // ---- dgrad layout: K = forward cout (groups of CPC), N = forward cin, taps flipped --------------------------------
+  if (g.p1) {
+    for (int c = tid; c < taps * G * KC; c += 256) {
+      const int ci_l = c % KC, gg = (c / KC) % G, tap = c / (KC * G);
+      const int k0 = co0 + gg * CPC, q1 = k0 / KC, slot = (k0 - q1 * KC) / CPC;
+      const int ci = ci0 + ci_l, nb1 = ci / g.BN1, nn1 = ci - nb1 * g.BN1;
+      if (q1 >= g.nch1 || nb1 >= n_nblk1) continue;
+      u32x4 v;
+      if (ES == 2) {
+        unsigned h[CPC];
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) h[j] = *(const bf16_t*)(smem + (size_t)((tap * 32 + gg * CPC + j) * KC + ci_l) * 2);
+        v = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4 % CPC] | (h[5 % CPC] << 16), h[6 % CPC] | (h[7 % CPC] << 16)};
+      } else {
+        unsigned h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = *(const unsigned*)(smem + (size_t)((tap * 32 + gg * CPC + (j % CPC)) * KC + ci_l) * 4);
+        v = u32x4{h[0], h[1], h[2], h[3]};
+      }
+      const size_t ic = ((((size_t)(nb1 * g.nch1 + q1) * taps + (taps - 1 - tap)) * KG + (slot >> 1)) * 2 + (slot & 1)) * g.BN1 + nn1;
+      *(u32x4*)((unsigned char*)g.p1 + ic * 16) = v;
+    }
+  }
+}
+// blocks of one weight: (32-cout blocks incl. the n-block padding of the forward layout) x (KC-cin blocks incl. that of
+// the dgrad layout)
+static int pack_blocks(int dtype, int Cout, int Cin) {
+  const int KC = RB / (dtype == CBIM_BF16 ? 2 : 4);
+  const int BN0 = Cout <= 32 ? 32 : 64, BN1 = Cin <= 32 ? 32 : 64;
+  return (((Cout + BN0 - 1) / BN0) * BN0 / 32) * (((Cin + BN1 - 1) / BN1) * BN1 / KC);
 }
 
 // One launch packs the forward layout, the dgrad layout, or both (p0/p1 may be null).
 template <typename T>
-__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, void* __restrict__ p0,
-                                                      void* __restrict__ p1, int Cout_f, int Cin_f, int taps,
-                                                      int BN0, int nch0, int64_t total0, int BN1, int nch1,
-                                                      int64_t total1) {
-  constexpr int CPC = Elem<T>::CPC;
-  const int64_t c0 = total0 / CPC, c1 = total1 / CPC;
-  const int64_t tmax = c0 > c1 ? c0 : c1;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tmax; i += (int64_t)gridDim.x * 256) {
-    if (p0 && i < c0) pack_one<T>(w, nullptr, 0, p0, Cout_f, Cin_f, taps, 0, BN0, nch0, i);
-    if (p1 && i < c1) pack_one<T>(w, nullptr, 0, p1, Cout_f, Cin_f, taps, 1, BN1, nch1, i);
-  }
+__global__ void __launch_bounds__(256) k_pack_weights(PackGeom g) {
+  CBIM_DYN_SMEM(smem);
+  pack_block<T>(g, (int)blockIdx.x, smem);
 }
 
 // Every convolution weight of a model in ONE launch (the weights change once per optimizer step: 34 pack launches +
 // the torch.cat of each conv1|shortcut pair were 0.5 ms of a 19 ms ResUNet step).  The table lives in device memory;
 // blockIdx.x -> item by binary search over the items' first block.
-template <typename T>
-__device__ __forceinline__ void pack_item(const cbim_pack_item& it, int64_t first, int64_t step) {
-  constexpr int CPC = Elem<T>::CPC;
-  const int64_t c0 = it.total0 / CPC, c1 = it.total1 / CPC;
-  const int64_t tmax = c0 > c1 ? c0 : c1;
-  for (int64_t i = first; i < tmax; i += step) {
-    if (it.p0 && i < c0) pack_one<T>(it.w0, it.w1, it.rows0, it.p0, it.Cout, it.Cin, it.taps, 0, it.BN0, it.nch0, i);
-    if (it.p1 && i < c1) pack_one<T>(it.w0, it.w1, it.rows0, it.p1, it.Cout, it.Cin, it.taps, 1, it.BN1, it.nch1, i);
-  }
-}
 __global__ void __launch_bounds__(256) k_pack_weights_table(const cbim_pack_item* __restrict__ items, int n_items) {
+  CBIM_DYN_SMEM(smem);
   int lo = 0, hi = n_items - 1;
   while (lo < hi) {   // last item whose block_begin <= blockIdx.x
     const int mid = (lo + hi + 1) >> 1;
     if (items[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const cbim_pack_item it = items[lo];
-  const int64_t first = (int64_t)((int)blockIdx.x - it.block_begin) * 256 + threadIdx.x, step = (int64_t)it.n_blocks * 256;
-  if (it.dtype == CBIM_BF16) pack_item<bf16_tag>(it, first, step);
-  else pack_item<float>(it, first, step);
+  PackGeom g;
+  g.w0 = it.w0; g.w1 = it.w1; g.p0 = it.p0; g.p1 = it.p1; g.rows0 = it.rows0; g.Cout = it.Cout; g.Cin = it.Cin;
+  g.taps = it.taps; g.BN0 = it.BN0; g.nch0 = it.nch0; g.BN1 = it.BN1; g.nch1 = it.nch1;
+  const int blk = (int)blockIdx.x - it.block_begin;
+  if (it.dtype == CBIM_BF16) pack_block<bf16_tag>(g, blk, smem);
+  else pack_block<float>(g, blk, smem);
 }
 
 struct TileCfg { int MT, NTL, tD, tH, lgH, nth; };
@@ -927,24 +981,33 @@ extern "C" size_t cbim_conv3d_packed_bytes(const cbim_conv_desc* d, int mode) {
   return (size_t)n_nblk * n_chunks * taps * KG * 2 * BN * 16;
 }
 
+static int pack_smem_attr() {
+#ifndef CBIM_EMU
+  static bool done = false;
+  if (!done) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)k_pack_weights<bf16_tag>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_pack_weights<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e3 = hipFuncSetAttribute((const void*)k_pack_weights_table, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CBIM_CHECK(e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute (pack)");
+    done = true;
+  }
+#endif
+  return CBIM_OK;
+}
+
 static int pack_launch(const cbim_conv_desc* d, const float* w, void* p0, void* p1, void* stream) {
   if (int e = validate(d)) return e;
-  int KC = kc_of(d->dtype), taps = d->kD * d->kH * d->kW, es = elem_size(d->dtype);
-  int BN0 = d->Cout <= 32 ? 32 : 64, BN1 = d->Cin <= 32 ? 32 : 64;
-  int nch0 = (d->Cin + KC - 1) / KC, nch1 = (d->Cout + KC - 1) / KC;
-  int64_t t0 = p0 ? (int64_t)(cbim_conv3d_packed_bytes(d, 0) / es) : 0;
-  int64_t t1 = p1 ? (int64_t)(cbim_conv3d_packed_bytes(d, 1) / es) : 0;
-  int64_t tmax = (t0 > t1 ? t0 : t1) / (d->dtype == CBIM_BF16 ? 8 : 4);   // one 16-byte chunk per thread trip
-  int64_t blocks = (tmax + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
+  if (int e = pack_smem_attr()) return e;
+  const int KC = kc_of(d->dtype), taps = d->kD * d->kH * d->kW;
+  PackGeom g;
+  g.w0 = w; g.w1 = nullptr; g.p0 = p0; g.p1 = p1; g.rows0 = d->Cout; g.Cout = d->Cout; g.Cin = d->Cin; g.taps = taps;
+  g.BN0 = d->Cout <= 32 ? 32 : 64; g.BN1 = d->Cin <= 32 ? 32 : 64;
+  g.nch0 = (d->Cin + KC - 1) / KC; g.nch1 = (d->Cout + KC - 1) / KC;
+  const int blocks = pack_blocks(d->dtype, d->Cout, d->Cin);
+  const size_t smem = (size_t)taps * 2048;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_pack_weights<bf16_tag>), dim3((unsigned)blocks), dim3(256), 0, st, w, p0, p1, d->Cout, d->Cin, taps,
-                BN0, nch0, t0, BN1, nch1, t1);
-  else
-    CBIM_LAUNCH((k_pack_weights<float>), dim3((unsigned)blocks), dim3(256), 0, st, w, p0, p1, d->Cout, d->Cin, taps,
-                BN0, nch0, t0, BN1, nch1, t1);
+  if (d->dtype == CBIM_BF16) CBIM_LAUNCH((k_pack_weights<bf16_tag>), dim3((unsigned)blocks), dim3(256), smem, st, g);
+  else CBIM_LAUNCH((k_pack_weights<float>), dim3((unsigned)blocks), dim3(256), smem, st, g);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
@@ -973,18 +1036,17 @@ extern "C" int cbim_conv3d_pack_item_fill(const cbim_conv_desc* d, const float* 
   out->nch0 = (d->Cin + KC - 1) / KC; out->nch1 = (d->Cout + KC - 1) / KC;
   out->total0 = packed_fwd ? (int64_t)(cbim_conv3d_packed_bytes(d, 0) / es) : 0;
   out->total1 = packed_dgrad ? (int64_t)(cbim_conv3d_packed_bytes(d, 1) / es) : 0;
-  const int64_t tmax = out->total0 > out->total1 ? out->total0 : out->total1;
-  int64_t nb = (tmax + 256 * 16 - 1) / (256 * 16);   // ~2 sixteen-byte chunks per thread
-  if (nb < 1) nb = 1;
-  if (nb > 1024) nb = 1024;
+  const int nb = pack_blocks(d->dtype, d->Cout, d->Cin);   // one workgroup per 32 couts x KC cins (k_pack_weights_table)
   out->block_begin = block_begin; out->n_blocks = (int)nb; out->dtype = d->dtype;
   return CBIM_OK;
 }
 
 extern "C" int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, int n_items, int total_blocks,
-                                              void* stream) {
+                                              int max_taps, void* stream) {
   CBIM_CHECK(items_dev && n_items > 0 && total_blocks > 0, CBIM_EINVAL, "empty pack table");
-  CBIM_LAUNCH(k_pack_weights_table, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+  CBIM_CHECK(max_taps >= 1 && max_taps <= 64, CBIM_EUNSUPPORTED, "pack table: %d taps", max_taps);
+  if (int e = pack_smem_attr()) return e;
+  CBIM_LAUNCH(k_pack_weights_table, dim3((unsigned)total_blocks), dim3(256), (size_t)max_taps * 2048, (hipStream_t)stream, items_dev, n_items);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

@@ -264,6 +264,7 @@ class PackedWeights:
         self.stale = False     # set after a hipGraph replay (the captured optimizer moved the weights unseen)
         self.table = None      # device copy of the cbim_pack_item array
         self.n_blocks = 0
+        self.max_taps = 1
         self.dirty_table = True
 
     @staticmethod
@@ -323,6 +324,7 @@ class PackedWeights:
         dev = next(iter(self.entries.values())).p0.device
         self.table = raw.to(dev)       # (outside graph capture: see _repack_all)
         self.n_blocks = blk
+        self.max_taps = max(int(it.taps) for it in items)
         self.dirty_table = False
 
     def _pack_one(self, e):
@@ -362,7 +364,7 @@ class PackedWeights:
                                    "eager step first so that the pack table is complete")
             self._build_table()
         t = self.table
-        check(_lib.lib().cbim_conv3d_pack_weights_table(_p(t), len(self.entries), self.n_blocks, _stream(t)),
+        check(_lib.lib().cbim_conv3d_pack_weights_table(_p(t), len(self.entries), self.n_blocks, self.max_taps, _stream(t)),
               "pack_weights_table")
         for e in self.entries.values():
             e.versions = tuple(w._version for w in ((e.w0,) if e.w1 is None else (e.w0, e.w1)))

@@ -130,7 +130,8 @@ int cbim_conv3d_pack_weights_both(const cbim_conv_desc* fwd_desc, const float* w
 /* All convolution weights of a model in one launch.  The host fills one cbim_pack_item per weight with
  * cbim_conv3d_pack_item_fill (w1 != NULL: forward output channels >= rows0 come from w1 — the Cout-concatenated
  * conv1|shortcut pair of BasicBlock, conv_layers.py:86-94, packed without a torch.cat; block_begin = running sum of the
- * previous items' n_blocks), copies the array to the device and launches it once per optimizer step. */
+ * previous items' n_blocks; one workgroup per 32 output x 32 (bf16) / 16 (fp32) input channels, transposed through
+ * LDS), copies the array to the device and launches it once per optimizer step. */
 typedef struct cbim_pack_item {
   const float* w0; const float* w1; void* p0; void* p1;
   int64_t total0, total1;
@@ -138,7 +139,9 @@ typedef struct cbim_pack_item {
 } cbim_pack_item;
 int cbim_conv3d_pack_item_fill(const cbim_conv_desc* fwd_desc, const float* w0, const float* w1, int rows0,
                                void* packed_fwd, void* packed_dgrad, int block_begin, cbim_pack_item* out);
-int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, int n_items, int total_blocks, void* stream);
+/* max_taps: the largest `taps` of the items (sizes the kernel's LDS: taps * 2 KiB) */
+int cbim_conv3d_pack_weights_table(const cbim_pack_item* items_dev, int n_items, int total_blocks, int max_taps,
+                                   void* stream);
 /* Tuning knob: output voxels per image from which the Cin = 32 -> Cout <= 32 3x3x3 layers (bf16) run on the
  * "weights in registers" kernel (conv_r32.hip) instead of k_conv_igemm; v < 0 only queries.  Returns the previous
  * value (default 262144 = 64^3).  The two kernels compute the same function (tests lower it to cover small shapes). */
