@@ -26,6 +26,12 @@ def relerr(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-20))
 
 
+def act_ref(name):
+    """torch reference of an activation code (reference get_act, /root/reference/model/dim3/utils.py:23-30)"""
+    return {"relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.01), "gelu": F.gelu, "swish": F.silu, "silu": F.silu,
+            "none": lambda t: t}[name]
+
+
 def check_instnorm(dev, dtype, N=2, C=24, dhw=(5, 7, 9), act="relu"):
     torch.manual_seed(1)
     x = torch.randn(N, C, *dhw) * 2 + 3.0           # |mean| >> 0 exercises the centred moments
@@ -36,16 +42,19 @@ def check_instnorm(dev, dtype, N=2, C=24, dhw=(5, 7, 9), act="relu"):
     v = xr.var((2, 3, 4), unbiased=False)
     assert relerr(st[..., 0], m) < 1e-5
     assert relerr(st[..., 1], 1 / torch.sqrt(v + 1e-4)) < 1e-5
+    fa = act_ref(act)
     y = ops.norm_act_fwd(xl, st.to(dev), ops.ACT[act])
-    ref = F.relu(F.instance_norm(xr, eps=1e-4))
+    ref = fa(F.instance_norm(xr, eps=1e-4))
     assert relerr(from_cl(y.cpu()), ref) < tol(dtype, 1e-5, 8e-3)
     # backward of act(IN(x)) wrt x
-    xr2 = xr.clone().requires_grad_(True)
-    g = torch.randn_like(xr)
+    # (contiguous NCDHW copies for the reference: torch's CPU batch-norm backward mis-reads a permuted grad_output when
+    #  no activation sits between it and the norm)
+    xr2 = xr.contiguous().clone().requires_grad_(True)
+    g = torch.randn_like(xr2)
     gl = to_cl(g, dtype).to(dev)
-    F.relu(F.instance_norm(xr2, eps=1e-4)).backward(from_cl(gl.cpu()))
-    sums = ops.norm_bwd_sums(gl, xl, st.to(dev), 1, True)
-    dx = ops.norm_bwd_apply(gl, xl, st.to(dev), sums, 1, True)
+    fa(F.instance_norm(xr2, eps=1e-4)).backward(from_cl(gl.cpu()).contiguous())
+    sums = ops.norm_bwd_sums(gl, xl, st.to(dev), ops.ACT[act], True)
+    dx = ops.norm_bwd_apply(gl, xl, st.to(dev), sums, ops.ACT[act], True)
     assert relerr(from_cl(dx.cpu()), xr2.grad) < tol(dtype, 2e-5, 1e-2)
 
 
@@ -102,7 +111,8 @@ def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0, act="relu"):
     wp = ops.pack_weights(wdev, geom, 0)
     st = ops.instnorm_stats(xl)
     xh = F.instance_norm(xr, eps=1e-4)
-    a = F.relu(xh) if act == "relu" else xh.clone()
+    xh_g = xh.clone().requires_grad_(True)      # for act'(xh) of the masked dgrad
+    a = act_ref(act)(xh).clone()
     wr = w
     if dtype == torch.bfloat16:
         a = a.bfloat16().float()
@@ -132,7 +142,8 @@ def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0, act="relu"):
     assert e_w < tol(dtype, 5e-5, 1e-3), f"wgrad {e_w:.3e}"
     accl = to_cl(torch.randn_like(a), dtype).to(dev)
     g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=xl, mask_stats=st, accumulate=accl)
-    gm = (a.grad + from_cl(accl.cpu())) * ((xh > 0) if act == "relu" else 1.0)
+    act_ref(act)(xh_g).sum().backward()
+    gm = (a.grad + from_cl(accl.cpu())) * xh_g.grad                      # x act'(xh)
     assert relerr(from_cl(g2.cpu()), gm) < t, "masked dgrad"
     assert float((sums[..., 0].cpu() - gm.mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
     assert float((sums[..., 1].cpu() - (gm * xh).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())

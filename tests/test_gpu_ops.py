@@ -17,6 +17,8 @@ def test_backend_is_hip(dev):
 def test_instnorm(dev, dtype):
     oc.check_instnorm(dev, dtype)
     oc.check_instnorm(dev, dtype, N=1, C=72, dhw=(2, 3, 3))
+    for act in ("lrelu", "gelu", "swish", "none"):     # every code of the reference's get_act (model/dim3/utils.py:23-30)
+        oc.check_instnorm(dev, dtype, N=1, C=16, dhw=(3, 5, 6), act=act)
     oc.check_instnorm(dev, dtype, N=1, C=32, dhw=(40, 33, 31))
     oc.check_instnorm(dev, dtype, N=1, C=2056, dhw=(4, 4, 4))
 
@@ -97,6 +99,10 @@ def test_conv_pointwise_and_norm_without_act(dev):
     oc.check_conv(dev, BF16, 1, 128, 512, (32, 32, 32), (1, 1, 1))    # MBConv expand at 32^3
     oc.check_conv(dev, F32, 1, 16, 24, (4, 6, 8), (1, 1, 1), act="none")
     oc.check_conv(dev, BF16, 1, 16, 16, (4, 8, 8), (3, 3, 3), act="none")
+    # norm -> act fused into the conv's input transform / dgrad mask / wgrad for the other activation codes
+    oc.check_conv(dev, F32, 1, 8, 16, (4, 6, 8), (3, 3, 3), act="gelu")
+    oc.check_conv(dev, F32, 1, 8, 16, (4, 6, 8), (3, 3, 3), act="swish")
+    oc.check_conv(dev, BF16, 1, 16, 16, (4, 8, 8), (3, 3, 3), act="lrelu")
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
