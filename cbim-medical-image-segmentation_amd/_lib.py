@@ -57,6 +57,7 @@ _SIGS = {
     "cbim_conv3d_pack_weights_both": (i32, [_dp, vp, vp, vp, vp]),
     "cbim_conv3d_pack_item_fill": (i32, [_dp, vp, vp, i32, vp, vp, i32, vp]),
     "cbim_conv3d_pack_weights_table": (i32, [vp, i32, i32, i32, vp]),
+    "cbim_conv3d_last_kernel": (i32, []),
     "cbim_conv_r32_min_voxels": (i64, [i64]),
     "cbim_conv_r32_tile_depth": (i32, [i32]),
     "cbim_conv3d_num_tiles": (i32, [_dp]),

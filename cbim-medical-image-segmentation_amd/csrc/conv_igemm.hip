@@ -1125,6 +1125,10 @@ static int dispatch_act(int act, bool k3, const TileCfg& c, const IgemmParams& p
   }
 }
 
+// which kernel the last cbim_conv3d_igemm call of this thread launched: 0 = k_conv_igemm, 1 = k_conv3_r32 (profiling labels)
+static thread_local int g_last_conv_kernel = 0;
+extern "C" int cbim_conv3d_last_kernel(void) { return g_last_conv_kernel; }
+
 extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2,
                                  int64_t x2_stride, int cin_split,
                                  const float* in_stats, const void* w_packed, const void* res,
@@ -1134,9 +1138,12 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   if (int e = validate(d)) return e;
   CBIM_CHECK(x && w_packed && y, CBIM_EINVAL, "null tensor");
   CBIM_CHECK(!mask_x || mask_stats, CBIM_EINVAL, "mask_x needs mask_stats");
-  if (cbim_conv_r32_eligible(d, x2, cin_split, in_stats, res, mask_x))   // channels in multiples of 32 at high resolution: weights in registers
+  g_last_conv_kernel = 0;
+  if (cbim_conv_r32_eligible(d, x2, cin_split, in_stats, res, mask_x)) {  // channels in multiples of 32 at high resolution: weights in registers
+    g_last_conv_kernel = 1;
     return cbim_conv_r32_launch(d, x, x_stride, x2, x2_stride, cin_split, in_stats, w_packed, res, res_stride, mask_x, mask_stride, mask_stats, y,
                                 y_stride, partials, stream);
+  }
   TileCfg c = pick_cfg(d);
   IgemmParams p;
   p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.w = w_packed;

@@ -435,11 +435,11 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
         e1.record()
         cfg = (C.c_int * 4)()
         L.cbim_conv3d_tile_config(C.byref(desc), C.byref(cfg))
-        if cfg[0] == 4:
+        if L.cbim_conv3d_last_kernel() == 1:
             name = "k_conv3_r32<bf16>"
         else:
-            if cfg[0] == 4:
-                cfg[0] = 2
+            if cfg[0] == 4:       # a shape the r32 kernel takes for other calls: k_conv_igemm runs its 8x8x8 configuration
+                cfg[0], cfg[1] = 2, (1 if desc.Cout <= 32 else 2)
             name = "k_conv_igemm<%s,%d,%d>" % ("bf16" if desc.dtype == 1 else "f32", cfg[0], cfg[1])
         flops = 2.0 * desc.N * desc.Do * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.kD * desc.kH * desc.kW
         PROFILE.append((name, flops, e0, e1, (desc.Cin, desc.Cout, desc.Do, desc.Ho, desc.Wo)))
