@@ -52,21 +52,21 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
       rstd[j] = stats[((size_t)n * Cl + c_off + cc * CPC + j) * 2 + 1];
     }
   }
+  const size_t nb = (size_t)n * S;
+  if (MODE == 0 && active && v0 < v1) {
+    // ONE shift per channel for the whole part (its first voxel, read by every lane of the channel chunk: a cache hit):
+    // shifted sums of different lanes then simply add — no per-lane Chan merge (64 lanes x 8 channels of dependent
+    // divisions on 4 threads was most of this kernel on a 32-channel tensor)
+    Elem<T>::unpack(ld_chunk<T>(a, (nb + v0) * a_stride + c_off + (size_t)cc * CPC), shift);
+  }
   if (active) {
-    const size_t nb = (size_t)n * S;
-    // two rows per trip: both rows' loads are issued before either is consumed (one load pair in flight per trip
-    // left this streaming kernel latency bound); rows are accumulated in the same order as a one-row loop
     auto accumulate = [&](const u32x4& ra, const u32x4& rx) {
       float fa[CPC];
       Elem<T>::unpack(ra, fa);
       if (MODE == 0) {
-        if (cnt == 0.f) {
-#pragma unroll
-          for (int j = 0; j < CPC; ++j) shift[j] = fa[j];
-        }
         cnt += 1.f;
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) { float d = fa[j] - shift[j]; s0[j] += d; s1[j] += d * d; }
+        for (int j = 0; j < CPC; ++j) { float d = fa[j] - shift[j]; s0[j] += d; s1[j] = fmaf(d, d, s1[j]); }
       } else {
         float fx[CPC];
         Elem<T>::unpack(rx, fx);
@@ -75,58 +75,57 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
           float xh = (fx[j] - mean[j]) * rstd[j];
           float g = masked ? fa[j] * act_grad(xh, act) : fa[j];
           s0[j] += g;
-          s1[j] += g * xh;
+          s1[j] = fmaf(g, xh, s1[j]);
         }
       }
     };
-    for (int64_t v = v0 + vl; v < v1; v += 2 * vlc) {
-      const bool two = v + vlc < v1;
-      const int64_t vb = two ? v + vlc : v;
-      const u32x4 a0 = ld_chunk<T>(a, (nb + v) * a_stride + c_off + (size_t)cc * CPC);
-      const u32x4 a1 = ld_chunk<T>(a, (nb + vb) * a_stride + c_off + (size_t)cc * CPC);
-      u32x4 x0 = a0, x1 = a1;
-      if (MODE == 1) {
-        x0 = ld_chunk<T>(x, (nb + v) * x_stride + c_off + (size_t)cc * CPC);
-        x1 = ld_chunk<T>(x, (nb + vb) * x_stride + c_off + (size_t)cc * CPC);
-      }
-      accumulate(a0, x0);
-      if (two) accumulate(a1, x1);
-    }
-  }
-  // reduce over the voxel lanes through LDS (fixed order -> deterministic)
-  __shared__ float red[NT * 3 * 8];
+    // four rows per trip: all loads of a trip are issued before any is consumed (streaming kernel, latency bound
+    // otherwise); rows are accumulated in the same order as a one-row loop
+    constexpr int RPT = 4;
+    for (int64_t v = v0 + vl; v < v1; v += RPT * vlc) {
+      u32x4 ra[RPT], rx[RPT];
 #pragma unroll
-  for (int j = 0; j < CPC; ++j) {
-    if (MODE == 0) {
-      Moments m = moments_from_shifted(cnt, shift[j], s0[j], s1[j]);
-      red[(t * CPC + j) * 3 + 0] = m.n;
-      red[(t * CPC + j) * 3 + 1] = m.mean;
-      red[(t * CPC + j) * 3 + 2] = m.m2;
-    } else {
-      red[(t * CPC + j) * 3 + 0] = 0.f;
-      red[(t * CPC + j) * 3 + 1] = s0[j];
-      red[(t * CPC + j) * 3 + 2] = s1[j];
-    }
-  }
-  __syncthreads();
-  if (vl == 0 && active) {
-    for (int j = 0; j < CPC; ++j) {
-      Moments acc = {0.f, 0.f, 0.f};
-      for (int q = 0; q < vlc; ++q) {
-        const float* r = red + ((q * cch + cc) * CPC + j) * 3;
-        if (MODE == 0) {
-          Moments b = {r[0], r[1], r[2]};
-          acc = moments_merge(acc, b);
-        } else {
-          acc.mean += r[1];
-          acc.m2 += r[2];
+      for (int u = 0; u < RPT; ++u) {
+        const int64_t vv = v + (int64_t)u * vlc;
+        if (vv < v1) {
+          ra[u] = ld_chunk<T>(a, (nb + vv) * a_stride + c_off + (size_t)cc * CPC);
+          if (MODE == 1) rx[u] = ld_chunk<T>(x, (nb + vv) * x_stride + c_off + (size_t)cc * CPC);
+          else rx[u] = ra[u];
         }
       }
-      size_t o = (((size_t)n * P + part) * Cl + c_off + cc * CPC + j) * 3;
-      partials[o] = acc.n;
-      partials[o + 1] = acc.mean;
-      partials[o + 2] = acc.m2;
+#pragma unroll
+      for (int u = 0; u < RPT; ++u)
+        if (v + (int64_t)u * vlc < v1) accumulate(ra[u], rx[u]);
     }
+  }
+  // reduce over the voxel lanes through LDS: lane sums [t][2*CPC + 1], then one thread per (channel, quantity) adds the
+  // vlc lanes in fixed order (deterministic)
+  constexpr int W = 2 * CPC + 1;
+  __shared__ float red[NT * (2 * 8 + 1)];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) { red[t * W + j] = s0[j]; red[t * W + CPC + j] = s1[j]; }
+  red[t * W + 2 * CPC] = cnt;
+  __syncthreads();
+  for (int ch = t; ch < cch * CPC; ch += NT) {          // thread = one channel of this launch (wide tensors: several)
+    const int c2 = ch / CPC, j = ch % CPC;
+    float a0 = 0.f, a1 = 0.f, ac = 0.f;
+    for (int q = 0; q < vlc; ++q) {
+      const float* r = red + (q * cch + c2) * W;
+      a0 += r[j]; a1 += r[CPC + j]; ac += r[2 * CPC];
+    }
+    Moments acc;
+    if (MODE == 0) {
+      // every lane of the chunk used the same shift: the part's first voxel
+      float sh[CPC];
+      Elem<T>::unpack(v0 < v1 ? ld_chunk<T>(a, (nb + v0) * a_stride + c_off + (size_t)c2 * CPC) : u32x4{0u, 0u, 0u, 0u}, sh);
+      acc = moments_from_shifted(ac, sh[j], a0, a1);
+    } else {
+      acc.n = 0.f; acc.mean = a0; acc.m2 = a1;
+    }
+    const size_t o = (((size_t)n * P + part) * Cl + c_off + c2 * CPC + j) * 3;
+    partials[o] = acc.n;
+    partials[o + 1] = acc.mean;
+    partials[o + 2] = acc.m2;
   }
 }
 
