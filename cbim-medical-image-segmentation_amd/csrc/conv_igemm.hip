@@ -753,17 +753,16 @@ __global__ void __launch_bounds__(FT) k_splitk_finish(const float* __restrict__ 
     red[(t * CPC + j) * 3 + 2] = m.m2;
   }
   __syncthreads();
-  if (vl == 0 && active) {
-    for (int j = 0; j < CPC; ++j) {
-      Moments acc = {0.f, 0.f, 0.f};
-      for (int q = 0; q < vlc; ++q) {
-        const float* r = red + ((q * cch + cc) * CPC + j) * 3;
-        if (mx) { acc.mean += r[1]; acc.m2 += r[2]; }
-        else { Moments b = {r[0], r[1], r[2]}; acc = moments_merge(acc, b); }
-      }
-      size_t o = (((size_t)n * P + part) * C + cc * CPC + j) * 3;
-      partials[o] = acc.n; partials[o + 1] = acc.mean; partials[o + 2] = acc.m2;
+  for (int ch = t; ch < cch * CPC; ch += FT) {     // one thread per channel merges the voxel lanes in fixed order
+    const int c2 = ch / CPC, j = ch % CPC;
+    Moments acc = {0.f, 0.f, 0.f};
+    for (int q = 0; q < vlc; ++q) {
+      const float* r = red + ((q * cch + c2) * CPC + j) * 3;
+      if (mx) { acc.mean += r[1]; acc.m2 += r[2]; }
+      else { Moments b = {r[0], r[1], r[2]}; acc = moments_merge(acc, b); }
     }
+    const size_t o = (((size_t)n * P + part) * C + c2 * CPC + j) * 3;
+    partials[o] = acc.n; partials[o + 1] = acc.mean; partials[o + 2] = acc.m2;
   }
 }
 

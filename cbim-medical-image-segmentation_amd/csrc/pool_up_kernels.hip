@@ -235,17 +235,16 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd_stats(const void* __restrict__
     red[(t * CPC + j) * 3 + 2] = m.m2;
   }
   __syncthreads();
-  if (vl == 0 && active) {
-    for (int j = 0; j < CPC; ++j) {
-      Moments acc = {0.f, 0.f, 0.f};
-      for (int q = 0; q < vlc; ++q) {
-        const float* r = red + ((q * cch + cc) * CPC + j) * 3;
-        const Moments b = {r[0], r[1], r[2]};
-        acc = moments_merge(acc, b);
-      }
-      const size_t o = (((size_t)n * P + part) * Ct + c0 + j) * 3;
-      partials[o] = acc.n; partials[o + 1] = acc.mean; partials[o + 2] = acc.m2;
+  for (int ch = t; ch < cch * CPC; ch += NT) {     // one thread per channel merges the voxel lanes in fixed order
+    const int c2 = ch / CPC, j = ch % CPC;
+    Moments acc = {0.f, 0.f, 0.f};
+    for (int q = 0; q < vlc; ++q) {
+      const float* r = red + ((q * cch + c2) * CPC + j) * 3;
+      const Moments b = {r[0], r[1], r[2]};
+      acc = moments_merge(acc, b);
     }
+    const size_t o = (((size_t)n * P + part) * Ct + c2 * CPC + j) * 3;
+    partials[o] = acc.n; partials[o + 1] = acc.mean; partials[o + 2] = acc.m2;
   }
 }
 
