@@ -179,22 +179,35 @@ __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
   }
 }
 
+// 16 outputs per workgroup x 16 slab phases: thread (o, ph) adds slabs ph, ph+16, .. (two independent chains), the 16 phase
+// sums are combined through LDS in fixed order.  (One thread per output walking all 1024 slabs: 4 workgroups, 80 us.)
 __global__ void __launch_bounds__(NT) k_stem_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                           int n_slabs, int Cin, int taps, int Cout) {
-  int total = Cin * taps * Cout;
-  for (int i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
-    int co = i % Cout, r = i / Cout;
-    int k = r % taps, ci = r / taps;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 3 < n_slabs; s += 4) {
-      a0 += ws[(size_t)s * total + i];
-      a1 += ws[(size_t)(s + 1) * total + i];
-      a2 += ws[(size_t)(s + 2) * total + i];
-      a3 += ws[(size_t)(s + 3) * total + i];
+  __shared__ float red[16][17];
+  const int total = Cin * taps * Cout;
+  const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  for (int base = blockIdx.x * 16; base < total; base += gridDim.x * 16) {
+    const int i = base + o;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < total) {
+      int s = ph;
+      for (; s + 16 < n_slabs; s += 32) {
+        a0 += ws[(size_t)s * total + i];
+        a1 += ws[(size_t)(s + 16) * total + i];
+      }
+      if (s < n_slabs) a0 += ws[(size_t)s * total + i];
     }
-    for (; s < n_slabs; ++s) a0 += ws[(size_t)s * total + i];
-    dw[((size_t)co * Cin + ci) * taps + k] = (a0 + a1) + (a2 + a3);
+    red[ph][o] = a0 + a1;
+    __syncthreads();
+    if (ph == 0 && i < total) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc += red[q][o];
+      const int co = i % Cout, r = i / Cout;
+      const int k = r % taps, ci = r / taps;
+      dw[((size_t)co * Cin + ci) * taps + k] = acc;
+    }
+    __syncthreads();
   }
 }
 
@@ -649,7 +662,7 @@ extern "C" int cbim_stem_conv_wgrad(int dtype, const float* x, const void* dy, f
     else CBIM_LAUNCH((k_stem_wgrad<float, 1>), grid, dim3(NT), smem, st, p);
   }
   int total = Cin * p.taps * Cout;
-  CBIM_LAUNCH(k_stem_wgrad_reduce, dim3((total + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw,
+  CBIM_LAUNCH(k_stem_wgrad_reduce, dim3((total + 15) / 16), dim3(NT), 0, st, (const float*)workspace, dw,
               N * p.strips_per_n, Cin, p.taps, Cout);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
