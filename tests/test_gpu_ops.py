@@ -200,3 +200,5 @@ def test_wgrad_unrolled_plane_path_at_32k_voxels(dev):
     oc.check_wgrad_large(dev)                                # 8x64x64 = 2 x 8 x 8 tiles of 4x8x8
     oc.check_wgrad_large(dev, N=1, Cin=32, Cout=64, dhw=(30, 36, 41), act="none", split=32)
     oc.check_wgrad_large(dev, N=1, Cin=32, Cout=32, dhw=(33, 32, 40), raw=True)
+    # three cout blocks x two Cin blocks
+    oc.check_wgrad_large(dev, N=1, Cin=64, Cout=96, dhw=(30, 36, 41))
