@@ -75,7 +75,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._hyper = torch.tensor([step0, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                                     self.ema_alpha, 0.0, 1.0 - g["betas"][0], 1.0 - g["betas"][1]], dtype=torch.float32,
                                    device=dev)
-        self._lr_pushed = g["lr"]
+        self._lr_pushed = self._hyper_key(g)
         # pinned staging buffers, allocated up front (no host allocation may happen while a hipGraph is being
         # captured) and used round-robin: a captured graph re-reads the buffer it was recorded with on replay
         nb = len(self._params) * C.sizeof(_Rec)
@@ -126,9 +126,14 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._table is None:
             self._build()
         g = self.param_groups[0]
-        if g["lr"] != self._lr_pushed:          # scheduler changed the learning rate (training/utils.py:51-95)
-            self._hyper[1] = float(g["lr"])
-            self._lr_pushed = g["lr"]
+        key = self._hyper_key(g)
+        if key != self._lr_pushed:              # the scheduler changed the learning rate (training/utils.py:51-95), or the
+            # user edited betas / eps / weight_decay in param_groups: push the whole tuple (one small H2D copy; under a
+            # captured graph the step is replayed with the values captured — edit them between captures)
+            vals = torch.tensor([key[0], key[1], key[2], key[3], key[4], 1.0 - key[1], 1.0 - key[2]], dtype=torch.float32)
+            self._hyper[1:6] = vals[:5].to(self._hyper.device)
+            self._hyper[8:10] = vals[5:].to(self._hyper.device)
+            self._lr_pushed = key
         self._fill_table()
         _lib.check(_lib.lib().cbim_adamw_ema_step(_p(self._table), _p(self._blk_tensor), _p(self._blk_chunk), self._nblocks,
                                                   _p(self._hyper), _stream(self._params[0])), "adamw_ema_step")
@@ -142,8 +147,20 @@ class FusedAdamW(torch.optim.Optimizer):
                 eb.copy_(mb)
         return loss
 
+    @staticmethod
+    def _hyper_key(g):
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+
     def _model_buffers(self):
-        return getattr(self, "_buffers_src", ())
+        src = getattr(self, "_buffers_src", None)
+        if src is None:
+            # update_ema_variables copies every buffer of the model into the EMA model (training/utils.py:104-105); an EMA
+            # model WITH buffers (SwinUNETR: relative_position_index) needs the source model: fail loudly, not silently
+            if any(True for _ in self.ema_model.buffers()):
+                raise RuntimeError("cbim_amd: FusedAdamW(ema_model=...) mirrors buffers; call attach_buffers(model) "
+                                   "(get_optimizer does) so that the EMA model's buffers follow the model's")
+            return ()
+        return src
 
     def attach_buffers(self, model):
         """Give the model whose buffers the EMA model mirrors (only needed for nets that have buffers)."""
@@ -166,5 +183,8 @@ def get_optimizer(args, net, ema_net=None):
     """training/utils.py:8-14 for ``optimizer: adamw`` (the only optimiser the shipped 3-D configs use)."""
     if args.optimizer != "adamw":
         raise NotImplementedError(f"cbim_amd: optimizer '{args.optimizer}' is not built (shipped 3-D configs use adamw)")
-    return FusedAdamW(net.parameters(), lr=args.base_lr, betas=args.betas, weight_decay=args.weight_decay, eps=1e-5,
-                      ema_model=ema_net, ema_alpha=getattr(args, "ema_alpha", 0.99))
+    opt = FusedAdamW(net.parameters(), lr=args.base_lr, betas=args.betas, weight_decay=args.weight_decay, eps=1e-5,
+                     ema_model=ema_net, ema_alpha=getattr(args, "ema_alpha", 0.99))
+    if ema_net is not None:
+        opt.attach_buffers(net)
+    return opt

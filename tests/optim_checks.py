@@ -26,6 +26,11 @@ def check_adamw_ema(dev, steps=4, seed=31):
         if step == 2:                                   # scheduler changes the lr (training/utils.py:51-95)
             for o in (opt, opt_ref):
                 o.param_groups[0]["lr"] = 3e-4
+        if step == 3:                                   # live edits of the other hyper-parameters reach the device too
+            for o in (opt, opt_ref):
+                o.param_groups[0]["weight_decay"] = 0.01
+                o.param_groups[0]["betas"] = (0.8, 0.99)
+                o.param_groups[0]["eps"] = 1e-6
         for p, q in zip(net.parameters(), ref.parameters()):
             g = torch.randn_like(p)
             p.grad, q.grad = g.clone(), g.clone()
@@ -42,6 +47,25 @@ def check_adamw_ema(dev, steps=4, seed=31):
     for k in ("exp_avg", "exp_avg_sq"):
         a, b = sd["state"][2][k], ref_sd["state"][2][k]
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-10
+
+
+def check_ema_buffers(dev):
+    """An EMA model with buffers (SwinUNETR's relative_position_index) must be told where they come from."""
+    net = nn.Sequential(nn.Conv3d(1, 2, 1), nn.BatchNorm3d(2)).to(dev)
+    ema = copy.deepcopy(net)
+    opt = FusedAdamW(net.parameters(), ema_model=ema, lr=1e-3)
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    try:
+        opt.step()
+        raise AssertionError("FusedAdamW accepted an EMA model with buffers and no attach_buffers()")
+    except RuntimeError as e:
+        assert "attach_buffers" in str(e)
+    opt.attach_buffers(net)
+    with torch.no_grad():
+        net[1].running_mean.fill_(3.0)
+    opt.step()
+    assert float(ema[1].running_mean[0]) == 3.0
 
 
 def check_training_utils_surface(dev, seed=33):

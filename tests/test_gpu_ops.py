@@ -190,8 +190,9 @@ def test_resnorm(dev, dtype):
 
 
 def test_fused_adamw_ema(dev):
-    from tests.optim_checks import check_adamw_ema
+    from tests.optim_checks import check_adamw_ema, check_ema_buffers
     check_adamw_ema(dev)
+    check_ema_buffers(dev)
     check_adamw_ema(dev, steps=7, seed=32)
 
 

@@ -175,8 +175,9 @@ def test_resnorm(dev, dtype):
 
 
 def test_fused_adamw_ema(dev):
-    from tests.optim_checks import check_adamw_ema
+    from tests.optim_checks import check_adamw_ema, check_ema_buffers
     check_adamw_ema(dev)
+    check_ema_buffers(dev)
 
 
 def test_window_attention_matrix_core_path(dev):
