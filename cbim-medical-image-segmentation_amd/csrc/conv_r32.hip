@@ -36,6 +36,9 @@
 namespace cbim {
 
 static constexpr int R_RB = 64;                 // bytes per halo row (32 bf16 channels)
+#ifndef R32_LS_SINGLE
+#define R32_LS_SINGLE 0   // measured: 218 vs 183 us on 32->32 @128^3 (the per-tile butterfly costs more than the 10 spilled registers)
+#endif
 // Geometry by tile depth TD.  TD = 8: 8x8x8 tile, 512 threads, ONE workgroup per CU (2 x 64 KiB of halo).
 // TD = 4: 4x8x8 tile, 256 threads, TWO workgroups per CU (2 x 40 KiB of halo each, 80 KiB per workgroup): each SIMD then
 // hosts one wave of each workgroup, the two workgroups drift apart, and one's epilogue / halo transform (vector ALU
@@ -153,6 +156,9 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   const unsigned ist_base = G::IST_BASE;              // TR: (mean, rstd) of the input channels, 256 B per 32-channel chunk
   const int oc = blockIdx.y;                          // this workgroup's 32-channel chunk of Cout
   const int NC = MC ? p.NC : 1;                       // 32-channel chunks of Cin; a unit = (tile, chunk)
+  // tile statistics reduced in the epilogue into LDS records (no per-lane running sums held through the MFMA phase):
+  // multi-chunk kernels, and (R32_LS) the single-chunk forward whose transform already fills the register file
+  constexpr bool LS = MC || (R32_LS_SINGLE && TR && !MX);
   constexpr bool stream_w = MC;                       // weights of the next unit replace this unit's as they fall dead
 
   // ---- wave = (cout half ch, voxel group vg); lane = (voxel lv of a 2x8 patch, k-group / row-group lq) -----------
@@ -380,7 +386,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   auto flush_stats = [&](int n) {
     __syncthreads();
     float* red = (float*)(smem + red_base);
-    if (!MC) {
+    if (!LS) {
 #pragma unroll
     for (int msk = 1; msk < 32; msk <<= 1) {   // lanes differing in bits 0..4 (voxel, lq & 1) hold the same channels
       float t0[8], t1[8];
@@ -417,12 +423,12 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
       const size_t o = (((size_t)n * p.P + lb) * p.Cout + oc * 32 + tid) * 3;
       p.partials[o] = a.n; p.partials[o + 1] = a.mean; p.partials[o + 2] = a.m2;
     }
-    if (MC) {                                 // the next image starts from empty records
+    if (LS) {                                 // the next image starts from empty records
       __syncthreads();
       for (int i = tid; i < NW * 16 * 3; i += NT) red[i] = 0.f;
     }
   };
-  if (MC) {
+  if (LS) {
     for (int i = tid; i < NW * 16 * 3; i += NT) ((float*)(smem + red_base))[i] = 0.f;   // (the prologue barriers follow)
   }
   if (want_part && tid < 32 && oc * 32 + tid < p.Cout) {
@@ -599,11 +605,11 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
       bool lset = false;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { l0[j] = 0.f; l1[j] = 0.f; lsh[MX ? 0 : j] = 0.f; }
-      float (&S0)[8] = MC ? l0 : s0;
-      float (&S1)[8] = MC ? l1 : s1;
-      float (&SH)[MX ? 1 : 8] = MC ? lsh : sh;
-      float& CNT = MC ? lcnt : cnt;
-      bool& SHSET = MC ? lset : shift_set;
+      float (&S0)[8] = LS ? l0 : s0;
+      float (&S1)[8] = LS ? l1 : s1;
+      float (&SH)[MX ? 1 : 8] = LS ? lsh : sh;
+      float& CNT = LS ? lcnt : cnt;
+      bool& SHSET = LS ? lset : shift_set;
 #pragma unroll
       for (int pr = 0; pr < NPAIR; ++pr) {
         const bool in = pair_in(pr);
@@ -670,7 +676,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
         if (in && c_ok && !(p.dbg & 16)) *(u32x4*)(y_tile + (r_mul24(rel, y_sb) + cb)) = Elem<bf16_tag>::pack(v);
         CNT += live;
       }
-      if (MC && want_part && !(p.dbg & 32)) tile_stats(l0, l1, lsh, lcnt);
+      if (LS && want_part && !(p.dbg & 32)) tile_stats(l0, l1, lsh, lcnt);
     }
     cur = nxt;
     advance(nxt);
