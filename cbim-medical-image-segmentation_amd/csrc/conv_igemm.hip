@@ -931,8 +931,9 @@ static int pick_ksplit(const cbim_conv_desc* d, const TileCfg& c) {
   int BN = 32 * c.NTL;
   int64_t wgs = tiles * ((d->Cout + BN - 1) / BN);
   // the finish kernel keeps one 16-byte output chunk per thread (FT = 256 threads)
-  if (wgs >= 96 || n_chunks < 2 || d->Cout / (d->dtype == CBIM_BF16 ? 8 : 4) > 256) return 1;
-  int64_t s = (192 + wgs - 1) / wgs;
+  static const int target = getenv("CBIM_IGEMM_KSPLIT_TARGET") ? atoi(getenv("CBIM_IGEMM_KSPLIT_TARGET")) : 192;
+  if (wgs >= target / 2 || n_chunks < 2 || d->Cout / (d->dtype == CBIM_BF16 ? 8 : 4) > 256) return 1;
+  int64_t s = (target + wgs - 1) / wgs;
   if (s > n_chunks) s = n_chunks;
   if (s > 16) s = 16;
   return (int)s;
