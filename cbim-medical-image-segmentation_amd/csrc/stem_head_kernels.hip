@@ -457,12 +457,13 @@ __global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x
   constexpr int CPC = Elem<T>::CPC, KT = 16, RING = 3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.y, cch = Cin / CPC;
+  const int q0 = (int)blockIdx.z * 4 * CHW;      // rows of more than 4 * CHW chunks: blockIdx.z = chunk group (dz is re-read, it is small)
   float wr[CHW][KT][CPC];     // W[k][chunk channels] of this wave's chunks (zero rows for k >= K)
   float acc[CHW][KT][CPC];
   float dbv[KT];
 #pragma unroll
   for (int h = 0; h < CHW; ++h) {
-    const int q = wave + 4 * h;
+    const int q = q0 + wave + 4 * h;
 #pragma unroll
     for (int k = 0; k < KT; ++k)
 #pragma unroll
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x
       for (int k = 0; k < KT; ++k) g[slot][k] = k < K ? dzn[(size_t)k * S + v] : 0.f;
 #pragma unroll
       for (int h = 0; h < CHW; ++h) {
-        const int q = wave + 4 * h;
+        const int q = q0 + wave + 4 * h;
         if (q < cch) raw[slot][h] = *(const u32x4*)(xn + ((size_t)v * Cin + (size_t)q * CPC) * Elem<T>::SIZE);
       }
     }
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x
     for (int k = 0; k < KT; ++k) dbv[k] += g[slot][k];
 #pragma unroll
     for (int h = 0; h < CHW; ++h) {
-      const int q = wave + 4 * h;
+      const int q = q0 + wave + 4 * h;
       if (q < cch) {
         float xf[CPC];
         Elem<T>::unpack(raw[slot][h], xf);
@@ -535,7 +536,7 @@ __global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x
   float* slab = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * npairs;
 #pragma unroll
   for (int h = 0; h < CHW; ++h) {
-    const int q = wave + 4 * h;
+    const int q = q0 + wave + 4 * h;
 #pragma unroll
     for (int k = 0; k < KT; ++k)
 #pragma unroll
@@ -547,7 +548,7 @@ __global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     const float a = wave_sum(dbv[k]);
-    if (wave == 0 && lane == 0 && k < K) slab[(size_t)k * (Cin + 1) + Cin] = a;
+    if (blockIdx.z == 0 && wave == 0 && lane == 0 && k < K) slab[(size_t)k * (Cin + 1) + Cin] = a;
   }
 }
 
@@ -721,23 +722,20 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
   {
     // one fused pass (dx, dw, db) when the channel chunks of a row fit the 4 waves x CHW layout of k_head_bwd_k
     const int cpc = dtype == CBIM_BF16 ? 8 : 4, cch = Cin / cpc;
-    // (bf16 rows of more than 4 chunks would need 2 x 16 x 8 accumulators + as many weight registers per lane: spills;
-    //  they keep the two-kernel path below)
-    if (K <= 16 && cch <= (dtype == CBIM_BF16 ? 4 : 8) && (size_t)Cin * 16 * sizeof(float) <= 64 * 1024) {
+    // (bf16: one chunk per wave — two would need 2 x 16 x 8 accumulators + as many weight registers per lane: spills;
+    //  wider rows, e.g. MedFormer's aux head on 128 channels, run as blockIdx.z groups of 4 chunks)
+    if (K <= 16) {
       int nb = head_bwd_blocks(S);      // (the workspace is sized for head_bwd_blocks(S) slabs)
       if (nb > 256) nb = 256;           // one workgroup per CU: fewer slabs for the reduce
       int64_t vpb = (S + nb - 1) / nb;
       vpb = (vpb + 63) / 64 * 64;
       const size_t sm = 0;
-      dim3 grid((unsigned)nb, (unsigned)N);
+      const int per = dtype == CBIM_BF16 ? 4 : 8;     // chunks per workgroup: 4 waves x CHW
+      dim3 grid((unsigned)nb, (unsigned)N, (unsigned)((cch + per - 1) / per));
       float* wsf = (float*)workspace;
-      if (dtype == CBIM_BF16) {
-        if (cch <= 4) CBIM_LAUNCH((k_head_bwd_k<bf16_tag, 1>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
-        else CBIM_LAUNCH((k_head_bwd_k<bf16_tag, 2>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
-      } else {
-        if (cch <= 4) CBIM_LAUNCH((k_head_bwd_k<float, 1>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
-        else CBIM_LAUNCH((k_head_bwd_k<float, 2>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
-      }
+      if (dtype == CBIM_BF16) CBIM_LAUNCH((k_head_bwd_k<bf16_tag, 1>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
+      else if (cch <= 4) CBIM_LAUNCH((k_head_bwd_k<float, 1>), dim3((unsigned)nb, (unsigned)N, 1), dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
+      else CBIM_LAUNCH((k_head_bwd_k<float, 2>), grid, dim3(NT), sm, st, x, w, dlogits, dx, wsf, S, Cin, K, vpb);
       if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
       const int npairs = K * (Cin + 1);
       CBIM_LAUNCH(k_head_bwd_reduce4, dim3((npairs + 63) / 64), dim3(NT), 0, st, (const float*)workspace, dw, db,

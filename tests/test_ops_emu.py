@@ -132,6 +132,8 @@ def test_conv_r32_weights_in_registers(dev):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
+    oc.check_stem_head(dev, dtype, N=1, Cin=1, base=72, K=6, dhw=(5, 8, 9))     # head rows of 9 / 18 chunks: chunk groups on blockIdx.z
+    oc.check_stem_head(dev, dtype, N=2, Cin=1, base=48, K=4, dhw=(4, 6, 10))    # SwinUNETR's head width
     oc.check_stem_head(dev, dtype, Cin=1, base=16, K=3, dhw=(4, 8, 8), k=(1, 3, 3))
     oc.check_stem_head(dev, dtype, Cin=5, base=8, K=3, dhw=(4, 8, 9))     # two channel groups in the stem wgrad
     oc.check_stem_head(dev, dtype, N=2, Cin=1, base=32, K=16, dhw=(5, 7, 9))   # head: 4 (bf16) / 8 (fp32) chunks per row
