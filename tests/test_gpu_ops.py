@@ -66,6 +66,9 @@ def test_conv_r32_weights_in_registers(dev):
     oc.check_conv_r32(dev, N=1, Cin=64, Cout=32, dhw=(9, 8, 16))
     oc.check_conv_r32(dev, N=2, Cin=96, Cout=64, dhw=(8, 9, 8), dy_split=32)     # 64-cout weight blocks; dgrad over [dy1 | dout]
     oc.check_conv_r32(dev, N=1, Cin=32, Cout=96, dhw=(8, 8, 8), act="none")     # Cout 96: the last 64-block is half empty
+    # the fused decoder layer of the headline ResUNet (96 -> 64, conv1 | shortcut) at 64^3: default selection, persistent
+    # strips of several tiles per workgroup, dgrad over [dy1 | dout]
+    oc.check_conv_r32(dev, N=1, Cin=96, Cout=64, dhw=(64, 64, 64), dy_split=32)
     oc.check_conv_r32(dev, N=1, Cout=32, dhw=(64, 64, 64))          # the default threshold: picked without the knob
 
 
