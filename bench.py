@@ -178,16 +178,43 @@ def _reference_cpu_baseline(args, cores):
                       f"torch {torch.__version__} CPU, {dt:.1f} s" + ("" if s == 128 else f" (scaled x{scale:.2f} to 128^3)")}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (one process per GPU,
+    RCCL rendezvous on 127.0.0.1) the way the reference's trainer spawns its own workers
+    (/root/reference/train_ddp.py:413 mp.spawn, :321 init_process_group) — through torch.distributed.run, i.e. the very
+    command line the driver uses.  Fails loudly when the node has fewer GPUs than ranks were asked for."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to report a "
+                 f"{args.gpus}-GPU number from fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    assert local < torch.cuda.device_count(), f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} GPU(s) visible"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     elif args.ddp1:
         import socket
         with socket.socket() as sk:
@@ -241,15 +268,22 @@ def main():
                                    _ap.Namespace(training_size=[args.size] * 3, affine_pad_size=[40] * 3, scale=[0.3] * 3,
                                                  rotate=[30] * 3, translate=[0] * 3))
         feeder = DevicePrefetcher(ds)
-        use_graph = False   # the pipeline draws host-side random parameters every step
+        # the pipeline draws host-side random parameters (and picks its kernels) every step: it stays OUTSIDE the
+        # hipGraph — samples are built eagerly on the prefetcher's side stream while the replay runs and handed to the
+        # captured step through two static input buffers (one 8 MB + one 16 MB device copy per step)
+        x, lab = (t.clone() for t in feeder.next())
 
     def draw():
         return feeder.next()
 
     def step():
         opt.zero_grad(set_to_none=True)
-        xs, ls = draw() if args.aug else (x, lab)
-        out = net(xs)
+        if args.aug:
+            xs, ls = draw()
+            x.copy_(xs)
+            lab.copy_(ls)
+        out = net(x)
+        ls = lab
         if isinstance(out, (list, tuple)):      # deep supervision, train.py:207-210 (aux_weight [0.5, 0.5])
             loss = sum(0.5 * crit(o, ls) for o in out)
         else:
@@ -277,11 +311,17 @@ def main():
                 opt.zero_grad(set_to_none=True)
                 # the RCCL collectives of the gradient exchange are captured with the kernels (N > 1): every rank
                 # captures and replays the same sequence
+                aug_on, args.aug = args.aug, 0      # the captured step reads the static buffers x / lab
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if ddp is not None else "global"):
                     static_loss = eager_step()
+                args.aug = aug_on
             torch.cuda.current_stream().wait_stream(side)
 
             def step():
+                if args.aug:
+                    xs, ls = draw()
+                    x.copy_(xs)
+                    lab.copy_(ls)
                 graph.replay()
                 return static_loss
             step()
@@ -312,7 +352,7 @@ def main():
 
     out = {
         "metric": "3D volumes/sec (fwd+bwd) at 128^3", "value": value, "unit": "volumes/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "n_gpus": dist.get_world_size() if dist.is_initialized() and not args.ddp1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": {"medformer": "3D MedFormer (amos_ct/medformer_3d.yaml, aux loss)",
@@ -322,7 +362,8 @@ def main():
                                + (", HBM-resident volumes + on-device augmentation (crop/affine/intensity, dataset_amos_ct recipe) prefetched on a side stream" if args.aug else "")
                                + (" (hipGraph replay)" if use_graph else "")
                                + (", bucketed in-place grad all-reduce (RCCL)" if ddp is not None else ""),
-                   "global_batch": world, "parallelism": f"dp{world}", "final_loss": loss_val},
+                   "global_batch": world, "parallelism": f"dp{world}",
+                   "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0, "final_loss": loss_val},
     }
 
     # ---- roofline of the dominant kernel: every launch of the conv kernels in one step, HIP events on the launch stream

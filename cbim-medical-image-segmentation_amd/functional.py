@@ -23,7 +23,11 @@ from . import ops
 from .ops import ACT, IN_EPS, ConvGeom
 
 _COMPUTE_DTYPE: Optional[torch.dtype] = None
-_CHECK_LABELS = os.environ.get("CBIM_CHECK_LABELS", "0") not in ("", "0")
+# labels outside [0, C): the reference raises (scatter_ / CrossEntropyLoss "Target out of bounds"); the kernel counts
+# them in out[3].  Reading the count is a device synchronisation, so by default only the first calls of a process
+# are checked (a wrong class count in a config shows up at once); CBIM_CHECK_LABELS=1 checks every call, =0 none.
+_CHECK_LABELS = os.environ.get("CBIM_CHECK_LABELS", "first")
+_label_checks_left = 4
 
 
 def set_compute_dtype(dtype):
@@ -72,6 +76,22 @@ def _geom(x: torch.Tensor, w: torch.Tensor, act: int) -> ConvGeom:
     return ConvGeom(x.dtype, int(x.shape[0]), tuple(x.shape[1:4]), int(w.shape[1]), int(w.shape[0]), k, pad, act)
 
 
+class _GradAwareFunction(torch.autograd.Function):
+    """autograd.Function whose forward can tell whether the CALLER ran under torch.no_grad() (inside forward() grad mode
+    is always off, and ctx.needs_input_grad only mirrors the inputs' requires_grad flags): sliding-window inference and
+    validation must not pack the dgrad weight layouts they never use."""
+    _caller_grad = True
+
+    @classmethod
+    def apply(cls, *args):
+        _GradAwareFunction._caller_grad = torch.is_grad_enabled()
+        return super().apply(*args)
+
+
+def _training(ctx) -> bool:
+    return _GradAwareFunction._caller_grad and any(ctx.needs_input_grad)
+
+
 class StemFn(torch.autograd.Function):
     """inconv.conv1: raw Conv3d, NCDHW fp32 in -> channels-last out (unet_utils.py:14,19)."""
 
@@ -99,7 +119,7 @@ def _fusable(x: torch.Tensor, cout: int) -> bool:
     return cout % kc == 0 and cout % 32 == 0
 
 
-class BasicBlockFn(torch.autograd.Function):
+class BasicBlockFn(_GradAwareFunction):
     """BasicBlock.forward (conv_layers.py:86-94) with pre-activation ConvNormAct (:48-49).
 
     inputs : x (raw, pre-norm), its statistics, w1, w2, wsc (or None), act code
@@ -114,7 +134,7 @@ class BasicBlockFn(torch.autograd.Function):
     def forward(ctx, x, x_stats, w1, w2, wsc, act, want_out_stats):
         cout = int(w1.shape[0])
         fused = wsc is not None and _fusable(x, cout)
-        train = any(ctx.needs_input_grad)
+        train = _training(ctx)
         # weights live in MFMA fragment order in a cache that one launch per optimizer step refreshes
         # (ops.PackedWeights); the dgrad layout comes out of the same launch
         wdsc = None
@@ -183,13 +203,13 @@ class BasicBlockFn(torch.autograd.Function):
         return dx, None, dw1, dw2, dwsc, None, None
 
 
-class SingleConvFn(torch.autograd.Function):
+class SingleConvFn(_GradAwareFunction):
     """SingleConv = post-activation ConvNormAct: act(IN(conv(x))) (conv_layers.py:51,56-68)."""
 
     @staticmethod
     def forward(ctx, x, w, act, need_dx):
         g = _geom(x, w, act)
-        wp, wpd = ops.packed_weights((w,), g, bool(need_dx))
+        wp, wpd = ops.packed_weights((w,), g, bool(need_dx) and _training(ctx))
         z, sz = ops.conv_fwd(x, wp, g, want_stats=True)
         ctx.wpd = wpd
         y = ops.norm_act_fwd(z, sz, act)
@@ -275,7 +295,10 @@ class DiceCEFn(torch.autograd.Function):
         out, coef = ops.dice_ce_fwd(logits, labels, weight)
         # out[3] = number of labels outside [0, C): the reference raises (scatter_ / CrossEntropyLoss); reading the
         # count is a device synchronisation, so it is only checked on request
-        if _CHECK_LABELS and not (logits.is_cuda and torch.cuda.is_current_stream_capturing()):
+        global _label_checks_left
+        want = _CHECK_LABELS == "1" or (_CHECK_LABELS not in ("", "0") and _label_checks_left > 0)
+        if want and not (logits.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _label_checks_left -= 1
             bad = int(out[3].item())
             if bad:
                 raise IndexError(f"cbim_amd: {bad} label(s) outside [0, {int(logits.shape[1])}) (Target out of bounds)")
@@ -303,7 +326,7 @@ def restat(stats: torch.Tensor, eps_from: float, eps_to: float) -> torch.Tensor:
     return torch.stack([stats[..., 0], (var + eps_to).rsqrt().float()], -1).contiguous()
 
 
-class NormConvFn(torch.autograd.Function):
+class NormConvFn(_GradAwareFunction):
     """y = conv(act(IN(x))) [+ res]  (pre-activation ConvNormAct, conv_layers.py:48-49); stats=None -> raw
     conv.  `se` (float [N,Cin], optional; act must be none) folds the SEBlock gate of conv_layers.py:159-175
     into the normalisation: IN(x*s) = (x-mean) * s*rsqrt(var*s^2+eps), so the gated tensor is never written.
@@ -312,7 +335,7 @@ class NormConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stats, w, act, res, want_stats, se, eps_out):
         g = _geom(x, w, act)
-        wp, wpd = ops.packed_weights((w,), g, bool(ctx.needs_input_grad[0]))
+        wp, wpd = ops.packed_weights((w,), g, bool(ctx.needs_input_grad[0]) and _training(ctx))
         st = stats
         if se is not None:
             assert act == 0 and stats is not None

@@ -247,7 +247,7 @@ def pack_weights_both(w: torch.Tensor, geom: ConvGeom):
 
 
 class _PackEntry:
-    __slots__ = ("w0", "w1", "rows0", "geom", "p0", "p1", "versions", "used", "idle")
+    __slots__ = ("w0", "w1", "rows0", "geom", "p0", "p1", "versions", "used", "idle", "pinned")
 
 
 class PackedWeights:
@@ -266,6 +266,9 @@ class PackedWeights:
         self.n_blocks = 0
         self.max_taps = 1
         self.dirty_table = True
+        # a hipGraph that captured a table launch replays with the raw pointers of that table and of every entry's
+        # p0/p1 baked in: both are kept alive here (and the entries exempt from aging) for the life of the process
+        self._graph_refs = []
 
     @staticmethod
     def _key(ws, geom: ConvGeom):
@@ -307,7 +310,7 @@ class PackedWeights:
         e.p1 = torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 1),), dtype=torch.uint8, device=dev) \
             if with_dgrad else None
         e.versions = None
-        e.used, e.idle = True, 0
+        e.used, e.idle, e.pinned = True, 0, False
         self.entries[key] = e
         self.dirty_table = True
         return e
@@ -350,7 +353,7 @@ class PackedWeights:
             for k, e in self.entries.items():
                 e.idle = 0 if e.used else e.idle + 1
                 e.used = False
-                if e.idle > self.MAX_IDLE:
+                if e.idle > self.MAX_IDLE and not e.pinned:
                     dead.append(k)
             for k in dead:
                 del self.entries[k]
@@ -364,6 +367,10 @@ class PackedWeights:
                                    "eager step first so that the pack table is complete")
             self._build_table()
         t = self.table
+        if capturing:
+            for e in self.entries.values():
+                e.pinned = True
+            self._graph_refs.append((t, list(self.entries.values())))
         check(_lib.lib().cbim_conv3d_pack_weights_table(_p(t), len(self.entries), self.n_blocks, self.max_taps, _stream(t)),
               "pack_weights_table")
         for e in self.entries.values():

@@ -69,11 +69,13 @@ class GradAllReduce:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._exchange = dist.is_initialized()      # a 1-rank group still runs the collective (tests, graph capture)
         self._sync = True
-        self._accumulated = False                   # a no_sync backward has left partial sums in the views
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast_parameters and self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, src=0, group=process_group)
+                # t.detach() shares the version counter with t (t.data does not): the in-place broadcast invalidates any
+                # packed copy of a weight made by a forward pass that ran before the wrap (ops.PackedWeights)
+                with torch.no_grad():
+                    dist.broadcast(t.detach(), src=0, group=process_group)
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets: List[_Bucket] = []
         cur = _Bucket()
@@ -108,10 +110,7 @@ class GradAllReduce:
         view = self._views[p]
         g = p.grad
         if g is not view:                       # fresh tensor from autograd (grad was None): move it into its slot
-            if self._accumulated:
-                view.add_(g)
-            else:
-                view.copy_(g)
+            view.copy_(g)                       # (a None grad means nothing was accumulated for p so far in this step)
             p.grad = view
         # else: autograd accumulated in place into the view (grad was already the view)
         if not self._sync:
@@ -137,7 +136,6 @@ class GradAllReduce:
             yield
         finally:
             self._sync = old
-            self._accumulated = True
 
     def synchronize(self):
         """Wait for every bucket; ``param.grad`` (a view of the bucket's flat buffer) then holds the average."""
@@ -158,7 +156,6 @@ class GradAllReduce:
                     b.flat.div_(self.world)
             b.fired = False
             b.pending = len(b.params)
-        self._accumulated = False
 
     def remove(self):
         for h in self._handles:

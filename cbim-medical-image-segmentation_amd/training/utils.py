@@ -89,6 +89,9 @@ def update_ema_variables(model, ema_model, alpha, global_step):
         p0 = tab.pairs[0][1]
         _lib.check(_lib.lib().cbim_ema_step(_p(tab.table), _p(tab.blk_tensor), _p(tab.blk_chunk), tab.nblocks, float(alpha),
                                             float(1 - alpha), _stream(p0)), "ema_step")
+        # the kernel wrote the EMA parameters through raw pointers: move their version counters, which is what the
+        # packed-weight cache (ops.PackedWeights) keys on — an ema_net forward after this must re-pack
+        torch.autograd.graph.increment_version([e for e, _ in tab.pairs])
     for ema_buffer, m_buffer in zip(ema_model.buffers(), model.buffers()):
         ema_buffer.copy_(m_buffer)
 

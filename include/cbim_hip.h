@@ -26,6 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libcbim_hip.so is built with -fvisibility=hidden: exactly the entry points declared in this header are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define CBIM_F32 0
 #define CBIM_BF16 1
@@ -407,6 +411,9 @@ int cbim_gate_bwd(int dtype, const void* dy, const void* x, const float* psi, vo
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,11 @@ def test_hip_library_builds_and_exports_every_symbol():
         assert hasattr(h, name), name
     h.cbim_backend.restype = ctypes.c_char_p
     assert h.cbim_backend() == b"hip-gfx950"
+    # -fvisibility=hidden: the header's entry points are ALL the library exports (no internal launcher / warm-up symbol)
+    r = subprocess.run(["nm", "-D", "--defined-only", SO], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exported = sorted(l.split()[-1] for l in r.stdout.splitlines() if l.split() and not l.split()[-1].startswith("_"))
+    assert exported == _declared(), sorted(set(exported) ^ set(_declared()))
 
 
 def test_missing_library_is_a_hard_error(tmp_path):

@@ -68,3 +68,48 @@ def test_dead_models_leave_the_table(dev, monkeypatch):
     finally:
         cbim_amd.set_compute_dtype(None)
         ops.PACKED.clear()
+
+
+def test_ema_update_invalidates_the_ema_net_packing(dev):
+    """update_ema_variables writes the EMA parameters through raw pointers (cbim_ema_step): their version counters must
+    move, or an ema_net forward after EMA updates runs on stale packed conv weights."""
+    import copy
+    from cbim_amd.training.utils import update_ema_variables
+    cbim_amd.set_compute_dtype("fp32")
+    try:
+        ops.PACKED.clear()
+        net = _net().to(dev)
+        ema = copy.deepcopy(net)
+        x = torch.randn(1, 1, 2, 16, 16, generator=torch.Generator().manual_seed(1)).to(dev)
+        with torch.no_grad():
+            y0 = ema(x)                                   # packs the EMA weights
+            for p in net.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+            v0 = [p._version for p in ema.parameters()]
+            for step in range(3):
+                update_ema_variables(net, ema, 0.5, step + 1)
+            assert all(p._version > v for p, v in zip(ema.parameters(), v0))
+            y1 = ema(x)
+            ops.PACKED.clear()
+            y2 = ema(x)                                   # cold cache
+        assert torch.equal(y1, y2) and not torch.equal(y0, y1)
+    finally:
+        cbim_amd.set_compute_dtype(None)
+        ops.PACKED.clear()
+
+
+def test_no_grad_forward_packs_no_dgrad_layout(dev):
+    """sliding-window inference / validation run under torch.no_grad(): only the forward weight layout is packed."""
+    cbim_amd.set_compute_dtype("fp32")
+    try:
+        ops.PACKED.clear()
+        net = _net().to(dev)
+        x = torch.randn(1, 1, 2, 16, 16).to(dev)
+        with torch.no_grad():
+            net(x)
+        assert ops.PACKED.entries and all(e.p1 is None for e in ops.PACKED.entries.values())
+        net(x).sum().backward()                           # training afterwards adds the dgrad layouts
+        assert any(e.p1 is not None for e in ops.PACKED.entries.values())
+    finally:
+        cbim_amd.set_compute_dtype(None)
+        ops.PACKED.clear()
