@@ -248,3 +248,69 @@ def test_engine_replicas_exchange_gradients_in_place():
     mean_local = [(torch.from_numpy(a) + torch.from_numpy(b)) / 2 for a, b in zip(got[0][2], got[1][2])]
     for acc, ml in zip(got[0][3], mean_local):
         assert torch.allclose(torch.from_numpy(acc), 2 * ml, rtol=1e-4, atol=1e-6)
+
+
+# ---- the wrapper the reference's trainer really uses: stock DistributedDataParallel(find_unused_parameters=True) ------
+# (/root/reference/train_ddp.py:353,358).  The engine module delivers parameter gradients through autograd, so DDP's
+# reducer hooks fire per parameter as the HIP-kernel backward proceeds.
+
+def _worker_stock_ddp(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.nn.parallel import DistributedDataParallel
+    from cbim_amd.training.losses import DiceCELoss
+    from cbim_amd.training.optim import FusedAdamW
+    net = _engine_net()
+    if rank == 1:     # DDP's constructor broadcasts rank 0's parameters
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.5)
+    net(_engine_data(rank)[0])                    # a forward BEFORE the wrap: its packed weights must not survive it
+    ddp = DistributedDataParallel(net, find_unused_parameters=True)
+    opt = FusedAdamW(ddp.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=0.05, eps=1e-5)
+    crit = DiceCELoss(torch.tensor([0.5, 1.0, 1.0]))
+    x, lab = _engine_data(rank)
+    grads = None
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        crit(ddp(x), lab).backward()
+        if it == 0:
+            grads = [p.grad.clone().numpy() for p in net.parameters()]
+        opt.step()
+    q.put((rank, grads, [p.detach().numpy() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_engine_module_under_stock_distributed_data_parallel():
+    if not os.environ.get("CBIM_HIP_LIBRARY"):
+        pytest.skip("needs the host-side kernel executor (CPU suite)")
+    from cbim_amd.training.losses import DiceCELoss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_stock_ddp, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, g, w = q.get(timeout=900)
+        got[r] = (g, w)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    crit = DiceCELoss(torch.tensor([0.5, 1.0, 1.0]))
+    ref = None
+    for r in range(2):
+        net = _engine_net()
+        x, lab = _engine_data(r)
+        crit(net(x), lab).backward()
+        gs = [p.grad.clone() for p in net.parameters()]
+        ref = gs if ref is None else [a + b for a, b in zip(ref, gs)]
+    for a, b, g in zip(got[0][0], got[1][0], ref):
+        assert (a == b).all()
+        assert torch.allclose(torch.from_numpy(a), g / 2, rtol=1e-5, atol=1e-7)
+    for a, b in zip(got[0][1], got[1][1]):
+        assert (a == b).all()                                   # replicas bit-identical after two optimizer steps
