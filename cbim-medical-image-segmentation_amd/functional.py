@@ -119,6 +119,33 @@ def _fusable(x: torch.Tensor, cout: int) -> bool:
     return cout % kc == 0 and cout % 32 == 0
 
 
+# A/B switch of the round-3 experiment "materialise act(IN(x)) once" (profiles/r03_*): 1 = every pre-activation conv
+# input of a BasicBlock is written ONCE as a = act(IN(x)) by a streaming pass and the forward conv, the weight-gradient
+# staging and the dgrad mask all read `a` as it is (pure LDS-DMA, no normalisation in LDS, no statistics tables);
+# 0 = normalise on load inside every consumer (round 2).
+_MATERIALIZE = os.environ.get("CBIM_MATERIALIZE", "1") not in ("", "0")
+
+
+def set_materialize(on: bool):
+    global _MATERIALIZE
+    _MATERIALIZE = bool(on)
+
+
+_IDENT_STATS = {}
+
+
+def _identity_stats(n: int, c: int, device) -> torch.Tensor:
+    """(mean 0, rstd 1) records: a dgrad launch masked by a = relu(IN(x)) itself — act'(a) = [a > 0] and, wherever the
+    mask is open, a IS the normalised value the InstanceNorm-backward sum needs."""
+    key = (n, c, str(device))
+    t = _IDENT_STATS.get(key)
+    if t is None:
+        t = torch.zeros((n, c, 2), dtype=torch.float32, device=device)
+        t[..., 1] = 1.0
+        _IDENT_STATS[key] = t
+    return t
+
+
 class BasicBlockFn(_GradAwareFunction):
     """BasicBlock.forward (conv_layers.py:86-94) with pre-activation ConvNormAct (:48-49).
 
@@ -128,6 +155,10 @@ class BasicBlockFn(_GradAwareFunction):
     conv1 and the shortcut conv read the same act(IN(x)) (InstanceNorm is parameter-free), so when
     the channel counts allow they run as ONE convolution with Cout-concatenated weights (forward,
     wgrad) / K-concatenated inputs (dgrad): the halo is staged and normalised once.
+
+    ReLU blocks (every shipped configuration) materialise a = relu(IN(.)) of both conv inputs once
+    (`_MATERIALIZE`): zero padding after the activation (conv_layers.py:48-49) is then simply the
+    zero halo of a raw convolution.
     """
 
     @staticmethod
@@ -135,13 +166,15 @@ class BasicBlockFn(_GradAwareFunction):
         cout = int(w1.shape[0])
         fused = wsc is not None and _fusable(x, cout)
         train = _training(ctx)
+        mat = _MATERIALIZE and act == ACT["relu"]
         # weights live in MFMA fragment order in a cache that one launch per optimizer step refreshes
         # (ops.PackedWeights); the dgrad layout comes out of the same launch
         wdsc = None
+        xin, sin = (ops.norm_act_fwd(x, x_stats, act), None) if mat else (x, x_stats)
         if fused:
             gc = _geom_c(x, 2 * cout, w1, act)
             wp, wd1 = ops.packed_weights((w1, wsc), gc, train)
-            ycat, scat = ops.conv_fwd(x, wp, gc, in_stats=x_stats, want_stats=True)
+            ycat, scat = ops.conv_fwd(xin, wp, gc, in_stats=sin, want_stats=True)
             y1, res = ycat[..., :cout], ycat[..., cout:]
             s1 = scat[:, :cout].contiguous()
             g1 = gsc = None
@@ -149,21 +182,24 @@ class BasicBlockFn(_GradAwareFunction):
             gc = None
             g1 = _geom(x, w1, act)
             wp, wd1 = ops.packed_weights((w1,), g1, train)
-            y1, s1 = ops.conv_fwd(x, wp, g1, in_stats=x_stats, want_stats=True)
+            y1, s1 = ops.conv_fwd(xin, wp, g1, in_stats=sin, want_stats=True)
             if wsc is not None:
                 gsc = _geom(x, wsc, act)
                 wpsc, wdsc = ops.packed_weights((wsc,), gsc, train)
-                res, _ = ops.conv_fwd(x, wpsc, gsc, in_stats=x_stats)
+                res, _ = ops.conv_fwd(xin, wpsc, gsc, in_stats=sin)
             else:
                 gsc = None
                 res = x
         g2 = _geom(y1, w2, act)
         wp2, wd2 = ops.packed_weights((w2,), g2, train)
-        out, so = ops.conv_fwd(y1, wp2, g2, in_stats=s1, res=res, want_stats=want_out_stats)
-        ctx.save_for_backward(x, x_stats, y1, s1, w1, w2, wsc if wsc is not None else torch.empty(0))
+        yin, s1in = (ops.norm_act_fwd(y1, s1, act), None) if mat else (y1, s1)
+        out, so = ops.conv_fwd(yin, wp2, g2, in_stats=s1in, res=res, want_stats=want_out_stats)
+        none = torch.empty(0)
+        ctx.save_for_backward(x, x_stats, y1, s1, w1, w2, wsc if wsc is not None else none,
+                              xin if mat and train else none, yin if mat and train else none)
         ctx.packed = (wd1, wd2, wdsc)
         ctx.geoms = (g1, g2, gsc, gc)
-        ctx.act = act
+        ctx.act, ctx.mat = act, mat
         if so is None:
             so = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(so)
@@ -172,33 +208,40 @@ class BasicBlockFn(_GradAwareFunction):
 
     @staticmethod
     def backward(ctx, dout, _dso):
-        x, x_stats, y1, s1, w1, w2, wsc = ctx.saved_tensors
+        x, x_stats, y1, s1, w1, w2, wsc, ax, ay1 = ctx.saved_tensors
         g1, g2, gsc, gc = ctx.geoms
         wd1, wd2, wdsc = ctx.packed
         act = ctx.act
         dout = dout.contiguous()
+        if ctx.mat:
+            # the conv inputs as the forward saw them: activated tensors, no statistics; the dgrad mask is [a > 0]
+            cx, cxs, cy, cys = ax, None, ay1, None
+            mxs = _identity_stats(int(x.shape[0]), int(x.shape[-1]), x.device)
+            mys = _identity_stats(int(y1.shape[0]), int(y1.shape[-1]), x.device)
+        else:
+            cx, cxs, cy, cys, mxs, mys = x, x_stats, y1, s1, x_stats, s1
         # conv2
-        dw2 = ops.conv_wgrad(y1, s1, dout, g2)
-        gy1, sums2 = ops.conv_dgrad(dout, wd2, g2, mask_x=y1, mask_stats=s1)
+        dw2 = ops.conv_wgrad(cy, cys, dout, g2)
+        gy1, sums2 = ops.conv_dgrad(dout, wd2, g2, mask_x=cy, mask_stats=mys)
         dy1 = ops.norm_bwd_apply(gy1, y1, s1, sums2, act, masked=False)
         if gc is not None:
             # conv1 + shortcut as one GEMM: dy = [dy1 | dout]
             cout = int(w1.shape[0])
-            dwcat = ops.conv_wgrad(x, x_stats, dy1, gc, dy2=dout)
+            dwcat = ops.conv_wgrad(cx, cxs, dy1, gc, dy2=dout)
             dw1, dwsc = dwcat[:cout], dwcat[cout:]
-            gx, sums1 = ops.conv_dgrad(dy1, wd1, gc, mask_x=x, mask_stats=x_stats, dy2=dout)
+            gx, sums1 = ops.conv_dgrad(dy1, wd1, gc, mask_x=cx, mask_stats=mxs, dy2=dout)
             dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False)
             return dx, None, dw1, dw2, dwsc, None, None
         # conv1 (+ shortcut conv share act(IN(x)))
-        dw1 = ops.conv_wgrad(x, x_stats, dy1, g1)
+        dw1 = ops.conv_wgrad(cx, cxs, dy1, g1)
         if gsc is not None:
-            dwsc = ops.conv_wgrad(x, x_stats, dout, gsc)
+            dwsc = ops.conv_wgrad(cx, cxs, dout, gsc)
             gx_u, _ = ops.conv_dgrad(dy1, wd1, g1)
-            gx, sums1 = ops.conv_dgrad(dout, wdsc, gsc, mask_x=x, mask_stats=x_stats, accumulate=gx_u)
+            gx, sums1 = ops.conv_dgrad(dout, wdsc, gsc, mask_x=cx, mask_stats=mxs, accumulate=gx_u)
             dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False)
         else:
             dwsc = None
-            gx, sums1 = ops.conv_dgrad(dy1, wd1, g1, mask_x=x, mask_stats=x_stats)
+            gx, sums1 = ops.conv_dgrad(dy1, wd1, g1, mask_x=cx, mask_stats=mxs)
             dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False, add=dout)
         return dx, None, dw1, dw2, dwsc, None, None
 
