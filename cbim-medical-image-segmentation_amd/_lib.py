@@ -65,7 +65,10 @@ _SIGS = {
     "cbim_conv3d_igemm": (i32, [_dp, vp, i64, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, sz, vp]),
     "cbim_conv3d_igemm_workspace": (sz, [_dp]),
     "cbim_conv3d_wgrad_workspace": (sz, [_dp]),
-    "cbim_conv3d_wgrad": (i32, [_dp, vp, i64, vp, vp, i64, vp, i64, i32, vp, vp, sz, vp]),
+    "cbim_conv3d_wgrad_last_kernel": (i32, []),
+    "cbim_wgrad_r32_enable": (i32, [i32]),
+    "cbim_wgrad_r32_waves": (i32, [i32]),
+    "cbim_conv3d_wgrad": (i32, [_dp, vp, i64, vp, i64, i32, vp, vp, i64, vp, i64, i32, vp, vp, sz, vp]),
     "cbim_stem_conv_fwd": (i32, [i32, vp, vp, vp] + [i32] * 15 + [vp]),
     "cbim_stem_conv_wgrad_workspace": (sz, [i32] * 9),
     "cbim_stem_conv_wgrad": (i32, [i32, vp, vp, vp] + [i32] * 15 + [vp, sz, vp]),

@@ -18,6 +18,7 @@
 // Replaces aten::convolution_backward(weight) for nn.Conv3d in ConvNormAct
 // (/root/reference/model/dim3/conv_layers.py:29-38).
 #include "cbim_common.h"
+#include "conv_wgrad_r32.h"
 
 namespace cbim {
 
@@ -434,8 +435,18 @@ extern "C" size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* d) {
   WgCfg c = wg_cfg(d);
   int taps = d->kD * d->kH * d->kW;
   // one tap: each of the 4 waves writes its own slab (they split the voxel loop)
-  return (size_t)d->N * c.strips_per_n * (taps == 1 ? 4 : taps) * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
+  size_t need = (size_t)d->N * c.strips_per_n * (taps == 1 ? 4 : taps) * c.co_blocks * 32 * c.ci_blocks * 32 * sizeof(float);
+  // (the kernel is picked at launch, from arguments this query does not see: room for either)
+  if (cbim_wgrad_r32_eligible(d, nullptr, nullptr, 0, nullptr, 0)) {
+    size_t r = cbim_wgrad_r32_workspace(d);
+    if (r > need) need = r;
+  }
+  return need;
 }
+
+// which kernel the last cbim_conv3d_wgrad call of this thread launched: 0 = k_conv_wgrad, 1 = k_wgrad_r32 (profiling labels)
+static thread_local int g_last_wgrad_kernel = 0;
+extern "C" int cbim_conv3d_wgrad_last_kernel(void) { return g_last_wgrad_kernel; }
 
 template <typename T, int TPW, int ACT, bool K3T = false>
 static int launch_wgrad(const WgradParams& p, dim3 grid, size_t smem, hipStream_t st) {
@@ -465,11 +476,29 @@ static int dispatch_tpw(int taps, const WgradParams& p, dim3 grid, size_t smem, 
   return launch_wgrad<T, 7, ACT>(p, grid, smem, st);
 }
 
-extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t x_stride,
+extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2,
+                                 int64_t x2_stride, int cin_split,
                                  const float* in_stats, const void* dy, int64_t dy_stride, const void* dy2,
                                  int64_t dy2_stride, int cout_split, float* dw,
                                  void* workspace, size_t ws_bytes, void* stream) {
   CBIM_CHECK(d && x && dy && dw, CBIM_EINVAL, "null argument");
+  g_last_wgrad_kernel = 0;
+  if (cbim_wgrad_r32_eligible(d, in_stats, x2, cin_split, dy2, cout_split)) {
+    size_t need = cbim_wgrad_r32_workspace(d);
+    CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "wgrad workspace %zu < %zu", ws_bytes, need);
+    g_last_wgrad_kernel = 1;
+    if (int rc = cbim_wgrad_r32_launch(d, x, x_stride, x2, x2_stride, cin_split, dy, dy_stride, dy2, dy2_stride, cout_split,
+                                       (float*)workspace, stream))
+      return rc;
+    const int64_t total = (int64_t)27 * d->Cout * d->Cin;
+    int64_t blocks = (total + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, (const float*)workspace, dw,
+                cbim_wgrad_r32_strips(d), 27, d->Cout, d->Cin, d->Cout, d->Cin, total);
+    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  }
+  CBIM_CHECK(!x2, CBIM_EUNSUPPORTED, "wgrad: a second input tensor is only taken by the bf16 3x3x3 kernel on raw (un-normalised) "
+             "inputs with channel counts in multiples of 32");
   CBIM_CHECK(d->dtype == CBIM_F32 || d->dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype");
   int cpc = d->dtype == CBIM_BF16 ? 8 : 4;
   CBIM_CHECK(d->Cin % cpc == 0 && d->Cout % cpc == 0, CBIM_EUNSUPPORTED,

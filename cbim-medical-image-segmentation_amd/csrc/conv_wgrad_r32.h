@@ -1,0 +1,17 @@
+// conv_wgrad_r32.h — internal interface of the "accumulators in registers" 3x3x3 weight-gradient kernel
+// (conv_wgrad_r32.hip), used by the cbim_conv3d_wgrad launcher (conv_wgrad.hip).  Not part of the C ABI.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/cbim_hip.h"
+
+// bf16, 3x3x3 / stride 1 / pad 1, Cin and Cout multiples of 32, the convolution input used AS IT IS (no statistics:
+// the caller materialised act(IN(x)) once), optional second input / second dy tensor split at multiples of 32
+bool cbim_wgrad_r32_eligible(const cbim_conv_desc* d, const float* in_stats, const void* x2, int cin_split, const void* dy2,
+                             int cout_split);
+// strips (= fp32 slabs [27][Cout][Cin] in the workspace) the launch writes; the caller reduces them in fixed order
+int cbim_wgrad_r32_strips(const cbim_conv_desc* d);
+size_t cbim_wgrad_r32_workspace(const cbim_conv_desc* d);
+int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                          int cin_split, const void* dy, int64_t dy_stride, const void* dy2, int64_t dy2_stride,
+                          int cout_split, float* workspace, void* stream);

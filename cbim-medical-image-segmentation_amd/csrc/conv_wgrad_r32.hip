@@ -1,0 +1,440 @@
+// conv_wgrad_r32.hip — weight gradient of the 3x3x3 convolution, bf16, channel counts in multiples of 32:
+// "accumulators in registers", the mirror image of conv_r32.hip (round 3).
+//
+//   dw[tap][co][ci] = sum_v dy[v][co] * a[v + tap - 1][ci]        a = the conv's input AS IT IS in memory: the caller
+//                                                                  materialised act(IN(x)) once (functional.BasicBlockFn)
+//
+// Why a second kernel: k_conv_wgrad (conv_wgrad.hip) ran at 21 % of the MFMA peak and took 30 % of the ResUNet step.
+// Its 4x8x8 tile is staged global -> registers -> (normalise) -> LDS between two workgroup barriers, a tile's
+// contraction (112 MFMAs) is shorter than one HBM round trip, and every k-step re-reads both operands through the LDS
+// transpose (16 ds_read_b64_tr_b16 per 7 MFMAs): three rewrites of the staging left the tile time where it was
+// (DESIGN.md "measured and rejected").  The shape of the work is what changes here:
+//   * persistent 512-thread workgroup per CU on 8x8x8 tiles; the 10x10x10 input halo is DOUBLE buffered in LDS and
+//     arrives by LDS-DMA (global_load_lds_dwordx4: no registers, no vector ALU, one barrier per tile) — possible
+//     because the input needs no transform any more;
+//   * the 27 tap accumulators of a (16 co x 16 ci) quadrant live in registers for the whole strip of tiles
+//     (27 x 4 VGPRs = the register image of conv_r32's weight fragments); a wave = (quadrant, half of the tile's rows);
+//   * v_mfma_f32_16x16x32_bf16 with K = 32 VOXELS = 4 rows x 8 w of one plane.  The wave reads its 8 dy fragments
+//     (one per plane) ONCE per tile; an input fragment of halo plane p at (kh, kw) then feeds the taps (kd = 0, 1, 2)
+//     against dy planes p, p-1, p-2: 10 fragment reads per 24 MFMAs, the ratio conv_r32 runs at;
+//   * both operands are channels-last rows in LDS and contract over voxels: every fragment is two
+//     ds_read_b64_tr_b16 (a 16-lane group fetches [4 voxels][16 channels] and each lane keeps one channel's 4 voxels);
+//   * the dy tile (32 KiB) is single buffered: it is dead once the 8 fragments are in registers, so the next tile's
+//     dy streams in behind a barrier at the top of the tile.
+// LDS: 2 x 63 KiB halo + 32 KiB dy = 158 KiB.  Per-strip fp32 slabs + the fixed-order k_wgrad_reduce as before.
+//
+// Replaces aten::convolution_backward(weight) for nn.Conv3d in ConvNormAct
+// (/root/reference/model/dim3/conv_layers.py:29-38).
+#include "cbim_common.h"
+#include "conv_wgrad_r32.h"
+#include <stdlib.h>
+
+namespace cbim {
+
+// WV = 8: 512 threads, two waves per SIMD (256 registers each); a wave = (co half, ci half, row group): 27 x 4 accumulators.
+// WV = 4: 256 threads, ONE wave per SIMD with the whole 512-register file; a wave = (ci half, row group) and keeps the
+//         accumulators of BOTH co halves (2 x 27 x 4): every input fragment read feeds 6 MFMAs instead of 3, which halves
+//         the LDS traffic per MFMA (at WV = 8 the LDS pipe is ~90 % busy at the full MFMA rate).
+static constexpr unsigned WR_HB = 63u * 1024u;          // one halo buffer: 1000 rows x 64 B in 63 LDS-DMA pieces of 1 KiB
+static constexpr unsigned WR_DY = 2u * WR_HB;            // dy tile: 512 rows x 64 B
+static constexpr unsigned WR_SMEM = WR_DY + 32u * 1024u;
+static_assert(WR_SMEM <= 160 * 1024, "LDS");
+
+__device__ __attribute__((aligned(64))) unsigned int g_wr32_zero[16];   // source of padding rows for the LDS-DMA
+
+struct WR32Params {
+  const void* x; int64_t x_stride;
+  const void* x2; int64_t x2_stride; int ci_split;     // ci chunks >= ci_split come from x2
+  const void* dy; int64_t dy_stride;
+  const void* dy2; int64_t dy2_stride; int co_split;   // co chunks >= co_split come from dy2
+  float* ws;
+  int N, Di, Hi, Wi, Do, Ho, Wo;
+  int tiles_d, tiles_h, tiles_w;
+  int ci_blocks, Cout_pad, Cin_pad;
+};
+
+#ifdef CBIM_EMU
+#define WR_SCHED_FENCE() ((void)0)
+#define WR_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
+#else
+#define WR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WR_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+// one 1 KiB LDS-DMA piece: lane l copies 16 bytes from its own global address to lds_wave_base + 16 l.  M0 (the LDS
+// base of the instruction) is saved and restored inside the statement, so nothing is hidden from the compiler.
+__device__ __forceinline__ void wr_dma16(const unsigned char* gsrc, unsigned char* smem, unsigned lds_base, unsigned off) {
+#ifdef CBIM_EMU
+  (void)lds_base;
+  emu_global_load_lds16(gsrc, smem + off);
+#else
+  (void)smem;
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_base + off);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(a), "v"(gsrc) : "memory");
+#endif
+}
+__device__ __forceinline__ void wr_wait_vm0() {
+#ifndef CBIM_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void wr_wait_lgkm0() {
+#ifndef CBIM_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ unsigned wr_mul24(unsigned a, unsigned b) {
+#ifdef CBIM_EMU
+  return a * b;
+#else
+  return __umul24(a, b);
+#endif
+}
+// 4 consecutive-voxel bf16 of one channel via the LDS transpose read (per-lane address of 4 bf16)
+__device__ __forceinline__ u32x2 wr_tr16_b64(const unsigned char* p) {
+#ifdef CBIM_EMU
+  unsigned short o[4];
+  emu_ds_read_tr16_b64(p, o);
+  u32x2 r;
+  r.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+  r.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+  return r;
+#else
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  return __builtin_bit_cast(u32x2, v);
+#endif
+}
+// XOR key of the 16-byte slot inside an LDS row, by the row's h coordinate: the four 16-lane groups of a transposed
+// read sit on four consecutive h rows (640 / 512 bytes apart = 128 / 0 modulo the 256-byte bank window); alternating
+// the 32-byte halves spreads them over all banks (same key as the conv_r32 halo)
+__device__ __forceinline__ unsigned wr_swz(unsigned h) { return (h & 1u) << 1; }
+
+typedef __attribute__((ext_vector_type(4))) float wr_f32x4;
+
+template <int WV>
+__global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
+  constexpr int WR_NT = WV * 64;
+  constexpr int NCH = WV == 8 ? 1 : 2;                                // co halves per wave
+  WR_DYN_SMEM(smem);
+#ifdef CBIM_EMU
+  const unsigned lds_base = 0;
+#else
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#endif
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lv = lane & 15, lq = lane >> 4;
+  // co half (WV = 8 only), ci half, row group of the 8x8 plane
+  const int ch0 = WV == 8 ? (wave & 1) : 0, cih = WV == 8 ? ((wave >> 1) & 1) : (wave & 1), vg = WV == 8 ? (wave >> 2) : (wave >> 1);
+  const int cb = blockIdx.y / p.ci_blocks, ib = blockIdx.y % p.ci_blocks;
+  const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+  const int n_tiles = p.N * tiles_per_n;
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int t_begin = (int)(((long long)lb * n_tiles) / gridDim.x);
+  const int t_end = (int)(((long long)(lb + 1) * n_tiles) / gridDim.x);
+
+  // ---- this workgroup's 32-channel chunks of the input and of dy (wave-uniform) ----------------------------------
+  const bool x_second = p.x2 != nullptr && ib >= p.ci_split;
+  const bool dy_second = p.dy2 != nullptr && cb >= p.co_split;
+  const unsigned x_sb = (unsigned)(x_second ? p.x2_stride : p.x_stride) * 2u;
+  const unsigned dy_sb = (unsigned)(dy_second ? p.dy2_stride : p.dy_stride) * 2u;
+  const unsigned char* const x_chunk = x_second ? (const unsigned char*)p.x2 + (ib - p.ci_split) * 64
+                                                : (const unsigned char*)p.x + ib * 64;
+  const unsigned char* const dy_chunk = dy_second ? (const unsigned char*)p.dy2 + (cb - p.co_split) * 64
+                                                  : (const unsigned char*)p.dy + cb * 64;
+
+  // ---- LDS-DMA items of this thread (the same for every tile).  Item q = tid + 512 u is PHYSICAL: LDS byte 16 q of
+  //      its region = row q >> 2, slot q & 3; the source slot is (q & 3) ^ swz(h of the row).  Position and source
+  //      offset are decoded once and stay in registers (the 27 x 4 accumulators leave room for them) -------------------
+  constexpr int UH = 64 / WV, UD = 32 / WV;         // halo items (63 pieces over the waves), dy items (32 pieces)
+  const unsigned my_slot = (unsigned)tid & 3u;
+  unsigned hoff[UH], hpos[UH], doff[UD], dpos[UD];
+#pragma unroll
+  for (int u = 0; u < UH; ++u) {
+    const unsigned row = ((unsigned)tid + (unsigned)WR_NT * (unsigned)u) >> 2;
+    const unsigned hd = (row * 5243u) >> 19;            // row / 100 for row < 1024
+    const unsigned r2 = row - hd * 100u;
+    const unsigned hh = (r2 * 205u) >> 11;              // r2 / 10 for r2 < 100
+    const unsigned hw = r2 - hh * 10u;
+    hpos[u] = hd | (hh << 8) | (hw << 16) | (row < 1000u ? 1u << 24 : 0u);
+    hoff[u] = wr_mul24(wr_mul24(wr_mul24(hd, (unsigned)p.Hi) + hh, (unsigned)p.Wi) + hw, x_sb) + ((my_slot ^ wr_swz(hh)) << 4);
+  }
+#pragma unroll
+  for (int u = 0; u < UD; ++u) {
+    const unsigned row = ((unsigned)tid + (unsigned)WR_NT * (unsigned)u) >> 2;   // < 512: (plane, h, w) of the 8x8x8 tile
+    const unsigned i = row >> 6, h = (row >> 3) & 7u, w = row & 7u;
+    dpos[u] = i | (h << 8) | (w << 16);
+    doff[u] = wr_mul24(wr_mul24(wr_mul24(i, (unsigned)p.Ho) + h, (unsigned)p.Wo) + w, dy_sb) + ((my_slot ^ wr_swz(h)) << 4);
+  }
+
+  struct TilePos { int n, td, th, tw; };
+  auto advance = [&](TilePos& u) {
+    if (++u.tw == p.tiles_w) { u.tw = 0; if (++u.th == p.tiles_h) { u.th = 0; if (++u.td == p.tiles_d) { u.td = 0; ++u.n; } } }
+  };
+  TilePos cur, nxt;
+  {
+    const int tt = t_begin % tiles_per_n;
+    cur.n = t_begin / tiles_per_n; cur.td = tt / (p.tiles_w * p.tiles_h); cur.th = (tt / p.tiles_w) % p.tiles_h; cur.tw = tt % p.tiles_w;
+    nxt = cur;
+    advance(nxt);
+  }
+
+  // halo piece u of tile `tp` into halo buffer at LDS offset `buf` (rows outside the tensor: 64 zero bytes)
+  auto dma_halo = [&](const TilePos& tp, int u, unsigned buf) {
+    if (wave * 64 + WR_NT * u >= 63 * 64) return;                      // wave-uniform: the 64th piece does not exist
+    const int id0 = tp.td * 8 - 1, ih0 = tp.th * 8 - 1, iw0 = tp.tw * 8 - 1;
+    const long long org = (((long long)tp.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0;
+    const unsigned char* tbase = x_chunk + org * (long long)x_sb;      // wave-uniform
+    const unsigned pk = hpos[u];
+    const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
+    const bool ld = (pk >> 24) != 0 && (unsigned)(id0 + (int)hd) < (unsigned)p.Di && (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi &&
+                    (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
+    const unsigned char* src = (ld ? tbase : (const unsigned char*)g_wr32_zero) + (ld ? hoff[u] : 0u);
+    wr_dma16(src, smem, lds_base, buf + (unsigned)(wave * 64 + WR_NT * u) * 16u);
+  };
+  auto dma_dy = [&](const TilePos& tp, int u) {
+    const int od0 = tp.td * 8, oh0 = tp.th * 8, ow0 = tp.tw * 8;
+    const long long org = (((long long)tp.n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
+    const unsigned char* tbase = dy_chunk + org * (long long)dy_sb;
+    const unsigned pk = dpos[u];
+    const unsigned i = pk & 255u, h = (pk >> 8) & 255u, w = (pk >> 16) & 255u;
+    const bool ld = od0 + (int)i < p.Do && oh0 + (int)h < p.Ho && ow0 + (int)w < p.Wo;
+    const unsigned char* src = (ld ? tbase : (const unsigned char*)g_wr32_zero) + (ld ? doff[u] : 0u);
+    wr_dma16(src, smem, lds_base, WR_DY + (unsigned)(wave * 64 + WR_NT * u) * 16u);
+  };
+
+  // ---- fragment addresses.  A transposed read: lane s of a 16-lane group supplies the address of voxel (s >> 2) [+4],
+  //      channels 4 (s & 3) .. +3 of the group's 16; it receives channel s, 4 voxels.  Group lq = row 4 vg + lq of the
+  //      plane, the two reads of a fragment are w 0..3 and w 4..7: lane (lv, lq) ends up with its channel's 8 voxels
+  //      (plane, 4 vg + lq, w = 0..7) = k-group lq of the 32-voxel k-step.
+  const unsigned sub = ((unsigned)lv & 1u) * 8u;                       // 8-byte half of the 16-byte slot
+  const unsigned a_h = (unsigned)(4 * vg + lq);
+  unsigned a_base[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    a_base[c] = WR_DY + (a_h * 8u + ((unsigned)lv >> 2)) * 64u + ((((unsigned)(2 * (ch0 + c)) + (((unsigned)lv & 3u) >> 1)) ^ wr_swz(a_h)) << 4) + sub;
+  unsigned b_base[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const unsigned hh = a_h + (unsigned)kh;
+    b_base[kh] = (hh * 10u + ((unsigned)lv >> 2)) * 64u + ((((unsigned)(2 * cih) + (((unsigned)lv & 3u) >> 1)) ^ wr_swz(hh)) << 4) + sub;
+  }
+
+  wr_f32x4 acc[NCH][27];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) acc[c][tp] = wr_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n_my = t_end - t_begin;
+  if (n_my > 0) {
+    // ---- prologue: first tile's dy and halo -------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < UD; ++u) dma_dy(cur, u);
+#pragma unroll
+    for (int u = 0; u < UH; ++u) dma_halo(cur, u, 0);
+    wr_wait_vm0();
+    __syncthreads();
+  }
+  for (int t = 0; t < n_my; ++t) {
+    const unsigned buf = (unsigned)(t & 1) * WR_HB, obuf = WR_HB - buf;
+    const bool more = t + 1 < n_my;                                    // workgroup-uniform
+    // (A) the wave's 8 dy fragments (one per plane); the dy region is dead afterwards
+    u32x4 af[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u32x2 a0 = wr_tr16_b64(smem + a_base[c] + (unsigned)i * 4096u);
+        const u32x2 a1 = wr_tr16_b64(smem + a_base[c] + (unsigned)i * 4096u + 256u);
+        af[c][i] = u32x4{a0.x, a0.y, a1.x, a1.y};
+      }
+    if (more) {
+      wr_wait_lgkm0();                                                 // the reads have returned their data
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < UD; ++u) dma_dy(nxt, u);
+    }
+    // (B) 9 (kh, kw) steps: the 10 halo-plane fragments stream through a ring of 5 registers; plane p feeds the taps
+    //     (kd 0, dy plane p), (kd 1, p-1), (kd 2, p-2).  The next tile's halo is fetched during the first four steps.
+    {
+      constexpr int RING = 5, PLN = 10, SEQ = 9 * PLN;
+      u32x4 xr[RING];
+      auto frag = [&](int e) -> u32x4 {                                // e = (kh*3 + kw) * PLN + plane
+        const int pl = e % PLN, s = e / PLN;
+        const unsigned a = buf + b_base[s / 3] + (unsigned)((s % 3) * 64) + (unsigned)(pl * 6400);
+        const u32x2 b0 = wr_tr16_b64(smem + a);
+        const u32x2 b1 = wr_tr16_b64(smem + a + 256u);
+        return u32x4{b0.x, b0.y, b1.x, b1.y};
+      };
+#pragma unroll
+      for (int e = 0; e < RING - 1; ++e) xr[e] = frag(e);
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        const int kh = s / 3, kw = s % 3;
+        if (more && 2 * s < UH) {
+          dma_halo(nxt, 2 * s, obuf);
+          dma_halo(nxt, 2 * s + 1, obuf);
+        }
+#pragma unroll
+        for (int pl = 0; pl < PLN; ++pl) {
+          const int e = s * PLN + pl;
+          if (e + RING - 1 < SEQ) xr[(e + RING - 1) % RING] = frag(e + RING - 1);
+          WR_SCHED_FENCE();
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd) {
+            const int i = pl - kd;
+            if (i >= 0 && i < 8) {
+              const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+              for (int c = 0; c < NCH; ++c)
+                acc[c][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[c][i]), __builtin_bit_cast(bf16x8, xr[e % RING]),
+                                                                      acc[c][tap], 0, 0, 0);
+            }
+          }
+          WR_SCHED_FENCE();
+        }
+      }
+    }
+    // (C) ONE barrier per tile (two with the dy hand-over): every wave is done with `buf`, the other buffer and the dy
+    //     tile are complete (own LDS-DMA pieces waited for)
+    wr_wait_vm0();
+    __syncthreads();
+    cur = nxt;
+    advance(nxt);
+  }
+
+  // ---- the two row groups of a quadrant hold partial sums of the same (tap, co, ci): add them through LDS in fixed
+  //      order (vg 0 + vg 1) and write this strip's slab ws[strip][tap][Cout_pad][Cin_pad] --------------------------------
+  float* red = (float*)smem;                                           // [quadrant][tap][r][lane], 108 KiB
+  if (vg == 1) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(((2 * cih + ch0 + c) * 27 + tp) * 4 + r) * 64 + lane] = acc[c][tp][r];
+  }
+  __syncthreads();
+  if (vg == 0) {
+    const size_t slab = (size_t)27 * p.Cout_pad * p.Cin_pad;
+    float* wsb = p.ws + (size_t)lb * slab;
+    const int ci = ib * 32 + 16 * cih + lv;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = cb * 32 + 16 * (ch0 + c) + 4 * lq + r;
+          wsb[((size_t)tp * p.Cout_pad + co) * p.Cin_pad + ci] = acc[c][tp][r] + red[(((2 * cih + ch0 + c) * 27 + tp) * 4 + r) * 64 + lane];
+        }
+  }
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+// CBIM_WGRAD_R32=0 keeps every weight gradient on k_conv_wgrad (A/B runs)
+static int g_wr32_on = getenv("CBIM_WGRAD_R32") ? atoi(getenv("CBIM_WGRAD_R32")) : 1;
+static int wr32_on() { return g_wr32_on; }
+extern "C" int cbim_wgrad_r32_enable(int on) {
+  const int old = g_wr32_on;
+  if (on >= 0) g_wr32_on = on;
+  return old;
+}
+
+// CBIM_WGRAD_R32_WAVES=4|8: waves per workgroup (see k_wgrad_r32); process-wide knob for tools and tests
+static int g_wr32_waves = getenv("CBIM_WGRAD_R32_WAVES") && atoi(getenv("CBIM_WGRAD_R32_WAVES")) == 4 ? 4 : 8;
+static int wr32_waves() { return g_wr32_waves; }
+extern "C" int cbim_wgrad_r32_waves(int w) {
+  const int old = g_wr32_waves;
+  if (w == 4 || w == 8) g_wr32_waves = w;
+  return old;
+}
+
+bool cbim_wgrad_r32_eligible(const cbim_conv_desc* d, const float* in_stats, const void* x2, int cin_split, const void* dy2,
+                             int cout_split) {
+  if (!wr32_on() || d->dtype != CBIM_BF16 || in_stats) return false;
+  if (d->kD != 3 || d->kH != 3 || d->kW != 3 || d->pD != 1 || d->pH != 1 || d->pW != 1) return false;
+  if (d->Cin % 32 != 0 || d->Cout % 32 != 0) return false;
+  if (x2 && (cin_split <= 0 || cin_split >= d->Cin || cin_split % 32 != 0)) return false;
+  if (dy2 && (cout_split <= 0 || cout_split >= d->Cout || cout_split % 32 != 0)) return false;
+  if (d->Do != d->Di || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+  // below 8 in a dimension most of an 8x8x8 tile is padding: k_conv_wgrad's 4x4x8 / 2x8x8 tiles fit better
+  return d->Do >= 8 && d->Ho >= 8 && d->Wo >= 8;
+}
+
+static void wr32_tiles(const cbim_conv_desc* d, int& td, int& th, int& tw) {
+  td = (d->Do + 7) / 8; th = (d->Ho + 7) / 8; tw = (d->Wo + 7) / 8;
+}
+
+// strips per (co chunk, ci chunk) pair: whole rounds of 256 persistent workgroups, a tile and a half of fixed cost per
+// workgroup (exposed first load, slab write), slabs capped at 96 MiB
+int cbim_wgrad_r32_strips(const cbim_conv_desc* d) {
+  int td, th, tw;
+  wr32_tiles(d, td, th, tw);
+  const int64_t n_tiles = (int64_t)d->N * td * th * tw;
+  const int64_t pairs = (int64_t)(d->Cout / 32) * (d->Cin / 32);
+  const int64_t slab = (int64_t)27 * d->Cout * d->Cin * 4;
+  int64_t gmax = (96ll << 20) / slab;
+  if (gmax < 1) gmax = 1;
+  if (gmax > n_tiles) gmax = n_tiles;
+  if (gmax > 256) gmax = 256;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int64_t g = 1; g <= gmax; ++g) {
+    // several pairs: strips in multiples of 8 put the pairs of one strip (same dy tile / same input halo) on the same
+    // XCD (workgroup k runs on XCD k % 8), where the second reader hits the L2
+    if (pairs > 1 && gmax >= 8 && g % 8 != 0) continue;
+    const double rounds = (double)((pairs * g + 255) / 256);
+    const double cost = rounds * ((double)((n_tiles + g - 1) / g) + 1.5);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = (int)g; }
+  }
+  return best;
+}
+
+size_t cbim_wgrad_r32_workspace(const cbim_conv_desc* d) {
+  return (size_t)cbim_wgrad_r32_strips(d) * 27 * d->Cout * d->Cin * sizeof(float);
+}
+
+int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                          int cin_split, const void* dy, int64_t dy_stride, const void* dy2, int64_t dy2_stride,
+                          int cout_split, float* workspace, void* stream) {
+  WR32Params p;
+  p.x = x; p.x_stride = x_stride; p.x2 = x2; p.x2_stride = x2 ? x2_stride : x_stride; p.ci_split = x2 ? cin_split / 32 : d->Cin / 32;
+  p.dy = dy; p.dy_stride = dy_stride; p.dy2 = dy2; p.dy2_stride = dy2 ? dy2_stride : dy_stride;
+  p.co_split = dy2 ? cout_split / 32 : d->Cout / 32;
+  p.ws = workspace;
+  p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
+  wr32_tiles(d, p.tiles_d, p.tiles_h, p.tiles_w);
+  p.ci_blocks = d->Cin / 32; p.Cout_pad = d->Cout; p.Cin_pad = d->Cin;
+  {
+    // 32-bit byte offsets inside one halo box / one dy tile, built from 24-bit multiplies
+    const int64_t box_rows = (int64_t)10 * d->Hi * d->Wi, xs = (x2 && x2_stride > x_stride ? x2_stride : x_stride) * 2;
+    const int64_t ds = (dy2 && dy2_stride > dy_stride ? dy2_stride : dy_stride) * 2;
+    CBIM_CHECK(box_rows < (1 << 24) && xs < (1 << 24) && ds < (1 << 24) && box_rows * xs < ((int64_t)1 << 32) &&
+               box_rows * ds < ((int64_t)1 << 32), CBIM_EUNSUPPORTED,
+               "wgrad r32: plane %dx%d with row strides %lld/%lld B exceeds the 32-bit tile addressing", d->Hi, d->Wi, (long long)xs, (long long)ds);
+  }
+#ifndef CBIM_EMU
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_r32<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_wgrad_r32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+#endif
+  dim3 grid((unsigned)cbim_wgrad_r32_strips(d), (unsigned)((d->Cout / 32) * (d->Cin / 32)));
+  if (wr32_waves() == 4) CBIM_LAUNCH(k_wgrad_r32<4>, grid, dim3(256), (size_t)WR_SMEM, (hipStream_t)stream, p);
+  else CBIM_LAUNCH(k_wgrad_r32<8>, grid, dim3(512), (size_t)WR_SMEM, (hipStream_t)stream, p);
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "wgrad r32 launch: %s", hipGetErrorString(e));
+  return CBIM_OK;
+}
+
+CBIM_DEFINE_WARM(wgrad_r32)

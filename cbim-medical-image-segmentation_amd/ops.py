@@ -477,9 +477,10 @@ def conv_dgrad(dy, w_packed_dgrad, geom: ConvGeom, mask_x=None, mask_stats=None,
     return g, sums
 
 
-def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None) -> torch.Tensor:
-    """dy2: gradient of the output channels >= dy.shape[-1] (Cout-concatenated convs)."""
-    _dev_ok(x, in_stats, dy, dy2)
+def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None, x2=None) -> torch.Tensor:
+    """dy2: gradient of the output channels >= dy.shape[-1] (Cout-concatenated convs); x2: the input channels
+    >= x.shape[-1] (virtual concatenation, raw bf16 3x3x3 inputs only)."""
+    _dev_ok(x, in_stats, dy, dy2, x2)
     L = _lib.lib()
     nbytes = L.cbim_conv3d_wgrad_workspace(C.byref(geom.fwd))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
@@ -488,7 +489,8 @@ def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None) -> torch.Tensor:
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.cbim_conv3d_wgrad(C.byref(geom.fwd), _p(x), _rs(x), _p(in_stats), _p(dy), _rs(dy),
+    check(L.cbim_conv3d_wgrad(C.byref(geom.fwd), _p(x), _rs(x), _p(x2), _rs(x2) if x2 is not None else 0,
+                              int(x.shape[-1]) if x2 is not None else 0, _p(in_stats), _p(dy), _rs(dy),
                               _p(dy2), _rs(dy2) if dy2 is not None else 0,
                               int(dy.shape[-1]) if dy2 is not None else 0,
                               _p(dw), _p(ws), nbytes, _stream(x)), "conv3d_wgrad")
@@ -496,7 +498,9 @@ def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None) -> torch.Tensor:
         e1.record()
         d = geom.fwd
         flops = 2.0 * d.N * d.Do * d.Ho * d.Wo * d.Cout * d.Cin * d.kD * d.kH * d.kW
-        PROFILE.append(("k_conv_wgrad<%s>+reduce" % ("bf16" if d.dtype == 1 else "f32"), flops, e0, e1,
+        name = "k_wgrad_r32<bf16>+reduce" if L.cbim_conv3d_wgrad_last_kernel() == 1 else \
+            "k_conv_wgrad<%s>+reduce" % ("bf16" if d.dtype == 1 else "f32")
+        PROFILE.append((name, flops, e0, e1,
                         (d.Cin, d.Cout, d.Do, d.Ho, d.Wo)))
     return dw
 

@@ -184,9 +184,18 @@ size_t cbim_conv3d_igemm_workspace(const cbim_conv_desc* desc);
 /* dw[co][ci][tap] (fp32, natural nn.Conv3d layout) = sum_v dy[v][co] * xform(x)[v+tap][ci].
  * desc is the FORWARD desc.  workspace: cbim_conv3d_wgrad_workspace(desc) bytes.
  * dy2 != NULL: output channels >= cout_split (a multiple of 32) take their gradient from dy2
- * (Cout-concatenated conv1 + shortcut conv sharing one staged input halo). */
+ * (Cout-concatenated conv1 + shortcut conv sharing one staged input halo).
+ * x2 != NULL: input channels >= cin_split (a multiple of 32) come from x2 — the virtual concatenation
+ * [skip | upsampled] of up_block (unet_utils.py:69-71); bf16 3x3x3 on raw inputs only (in_stats NULL).
+ * bf16 3x3x3 convolutions whose input is used as it is (in_stats NULL, channel counts in multiples of 32,
+ * extents >= 8) run on k_wgrad_r32 (conv_wgrad_r32.hip: LDS-DMA double-buffered 8x8x8 tiles, the 27 tap
+ * accumulators in registers); everything else on k_conv_wgrad. */
 size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* fwd_desc);
-int cbim_conv3d_wgrad(const cbim_conv_desc* fwd_desc, const void* x, int64_t x_stride,
+int cbim_conv3d_wgrad_last_kernel(void);   /* 0 = k_conv_wgrad, 1 = k_wgrad_r32 (profiling labels) */
+int cbim_wgrad_r32_enable(int on);          /* process-wide knob (tests, tools): 0 keeps every wgrad on k_conv_wgrad; returns the old value */
+int cbim_wgrad_r32_waves(int waves);        /* process-wide knob (tests, tools): 8 or 4 waves per workgroup; returns the old value */
+int cbim_conv3d_wgrad(const cbim_conv_desc* fwd_desc, const void* x, int64_t x_stride, const void* x2,
+                      int64_t x2_stride, int cin_split,
                       const float* in_stats, const void* dy, int64_t dy_stride, const void* dy2,
                       int64_t dy2_stride, int cout_split, float* dw,
                       void* workspace, size_t ws_bytes, void* stream);

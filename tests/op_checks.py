@@ -579,3 +579,31 @@ def check_window_attn_mfma(dev, B=1, dhw=(9, 8, 7), C=48, heads=3, window=(7, 7,
     assert relerr(dq16.float().cpu(), dq32.cpu()) < 3e-2, f"window attention (mfma) dqkv {relerr(dq16.float().cpu(), dq32.cpu()):.3e}"
     assert relerr(dt16.cpu(), dt32.cpu()) < 3e-2, f"window attention (mfma) dtable {relerr(dt16.cpu(), dt32.cpu()):.3e}"
     assert relerr(db16.cpu(), db32.cpu()) < 3e-2 + 1e-6, f"window attention (mfma) dbias {relerr(db16.cpu(), db32.cpu()):.3e}"
+
+
+def check_wgrad_r32(dev, N=1, Cin=32, Cout=32, dhw=(8, 16, 8), split=0, xsplit=0, seed=7):
+    """Weight gradient of a bf16 3x3x3 convolution on a RAW input (the caller materialised act(IN(x))) through
+    k_wgrad_r32 (8x8x8 tiles, LDS-DMA double buffering, 27 tap accumulators in registers) against torch.
+    split > 0: dy as two tensors (conv1 + shortcut as one GEMM); xsplit > 0: the input as two tensors (virtual concat)."""
+    from cbim_amd import _lib
+    dtype = torch.bfloat16
+    torch.manual_seed(seed)
+    k, pad = (3, 3, 3), (1, 1, 1)
+    x = torch.relu(torch.randn(N, Cin, *dhw) * 1.2 + 0.3)
+    xl = to_cl(x, dtype).to(dev)
+    a = from_cl(xl.cpu())
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, ops.ACT["relu"])
+    dy = torch.randn(N, Cout, *dhw)
+    dyl = to_cl(dy, dtype).to(dev)
+    kw = {}
+    if split:
+        kw["dy2"] = dyl[..., split:].contiguous()
+    if xsplit:
+        kw["x2"] = xl[..., xsplit:]                      # a channel-range view of the wider tensor (row stride Cin)
+    dw = ops.conv_wgrad(xl[..., :xsplit].contiguous() if xsplit else xl, None, dyl[..., :split].contiguous() if split else dyl,
+                        geom, **kw)
+    assert _lib.lib().cbim_conv3d_wgrad_last_kernel() == 1, "k_wgrad_r32 was not selected"
+    w = torch.zeros(Cout, Cin, *k, requires_grad=True)
+    F.conv3d(a, w, None, 1, pad).backward(from_cl(dyl.cpu()))
+    e = relerr(dw.cpu(), w.grad)
+    assert e < 1e-3, f"wgrad r32 vs torch {e:.3e}"

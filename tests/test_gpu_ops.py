@@ -208,3 +208,20 @@ def test_wgrad_unrolled_plane_path_at_32k_voxels(dev):
     oc.check_wgrad_large(dev, N=1, Cin=32, Cout=32, dhw=(33, 32, 40), raw=True)
     # three cout blocks x two Cin blocks
     oc.check_wgrad_large(dev, N=1, Cin=64, Cout=96, dhw=(30, 36, 41))
+
+
+@pytest.mark.gpu
+def test_wgrad_r32_accumulators_in_registers(dev):
+    """k_wgrad_r32 against torch at the sizes the ResUNet launches it with (and ragged ones), both wave layouts."""
+    from cbim_amd import _lib
+    L = _lib.lib()
+    try:
+        for wv in (8, 4):
+            L.cbim_wgrad_r32_waves(wv)
+            oc.check_wgrad_r32(dev, N=1, Cin=32, Cout=32, dhw=(64, 64, 64))
+            oc.check_wgrad_r32(dev, N=2, Cin=64, Cout=64, dhw=(30, 36, 41), split=32)
+            oc.check_wgrad_r32(dev, N=1, Cin=96, Cout=64, dhw=(32, 40, 24), split=32, xsplit=32)
+            oc.check_wgrad_r32(dev, N=1, Cin=320, Cout=320, dhw=(8, 8, 8))
+            oc.check_wgrad_r32(dev, N=1, Cin=576, Cout=512, dhw=(16, 16, 16), split=256, xsplit=256)
+    finally:
+        L.cbim_wgrad_r32_waves(8)

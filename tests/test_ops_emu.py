@@ -204,3 +204,18 @@ def test_wgrad_unrolled_plane_path_at_32k_voxels(dev):
     oc.check_wgrad_large(dev, N=1, Cin=32, Cout=32, dhw=(8, 64, 64), raw=True)
     # three cout blocks x two Cin blocks
     oc.check_wgrad_large(dev, N=1, Cin=64, Cout=96, dhw=(8, 64, 64))
+
+
+def test_wgrad_r32_accumulators_in_registers(dev):
+    """k_wgrad_r32 (raw bf16 3x3x3 inputs, channel multiples of 32) on the executor: both wave layouts, ragged extents,
+    several (co, ci) chunk pairs, dy and x as two tensors."""
+    from cbim_amd import _lib
+    L = _lib.lib()
+    try:
+        for wv in (8, 4):
+            L.cbim_wgrad_r32_waves(wv)
+            oc.check_wgrad_r32(dev)
+            oc.check_wgrad_r32(dev, N=2, Cin=64, Cout=64, dhw=(9, 11, 17), split=32)
+        oc.check_wgrad_r32(dev, N=1, Cin=96, Cout=32, dhw=(8, 8, 24), xsplit=32)
+    finally:
+        L.cbim_wgrad_r32_waves(8)
