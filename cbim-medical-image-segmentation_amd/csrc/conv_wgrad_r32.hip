@@ -51,6 +51,7 @@ struct WR32Params {
   int N, Di, Hi, Wi, Do, Ho, Wo;
   int tiles_d, tiles_h, tiles_w;
   int ci_blocks, Cout_pad, Cin_pad;
+  int dbg;   // timing ablations for tools/ (env CBIM_WR32_DBG, wrong results); 0 in production
 };
 
 #ifdef CBIM_EMU
@@ -254,12 +255,14 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
     if (more) {
       wr_wait_lgkm0();                                                 // the reads have returned their data
       __syncthreads();
+      if (!(p.dbg & 1)) {
 #pragma unroll
-      for (int u = 0; u < UD; ++u) dma_dy(nxt, u);
+        for (int u = 0; u < UD; ++u) dma_dy(nxt, u);
+      }
     }
     // (B) 9 (kh, kw) steps: the 10 halo-plane fragments stream through a ring of 5 registers; plane p feeds the taps
     //     (kd 0, dy plane p), (kd 1, p-1), (kd 2, p-2).  The next tile's halo is fetched during the first four steps.
-    {
+    if (!(p.dbg & 2)) {
       constexpr int RING = 5, PLN = 10, SEQ = 9 * PLN;
       u32x4 xr[RING];
       auto frag = [&](int e) -> u32x4 {                                // e = (kh*3 + kw) * PLN + plane
@@ -274,19 +277,19 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
         const int kh = s / 3, kw = s % 3;
-        if (more && 2 * s < UH) {
+        if (more && 2 * s < UH && !(p.dbg & 1)) {
           dma_halo(nxt, 2 * s, obuf);
           dma_halo(nxt, 2 * s + 1, obuf);
         }
 #pragma unroll
         for (int pl = 0; pl < PLN; ++pl) {
           const int e = s * PLN + pl;
-          if (e + RING - 1 < SEQ) xr[(e + RING - 1) % RING] = frag(e + RING - 1);
+          if (e + RING - 1 < SEQ && !(p.dbg & 4)) xr[(e + RING - 1) % RING] = frag(e + RING - 1);
           WR_SCHED_FENCE();
 #pragma unroll
           for (int kd = 0; kd < 3; ++kd) {
             const int i = pl - kd;
-            if (i >= 0 && i < 8) {
+            if (i >= 0 && i < 8 && !(p.dbg & 8)) {
               const int tap = (kd * 3 + kh) * 3 + kw;
 #pragma unroll
               for (int c = 0; c < NCH; ++c)
@@ -412,6 +415,7 @@ int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stri
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
   wr32_tiles(d, p.tiles_d, p.tiles_h, p.tiles_w);
   p.ci_blocks = d->Cin / 32; p.Cout_pad = d->Cout; p.Cin_pad = d->Cin;
+  { const char* e = getenv("CBIM_WR32_DBG"); p.dbg = e ? atoi(e) : 0; }
   {
     // 32-bit byte offsets inside one halo box / one dy tile, built from 24-bit multiplies
     const int64_t box_rows = (int64_t)10 * d->Hi * d->Wi, xs = (x2 && x2_stride > x_stride ? x2_stride : x_stride) * 2;

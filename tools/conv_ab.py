@@ -67,4 +67,4 @@ for cin, cout, s in SHAPES:
     L.cbim_wgrad_r32_waves(8)
     wb = min(w8, w4) if k8 == 1 else wR
     print(f"{cin:4d}->{cout:4d} @{s:3d}^3 {gf:7.1f} | {fT:7.1f} {ps:6.1f} {fR:7.1f} {fR+ps:7.1f} | {dT:7.1f} {dA:7.1f} | {wT:7.1f} {wR:7.1f} "
-          f"{w8 if k8 == 1 else float('nan'):7.1f} {w4 if k8 == 1 else float('nan'):7.1f} | {gf/fR*1e-3:9.1f} {gf/dA*1e-3:9.1f} {gf/wb*1e-3:10.1f}", flush=True)
+          f"{w8 if k8 == 1 else float('nan'):7.1f} {w4 if k8 == 1 else float('nan'):7.1f} | {gf/fR*1e3:9.1f} {gf/dA*1e3:9.1f} {gf/wb*1e3:10.1f}", flush=True)
