@@ -31,6 +31,13 @@
 #include "conv_r32.h"
 #include <stdlib.h>
 
+// timing ablations of tools/conv_ablate.py (wrong results): compiled in only with `make EXTRA=-DCBIM_IGEMM_DBG_RT`
+#ifdef CBIM_IGEMM_DBG_RT
+#define I_DBG (p.dbg)
+#else
+#define I_DBG 0
+#endif
+
 namespace cbim {
 
 static constexpr int NT = 512;
@@ -250,7 +257,7 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
 
   // ---- weight stage s -> LDS buffer (s & 1) by LDS-DMA ------------------------------------------------
   auto dma_stage = [&](int q, int kd, int buf) {
-    if (p.dbg & 2) return;
+    if (I_DBG & 2) return;
     const unsigned char* src = (const unsigned char*)p.w +
         ((size_t)nb * p.n_chunks + q) * ((size_t)p.kD * stage_bytes) + (size_t)kd * stage_bytes;
     unsigned char* dst = smem + b_base + (unsigned)buf * stage_bytes;
@@ -319,7 +326,7 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
       const unsigned hd = pk & 255u, hh = (pk >> 8) & 255u, hw = (pk >> 16) & 255u;
       // every thread issues exactly UH loads (discarded items read the safe row): the stage-end wait can then
       // leave exactly these UH loads in flight (wait_vm_halo)
-      const bool ld = !(p.dbg & 1) && (pk >> 24) != 0 && c_ok && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
+      const bool ld = !(I_DBG & 1) && (pk >> 24) != 0 && c_ok && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
                       (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
       const unsigned rel = mad24(mad24(hd, (unsigned)p.Hi, hh), (unsigned)p.Wi, hw);
       const unsigned voff = ld ? mad24(rel, stride_b, c_byte) : safe;
@@ -610,7 +617,7 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
                   for (int j = 0; j < CPC; ++j) { float d = v[j] - sh[j]; s0[j] += d; s1[j] += d * d; }
                 }
                 cnt += 1.f;
-                if (!(p.dbg & 4)) *(u32x4*)(y_tile + mad24(rel, y_sb, cb)) = Elem<T>::pack(v);
+                if (!(I_DBG & 4)) *(u32x4*)(y_tile + mad24(rel, y_sb, cb)) = Elem<T>::pack(v);
               }
             }
           }

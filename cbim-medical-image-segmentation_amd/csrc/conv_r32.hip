@@ -36,6 +36,14 @@
 namespace cbim {
 
 static constexpr int R_RB = 64;                 // bytes per halo row (32 bf16 channels)
+// timing ablations of tools/r32_ablate.py (wrong results): compiled in only with `make EXTRA=-DCBIM_R32_DBG_RT` — as a
+// run-time parameter every test is a scalar branch, and the 90 of them inside the MFMA loop (one per fragment read) cut
+// the loop into basic blocks the scheduler cannot interleave across
+#ifdef CBIM_R32_DBG_RT
+#define R_DBG (p.dbg)
+#else
+#define R_DBG 0
+#endif
 #ifndef R32_LS_SINGLE
 #define R32_LS_SINGLE 0   // measured: 218 vs 183 us on 32->32 @128^3 (the per-tile butterfly costs more than the 10 spilled registers)
 #endif
@@ -271,7 +279,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     unsigned hd, hh, hw, off;
     bool exists;
     item_get(u, sb, hd, hh, hw, exists, off);
-    const bool ld = !(p.dbg & 1) && exists && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
+    const bool ld = !(R_DBG & 1) && exists && (unsigned)(id0 + (int)hd) < (unsigned)p.Di &&
                     (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
     return (ld ? tbase : (const unsigned char*)g_r32_zero) + (ld ? off : 0u);
   };
@@ -496,7 +504,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     //     plane i feeds the MFMAs (n-tile i, kd 0), (i-1, kd 1), (i-2, kd 2).  The halo of the next tile is fetched by
     //     LDS-DMA during the first steps; TR: a piece is transformed in place four steps after its fetch.
     //     Branch-free (the strip's last tile re-fetches itself into the idle buffer).
-    if (!(p.dbg & 2)) {
+    if (!(R_DBG & 2)) {
       constexpr int RING = 5, PLN = TD + 2, SEQ = 9 * HP * PLN;   // fragment reads of a tile, in order
       u32x4 xr[RING];
       auto frag_addr = [&](int e) -> unsigned {                   // e = ((kh*3 + kw) * HP + hp) * PLN + plane
@@ -531,7 +539,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
             const int e = (s * HP + hp) * PLN + i;
             // read RING-1 entries ahead; the fences keep the compiler from sinking the read next to its use (it then
             // waits a full LDS round trip every third MFMA: measured 57 % of the MFMA rate)
-            if (e + RING - 1 < SEQ && !(p.dbg & 128)) xr[(e + RING - 1) % RING] = *(const u32x4*)(smem + frag_addr(e + RING - 1));
+            if (e + RING - 1 < SEQ && !(R_DBG & 128)) xr[(e + RING - 1) % RING] = *(const u32x4*)(smem + frag_addr(e + RING - 1));
             R_SCHED_FENCE();
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd) {
@@ -579,7 +587,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     if (last_cc) {      // (a branch, not a predicate: the units in between must not touch — reload — any of this)
 #pragma unroll
       for (int pr = 0; pr < NPAIR; ++pr) {
-        const bool in = pair_in(pr) && c_ok && !(p.dbg & (4 | 8));
+        const bool in = pair_in(pr) && c_ok && !(R_DBG & (4 | 8));
         const unsigned rel = pair_rel(pr);
         if (in) {
           if (MX) rq[pr] = *(const u32x4*)(mx_tile + (r_mul24(rel, mx_sb) + cb));
@@ -597,7 +605,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     __syncthreads();
     // (C) epilogue of this tile — no barrier inside (except at an image change); its stores drain under the next
     //     tile's MFMAs
-    if (last_cc && !(p.dbg & 4)) {
+    if (last_cc && !(R_DBG & 4)) {
       if (want_part && n != run_n) { flush_stats(run_n); run_n = n; }
       // statistics of this tile: running per-lane sums (single chunk) or tile-local sums reduced below (MC)
       float l0[8], l1[8], lsh[MX ? 1 : 8];
@@ -656,7 +664,7 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
             v[2 * j] += __uint_as_float(rw[j] << 16);
             v[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u);
           }
-          if (want_part && !(p.dbg & 32)) {
+          if (want_part && !(R_DBG & 32)) {
             if (!SHSET) {            // common shift of the 32 lanes that hold this chunk: any finite value near
               SHSET = true;             // the data works (shifted moments); taken from the group's first lane
 #pragma unroll
@@ -673,15 +681,15 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
             }
           }
         }
-        if (in && c_ok && !(p.dbg & 16)) *(u32x4*)(y_tile + (r_mul24(rel, y_sb) + cb)) = Elem<bf16_tag>::pack(v);
+        if (in && c_ok && !(R_DBG & 16)) *(u32x4*)(y_tile + (r_mul24(rel, y_sb) + cb)) = Elem<bf16_tag>::pack(v);
         CNT += live;
       }
-      if (LS && want_part && !(p.dbg & 32)) tile_stats(l0, l1, lsh, lcnt);
+      if (LS && want_part && !(R_DBG & 32)) tile_stats(l0, l1, lsh, lcnt);
     }
     cur = nxt;
     advance(nxt);
   }
-  if (want_part && !(p.dbg & 64)) flush_stats(run_n);
+  if (want_part && !(R_DBG & 64)) flush_stats(run_n);
 }
 
 }  // namespace cbim

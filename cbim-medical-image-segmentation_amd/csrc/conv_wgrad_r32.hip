@@ -54,6 +54,13 @@ struct WR32Params {
   int dbg;   // timing ablations for tools/ (env CBIM_WR32_DBG, wrong results); 0 in production
 };
 
+// timing ablations of tools/wr32_ablate.py (wrong results): compiled in only with `make EXTRA=-DCBIM_WR32_DBG_RT` (as run-time
+// tests they are ~300 scalar branches per tile that cut the MFMA loop into basic blocks: +12 % kernel time, measured)
+#ifdef CBIM_WR32_DBG_RT
+#define WR_DBG (p.dbg)
+#else
+#define WR_DBG 0
+#endif
 #ifdef CBIM_EMU
 #define WR_SCHED_FENCE() ((void)0)
 #define WR_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
@@ -255,14 +262,14 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
     if (more) {
       wr_wait_lgkm0();                                                 // the reads have returned their data
       __syncthreads();
-      if (!(p.dbg & 1)) {
+      if (!(WR_DBG & 1)) {
 #pragma unroll
         for (int u = 0; u < UD; ++u) dma_dy(nxt, u);
       }
     }
     // (B) 9 (kh, kw) steps: the 10 halo-plane fragments stream through a ring of 5 registers; plane p feeds the taps
     //     (kd 0, dy plane p), (kd 1, p-1), (kd 2, p-2).  The next tile's halo is fetched during the first four steps.
-    if (!(p.dbg & 2)) {
+    if (!(WR_DBG & 2)) {
       constexpr int RING = 5, PLN = 10, SEQ = 9 * PLN;
       u32x4 xr[RING];
       auto frag = [&](int e) -> u32x4 {                                // e = (kh*3 + kw) * PLN + plane
@@ -277,19 +284,19 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
         const int kh = s / 3, kw = s % 3;
-        if (more && 2 * s < UH && !(p.dbg & 1)) {
+        if (more && 2 * s < UH && !(WR_DBG & 1)) {
           dma_halo(nxt, 2 * s, obuf);
           dma_halo(nxt, 2 * s + 1, obuf);
         }
 #pragma unroll
         for (int pl = 0; pl < PLN; ++pl) {
           const int e = s * PLN + pl;
-          if (e + RING - 1 < SEQ && !(p.dbg & 4)) xr[(e + RING - 1) % RING] = frag(e + RING - 1);
+          if (e + RING - 1 < SEQ && !(WR_DBG & 4)) xr[(e + RING - 1) % RING] = frag(e + RING - 1);
           WR_SCHED_FENCE();
 #pragma unroll
           for (int kd = 0; kd < 3; ++kd) {
             const int i = pl - kd;
-            if (i >= 0 && i < 8 && !(p.dbg & 8)) {
+            if (i >= 0 && i < 8 && !(WR_DBG & 8)) {
               const int tap = (kd * 3 + kh) * 3 + kw;
 #pragma unroll
               for (int c = 0; c < NCH; ++c)
