@@ -490,12 +490,7 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
     if (int rc = cbim_wgrad_r32_launch(d, x, x_stride, x2, x2_stride, cin_split, dy, dy_stride, dy2, dy2_stride, cout_split,
                                        (float*)workspace, stream))
       return rc;
-    const int64_t total = (int64_t)27 * d->Cout * d->Cin;
-    int64_t blocks = (total + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                cbim_wgrad_r32_strips(d), 27, d->Cout, d->Cin, d->Cout, d->Cin, total);
-    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+    return cbim_wgrad_r32_reduce(d, (const float*)workspace, dw, stream);
   }
   CBIM_CHECK(!x2, CBIM_EUNSUPPORTED, "wgrad: a second input tensor is only taken by the bf16 3x3x3 kernel on raw (un-normalised) "
              "inputs with channel counts in multiples of 32");

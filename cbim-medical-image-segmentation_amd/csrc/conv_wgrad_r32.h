@@ -15,3 +15,5 @@ size_t cbim_wgrad_r32_workspace(const cbim_conv_desc* d);
 int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
                           int cin_split, const void* dy, int64_t dy_stride, const void* dy2, int64_t dy2_stride,
                           int cout_split, float* workspace, void* stream);
+// fixed-order sum of the strips' slabs into dw[co][ci][tap] (fp32, natural nn.Conv3d layout)
+int cbim_wgrad_r32_reduce(const cbim_conv_desc* d, const float* workspace, float* dw, void* stream);

@@ -344,6 +344,44 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
   }
 }
 
+// Fixed-order sum of the strips' slabs into the natural nn.Conv3d gradient dw[co][ci][tap].  512 threads = LW lanes x SP
+// slab phases: lane l owns 4 consecutive (tap, co, ci) values (one 16-byte load per slab), phase ph adds slabs ph, ph + SP,
+// ... in two alternating chains; the SP phase sums meet in LDS and are added in index order.  (k_wgrad_reduce walks all
+// slabs of 64 outputs with 4 phases: 19 us for the 256 slabs of a 32x32 layer; this form keeps 8-32 loads per thread in
+// flight over 400+ workgroups.)
+template <int SP>
+__global__ void __launch_bounds__(512) k_wgrad_r32_reduce(const float* __restrict__ ws, float* __restrict__ dw, int n_slabs,
+                                                          int Cout, int Cin, int64_t total) {
+  constexpr int LW = 512 / SP;
+  __shared__ f32x4 red[512];
+  const int l = threadIdx.x % LW, ph = threadIdx.x / LW;
+  const int64_t i = ((int64_t)blockIdx.x * LW + l) * 4;       // first of this lane's 4 values: ((tap * Cout + co) * Cin + ci)
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  if (i < total) {
+    const float* src = ws + i;
+    int sl = ph;
+    for (; sl + SP < n_slabs; sl += 2 * SP) {
+      const f32x4 v0 = *(const f32x4*)(src + (size_t)sl * total);
+      const f32x4 v1 = *(const f32x4*)(src + (size_t)(sl + SP) * total);
+      a0 += v0;
+      a1 += v1;
+    }
+    if (sl < n_slabs) a0 += *(const f32x4*)(src + (size_t)sl * total);
+  }
+  red[threadIdx.x] = a0 + a1;
+  __syncthreads();
+  if (ph == 0 && i < total) {
+    f32x4 r = red[l];
+#pragma unroll
+    for (int q = 1; q < SP; ++q) r += red[q * LW + l];
+    const int ci = (int)(i % Cin);
+    const int64_t t2 = i / Cin;
+    const int co = (int)(t2 % Cout), tap = (int)(t2 / Cout);
+    float* o = dw + ((size_t)co * Cin + ci) * 27 + tap;
+    o[0] = r.x; o[27] = r.y; o[54] = r.z; o[81] = r.w;
+  }
+}
+
 }  // namespace cbim
 
 using namespace cbim;
@@ -445,6 +483,28 @@ int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stri
   else CBIM_LAUNCH(k_wgrad_r32<8>, grid, dim3(512), (size_t)WR_SMEM, (hipStream_t)stream, p);
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "wgrad r32 launch: %s", hipGetErrorString(e));
+  return CBIM_OK;
+}
+
+int cbim_wgrad_r32_reduce(const cbim_conv_desc* d, const float* workspace, float* dw, void* stream) {
+  const int G = cbim_wgrad_r32_strips(d);
+  const int64_t total = (int64_t)27 * d->Cout * d->Cin;      // a multiple of 4 (Cin is a multiple of 32)
+  hipStream_t st = (hipStream_t)stream;
+#define WR_RED(SPV)                                                                                              \
+  do {                                                                                                           \
+    const int64_t per = (int64_t)(512 / SPV) * 4;                                                                \
+    CBIM_LAUNCH((k_wgrad_r32_reduce<SPV>), dim3((unsigned)((total + per - 1) / per)), dim3(512), 0, st, workspace, dw, G, \
+                d->Cout, d->Cin, total);                                                                         \
+  } while (0)
+  if (G >= 32) WR_RED(32);
+  else if (G >= 16) WR_RED(16);
+  else if (G >= 8) WR_RED(8);
+  else if (G >= 4) WR_RED(4);
+  else if (G >= 2) WR_RED(2);
+  else WR_RED(1);
+#undef WR_RED
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "wgrad r32 reduce launch: %s", hipGetErrorString(e));
   return CBIM_OK;
 }
 

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd_stats(const void* __restrict__
         }
         o = Elem<T>::pack(acc);
       }
-      st_chunk<T>(out, (nrow + v) * Ct + c0, o);
+      if (out) st_chunk<T>(out, (nrow + v) * Ct + c0, o);   // out == nullptr: statistics of the virtual tensor only
       float f[CPC];
       Elem<T>::unpack(o, f);   // statistics of the STORED (rounded) values, like a pass over the tensor
       if (cnt == 0.f) {
@@ -245,6 +245,131 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd_stats(const void* __restrict__
     }
     const size_t o = (((size_t)n * P + part) * Ct + c2 * CPC + j) * 3;
     partials[o] = acc.n; partials[o + 1] = acc.mean; partials[o + 2] = acc.m2;
+  }
+}
+
+
+// trilinear(align_corners) value of one channel chunk of `low` at fine voxel (n, d, h, w), rounded to the storage type
+// exactly as k_upcat_fwd writes it (the fused kernels below never store the up-sampled tensor, but must see the values
+// a stored copy would hold)
+template <typename T>
+__device__ __forceinline__ void up_chunk(const void* __restrict__ low, int n, int d, int h, int w, float sd, float sh,
+                                         float sw, int Dl, int Hl, int Wl, int Cl, int cl, float* f) {
+  constexpr int CPC = Elem<T>::CPC;
+  const Lin ld = lin_src(d, sd, Dl), lh = lin_src(h, sh, Hl), lw = lin_src(w, sw, Wl);
+  float acc[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int dd = a ? ld.i1 : ld.i0;
+    const float wa = a ? ld.l1 : ld.l0;
+    float pa[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) pa[j] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int hh = b ? lh.i1 : lh.i0;
+      const float wb = b ? lh.l1 : lh.l0;
+      const size_t rbase = (((size_t)n * Dl + dd) * Hl + hh) * Wl;
+      float f0[CPC], f1[CPC];
+      Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl), f0);
+      Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl), f1);
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) pa[j] += wb * (lw.l0 * f0[j] + lw.l1 * f1[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) acc[j] += wa * pa[j];
+  }
+  Elem<T>::unpack(Elem<T>::pack(acc), f);
+}
+
+// a = act(IN([skip | up(low)])) in ONE pass: the decoder level's first block reads the activated concatenation, the raw
+// concatenation is never written (round 2 wrote it, 403 MB at the 128^3 level, and a second pass normalised it).
+// grid = (parts, N); thread = (fixed channel chunk, voxel lane): its 2 x CPC statistics stay in registers.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_upcat_act_fwd(const void* __restrict__ low, const void* __restrict__ skip,
+                                                      const float* __restrict__ stats, void* __restrict__ out, int Dl,
+                                                      int Hl, int Wl, int Cl, int D, int H, int W, int Cs, int skip_first,
+                                                      int P, int act) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int Ct = Cs + Cl;
+  const int cch = Ct / CPC, vlc = NT / cch;
+  const int t = threadIdx.x, cc = t % cch, vl = t / cch;
+  if (vl >= vlc) return;
+  const int part = blockIdx.x, n = blockIdx.y;
+  const int S = D * H * W, per = (S + P - 1) / P;
+  const int v0 = part * per, v1 = v0 + per < S ? v0 + per : S;
+  const float sd = lin_scale(Dl, D), sh = lin_scale(Hl, H), sw = lin_scale(Wl, W);
+  const int skip_lo = skip_first ? 0 : Cl, low_lo = skip_first ? Cs : 0;
+  const int c0 = cc * CPC;
+  const bool is_skip = c0 >= skip_lo && c0 < skip_lo + Cs;
+  float mean[CPC], rstd[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) {
+    mean[j] = stats[((size_t)n * Ct + c0 + j) * 2];
+    rstd[j] = stats[((size_t)n * Ct + c0 + j) * 2 + 1];
+  }
+  const size_t nrow = (size_t)n * S;
+  for (int v = v0 + vl; v < v1; v += vlc) {
+    float f[CPC];
+    if (is_skip) Elem<T>::unpack(ld_chunk<T>(skip, (nrow + v) * Cs + (c0 - skip_lo)), f);
+    else {
+      const int w = v % W, q = v / W, h = q % H, d = q / H;
+      up_chunk<T>(low, n, d, h, w, sd, sh, sw, Dl, Hl, Wl, Cl, c0 - low_lo, f);
+    }
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], act);
+    st_chunk<T>(out, (nrow + v) * Ct + c0, Elem<T>::pack(f));
+  }
+}
+
+// InstanceNorm backward of the virtual concatenation, split on the way out: with xh = (x - mean) * rstd of
+// x = [skip | up(low)] (re-formed here) dx = rstd * (g - m1 - xh * m2); the skip channels go to dskip, the others to
+// dup (fine resolution; k_upcat_bwd_low then gathers it into dlow).  Replaces k_norm_bwd_apply over the stored
+// concatenation + k_slice_copy, and lets the gather read dense Cl-channel rows.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_upcat_norm_bwd(const void* __restrict__ g, const void* __restrict__ low,
+                                                       const void* __restrict__ skip, const float* __restrict__ stats,
+                                                       const float* __restrict__ sums, void* __restrict__ dskip,
+                                                       void* __restrict__ dup, int Dl, int Hl, int Wl, int Cl, int D, int H,
+                                                       int W, int Cs, int skip_first, int P) {
+  constexpr int CPC = Elem<T>::CPC;
+  const int Ct = Cs + Cl;
+  const int cch = Ct / CPC, vlc = NT / cch;
+  const int t = threadIdx.x, cc = t % cch, vl = t / cch;
+  if (vl >= vlc) return;
+  const int part = blockIdx.x, n = blockIdx.y;
+  const int S = D * H * W, per = (S + P - 1) / P;
+  const int v0 = part * per, v1 = v0 + per < S ? v0 + per : S;
+  const float sd = lin_scale(Dl, D), sh = lin_scale(Hl, H), sw = lin_scale(Wl, W);
+  const int skip_lo = skip_first ? 0 : Cl, low_lo = skip_first ? Cs : 0;
+  const int c0 = cc * CPC;
+  const bool is_skip = c0 >= skip_lo && c0 < skip_lo + Cs;
+  float mean[CPC], rstd[CPC], m1[CPC], m2[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) {
+    mean[j] = stats[((size_t)n * Ct + c0 + j) * 2];
+    rstd[j] = stats[((size_t)n * Ct + c0 + j) * 2 + 1];
+    m1[j] = sums[((size_t)n * Ct + c0 + j) * 2];
+    m2[j] = sums[((size_t)n * Ct + c0 + j) * 2 + 1];
+  }
+  const size_t nrow = (size_t)n * S;
+  for (int v = v0 + vl; v < v1; v += vlc) {
+    float f[CPC], gg[CPC];
+    Elem<T>::unpack(ld_chunk<T>(g, (nrow + v) * Ct + c0), gg);
+    if (is_skip) Elem<T>::unpack(ld_chunk<T>(skip, (nrow + v) * Cs + (c0 - skip_lo)), f);
+    else {
+      const int w = v % W, q = v / W, h = q % H, d = q / H;
+      up_chunk<T>(low, n, d, h, w, sd, sh, sw, Dl, Hl, Wl, Cl, c0 - low_lo, f);
+    }
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      const float xh = (f[j] - mean[j]) * rstd[j];
+      gg[j] = rstd[j] * (gg[j] - m1[j] - xh * m2[j]);
+    }
+    if (is_skip) st_chunk<T>(dskip, (nrow + v) * Cs + (c0 - skip_lo), Elem<T>::pack(gg));
+    else st_chunk<T>(dup, (nrow + v) * Cl + (c0 - low_lo), Elem<T>::pack(gg));
   }
 }
 
@@ -488,6 +613,54 @@ extern "C" int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dsk
     int64_t t2 = (int64_t)N * D * H * W * (Cs / cpc);
     DISPATCH_T(dtype, k_slice_copy, dim3(grid_for(t2)), st, dout, (int64_t)Ct, skip_lo, dskip, Cs, t2);
   }
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+/* statistics (eps) of the virtual up-sampled tensor up(low) [N, D, H, W, Cl] — nothing is written but the records */
+extern "C" int cbim_up_stats(int dtype, const void* low, int N, int Dl, int Hl, int Wl, int Cl, int D, int H, int W, float eps,
+                             float* partials, int P, float* stats, void* stream) {
+  if (int e = check_c(dtype, Cl, "up_stats low")) return e;
+  const int cpc = dtype == CBIM_BF16 ? 8 : 4;
+  const int64_t S = (int64_t)D * H * W;
+  CBIM_CHECK(partials && stats && P == cbim_stats_parts(S, Cl), CBIM_EINVAL, "up_stats: partials must have cbim_stats_parts(S, Cl) records");
+  CBIM_CHECK(Cl / cpc <= NT && S < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "up_stats: %d channels / %lld voxels unsupported", Cl, (long long)S);
+  dim3 grid((unsigned)P, (unsigned)N);
+  DISPATCH_T(dtype, k_upcat_fwd_stats, grid, (hipStream_t)stream, low, (const void*)nullptr, (void*)nullptr, Dl, Hl, Wl, Cl, D, H, W, 0, 1, P,
+             partials);
+  if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+  return cbim_stats_finalize(partials, N, P, Cl, (double)S, eps, 0, stats, stream);
+}
+
+extern "C" int cbim_upcat_act_fwd(int dtype, const void* low, const void* skip, const float* stats, void* out, int N, int Dl,
+                                  int Hl, int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, int act, void* stream) {
+  if (int e = check_c(dtype, Cl, "upcat low")) return e;
+  if (int e = check_c(dtype, Cs, "upcat skip")) return e;
+  const int cpc = dtype == CBIM_BF16 ? 8 : 4, Ct = Cs + Cl;
+  const int64_t S = (int64_t)D * H * W;
+  CBIM_CHECK(low && skip && stats && out, CBIM_EINVAL, "null argument");
+  CBIM_CHECK(Ct / cpc <= NT && S < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "upcat_act_fwd: %d channels / %lld voxels unsupported", Ct, (long long)S);
+  const int P = cbim_stats_parts(S, Ct);
+  dim3 grid((unsigned)P, (unsigned)N);
+  DISPATCH_T(dtype, k_upcat_act_fwd, grid, (hipStream_t)stream, low, skip, stats, out, Dl, Hl, Wl, Cl, D, H, W, Cs, skip_first, P, act);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_upcat_norm_bwd(int dtype, const void* g, const void* low, const void* skip, const float* stats,
+                                   const float* sums, void* dskip, void* dlow, void* dup_scratch, int N, int Dl, int Hl, int Wl,
+                                   int Cl, int D, int H, int W, int Cs, int skip_first, void* stream) {
+  if (int e = check_c(dtype, Cl, "upcat low")) return e;
+  if (int e = check_c(dtype, Cs, "upcat skip")) return e;
+  const int cpc = dtype == CBIM_BF16 ? 8 : 4, Ct = Cs + Cl;
+  const int64_t S = (int64_t)D * H * W;
+  CBIM_CHECK(g && low && skip && stats && sums && dskip && dlow && dup_scratch, CBIM_EINVAL, "null argument");
+  CBIM_CHECK(Ct / cpc <= NT && S < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "upcat_norm_bwd: %d channels / %lld voxels unsupported", Ct, (long long)S);
+  const int P = cbim_stats_parts(S, Ct);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)P, (unsigned)N);
+  DISPATCH_T(dtype, k_upcat_norm_bwd, grid, st, g, low, skip, stats, sums, dskip, dup_scratch, Dl, Hl, Wl, Cl, D, H, W, Cs, skip_first, P);
+  if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+  const int64_t total = (int64_t)N * Dl * Hl * Wl * (Cl / cpc);
+  DISPATCH_T(dtype, k_upcat_bwd_low, dim3(grid_for(total)), st, (const void*)dup_scratch, dlow, Dl, Hl, Wl, Cl, D, H, W, Cl, 0, total);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

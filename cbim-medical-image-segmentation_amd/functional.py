@@ -131,6 +131,15 @@ def set_materialize(on: bool):
     _MATERIALIZE = bool(on)
 
 
+def fused_up_block(block) -> bool:
+    """True when the decoder level's first block can take the fused up-sample + concat + activation path
+    (UpBlockFirstFn): a ReLU BasicBlock with a shortcut conv, materialisation on."""
+    from .model.dim3.conv_layers import BasicBlock, ConvNormAct
+    return (_MATERIALIZE and _FUSED_UP and isinstance(block, BasicBlock) and isinstance(block.shortcut, ConvNormAct)
+            and block.conv1.act_code == ACT["relu"])
+
+
+_FUSED_UP = os.environ.get("CBIM_FUSED_UP", "1") not in ("", "0")
 _IDENT_STATS = {}
 
 
@@ -144,6 +153,74 @@ def _identity_stats(n: int, c: int, device) -> torch.Tensor:
         t[..., 1] = 1.0
         _IDENT_STATS[key] = t
     return t
+
+
+def _bb_fwd(ctx, xshape, xin, sin, ident, w1, w2, wsc, act, want_out_stats, mat, train):
+    """conv1 (+ shortcut conv as one Cout-concatenated GEMM where the channel counts allow) and conv2 with the residual add
+    of a pre-activation BasicBlock.  xin / sin: the block input as the convolutions read it (activated tensor + None when
+    materialised, raw tensor + statistics otherwise); ident: the identity-shortcut tensor (None with a shortcut conv)."""
+    cout = int(w1.shape[0])
+    fused = wsc is not None and _fusable(xshape, cout)
+    wdsc = None
+    if fused:
+        gc = _geom_c(xshape, 2 * cout, w1, act)
+        wp, wd1 = ops.packed_weights((w1, wsc), gc, train)
+        ycat, scat = ops.conv_fwd(xin, wp, gc, in_stats=sin, want_stats=True)
+        y1, res = ycat[..., :cout], ycat[..., cout:]
+        s1 = scat[:, :cout].contiguous()
+        g1 = gsc = None
+    else:
+        gc = None
+        g1 = _geom(xshape, w1, act)
+        wp, wd1 = ops.packed_weights((w1,), g1, train)
+        y1, s1 = ops.conv_fwd(xin, wp, g1, in_stats=sin, want_stats=True)
+        if wsc is not None:
+            gsc = _geom(xshape, wsc, act)
+            wpsc, wdsc = ops.packed_weights((wsc,), gsc, train)
+            res, _ = ops.conv_fwd(xin, wpsc, gsc, in_stats=sin)
+        else:
+            gsc = None
+            res = ident
+    g2 = _geom(y1, w2, act)
+    wp2, wd2 = ops.packed_weights((w2,), g2, train)
+    yin, s1in = (ops.norm_act_fwd(y1, s1, act), None) if mat else (y1, s1)
+    out, so = ops.conv_fwd(yin, wp2, g2, in_stats=s1in, res=res, want_stats=want_out_stats)
+    ctx.packed = (wd1, wd2, wdsc)
+    ctx.geoms = (g1, g2, gsc, gc)
+    ctx.act, ctx.mat = act, mat
+    if so is None:
+        so = torch.empty(0, device=xin.device)
+    ctx.mark_non_differentiable(so)
+    ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output
+    return out, so, y1, s1, yin
+
+
+def _bb_bwd(ctx, dout, cx, cxs, mxs, y1, s1, cy, cys, mys, w1):
+    """backward of _bb_fwd down to the masked gradient of the block input: (gx, sums1, dw1, dw2, dwsc).
+    cx / cy: the conv inputs as the forward saw them (+ statistics or None); mxs / mys: statistics for the dgrad mask."""
+    g1, g2, gsc, gc = ctx.geoms
+    wd1, wd2, wdsc = ctx.packed
+    act = ctx.act
+    dw2 = ops.conv_wgrad(cy, cys, dout, g2)
+    gy1, sums2 = ops.conv_dgrad(dout, wd2, g2, mask_x=cy, mask_stats=mys)
+    dy1 = ops.norm_bwd_apply(gy1, y1, s1, sums2, act, masked=False)
+    if gc is not None:
+        # conv1 + shortcut as one GEMM: dy = [dy1 | dout]
+        cout = int(w1.shape[0])
+        dwcat = ops.conv_wgrad(cx, cxs, dy1, gc, dy2=dout)
+        dw1, dwsc = dwcat[:cout], dwcat[cout:]
+        gx, sums1 = ops.conv_dgrad(dy1, wd1, gc, mask_x=cx, mask_stats=mxs, dy2=dout)
+        return gx, sums1, dw1, dw2, dwsc
+    # conv1 (+ shortcut conv share act(IN(x)))
+    dw1 = ops.conv_wgrad(cx, cxs, dy1, g1)
+    if gsc is not None:
+        dwsc = ops.conv_wgrad(cx, cxs, dout, gsc)
+        gx_u, _ = ops.conv_dgrad(dy1, wd1, g1)
+        gx, sums1 = ops.conv_dgrad(dout, wdsc, gsc, mask_x=cx, mask_stats=mxs, accumulate=gx_u)
+    else:
+        dwsc = None
+        gx, sums1 = ops.conv_dgrad(dy1, wd1, g1, mask_x=cx, mask_stats=mxs)
+    return gx, sums1, dw1, dw2, dwsc
 
 
 class BasicBlockFn(_GradAwareFunction):
@@ -163,54 +240,18 @@ class BasicBlockFn(_GradAwareFunction):
 
     @staticmethod
     def forward(ctx, x, x_stats, w1, w2, wsc, act, want_out_stats):
-        cout = int(w1.shape[0])
-        fused = wsc is not None and _fusable(x, cout)
         train = _training(ctx)
         mat = _MATERIALIZE and act == ACT["relu"]
-        # weights live in MFMA fragment order in a cache that one launch per optimizer step refreshes
-        # (ops.PackedWeights); the dgrad layout comes out of the same launch
-        wdsc = None
         xin, sin = (ops.norm_act_fwd(x, x_stats, act), None) if mat else (x, x_stats)
-        if fused:
-            gc = _geom_c(x, 2 * cout, w1, act)
-            wp, wd1 = ops.packed_weights((w1, wsc), gc, train)
-            ycat, scat = ops.conv_fwd(xin, wp, gc, in_stats=sin, want_stats=True)
-            y1, res = ycat[..., :cout], ycat[..., cout:]
-            s1 = scat[:, :cout].contiguous()
-            g1 = gsc = None
-        else:
-            gc = None
-            g1 = _geom(x, w1, act)
-            wp, wd1 = ops.packed_weights((w1,), g1, train)
-            y1, s1 = ops.conv_fwd(xin, wp, g1, in_stats=sin, want_stats=True)
-            if wsc is not None:
-                gsc = _geom(x, wsc, act)
-                wpsc, wdsc = ops.packed_weights((wsc,), gsc, train)
-                res, _ = ops.conv_fwd(xin, wpsc, gsc, in_stats=sin)
-            else:
-                gsc = None
-                res = x
-        g2 = _geom(y1, w2, act)
-        wp2, wd2 = ops.packed_weights((w2,), g2, train)
-        yin, s1in = (ops.norm_act_fwd(y1, s1, act), None) if mat else (y1, s1)
-        out, so = ops.conv_fwd(yin, wp2, g2, in_stats=s1in, res=res, want_stats=want_out_stats)
+        out, so, y1, s1, yin = _bb_fwd(ctx, x, xin, sin, x, w1, w2, wsc, act, want_out_stats, mat, train)
         none = torch.empty(0)
         ctx.save_for_backward(x, x_stats, y1, s1, w1, w2, wsc if wsc is not None else none,
                               xin if mat and train else none, yin if mat and train else none)
-        ctx.packed = (wd1, wd2, wdsc)
-        ctx.geoms = (g1, g2, gsc, gc)
-        ctx.act, ctx.mat = act, mat
-        if so is None:
-            so = torch.empty(0, device=x.device)
-        ctx.mark_non_differentiable(so)
-        ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output
         return out, so
 
     @staticmethod
     def backward(ctx, dout, _dso):
         x, x_stats, y1, s1, w1, w2, wsc, ax, ay1 = ctx.saved_tensors
-        g1, g2, gsc, gc = ctx.geoms
-        wd1, wd2, wdsc = ctx.packed
         act = ctx.act
         dout = dout.contiguous()
         if ctx.mat:
@@ -220,30 +261,40 @@ class BasicBlockFn(_GradAwareFunction):
             mys = _identity_stats(int(y1.shape[0]), int(y1.shape[-1]), x.device)
         else:
             cx, cxs, cy, cys, mxs, mys = x, x_stats, y1, s1, x_stats, s1
-        # conv2
-        dw2 = ops.conv_wgrad(cy, cys, dout, g2)
-        gy1, sums2 = ops.conv_dgrad(dout, wd2, g2, mask_x=cy, mask_stats=mys)
-        dy1 = ops.norm_bwd_apply(gy1, y1, s1, sums2, act, masked=False)
-        if gc is not None:
-            # conv1 + shortcut as one GEMM: dy = [dy1 | dout]
-            cout = int(w1.shape[0])
-            dwcat = ops.conv_wgrad(cx, cxs, dy1, gc, dy2=dout)
-            dw1, dwsc = dwcat[:cout], dwcat[cout:]
-            gx, sums1 = ops.conv_dgrad(dy1, wd1, gc, mask_x=cx, mask_stats=mxs, dy2=dout)
-            dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False)
-            return dx, None, dw1, dw2, dwsc, None, None
-        # conv1 (+ shortcut conv share act(IN(x)))
-        dw1 = ops.conv_wgrad(cx, cxs, dy1, g1)
-        if gsc is not None:
-            dwsc = ops.conv_wgrad(cx, cxs, dout, gsc)
-            gx_u, _ = ops.conv_dgrad(dy1, wd1, g1)
-            gx, sums1 = ops.conv_dgrad(dout, wdsc, gsc, mask_x=cx, mask_stats=mxs, accumulate=gx_u)
-            dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False)
-        else:
-            dwsc = None
-            gx, sums1 = ops.conv_dgrad(dy1, wd1, g1, mask_x=cx, mask_stats=mxs)
-            dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False, add=dout)
+        gx, sums1, dw1, dw2, dwsc = _bb_bwd(ctx, dout, cx, cxs, mxs, y1, s1, cy, cys, mys, w1)
+        identity = ctx.geoms[2] is None and ctx.geoms[3] is None
+        dx = ops.norm_bwd_apply(gx, x, x_stats, sums1, act, masked=False, add=dout if identity else None)
         return dx, None, dw1, dw2, dwsc, None, None
+
+
+class UpBlockFirstFn(_GradAwareFunction):
+    """up_block's trilinear up-sampling + concatenation (unet_utils.py:69-71) fused with the decoder level's first
+    BasicBlock (in_ch + out_ch -> out_ch, always with a shortcut conv): the block reads a = relu(IN([skip | up(low)])),
+    which ONE pass writes straight from `low` and `skip`; the raw concatenation is never stored.  Backward: the
+    InstanceNorm backward of the (re-formed) concatenation writes dskip and the fine-resolution gradient of the
+    up-sampled part, which the transposed trilinear gather turns into dlow."""
+
+    @staticmethod
+    def forward(ctx, low, skip, skip_stats, w1, w2, wsc, act, want_out_stats, skip_first):
+        train = _training(ctx)
+        up_st = ops.up_stats(low, skip.shape[1:4])
+        stats_cat = torch.cat([skip_stats, up_st] if skip_first else [up_st, skip_stats], 1)
+        a = ops.upcat_act_fwd(low, skip, stats_cat, act, skip_first)
+        out, so, y1, s1, yin = _bb_fwd(ctx, a, a, None, None, w1, w2, wsc, act, want_out_stats, True, train)
+        none = torch.empty(0)
+        ctx.save_for_backward(low, skip, stats_cat, y1, s1, w1, w2, wsc, a if train else none, yin if train else none)
+        ctx.skip_first = skip_first
+        return out, so
+
+    @staticmethod
+    def backward(ctx, dout, _dso):
+        low, skip, stats_cat, y1, s1, w1, w2, wsc, a, ay1 = ctx.saved_tensors
+        dout = dout.contiguous()
+        mxs = _identity_stats(int(a.shape[0]), int(a.shape[-1]), a.device)
+        mys = _identity_stats(int(y1.shape[0]), int(y1.shape[-1]), a.device)
+        gx, sums1, dw1, dw2, dwsc = _bb_bwd(ctx, dout, a, None, mxs, y1, s1, ay1, None, mys, w1)
+        dlow, dskip = ops.upcat_norm_bwd(gx, low, skip, stats_cat, sums1, ctx.skip_first)
+        return dlow, dskip, None, dw1, dw2, dwsc, None, None, None
 
 
 class SingleConvFn(_GradAwareFunction):

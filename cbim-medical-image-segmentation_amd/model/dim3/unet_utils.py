@@ -70,7 +70,18 @@ class up_block(nn.Module):
         self.conv = nn.Sequential(*mods)
 
     def forward(self, low: Fn.FMap, skip: Fn.FMap) -> Fn.FMap:
-        f = Fn.FMap(*Fn.UpCatFn.apply(low.t, skip.t, True, True))   # concat + its InstanceNorm statistics in one pass
-        for m in self.conv:
+        first = self.conv[0]
+        if Fn.fused_up_block(first):
+            # a = relu(IN([skip | up(low)])) straight from `low` and `skip`: the concatenation is never stored
+            skip = Fn.ensure_stats(skip)
+            want = len(self.conv) > 1
+            out, so = Fn.UpBlockFirstFn.apply(low.t, skip.t, skip.stats, first.conv1.conv.weight, first.conv2.conv.weight,
+                                              first.shortcut.conv.weight, first.conv1.act_code, want, True)
+            f = Fn.FMap(out, so if want else None)
+            rest = list(self.conv)[1:]
+        else:
+            f = Fn.FMap(*Fn.UpCatFn.apply(low.t, skip.t, True, True))   # concat + its InstanceNorm statistics in one pass
+            rest = list(self.conv)
+        for m in rest:
             f = m(f)
         return f

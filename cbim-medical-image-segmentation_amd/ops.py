@@ -193,6 +193,43 @@ def upcat_fwd_stats(low, skip, skip_first: bool = True, eps: float = IN_EPS):
     return out, stats
 
 
+def up_stats(low, out_dhw, eps: float = IN_EPS):
+    """InstanceNorm statistics of trilinear(low -> out_dhw, align_corners=True) without writing it."""
+    _dev_ok(low)
+    N, Dl, Hl, Wl, Cl = map(int, low.shape)
+    D, H, W = (int(i) for i in out_dhw)
+    L = _lib.lib()
+    P = L.cbim_stats_parts(D * H * W, Cl)
+    part = torch.empty((N, P, Cl, 3), dtype=torch.float32, device=low.device)
+    stats = torch.empty((N, Cl, 2), dtype=torch.float32, device=low.device)
+    check(L.cbim_up_stats(_dt(low), _p(low), N, Dl, Hl, Wl, Cl, D, H, W, eps, _p(part), P, _p(stats), _stream(low)), "up_stats")
+    return stats
+
+
+def upcat_act_fwd(low, skip, stats_cat, act: int, skip_first: bool = True):
+    """act(IN([skip | up(low)])) (channel order by skip_first) in one pass; stats_cat float [N, Cs+Cl, 2]."""
+    _dev_ok(low, skip, stats_cat)
+    N, Dl, Hl, Wl, Cl = map(int, low.shape)
+    _, D, H, W, Cs = map(int, skip.shape)
+    out = torch.empty((N, D, H, W, Cs + Cl), dtype=low.dtype, device=low.device)
+    check(_lib.lib().cbim_upcat_act_fwd(_dt(low), _p(low), _p(skip), _p(stats_cat), _p(out), N, Dl, Hl, Wl, Cl, D, H, W, Cs,
+                                        int(skip_first), act, _stream(low)), "upcat_act_fwd")
+    return out
+
+
+def upcat_norm_bwd(g, low, skip, stats_cat, sums, skip_first: bool = True):
+    """InstanceNorm backward over the virtual concatenation -> (dlow, dskip)."""
+    _dev_ok(g, low, skip, stats_cat, sums)
+    N, Dl, Hl, Wl, Cl = map(int, low.shape)
+    _, D, H, W, Cs = map(int, skip.shape)
+    dskip = torch.empty_like(skip)
+    dlow = torch.empty_like(low)
+    dup = torch.empty((N, D, H, W, Cl), dtype=low.dtype, device=low.device)
+    check(_lib.lib().cbim_upcat_norm_bwd(_dt(low), _p(g), _p(low), _p(skip), _p(stats_cat), _p(sums), _p(dskip), _p(dlow), _p(dup),
+                                         N, Dl, Hl, Wl, Cl, D, H, W, Cs, int(skip_first), _stream(low)), "upcat_norm_bwd")
+    return dlow, dskip
+
+
 def upcat_bwd(dout, low_shape, Cs: int, skip_first: bool = True):
     _dev_ok(dout)
     N, Dl, Hl, Wl, Cl = map(int, low_shape)

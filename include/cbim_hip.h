@@ -104,6 +104,20 @@ int cbim_upcat_fwd(int dtype, const void* low, const void* skip, void* out, int 
 int cbim_upcat_fwd_stats(int dtype, const void* low, const void* skip, void* out, int N, int Dl, int Hl, int Wl,
                          int Cl, int D, int H, int W, int Cs, int skip_first, float eps, float* partials, int P,
                          float* stats, void* stream);
+/* The decoder level's first block without the stored concatenation (round 3): statistics of the virtual
+ * up-sampled tensor (cbim_up_stats: partials float [N][P][Cl][3], P = cbim_stats_parts(S, Cl)), then
+ * out = act(IN([skip | up(low)])) in one pass (cbim_upcat_act_fwd; stats float [N][Cs+Cl][2] in the
+ * concatenation's channel order), and in the backward dx = rstd*(g - m1 - xh*m2) of the re-formed
+ * concatenation written as dskip and — through dup_scratch [N][D][H][W][Cl] and the transposed
+ * trilinear gather — dlow (cbim_upcat_norm_bwd).  unet_utils.py:69-71 + conv_layers.py:40-49. */
+int cbim_up_stats(int dtype, const void* low, int N, int Dl, int Hl, int Wl, int Cl, int D, int H, int W,
+                  float eps, float* partials, int P, float* stats, void* stream);
+int cbim_upcat_act_fwd(int dtype, const void* low, const void* skip, const float* stats, void* out, int N,
+                       int Dl, int Hl, int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, int act,
+                       void* stream);
+int cbim_upcat_norm_bwd(int dtype, const void* g, const void* low, const void* skip, const float* stats,
+                        const float* sums, void* dskip, void* dlow, void* dup_scratch, int N, int Dl, int Hl,
+                        int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
 int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dskip, int N, int Dl, int Hl,
                    int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
 

@@ -97,6 +97,40 @@ def check_upcat(dev, dtype, N=1, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_
     assert torch.equal(from_cl(dskip.cpu()), skr.grad)
 
 
+def check_upcat_fused(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_first=True):
+    """The decoder level's first block without the stored concatenation: statistics of the virtual up-sampled tensor,
+    a = relu(IN([skip | up(low)])) in one pass, and the InstanceNorm backward split into (dlow, dskip) — against the
+    materialising kernels (bit for bit where the arithmetic is the same) and torch autograd."""
+    torch.manual_seed(4)
+    lo = torch.randn(N, Cl, *low) * 1.5 + 0.2
+    sk = torch.randn(N, Cs, *hi) * 0.7 - 0.1
+    lol, skl = to_cl(lo, dtype).to(dev), to_cl(sk, dtype).to(dev)
+    cat, st_cat = ops.upcat_fwd_stats(lol, skl, skip_first)                # round-2 path: stored concatenation
+    st_up = ops.up_stats(lol, hi)
+    up_slice = slice(Cs, None) if skip_first else slice(0, Cl)
+    assert relerr(st_up.cpu()[..., 0], st_cat.cpu()[:, up_slice, 0]) < 1e-5
+    assert relerr(st_up.cpu()[..., 1], st_cat.cpu()[:, up_slice, 1]) < 1e-5
+    a = ops.upcat_act_fwd(lol, skl, st_cat, ops.ACT["relu"], skip_first)
+    assert torch.equal(a.cpu(), ops.norm_act_fwd(cat, st_cat, ops.ACT["relu"]).cpu())
+    # backward: g -> IN backward over the concatenation -> (trilinear adjoint, slice)
+    g = torch.randn(N, Cs + Cl, *hi)
+    gl = to_cl(g, dtype).to(dev)
+    sums = ops.norm_bwd_sums(gl, cat, st_cat, 0, masked=False)
+    dlow, dskip = ops.upcat_norm_bwd(gl, lol, skl, st_cat, sums, skip_first)
+    dcat = ops.norm_bwd_apply(gl, cat, st_cat, sums, 0, masked=False)
+    dlow_r, dskip_r = ops.upcat_bwd(dcat, tuple(lol.shape), Cs, skip_first)
+    assert torch.equal(dskip.cpu(), dskip_r.cpu())
+    assert relerr(from_cl(dlow.cpu()), from_cl(dlow_r.cpu())) < tol(dtype, 1e-6, 1e-2)
+    # torch: d/d(low, skip) of sum(g * IN(cat([skip, up(low)])))
+    lor = from_cl(lol.cpu()).requires_grad_(True)
+    skr = from_cl(skl.cpu()).requires_grad_(True)
+    up = F.interpolate(lor, size=hi, mode="trilinear", align_corners=True)
+    ref = F.instance_norm(torch.cat([skr, up] if skip_first else [up, skr], 1), eps=1e-4)
+    ref.backward(from_cl(gl.cpu()).contiguous())   # (a permuted view with N = 1 sends torch's CPU batch-norm backward down its channels-last path)
+    assert relerr(from_cl(dlow.cpu()), lor.grad) < tol(dtype, 2e-4, 3e-2)
+    assert relerr(from_cl(dskip.cpu()), skr.grad) < tol(dtype, 2e-4, 3e-2)
+
+
 def check_conv(dev, dtype, N, Cin, Cout, dhw, k, seed=0, act="relu"):
     """conv(relu(IN(x))) forward (+epilogue statistics, +residual), dgrad (+mask, +IN-backward sums,
     +accumulate) and wgrad of one ConvNormAct (reference conv_layers.py:48-49)."""
