@@ -193,12 +193,24 @@ def upcat_fwd_stats(low, skip, skip_first: bool = True, eps: float = IN_EPS):
     return out, stats
 
 
+UP_TILES = __import__("os").environ.get("CBIM_UP_TILES", "1") not in ("", "0")   # LDS-tiled up-path kernels (up_tile_kernels.hip); off: the gather kernels (A/B, tests)
+_UNSUPPORTED = -2   # CBIM_EUNSUPPORTED
+
+
 def up_stats(low, out_dhw, eps: float = IN_EPS):
     """InstanceNorm statistics of trilinear(low -> out_dhw, align_corners=True) without writing it."""
     _dev_ok(low)
     N, Dl, Hl, Wl, Cl = map(int, low.shape)
     D, H, W = (int(i) for i in out_dhw)
     L = _lib.lib()
+    if UP_TILES:
+        P = L.cbim_up_tile_parts(D, H, W)
+        part = torch.empty((N, P, Cl, 3), dtype=torch.float32, device=low.device)
+        stats = torch.empty((N, Cl, 2), dtype=torch.float32, device=low.device)
+        rc = L.cbim_up_stats_tile(_dt(low), _p(low), N, Dl, Hl, Wl, Cl, D, H, W, eps, _p(part), P, _p(stats), _stream(low))
+        if rc != _UNSUPPORTED:
+            check(rc, "up_stats_tile")
+            return stats
     P = L.cbim_stats_parts(D * H * W, Cl)
     part = torch.empty((N, P, Cl, 3), dtype=torch.float32, device=low.device)
     stats = torch.empty((N, Cl, 2), dtype=torch.float32, device=low.device)
@@ -212,6 +224,12 @@ def upcat_act_fwd(low, skip, stats_cat, act: int, skip_first: bool = True):
     N, Dl, Hl, Wl, Cl = map(int, low.shape)
     _, D, H, W, Cs = map(int, skip.shape)
     out = torch.empty((N, D, H, W, Cs + Cl), dtype=low.dtype, device=low.device)
+    if UP_TILES:
+        rc = _lib.lib().cbim_upcat_act_fwd_tile(_dt(low), _p(low), _p(skip), _p(stats_cat), _p(out), N, Dl, Hl, Wl, Cl, D, H, W, Cs,
+                                                int(skip_first), act, _stream(low))
+        if rc != _UNSUPPORTED:
+            check(rc, "upcat_act_fwd_tile")
+            return out
     check(_lib.lib().cbim_upcat_act_fwd(_dt(low), _p(low), _p(skip), _p(stats_cat), _p(out), N, Dl, Hl, Wl, Cl, D, H, W, Cs,
                                         int(skip_first), act, _stream(low)), "upcat_act_fwd")
     return out
@@ -225,6 +243,12 @@ def upcat_norm_bwd(g, low, skip, stats_cat, sums, skip_first: bool = True):
     dskip = torch.empty_like(skip)
     dlow = torch.empty_like(low)
     dup = torch.empty((N, D, H, W, Cl), dtype=low.dtype, device=low.device)
+    if UP_TILES:
+        rc = _lib.lib().cbim_upcat_norm_bwd_tile(_dt(low), _p(g), _p(low), _p(skip), _p(stats_cat), _p(sums), _p(dskip), _p(dlow),
+                                                 _p(dup), N, Dl, Hl, Wl, Cl, D, H, W, Cs, int(skip_first), _stream(low))
+        if rc != _UNSUPPORTED:
+            check(rc, "upcat_norm_bwd_tile")
+            return dlow, dskip
     check(_lib.lib().cbim_upcat_norm_bwd(_dt(low), _p(g), _p(low), _p(skip), _p(stats_cat), _p(sums), _p(dskip), _p(dlow), _p(dup),
                                          N, Dl, Hl, Wl, Cl, D, H, W, Cs, int(skip_first), _stream(low)), "upcat_norm_bwd")
     return dlow, dskip

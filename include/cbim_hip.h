@@ -118,6 +118,19 @@ int cbim_upcat_act_fwd(int dtype, const void* low, const void* skip, const float
 int cbim_upcat_norm_bwd(int dtype, const void* g, const void* low, const void* skip, const float* stats,
                         const float* sums, void* dskip, void* dlow, void* dup_scratch, int N, int Dl, int Hl,
                         int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
+/* The same three operations on LDS tiles (up_tile_kernels.hip): a workgroup stages the coarse box of a 4x8x8
+ * fine tile once and interpolates from LDS.  CBIM_EUNSUPPORTED when the box does not fit the LDS budget
+ * (the caller then uses the entry points above).  cbim_up_stats_tile's partials have
+ * cbim_up_tile_parts(D, H, W) records per image. */
+int cbim_up_tile_parts(int D, int H, int W);
+int cbim_up_stats_tile(int dtype, const void* low, int N, int Dl, int Hl, int Wl, int Cl, int D, int H, int W,
+                       float eps, float* partials, int P, float* stats, void* stream);
+int cbim_upcat_act_fwd_tile(int dtype, const void* low, const void* skip, const float* stats, void* out, int N,
+                            int Dl, int Hl, int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, int act,
+                            void* stream);
+int cbim_upcat_norm_bwd_tile(int dtype, const void* g, const void* low, const void* skip, const float* stats,
+                             const float* sums, void* dskip, void* dlow, void* dup_scratch, int N, int Dl,
+                             int Hl, int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
 int cbim_upcat_bwd(int dtype, const void* dout, void* dlow, void* dskip, int N, int Dl, int Hl,
                    int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
 

@@ -97,7 +97,7 @@ def check_upcat(dev, dtype, N=1, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_
     assert torch.equal(from_cl(dskip.cpu()), skr.grad)
 
 
-def check_upcat_fused(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_first=True):
+def check_upcat_fused(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_first=True, tiles=True):
     """The decoder level's first block without the stored concatenation: statistics of the virtual up-sampled tensor,
     a = relu(IN([skip | up(low)])) in one pass, and the InstanceNorm backward split into (dlow, dskip) — against the
     materialising kernels (bit for bit where the arithmetic is the same) and torch autograd."""
@@ -106,6 +106,20 @@ def check_upcat_fused(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9),
     sk = torch.randn(N, Cs, *hi) * 0.7 - 0.1
     lol, skl = to_cl(lo, dtype).to(dev), to_cl(sk, dtype).to(dev)
     cat, st_cat = ops.upcat_fwd_stats(lol, skl, skip_first)                # round-2 path: stored concatenation
+    if tiles:
+        # the LDS-tiled kernels against the gather kernels: same arithmetic in the same order -> same bits
+        g0 = to_cl(torch.randn(N, Cs + Cl, *hi), dtype).to(dev)
+        sums0 = ops.norm_bwd_sums(g0, cat, st_cat, 0, masked=False)
+        ref, got = [], []
+        for flag, dst in ((False, ref), (True, got)):
+            ops.UP_TILES = flag
+            dst.append(ops.up_stats(lol, hi))
+            dst.append(ops.upcat_act_fwd(lol, skl, st_cat, ops.ACT["relu"], skip_first))
+            dst.extend(ops.upcat_norm_bwd(g0, lol, skl, st_cat, sums0, skip_first))
+        assert relerr(got[0].cpu(), ref[0].cpu()) < 1e-5          # statistics: other partition of the voxels
+        for a_, b_ in zip(got[1:], ref[1:]):
+            assert torch.equal(a_.cpu(), b_.cpu())
+    ops.UP_TILES = tiles
     st_up = ops.up_stats(lol, hi)
     up_slice = slice(Cs, None) if skip_first else slice(0, Cl)
     assert relerr(st_up.cpu()[..., 0], st_cat.cpu()[:, up_slice, 0]) < 1e-5
