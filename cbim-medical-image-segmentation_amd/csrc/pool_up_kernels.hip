@@ -8,6 +8,7 @@
 // unet_utils.py:69-71.  Index/weight arithmetic follows ATen's align_corners rule:
 // scale=(in-1)/(out-1) (0 if out==1), src=scale*dst, i0=(int)src, i1=min(i0+1,in-1), l1=src-i0.
 #include "cbim_common.h"
+#include "up_lerp.h"
 
 namespace cbim {
 
@@ -125,30 +126,17 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd(const void* __restrict__ low, 
     int64_t n = q / D;
     Lin ld = lin_src(d, sd, Dl), lh = lin_src(h, sh, Hl), lw = lin_src(w, sw, Wl);
     int cl = c0 - low_lo;
-    float acc[CPC];
+    u32x4 cn[8];
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      int dd = a ? ld.i1 : ld.i0;
-      float wa = a ? ld.l1 : ld.l0;
-      float pa[CPC];
-#pragma unroll
-      for (int j = 0; j < CPC; ++j) pa[j] = 0.f;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        int hh = b ? lh.i1 : lh.i0;
-        float wb = b ? lh.l1 : lh.l0;
-        size_t rbase = (((size_t)n * Dl + dd) * Hl + hh) * Wl;
-        float f0[CPC], f1[CPC];
-        Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl), f0);
-        Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl), f1);
-#pragma unroll
-        for (int j = 0; j < CPC; ++j) pa[j] += wb * (lw.l0 * f0[j] + lw.l1 * f1[j]);
+        size_t rbase = (((size_t)n * Dl + (a ? ld.i1 : ld.i0)) * Hl + (b ? lh.i1 : lh.i0)) * Wl;
+        cn[(a * 2 + b) * 2] = ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl);
+        cn[(a * 2 + b) * 2 + 1] = ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl);
       }
-#pragma unroll
-      for (int j = 0; j < CPC; ++j) acc[j] += wa * pa[j];
-    }
+    float acc[CPC];
+    trilerp<T>(cn, ld.l0, ld.l1, lh.l0, lh.l1, lw.l0, lw.l1, acc);
     st_chunk<T>(out, (size_t)r * Ct + c0, Elem<T>::pack(acc));
   }
 }
@@ -188,30 +176,17 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd_stats(const void* __restrict__
         const int w = v % W, q = v / W, h = q % H, d = q / H;
         const Lin ld = lin_src(d, sd, Dl), lh = lin_src(h, sh, Hl), lw = lin_src(w, sw, Wl);
         const int cl = c0 - low_lo;
-        float acc[CPC];
+        u32x4 cn[8];
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const int dd = a ? ld.i1 : ld.i0;
-          const float wa = a ? ld.l1 : ld.l0;
-          float pa[CPC];
-#pragma unroll
-          for (int j = 0; j < CPC; ++j) pa[j] = 0.f;
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            const int hh = b ? lh.i1 : lh.i0;
-            const float wb = b ? lh.l1 : lh.l0;
-            const size_t rbase = (((size_t)n * Dl + dd) * Hl + hh) * Wl;
-            float f0[CPC], f1[CPC];
-            Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl), f0);
-            Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl), f1);
-#pragma unroll
-            for (int j = 0; j < CPC; ++j) pa[j] += wb * (lw.l0 * f0[j] + lw.l1 * f1[j]);
+            const size_t rbase = (((size_t)n * Dl + (a ? ld.i1 : ld.i0)) * Hl + (b ? lh.i1 : lh.i0)) * Wl;
+            cn[(a * 2 + b) * 2] = ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl);
+            cn[(a * 2 + b) * 2 + 1] = ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl);
           }
-#pragma unroll
-          for (int j = 0; j < CPC; ++j) acc[j] += wa * pa[j];
-        }
+        float acc[CPC];
+        trilerp<T>(cn, ld.l0, ld.l1, lh.l0, lh.l1, lw.l0, lw.l1, acc);
         o = Elem<T>::pack(acc);
       }
       if (out) st_chunk<T>(out, (nrow + v) * Ct + c0, o);   // out == nullptr: statistics of the virtual tensor only
@@ -257,30 +232,17 @@ __device__ __forceinline__ void up_chunk(const void* __restrict__ low, int n, in
                                          float sw, int Dl, int Hl, int Wl, int Cl, int cl, float* f) {
   constexpr int CPC = Elem<T>::CPC;
   const Lin ld = lin_src(d, sd, Dl), lh = lin_src(h, sh, Hl), lw = lin_src(w, sw, Wl);
-  float acc[CPC];
+  u32x4 cn[8];
 #pragma unroll
-  for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int dd = a ? ld.i1 : ld.i0;
-    const float wa = a ? ld.l1 : ld.l0;
-    float pa[CPC];
-#pragma unroll
-    for (int j = 0; j < CPC; ++j) pa[j] = 0.f;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int hh = b ? lh.i1 : lh.i0;
-      const float wb = b ? lh.l1 : lh.l0;
-      const size_t rbase = (((size_t)n * Dl + dd) * Hl + hh) * Wl;
-      float f0[CPC], f1[CPC];
-      Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl), f0);
-      Elem<T>::unpack(ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl), f1);
-#pragma unroll
-      for (int j = 0; j < CPC; ++j) pa[j] += wb * (lw.l0 * f0[j] + lw.l1 * f1[j]);
+      const size_t rbase = (((size_t)n * Dl + (a ? ld.i1 : ld.i0)) * Hl + (b ? lh.i1 : lh.i0)) * Wl;
+      cn[(a * 2 + b) * 2] = ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl);
+      cn[(a * 2 + b) * 2 + 1] = ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl);
     }
-#pragma unroll
-    for (int j = 0; j < CPC; ++j) acc[j] += wa * pa[j];
-  }
+  float acc[CPC];
+  trilerp<T>(cn, ld.l0, ld.l1, lh.l0, lh.l1, lw.l0, lw.l1, acc);
   Elem<T>::unpack(Elem<T>::pack(acc), f);
 }
 

@@ -20,6 +20,7 @@
 // Shapes whose boxes do not fit the LDS budget stay on the gather kernels (the launchers return CBIM_EUNSUPPORTED and the
 // host side falls back — both paths are tested against each other bit for bit).
 #include "cbim_common.h"
+#include "up_lerp.h"
 
 namespace cbim {
 
@@ -104,30 +105,17 @@ __device__ __forceinline__ void up_from_box(const UpTileParams& p, const unsigne
   const unsigned rowb = (unsigned)p.Cl * ES;
   const AxTab* tab = (const AxTab*)(smem + (unsigned)(p.bd * p.bh * p.bw) * rowb);
   const AxTab ad = tab[fd], ah = tab[FD + fh], aw = tab[FD + FH + fw];
-  float acc[CPC];
+  u32x4 cn[8];
 #pragma unroll
-  for (int j = 0; j < CPC; ++j) acc[j] = 0.f;
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int dd = a ? ad.r1 : ad.r0;
-    const float wa = a ? ad.l1 : ad.l0;
-    float pa[CPC];
-#pragma unroll
-    for (int j = 0; j < CPC; ++j) pa[j] = 0.f;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int hh = b ? ah.r1 : ah.r0;
-      const float wb = b ? ah.l1 : ah.l0;
-      const unsigned rbase = (unsigned)((dd * p.bh + hh) * p.bw);
-      float f0[CPC], f1[CPC];
-      Elem<T>::unpack(*(const u32x4*)(smem + (rbase + (unsigned)aw.r0) * rowb + (unsigned)cl * ES), f0);
-      Elem<T>::unpack(*(const u32x4*)(smem + (rbase + (unsigned)aw.r1) * rowb + (unsigned)cl * ES), f1);
-#pragma unroll
-      for (int j = 0; j < CPC; ++j) pa[j] += wb * (aw.l0 * f0[j] + aw.l1 * f1[j]);
+      const unsigned rbase = (unsigned)(((a ? ad.r1 : ad.r0) * p.bh + (b ? ah.r1 : ah.r0)) * p.bw);
+      cn[(a * 2 + b) * 2] = *(const u32x4*)(smem + (rbase + (unsigned)aw.r0) * rowb + (unsigned)cl * ES);
+      cn[(a * 2 + b) * 2 + 1] = *(const u32x4*)(smem + (rbase + (unsigned)aw.r1) * rowb + (unsigned)cl * ES);
     }
-#pragma unroll
-    for (int j = 0; j < CPC; ++j) acc[j] += wa * pa[j];
-  }
+  float acc[CPC];
+  trilerp<T>(cn, ad.l0, ad.l1, ah.l0, ah.l1, aw.l0, aw.l1, acc);
   Elem<T>::unpack(Elem<T>::pack(acc), f);
 }
 
@@ -237,12 +225,18 @@ extern "C" int cbim_stats_finalize(const float* partials, int N, int P, int C, d
 
 static constexpr size_t UP_LDS_CAP = 96 * 1024;      // leaves room for a second workgroup on the CU
 
-// upper bound of the coarse-box extent along one axis for a fine tile of length t
+// largest coarse-box extent along one axis over all fine tiles of length t: the kernel's own index arithmetic (float
+// scale, truncation) replayed on the host
 static int box_extent(int in, int out, int t) {
-  if (out <= 1) return in < 2 ? in : 2;
-  const double s = (double)(in - 1) / (double)(out - 1);
-  int e = (int)(s * (t - 1)) + 4;   // i1(last) - i0(first) + 1 <= floor(s (t-1)) + 3, one more for float rounding
-  return e > in ? in : e;
+  const float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  auto i0 = [&](int dst) { int i = (int)(sc * (float)dst); return i > in - 1 ? in - 1 : i; };
+  int best = 1;
+  for (int f0 = 0; f0 < out; f0 += t) {
+    const int fl = f0 + t - 1 < out ? f0 + t - 1 : out - 1;
+    const int a = i0(f0), b = i0(fl), e = b + (b < in - 1 ? 1 : 0) - a + 1;
+    if (e > best) best = e;
+  }
+  return best;
 }
 
 static int up_fill(UpTileParams& p, int dtype, int Dl, int Hl, int Wl, int Cl, int D, int H, int W, int Cs, size_t* smem) {
