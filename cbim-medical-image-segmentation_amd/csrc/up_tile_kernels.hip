@@ -155,36 +155,63 @@ __global__ void __launch_bounds__(UT) k_up_tile(UpTileParams p) {
     stage_box<T>(p, smem, n, td, th, tw, sd, sh, sw);
     __syncthreads();
     if (!active) continue;
-    for (int v = vl; v < FV; v += vlc) {
-      const int fw = v % FW, fh = (v / FW) % FH, fd = v / (FW * FH);
-      const int d = td * FD + fd, h = th * FH + fh, w = tw * FW + fw;
-      if (d >= p.D || h >= p.H || w >= p.W) continue;
-      const size_t row = (size_t)n * S + ((size_t)d * p.H + h) * p.W + w;
-      float f[CPC];
-      if (is_skip) Elem<T>::unpack(ld_chunk<T>(p.skip, row * p.Cs + (c0 - skip_lo)), f);
-      else up_from_box<T>(p, smem, fd, fh, fw, c0 - low_lo, f);
-      if (MODE == 0) {
-        if (cnt == 0.f) {
+    // B voxels per trip: every global load of the batch (skip rows, gradient rows) is in flight before the first use —
+    // one load -> use -> store chain per voxel left a skip-chunk thread waiting a full memory round trip 12 times per
+    // tile (the kernel ran at 2.4 TB/s)
+    constexpr int B = 4;
+    for (int vb = vl; vb < FV; vb += vlc * B) {
+      u32x4 sk[B], gq[B];
+      size_t row[B];
+      int fdv[B], fhv[B], fwv[B];
+      bool ok[B];
 #pragma unroll
-          for (int j = 0; j < CPC; ++j) shift[j] = f[j];
+      for (int b = 0; b < B; ++b) {
+        const int v = vb + b * vlc;
+        fwv[b] = v % FW; fhv[b] = (v / FW) % FH; fdv[b] = v / (FW * FH);
+        const int d = td * FD + fdv[b], h = th * FH + fhv[b], w = tw * FW + fwv[b];
+        ok[b] = v < FV && d < p.D && h < p.H && w < p.W;
+        row[b] = (size_t)n * S + ((size_t)d * p.H + h) * p.W + w;
+        sk[b] = u32x4{0u, 0u, 0u, 0u};
+        gq[b] = u32x4{0u, 0u, 0u, 0u};
+        if (ok[b]) {
+          if (is_skip) sk[b] = ld_chunk<T>(p.skip, row[b] * p.Cs + (c0 - skip_lo));
+          if (MODE == 2) gq[b] = ld_chunk<T>(p.g, row[b] * Ct + c0);
         }
-        cnt += 1.f;
+      }
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) { const float dlt = f[j] - shift[j]; s0[j] += dlt; s1[j] += dlt * dlt; }
-      } else if (MODE == 1) {
+      for (int b = 0; b < B; ++b) {
+        if (!ok[b]) continue;
+        float f[CPC];
+        if (is_skip) Elem<T>::unpack(sk[b], f);
+        else up_from_box<T>(p, smem, fdv[b], fhv[b], fwv[b], c0 - low_lo, f);
+        if (MODE == 0) {
+          if (cnt == 0.f) {
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
-        st_chunk<T>(p.out, row * Ct + c0, Elem<T>::pack(f));
-      } else {
-        float gg[CPC];
-        Elem<T>::unpack(ld_chunk<T>(p.g, row * Ct + c0), gg);
+            for (int j = 0; j < CPC; ++j) shift[j] = f[j];
+          }
+          cnt += 1.f;
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) {
-          const float xh = (f[j] - mean[j]) * rstd[j];
-          gg[j] = rstd[j] * (gg[j] - m1[j] - xh * m2[j]);
+          for (int j = 0; j < CPC; ++j) { const float dlt = f[j] - shift[j]; s0[j] += dlt; s1[j] += dlt * dlt; }
+        } else if (MODE == 1) {
+          if (p.act == CBIM_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) { const float y = (f[j] - mean[j]) * rstd[j]; f[j] = y > 0.f ? y : 0.f; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
+          }
+          st_chunk<T>(p.out, row[b] * Ct + c0, Elem<T>::pack(f));
+        } else {
+          float gg[CPC];
+          Elem<T>::unpack(gq[b], gg);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) {
+            const float xh = (f[j] - mean[j]) * rstd[j];
+            gg[j] = rstd[j] * (gg[j] - m1[j] - xh * m2[j]);
+          }
+          if (is_skip) st_chunk<T>(p.out, row[b] * p.Cs + (c0 - skip_lo), Elem<T>::pack(gg));
+          else st_chunk<T>(p.out2, row[b] * p.Cl + (c0 - low_lo), Elem<T>::pack(gg));
         }
-        if (is_skip) st_chunk<T>(p.out, row * p.Cs + (c0 - skip_lo), Elem<T>::pack(gg));
-        else st_chunk<T>(p.out2, row * p.Cl + (c0 - low_lo), Elem<T>::pack(gg));
       }
     }
   }
@@ -224,6 +251,12 @@ extern "C" int cbim_stats_finalize(const float* partials, int N, int P, int C, d
                                    float* out, void* stream);
 
 static constexpr size_t UP_LDS_CAP = 96 * 1024;      // leaves room for a second workgroup on the CU
+static int64_t g_up_tile_min = 512;                  // fewest fine tiles per image the tiled kernels take (0: any; tests)
+extern "C" int64_t cbim_up_tile_min_tiles(int64_t v) {
+  const int64_t old = g_up_tile_min;
+  if (v >= 0) g_up_tile_min = v;
+  return old;
+}
 
 // largest coarse-box extent along one axis over all fine tiles of length t: the kernel's own index arithmetic (float
 // scale, truncation) replayed on the host
@@ -251,6 +284,10 @@ static int up_fill(UpTileParams& p, int dtype, int Dl, int Hl, int Wl, int Cl, i
   const size_t red = (size_t)UT * cpc * 3 * sizeof(float);
   if (need < red) need = red;
   CBIM_CHECK(need <= UP_LDS_CAP, CBIM_EUNSUPPORTED, "up tile: coarse box of %dx%dx%d rows x %d channels exceeds the LDS budget", p.bd, p.bh, p.bw, Cl);
+  // a workgroup per 4x8x8 fine tile: below ~512 tiles the chip is under-filled and the wide rows of the low levels leave a
+  // thread 50-100 serial items (measured 75-115 us against 11-29 us of the gather kernels at 32^3 / 16^3)
+  CBIM_CHECK(g_up_tile_min <= 0 || (int64_t)p.tiles_d * p.tiles_h * p.tiles_w >= g_up_tile_min, CBIM_EUNSUPPORTED,
+             "up tile: %d tiles are too few for the tiled kernels", p.tiles_d * p.tiles_h * p.tiles_w);
   *smem = need;
   return CBIM_OK;
 }

@@ -123,6 +123,7 @@ int cbim_upcat_norm_bwd(int dtype, const void* g, const void* low, const void* s
  * (the caller then uses the entry points above).  cbim_up_stats_tile's partials have
  * cbim_up_tile_parts(D, H, W) records per image. */
 int cbim_up_tile_parts(int D, int H, int W);
+int64_t cbim_up_tile_min_tiles(int64_t v);   /* process-wide knob (tests): fewest fine tiles per image the tiled kernels take; returns the old value */
 int cbim_up_stats_tile(int dtype, const void* low, int N, int Dl, int Hl, int Wl, int Cl, int D, int H, int W,
                        float eps, float* partials, int P, float* stats, void* stream);
 int cbim_upcat_act_fwd_tile(int dtype, const void* low, const void* skip, const float* stats, void* out, int N,

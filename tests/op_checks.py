@@ -107,6 +107,8 @@ def check_upcat_fused(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9),
     lol, skl = to_cl(lo, dtype).to(dev), to_cl(sk, dtype).to(dev)
     cat, st_cat = ops.upcat_fwd_stats(lol, skl, skip_first)                # round-2 path: stored concatenation
     if tiles:
+        from cbim_amd import _lib
+        _lib.lib().cbim_up_tile_min_tiles(0)                       # (small test volumes: take the tiled kernels anyway)
         # the LDS-tiled kernels against the gather kernels: same arithmetic in the same order -> same bits
         g0 = to_cl(torch.randn(N, Cs + Cl, *hi), dtype).to(dev)
         sums0 = ops.norm_bwd_sums(g0, cat, st_cat, 0, masked=False)
