@@ -34,6 +34,14 @@ static constexpr int FV = FD * FH * FW;
 #define UT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
+__device__ __forceinline__ unsigned ut_mad24(unsigned a, unsigned b, unsigned c) {
+#ifdef CBIM_EMU
+  return a * b + c;
+#else
+  return __umul24(a, b) + c;
+#endif
+}
+
 // trilinear align_corners source index (the arithmetic of pool_up_kernels.hip / ATen: float scale, truncation)
 struct ULin { int i0, i1; float l0, l1; };
 __device__ __forceinline__ float ulin_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
@@ -149,6 +157,15 @@ __global__ void __launch_bounds__(UT) k_up_tile(UpTileParams p) {
   }
   const int tiles = p.tiles_d * p.tiles_h * p.tiles_w;
   const size_t S = (size_t)p.D * p.H * p.W;
+  // per-image base pointers (64-bit, once) + 32-bit byte offsets from 24-bit multiplies per voxel: the 64-bit element
+  // arithmetic per item was ~10 quarter-rate instructions
+  constexpr unsigned ES = Elem<T>::SIZE;
+  const unsigned cat_rb = (unsigned)Ct * ES, skip_rb = (unsigned)p.Cs * ES, low_rb = (unsigned)p.Cl * ES;
+  const unsigned cat_cb = (unsigned)c0 * ES, skip_cb = (unsigned)(c0 - skip_lo) * ES, low_cb = (unsigned)(c0 - low_lo) * ES;
+  const unsigned char* const skip_n = (const unsigned char*)p.skip + (size_t)n * S * skip_rb;
+  const unsigned char* const g_n = (const unsigned char*)p.g + (size_t)n * S * cat_rb;
+  unsigned char* const out_n = (unsigned char*)p.out + (size_t)n * S * (MODE == 2 ? skip_rb : cat_rb);
+  unsigned char* const out2_n = (unsigned char*)p.out2 + (size_t)n * S * low_rb;
   for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int tw = t % p.tiles_w, q = t / p.tiles_w, th = q % p.tiles_h, td = q / p.tiles_h;
     __syncthreads();                                   // the previous tile's box is no longer read
@@ -161,7 +178,7 @@ __global__ void __launch_bounds__(UT) k_up_tile(UpTileParams p) {
     constexpr int B = 4;
     for (int vb = vl; vb < FV; vb += vlc * B) {
       u32x4 sk[B], gq[B];
-      size_t row[B];
+      unsigned vox[B];                                  // voxel index inside the image (< 2^24, checked by the launcher)
       int fdv[B], fhv[B], fwv[B];
       bool ok[B];
 #pragma unroll
@@ -170,12 +187,12 @@ __global__ void __launch_bounds__(UT) k_up_tile(UpTileParams p) {
         fwv[b] = v % FW; fhv[b] = (v / FW) % FH; fdv[b] = v / (FW * FH);
         const int d = td * FD + fdv[b], h = th * FH + fhv[b], w = tw * FW + fwv[b];
         ok[b] = v < FV && d < p.D && h < p.H && w < p.W;
-        row[b] = (size_t)n * S + ((size_t)d * p.H + h) * p.W + w;
+        vox[b] = ut_mad24(ut_mad24((unsigned)d, (unsigned)p.H, (unsigned)h), (unsigned)p.W, (unsigned)w);
         sk[b] = u32x4{0u, 0u, 0u, 0u};
         gq[b] = u32x4{0u, 0u, 0u, 0u};
         if (ok[b]) {
-          if (is_skip) sk[b] = ld_chunk<T>(p.skip, row[b] * p.Cs + (c0 - skip_lo));
-          if (MODE == 2) gq[b] = ld_chunk<T>(p.g, row[b] * Ct + c0);
+          if (is_skip) sk[b] = *(const u32x4*)(skip_n + ut_mad24(vox[b], skip_rb, skip_cb));
+          if (MODE == 2) gq[b] = *(const u32x4*)(g_n + ut_mad24(vox[b], cat_rb, cat_cb));
         }
       }
 #pragma unroll
@@ -200,7 +217,7 @@ __global__ void __launch_bounds__(UT) k_up_tile(UpTileParams p) {
 #pragma unroll
             for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], p.act);
           }
-          st_chunk<T>(p.out, row[b] * Ct + c0, Elem<T>::pack(f));
+          *(u32x4*)(out_n + ut_mad24(vox[b], cat_rb, cat_cb)) = Elem<T>::pack(f);
         } else {
           float gg[CPC];
           Elem<T>::unpack(gq[b], gg);
@@ -209,8 +226,8 @@ __global__ void __launch_bounds__(UT) k_up_tile(UpTileParams p) {
             const float xh = (f[j] - mean[j]) * rstd[j];
             gg[j] = rstd[j] * (gg[j] - m1[j] - xh * m2[j]);
           }
-          if (is_skip) st_chunk<T>(p.out, row[b] * p.Cs + (c0 - skip_lo), Elem<T>::pack(gg));
-          else st_chunk<T>(p.out2, row[b] * p.Cl + (c0 - low_lo), Elem<T>::pack(gg));
+          if (is_skip) *(u32x4*)(out_n + ut_mad24(vox[b], skip_rb, skip_cb)) = Elem<T>::pack(gg);
+          else *(u32x4*)(out2_n + ut_mad24(vox[b], low_rb, low_cb)) = Elem<T>::pack(gg);
         }
       }
     }
@@ -277,6 +294,9 @@ static int up_fill(UpTileParams& p, int dtype, int Dl, int Hl, int Wl, int Cl, i
   CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
   CBIM_CHECK(Cl > 0 && Cl % cpc == 0 && Cs >= 0 && Cs % cpc == 0, CBIM_EUNSUPPORTED, "up tile: channel counts %d / %d must be multiples of %d", Cl, Cs, cpc);
   CBIM_CHECK((Cs + Cl) / cpc <= UT, CBIM_EUNSUPPORTED, "up tile: %d channels unsupported", Cs + Cl);
+  // 32-bit byte offsets inside one image, built from 24-bit multiplies
+  CBIM_CHECK((int64_t)D * H * W < (1 << 24) && (int64_t)(Cs + Cl) * es < (1 << 24) && (int64_t)D * H * W * (Cs + Cl) * es < ((int64_t)1 << 32),
+             CBIM_EUNSUPPORTED, "up tile: a %dx%dx%d image with %d channels exceeds the 32-bit addressing", D, H, W, Cs + Cl);
   p.Dl = Dl; p.Hl = Hl; p.Wl = Wl; p.Cl = Cl; p.D = D; p.H = H; p.W = W; p.Cs = Cs;
   p.tiles_d = (D + FD - 1) / FD; p.tiles_h = (H + FH - 1) / FH; p.tiles_w = (W + FW - 1) / FW;
   p.bd = box_extent(Dl, D, FD); p.bh = box_extent(Hl, H, FH); p.bw = box_extent(Wl, W, FW);
