@@ -120,6 +120,9 @@ _SIGS = {
     "cbim_dice_counts": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp]),
     "cbim_gate_fwd": (i32, [i32, vp, vp, vp, i64, i32, vp]),
     "cbim_gate_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "cbim_layernorm_fwd": (i32, [vp, vp, vp, f32, i32, vp, vp, i64, i32, vp]),
+    "cbim_layernorm_bwd_workspace": (sz, [i64, i32]),
+    "cbim_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, vp]),
     "cbim_ncdhw_to_ndhwc": (i32, [i32, vp, vp, i32, i32, i64, vp]),
     "cbim_ndhwc_to_ncdhw": (i32, [i32, vp, vp, i32, i32, i64, vp]),
 }

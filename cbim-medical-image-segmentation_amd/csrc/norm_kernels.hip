@@ -482,6 +482,7 @@ extern "C" int cbim_warm_r32(void* stream);
 extern "C" int cbim_warm_swin_mfma(void* stream);
 extern "C" int cbim_warm_wgrad_r32(void* stream);
 extern "C" int cbim_warm_up_tile(void* stream);
+extern "C" int cbim_warm_layernorm(void* stream);
 
 // One successful no-op launch from every code object of the library (see CBIM_DEFINE_WARM); the binding calls
 // this once per process before the first real launch.
@@ -503,6 +504,7 @@ extern "C" int cbim_runtime_warmup(void* stream) {
   if (int e = cbim_warm_swin_mfma(stream)) return e;
   if (int e = cbim_warm_wgrad_r32(stream)) return e;
   if (int e = cbim_warm_up_tile(stream)) return e;
+  if (int e = cbim_warm_layernorm(stream)) return e;
   return CBIM_OK;
 }
 

@@ -602,6 +602,35 @@ class WindowAttnFn(torch.autograd.Function):
         return dqkv, (dbias if has_bias else None), dtable, None, None, None, None
 
 
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm / F.layer_norm over the channel axis of channels-last token rows (swin_unetr.py:539,550,679,970-983):
+    x float32 [..., C] (the residual stream), optional affine parameters; y in `out_dtype` (bf16 for the token Linears
+    of the bf16 engine mode: the cast rides on the store)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        x = x.contiguous()
+        w = weight.detach().float().contiguous() if weight is not None else None
+        b = bias.detach().float().contiguous() if bias is not None else None
+        y, rs = ops.layernorm_fwd(x, w, b, eps, out_dtype)
+        ctx.save_for_backward(x, w if w is not None else torch.empty(0), rs)
+        ctx.has_w = w is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, rs = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dx, dg, db = ops.layernorm_bwd(dy, x, w if ctx.has_w else None, rs, ctx.has_w)
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, weight, bias, eps, out_dtype=torch.float32):
+    return LayerNormFn.apply(x, weight, bias, eps, out_dtype)
+
+
 class ResNormFn(torch.autograd.Function):
     """Tail of monai's UnetResBlock: y = act(IN(a) + (IN(b) | b)) with the statistics of a (and b) given
     (they come out of the producing convolutions' epilogues)."""

@@ -181,6 +181,16 @@ def _token_linear(lin, x):
     return lin(x)
 
 
+_FUSED_LN = os.environ.get("CBIM_SWIN_FUSED_LN", "1") != "0"
+
+
+def _layer_norm(ln, x, out_dtype):
+    """nn.LayerNorm `ln` applied by the HIP kernel (fp32 rows in, `out_dtype` out) — torch's own op for shapes it does not take"""
+    if _FUSED_LN and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 3072:
+        return Fn.layer_norm(x, ln.weight, ln.bias, ln.eps, out_dtype)
+    return ln(x)
+
+
 class MLPBlock(nn.Module):
     def __init__(self, hidden_size, mlp_dim):
         super().__init__()
@@ -241,9 +251,10 @@ class SwinTransformerBlock(nn.Module):
         # bf16 engine mode: the token Linears (qkv, proj, MLP), GELU and the window-attention kernel run in bf16 like
         # the reference under AMP (LayerNorm and the residual stream stay fp32); fp32 mode is untouched
         amp = x.is_cuda and Fn.compute_dtype() == torch.bfloat16 and _TRUNK_AMP
+        nd = torch.bfloat16 if amp else torch.float32       # the LayerNorm kernel stores what the Linears consume
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            x = x + self.attn(self.norm1(x), ws, ss)
-            return x + self.mlp(self.norm2(x))
+            x = x + self.attn(_layer_norm(self.norm1, x, nd), ws, ss)
+            return x + self.mlp(_layer_norm(self.norm2, x, nd))
 
 
 class PatchMerging(nn.Module):
@@ -260,7 +271,7 @@ class PatchMerging(nn.Module):
         if (d % 2) or (h % 2) or (w % 2):
             x = F.pad(x, (0, 0, 0, w % 2, 0, h % 2, 0, d % 2))
         x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self._SEL], -1)
-        return self.reduction(self.norm(x))
+        return self.reduction(_layer_norm(self.norm, x, torch.float32))
 
 
 class BasicLayer(nn.Module):
@@ -292,8 +303,14 @@ class SwinTransformer(nn.Module):
                                                           mlp_ratio=mlp_ratio, qkv_bias=qkv_bias)]))
 
     def forward(self, x, normalize=True):
+        od = Fn.compute_dtype()     # the conv encoder reads the hidden states in the engine's activation dtype
+
         def out(t):   # proj_out (:970-983): F.layer_norm(x, [ch]) without affine parameters
-            return F.layer_norm(t, (t.shape[-1],)) if normalize else t
+            if not normalize:
+                return t
+            if _FUSED_LN and t.dtype == torch.float32 and t.shape[-1] % 4 == 0 and t.shape[-1] <= 3072:
+                return Fn.layer_norm(t, None, None, 1e-5, od)
+            return F.layer_norm(t, (t.shape[-1],))
         x = self.patch_embed(x)
         outs = [out(x)]
         for layers in (self.layers1, self.layers2, self.layers3, self.layers4):

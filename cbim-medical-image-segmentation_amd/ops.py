@@ -835,6 +835,39 @@ def window_attn_bwd(qkv, qkv_bias, table, out, dout, lse, heads: int, window, sh
     return dqkv, dtable, dbias
 
 
+def layernorm_fwd(x, gamma, beta, eps: float, out_dtype: torch.dtype):
+    """nn.LayerNorm over the last axis of x (float32 [..., C]) -> (y [..., C] in out_dtype, rowstats float32 [rows, 2])."""
+    _dev_ok(x, gamma, beta)
+    if x.dtype != torch.float32:
+        raise TypeError("cbim_amd: layernorm_fwd takes the float32 residual stream")
+    Cc = int(x.shape[-1])
+    rows = x.numel() // Cc
+    y = torch.empty(tuple(x.shape), dtype=out_dtype, device=x.device)
+    rs = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cbim_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), 1 if out_dtype == torch.bfloat16 else 0, _p(y),
+                                        _p(rs), rows, Cc, _stream(x)), "layernorm_fwd")
+    return y, rs
+
+
+def layernorm_bwd(dy, x, gamma, rowstats, want_affine: bool):
+    """-> (dx float32, dgamma | None, dbeta | None)."""
+    _dev_ok(dy, x, gamma, rowstats)
+    Cc = int(x.shape[-1])
+    rows = x.numel() // Cc
+    L = _lib.lib()
+    dx = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    dg = db = ws = None
+    nbytes = 0
+    if want_affine:
+        dg = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        db = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        nbytes = L.cbim_layernorm_bwd_workspace(rows, Cc)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    check(L.cbim_layernorm_bwd(_dt(dy), _p(dy), _p(x), _p(gamma), _p(rowstats), _p(dx), _p(dg), _p(db), _p(ws), nbytes, rows, Cc,
+                               _stream(x)), "layernorm_bwd")
+    return dx, dg, db
+
+
 def resnorm_fwd(a, stats_a, b, stats_b, act: int):
     """y = act(IN(a) + (IN(b) if stats_b is given else b))."""
     _dev_ok(a, stats_a, b, stats_b)

@@ -444,6 +444,23 @@ int cbim_gate_fwd(int dtype, const void* x, const float* psi, void* y, int64_t r
 int cbim_gate_bwd(int dtype, const void* dy, const void* x, const float* psi, void* dx, float* dpsi, int64_t rows,
                   int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the channel axis of channels-last token rows — SwinUNETR trunk:
+ * SwinTransformerBlock.norm1 / norm2 (model/dim3/swin_unetr.py:539,550), PatchMerging.norm (:679),
+ * SwinTransformer.proj_out = F.layer_norm(x, [C]) without affine parameters (:970-983).
+ * x float [rows][C] (C a multiple of 4, <= 3072); gamma / beta float [C] or NULL; y [rows][C] in
+ * out_dtype (CBIM_F32 | CBIM_BF16); rowstats float [rows][2] = (mean, rstd) for the backward.
+ * Backward: dx float [rows][C] = rstd*(g - mean(g) - xh*mean(g*xh)), g = dy*gamma; dgamma / dbeta
+ * (float [C], NULL to skip) are summed in fixed order through
+ * cbim_layernorm_bwd_workspace(rows, C) bytes of scratch.
+ * ------------------------------------------------------------------------------------------ */
+int cbim_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int out_dtype,
+                       void* y, float* rowstats, int64_t rows, int C, void* stream);
+size_t cbim_layernorm_bwd_workspace(int64_t rows, int C);
+int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, const float* gamma,
+                       const float* rowstats, float* dx, float* dgamma, float* dbeta, void* workspace,
+                       size_t ws_bytes, int64_t rows, int C, void* stream);
+
 /* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);

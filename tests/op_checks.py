@@ -657,3 +657,30 @@ def check_wgrad_r32(dev, N=1, Cin=32, Cout=32, dhw=(8, 16, 8), split=0, xsplit=0
     F.conv3d(a, w, None, 1, pad).backward(from_cl(dyl.cpu()))
     e = relerr(dw.cpu(), w.grad)
     assert e < 1e-3, f"wgrad r32 vs torch {e:.3e}"
+
+
+def check_layernorm(dev, rows=(3, 5, 7), C=48, affine=True, out_bf16=False, seed=31):
+    """cbim_layernorm_fwd / _bwd against torch's layer_norm on the same fp32 rows (the SwinUNETR trunk's LayerNorms)."""
+    from cbim_amd import functional as Fn
+    torch.manual_seed(seed)
+    x = (torch.randn(*rows, C) * 1.7 + 0.4)
+    w = (torch.randn(C) * 0.3 + 1.0) if affine else None
+    b = (torch.randn(C) * 0.2) if affine else None
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True) if affine else None
+    br = b.clone().requires_grad_(True) if affine else None
+    ref = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    g = torch.randn_like(ref)
+    xe = x.clone().to(dev).requires_grad_(True)
+    we = w.clone().to(dev).requires_grad_(True) if affine else None
+    be = b.clone().to(dev).requires_grad_(True) if affine else None
+    od = torch.bfloat16 if out_bf16 else torch.float32
+    y = Fn.layer_norm(xe, we, be, 1e-5, od)
+    assert y.dtype == od
+    assert relerr(y.float().cpu(), ref.detach()) < (8e-3 if out_bf16 else 2e-6)
+    gd = g.to(dev).to(od)
+    ref.backward(gd.float().cpu())
+    y.backward(gd)
+    assert relerr(xe.grad.cpu(), xr.grad) < 2e-5
+    if affine:
+        assert relerr(we.grad.cpu(), wr.grad) < 2e-5 and relerr(be.grad.cpu(), br.grad) < 2e-5

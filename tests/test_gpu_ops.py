@@ -230,3 +230,17 @@ def test_wgrad_r32_accumulators_in_registers(dev):
             oc.check_wgrad_r32(dev, N=1, Cin=576, Cout=512, dhw=(16, 16, 16), split=256, xsplit=256)
     finally:
         L.cbim_wgrad_r32_waves(8)
+
+
+@pytest.mark.gpu
+def test_layernorm_token_rows(dev):
+    """nn.LayerNorm of the SwinUNETR trunk: every channel count of the shipped model (48 ... 3072), with and without affine
+    parameters, fp32 and bf16 outputs, row counts that do not fill the last workgroup."""
+    oc.check_layernorm(dev)
+    oc.check_layernorm(dev, rows=(2, 3, 11), C=96, out_bf16=True)
+    oc.check_layernorm(dev, rows=(1, 9, 4), C=192, affine=False)
+    oc.check_layernorm(dev, rows=(37,), C=384)
+    oc.check_layernorm(dev, rows=(5, 3), C=768, out_bf16=True)
+    oc.check_layernorm(dev, rows=(9,), C=1536)
+    oc.check_layernorm(dev, rows=(4,), C=3072, affine=True)
+    oc.check_layernorm(dev, rows=(64, 64, 64), C=48, out_bf16=True)

@@ -223,3 +223,15 @@ def test_wgrad_r32_accumulators_in_registers(dev):
         oc.check_wgrad_r32(dev, N=1, Cin=96, Cout=32, dhw=(8, 8, 24), xsplit=32)
     finally:
         L.cbim_wgrad_r32_waves(8)
+
+
+def test_layernorm_token_rows(dev):
+    """nn.LayerNorm of the SwinUNETR trunk: every channel count of the shipped model (48 ... 3072), with and without affine
+    parameters, fp32 and bf16 outputs, row counts that do not fill the last workgroup."""
+    oc.check_layernorm(dev)
+    oc.check_layernorm(dev, rows=(2, 3, 11), C=96, out_bf16=True)
+    oc.check_layernorm(dev, rows=(1, 9, 4), C=192, affine=False)
+    oc.check_layernorm(dev, rows=(37,), C=384)
+    oc.check_layernorm(dev, rows=(5, 3), C=768, out_bf16=True)
+    oc.check_layernorm(dev, rows=(9,), C=1536)
+    oc.check_layernorm(dev, rows=(4,), C=3072, affine=True)
