@@ -79,6 +79,7 @@ __device__ __forceinline__ unsigned wmad24(unsigned a, unsigned b, unsigned c) {
 
 template <int ACT> __device__ __forceinline__ float wg_actf(float x, int rt) {
   if (ACT == CBIM_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (ACT == CBIM_ACT_LRELU) return x > 0.f ? x : 0.01f * x;
   if (ACT == CBIM_ACT_NONE) return x;
   return act_fwd(x, rt);
 }
@@ -558,7 +559,11 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   const bool relu = d->act == CBIM_ACT_RELU || !in_stats;
   int rc;
   if (d->dtype == CBIM_BF16)
-    rc = relu ? dispatch_tpw<bf16_tag, CBIM_ACT_RELU>(taps, p, grid, smem, st) : dispatch_tpw<bf16_tag, -1>(taps, p, grid, smem, st);
+    // (LeakyReLU as a compile-time case: the monai blocks of SwinUNETR; the run-time switch of the generic instantiation
+    //  sits inside the staging loop, which is 64 % of this kernel's cycles)
+    rc = relu ? dispatch_tpw<bf16_tag, CBIM_ACT_RELU>(taps, p, grid, smem, st)
+              : d->act == CBIM_ACT_LRELU ? dispatch_tpw<bf16_tag, CBIM_ACT_LRELU>(taps, p, grid, smem, st)
+                                         : dispatch_tpw<bf16_tag, -1>(taps, p, grid, smem, st);
   else
     rc = relu ? dispatch_tpw<float, CBIM_ACT_RELU>(taps, p, grid, smem, st) : dispatch_tpw<float, -1>(taps, p, grid, smem, st);
   if (rc) return rc;

@@ -18,13 +18,16 @@ import itertools
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
-
 import os
+
+import torch.nn.functional as F
 
 from ... import functional as Fn
 from ...ops import ACT
 
+from ...ops import ncdhw_to_ndhwc as ops_ncdhw_to_ndhwc
+
+_STEM_MFMA = os.environ.get("CBIM_SWIN_STEM_MFMA", "1") != "0"
 _EPS = 1e-5          # nn.InstanceNorm3d default (monai get_norm_layer("instance"))
 _LRELU = ACT["lrelu"]  # monai UnetResBlock act: LeakyReLU(0.01)
 
@@ -63,6 +66,21 @@ class UnetResBlock(nn.Module):
 
     def forward(self, x, stem_dtype=None):
         """x: channels-last feature map, or (stem_dtype given) the NCDHW fp32 network input."""
+        if stem_dtype is not None and _STEM_MFMA and stem_dtype == torch.bfloat16 and x.shape[1] <= 8:
+            # the network input as an 8-channel (zero-padded) channels-last bf16 tensor: conv1 / conv3 of encoder1 then run
+            # on the matrix cores like every other conv (k_stem_fwd / k_stem_wgrad<4>, direct vector-ALU kernels, were
+            # 0.9 + 1.8 ms of the 32 ms step); the padded weight columns are zero and their gradient is sliced off
+            cin = int(x.shape[1])
+            xp = F.pad(x, (0, 0, 0, 0, 0, 0, 0, 8 - cin)) if cin < 8 else x
+            x = ops_ncdhw_to_ndhwc(xp.contiguous(), stem_dtype)
+            w1 = F.pad(self.conv1.conv.weight, (0, 0, 0, 0, 0, 0, 0, 8 - cin))
+            z1, s1 = Fn.NormConvFn.apply(x, None, w1, 0, None, True, None, _EPS)
+            z2, s2 = Fn.NormConvFn.apply(z1, s1, self.conv2.conv.weight, _LRELU, None, True, None, _EPS)
+            if not self.downsample:
+                raise NotImplementedError("cbim_amd: identity-residual UnetResBlock on the raw network input is not built")
+            w3 = F.pad(self.conv3.conv.weight, (0, 0, 0, 0, 0, 0, 0, 8 - cin))
+            r, s3 = Fn.NormConvFn.apply(x, None, w3, 0, None, True, None, _EPS)
+            return Fn.ResNormFn.apply(z2, s2, r, s3, _LRELU)
         if stem_dtype is not None:
             z1 = Fn.StemFn.apply(x, self.conv1.conv.weight, stem_dtype)
             s1 = Fn.ensure_stats(Fn.FMap(z1, None), _EPS).stats
