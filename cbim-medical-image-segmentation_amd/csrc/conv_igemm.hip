@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
           float cnt = 0.f;
 #pragma unroll
           for (int j = 0; j < CPC; ++j) { mm[j] = 0.f; mr[j] = 1.f; s0[j] = 0.f; s1[j] = 0.f; sh[j] = 0.f; }
-          if (p.mx && c_ok) {
+          if (p.mx && p.m_stats && c_ok) {     // (no statistics: the mask tensor is the activated a = relu(IN(x)): xh := a)
 #pragma unroll
             for (int j = 0; j < CPC; ++j) {
               mm[j] = p.m_stats[((size_t)n * p.Cout + cch0 + j) * 2];
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(FT) k_splitk_finish(const float* __restrict__ 
   float cnt = 0.f;
 #pragma unroll
   for (int j = 0; j < CPC; ++j) { mm[j] = 0.f; mr[j] = 1.f; s0[j] = 0.f; s1[j] = 0.f; sh[j] = 0.f; }
-  if (mx && active) {
+  if (mx && m_stats && active) {
 #pragma unroll
     for (int j = 0; j < CPC; ++j) {
       mm[j] = m_stats[((size_t)n * C + cc * CPC + j) * 2];
@@ -1144,7 +1144,9 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
                                  void* workspace, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
   CBIM_CHECK(x && w_packed && y, CBIM_EINVAL, "null tensor");
-  CBIM_CHECK(!mask_x || mask_stats, CBIM_EINVAL, "mask_x needs mask_stats");
+  // mask_x without statistics: the mask tensor is the caller's materialised a = relu(IN(x)) (act'(xh) = [a > 0], xh = a
+  // wherever the mask is open) — defined for ReLU only
+  CBIM_CHECK(!mask_x || mask_stats || d->act == CBIM_ACT_RELU, CBIM_EINVAL, "mask_x without mask_stats (an activated mask tensor) needs act = ReLU");
   g_last_conv_kernel = 0;
   if (cbim_conv_r32_eligible(d, x2, cin_split, in_stats, res, mask_x)) {  // channels in multiples of 32 at high resolution: weights in registers
     g_last_conv_kernel = 1;

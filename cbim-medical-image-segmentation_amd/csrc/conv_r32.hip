@@ -144,6 +144,9 @@ __device__ __forceinline__ void r_swap16(float& a, float& b) {
 
 // TR: the input is transformed (InstanceNorm + ACT) in place in LDS after the LDS-DMA; !TR: used as it is
 // MX: dgrad epilogue (x act'(xh) mask + the two InstanceNorm-backward sums); !MX: forward epilogue (moments)
+// p.m_stats == nullptr with MX: the mask tensor is the ACTIVATED tensor a = relu(IN(x)) the caller materialised:
+// act'(xh) = [a != 0] straight from the bf16 bits and, wherever the mask is open, a is the normalised value itself —
+// no statistics table, no normalisation arithmetic in the epilogue
 // TD: tile depth 8 (one 512-thread workgroup per CU) or 4 (two 256-thread workgroups per CU), see RGeom
 // MC: several 32-channel chunks of Cin (units = (tile, chunk), streamed weights, optional second input tensor)
 template <int ACT, bool TR, bool MX, int TD, bool MC>
@@ -453,8 +456,9 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   // (mean, rstd) tables in LDS: the mask tensor's channels (MX) / the input's channels (TR); refreshed at an image
   // change, always followed by a workgroup barrier before they are read
   int mst_n = -1, ist_n = -1;
+  const bool mask_is_act = MX && p.m_stats == nullptr;      // workgroup-uniform
   auto load_mstats = [&](int n) {
-    if (MX && n != mst_n) {
+    if (MX && !mask_is_act && n != mst_n) {
       if (tid < 64) {
         const int c = tid >> 1;
         ((float*)(smem + mst_base))[tid] = oc * 32 + c < p.Cout ? p.m_stats[((size_t)n * p.Cout + oc * 32 + c) * 2 + (tid & 1)] : (float)(tid & 1);
@@ -639,7 +643,22 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
         const float live = (in && c_ok) ? 1.f : 0.f;
         const f2_t live2 = {live, live};
         const unsigned rw[4] = {rq[pr].x, rq[pr].y, rq[pr].z, rq[pr].w};
-        if (MX) {
+        if (MX && mask_is_act) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f2_t a = {__uint_as_float(rw[j] << 16), __uint_as_float(rw[j] & 0xffff0000u)};
+            f2_t g;
+            g.x = (rw[j] & 0xffffu) != 0u ? v[2 * j] : 0.f;
+            g.y = (rw[j] >> 16) != 0u ? v[2 * j + 1] : 0.f;
+            v[2 * j] = g.x;
+            v[2 * j + 1] = g.y;
+            const f2_t gl = g * live2;
+            f2_t a0 = {S0[2 * j], S0[2 * j + 1]}, a1 = {S1[2 * j], S1[2 * j + 1]};
+            a0 = a0 + gl;
+            a1 = __builtin_elementwise_fma(gl, a, a1);
+            S0[2 * j] = a0.x; S0[2 * j + 1] = a0.y; S1[2 * j] = a1.x; S1[2 * j + 1] = a1.y;
+          }
+        } else if (MX) {
           const float* ms = (const float*)(smem + mst_base) + cidx * 16;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

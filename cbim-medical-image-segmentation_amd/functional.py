@@ -140,21 +140,6 @@ def fused_up_block(block) -> bool:
 
 
 _FUSED_UP = os.environ.get("CBIM_FUSED_UP", "1") not in ("", "0")
-_IDENT_STATS = {}
-
-
-def _identity_stats(n: int, c: int, device) -> torch.Tensor:
-    """(mean 0, rstd 1) records: a dgrad launch masked by a = relu(IN(x)) itself — act'(a) = [a > 0] and, wherever the
-    mask is open, a IS the normalised value the InstanceNorm-backward sum needs."""
-    key = (n, c, str(device))
-    t = _IDENT_STATS.get(key)
-    if t is None:
-        t = torch.zeros((n, c, 2), dtype=torch.float32, device=device)
-        t[..., 1] = 1.0
-        _IDENT_STATS[key] = t
-    return t
-
-
 def _bb_fwd(ctx, xshape, xin, sin, ident, w1, w2, wsc, act, want_out_stats, mat, train):
     """conv1 (+ shortcut conv as one Cout-concatenated GEMM where the channel counts allow) and conv2 with the residual add
     of a pre-activation BasicBlock.  xin / sin: the block input as the convolutions read it (activated tensor + None when
@@ -197,7 +182,8 @@ def _bb_fwd(ctx, xshape, xin, sin, ident, w1, w2, wsc, act, want_out_stats, mat,
 
 def _bb_bwd(ctx, dout, cx, cxs, mxs, y1, s1, cy, cys, mys, w1):
     """backward of _bb_fwd down to the masked gradient of the block input: (gx, sums1, dw1, dw2, dwsc).
-    cx / cy: the conv inputs as the forward saw them (+ statistics or None); mxs / mys: statistics for the dgrad mask."""
+    cx / cy: the conv inputs as the forward saw them (+ statistics or None); mxs / mys: statistics for the dgrad mask (None:
+    cx / cy are the activated tensors themselves and mask the gradient by [a > 0])."""
     g1, g2, gsc, gc = ctx.geoms
     wd1, wd2, wdsc = ctx.packed
     act = ctx.act
@@ -256,9 +242,7 @@ class BasicBlockFn(_GradAwareFunction):
         dout = dout.contiguous()
         if ctx.mat:
             # the conv inputs as the forward saw them: activated tensors, no statistics; the dgrad mask is [a > 0]
-            cx, cxs, cy, cys = ax, None, ay1, None
-            mxs = _identity_stats(int(x.shape[0]), int(x.shape[-1]), x.device)
-            mys = _identity_stats(int(y1.shape[0]), int(y1.shape[-1]), x.device)
+            cx, cxs, cy, cys, mxs, mys = ax, None, ay1, None, None, None
         else:
             cx, cxs, cy, cys, mxs, mys = x, x_stats, y1, s1, x_stats, s1
         gx, sums1, dw1, dw2, dwsc = _bb_bwd(ctx, dout, cx, cxs, mxs, y1, s1, cy, cys, mys, w1)
@@ -290,9 +274,7 @@ class UpBlockFirstFn(_GradAwareFunction):
     def backward(ctx, dout, _dso):
         low, skip, stats_cat, y1, s1, w1, w2, wsc, a, ay1 = ctx.saved_tensors
         dout = dout.contiguous()
-        mxs = _identity_stats(int(a.shape[0]), int(a.shape[-1]), a.device)
-        mys = _identity_stats(int(y1.shape[0]), int(y1.shape[-1]), a.device)
-        gx, sums1, dw1, dw2, dwsc = _bb_bwd(ctx, dout, a, None, mxs, y1, s1, ay1, None, mys, w1)
+        gx, sums1, dw1, dw2, dwsc = _bb_bwd(ctx, dout, a, None, None, y1, s1, ay1, None, None, w1)
         dlow, dskip = ops.upcat_norm_bwd(gx, low, skip, stats_cat, sums1, ctx.skip_first)
         return dlow, dskip, None, dw1, dw2, dwsc, None, None, None
 

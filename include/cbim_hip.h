@@ -199,6 +199,8 @@ int cbim_conv3d_num_tiles(const cbim_conv_desc* desc);
  * x2 != NULL: the input is the channel concatenation [x | x2] without materialising it; channels
  * >= cin_split (a multiple of the 64-byte chunk) come from x2 — the two dgrads of a BasicBlock that
  * share act(IN(x)) (conv1 and the shortcut conv, conv_layers.py:86-94) run as ONE K-concatenated GEMM. */
+/* mask_x with mask_stats == NULL (act = ReLU only): the mask tensor is the ACTIVATED tensor a = relu(IN(x)) the caller
+ * materialised once — act'(xh) = [a > 0] and a itself stands for xh in the second InstanceNorm-backward sum. */
 int cbim_conv3d_igemm(const cbim_conv_desc* desc, const void* x, int64_t x_stride, const void* x2,
                       int64_t x2_stride, int cin_split,
                       const float* in_stats, const void* w_packed, const void* res,

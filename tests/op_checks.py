@@ -684,3 +684,38 @@ def check_layernorm(dev, rows=(3, 5, 7), C=48, affine=True, out_bf16=False, seed
     assert relerr(xe.grad.cpu(), xr.grad) < 2e-5
     if affine:
         assert relerr(we.grad.cpu(), wr.grad) < 2e-5 and relerr(be.grad.cpu(), br.grad) < 2e-5
+
+
+def check_dgrad_mask_by_activated(dev, dtype, N=1, Cin=32, Cout=32, dhw=(8, 16, 8), seed=41):
+    """Masked dgrad whose mask tensor is the activated a = relu(IN(x)) itself (mask_stats None) against the same launch
+    with identity statistics (mean 0, rstd 1) — the same arithmetic, so the same bits — and against torch."""
+    torch.manual_seed(seed)
+    k, pad = (3, 3, 3), (1, 1, 1)
+    a = torch.relu(torch.randn(N, Cin, *dhw))
+    al = to_cl(a, dtype).to(dev)
+    w = torch.randn(Cout, Cin, *k) * 0.1
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, ops.ACT["relu"])
+    wd = ops.pack_weights(w.to(dev), geom, 1)
+    dy = torch.randn(N, Cout, *dhw)
+    dyl = to_cl(dy, dtype).to(dev)
+    ident = torch.zeros(N, Cin, 2)
+    ident[..., 1] = 1.0
+    from cbim_amd import _lib
+    L = _lib.lib()
+    old = L.cbim_conv_r32_min_voxels(0)                   # bf16 multiples of 32: force k_conv3_r32 on this small volume
+    try:
+        g0, s0 = ops.conv_dgrad(dyl, wd, geom, mask_x=al, mask_stats=ident.to(dev))
+        g1, s1 = ops.conv_dgrad(dyl, wd, geom, mask_x=al, mask_stats=None)
+        if dtype == torch.bfloat16 and Cin % 32 == 0 and Cout % 32 == 0:
+            assert L.cbim_conv3d_last_kernel() == 1
+    finally:
+        L.cbim_conv_r32_min_voxels(old)
+    assert torch.equal(g0.cpu(), g1.cpu()) and torch.equal(s0.cpu(), s1.cpu())
+    ar = from_cl(al.cpu())
+    wr = w.to(dtype).float() if dtype == torch.bfloat16 else w
+    xin = torch.zeros(N, Cin, *dhw, requires_grad=True)
+    F.conv3d(xin, wr, None, 1, pad).backward(from_cl(dyl.cpu()).contiguous())
+    ref = xin.grad * (ar > 0)
+    assert relerr(from_cl(g1.cpu()), ref) < tol(dtype, 1e-5, 1e-2)
+    assert relerr(s1.cpu()[..., 0], ref.mean((2, 3, 4))) < tol(dtype, 1e-4, 2e-2)
+    assert relerr(s1.cpu()[..., 1], (ref * ar).mean((2, 3, 4))) < tol(dtype, 1e-4, 2e-2)

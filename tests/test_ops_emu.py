@@ -235,3 +235,10 @@ def test_layernorm_token_rows(dev):
     oc.check_layernorm(dev, rows=(5, 3), C=768, out_bf16=True)
     oc.check_layernorm(dev, rows=(9,), C=1536)
     oc.check_layernorm(dev, rows=(4,), C=3072, affine=True)
+
+
+def test_dgrad_masked_by_the_activated_tensor(dev):
+    import torch
+    oc.check_dgrad_mask_by_activated(dev, torch.bfloat16)                                  # k_conv3_r32, single chunk
+    oc.check_dgrad_mask_by_activated(dev, torch.bfloat16, Cin=64, Cout=32, dhw=(8, 8, 16))   # k_conv3_r32, several chunks
+    oc.check_dgrad_mask_by_activated(dev, torch.float32, Cin=8, Cout=12, dhw=(5, 6, 7))      # k_conv_igemm
