@@ -100,7 +100,11 @@ __device__ __forceinline__ void r_dma16(const unsigned char* gsrc, unsigned char
   // inline asm on purpose (conv_igemm.hip dma16): the compiler must not treat LGKM as out of order
   unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
   a = __builtin_amdgcn_readfirstlane(a);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc) : "memory", "m0");
+  // M0 (the LDS base of the instruction) is saved and restored INSIDE the statement: no reserved register in the clobber
+  // list (clang: "may lead to undefined behaviour"), nothing about M0 is hidden from the compiler
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(a), "v"(gsrc) : "memory");
 #endif
 }
 __device__ __forceinline__ void r_wait_vm0() {
