@@ -489,7 +489,7 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
     CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "wgrad workspace %zu < %zu", ws_bytes, need);
     g_last_wgrad_kernel = 1;
     if (int rc = cbim_wgrad_r32_launch(d, x, x_stride, x2, x2_stride, cin_split, dy, dy_stride, dy2, dy2_stride, cout_split,
-                                       (float*)workspace, stream))
+                                       (float*)workspace, dw, stream))
       return rc;
     return cbim_wgrad_r32_reduce(d, (const float*)workspace, dw, stream);
   }

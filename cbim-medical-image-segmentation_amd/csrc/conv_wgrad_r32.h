@@ -9,11 +9,12 @@
 // the caller materialised act(IN(x)) once), optional second input / second dy tensor split at multiples of 32
 bool cbim_wgrad_r32_eligible(const cbim_conv_desc* d, const float* in_stats, const void* x2, int cin_split, const void* dy2,
                              int cout_split);
-// strips (= fp32 slabs [27][Cout][Cin] in the workspace) the launch writes; the caller reduces them in fixed order
+// strips (= fp32 slabs [Cout][Cin][27] in the workspace) the launch writes; the caller reduces them in fixed order
+// (cbim_wgrad_r32_reduce; a single strip writes dw directly)
 int cbim_wgrad_r32_strips(const cbim_conv_desc* d);
 size_t cbim_wgrad_r32_workspace(const cbim_conv_desc* d);
 int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
                           int cin_split, const void* dy, int64_t dy_stride, const void* dy2, int64_t dy2_stride,
-                          int cout_split, float* workspace, void* stream);
+                          int cout_split, float* workspace, float* dw, void* stream);
 // fixed-order sum of the strips' slabs into dw[co][ci][tap] (fp32, natural nn.Conv3d layout)
 int cbim_wgrad_r32_reduce(const cbim_conv_desc* d, const float* workspace, float* dw, void* stream);

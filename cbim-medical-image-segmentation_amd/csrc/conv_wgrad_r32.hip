@@ -316,46 +316,55 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
     advance(nxt);
   }
 
-  // ---- the two row groups of a quadrant hold partial sums of the same (tap, co, ci): add them through LDS in fixed
-  //      order (vg 0 + vg 1) and write this strip's slab ws[strip][tap][Cout_pad][Cin_pad] --------------------------------
-  float* red = (float*)smem;                                           // [quadrant][tap][r][lane], 108 KiB
+  // ---- the two row groups of a quadrant hold partial sums of the same (tap, co, ci): they meet in an LDS tile laid out
+  //      like the gradient itself, T[co][ci][tap] (vg 1 stores, vg 0 adds: fixed order), and the tile leaves as 32 rows
+  //      of 864 contiguous floats — into this strip's slab ws[strip][Cout][Cin][27], or straight into dw when the launch
+  //      has a single strip (no reduce kernel then) ----------------------------------------------------------------------
+  float* T = (float*)smem;                                              // 32 x 32 x 27 floats = 108 KiB (the halos are dead)
+  const int t_ci = 16 * cih + lv;
   if (vg == 1) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-      for (int tp = 0; tp < 27; ++tp)
+      for (int r = 0; r < 4; ++r) {
+        float* row = T + ((16 * (ch0 + c) + 4 * lq + r) * 32 + t_ci) * 27;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(((2 * cih + ch0 + c) * 27 + tp) * 4 + r) * 64 + lane] = acc[c][tp][r];
+        for (int tp = 0; tp < 27; ++tp) row[tp] = acc[c][tp][r];
+      }
   }
   __syncthreads();
   if (vg == 0) {
-    const size_t slab = (size_t)27 * p.Cout_pad * p.Cin_pad;
-    float* wsb = p.ws + (size_t)lb * slab;
-    const int ci = ib * 32 + 16 * cih + lv;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-      for (int tp = 0; tp < 27; ++tp)
+      for (int r = 0; r < 4; ++r) {
+        float* row = T + ((16 * (ch0 + c) + 4 * lq + r) * 32 + t_ci) * 27;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = cb * 32 + 16 * (ch0 + c) + 4 * lq + r;
-          wsb[((size_t)tp * p.Cout_pad + co) * p.Cin_pad + ci] = acc[c][tp][r] + red[(((2 * cih + ch0 + c) * 27 + tp) * 4 + r) * 64 + lane];
-        }
+        for (int tp = 0; tp < 27; ++tp) row[tp] += acc[c][tp][r];
+      }
+  }
+  __syncthreads();
+  {
+    const size_t total = (size_t)27 * p.Cout_pad * p.Cin_pad;
+    float* dst = p.ws + (size_t)lb * total;              // (a single strip: p.ws is dw itself)
+    constexpr int ROW4 = 32 * 27 / 4;                    // float4 per co row of the tile
+    for (int i = tid; i < 32 * ROW4; i += WR_NT) {
+      const int co = i / ROW4, k = i % ROW4;
+      *(f32x4*)(dst + ((size_t)(cb * 32 + co) * p.Cin_pad + ib * 32) * 27 + 4 * k) = *(const f32x4*)(T + co * 864 + 4 * k);
+    }
   }
 }
 
-// Fixed-order sum of the strips' slabs into the natural nn.Conv3d gradient dw[co][ci][tap].  512 threads = LW lanes x SP
-// slab phases: lane l owns 4 consecutive (tap, co, ci) values (one 16-byte load per slab), phase ph adds slabs ph, ph + SP,
-// ... in two alternating chains; the SP phase sums meet in LDS and are added in index order.  (k_wgrad_reduce walks all
-// slabs of 64 outputs with 4 phases: 19 us for the 256 slabs of a 32x32 layer; this form keeps 8-32 loads per thread in
-// flight over 400+ workgroups.)
+// Fixed-order sum of the strips' slabs (each already in the gradient's own layout [Cout][Cin][27]) into dw.  512 threads =
+// LW lanes x SP slab phases: lane l owns 4 consecutive values (one 16-byte load per slab), phase ph adds slabs ph, ph + SP,
+// ... in two alternating chains; the SP phase sums meet in LDS and are added in phase order.
 template <int SP>
 __global__ void __launch_bounds__(512) k_wgrad_r32_reduce(const float* __restrict__ ws, float* __restrict__ dw, int n_slabs,
-                                                          int Cout, int Cin, int64_t total) {
+                                                          int64_t total) {
   constexpr int LW = 512 / SP;
   __shared__ f32x4 red[512];
   const int l = threadIdx.x % LW, ph = threadIdx.x / LW;
-  const int64_t i = ((int64_t)blockIdx.x * LW + l) * 4;       // first of this lane's 4 values: ((tap * Cout + co) * Cin + ci)
+  const int64_t i = ((int64_t)blockIdx.x * LW + l) * 4;
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   if (i < total) {
     const float* src = ws + i;
@@ -374,11 +383,7 @@ __global__ void __launch_bounds__(512) k_wgrad_r32_reduce(const float* __restric
     f32x4 r = red[l];
 #pragma unroll
     for (int q = 1; q < SP; ++q) r += red[q * LW + l];
-    const int ci = (int)(i % Cin);
-    const int64_t t2 = i / Cin;
-    const int co = (int)(t2 % Cout), tap = (int)(t2 / Cout);
-    float* o = dw + ((size_t)co * Cin + ci) * 27 + tap;
-    o[0] = r.x; o[27] = r.y; o[54] = r.z; o[81] = r.w;
+    *(f32x4*)(dw + i) = r;
   }
 }
 
@@ -451,12 +456,12 @@ size_t cbim_wgrad_r32_workspace(const cbim_conv_desc* d) {
 
 int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
                           int cin_split, const void* dy, int64_t dy_stride, const void* dy2, int64_t dy2_stride,
-                          int cout_split, float* workspace, void* stream) {
+                          int cout_split, float* workspace, float* dw, void* stream) {
   WR32Params p;
   p.x = x; p.x_stride = x_stride; p.x2 = x2; p.x2_stride = x2 ? x2_stride : x_stride; p.ci_split = x2 ? cin_split / 32 : d->Cin / 32;
   p.dy = dy; p.dy_stride = dy_stride; p.dy2 = dy2; p.dy2_stride = dy2 ? dy2_stride : dy_stride;
   p.co_split = dy2 ? cout_split / 32 : d->Cout / 32;
-  p.ws = workspace;
+  p.ws = cbim_wgrad_r32_strips(d) == 1 ? dw : workspace;     // a single strip writes the gradient itself
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
   wr32_tiles(d, p.tiles_d, p.tiles_h, p.tiles_w);
   p.ci_blocks = d->Cin / 32; p.Cout_pad = d->Cout; p.Cin_pad = d->Cin;
@@ -488,20 +493,20 @@ int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stri
 
 int cbim_wgrad_r32_reduce(const cbim_conv_desc* d, const float* workspace, float* dw, void* stream) {
   const int G = cbim_wgrad_r32_strips(d);
+  if (G == 1) return CBIM_OK;                                // the single strip wrote dw itself (cbim_wgrad_r32_launch)
   const int64_t total = (int64_t)27 * d->Cout * d->Cin;      // a multiple of 4 (Cin is a multiple of 32)
   hipStream_t st = (hipStream_t)stream;
 #define WR_RED(SPV)                                                                                              \
   do {                                                                                                           \
     const int64_t per = (int64_t)(512 / SPV) * 4;                                                                \
     CBIM_LAUNCH((k_wgrad_r32_reduce<SPV>), dim3((unsigned)((total + per - 1) / per)), dim3(512), 0, st, workspace, dw, G, \
-                d->Cout, d->Cin, total);                                                                         \
+                total);                                                                                          \
   } while (0)
   if (G >= 32) WR_RED(32);
   else if (G >= 16) WR_RED(16);
   else if (G >= 8) WR_RED(8);
   else if (G >= 4) WR_RED(4);
-  else if (G >= 2) WR_RED(2);
-  else WR_RED(1);
+  else WR_RED(2);
 #undef WR_RED
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "wgrad r32 reduce launch: %s", hipGetErrorString(e));

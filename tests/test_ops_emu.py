@@ -221,6 +221,7 @@ def test_wgrad_r32_accumulators_in_registers(dev):
             oc.check_wgrad_r32(dev)
             oc.check_wgrad_r32(dev, N=2, Cin=64, Cout=64, dhw=(9, 11, 17), split=32)
         oc.check_wgrad_r32(dev, N=1, Cin=96, Cout=32, dhw=(8, 8, 24), xsplit=32)
+        oc.check_wgrad_r32(dev, N=1, Cin=64, Cout=32, dhw=(8, 8, 8))      # one tile = one strip: written straight into dw
     finally:
         L.cbim_wgrad_r32_waves(8)
 
