@@ -386,7 +386,7 @@ def main():
                      "frac_of_peak": v[0] / v[1] / 1e12 / peak} for k, v in per.items()}
         # the dominant kernel = the MFMA conv kernel with the largest share of the step (forward/dgrad kernels; the wgrad
         # entry sums k_conv_wgrad and its reduce)
-        dom = max((k for k in per if k.startswith(("k_conv_igemm", "k_conv3_r32"))), key=lambda k: per[k][1])
+        dom = max((k for k in per if k.startswith(("k_conv_igemm", "k_conv3_r32", "k_wgrad_r32"))), key=lambda k: per[k][1])
         f, tsec, nl = per[dom]
         fwd128 = {"medformer": FWD_FLOPS_128_MEDFORMER, "swin_unetr": FWD_FLOPS_128_SWIN,
                   "resunet": FWD_FLOPS_128 * (args.base / 32.0) ** 2}[args.model]
@@ -394,7 +394,7 @@ def main():
         # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run
         # inside this process); null when no recorded pass covers this kernel / dtype / model
         traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in ("r02_traffic.json", "r01_j_traffic.json", "r01_c_traffic.json"))
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in ("r03_traffic.json", "r02_traffic.json", "r01_j_traffic.json", "r01_c_traffic.json"))
                       if os.path.isfile(q)), "")
         if args.model == "resunet" and args.size == 128 and os.path.isfile(tpath):
             traffic = (json.load(open(tpath)).get(dom) or {}).get("hbm_bytes_per_launch")
