@@ -54,13 +54,10 @@ struct WR32Params {
   int dbg;   // timing ablations for tools/ (env CBIM_WR32_DBG, wrong results); 0 in production
 };
 
-// timing ablations of tools/wr32_ablate.py (wrong results): compiled in only with `make EXTRA=-DCBIM_WR32_DBG_RT` (as run-time
-// tests they are ~300 scalar branches per tile that cut the MFMA loop into basic blocks: +12 % kernel time, measured)
-#ifdef CBIM_WR32_DBG_RT
-#define WR_DBG (p.dbg)
-#else
-#define WR_DBG 0
-#endif
+// timing ablations of tools/wr32_ablate.py (wrong results): a COMPILE-TIME parameter of the kernel (as run-time tests they
+// were ~300 scalar branches per tile that cut the MFMA loop into basic blocks: +12 % kernel time, measured); the ablated
+// instantiations exist only in builds with `make EXTRA=-DCBIM_WR32_ABLATE`
+#define WR_DBG DBG
 #ifdef CBIM_EMU
 #define WR_SCHED_FENCE() ((void)0)
 #define WR_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
@@ -123,7 +120,7 @@ __device__ __forceinline__ unsigned wr_swz(unsigned h) { return (h & 1u) << 1; }
 
 typedef __attribute__((ext_vector_type(4))) float wr_f32x4;
 
-template <int WV>
+template <int WV, int DBG = 0>
 __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
   constexpr int WR_NT = WV * 64;
   constexpr int NCH = WV == 8 ? 1 : 2;                                // co halves per wave
@@ -296,6 +293,9 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
 #pragma unroll
           for (int kd = 0; kd < 3; ++kd) {
             const int i = pl - kd;
+#ifndef CBIM_EMU
+            if (WR_DBG & 8) asm volatile("" ::"v"(xr[e % RING]));   // (ablation: the fragment reads stay alive without the MFMAs)
+#endif
             if (i >= 0 && i < 8 && !(WR_DBG & 8)) {
               const int tap = (kd * 3 + kh) * 3 + kw;
 #pragma unroll
@@ -484,6 +484,16 @@ int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stri
   }
 #endif
   dim3 grid((unsigned)cbim_wgrad_r32_strips(d), (unsigned)((d->Cout / 32) * (d->Cin / 32)));
+#ifdef CBIM_WR32_ABLATE
+#define WR_ABL(W, D)                                                                                                   \
+  if (wr32_waves() == W && p.dbg == D) {                                                                               \
+    (void)hipFuncSetAttribute((const void*)k_wgrad_r32<W, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    CBIM_LAUNCH((k_wgrad_r32<W, D>), grid, dim3(W * 64), (size_t)WR_SMEM, (hipStream_t)stream, p);                     \
+  } else
+  WR_ABL(8, 1) WR_ABL(8, 2) WR_ABL(8, 4) WR_ABL(8, 8) WR_ABL(8, 5) WR_ABL(8, 9) WR_ABL(8, 12) WR_ABL(8, 13) WR_ABL(8, 3)
+  WR_ABL(4, 1) WR_ABL(4, 2) WR_ABL(4, 4) WR_ABL(4, 8) WR_ABL(4, 5) WR_ABL(4, 9) WR_ABL(4, 12) WR_ABL(4, 13) WR_ABL(4, 3)
+#undef WR_ABL
+#endif
   if (wr32_waves() == 4) CBIM_LAUNCH(k_wgrad_r32<4>, grid, dim3(256), (size_t)WR_SMEM, (hipStream_t)stream, p);
   else CBIM_LAUNCH(k_wgrad_r32<8>, grid, dim3(512), (size_t)WR_SMEM, (hipStream_t)stream, p);
   hipError_t e = CBIM_LAST_LAUNCH();
