@@ -58,6 +58,16 @@ struct WR32Params {
 // were ~300 scalar branches per tile that cut the MFMA loop into basic blocks: +12 % kernel time, measured); the ablated
 // instantiations exist only in builds with `make EXTRA=-DCBIM_WR32_ABLATE`
 #define WR_DBG DBG
+// tuning knobs (tools/run_wr32_variants.sh builds and times the alternatives)
+#ifndef WR32_RING
+#define WR32_RING 5          // input-fragment reads in flight ahead of their MFMAs (+1)
+#endif
+#ifndef WR32_DMA_STEPS
+#define WR32_DMA_STEPS 0     // 0: the next halo is requested two pieces per (kh, kw) step from step 0; n > 0: one piece per step from step n
+#endif
+#ifndef WR32_SETPRIO
+#define WR32_SETPRIO 0       // 1: raise the wave's priority around each MFMA group
+#endif
 #ifdef CBIM_EMU
 #define WR_SCHED_FENCE() ((void)0)
 #define WR_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
@@ -267,7 +277,7 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
     // (B) 9 (kh, kw) steps: the 10 halo-plane fragments stream through a ring of 5 registers; plane p feeds the taps
     //     (kd 0, dy plane p), (kd 1, p-1), (kd 2, p-2).  The next tile's halo is fetched during the first four steps.
     if (!(WR_DBG & 2)) {
-      constexpr int RING = 5, PLN = 10, SEQ = 9 * PLN;
+      constexpr int RING = WR32_RING, PLN = 10, SEQ = 9 * PLN;
       u32x4 xr[RING];
       auto frag = [&](int e) -> u32x4 {                                // e = (kh*3 + kw) * PLN + plane
         const int pl = e % PLN, s = e / PLN;
@@ -281,15 +291,26 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
         const int kh = s / 3, kw = s % 3;
-        if (more && 2 * s < UH && !(WR_DBG & 1)) {
-          dma_halo(nxt, 2 * s, obuf);
-          dma_halo(nxt, 2 * s + 1, obuf);
+        if (WR32_DMA_STEPS == 0) {
+          if (more && 2 * s < UH && !(WR_DBG & 1)) {
+            dma_halo(nxt, 2 * s, obuf);
+            dma_halo(nxt, 2 * s + 1, obuf);
+          }
+        } else if (more && !(WR_DBG & 1)) {           // one piece per step; the ninth step takes what is left
+          if (s < UH) dma_halo(nxt, s, obuf);
+          if (s == 8) {
+#pragma unroll
+            for (int u = 9; u < UH; ++u) dma_halo(nxt, u, obuf);
+          }
         }
 #pragma unroll
         for (int pl = 0; pl < PLN; ++pl) {
           const int e = s * PLN + pl;
           if (e + RING - 1 < SEQ && !(WR_DBG & 4)) xr[(e + RING - 1) % RING] = frag(e + RING - 1);
           WR_SCHED_FENCE();
+#if WR32_SETPRIO && !defined(CBIM_EMU)
+          __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
           for (int kd = 0; kd < 3; ++kd) {
             const int i = pl - kd;
@@ -304,6 +325,9 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
                                                                       acc[c][tap], 0, 0, 0);
             }
           }
+#if WR32_SETPRIO && !defined(CBIM_EMU)
+          __builtin_amdgcn_s_setprio(0);
+#endif
           WR_SCHED_FENCE();
         }
       }

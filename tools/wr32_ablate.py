@@ -9,7 +9,7 @@ import torch
 import cbim_amd
 from cbim_amd import ops, _lib
 dtype = torch.bfloat16
-def timeit(fn, reps=10):
+def timeit(fn, reps=30):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,7 +25,7 @@ gf = 2.0 * s ** 3 * cin * cout * 27 / 1e9
 L = _lib.lib()
 for wv in (8, 4):
     L.cbim_wgrad_r32_waves(wv)
-    for dbg in (0, 0, 1, 2, 3, 4, 5, 8, 9, 12, 13):
+    for dbg in ((0, 0, 0) if os.environ.get("WR_ONLY0") else (0, 0, 1, 2, 3, 4, 5, 8, 9, 12, 13)):
         os.environ["CBIM_WR32_DBG"] = str(dbg)
         t = timeit(lambda: ops.conv_wgrad(x, None, dy, geom))
         print(f"waves={wv} dbg={dbg:2d}: {t:7.1f} us  ({gf / t * 1e3:6.0f} TF/s)", flush=True)
