@@ -245,12 +245,24 @@ class up_block(nn.Module):
         self.conv_blocks = nn.Sequential(*convs)
 
     def forward(self, low: Fn.FMap, skip: Fn.FMap, map1, map2=None):
-        f = Fn.FMap(*Fn.UpCatFn.apply(low.t, skip.t, False, True))   # concat + InstanceNorm statistics in one pass
         if self.map_shortcut and map2 is not None:
             semantic_map = pointwise(self.map_reduction, torch.cat([map1, map2], dim=1))
         else:
             semantic_map = map1
-        f, semantic_map = self.trans_blocks(f, semantic_map)
-        for blk in self.conv_blocks:
+        convs = list(self.conv_blocks)
+        if len(self.trans_blocks.blocks) == 0 and convs and Fn.fused_up_block(convs[0]):
+            # conv-only decoder level (up3 / up4 of the shipped configs): the first block reads
+            # a = relu(IN([up(low) | skip])) written in one pass; the concatenation is never stored
+            first = convs[0]
+            skip = Fn.ensure_stats(skip)
+            want = len(convs) > 1
+            out, so = Fn.UpBlockFirstFn.apply(low.t, skip.t, skip.stats, first.conv1.conv.weight, first.conv2.conv.weight,
+                                              first.shortcut.conv.weight, first.conv1.act_code, want, False)
+            f = Fn.FMap(out, so if want else None)
+            convs = convs[1:]
+        else:
+            f = Fn.FMap(*Fn.UpCatFn.apply(low.t, skip.t, False, True))   # concat + InstanceNorm statistics in one pass
+            f, semantic_map = self.trans_blocks(f, semantic_map)
+        for blk in convs:
             f = blk(f)
         return f, semantic_map
