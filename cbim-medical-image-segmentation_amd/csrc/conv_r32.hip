@@ -129,6 +129,23 @@ __device__ __forceinline__ unsigned r_mul24(unsigned a, unsigned b) {
 // two h rows of the wave's patch and two k-groups; keys 0 / 2 on alternating rows give it 16 distinct cells of the
 // 256-byte bank window (key hh & 3, right for the 4-row patches of conv_igemm.hip, measured 37 % conflict cycles here)
 __device__ __forceinline__ unsigned r_swz(unsigned hh) { return (hh & 1u) << 1; }
+// partner value of the butterfly step `msk` (1, 2, 4, 8, 16) of an all-reduce SUM over 32 lanes.  Steps 1 and 2 are quad
+// permutes, steps 4 and 8 the half-row / row mirrors of the data-parallel-primitive path (vector-ALU rate): after steps 1, 2
+// the four lanes of a quad hold the same value, so the mirror partner (other quad, any lane) is as good as lane ^ 4 —
+// bit-identical to the xor butterfly; only step 16 crosses 16-lane rows and goes through the LDS crossbar.  (All five
+// steps as ds_bpermute were 85 LDS round trips per tile in the multi-chunk epilogues.)
+template <int MSK>
+__device__ __forceinline__ float r_bfly(float v) {
+#ifdef CBIM_EMU
+  return __shfl_xor(v, MSK, 64);
+#else
+  if (MSK == 16) return __shfl_xor(v, 16, 64);
+  constexpr int ctrl = MSK == 1 ? 0xB1 : MSK == 2 ? 0x4E : MSK == 4 ? 0x141 : 0x140;   // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false));
+#endif
+}
+#define R_BFLY_ROUNDS(...) { constexpr int msk = 1; __VA_ARGS__ } { constexpr int msk = 2; __VA_ARGS__ } { constexpr int msk = 4; __VA_ARGS__ } { constexpr int msk = 8; __VA_ARGS__ } { constexpr int msk = 16; __VA_ARGS__ }
+
 // exchange between 16-lane rows: a's odd rows (lanes 16..31, 48..63) <-> b's even rows (lanes 0..15, 32..47)
 // (v_permlane16_swap_b32)
 __device__ __forceinline__ void r_swap16(float& a, float& b) {
@@ -374,16 +391,13 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
   // epilogue — once per NC units — and merged into the wave's running record in LDS (red, wave-private).
   auto tile_stats = [&](float (&t0)[8], float (&t1)[8], const float (&tsh)[MX ? 1 : 8], float tcnt) {
     float* red = (float*)(smem + red_base);
-#pragma unroll
-    for (int msk = 1; msk < 32; msk <<= 1) {
+    R_BFLY_ROUNDS(
       float u0[8], u1[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { u0[j] = __shfl_xor(t0[j], msk, 64); u1[j] = __shfl_xor(t1[j], msk, 64); }
-      const float tc = __shfl_xor(tcnt, msk, 64);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { t0[j] += u0[j]; t1[j] += u1[j]; }
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { u0[j] = r_bfly<msk>(t0[j]); u1[j] = r_bfly<msk>(t1[j]); }
+      const float tc = r_bfly<msk>(tcnt);
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { t0[j] += u0[j]; t1[j] += u1[j]; }
       tcnt += tc;
-    }
+    )
     if ((lane & 31) == 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -402,16 +416,13 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     __syncthreads();
     float* red = (float*)(smem + red_base);
     if (!LS) {
-#pragma unroll
-    for (int msk = 1; msk < 32; msk <<= 1) {   // lanes differing in bits 0..4 (voxel, lq & 1) hold the same channels
+    R_BFLY_ROUNDS(                             // lanes differing in bits 0..4 (voxel, lq & 1) hold the same channels
       float t0[8], t1[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { t0[j] = __shfl_xor(s0[j], msk, 64); t1[j] = __shfl_xor(s1[j], msk, 64); }
-      const float tc = __shfl_xor(cnt, msk, 64);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s0[j] += t0[j]; s1[j] += t1[j]; }
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { t0[j] = r_bfly<msk>(s0[j]); t1[j] = r_bfly<msk>(s1[j]); }
+      const float tc = r_bfly<msk>(cnt);
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { s0[j] += t0[j]; s1[j] += t1[j]; }
       cnt += tc;
-    }
+    )
     if ((lane & 31) == 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -581,9 +592,13 @@ __global__ void __launch_bounds__(RGeom<TD>::NT, TD == 8 ? 1 : 2) k_conv3_r32(R3
     const unsigned cb = (unsigned)(oc * 4 + cidx) * 16u;
     // after the exchange this lane owns, for pair pr = (hp, pp): chunk cidx of voxel (2pp + (lq&1), th(hp), tw)
     constexpr int NPAIR = 4;                               // 8 n-tiles
+    // (the offsets below depend on the lane only: laundering the lane's plane bit keeps the compiler from hoisting the
+    //  four of them — and the 64-bit addresses built on them — out of the tile loop, where they were spilled to scratch
+    //  and reloaded in every epilogue: 12-17 spilled VGPRs in the masked multi-chunk instantiations)
+    const unsigned lq1 = r_launder((unsigned)(lq & 1));
     auto pair_rel = [&](int pr) -> unsigned {
       const int hp = pr / (TD / 2), pp = pr % (TD / 2);
-      return r_mul24(r_mul24((unsigned)(lq & 1), (unsigned)p.Ho) + (unsigned)thp[hp], (unsigned)p.Wo) + (unsigned)tw + (unsigned)pp * plane2;
+      return r_mul24(r_mul24(lq1, (unsigned)p.Ho) + (unsigned)thp[hp], (unsigned)p.Wo) + (unsigned)tw + (unsigned)pp * plane2;
     };
     auto pair_in = [&](int pr) -> bool {
       const int hp = pr / (TD / 2), pp = pr % (TD / 2);
