@@ -153,13 +153,35 @@ __global__ void __launch_bounds__(NT) k_dwconv_wgrad(const void* __restrict__ x,
 // block's chunk group sit in LDS as [tap][channel].  blockIdx.y = chunk group (DG chunks).
 static constexpr int DG = 32;   // channel chunks per block (one 512-byte bf16 row segment per voxel)
 static constexpr int WT = 4;
-template <typename T>
+// MODE: 0 raw input (dgrad; optional bias) | 1 InstanceNorm + ReLU on load | 2 InstanceNorm only | 3 InstanceNorm + run-time
+// activation.  Packed f32 pairs throughout (v_pk_add / v_pk_mul / v_pk_fma_f32): the kernel is vector-ALU bound (27 taps x 8
+// channels per output against 32 bytes of traffic), and as scalar fmaf + a run-time activation switch per element it spent
+// ~750 lane-instructions per output chunk (52 us per call on the 4x-expanded MBConv tensors of MedFormer).
+typedef float dw_f2 __attribute__((ext_vector_type(2)));
+template <typename T> struct DwPairs;
+template <> struct DwPairs<bf16_tag> {
+  static constexpr int NP = 4;
+  static __device__ __forceinline__ void unpack(const u32x4& v, dw_f2* f) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = dw_f2{__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+  }
+};
+template <> struct DwPairs<float> {
+  static constexpr int NP = 2;
+  static __device__ __forceinline__ void unpack(const u32x4& v, dw_f2* f) {
+    f[0] = dw_f2{__uint_as_float(v.x), __uint_as_float(v.y)};
+    f[1] = dw_f2{__uint_as_float(v.z), __uint_as_float(v.w)};
+  }
+};
+
+template <typename T, int MODE>
 __global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int64_t xs,
                                                 const float* __restrict__ in_stats, int act,
                                                 const float* __restrict__ bias, const float* __restrict__ w,
                                                 int flip, void* __restrict__ y, int64_t ys, int N, int D, int H, int W,
                                                 int C, int kD, int kH) {
-  constexpr int CPC = Elem<T>::CPC;
+  constexpr int CPC = Elem<T>::CPC, NP = DwPairs<T>::NP;
   __shared__ float w_s[27 * DG * CPC];
   const int cch = C / CPC;
   const int g0 = blockIdx.y * DG;
@@ -183,14 +205,18 @@ __global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int6
     const int ho = (int)(r % (unsigned)H); r /= (unsigned)H;
     const int dz = (int)(r % (unsigned)D);
     const int64_t n = r / (unsigned)D;
-    float mean[CPC], rstd[CPC], bs[CPC], acc[WT][CPC];
+    dw_f2 nmean[NP], rstd[NP], bs[NP], acc[WT][NP];
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) {
-      mean[j] = in_stats ? in_stats[((size_t)n * C + c0 + j) * 2] : 0.f;
-      rstd[j] = in_stats ? in_stats[((size_t)n * C + c0 + j) * 2 + 1] : 1.f;
-      bs[j] = bias ? bias[(size_t)n * C + c0 + j] : 0.f;
+    for (int j = 0; j < NP; ++j) {
+      nmean[j] = dw_f2{0.f, 0.f}; rstd[j] = dw_f2{1.f, 1.f}; bs[j] = dw_f2{0.f, 0.f};
+      if (MODE != 0) {
+        const float* st = in_stats + ((size_t)n * C + c0 + 2 * j) * 2;
+        nmean[j] = dw_f2{-st[0], -st[2]};
+        rstd[j] = dw_f2{st[1], st[3]};
+      }
+      if (bias) bs[j] = dw_f2{bias[(size_t)n * C + c0 + 2 * j], bias[(size_t)n * C + c0 + 2 * j + 1]};
 #pragma unroll
-      for (int o = 0; o < WT; ++o) acc[o][j] = 0.f;
+      for (int o = 0; o < WT; ++o) acc[o][j] = dw_f2{0.f, 0.f};
     }
     for (int a = 0; a < kD; ++a) {
       const int dd = dz + a - pD;
@@ -202,46 +228,52 @@ __global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int6
         // one 64-bit row pointer per (kd,kh); the WT+2 chunks are xs elements apart
         const unsigned char* rp = (const unsigned char*)x + ((int64_t)(rbase + w0 - 1) * xs + c0) * (int64_t)Elem<T>::SIZE;
         const unsigned xsb = (unsigned)xs * Elem<T>::SIZE;
-        float in[WT + 2][CPC];
+        dw_f2 in[WT + 2][NP];
 #pragma unroll
         for (int q = 0; q < WT + 2; ++q) {
           const int ww = w0 - 1 + q;
           if (ww >= 0 && ww < W) {
-            Elem<T>::unpack(*(const u32x4*)(rp + (size_t)q * xsb), in[q]);
+            DwPairs<T>::unpack(*(const u32x4*)(rp + (size_t)q * xsb), in[q]);
 #pragma unroll
-            for (int j = 0; j < CPC; ++j) {
-              float v = in[q][j];
-              if (in_stats) v = act_fwd((v - mean[j]) * rstd[j], act);
+            for (int j = 0; j < NP; ++j) {
+              dw_f2 v = in[q][j];
+              if (MODE != 0) {
+                v = (v + nmean[j]) * rstd[j];
+                if (MODE == 1) v = __builtin_elementwise_max(v, dw_f2{0.f, 0.f});
+                if (MODE == 3) v = dw_f2{act_fwd(v.x, act), act_fwd(v.y, act)};
+              }
               in[q][j] = v + bs[j];
             }
           } else {
 #pragma unroll
-            for (int j = 0; j < CPC; ++j) in[q][j] = 0.f;
+            for (int j = 0; j < NP; ++j) in[q][j] = dw_f2{0.f, 0.f};
           }
         }
         const float* wt = w_s + ((a * kH + b) * 3) * (DG * CPC) + cl * CPC;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float wv[CPC];
+          dw_f2 wv[NP];
 #pragma unroll
-          for (int j = 0; j < CPC; ++j) wv[j] = wt[c * (DG * CPC) + j];
+          for (int j = 0; j < NP; ++j) wv[j] = dw_f2{wt[c * (DG * CPC) + 2 * j], wt[c * (DG * CPC) + 2 * j + 1]};
 #pragma unroll
           for (int o = 0; o < WT; ++o)
 #pragma unroll
-            for (int j = 0; j < CPC; ++j) acc[o][j] = fmaf(in[o + c][j], wv[j], acc[o][j]);   // 27 taps x 8 channels per output: VALU-bound, mul+add would double it
+            for (int j = 0; j < NP; ++j) acc[o][j] = __builtin_elementwise_fma(in[o + c][j], wv[j], acc[o][j]);
         }
       }
     }
     const size_t obase = (((size_t)n * D + dz) * H + ho) * W;
 #pragma unroll
     for (int o = 0; o < WT; ++o)
-      if (w0 + o < W) st_chunk<T>(y, (obase + w0 + o) * ys + c0, Elem<T>::pack(acc[o]));
+      if (w0 + o < W) {
+        float f[CPC];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { f[2 * j] = acc[o][j].x; f[2 * j + 1] = acc[o][j].y; }
+        st_chunk<T>(y, (obase + w0 + o) * ys + c0, Elem<T>::pack(f));
+      }
   }
 }
 
-// depthwise weight gradient, kW == 3: thread = (channel chunk, row lane); for each (kd,kh) pair it sweeps
-// its rows with a 3-wide sliding window over W (1 new x chunk + 1 dy chunk per voxel, 24 accumulators),
-// then the row lanes are summed through LDS and the block writes its partial [C][T] slab.
 template <typename T>
 __global__ void __launch_bounds__(NT) k_dwconv3_wgrad(const void* __restrict__ x, int64_t xs,
                                                       const float* __restrict__ in_stats, int act,
@@ -339,13 +371,13 @@ __global__ void __launch_bounds__(NT) k_dwconv3_wgrad(const void* __restrict__ x
 // gradient of TH rows x all W of one depth slice for WG_CH channel chunks ONCE, then thread (chunk, tap)
 // accumulates its tap over the tile from LDS — every global byte is read once per tile instead of once per
 // (kd,kh) pair.  Partials [tile][C][27] are summed in tile order by k_dwconv_wgrad_reduce.
-static constexpr int WG_CH = 8;   // channel chunks per workgroup (128 bytes of bf16 / fp32 channels per voxel)
+static constexpr int WG_CH_MAX = 8;   // channel chunks per workgroup: 8, or 4 / 2 where a row of 8 does not fit the LDS budget (W >= 64)
 template <typename T>
 __global__ void __launch_bounds__(NT) k_dwconv3_wgrad_lds(const void* __restrict__ x, int64_t xs,
                                                           const float* __restrict__ in_stats, int act,
                                                           const void* __restrict__ dy, int64_t dys,
                                                           const float* __restrict__ dy_bias, float* __restrict__ part,
-                                                          int N, int D, int H, int W, int C, int TH) {
+                                                          int N, int D, int H, int W, int C, int TH, int WG_CH) {
   constexpr int CPC = Elem<T>::CPC;
   CBIM_DYN_SMEM(smem);
   const int cch = C / CPC;
@@ -403,36 +435,44 @@ __global__ void __launch_bounds__(NT) k_dwconv3_wgrad_lds(const void* __restrict
   const int ab = rem / 3, rs = rem % 3;
   const int ka = ab / 3, kb = ab % 3;
   const bool active = cl < G;
-  float acc[3][CPC];
+  // packed f32 pairs (v_pk_fma_f32): 12 instead of 24 multiply-add instructions per LDS read pair
+  constexpr int NP2 = CPC / 2;
+  dw_f2 acc2[3][NP2];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) acc[c][j] = 0.f;
+    for (int j = 0; j < NP2; ++j) acc2[c][j] = dw_f2{0.f, 0.f};
   if (active) {
     for (int r = rs; r < TH; r += 3) {
-      const float* xr = x_s + ((size_t)((ka * hH + r + kb) * hW) * WG_CH + cl) * CPC;
-      const float* gr = g_s + ((size_t)(r * W) * WG_CH + cl) * CPC;
-      float x0[CPC], x1[CPC];
+      const dw_f2* xr = (const dw_f2*)(x_s + ((size_t)((ka * hH + r + kb) * hW) * WG_CH + cl) * CPC);
+      const dw_f2* gr = (const dw_f2*)(g_s + ((size_t)(r * W) * WG_CH + cl) * CPC);
+      const int RS = WG_CH * CPC / 2;                     // pairs per LDS voxel row
+      dw_f2 x0[NP2], x1[NP2];
 #pragma unroll
-      for (int j = 0; j < CPC; ++j) { x0[j] = xr[j]; x1[j] = xr[(size_t)WG_CH * CPC + j]; }
+      for (int j = 0; j < NP2; ++j) { x0[j] = xr[j]; x1[j] = xr[RS + j]; }
       for (int w = 0; w < W; ++w) {
-        float x2[CPC], g[CPC];
+        dw_f2 x2[NP2], g[NP2];
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) {
-          x2[j] = xr[(size_t)(w + 2) * WG_CH * CPC + j];
-          g[j] = gr[(size_t)w * WG_CH * CPC + j];
+        for (int j = 0; j < NP2; ++j) {
+          x2[j] = xr[(size_t)(w + 2) * RS + j];
+          g[j] = gr[(size_t)w * RS + j];
         }
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) {
-          acc[0][j] = fmaf(x0[j], g[j], acc[0][j]);
-          acc[1][j] = fmaf(x1[j], g[j], acc[1][j]);
-          acc[2][j] = fmaf(x2[j], g[j], acc[2][j]);
+        for (int j = 0; j < NP2; ++j) {
+          acc2[0][j] = __builtin_elementwise_fma(x0[j], g[j], acc2[0][j]);
+          acc2[1][j] = __builtin_elementwise_fma(x1[j], g[j], acc2[1][j]);
+          acc2[2][j] = __builtin_elementwise_fma(x2[j], g[j], acc2[2][j]);
           x0[j] = x1[j];
           x1[j] = x2[j];
         }
       }
     }
   }
+  float acc[3][CPC];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < NP2; ++j) { acc[c][2 * j] = acc2[c][j].x; acc[c][2 * j + 1] = acc2[c][j].y; }
   __syncthreads();                       // x_s is dead: reuse it for the row-third partials [NT][3][CPC]
   float* red = x_s;
 #pragma unroll
@@ -1064,8 +1104,12 @@ extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const f
     int64_t cap = 4096 / groups > 1 ? 4096 / groups : 1;
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
-    DISPATCH_T(dtype, k_dwconv3, dim3((unsigned)bx, groups), (hipStream_t)stream, x, x_stride, in_stats, act, bias, w, flip,
-               y, y_stride, N, D, H, W, C, kD, kH);
+    const int mode = !in_stats ? 0 : act == CBIM_ACT_RELU ? 1 : act == CBIM_ACT_NONE ? 2 : 3;
+#define DW3_LAUNCH(TT, MM) CBIM_LAUNCH((k_dwconv3<TT, MM>), dim3((unsigned)bx, groups), dim3(NT), 0, (hipStream_t)stream, x, x_stride, in_stats, act, \
+                                       bias, w, flip, y, y_stride, N, D, H, W, C, kD, kH)
+    if (dtype == CBIM_BF16) { if (mode == 0) DW3_LAUNCH(bf16_tag, 0); else if (mode == 1) DW3_LAUNCH(bf16_tag, 1); else if (mode == 2) DW3_LAUNCH(bf16_tag, 2); else DW3_LAUNCH(bf16_tag, 3); }
+    else { if (mode == 0) DW3_LAUNCH(float, 0); else if (mode == 1) DW3_LAUNCH(float, 1); else if (mode == 2) DW3_LAUNCH(float, 2); else DW3_LAUNCH(float, 3); }
+#undef DW3_LAUNCH
     return launch_ok("dwconv3d");
   }
   int64_t total = (int64_t)N * D * H * W * (C / cpc);
@@ -1075,13 +1119,13 @@ extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const f
 }
 
 // LDS-tiled 3x3x3 path: rows of h per tile so that the fp32 halo + gradient tiles fit ~120 KiB
-static size_t dw3_lds_bytes(int W, int TH, int cpc) {
+static size_t dw3_lds_bytes(int W, int TH, int cpc, int WG_CH) {
   size_t b = ((size_t)3 * (TH + 2) * (W + 2) + (size_t)TH * W) * WG_CH * cpc * 4;
   const size_t red = (size_t)NT * 3 * cpc * 4;     // row-third partials re-use the front of the buffer
   return b > red ? b : red;
 }
 static constexpr int64_t DW3_LDS_BUDGET = 120 * 1024;   // of 160 KiB per CU
-static int dw3_lds_th(int H, int W, int cpc) {
+static int dw3_lds_th(int H, int W, int cpc, int WG_CH) {
   // signed: two halo rows alone exceed the budget for W >= 79 (bf16) / W >= 159 (fp32) -> 0 -> streaming kernel
   const int64_t per_row_x = (int64_t)3 * (W + 2) * WG_CH * cpc * 4, per_row_g = (int64_t)W * WG_CH * cpc * 4;
   const int64_t room = DW3_LDS_BUDGET - 2 * per_row_x;
@@ -1089,7 +1133,7 @@ static int dw3_lds_th(int H, int W, int cpc) {
   int64_t th = room / (per_row_x + per_row_g);
   if (th > H) th = H;
   if (th > 8) th = 8;
-  if (th < 1 || (int64_t)dw3_lds_bytes(W, (int)th, cpc) > 160 * 1024) return 0;
+  if (th < 1 || (int64_t)dw3_lds_bytes(W, (int)th, cpc, WG_CH) > 160 * 1024) return 0;
   return (int)th;   // 0: does not fit, use the streaming kernel
 }
 
@@ -1136,12 +1180,16 @@ extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, c
   dw_wgrad_cfg((int64_t)N * D * H * W, &nblk, &vpb);
   int TT = kD * kH * kW, G = NT / TT, cch = C / cpc;
   hipStream_t st = (hipStream_t)stream;
-  const int th_lds = (kD == 3 && kH == 3 && kW == 3) ? dw3_lds_th(H, W, cpc) : 0;
+  // channel chunks per workgroup: the widest group whose halo rows fit the LDS budget (64-wide rows need 4: the
+  // 64^3 x 256-channel PatchMerging depthwise of MedFormer fell back to the streaming kernel, 897 us)
+  int wch = WG_CH_MAX, th_lds = 0;
+  if (kD == 3 && kH == 3 && kW == 3)
+    for (; wch >= 2; wch >>= 1) { th_lds = dw3_lds_th(H, W, cpc, wch); if (th_lds >= 1) break; }
   if (th_lds >= 1) {
     const int htiles = (H + th_lds - 1) / th_lds;
     nblk = N * D * htiles;
-    const size_t smem = dw3_lds_bytes(W, th_lds, cpc);
-    dim3 grid(nblk, (cch + WG_CH - 1) / WG_CH);
+    const size_t smem = dw3_lds_bytes(W, th_lds, cpc, wch);
+    dim3 grid(nblk, (cch + wch - 1) / wch);
 #ifndef CBIM_EMU
     static bool attr_done[2] = {false, false};
     if (!attr_done[dtype == CBIM_BF16]) {
@@ -1154,10 +1202,10 @@ extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, c
 #endif
     if (dtype == CBIM_BF16)
       CBIM_LAUNCH((k_dwconv3_wgrad_lds<bf16_tag>), grid, dim3(NT), smem, st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias,
-                  (float*)workspace, N, D, H, W, C, th_lds);
+                  (float*)workspace, N, D, H, W, C, th_lds, wch);
     else
       CBIM_LAUNCH((k_dwconv3_wgrad_lds<float>), grid, dim3(NT), smem, st, x, x_stride, in_stats, act, dy, dy_stride, dy_bias,
-                  (float*)workspace, N, D, H, W, C, th_lds);
+                  (float*)workspace, N, D, H, W, C, th_lds, wch);
   } else if (kW == 3 && kD <= 3 && kH <= 3) {
     int groups = (cch + DG - 1) / DG, rpb;
     dw3_wgrad_cfg((int64_t)N * D * H, groups, &nblk, &rpb);

@@ -74,7 +74,7 @@ def test_dwconv(dev, dtype):
     oc.check_dwconv(dev, dtype, N=1, C=16, dhw=(4, 5, 6), k=(3, 3, 1))  # generic path
 
 
-@pytest.mark.parametrize("dtype,W", [(BF16, 78), (BF16, 80), (BF16, 112), (F32, 160)])
+@pytest.mark.parametrize("dtype,W", [(BF16, 64), (BF16, 78), (BF16, 80), (BF16, 112), (F32, 160)])
 def test_dwconv_wide_rows(dev, dtype, W):
     """rows too wide for the LDS-tiled depthwise wgrad must fall back to the streaming kernel (the executor refuses
     launches over 160 KiB of LDS like the hardware does; round-1 crash at W = 112, amos_mr/medformer_3d.yaml)."""
