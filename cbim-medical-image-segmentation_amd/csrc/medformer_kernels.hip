@@ -1180,11 +1180,11 @@ extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, c
   dw_wgrad_cfg((int64_t)N * D * H * W, &nblk, &vpb);
   int TT = kD * kH * kW, G = NT / TT, cch = C / cpc;
   hipStream_t st = (hipStream_t)stream;
-  // channel chunks per workgroup: the widest group whose halo rows fit the LDS budget (64-wide rows need 4: the
-  // 64^3 x 256-channel PatchMerging depthwise of MedFormer fell back to the streaming kernel, 897 us)
+  // channel chunks per workgroup: 8.  (Narrower groups would let 64-wide rows into the LDS-tiled kernel — the 64^3 x 256-channel
+  // PatchMerging depthwise of MedFormer runs on the streaming kernel at 897 us — but with 4 chunks and 2-row tiles the tiled
+  // kernel took 1.64 ms on that call: measured and rejected, profiles/r03_q_medformer_kernels.txt.)
   int wch = WG_CH_MAX, th_lds = 0;
-  if (kD == 3 && kH == 3 && kW == 3)
-    for (; wch >= 2; wch >>= 1) { th_lds = dw3_lds_th(H, W, cpc, wch); if (th_lds >= 1) break; }
+  if (kD == 3 && kH == 3 && kW == 3) th_lds = dw3_lds_th(H, W, cpc, wch);
   if (th_lds >= 1) {
     const int htiles = (H + th_lds - 1) / th_lds;
     nblk = N * D * htiles;
