@@ -192,6 +192,40 @@ __global__ void __launch_bounds__(LNF_T) k_layernorm_bwd_finish(const float* __r
   }
 }
 
+// Column sums of token rows: out[c] = sum over rows of x[row][c] (the bias gradient of the trunk's token Linears,
+// swin_unetr.py:467-490,640-643: `g.float().sum(0)` was a full fp32 copy of the [tokens, C] gradient plus an ATen reduction).
+// thread = (8-channel chunk, row lane); rows strided over the grid; per-workgroup records summed in block order by
+// k_layernorm_bwd_finish's phase reduction.
+template <bool BF16_IN>
+__global__ void __launch_bounds__(LN_T) k_colsum_partial(const void* __restrict__ x, int64_t rows, int C, float* __restrict__ partials) {
+  constexpr int CP = BF16_IN ? 8 : 4;                 // channels per 16-byte chunk
+  const int cch = C / CP, rl = LN_T / cch;
+  const int cc = threadIdx.x % cch, rr = threadIdx.x / cch;
+  float a[CP];
+#pragma unroll
+  for (int j = 0; j < CP; ++j) a[j] = 0.f;
+  if (rr < rl) {
+    for (int64_t r = (int64_t)blockIdx.x * rl + rr; r < rows; r += (int64_t)gridDim.x * rl) {
+      const u32x4 v = *(const u32x4*)((const char*)x + (r * C + (int64_t)cc * CP) * (BF16_IN ? 2 : 4));
+      float f[CP];
+      if (BF16_IN) Elem<bf16_tag>::unpack(v, f);
+      else { f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w); }
+#pragma unroll
+      for (int j = 0; j < CP; ++j) a[j] += f[j];
+    }
+  }
+  __shared__ float red[LN_T * 8];
+#pragma unroll
+  for (int j = 0; j < CP; ++j) red[threadIdx.x * CP + j] = a[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += LN_T) {
+    const int c2 = c / CP, j = c % CP;
+    float s = 0.f;
+    for (int q = 0; q < rl; ++q) s += red[(q * cch + c2) * CP + j];
+    partials[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+
 }  // namespace cbim
 
 using namespace cbim;
@@ -258,6 +292,30 @@ extern "C" int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, 
     if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
   }
   return CBIM_OK;
+}
+
+extern "C" size_t cbim_colsum_workspace(int64_t rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)1024 * C * sizeof(float);
+}
+
+extern "C" int cbim_colsum(int dtype, const void* x, int64_t rows, int C, float* out, void* workspace, size_t ws_bytes, void* stream) {
+  CBIM_CHECK(x && out && rows > 0, CBIM_EINVAL, "null argument");
+  CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dtype);
+  const int cp = dtype == CBIM_BF16 ? 8 : 4;
+  CBIM_CHECK(C % cp == 0 && C / cp <= LN_T && C % 2 == 0, CBIM_EUNSUPPORTED, "colsum: %d channels (a multiple of %d up to %d)", C, cp, LN_T * cp);
+  CBIM_CHECK(workspace && ws_bytes >= cbim_colsum_workspace(rows, C), CBIM_EWORKSPACE, "colsum workspace too small");
+  const int rl = LN_T / (C / cp);
+  int64_t P = (rows + (int64_t)rl * 16 - 1) / ((int64_t)rl * 16);       // ~16 rows per thread
+  if (P > 1024) P = 1024;
+  if (P < 1) P = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CBIM_BF16) CBIM_LAUNCH((k_colsum_partial<true>), dim3((unsigned)P), dim3(LN_T), 0, st, x, rows, C, (float*)workspace);
+  else CBIM_LAUNCH((k_colsum_partial<false>), dim3((unsigned)P), dim3(LN_T), 0, st, x, rows, C, (float*)workspace);
+  if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+  // records [P][C] summed in block order: the finish kernel takes [P][2 C'] with C' = C / 2 and two output halves
+  CBIM_LAUNCH(k_layernorm_bwd_finish, dim3((unsigned)((C + 63) / 64)), dim3(LNF_T), 0, st, (const float*)workspace, (int)P, C / 2, out, out + C / 2);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 CBIM_DEFINE_WARM(layernorm)

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from ... import functional as Fn
 from ...ops import ACT
 
+from ...ops import colsum as ops_colsum
 from ...ops import ncdhw_to_ndhwc as ops_ncdhw_to_ndhwc
 
 _STEM_MFMA = os.environ.get("CBIM_SWIN_STEM_MFMA", "1") != "0"
@@ -189,7 +190,13 @@ class _TokenLinearFn(torch.autograd.Function):
             gw = torch.bmm(g2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1)).float().sum(0)
         else:
             gw = (g2.t() @ x2).float()
-        gb = g2.float().sum(0) if ctx.has_b else None
+        gb = None
+        if ctx.has_b:
+            cp = 8 if g2.dtype == torch.bfloat16 else 4
+            if g2.is_contiguous() and g2.dtype in (torch.bfloat16, torch.float32) and g2.shape[1] % cp == 0 and g2.shape[1] // cp <= 256:
+                gb = ops_colsum(g2)                    # one pass over the gradient rows (no fp32 copy, fixed order)
+            else:
+                gb = g2.float().sum(0)
         return gx, gw, gb
 
 
@@ -200,6 +207,7 @@ def _token_linear(lin, x):
 
 
 _FUSED_LN = os.environ.get("CBIM_SWIN_FUSED_LN", "1") != "0"
+_FUSED_MERGE = os.environ.get("CBIM_SWIN_FUSED_MERGE", "1") != "0"
 
 
 def _layer_norm(ln, x, out_dtype):
@@ -279,6 +287,18 @@ class PatchMerging(nn.Module):
     """The v0.9 ``PatchMerging`` (swin_unetr.py:707-731): note the slice list repeats three octants."""
     _SEL = ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0), (0, 0, 1), (1, 1, 1))
 
+    _SEL_CACHE = {}
+
+    @classmethod
+    def _sel_index(cls, device):
+        """octant numbers (4 i + 2 j + k) of the slice list, resident on `device` (created once: a host -> device copy inside
+        a hipGraph capture is not allowed)"""
+        t = cls._SEL_CACHE.get(str(device))
+        if t is None:
+            t = torch.tensor([4 * i + 2 * j + k for i, j, k in cls._SEL], device=device)
+            cls._SEL_CACHE[str(device)] = t
+        return t
+
     def __init__(self, dim):
         super().__init__()
         self.reduction = nn.Linear(8 * dim, 2 * dim, bias=False)
@@ -288,7 +308,16 @@ class PatchMerging(nn.Module):
         _, d, h, w, _ = x.shape
         if (d % 2) or (h % 2) or (w % 2):
             x = F.pad(x, (0, 0, 0, w % 2, 0, h % 2, 0, d % 2))
-        x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self._SEL], -1)
+        cdiv = 8 if x.dtype == torch.bfloat16 else 4
+        if _FUSED_MERGE and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % cdiv == 0:
+            # the 8 strided slices as ONE gather kernel (octant o = 4 i + 2 j + k), then the v0.9 slice order — with its
+            # repeated octants — as an index_select over the 8 channel blocks.  The slice-by-slice form costs autograd one
+            # zero-filled full-size tensor and one strided add per slice in the backward (16 launches per layer).
+            B, d2, h2, w2, Cc = x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3] // 2, x.shape[4]
+            m = Fn.SpaceToDepthFn.apply(x.contiguous(), (2, 2, 2)).view(B, d2, h2, w2, 8, Cc)
+            x = m.index_select(4, self._sel_index(x.device)).reshape(B, d2, h2, w2, 8 * Cc)
+        else:
+            x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self._SEL], -1)
         return self.reduction(_layer_norm(self.norm, x, torch.float32))
 
 

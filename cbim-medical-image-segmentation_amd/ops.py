@@ -868,6 +868,18 @@ def layernorm_bwd(dy, x, gamma, rowstats, want_affine: bool):
     return dx, dg, db
 
 
+def colsum(x2d):
+    """float32 [C] = column sums of x2d [rows, C] (bf16 or fp32), fixed summation order."""
+    _dev_ok(x2d)
+    rows, Cc = int(x2d.shape[0]), int(x2d.shape[1])
+    L = _lib.lib()
+    nbytes = L.cbim_colsum_workspace(rows, Cc)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x2d.device)
+    out = torch.empty((Cc,), dtype=torch.float32, device=x2d.device)
+    check(L.cbim_colsum(_dt(x2d), _p(x2d), rows, Cc, _p(out), _p(ws), nbytes, _stream(x2d)), "colsum")
+    return out
+
+
 def resnorm_fwd(a, stats_a, b, stats_b, act: int):
     """y = act(IN(a) + (IN(b) if stats_b is given else b))."""
     _dev_ok(a, stats_a, b, stats_b)

@@ -463,6 +463,12 @@ int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, const float
                        const float* rowstats, float* dx, float* dgamma, float* dbeta, void* workspace,
                        size_t ws_bytes, int64_t rows, int C, void* stream);
 
+/* Column sums of token rows, out[c] = sum_r x[r][c] (fp32, fixed order): the bias gradient of the trunk's token Linears
+ * (swin_unetr.py:467-490,640-643).  x [rows][C] in dtype; workspace: cbim_colsum_workspace(rows, C) bytes. */
+size_t cbim_colsum_workspace(int64_t rows, int C);
+int cbim_colsum(int dtype, const void* x, int64_t rows, int C, float* out, void* workspace, size_t ws_bytes,
+                void* stream);
+
 /* Layout helpers (caller-facing NCDHW fp32 <-> internal NDHWC). */
 int cbim_ncdhw_to_ndhwc(int dtype_out, const float* x, void* y, int N, int C, int64_t S, void* stream);
 int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N, int C, int64_t S, void* stream);

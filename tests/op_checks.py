@@ -719,3 +719,11 @@ def check_dgrad_mask_by_activated(dev, dtype, N=1, Cin=32, Cout=32, dhw=(8, 16, 
     assert relerr(from_cl(g1.cpu()), ref) < tol(dtype, 1e-5, 1e-2)
     assert relerr(s1.cpu()[..., 0], ref.mean((2, 3, 4))) < tol(dtype, 1e-4, 2e-2)
     assert relerr(s1.cpu()[..., 1], (ref * ar).mean((2, 3, 4))) < tol(dtype, 1e-4, 2e-2)
+
+
+def check_colsum(dev, dtype, rows=1000, C=48, seed=51):
+    torch.manual_seed(seed)
+    x = torch.randn(rows, C).to(dtype)
+    got = ops.colsum(x.to(dev))
+    ref = x.float().sum(0)
+    assert relerr(got.cpu(), ref) < 1e-5

@@ -243,6 +243,10 @@ def test_layernorm_token_rows(dev):
     oc.check_layernorm(dev, rows=(5, 3), C=768, out_bf16=True)
     oc.check_layernorm(dev, rows=(9,), C=1536)
     oc.check_layernorm(dev, rows=(4,), C=3072, affine=True)
+    import torch
+    oc.check_colsum(dev, torch.bfloat16)
+    oc.check_colsum(dev, torch.bfloat16, rows=77, C=576)
+    oc.check_colsum(dev, torch.float32, rows=513, C=144)
     oc.check_layernorm(dev, rows=(64, 64, 64), C=48, out_bf16=True)
 
 
