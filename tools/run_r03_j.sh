@@ -1,5 +1,5 @@
 #!/bin/bash
-T=${1:-r03_j}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+T=${1:-r03_r}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_parity.py -m gpu -x -q -k "layernorm or swin" 2>&1 | tail -3
 for v in 1 0; do
