@@ -154,7 +154,12 @@ class PatchEmbed(nn.Module):
             x = F.pad(x, (0, (-W) % p[2], 0, (-H) % p[1], 0, (-D) % p[0]))
             _, _, D, H, W = x.shape
         x = x.reshape(B, Cc, D // p[0], p[0], H // p[1], p[1], W // p[2], p[2]).permute(0, 2, 4, 6, 1, 3, 5, 7)
-        return F.linear(x.reshape(B, D // p[0], H // p[1], W // p[2], -1), self.proj.weight.flatten(1), self.proj.bias)
+        tok = x.reshape(B, D // p[0], H // p[1], W // p[2], -1)
+        if _SPLITK_DW and tok.is_cuda and torch.is_grad_enabled() and self.proj.weight.requires_grad:
+            # (the weight gradient is a 48 x 32 output over 262 144 tokens: one workgroup and 612 us in the library's
+            #  default tiling; the split-K form of the other token Linears fills the chip)
+            return _TokenLinearFn.apply(tok, self.proj.weight.flatten(1), self.proj.bias)
+        return F.linear(tok, self.proj.weight.flatten(1), self.proj.bias)
 
 
 _TRUNK_AMP = os.environ.get("CBIM_SWIN_TRUNK_AMP", "1") != "0"
@@ -318,7 +323,7 @@ class PatchMerging(nn.Module):
             x = m.index_select(4, self._sel_index(x.device)).reshape(B, d2, h2, w2, 8 * Cc)
         else:
             x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self._SEL], -1)
-        return self.reduction(_layer_norm(self.norm, x, torch.float32))
+        return _token_linear(self.reduction, _layer_norm(self.norm, x, torch.float32))
 
 
 class BasicLayer(nn.Module):
