@@ -763,6 +763,11 @@ bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, int cin_spl
   const int64_t tiles = (int64_t)d->N * ((d->Do + 7) / 8) * ((d->Ho + 7) / 8) * ((d->Wo + 7) / 8);
   const int n_oc = (d->Cout + 31) / 32;
   if (S >= g_r32_min_voxels) return !in_stats || d->Cin == 32 || d->Cout % 64 != 0;
+  // low-resolution layers: enough (tile strip, Cout chunk) workgroups to fill half the chip.  Raw inputs (round 3,
+  // profiles/r03_t_small_layers_r32.txt): 576->512 @16^3 138 -> 97 us forward, 124 -> 86 us dgrad; 128->512 @16^3 forward
+  // 46 -> 35 us; 256->64 @32^3 dgrad 68 -> 50 us; below 128 workgroups (256->256 @16^3, everything at 8^3) the split-K
+  // k_conv_igemm stays ahead
+  if (!in_stats) return tiles * n_oc >= 128;
   return S >= g_r32_min_voxels / 8 && tiles * n_oc >= 192;
 }
 

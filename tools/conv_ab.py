@@ -19,6 +19,8 @@ SHAPES = [(32, 32, 128), (96, 64, 128), (32, 128, 64), (64, 64, 64), (192, 128, 
 if os.environ.get("CB_SHAPES"):
     SHAPES = [tuple(int(v) for v in s.split("x")) for s in os.environ["CB_SHAPES"].split(",")]
 L = _lib.lib()
+if os.environ.get("CB_R32_MINVOX"):
+    L.cbim_conv_r32_min_voxels(int(os.environ["CB_R32_MINVOX"]))      # 0: k_conv3_r32 on every eligible shape
 
 
 def timeit(fn):
