@@ -44,6 +44,9 @@ _SIGS = {
     "cbim_stats_parts": (i32, [i64, i32]),
     "cbim_instnorm_stats": (i32, [i32, vp, i64, i32, i64, i32, f32, vp, i32, vp, vp]),
     "cbim_stats_finalize": (i32, [vp, i32, i32, i32, f64, f32, i32, vp, vp]),
+    "cbim_stats_restat": (i32, [vp, f32, f32, vp, i32, vp]),
+    "cbim_se_fold_fwd": (i32, [vp, vp, f32, vp, vp, i32, vp]),
+    "cbim_se_fold_bwd": (i32, [vp, vp, vp, f32, f64, vp, i32, vp]),
     "cbim_norm_act_fwd": (i32, [i32, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
     "cbim_norm_bwd_reduce": (i32, [i32, vp, i64, vp, i64, vp, i32, i64, i32, i32, i32, vp, i32, vp]),
     "cbim_norm_bwd_apply": (i32, [i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, i32, i64, i32, i32, i32, vp]),

@@ -681,4 +681,56 @@ extern "C" int cbim_ndhwc_to_ncdhw(int dtype_in, const void* x, float* y, int N,
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
+// ---- per-(n, c) statistics arithmetic of the MedFormer blocks (a few hundred numbers; fp64 inside) ------------------------
+// Each of these was 7-14 tiny ATen launches per block (cast to double, pow, sub, clamp, ..., stack): ~480 launches per step.
+namespace cbim {
+// MODE 0: (mean, rstd[eps_a]) -> (mean, rstd[eps_b])                      (InstanceNorm3d eps 1e-4 vs the 1e-5 default,
+//         medformer_utils.py:112,158 vs conv_layers.py:40)
+// MODE 1: SE gate folded into the normalisation, IN(x * s) = (x - mean) * s * rsqrt(var s^2 + eps): out = (mean, s * sqrt(rz2)),
+//         rz2 = 1 / (var s^2 + eps) kept (double) for the backward          (conv_layers.py:159-175,223-236)
+// MODE 2: gradient of the gate, ds = S * eps * m2 * rz2 / s  (m2 = the second InstanceNorm-backward mean of the dgrad epilogue)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_stats_remap(const float* __restrict__ stats, const float* __restrict__ se,
+                                                     const float* __restrict__ sums, double* __restrict__ rz2, float eps_a,
+                                                     float eps_b, double S, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (MODE == 2) {
+    out[i] = (float)(S * (double)eps_a * (double)sums[2 * i + 1] * rz2[i] / (double)se[i]);
+    return;
+  }
+  const double r = (double)stats[2 * i + 1];
+  double var = 1.0 / (r * r) - (double)eps_a;
+  if (var < 0.0) var = 0.0;
+  out[2 * i] = stats[2 * i];
+  if (MODE == 0) out[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps_b));
+  else {
+    const double sd = (double)se[i];
+    const double z = 1.0 / (var * sd * sd + (double)eps_a);
+    rz2[i] = z;
+    out[2 * i + 1] = (float)(sd * sqrt(z));
+  }
+}
+}  // namespace cbim
+
+extern "C" int cbim_stats_restat(const float* stats, float eps_from, float eps_to, float* out, int n, void* stream) {
+  CBIM_CHECK(stats && out && n > 0, CBIM_EINVAL, "null argument");
+  CBIM_LAUNCH((cbim::k_stats_remap<0>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (const float*)nullptr,
+              (const float*)nullptr, (double*)nullptr, eps_from, eps_to, 0.0, out, n);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+extern "C" int cbim_se_fold_fwd(const float* stats, const float* se, float eps, float* out_stats, double* rz2, int n, void* stream) {
+  CBIM_CHECK(stats && se && out_stats && rz2 && n > 0, CBIM_EINVAL, "null argument");
+  CBIM_LAUNCH((cbim::k_stats_remap<1>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, se, (const float*)nullptr, rz2,
+              eps, 0.f, 0.0, out_stats, n);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+extern "C" int cbim_se_fold_bwd(const float* sums, const float* se, const double* rz2, float eps, double S, float* ds, int n,
+                                void* stream) {
+  CBIM_CHECK(sums && se && rz2 && ds && n > 0, CBIM_EINVAL, "null argument");
+  CBIM_LAUNCH((cbim::k_stats_remap<2>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, se, sums,
+              (double*)rz2, eps, 0.f, S, ds, n);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
 CBIM_DEFINE_WARM(norm)

@@ -398,8 +398,7 @@ def restat(stats: torch.Tensor, eps_from: float, eps_to: float) -> torch.Tensor:
     """(mean, rstd) computed with one epsilon -> the same moments under another.  The reference's
     BidirectionAttentionBlock.norm1 / PatchMerging.norm use the InstanceNorm3d default 1e-5 while every
     ConvNormAct norm is built with 1e-4 (medformer_utils.py:112,158 vs conv_layers.py:40)."""
-    var = (stats[..., 1].double() ** -2 - eps_from).clamp_min(0.0)
-    return torch.stack([stats[..., 0], (var + eps_to).rsqrt().float()], -1).contiguous()
+    return ops.stats_restat(stats.contiguous(), eps_from, eps_to)
 
 
 class NormConvFn(_GradAwareFunction):
@@ -415,11 +414,7 @@ class NormConvFn(_GradAwareFunction):
         st = stats
         if se is not None:
             assert act == 0 and stats is not None
-            var = (stats[..., 1].double() ** -2 - IN_EPS).clamp_min(0.0)
-            sd = se.detach().double()
-            rz2 = 1.0 / (var * sd * sd + IN_EPS)
-            st = torch.stack([stats[..., 0], (sd * rz2.sqrt()).float()], -1).contiguous()
-            ctx.rz2 = rz2
+            st, ctx.rz2 = ops.se_fold_fwd(stats.contiguous(), se.detach().float().contiguous(), IN_EPS)
         y, so = ops.conv_fwd(x, wp, g, in_stats=st, res=res, want_stats=want_stats, eps=eps_out)
         ctx.save_for_backward(x, st if st is not None else torch.empty(0), se if se is not None else torch.empty(0))
         ctx.geom, ctx.act, ctx.wpd, ctx.has = g, act, wpd, (stats is not None, res is not None, se is not None)
@@ -443,7 +438,7 @@ class NormConvFn(_GradAwareFunction):
                 dx = ops.norm_bwd_apply(gx, x, st, sums, act, masked=False)
                 if has_se:
                     S = g.in_dhw[0] * g.in_dhw[1] * g.in_dhw[2]
-                    ds = (S * IN_EPS * sums[..., 1].double() * ctx.rz2 / se.double()).float()
+                    ds = ops.se_fold_bwd(sums.contiguous(), se.detach().float().contiguous(), ctx.rz2, IN_EPS, S)
             else:
                 dx, _ = ops.conv_dgrad(dy, ctx.wpd, g)
         return dx, None, dw, None, (dy if has_res else None), None, ds, None

@@ -107,6 +107,31 @@ def stats_finalize(partials: torch.Tensor, count: float, eps: float, mode: int) 
     return out
 
 
+def stats_restat(stats, eps_from: float, eps_to: float):
+    """(mean, rstd) records computed with one epsilon -> the same moments under another (one launch, fp64 inside)."""
+    _dev_ok(stats)
+    out = torch.empty_like(stats)
+    check(_lib.lib().cbim_stats_restat(_p(stats), float(eps_from), float(eps_to), _p(out), stats.numel() // 2, _stream(stats)),
+          "stats_restat")
+    return out
+
+
+def se_fold_fwd(stats, se, eps: float):
+    """SE gate folded into the normalisation -> (stats' float32 [N,C,2], rz2 float64 [N,C])."""
+    _dev_ok(stats, se)
+    out = torch.empty_like(stats)
+    rz2 = torch.empty(tuple(se.shape), dtype=torch.float64, device=se.device)
+    check(_lib.lib().cbim_se_fold_fwd(_p(stats), _p(se), float(eps), _p(out), _p(rz2), se.numel(), _stream(stats)), "se_fold_fwd")
+    return out, rz2
+
+
+def se_fold_bwd(sums, se, rz2, eps: float, S: int):
+    _dev_ok(sums, se, rz2)
+    ds = torch.empty(tuple(se.shape), dtype=torch.float32, device=se.device)
+    check(_lib.lib().cbim_se_fold_bwd(_p(sums), _p(se), _p(rz2), float(eps), float(S), _p(ds), se.numel(), _stream(sums)), "se_fold_bwd")
+    return ds
+
+
 def norm_act_fwd(x, stats, act: int):
     _dev_ok(x, stats)
     N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)

@@ -67,6 +67,19 @@ int cbim_instnorm_stats(int dtype, const void* x, int64_t x_stride, int N, int64
 int cbim_stats_finalize(const float* partials, int N, int P, int C, double count, float eps,
                         int mode, float* out, void* stream);
 
+/* Per-(n, c) statistics arithmetic of the MedFormer blocks, n = N*C records, fp64 inside:
+ * restat: (mean, rstd) computed with eps_from -> the same moments under eps_to (InstanceNorm3d(eps=1e-4) of
+ *   ConvNormAct vs the 1e-5 default of BidirectionAttentionBlock.norm1 / PatchMerging.norm,
+ *   conv_layers.py:40 vs medformer_utils.py:112,158);
+ * se_fold_fwd: the SEBlock gate s (conv_layers.py:159-175) folded into the next normalisation,
+ *   IN(x*s) = (x-mean) * s*rsqrt(var*s^2+eps): out_stats = (mean, s*sqrt(rz2)), rz2 = 1/(var*s^2+eps) (double [n]);
+ * se_fold_bwd: ds = S*eps*m2*rz2/s from the dgrad epilogue's second InstanceNorm-backward mean (sums float [n][2]). */
+int cbim_stats_restat(const float* stats, float eps_from, float eps_to, float* out, int n, void* stream);
+int cbim_se_fold_fwd(const float* stats, const float* se, float eps, float* out_stats, double* rz2, int n,
+                     void* stream);
+int cbim_se_fold_bwd(const float* sums, const float* se, const double* rz2, float eps, double S, float* ds,
+                     int n, void* stream);
+
 /* y = act((x-mean)*rstd) — post-activation ConvNormAct tail (conv_layers.py:51). */
 int cbim_norm_act_fwd(int dtype, const void* x, int64_t x_stride, const float* stats, void* y,
                       int64_t y_stride, int N, int64_t S, int C, int act, void* stream);
