@@ -63,6 +63,7 @@ _SIGS = {
     "cbim_up_stats_tile": (i32, [i32, vp] + [i32] * 8 + [f32, vp, i32, vp, vp]),
     "cbim_upcat_act_fwd_tile": (i32, [i32, vp, vp, vp, vp] + [i32] * 11 + [vp]),
     "cbim_upcat_norm_bwd_tile": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 10 + [vp]),
+    "cbim_lin_adjoint_axis": (i32, [i32, i32, vp, i64, i64, vp, i64, i32, i32, i64, vp]),
     "cbim_conv3d_packed_bytes": (sz, [_dp, i32]),
     "cbim_conv3d_pack_weights": (i32, [_dp, i32, vp, vp, vp]),
     "cbim_conv3d_pack_weights_both": (i32, [_dp, vp, vp, vp, vp]),

@@ -365,11 +365,12 @@ extern "C" int cbim_upcat_norm_bwd_tile(int dtype, const void* g, const void* lo
   UpTileParams p = {};
   size_t smem;
   if (int e = up_fill(p, dtype, Dl, Hl, Wl, Cl, D, H, W, Cs, &smem)) return e;
-  CBIM_CHECK(g && low && skip && stats && sums && dskip && dlow && dup_scratch && Cs > 0, CBIM_EINVAL, "null argument");
+  CBIM_CHECK(g && low && skip && stats && sums && dskip && dup_scratch && Cs > 0, CBIM_EINVAL, "null argument");
   p.g = g; p.low = low; p.skip = skip; p.stats = stats; p.sums = sums; p.out = dskip; p.out2 = dup_scratch; p.skip_first = skip_first;
   const int64_t tiles = (int64_t)p.tiles_d * p.tiles_h * p.tiles_w;
   hipStream_t st = (hipStream_t)stream;
   if (int e = up_launch<2>(dtype, p, dim3((unsigned)(tiles < 65535 ? tiles : 65535), (unsigned)N), smem, st)) return e;
+  if (!dlow) return CBIM_OK;   // the caller reduces dup_scratch with cbim_lin_adjoint_axis
   // transposed interpolation of the fine-resolution gradient: the gather kernel on dense Cl-channel rows
   return cbim_upcat_bwd(dtype, dup_scratch, dlow, nullptr, N, Dl, Hl, Wl, Cl, D, H, W, 0, 1, stream);
 }

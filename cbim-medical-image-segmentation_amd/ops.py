@@ -260,22 +260,52 @@ def upcat_act_fwd(low, skip, stats_cat, act: int, skip_first: bool = True):
     return out
 
 
+UP_SEPARABLE = __import__("os").environ.get("CBIM_UP_SEPARABLE", "1") not in ("", "0")   # dup -> dlow as three 1-D passes; off: the one-pass gather (A/B, tests)
+
+
+def _lin_adjoint(src, src_row, c_off, dst, outer, F, L, inner, vec=0):
+    check(_lib.lib().cbim_lin_adjoint_axis(_dt(src), vec, _p(src), src_row, c_off, _p(dst), outer, F, L, inner, _stream(src)),
+          "lin_adjoint_axis")
+
+
+def up_adjoint(src, c_off: int, Cl: int, low_dhw):
+    """Transposed trilinear(align_corners=True) interpolation of channels [c_off, c_off+Cl) of the channels-last src
+    [N, D, H, W, Ct] down to low_dhw, as one reduction per axis (W, then H, then D)."""
+    N, D, H, W, Ct = map(int, src.shape)
+    Dl, Hl, Wl = (int(i) for i in low_dhw)
+    kw = dict(dtype=src.dtype, device=src.device)
+    t1 = torch.empty((N, D, H, Wl, Cl), **kw)
+    _lin_adjoint(src, Ct, c_off, t1, N * D * H, W, Wl, Cl)
+    if H != Hl:
+        t2 = torch.empty((N, D, Hl, Wl, Cl), **kw)
+        _lin_adjoint(t1, Wl * Cl, 0, t2, N * D, H, Hl, Wl * Cl)
+        t1 = t2
+    if D != Dl:
+        t2 = torch.empty((N, Dl, Hl, Wl, Cl), **kw)
+        _lin_adjoint(t1, Hl * Wl * Cl, 0, t2, N, D, Dl, Hl * Wl * Cl)
+        t1 = t2
+    return t1
+
+
 def upcat_norm_bwd(g, low, skip, stats_cat, sums, skip_first: bool = True):
     """InstanceNorm backward over the virtual concatenation -> (dlow, dskip)."""
     _dev_ok(g, low, skip, stats_cat, sums)
     N, Dl, Hl, Wl, Cl = map(int, low.shape)
     _, D, H, W, Cs = map(int, skip.shape)
     dskip = torch.empty_like(skip)
-    dlow = torch.empty_like(low)
+    dlow = None if UP_SEPARABLE else torch.empty_like(low)
     dup = torch.empty((N, D, H, W, Cl), dtype=low.dtype, device=low.device)
+    rc = _UNSUPPORTED
     if UP_TILES:
         rc = _lib.lib().cbim_upcat_norm_bwd_tile(_dt(low), _p(g), _p(low), _p(skip), _p(stats_cat), _p(sums), _p(dskip), _p(dlow),
                                                  _p(dup), N, Dl, Hl, Wl, Cl, D, H, W, Cs, int(skip_first), _stream(low))
         if rc != _UNSUPPORTED:
             check(rc, "upcat_norm_bwd_tile")
-            return dlow, dskip
-    check(_lib.lib().cbim_upcat_norm_bwd(_dt(low), _p(g), _p(low), _p(skip), _p(stats_cat), _p(sums), _p(dskip), _p(dlow), _p(dup),
-                                         N, Dl, Hl, Wl, Cl, D, H, W, Cs, int(skip_first), _stream(low)), "upcat_norm_bwd")
+    if rc == _UNSUPPORTED:
+        check(_lib.lib().cbim_upcat_norm_bwd(_dt(low), _p(g), _p(low), _p(skip), _p(stats_cat), _p(sums), _p(dskip), _p(dlow), _p(dup),
+                                             N, Dl, Hl, Wl, Cl, D, H, W, Cs, int(skip_first), _stream(low)), "upcat_norm_bwd")
+    if dlow is None:
+        dlow = up_adjoint(dup, 0, Cl, (Dl, Hl, Wl))
     return dlow, dskip
 
 
@@ -283,10 +313,12 @@ def upcat_bwd(dout, low_shape, Cs: int, skip_first: bool = True):
     _dev_ok(dout)
     N, Dl, Hl, Wl, Cl = map(int, low_shape)
     _, D, H, W, Ct = map(int, dout.shape)
-    dlow = torch.empty(tuple(low_shape), dtype=dout.dtype, device=dout.device)
+    dlow = None if UP_SEPARABLE else torch.empty(tuple(low_shape), dtype=dout.dtype, device=dout.device)
     dskip = torch.empty((N, D, H, W, Cs), dtype=dout.dtype, device=dout.device)
     check(_lib.lib().cbim_upcat_bwd(_dt(dout), _p(dout), _p(dlow), _p(dskip), N, Dl, Hl, Wl, Cl, D, H, W, Cs,
                                     int(skip_first), _stream(dout)), "upcat_bwd")
+    if dlow is None:
+        dlow = up_adjoint(dout, Cs if skip_first else 0, Cl, (Dl, Hl, Wl))
     return dlow, dskip
 
 
@@ -814,6 +846,15 @@ def trilinear_planes_bwd(dy, in_shape):
     _dev_ok(dy)
     N, Cc, Di, Hi, Wi = map(int, in_shape)
     _, _, Do, Ho, Wo = map(int, dy.shape)
+    if UP_SEPARABLE:   # W, H, D reductions of the NCDHW planes (scalar items along W, 16-byte chunks when the rows allow)
+        kw = dict(dtype=torch.float32, device=dy.device)
+        t = torch.empty((N, Cc, Do, Ho, Wi), **kw)
+        _lin_adjoint(dy, 1, 0, t, N * Cc * Do * Ho, Wo, Wi, 1, vec=1)
+        for (outer, F, L, inner, shape) in ((N * Cc * Do, Ho, Hi, Wi, (N, Cc, Do, Hi, Wi)), (N * Cc, Do, Di, Hi * Wi, (N, Cc, Di, Hi, Wi))):
+            t2 = torch.empty(shape, **kw)
+            _lin_adjoint(t, inner, 0, t2, outer, F, L, inner, vec=0 if inner % 4 == 0 else 1)
+            t = t2
+        return t
     dx = torch.empty(tuple(in_shape), dtype=torch.float32, device=dy.device)
     check(_lib.lib().cbim_trilinear_planes_bwd(_p(dy), _p(dx), N * Cc, Di, Hi, Wi, Do, Ho, Wo, _stream(dy)),
           "trilinear_planes_bwd")

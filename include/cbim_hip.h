@@ -131,6 +131,13 @@ int cbim_upcat_act_fwd(int dtype, const void* low, const void* skip, const float
 int cbim_upcat_norm_bwd(int dtype, const void* g, const void* low, const void* skip, const float* stats,
                         const float* sums, void* dskip, void* dlow, void* dup_scratch, int N, int Dl, int Hl,
                         int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, void* stream);
+/* One axis of the transposed trilinear interpolation (the adjoint of F.interpolate(trilinear, align_corners=True)
+ * factorises over W, H, D; unet_utils.py:69 / medformer.py:91 in the backward): src [outer][F][src_row] elements of
+ * which `inner` starting at c_off are reduced -> dst [outer][L][inner] dense, L <= F.  vec 0: items of one 16-byte
+ * chunk of dtype; vec 1: scalar float32 items (NCDHW planes).  cbim_upcat_bwd / cbim_upcat_norm_bwd[_tile] called with
+ * dlow == NULL leave the reduction of the fine-resolution gradient to three of these passes. */
+int cbim_lin_adjoint_axis(int dtype, int vec, const void* src, int64_t src_row, int64_t c_off, void* dst,
+                          int64_t outer, int F, int L, int64_t inner, void* stream);
 /* The same three operations on LDS tiles (up_tile_kernels.hip): a workgroup stages the coarse box of a 4x8x8
  * fine tile once and interpolates from LDS.  CBIM_EUNSUPPORTED when the box does not fit the LDS budget
  * (the caller then uses the entry points above).  cbim_up_stats_tile's partials have

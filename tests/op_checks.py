@@ -97,6 +97,27 @@ def check_upcat(dev, dtype, N=1, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_
     assert torch.equal(from_cl(dskip.cpu()), skr.grad)
 
 
+def check_up_adjoint(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_first=True):
+    """dup -> dlow as three 1-D reductions (cbim_lin_adjoint_axis) against the one-pass 64-candidate gather, for a
+    strided slice of the concatenation's gradient and for float32 NCDHW planes."""
+    torch.manual_seed(6)
+    g = to_cl(torch.randn(N, Cs + Cl, *hi), dtype).to(dev)
+    low_shape = (N,) + tuple(low) + (Cl,)
+    keep = ops.UP_SEPARABLE
+    try:
+        ops.UP_SEPARABLE = False
+        ref, rskip = ops.upcat_bwd(g, low_shape, Cs, skip_first)
+        pref = ops.trilinear_planes_bwd(from_cl(g.float()).contiguous(), (N, Cs + Cl) + tuple(low))
+        ops.UP_SEPARABLE = True
+        got, gskip = ops.upcat_bwd(g, low_shape, Cs, skip_first)
+        pgot = ops.trilinear_planes_bwd(from_cl(g.float()).contiguous(), (N, Cs + Cl) + tuple(low))
+    finally:
+        ops.UP_SEPARABLE = keep
+    assert got.shape == ref.shape and torch.equal(gskip.cpu(), rskip.cpu())
+    assert relerr(got.cpu().float(), ref.cpu().float()) < tol(dtype, 1e-6, 8e-3)
+    assert relerr(pgot.cpu(), pref.cpu()) < 1e-6
+
+
 def check_upcat_fused(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_first=True, tiles=True):
     """The decoder level's first block without the stored concatenation: statistics of the virtual up-sampled tensor,
     a = relu(IN([skip | up(low)])) in one pass, and the InstanceNorm backward split into (dlow, dskip) — against the

@@ -39,6 +39,11 @@ def test_upcat(dev, dtype):
     oc.check_upcat_fused(dev, dtype, tiles=False)
     oc.check_upcat_fused(dev, dtype, N=1, Cl=8, Cs=8, low=(4, 7, 5), hi=(4, 14, 10))      # anisotropic scale [1, 2, 2]
     oc.check_upcat_fused(dev, dtype, N=1, low=(5, 4, 4), hi=(10, 8, 8), skip_first=False)
+    oc.check_up_adjoint(dev, dtype)
+    oc.check_up_adjoint(dev, dtype, N=1, Cl=8, Cs=8, low=(4, 7, 5), hi=(4, 14, 10), skip_first=False)   # [1, 2, 2]
+    oc.check_up_adjoint(dev, dtype, N=1, low=(1, 3, 2), hi=(2, 6, 4))
+    oc.check_up_adjoint(dev, dtype, N=1, Cl=64, Cs=32, low=(16, 16, 16), hi=(32, 32, 32))
+    oc.check_up_adjoint(dev, dtype, N=1, Cl=16, Cs=0, low=(8, 8, 8), hi=(32, 32, 32))            # the aux head's x4
     oc.check_upcat_fused(dev, dtype, N=1, Cl=64, Cs=32, low=(16, 16, 16), hi=(32, 32, 32))
     oc.check_upcat(dev, dtype, Cl=64, Cs=32, low=(16, 16, 16), hi=(32, 32, 32))
 
