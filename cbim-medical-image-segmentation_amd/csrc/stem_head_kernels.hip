@@ -552,6 +552,165 @@ __global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x
   }
 }
 
+// ---- head backward on the matrix cores: bf16 rows of Cin = 32 * CP <= 128 channels, K <= 16 classes, S % 32 == 0 -----------
+// k_head_bwd_k does 2 x 16 x 8 fp32 FMAs per voxel chunk with ONE wave per SIMD (its 256 accumulator / weight registers) and
+// runs 4x above its VALU bound (211 us at 128^3 x 32, the tensors move in ~70 us).  Here a wave takes 32 voxels per step:
+//   dw[k][c] += dz[k][v] x[v][c]   v_mfma_f32_16x16x32_bf16 contracting over the 32 VOXELS: A = dz rows straight from the
+//                                  fp32 planes (two 16-byte loads per lane, split into bf16 hi + lo so dw keeps fp32 accuracy),
+//                                  B = the x rows through the LDS transpose read (as k_wgrad_r32 does);
+//   dx[v][c]  = sum_k dz[k][v] W[k][c]  contracting over the classes (padded to 32): A = W^T with the rows of a tile pair
+//                                  permuted so that a lane ends up with 8 consecutive channels of one voxel (one 16-byte
+//                                  store), B = dz[k][v] transposed through a 1 KiB LDS tile of the bf16 planes.
+// Registers ~64, 8 waves per workgroup, steps are wave-private (no workgroup barrier inside the loop); the next step's
+// global loads are in flight while a step is computed.  Slab per workgroup [K][Cin+1] as before (k_head_bwd_reduce4).
+__device__ __forceinline__ u32x2 hd_tr16_b64(const unsigned char* p) {
+#ifdef CBIM_EMU
+  unsigned short o[4];
+  emu_ds_read_tr16_b64(p, o);
+  u32x2 r;
+  r.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+  r.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+  return r;
+#else
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  return __builtin_bit_cast(u32x2, v);
+#endif
+}
+// LDS written by some lanes of the wave, read by others: DS instructions of a wave execute in order, so only the compiler
+// (and the host-side executor, whose lanes are fibers) needs a fence
+__device__ __forceinline__ void hd_wave_sync() {
+#ifdef CBIM_EMU
+  (void)__any(0);
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
+static constexpr int HM_NW = 8;     // waves per workgroup
+template <int CP>
+__global__ void __launch_bounds__(HM_NW * 64) k_head_bwd_mfma(const void* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ dz, void* __restrict__ dx,
+                                                              float* __restrict__ ws, int64_t S, int K, int64_t vox_per_block) {
+  constexpr int Cin = 32 * CP, ROWB = Cin * 2, XT = 32 * ROWB, DZT = 16 * 64, WT = XT + DZT, NX = 2 * CP;
+  CBIM_DYN_SMEM(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  unsigned char* xs = smem + wave * WT;
+  unsigned char* dzs = xs + XT;
+  const int n = blockIdx.y;
+  u32x4 wa[CP][2];
+#pragma unroll
+  for (int p = 0; p < CP; ++p)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int c = 32 * p + 8 * (li >> 2) + 4 * t + (li & 3);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 8 * g + j < K ? w[(size_t)(8 * g + j) * Cin + c] : 0.f;
+      wa[p][t] = Elem<bf16_tag>::pack(f);
+    }
+  f32x4 acc[2 * CP];
+#pragma unroll
+  for (int ct = 0; ct < 2 * CP; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbv = 0.f;
+  const int64_t v_begin = (int64_t)blockIdx.x * vox_per_block;
+  int64_t v_end = v_begin + vox_per_block;
+  if (v_end > S) v_end = S;
+  const float* dzk = dz + ((size_t)n * K + (li < K ? li : 0)) * S + 8 * g;     // this lane's class plane, at its 8 voxels
+  const unsigned char* xn = (const unsigned char*)x + (size_t)n * S * ROWB;
+  unsigned char* dxn = dx ? (unsigned char*)dx + (size_t)n * S * ROWB : nullptr;
+  u32x4 xr[2][NX];
+  f32x4 dr[2][2];
+  auto load = [&](int slot, int64_t v) {
+    if (v >= v_end) return;
+#pragma unroll
+    for (int u = 0; u < NX; ++u) xr[slot][u] = *(const u32x4*)(xn + (size_t)v * ROWB + (size_t)(lane + 64 * u) * 16);
+    if (li < K) {
+      dr[slot][0] = *(const f32x4*)(dzk + v);
+      dr[slot][1] = *(const f32x4*)(dzk + v + 4);
+    } else {
+      dr[slot][0] = dr[slot][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto step = [&](int slot, int64_t v) {
+    float d[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { d[j] = dr[slot][0][j]; d[4 + j] = dr[slot][1][j]; }
+    dbv += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+    const u32x4 ahi = Elem<bf16_tag>::pack(d);
+    {
+      float h[8];
+      Elem<bf16_tag>::unpack(ahi, h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lo[j] = d[j] - h[j];
+    }
+    const u32x4 alo = Elem<bf16_tag>::pack(lo);
+    hd_wave_sync();                                                      // the previous step's LDS reads are done
+#pragma unroll
+    for (int u = 0; u < NX; ++u) *(u32x4*)(xs + (size_t)(lane + 64 * u) * 16) = xr[slot][u];
+    *(u32x4*)(dzs + li * 64 + g * 16) = ahi;
+    hd_wave_sync();
+    // dw: contraction over the 32 voxels
+#pragma unroll
+    for (int ct = 0; ct < 2 * CP; ++ct) {
+      const unsigned char* a = xs + (8 * g + (li >> 2)) * ROWB + ct * 32 + (li & 3) * 8;
+      const u32x2 b0 = hd_tr16_b64(a), b1 = hd_tr16_b64(a + 4 * ROWB);
+      const u32x4 bf = u32x4{b0.x, b0.y, b1.x, b1.y};
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ahi), __builtin_bit_cast(bf16x8, bf), acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, alo), __builtin_bit_cast(bf16x8, bf), acc[ct], 0, 0, 0);
+    }
+    // dx: contraction over the classes (k >= 16: zero operand rows)
+    if (dxn) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned char* a = dzs + ((8 * g + (li >> 2)) & 15) * 64 + h * 32 + (li & 3) * 8;
+        u32x2 e0 = hd_tr16_b64(a), e1 = hd_tr16_b64(a + 4 * 64);
+        if (g >= 2) { e0 = u32x2{0u, 0u}; e1 = u32x2{0u, 0u}; }
+        const u32x4 ef = u32x4{e0.x, e0.y, e1.x, e1.y};
+#pragma unroll
+        for (int p = 0; p < CP; ++p) {
+          const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[p][0]), __builtin_bit_cast(bf16x8, ef), z, 0, 0, 0);
+          const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[p][1]), __builtin_bit_cast(bf16x8, ef), z, 0, 0, 0);
+          const float f[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+          *(u32x4*)(dxn + (size_t)(v + 16 * h + li) * ROWB + (size_t)(32 * p + 8 * g) * 2) = Elem<bf16_tag>::pack(f);
+        }
+      }
+    }
+  };
+  int64_t v = v_begin + wave * 32;
+  load(0, v);
+  for (; v < v_end; v += 2 * HM_NW * 32) {
+    load(1, v + HM_NW * 32);
+    step(0, v);
+    load(0, v + 2 * HM_NW * 32);
+    if (v + HM_NW * 32 < v_end) step(1, v + HM_NW * 32);
+  }
+  // the 8 waves' partial dw / db -> the workgroup's slab, fixed order
+  __syncthreads();
+  float* red = (float*)smem;                         // [wave][16][Cin]
+  float* rdb = red + HM_NW * 16 * Cin;               // [wave][16]
+#pragma unroll
+  for (int ct = 0; ct < 2 * CP; ++ct)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[(wave * 16 + 4 * g + i) * Cin + 16 * ct + li] = acc[ct][i];
+  dbv += __shfl_xor(dbv, 16);
+  dbv += __shfl_xor(dbv, 32);
+  if (g == 0) rdb[wave * 16 + li] = dbv;
+  __syncthreads();
+  const int npairs = K * (Cin + 1);
+  float* slab = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * npairs;
+  for (int o = tid; o < npairs; o += HM_NW * 64) {
+    const int k = o / (Cin + 1), c = o % (Cin + 1);
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < HM_NW; ++q) a += c < Cin ? red[(q * 16 + k) * Cin + c] : rdb[q * 16 + k];
+    slab[o] = a;
+  }
+}
+static_assert(HM_NW * (32 * 256 + 16 * 64) <= 160 * 1024, "LDS");
+
 // slabs -> dw, db: 64 outputs x 4 slab phases per workgroup, fixed order
 __global__ void __launch_bounds__(NT) k_head_bwd_reduce4(const float* __restrict__ ws, float* __restrict__ dw,
                                                          float* __restrict__ db, int n_slabs, int Cin, int K) {
@@ -699,6 +858,14 @@ extern "C" int cbim_head_fwd(int dtype, const void* x, const float* w, const flo
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
+static int g_head_mfma = 1;
+/* process-wide switch (tests, A/B): 0 = the VALU head backward also where the matrix-core kernel applies; returns the old value */
+extern "C" int cbim_head_mfma_enable(int on) {
+  const int old = g_head_mfma;
+  g_head_mfma = on ? 1 : 0;
+  return old;
+}
+
 static int head_bwd_blocks(int64_t S) {
   int64_t b = (S + 4095) / 4096;
   if (b > 512) b = 512;
@@ -724,6 +891,37 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
     const int cpc = dtype == CBIM_BF16 ? 8 : 4, cch = Cin / cpc;
     // (bf16: one chunk per wave — two would need 2 x 16 x 8 accumulators + as many weight registers per lane: spills;
     //  wider rows, e.g. MedFormer's aux head on 128 channels, run as blockIdx.z groups of 4 chunks)
+    if (K <= 16 && g_head_mfma && dtype == CBIM_BF16 && Cin % 32 == 0 && Cin <= 128 && S % 32 == 0) {
+      // matrix-core form (k_head_bwd_mfma): workgroups of 8 waves x 32-voxel steps, two per CU at full size
+      int nb = head_bwd_blocks(S);
+      int64_t vpb = (S + nb - 1) / nb;
+      vpb = (vpb + HM_NW * 32 - 1) / (HM_NW * 32) * (HM_NW * 32);
+      nb = (int)((S + vpb - 1) / vpb);
+      const int CP = Cin / 32;
+      const size_t sm = (size_t)HM_NW * (32 * Cin * 2 + 16 * 64);
+      dim3 grid((unsigned)nb, (unsigned)N);
+      float* wsf = (float*)workspace;
+      static bool attr_done = false;
+      if (!attr_done) {
+#ifndef CBIM_EMU
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_head_bwd_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e2 = hipFuncSetAttribute((const void*)k_head_bwd_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        CBIM_CHECK(e1 == hipSuccess && e2 == hipSuccess, CBIM_ELAUNCH, "head bwd: cannot raise the dynamic LDS limit");
+#endif
+        attr_done = true;
+      }
+      switch (CP) {
+        case 1: CBIM_LAUNCH((k_head_bwd_mfma<1>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb); break;
+        case 2: CBIM_LAUNCH((k_head_bwd_mfma<2>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb); break;
+        case 3: CBIM_LAUNCH((k_head_bwd_mfma<3>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb); break;
+        default: CBIM_LAUNCH((k_head_bwd_mfma<4>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb); break;
+      }
+      if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+      const int npairs = K * (Cin + 1);
+      CBIM_LAUNCH(k_head_bwd_reduce4, dim3((npairs + 63) / 64), dim3(NT), 0, st, (const float*)workspace, dw, db,
+                  N * nb, Cin, K);
+      return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+    }
     if (K <= 16) {
       int nb = head_bwd_blocks(S);      // (the workspace is sized for head_bwd_blocks(S) slabs)
       if (nb > 256) nb = 256;           // one workgroup per CU: fewer slabs for the reduce

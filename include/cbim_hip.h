@@ -271,6 +271,9 @@ size_t cbim_head_bwd_workspace(int64_t S, int N, int Cin, int K);
 int cbim_head_bwd(int dtype, const void* x, const float* w, const float* dlogits, void* dx, float* dw,
                   float* db, int N, int64_t S, int Cin, int K, void* workspace, size_t ws_bytes,
                   void* stream);
+/* process-wide switch (tests, A/B): 0 = keep the VALU head backward where the matrix-core kernel (bf16, K <= 16,
+ * Cin a multiple of 32 up to 128, S a multiple of 32) would run; returns the old value. */
+int cbim_head_mfma_enable(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Loss: nn.CrossEntropyLoss(weight)(logits, label) + DiceLoss()(logits, label)

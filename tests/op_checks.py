@@ -356,6 +356,34 @@ def check_stem_head(dev, dtype, N=1, Cin=2, base=8, K=5, dhw=(6, 9, 10), k=(3, 3
     assert relerr(dbh.cpu(), bh.grad) < 2e-5
 
 
+def check_head_mfma(dev, N=2, base=32, K=5, dhw=(4, 8, 8), need_dx=True):
+    """The matrix-core head backward (k_head_bwd_mfma: bf16 rows of 32..128 channels, K <= 16, S % 32 == 0) against torch
+    and against the VALU kernel it replaces."""
+    from cbim_amd import _lib
+    torch.manual_seed(44)
+    BF = torch.bfloat16
+    hl = to_cl(torch.randn(N, base, *dhw), BF).to(dev)
+    hr = from_cl(hl.cpu()).requires_grad_(True)
+    wh = (torch.randn(K, base, 1, 1, 1) * 0.3).requires_grad_(True)
+    bh = torch.randn(K).requires_grad_(True)
+    zr = F.conv3d(hr, wh, bh)
+    dz = torch.randn(zr.shape) * 0.01
+    dz[:, :, :1] *= 300.0                       # a wide range of magnitudes: the bf16 hi + lo split of dz
+    zr.backward(dz)
+    w2 = wh.detach().reshape(K, base).contiguous().to(dev)
+    old = _lib.lib().cbim_head_mfma_enable(1)
+    try:
+        dx, dwh, dbh = ops.head_bwd(hl, w2, dz.to(dev), need_dx=need_dx)
+        _lib.lib().cbim_head_mfma_enable(0)
+        dx0, dwh0, dbh0 = ops.head_bwd(hl, w2, dz.to(dev))
+    finally:
+        _lib.lib().cbim_head_mfma_enable(old)
+    if need_dx:
+        assert relerr(from_cl(dx.cpu()), hr.grad) < 8e-3 and relerr(dx.cpu().float(), dx0.cpu().float()) < 8e-3
+    assert relerr(dwh.cpu(), wh.grad.reshape(K, base)) < 2e-5 and relerr(dwh.cpu(), dwh0.cpu()) < 2e-5
+    assert relerr(dbh.cpu(), bh.grad) < 2e-5
+
+
 def check_loss(dev, N=2, C=6, dhw=(6, 7, 8), weighted=True, seed=5):
     from oracle import loss_ref
     torch.manual_seed(seed)

@@ -148,6 +148,13 @@ def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype, Cin=1, base=16, K=19, dhw=(3, 4, 5))        # head: more than 16 classes -> generic kernels
 
 
+def test_head_backward_on_matrix_cores(dev):
+    oc.check_head_mfma(dev)
+    oc.check_head_mfma(dev, N=1, base=64, K=16, dhw=(8, 8, 9))              # 18 steps over 8 waves: ragged last round
+    oc.check_head_mfma(dev, N=1, base=96, K=3, dhw=(2, 4, 8))
+    oc.check_head_mfma(dev, N=1, base=128, K=13, dhw=(4, 4, 8), need_dx=False)
+
+
 def test_loss(dev):
     oc.check_loss(dev)
     oc.check_loss(dev, N=1, C=3, dhw=(4, 4, 4), weighted=False, seed=9)
