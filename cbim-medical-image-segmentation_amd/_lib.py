@@ -88,6 +88,7 @@ _SIGS = {
     "cbim_head_bwd_workspace": (sz, [i64, i32, i32, i32]),
     "cbim_head_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, sz, vp]),
     "cbim_head_mfma_enable": (i32, [i32]),
+    "cbim_stem_mfma_enable": (i32, [i32]),
     "cbim_dice_ce_workspace": (sz, [i32, i32, i64]),
     "cbim_dice_ce_fwd": (i32, [vp, vp, vp, i32, i32, i64, vp, vp, vp, sz, vp]),
     "cbim_dice_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, vp]),

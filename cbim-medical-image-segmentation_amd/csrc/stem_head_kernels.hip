@@ -6,6 +6,7 @@
 //   head: outc = nn.Conv3d(base, classes, 1) with bias (unet.py:47): channels-last T in, NCDHW fp32
 //         logits out (the layout nn.CrossEntropyLoss / DiceLoss consume, train.py:212).
 #include "cbim_common.h"
+#include <stdlib.h>
 
 namespace cbim {
 
@@ -76,6 +77,251 @@ __global__ void __launch_bounds__(NT) k_stem_fwd(StemParams p) {
           }
     }
     if (ok) st_chunk<T>(p.y, row * p.Cout + cg, Elem<T>::pack(acc));
+  }
+}
+
+// ---- stem forward on the matrix cores: one input channel, <= 27 taps, bf16 rows of Cout = 32 * CP channels --------------
+// out^T[co][v] = sum_tap W[co][tap] X[tap][v]: v_mfma_f32_16x16x32_bf16 with the (<= 27, zero padded) TAPS as the contraction.
+// A = W rows (co permuted inside a 32-channel pair so that a lane ends up with 8 consecutive channels of one voxel: one
+// 16-byte store), B = the im2col column of a voxel gathered from the LDS halo (8 ds_read_b32 per lane and 16 voxels).  Both
+// operands are split into bf16 hi + lo (hi*hi + lo*hi + hi*lo: the fp32 image and the fp32 master weights keep ~2^-17), the
+// matrix cores have time to spare: the kernel is bound by its 16-byte output stores.  k_stem_fwd spends 27 x 32 fp32 FMAs and
+// 27 x 9 LDS reads per voxel (152 us at 128^3 x 32; the output is written in ~25 us).
+template <int CP>
+__global__ void __launch_bounds__(NT) k_stem_fwd_mfma(StemParams p) {
+  CBIM_DYN_SMEM(smem);
+  unsigned* halo = (unsigned*)smem;                       // [hD][hH][hW]: bf16 hi | bf16 lo << 16
+  const int hV = p.hD * p.hH * p.hW;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w, n_tiles = p.N * tiles_per_n;
+  const size_t Sin = (size_t)p.Di * p.Hi * p.Wi;
+  // weight fragments (hi, lo) and the halo offsets of this lane's 8 taps: once per (persistent) workgroup
+  u32x4 wh[CP][2], wl[CP][2];
+  int off[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int tp = 8 * g + j;
+    const int kw = tp % p.kW, kh = (tp / p.kW) % p.kH, kd = tp / (p.kW * p.kH);
+    off[j] = tp < p.taps ? (kd * p.hH + kh) * p.hW + kw : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < CP; ++q)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int co = 32 * q + 8 * (li >> 2) + 4 * u + (li & 3);
+      float fh[8], fl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int tp = 8 * g + j;
+        const float wv = tp < p.taps ? p.w[(size_t)co * p.taps + tp] : 0.f;
+        fh[j] = Elem<bf16_tag>::round(wv);
+        fl[j] = wv - fh[j];
+      }
+      wh[q][u] = Elem<bf16_tag>::pack(fh);
+      wl[q][u] = Elem<bf16_tag>::pack(fl);
+    }
+  // this thread's halo items (the same positions in every tile)
+  constexpr int HI = 3;                                   // 600 halo values of a 3x3x3 stem over 256 threads
+  int hpos[HI];
+#pragma unroll
+  for (int e = 0; e < HI; ++e) {
+    const int i = tid + NT * e;
+    const int hw = i % p.hW, r = i / p.hW, hh = r % p.hH, hd = r / p.hH;
+    hpos[e] = i < hV ? (hd | (hh << 8) | (hw << 16)) : -1;
+  }
+  for (int tile = (int)xcd_remap(blockIdx.x, gridDim.x); tile < n_tiles; tile += gridDim.x) {
+    const int n = tile / tiles_per_n, t = tile % tiles_per_n;
+    const int od0 = (t / (p.tiles_w * p.tiles_h)) * 4, oh0 = ((t / p.tiles_w) % p.tiles_h) * 8, ow0 = (t % p.tiles_w) * 8;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < HI; ++e) {
+      if (hpos[e] < 0) continue;
+      const int id = od0 - p.pD + (hpos[e] & 255), ih = oh0 - p.pH + ((hpos[e] >> 8) & 255), iw = ow0 - p.pW + (hpos[e] >> 16);
+      float v = 0.f;
+      if (id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi) v = p.x[(size_t)n * Sin + ((size_t)id * p.Hi + ih) * p.Wi + iw];
+      const unsigned hi = pk_bf16(v, 0.f) & 0xffffu;
+      const unsigned lo = pk_bf16(v - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+      halo[tid + NT * e] = hi | (lo << 16);
+    }
+    __syncthreads();
+    const int td = wave, od = od0 + td;
+#pragma unroll
+    for (int r2 = 0; r2 < 4; ++r2) {
+      const int th = 2 * r2 + (li >> 3), tw = li & 7;
+      const int base = (td * p.hH + th) * p.hW + tw;
+      unsigned u[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] = halo[base + off[j]];
+      u32x4 bh, bl;
+      bh.x = (u[0] & 0xffffu) | (u[1] << 16); bh.y = (u[2] & 0xffffu) | (u[3] << 16);
+      bh.z = (u[4] & 0xffffu) | (u[5] << 16); bh.w = (u[6] & 0xffffu) | (u[7] << 16);
+      bl.x = (u[0] >> 16) | (u[1] & 0xffff0000u); bl.y = (u[2] >> 16) | (u[3] & 0xffff0000u);
+      bl.z = (u[4] >> 16) | (u[5] & 0xffff0000u); bl.w = (u[6] >> 16) | (u[7] & 0xffff0000u);
+      const int oh = oh0 + th, ow = ow0 + tw;
+      const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+      const size_t row = (size_t)n * p.Do * p.Ho * p.Wo + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+#pragma unroll
+      for (int q = 0; q < CP; ++q) {
+        f32x4 d[2];
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          d[uu] = f32x4{0.f, 0.f, 0.f, 0.f};
+          d[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl[q][uu]), __builtin_bit_cast(bf16x8, bh), d[uu], 0, 0, 0);
+          d[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh[q][uu]), __builtin_bit_cast(bf16x8, bl), d[uu], 0, 0, 0);
+          d[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh[q][uu]), __builtin_bit_cast(bf16x8, bh), d[uu], 0, 0, 0);
+        }
+        const float f[8] = {d[0][0], d[0][1], d[0][2], d[0][3], d[1][0], d[1][1], d[1][2], d[1][3]};
+        if (ok) st_chunk<bf16_tag>(p.y, row * p.Cout + 32 * q + 8 * g, Elem<bf16_tag>::pack(f));
+      }
+    }
+  }
+}
+
+// LDS transpose read / wave-level LDS fence of the matrix-core kernels below
+__device__ __forceinline__ u32x2 hd_tr16_b64(const unsigned char* p) {
+#ifdef CBIM_EMU
+  unsigned short o[4];
+  emu_ds_read_tr16_b64(p, o);
+  u32x2 r;
+  r.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+  r.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+  return r;
+#else
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  return __builtin_bit_cast(u32x2, v);
+#endif
+}
+// LDS written by some lanes of the wave, read by others: DS instructions of a wave execute in order, so only the compiler
+// (and the host-side executor, whose lanes are fibers) needs a fence
+__device__ __forceinline__ void hd_wave_sync() {
+#ifdef CBIM_EMU
+  (void)__any(0);
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
+
+// ---- stem weight gradient on the matrix cores: one input channel, bf16 dy rows of Cout = 32 * CP channels ------------------
+// dw[co][tap] = sum_v dy[v][co] x[v + tap]: v_mfma_f32_16x16x32_bf16 contracting over 32 VOXELS (4 w-rows of the 4x8x8 tile).
+// A = dy^T through the LDS transpose read (as k_wgrad_r32), B = the im2col column of a tap: the 8 voxels of a w-row are 8
+// consecutive halo values starting at kw — one 16-byte + one 4-byte LDS read and a 16-bit funnel shift; the fp32 image is
+// split into bf16 hi + lo planes (two MFMAs, ~2^-17).  Accumulators [co 32 CP][tap 32] stay in registers over the
+// workgroup's strip of tiles; slab per workgroup + k_stem_wgrad_reduce as before.  k_stem_wgrad spends 27 x 8 FMAs per
+// (voxel row, co) thread on the vector ALU: 196 us at 128^3 x 32 (dy is read in ~25 us).
+template <int CP>
+__global__ void __launch_bounds__(NT) k_stem_wgrad_mfma(StemParams p) {
+  constexpr int Cout = 32 * CP, ROWB = Cout * 2;
+  CBIM_DYN_SMEM(smem);
+  const int rows = p.hD * p.hH;
+  unsigned char* hiL = smem;                                  // [hD*hH][16] bf16
+  unsigned char* loL = hiL + rows * 32;
+  unsigned char* dyL = loL + rows * 32;                       // [256 voxels][Cout] bf16 (offset: a multiple of 64 B)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int n = blockIdx.x / p.strips_per_n, strip = blockIdx.x % p.strips_per_n;
+  const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+  const int t_begin = strip * p.tiles_per_strip;
+  int t_end = t_begin + p.tiles_per_strip;
+  if (t_end > tiles_per_n) t_end = tiles_per_n;
+  const size_t Sin = (size_t)p.Di * p.Hi * p.Wi;
+  // this lane's two taps (tap tile tt: tap = li + 16 tt)
+  int trow[2], tkw[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int tp = li + 16 * tt < p.taps ? li + 16 * tt : 0;
+    const int kw = tp % p.kW, kh = (tp / p.kW) % p.kH, kd = tp / (p.kW * p.kH);
+    trow[tt] = kd * p.hH + kh;
+    tkw[tt] = kw;
+  }
+  f32x4 acc[CP][2][2];
+#pragma unroll
+  for (int q = 0; q < CP; ++q)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) acc[q][u][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = t_begin; t < t_end; ++t) {
+    const int od0 = (t / (p.tiles_w * p.tiles_h)) * 4, oh0 = ((t / p.tiles_w) % p.tiles_h) * 8, ow0 = (t % p.tiles_w) * 8;
+    __syncthreads();
+    for (int i = tid; i < rows * 16; i += NT) {
+      const int hw = i & 15, r = i >> 4, hh = r % p.hH, hd = r / p.hH;
+      const int id = od0 - p.pD + hd, ih = oh0 - p.pH + hh, iw = ow0 - p.pW + hw;
+      float v = 0.f;
+      if (hw < p.hW && id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi)
+        v = p.x[(size_t)n * Sin + ((size_t)id * p.Hi + ih) * p.Wi + iw];
+      const unsigned hi = pk_bf16(v, 0.f) & 0xffffu;
+      ((bf16_t*)hiL)[i] = (bf16_t)hi;
+      ((bf16_t*)loL)[i] = (bf16_t)(pk_bf16(v - __uint_as_float(hi << 16), 0.f) & 0xffffu);
+    }
+#pragma unroll
+    for (int u = 0; u < 4 * CP; ++u) {                         // 256 voxels x 4 CP chunks of 16 bytes
+      const int item = tid + NT * u, vx = item / (4 * CP), ch = item % (4 * CP);
+      const int od = od0 + (vx >> 6), oh = oh0 + ((vx >> 3) & 7), ow = ow0 + (vx & 7);
+      u32x4 val = u32x4{0u, 0u, 0u, 0u};
+      if (od < p.Do && oh < p.Ho && ow < p.Wo) {
+        const size_t row = (size_t)n * p.Do * p.Ho * p.Wo + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+        val = ld_chunk<bf16_tag>(p.dy, row * Cout + (size_t)ch * 8);
+      }
+      *(u32x4*)(dyL + (size_t)vx * ROWB + ch * 16) = val;
+    }
+    __syncthreads();
+    const int td = wave;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                           // two 32-voxel steps per wave: w-rows th0 .. th0 + 3 of plane td
+      const int th0 = 4 * ks;
+      u32x4 bh[2], bl[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int r = (td * p.hH + th0 + g) + trow[tt];
+        const int kw = tkw[tt];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+          const unsigned char* src = (part ? loL : hiL) + r * 32;
+          const u32x4 a = *(const u32x4*)src;
+          const unsigned a4 = *(const unsigned*)(src + 16);
+          const unsigned d0 = a.x, d1 = a.y, d2 = a.z, d3 = a.w;
+          u32x4 o;
+          o.x = kw == 0 ? d0 : kw == 1 ? (d0 >> 16) | (d1 << 16) : d1;
+          o.y = kw == 0 ? d1 : kw == 1 ? (d1 >> 16) | (d2 << 16) : d2;
+          o.z = kw == 0 ? d2 : kw == 1 ? (d2 >> 16) | (d3 << 16) : d3;
+          o.w = kw == 0 ? d3 : kw == 1 ? (d3 >> 16) | (a4 << 16) : a4;
+          if (part) bl[tt] = o; else bh[tt] = o;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CP; ++q)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned char* a = dyL + (size_t)(td * 64 + th0 * 8 + 8 * g + (li >> 2)) * ROWB + (32 * q + 16 * u) * 2 + (li & 3) * 8;
+          const u32x2 a0 = hd_tr16_b64(a), a1 = hd_tr16_b64(a + 4 * ROWB);
+          const u32x4 af = u32x4{a0.x, a0.y, a1.x, a1.y};
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            acc[q][u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bl[tt]), acc[q][u][tt], 0, 0, 0);
+            acc[q][u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bh[tt]), acc[q][u][tt], 0, 0, 0);
+          }
+        }
+    }
+  }
+  // four waves' partial sums -> the workgroup's slab [taps][Cout], fixed order
+  __syncthreads();
+  float* red = (float*)smem;                                   // [4][32 taps][Cout]
+#pragma unroll
+  for (int q = 0; q < CP; ++q)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(wave * 32 + li + 16 * tt) * Cout + 32 * q + 16 * u + 4 * g + i] = acc[q][u][tt][i];
+  __syncthreads();
+  const size_t slab = (size_t)p.taps * Cout;
+  for (int o = tid; o < p.taps * Cout; o += NT) {
+    const int co = o % Cout, k = o / Cout;
+    const float a = (red[(0 * 32 + k) * Cout + co] + red[(1 * 32 + k) * Cout + co]) + (red[(2 * 32 + k) * Cout + co] + red[(3 * 32 + k) * Cout + co]);
+    p.ws[(size_t)blockIdx.x * slab + o] = a;
   }
 }
 
@@ -563,31 +809,6 @@ __global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x
 //                                  store), B = dz[k][v] transposed through a 1 KiB LDS tile of the bf16 planes.
 // Registers ~64, 8 waves per workgroup, steps are wave-private (no workgroup barrier inside the loop); the next step's
 // global loads are in flight while a step is computed.  Slab per workgroup [K][Cin+1] as before (k_head_bwd_reduce4).
-__device__ __forceinline__ u32x2 hd_tr16_b64(const unsigned char* p) {
-#ifdef CBIM_EMU
-  unsigned short o[4];
-  emu_ds_read_tr16_b64(p, o);
-  u32x2 r;
-  r.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
-  r.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
-  return r;
-#else
-  typedef __attribute__((ext_vector_type(4))) short s16x4;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-  return __builtin_bit_cast(u32x2, v);
-#endif
-}
-// LDS written by some lanes of the wave, read by others: DS instructions of a wave execute in order, so only the compiler
-// (and the host-side executor, whose lanes are fibers) needs a fence
-__device__ __forceinline__ void hd_wave_sync() {
-#ifdef CBIM_EMU
-  (void)__any(0);
-#else
-  asm volatile("" ::: "memory");
-#endif
-}
-
 static constexpr int HM_NW = 8;     // waves per workgroup
 template <int CP>
 __global__ void __launch_bounds__(HM_NW * 64) k_head_bwd_mfma(const void* __restrict__ x, const float* __restrict__ w,
@@ -758,6 +979,14 @@ static StemCfg stem_cfg(int N, int Do, int Ho, int Wo) {
 
 using namespace cbim;
 
+static int g_stem_mfma = getenv("CBIM_STEM_MFMA") ? atoi(getenv("CBIM_STEM_MFMA")) : 1;
+/* process-wide switch (tests, A/B): 0 = the VALU stem kernels also where the matrix-core ones apply; returns the old value */
+extern "C" int cbim_stem_mfma_enable(int on) {
+  const int old = g_stem_mfma;
+  g_stem_mfma = on ? 1 : 0;
+  return old;
+}
+
 static int stem_check(int dtype, int Cin, int Cout, int kD, int kH, int kW) {
   CBIM_CHECK(dtype == CBIM_F32 || dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype");
   int cpc = dtype == CBIM_BF16 ? 8 : 4;
@@ -788,6 +1017,17 @@ extern "C" int cbim_stem_conv_fwd(int dtype_out, const float* x, const float* w,
   CBIM_CHECK(smem <= 64 * 1024, CBIM_EUNSUPPORTED, "stem needs %zu B of LDS", smem);
   dim3 grid((unsigned)(N * p.tiles_d * p.tiles_h * p.tiles_w));
   hipStream_t st = (hipStream_t)stream;
+  if (g_stem_mfma && dtype_out == CBIM_BF16 && Cin == 1 && Cout % 32 == 0 && Cout <= 128) {   // matrix-core form
+    const size_t sm = (size_t)3 * NT * sizeof(unsigned);
+    dim3 pg(grid.x < 2048u ? grid.x : 2048u);             // persistent workgroups: the weight fragments are built once
+    switch (Cout / 32) {
+      case 1: CBIM_LAUNCH((k_stem_fwd_mfma<1>), pg, dim3(NT), sm, st, p); break;
+      case 2: CBIM_LAUNCH((k_stem_fwd_mfma<2>), pg, dim3(NT), sm, st, p); break;
+      case 3: CBIM_LAUNCH((k_stem_fwd_mfma<3>), pg, dim3(NT), sm, st, p); break;
+      default: CBIM_LAUNCH((k_stem_fwd_mfma<4>), pg, dim3(NT), sm, st, p); break;
+    }
+    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  }
   if (dtype_out == CBIM_BF16) CBIM_LAUNCH((k_stem_fwd<bf16_tag>), grid, dim3(NT), smem, st, p);
   else CBIM_LAUNCH((k_stem_fwd<float>), grid, dim3(NT), smem, st, p);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
@@ -809,6 +1049,31 @@ extern "C" int cbim_stem_conv_wgrad(int dtype, const float* x, const void* dy, f
   StemParams p;
   p.x = x; p.w = nullptr; p.y = nullptr; p.dy = dy; p.ws = (float*)workspace;
   stem_fill(p, N, Cin, Di, Hi, Wi, Cout, kD, kH, kW, pD, pH, pW, Do, Ho, Wo);
+  if (g_stem_mfma && dtype == CBIM_BF16 && Cin == 1 && Cout % 32 == 0 && Cout <= 128) {   // matrix-core form
+    const size_t tile = (size_t)p.hD * p.hH * 64 + (size_t)256 * Cout * 2, red = (size_t)4 * 32 * Cout * sizeof(float);
+    const size_t sm = tile > red ? tile : red;
+    dim3 grid((unsigned)(N * p.strips_per_n));
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+#ifndef CBIM_EMU
+      hipError_t e1 = hipFuncSetAttribute((const void*)k_stem_wgrad_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      CBIM_CHECK(e1 == hipSuccess, CBIM_ELAUNCH, "stem wgrad: cannot raise the dynamic LDS limit");
+#endif
+      attr_done = true;
+    }
+    switch (Cout / 32) {
+      case 1: CBIM_LAUNCH((k_stem_wgrad_mfma<1>), grid, dim3(NT), sm, st, p); break;
+      case 2: CBIM_LAUNCH((k_stem_wgrad_mfma<2>), grid, dim3(NT), sm, st, p); break;
+      case 3: CBIM_LAUNCH((k_stem_wgrad_mfma<3>), grid, dim3(NT), sm, st, p); break;
+      default: CBIM_LAUNCH((k_stem_wgrad_mfma<4>), grid, dim3(NT), sm, st, p); break;
+    }
+    if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+    const int total = p.taps * Cout;
+    CBIM_LAUNCH(k_stem_wgrad_reduce, dim3((total + 15) / 16), dim3(NT), 0, st, (const float*)workspace, dw,
+                N * p.strips_per_n, 1, p.taps, Cout);
+    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  }
   const int cg = Cin >= 2 ? 4 : 1;   // input channels sharing one pass over dy
   size_t smem = ((((size_t)p.hD * p.hH * p.hW + 3) & ~(size_t)3) * cg + (size_t)(NT / 32) * MAXTAPS * 32) * sizeof(float);
   CBIM_CHECK(smem <= 64 * 1024, CBIM_EUNSUPPORTED, "stem wgrad needs %zu B of LDS", smem);
@@ -858,7 +1123,7 @@ extern "C" int cbim_head_fwd(int dtype, const void* x, const float* w, const flo
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
-static int g_head_mfma = 1;
+static int g_head_mfma = getenv("CBIM_HEAD_MFMA") ? atoi(getenv("CBIM_HEAD_MFMA")) : 1;
 /* process-wide switch (tests, A/B): 0 = the VALU head backward also where the matrix-core kernel applies; returns the old value */
 extern "C" int cbim_head_mfma_enable(int on) {
   const int old = g_head_mfma;

@@ -274,6 +274,8 @@ int cbim_head_bwd(int dtype, const void* x, const float* w, const float* dlogits
 /* process-wide switch (tests, A/B): 0 = keep the VALU head backward where the matrix-core kernel (bf16, K <= 16,
  * Cin a multiple of 32 up to 128, S a multiple of 32) would run; returns the old value. */
 int cbim_head_mfma_enable(int on);
+/* the same switch for the stem (one input channel, bf16 rows of 32..128 channels: k_stem_fwd_mfma, k_stem_wgrad_mfma) */
+int cbim_stem_mfma_enable(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Loss: nn.CrossEntropyLoss(weight)(logits, label) + DiceLoss()(logits, label)

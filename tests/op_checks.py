@@ -356,6 +356,34 @@ def check_stem_head(dev, dtype, N=1, Cin=2, base=8, K=5, dhw=(6, 9, 10), k=(3, 3
     assert relerr(dbh.cpu(), bh.grad) < 2e-5
 
 
+def check_stem_mfma(dev, N=2, base=32, dhw=(6, 9, 10), k=(3, 3, 3)):
+    """The matrix-core stem kernels (one input channel, bf16 rows of 32..128 channels) against torch fp32 and the VALU kernels."""
+    from cbim_amd import _lib
+    torch.manual_seed(45)
+    BF = torch.bfloat16
+    pad = [i // 2 for i in k]
+    x = torch.randn(N, 1, *dhw) * 3.0 + 100.0            # CT-like offsets: the bf16 hi + lo split of the image
+    w = (torch.randn(base, 1, *k) * 0.2).requires_grad_(True)
+    yr = F.conv3d(x, w, None, 1, pad)
+    dyl = to_cl(torch.randn_like(yr), BF).to(dev)
+    yr.backward(from_cl(dyl.cpu()))
+    L = _lib.lib()
+    old = L.cbim_stem_mfma_enable(1)
+    try:
+        y = ops.stem_fwd(x.to(dev), w.detach().to(dev), pad, BF)
+        dw = ops.stem_wgrad(x.to(dev), dyl, tuple(w.shape), pad)
+        L.cbim_stem_mfma_enable(0)
+        y0 = ops.stem_fwd(x.to(dev), w.detach().to(dev), pad, BF)
+        dw0 = ops.stem_wgrad(x.to(dev), dyl, tuple(w.shape), pad)
+    finally:
+        L.cbim_stem_mfma_enable(old)
+    assert relerr(from_cl(y.cpu()), yr.detach()) < 4e-3
+    # same fp32 value up to ~2^-17 before the bf16 rounding: the two kernels agree except for a few last-bit flips
+    diff = (y.cpu().float() - y0.cpu().float()).abs()
+    assert float((diff > 0).float().mean()) < 0.02 and relerr(y.cpu().float(), y0.cpu().float()) < 8e-3
+    assert relerr(dw.cpu(), w.grad) < 2e-5 and relerr(dw.cpu(), dw0.cpu()) < 2e-5
+
+
 def check_head_mfma(dev, N=2, base=32, K=5, dhw=(4, 8, 8), need_dx=True):
     """The matrix-core head backward (k_head_bwd_mfma: bf16 rows of 32..128 channels, K <= 16, S % 32 == 0) against torch
     and against the VALU kernel it replaces."""

@@ -148,6 +148,12 @@ def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype, Cin=1, base=16, K=19, dhw=(3, 4, 5))        # head: more than 16 classes -> generic kernels
 
 
+def test_stem_on_matrix_cores(dev):
+    oc.check_stem_mfma(dev)
+    oc.check_stem_mfma(dev, N=1, base=64, dhw=(4, 8, 8), k=(1, 3, 3))
+    oc.check_stem_mfma(dev, N=1, base=96, dhw=(5, 7, 9))
+
+
 def test_head_backward_on_matrix_cores(dev):
     oc.check_head_mfma(dev)
     oc.check_head_mfma(dev, N=1, base=64, K=16, dhw=(8, 8, 9))              # 18 steps over 8 waves: ragged last round

@@ -73,8 +73,11 @@ del g96, dup, low, skip
 # stem / head
 xin = torch.randn(1, 1, n, n, n, device=dev)
 w = torch.randn(32, 1, 3, 3, 3, device=dev) * 0.2
-row("stem_fwd (1 -> 32, 3^3)", S * 4 + tb, lambda: ops.stem_fwd(xin, w, (1, 1, 1), BF))
-row("stem_wgrad", S * 4 + tb, lambda: ops.stem_wgrad(xin, g32, tuple(w.shape), (1, 1, 1)))
+for flag in (0, 1):
+    _lib.lib().cbim_stem_mfma_enable(flag)
+    tag = "matrix cores" if flag else "VALU"
+    row(f"stem_fwd (1 -> 32, 3^3) {tag}", S * 4 + tb, lambda: ops.stem_fwd(xin, w, (1, 1, 1), BF))
+    row(f"stem_wgrad {tag}", S * 4 + tb, lambda: ops.stem_wgrad(xin, g32, tuple(w.shape), (1, 1, 1)))
 wh = torch.randn(K, C, device=dev) * 0.3
 bh = torch.randn(K, device=dev)
 row(f"head_fwd (32 -> {K}, fp32 planes out)", tb + S * K * 4, lambda: ops.head_fwd(x32, wh, bh))
