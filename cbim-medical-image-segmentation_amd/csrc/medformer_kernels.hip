@@ -187,9 +187,24 @@ __global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int6
   const int g0 = blockIdx.y * DG;
   const int G = cch - g0 < DG ? cch - g0 : DG;
   const int TT = kD * kH * 3, pD = kD / 2, pH = kH / 2;
-  for (int i = threadIdx.x; i < TT * G * CPC; i += NT) {
-    int tap = i / (G * CPC), ch = i % (G * CPC);
-    w_s[tap * (DG * CPC) + ch] = w[(size_t)(g0 * CPC + ch) * TT + (flip ? TT - 1 - tap : tap)];
+  // 8 loads in flight per thread (one load per trip of a rolled loop: up to 27 serial memory round trips, ~20 us of every
+  // launch — the whole duration of the calls on the 8^3 .. 16^3 tensors of the deep stages)
+  for (int base = threadIdx.x; base < TT * G * CPC; base += NT * 8) {
+    float wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * NT;
+      wv[u] = 0.f;
+      if (i < TT * G * CPC) {
+        const int tap = i / (G * CPC), ch = i % (G * CPC);
+        wv[u] = w[(size_t)(g0 * CPC + ch) * TT + (flip ? TT - 1 - tap : tap)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * NT;
+      if (i < TT * G * CPC) w_s[(i / (G * CPC)) * (DG * CPC) + i % (G * CPC)] = wv[u];
+    }
   }
   __syncthreads();
   const int cl = threadIdx.x % G, sl = threadIdx.x / G, SL = NT / G;
@@ -392,40 +407,97 @@ __global__ void __launch_bounds__(NT) k_dwconv3_wgrad_lds(const void* __restrict
   float* x_s = (float*)smem;
   float* g_s = x_s + (size_t)3 * hH * hW * WG_CH * CPC;
   const int xitems = 3 * hH * hW * G, gitems = TH * W * G;
-  for (int i = threadIdx.x; i < xitems; i += NT) {
-    int cl = i % G, v = i / G;
-    int ww = v % hW - 1, hh = (v / hW) % hH - 1 + h0, dd = v / (hW * hH) - 1 + dz;
-    float f[CPC];
+  // Staging with SB loads in flight per thread: the one-item-per-trip loop it replaces waited a full memory round trip per
+  // item (13 items per thread on a 32^3 x 512-channel tensor: 26 us per workgroup at one workgroup per CU, 423 us for a
+  // launch that moves 67 MB).  With G dividing the workgroup size a thread always stages the same channel chunk, so its
+  // statistics / bias live in registers.
+  constexpr int SB = 8;
+  const bool fixed_cl = NT % G == 0;
+  float mean[CPC], rstd[CPC], bias[CPC];
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) f[j] = 0.f;
-    if (dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W) {
-      const int c0 = (g0 + cl) * CPC;
-      Elem<T>::unpack(ld_chunk<T>(x, ((((size_t)n * D + dd) * H + hh) * W + ww) * xs + c0), f);
-      if (in_stats) {
+  for (int j = 0; j < CPC; ++j) { mean[j] = 0.f; rstd[j] = 1.f; bias[j] = 0.f; }
+  if (fixed_cl) {
+    const int c0 = (g0 + threadIdx.x % G) * CPC;
 #pragma unroll
-        for (int j = 0; j < CPC; ++j)
-          f[j] = act_fwd((f[j] - in_stats[((size_t)n * C + c0 + j) * 2]) * in_stats[((size_t)n * C + c0 + j) * 2 + 1], act);
-      }
+    for (int j = 0; j < CPC; ++j) {
+      if (in_stats) { mean[j] = in_stats[((size_t)n * C + c0 + j) * 2]; rstd[j] = in_stats[((size_t)n * C + c0 + j) * 2 + 1]; }
+      if (dy_bias) bias[j] = dy_bias[(size_t)n * C + c0 + j];
     }
-#pragma unroll
-    for (int j = 0; j < CPC; ++j) x_s[((size_t)v * WG_CH + cl) * CPC + j] = f[j];
   }
-  for (int i = threadIdx.x; i < gitems; i += NT) {
-    int cl = i % G, v = i / G;
-    int ww = v % W, hh = v / W + h0;
-    float f[CPC];
+  for (int base = threadIdx.x; base < xitems; base += NT * SB) {
+    u32x4 raw[SB];
+    bool in[SB];
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) f[j] = 0.f;
-    if (hh < H) {
-      const int c0 = (g0 + cl) * CPC;
-      Elem<T>::unpack(ld_chunk<T>(dy, ((((size_t)n * D + dz) * H + hh) * W + ww) * dys + c0), f);
-      if (dy_bias) {
-#pragma unroll
-        for (int j = 0; j < CPC; ++j) f[j] += dy_bias[(size_t)n * C + c0 + j];
+    for (int u = 0; u < SB; ++u) {
+      const int i = base + u * NT;
+      raw[u] = u32x4{0u, 0u, 0u, 0u};
+      in[u] = false;
+      if (i < xitems) {
+        const int cl = i % G, v = i / G;
+        const int ww = v % hW - 1, hh = (v / hW) % hH - 1 + h0, dd = v / (hW * hH) - 1 + dz;
+        in[u] = dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        if (in[u]) raw[u] = ld_chunk<T>(x, ((((size_t)n * D + dd) * H + hh) * W + ww) * xs + (size_t)(g0 + cl) * CPC);
       }
     }
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) g_s[((size_t)v * WG_CH + cl) * CPC + j] = f[j];
+    for (int u = 0; u < SB; ++u) {
+      const int i = base + u * NT;
+      if (i < xitems) {
+        const int cl = i % G, v = i / G;
+        float f[CPC];
+        Elem<T>::unpack(raw[u], f);
+        if (in[u] && in_stats) {
+          if (fixed_cl) {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], act);
+          } else {
+            const int c0 = (g0 + cl) * CPC;
+#pragma unroll
+            for (int j = 0; j < CPC; ++j)
+              f[j] = act_fwd((f[j] - in_stats[((size_t)n * C + c0 + j) * 2]) * in_stats[((size_t)n * C + c0 + j) * 2 + 1], act);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) x_s[((size_t)v * WG_CH + cl) * CPC + j] = f[j];
+      }
+    }
+  }
+  for (int base = threadIdx.x; base < gitems; base += NT * SB) {
+    u32x4 raw[SB];
+    bool in[SB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int i = base + u * NT;
+      raw[u] = u32x4{0u, 0u, 0u, 0u};
+      in[u] = false;
+      if (i < gitems) {
+        const int cl = i % G, v = i / G;
+        const int ww = v % W, hh = v / W + h0;
+        in[u] = hh < H;
+        if (in[u]) raw[u] = ld_chunk<T>(dy, ((((size_t)n * D + dz) * H + hh) * W + ww) * dys + (size_t)(g0 + cl) * CPC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int i = base + u * NT;
+      if (i < gitems) {
+        const int cl = i % G, v = i / G;
+        float f[CPC];
+        Elem<T>::unpack(raw[u], f);
+        if (in[u] && dy_bias) {
+          if (fixed_cl) {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) f[j] += bias[j];
+          } else {
+            const int c0 = (g0 + cl) * CPC;
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) f[j] += dy_bias[(size_t)n * C + c0 + j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) g_s[((size_t)v * WG_CH + cl) * CPC + j] = f[j];
+      }
+    }
   }
   __syncthreads();
   // thread = (channel chunk, (kd,kh) pair, row third): the three kw taps of a pair share every dy value and slide

@@ -12,6 +12,7 @@ ap.add_argument("--size", type=int, default=128)
 ap.add_argument("--classes", type=int, default=16)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--json", default="")
+ap.add_argument("--only", default="", help="substring of the rows to time (the others are skipped)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 BF = torch.bfloat16
@@ -37,6 +38,8 @@ rows = []
 
 
 def row(name, nbytes, fn):
+    if a.only and a.only not in name:
+        return
     us = timeit(fn)
     rows.append({"kernel": name, "MB": round(nbytes / MB, 1), "us": round(us, 1), "GBps": round(nbytes / us / 1e3, 0)})
     print(f"{name:58s} {nbytes / MB:8.1f} MB {us:8.1f} us {nbytes / us / 1e3:7.0f} GB/s  ({nbytes / us / 1e3 / 6300 * 100:4.1f} % of 6.3 TB/s)", flush=True)
