@@ -11,6 +11,7 @@ python $R/bench.py > $O/${T}_resunet_bench.json 2> $O/${T}_resunet_bench.err
 python $R/bench.py --model medformer --cpu-size 64 > $O/${T}_medformer_bench.json 2> $O/${T}_medformer_bench.err
 python $R/bench.py --model swin_unetr --cpu-size 64 > $O/${T}_swin_bench.json 2> $O/${T}_swin_bench.err
 python $R/bench.py --aug 1 --no-cpu-baseline > $O/${T}_resunet_aug_bench.json 2> $O/${T}_resunet_aug_bench.err
+timeout 600 python $R/tools/stream_bench.py --json $O/${T}_stream.json > $O/${T}_stream.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 for m in resunet medformer swin_unetr; do
   rm -rf /tmp/pf_$m
