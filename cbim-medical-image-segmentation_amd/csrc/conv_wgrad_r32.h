@@ -18,3 +18,12 @@ int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stri
                           int cout_split, float* workspace, float* dw, void* stream);
 // fixed-order sum of the strips' slabs into dw[co][ci][tap] (fp32, natural nn.Conv3d layout)
 int cbim_wgrad_r32_reduce(const cbim_conv_desc* d, const float* workspace, float* dw, void* stream);
+
+// Depthwise 3x3x3 weight gradient on the same kernel (round 3): dw[c][tap] = sum_v dy[v][c] x[v + tap][c] is the DIAGONAL of the
+// dense 32 x 32 block of a 32-channel group — 32x more multiply-adds than needed, on matrix cores that are 16-32x faster than
+// the vector ALU form and fed by LDS-DMA (k_dwconv3_wgrad_lds: 331 us on a 32^3 x 512-channel tensor that moves 67 MB).
+// d->Cin == d->Cout == C; slabs [strips][C][27] into `workspace` (>= strips * C * 27 floats), summed by the caller.
+bool cbim_wgrad_r32_dw_eligible(const cbim_conv_desc* d);
+int cbim_wgrad_r32_dw_strips(const cbim_conv_desc* d);
+int cbim_wgrad_r32_dw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* dy, int64_t dy_stride,
+                             float* workspace, void* stream);

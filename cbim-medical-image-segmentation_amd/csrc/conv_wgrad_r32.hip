@@ -52,6 +52,7 @@ struct WR32Params {
   int tiles_d, tiles_h, tiles_w;
   int ci_blocks, Cout_pad, Cin_pad;
   int dbg;   // timing ablations for tools/ (env CBIM_WR32_DBG, wrong results); 0 in production
+  int diag;  // depthwise form: blockIdx.y = 32-channel group, only the diagonal (co == ci) of the 32 x 32 block is kept
 };
 
 // timing ablations of tools/wr32_ablate.py (wrong results): a COMPILE-TIME parameter of the kernel (as run-time tests they
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lv = lane & 15, lq = lane >> 4;
   // co half (WV = 8 only), ci half, row group of the 8x8 plane
   const int ch0 = WV == 8 ? (wave & 1) : 0, cih = WV == 8 ? ((wave >> 1) & 1) : (wave & 1), vg = WV == 8 ? (wave >> 2) : (wave >> 1);
-  const int cb = blockIdx.y / p.ci_blocks, ib = blockIdx.y % p.ci_blocks;
+  const int cb = p.diag ? (int)blockIdx.y : (int)blockIdx.y / p.ci_blocks, ib = p.diag ? (int)blockIdx.y : (int)blockIdx.y % p.ci_blocks;
   const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
   const int n_tiles = p.N * tiles_per_n;
   const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -368,7 +369,14 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
       }
   }
   __syncthreads();
-  {
+  if (p.diag) {
+    // depthwise: T[c][c][tap] of this 32-channel group -> slab [strip][C][27]
+    float* dst = p.ws + ((size_t)lb * p.Cout_pad + (size_t)cb * 32) * 27;
+    for (int i = tid; i < 32 * 27; i += WR_NT) {
+      const int c = i / 27, tp = i % 27;
+      dst[i] = T[(c * 32 + c) * 27 + tp];
+    }
+  } else {
     const size_t total = (size_t)27 * p.Cout_pad * p.Cin_pad;
     float* dst = p.ws + (size_t)lb * total;              // (a single strip: p.ws is dw itself)
     constexpr int ROW4 = 32 * 27 / 4;                    // float4 per co row of the tile
@@ -451,12 +459,19 @@ static void wr32_tiles(const cbim_conv_desc* d, int& td, int& th, int& tw) {
 
 // strips per (co chunk, ci chunk) pair: whole rounds of 256 persistent workgroups, a tile and a half of fixed cost per
 // workgroup (exposed first load, slab write), slabs capped at 96 MiB
+static int wr32_strips_for(int64_t n_tiles, int64_t pairs, int64_t slab);
 int cbim_wgrad_r32_strips(const cbim_conv_desc* d) {
   int td, th, tw;
   wr32_tiles(d, td, th, tw);
-  const int64_t n_tiles = (int64_t)d->N * td * th * tw;
-  const int64_t pairs = (int64_t)(d->Cout / 32) * (d->Cin / 32);
-  const int64_t slab = (int64_t)27 * d->Cout * d->Cin * 4;
+  return wr32_strips_for((int64_t)d->N * td * th * tw, (int64_t)(d->Cout / 32) * (d->Cin / 32), (int64_t)27 * d->Cout * d->Cin * 4);
+}
+// depthwise form: one (group, group) pair per 32 channels, slabs [C][27]
+int cbim_wgrad_r32_dw_strips(const cbim_conv_desc* d) {
+  int td, th, tw;
+  wr32_tiles(d, td, th, tw);
+  return wr32_strips_for((int64_t)d->N * td * th * tw, (int64_t)(d->Cout / 32), (int64_t)27 * d->Cout * 4);
+}
+static int wr32_strips_for(int64_t n_tiles, int64_t pairs, int64_t slab) {
   int64_t gmax = (96ll << 20) / slab;
   if (gmax < 1) gmax = 1;
   if (gmax > n_tiles) gmax = n_tiles;
@@ -478,14 +493,32 @@ size_t cbim_wgrad_r32_workspace(const cbim_conv_desc* d) {
   return (size_t)cbim_wgrad_r32_strips(d) * 27 * d->Cout * d->Cin * sizeof(float);
 }
 
+static int wr32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                       int cin_split, const void* dy, int64_t dy_stride, const void* dy2, int64_t dy2_stride,
+                       int cout_split, float* workspace, float* dw, void* stream, int diag);
 int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
                           int cin_split, const void* dy, int64_t dy_stride, const void* dy2, int64_t dy2_stride,
                           int cout_split, float* workspace, float* dw, void* stream) {
+  return wr32_launch(d, x, x_stride, x2, x2_stride, cin_split, dy, dy_stride, dy2, dy2_stride, cout_split, workspace, dw, stream, 0);
+}
+// depthwise weight gradient (d->Cin == d->Cout == C, groups = C): slabs [strips][C][27] into `workspace`
+int cbim_wgrad_r32_dw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* dy, int64_t dy_stride,
+                             float* workspace, void* stream) {
+  return wr32_launch(d, x, x_stride, nullptr, 0, 0, dy, dy_stride, nullptr, 0, 0, workspace, workspace, stream, 1);
+}
+bool cbim_wgrad_r32_dw_eligible(const cbim_conv_desc* d) {
+  return cbim_wgrad_r32_eligible(d, nullptr, nullptr, 0, nullptr, 0) && d->Cin == d->Cout;
+}
+static int wr32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                       int cin_split, const void* dy, int64_t dy_stride, const void* dy2, int64_t dy2_stride,
+                       int cout_split, float* workspace, float* dw, void* stream, int diag) {
   WR32Params p;
+  p.diag = diag;
+  const int strips = diag ? cbim_wgrad_r32_dw_strips(d) : cbim_wgrad_r32_strips(d);
   p.x = x; p.x_stride = x_stride; p.x2 = x2; p.x2_stride = x2 ? x2_stride : x_stride; p.ci_split = x2 ? cin_split / 32 : d->Cin / 32;
   p.dy = dy; p.dy_stride = dy_stride; p.dy2 = dy2; p.dy2_stride = dy2 ? dy2_stride : dy_stride;
   p.co_split = dy2 ? cout_split / 32 : d->Cout / 32;
-  p.ws = cbim_wgrad_r32_strips(d) == 1 ? dw : workspace;     // a single strip writes the gradient itself
+  p.ws = strips == 1 ? dw : workspace;     // a single strip writes the gradient itself
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
   wr32_tiles(d, p.tiles_d, p.tiles_h, p.tiles_w);
   p.ci_blocks = d->Cin / 32; p.Cout_pad = d->Cout; p.Cin_pad = d->Cin;
@@ -507,7 +540,7 @@ int cbim_wgrad_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stri
     attr_done = true;
   }
 #endif
-  dim3 grid((unsigned)cbim_wgrad_r32_strips(d), (unsigned)((d->Cout / 32) * (d->Cin / 32)));
+  dim3 grid((unsigned)strips, (unsigned)(diag ? d->Cout / 32 : (d->Cout / 32) * (d->Cin / 32)));
 #ifdef CBIM_WR32_ABLATE
 #define WR_ABL(W, D)                                                                                                   \
   if (wr32_waves() == W && p.dbg == D) {                                                                               \

@@ -16,6 +16,7 @@
 // Layout: feature maps channels-last [N][L][C]; head split is the reference's "(dim_head heads)":
 // channel c = d*heads + h (medformer_utils.py:43-51).  Map-side tensors are float32 [N][M][inner].
 #include "cbim_common.h"
+#include "conv_wgrad_r32.h"
 #include <stdlib.h>
 
 #ifdef CBIM_EMU
@@ -1252,6 +1253,21 @@ extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, c
   dw_wgrad_cfg((int64_t)N * D * H * W, &nblk, &vpb);
   int TT = kD * kH * kW, G = NT / TT, cch = C / cpc;
   hipStream_t st = (hipStream_t)stream;
+  // matrix-core form (k_wgrad_r32, diagonal of the 32-channel groups): raw input, no gradient bias (functional.DWConvFn
+  // materialises act(IN(x)) and dy + bias first), bf16, extents >= 8
+  static const int dw_mfma = getenv("CBIM_DW_WGRAD_MFMA") ? atoi(getenv("CBIM_DW_WGRAD_MFMA")) : 1;
+  if (dw_mfma && dtype == CBIM_BF16 && !in_stats && !dy_bias && kD == 3 && kH == 3 && kW == 3 && C % 32 == 0) {
+    cbim_conv_desc cd = {};
+    cd.dtype = CBIM_BF16; cd.N = N; cd.Di = D; cd.Hi = H; cd.Wi = W; cd.Cin = C; cd.Do = D; cd.Ho = H; cd.Wo = W; cd.Cout = C;
+    cd.kD = 3; cd.kH = 3; cd.kW = 3; cd.pD = 1; cd.pH = 1; cd.pW = 1; cd.act = 0;
+    if (cbim_wgrad_r32_dw_eligible(&cd)) {
+      const int strips = cbim_wgrad_r32_dw_strips(&cd);
+      CBIM_CHECK((size_t)strips * C * 27 * sizeof(float) <= ws_bytes, CBIM_EWORKSPACE, "dwconv wgrad workspace too small for %d strips", strips);
+      if (int e = cbim_wgrad_r32_dw_launch(&cd, x, x_stride, dy, dy_stride, (float*)workspace, stream)) return e;
+      CBIM_LAUNCH(k_dwconv_wgrad_reduce, dim3((C * 27 + NT - 1) / NT), dim3(NT), 0, st, (const float*)workspace, dw, strips, C * 27);
+      return launch_ok("dwconv3d_wgrad_reduce");
+    }
+  }
   // channel chunks per workgroup: 8.  (Narrower groups would let 64-wide rows into the LDS-tiled kernel — the 64^3 x 256-channel
   // PatchMerging depthwise of MedFormer runs on the streaming kernel at 897 us — but with 4 chunks and 2-row tiles the tiled
   // kernel took 1.64 ms on that call: measured and rejected, profiles/r03_q_medformer_kernels.txt.)

@@ -742,11 +742,30 @@ def dwconv(x, w2d, k, in_stats=None, act: int = 0, bias=None, flip: bool = False
     return y
 
 
+DW_WGRAD_MFMA = __import__("os").environ.get("CBIM_DW_WGRAD_MFMA", "1") not in ("", "0")   # depthwise wgrad on k_wgrad_r32 (diagonal of 32-channel groups)
+
+
+def dwconv_wgrad_on_matrix_cores(x, k) -> bool:
+    """Whether cbim_dwconv3d_wgrad takes the matrix-core form for this tensor when it gets the input AS IT IS and no
+    gradient bias (the caller then materialises act(IN(x)) and dy + bias first)."""
+    return (DW_WGRAD_MFMA and x.dtype == torch.bfloat16 and tuple(int(i) for i in k) == (3, 3, 3) and int(x.shape[-1]) % 32 == 0
+            and min(int(x.shape[1]), int(x.shape[2]), int(x.shape[3])) >= 8)
+
+
 def dwconv_wgrad(x, in_stats, act: int, dy, k, dy_bias=None):
     _dev_ok(x, in_stats, dy, dy_bias)
     N, D, H, W, Cc = map(int, x.shape)
     kD, kH, kW = (int(i) for i in k)
     L = _lib.lib()
+    if dwconv_wgrad_on_matrix_cores(x, k) and (in_stats is not None or dy_bias is not None):
+        # one streaming pass each: a = act(IN(x)) and dy + bias (fp32 add, rounded once — what autograd's bf16 accumulation of
+        # the two gradient branches does in the reference under autocast), then the raw form
+        if in_stats is not None:
+            x = norm_act_fwd(x, in_stats, act)
+        if dy_bias is not None:
+            shift = torch.stack([-dy_bias.float(), torch.ones_like(dy_bias, dtype=torch.float32)], -1).contiguous()
+            dy = norm_act_fwd(dy, shift, ACT["none"])
+        in_stats, dy_bias, act = None, None, 0
     nbytes = L.cbim_dwconv3d_wgrad_workspace(N, D, H, W, Cc, kD, kH, kW)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     dw = torch.empty((Cc, kD * kH * kW), dtype=torch.float32, device=x.device)

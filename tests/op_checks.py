@@ -519,6 +519,40 @@ def check_dwconv(dev, dtype, N=2, C=16, dhw=(5, 6, 7), k=(3, 3, 3), act="relu", 
     assert relerr(dw.cpu(), wr.grad.reshape(C, -1)) < tol(dtype, 5e-5, 1e-2), "dw wgrad"
 
 
+def check_dwconv_wgrad_mfma(dev, N=1, C=64, dhw=(8, 8, 16), act="relu", with_stats=True, with_bias=True, seed=13):
+    """Depthwise 3x3x3 weight gradient on the matrix cores (k_wgrad_r32, diagonal of the 32-channel groups) against torch and
+    against the vector-ALU kernels; act(IN(x)) and dy + bias are materialised first when given."""
+    torch.manual_seed(seed)
+    BF = torch.bfloat16
+    x = torch.randn(N, C, *dhw) + 0.3
+    xl = to_cl(x, BF).to(dev)
+    xr = from_cl(xl.cpu())
+    st = ops.instnorm_stats(xl, 1e-5) if with_stats else None
+    a = xr
+    if with_stats:
+        xh = F.instance_norm(xr, eps=1e-5)
+        a = F.relu(xh) if act == "relu" else xh
+    a = a.clone().requires_grad_(True)
+    wr = (torch.randn(C, 1, 3, 3, 3) * 0.3).requires_grad_(True)
+    yr = F.conv3d(a, wr, None, 1, 1, 1, C)
+    dyl = to_cl(torch.randn_like(yr), BF).to(dev)
+    bias = torch.randn(N, C) * 0.1 if with_bias else None
+    yr.backward(from_cl(dyl.cpu()) + (bias[:, :, None, None, None] if with_bias else 0.0))
+    keep = ops.DW_WGRAD_MFMA
+    try:
+        ops.DW_WGRAD_MFMA = True
+        assert ops.dwconv_wgrad_on_matrix_cores(xl, (3, 3, 3))
+        dw = ops.dwconv_wgrad(xl, st, ops.ACT[act], dyl, (3, 3, 3), dy_bias=None if bias is None else bias.to(dev))
+        ops.DW_WGRAD_MFMA = False
+        dw0 = ops.dwconv_wgrad(xl, st, ops.ACT[act], dyl, (3, 3, 3), dy_bias=None if bias is None else bias.to(dev))
+    finally:
+        ops.DW_WGRAD_MFMA = keep
+    # raw operands: same bf16 products, fp32 sums -> agreement to summation order; materialised operands are rounded to bf16 once
+    t = 2e-5 if not (with_stats or with_bias) else 1e-2          # (the bf16 bar of check_dwconv)
+    assert relerr(dw.cpu(), wr.grad.reshape(C, -1)) < t, "dw wgrad (matrix cores) vs torch"
+    assert relerr(dw.cpu(), dw0.cpu()) < t, "dw wgrad (matrix cores) vs vector ALU"
+
+
 def check_space_to_depth(dev, dtype, N=2, C=8, dhw=(4, 6, 8), scale=(2, 2, 2)):
     torch.manual_seed(12)
     x = torch.randn(N, C, *dhw)

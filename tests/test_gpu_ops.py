@@ -152,6 +152,14 @@ def test_dwconv_wide_rows(dev, dtype, W):
     oc.check_dwconv(dev, dtype, N=1, C=256, dhw=(2, 3, W), act="none")
 
 
+def test_dwconv_wgrad_on_matrix_cores(dev):
+    oc.check_dwconv_wgrad_mfma(dev, with_stats=False, with_bias=False)
+    oc.check_dwconv_wgrad_mfma(dev)
+    oc.check_dwconv_wgrad_mfma(dev, N=2, C=32, dhw=(9, 8, 11), act="none", with_bias=False)   # ragged tiles, two images
+    oc.check_dwconv_wgrad_mfma(dev, N=1, C=512, dhw=(32, 32, 32))                      # the MBConv expansion at 32^3
+    oc.check_dwconv_wgrad_mfma(dev, N=2, C=256, dhw=(16, 24, 64), with_stats=False)    # 64-wide rows (streaming-kernel territory before)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_space_to_depth(dev, dtype):
     oc.check_space_to_depth(dev, dtype)

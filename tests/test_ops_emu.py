@@ -84,6 +84,12 @@ def test_dwconv_wide_rows(dev, dtype, W):
     oc.check_dwconv(dev, dtype, N=1, C=16, dhw=(2, 3, W))
 
 
+def test_dwconv_wgrad_on_matrix_cores(dev):
+    oc.check_dwconv_wgrad_mfma(dev, with_stats=False, with_bias=False)
+    oc.check_dwconv_wgrad_mfma(dev)
+    oc.check_dwconv_wgrad_mfma(dev, N=2, C=32, dhw=(9, 8, 11), act="none", with_bias=False)   # ragged tiles, two images
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_space_to_depth(dev, dtype):
     oc.check_space_to_depth(dev, dtype)
