@@ -70,7 +70,7 @@ struct UpTileParams {
   int P;                                 // stats: records per image (workgroups per image)
 };
 
-struct AxTab { int r0, r1; float l0, l1; };          // source rows relative to the box origin + weights
+struct AxTab { int r0, r1; float l0, l1; };          // BYTE offsets of the two source rows / planes / columns inside the LDS box + weights
 
 // ---- stage the coarse box of fine tile (td, th, tw) of image n and the axis tables --------------------------------
 // LDS layout: [box rows][Cl * ES bytes] | AxTab d[FD] | AxTab h[FH] | AxTab w[FW]
@@ -101,7 +101,10 @@ __device__ __forceinline__ void stage_box(const UpTileParams& p, unsigned char* 
     else if (tid < FD + FH) { dst = h0 + tid - FD; if (dst > p.H - 1) dst = p.H - 1; in = p.Hl; org = oh; sc = sh; }
     else { dst = w0 + tid - FD - FH; if (dst > p.W - 1) dst = p.W - 1; in = p.Wl; org = ow; sc = sw; }
     const ULin l = ulin_src(dst, sc, in);
-    tab[tid] = AxTab{l.i0 - org, l.i1 - org, l.l0, l.l1};
+    // byte offset of a box coordinate along this axis: the per-voxel address is then three adds (the products of run-time
+    // extents were 16 quarter-rate 32-bit multiplies per output chunk)
+    const int unit = (int)rowb * (tid < FD ? p.bh * p.bw : tid < FD + FH ? p.bw : 1);
+    tab[tid] = AxTab{(l.i0 - org) * unit, (l.i1 - org) * unit, l.l0, l.l1};
   }
 }
 
@@ -118,9 +121,9 @@ __device__ __forceinline__ void up_from_box(const UpTileParams& p, const unsigne
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const unsigned rbase = (unsigned)(((a ? ad.r1 : ad.r0) * p.bh + (b ? ah.r1 : ah.r0)) * p.bw);
-      cn[(a * 2 + b) * 2] = *(const u32x4*)(smem + (rbase + (unsigned)aw.r0) * rowb + (unsigned)cl * ES);
-      cn[(a * 2 + b) * 2 + 1] = *(const u32x4*)(smem + (rbase + (unsigned)aw.r1) * rowb + (unsigned)cl * ES);
+      const unsigned rbase = (unsigned)((a ? ad.r1 : ad.r0) + (b ? ah.r1 : ah.r0)) + (unsigned)cl * ES;
+      cn[(a * 2 + b) * 2] = *(const u32x4*)(smem + rbase + (unsigned)aw.r0);
+      cn[(a * 2 + b) * 2 + 1] = *(const u32x4*)(smem + rbase + (unsigned)aw.r1);
     }
   float acc[CPC];
   trilerp<T>(cn, ad.l0, ad.l1, ah.l0, ah.l1, aw.l0, aw.l1, acc);
