@@ -56,6 +56,8 @@ _SIGS = {
     "cbim_upcat_bwd": (i32, [i32, vp, vp, vp] + [i32] * 10 + [vp]),
     "cbim_upcat_fwd_stats": (i32, [i32, vp, vp, vp] + [i32] * 10 + [f32, vp, i32, vp, vp]),
     "cbim_up_stats": (i32, [i32, vp] + [i32] * 8 + [f32, vp, i32, vp, vp]),
+    "cbim_up_gram_parts": (i32, [i32, i32, i32]),
+    "cbim_up_stats_gram": (i32, [i32, vp] + [i32] * 8 + [f32, vp, i32, vp, vp]),
     "cbim_upcat_act_fwd": (i32, [i32, vp, vp, vp, vp] + [i32] * 11 + [vp]),
     "cbim_upcat_norm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 10 + [vp]),
     "cbim_up_tile_parts": (i32, [i32, i32, i32]),

@@ -183,9 +183,16 @@ __global__ void __launch_bounds__(FIN_T) k_stats_finalize(const float* __restric
       double var = red[0] > 0.0 ? red[2] / red[0] : 0.0;
       out[(size_t)i * 2] = (float)red[1];
       out[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    } else {
+    } else if (mode == 1) {
       out[(size_t)i * 2] = (float)(red[1] / count);
       out[(size_t)i * 2 + 1] = (float)(red[2] / count);
+    } else {
+      // mode 2: records (shift, sum, sum of squares) of x - shift (k_up_gram_stats): mean and 1 / sqrt(var + eps)
+      const double m = red[1] / count;
+      double var = red[2] / count - m * m;
+      if (var < 0.0) var = 0.0;
+      out[(size_t)i * 2] = (float)((double)base[0] + m);
+      out[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
   }
 }

@@ -224,9 +224,9 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd_stats(const void* __restrict__
 }
 
 
-// trilinear(align_corners) value of one channel chunk of `low` at fine voxel (n, d, h, w), rounded to the storage type
-// exactly as k_upcat_fwd writes it (the fused kernels below never store the up-sampled tensor, but must see the values
-// a stored copy would hold)
+// trilinear(align_corners) value of one channel chunk of `low` at fine voxel (n, d, h, w) in float32: the fused kernels
+// below never store the up-sampled tensor, so it is never rounded to the storage type either — they normalise the fp32
+// interpolation with the statistics of the fp32 interpolation (k_up_gram_stats)
 template <typename T>
 __device__ __forceinline__ void up_chunk(const void* __restrict__ low, int n, int d, int h, int w, float sd, float sh,
                                          float sw, int Dl, int Hl, int Wl, int Cl, int cl, float* f) {
@@ -241,9 +241,7 @@ __device__ __forceinline__ void up_chunk(const void* __restrict__ low, int n, in
       cn[(a * 2 + b) * 2] = ld_chunk<T>(low, (rbase + lw.i0) * Cl + cl);
       cn[(a * 2 + b) * 2 + 1] = ld_chunk<T>(low, (rbase + lw.i1) * Cl + cl);
     }
-  float acc[CPC];
-  trilerp<T>(cn, ld.l0, ld.l1, lh.l0, lh.l1, lw.l0, lw.l1, acc);
-  Elem<T>::unpack(Elem<T>::pack(acc), f);
+  trilerp<T>(cn, ld.l0, ld.l1, lh.l0, lh.l1, lw.l0, lw.l1, f);
 }
 
 // a = act(IN([skip | up(low)])) in ONE pass: the decoder level's first block reads the activated concatenation, the raw
@@ -433,6 +431,164 @@ __global__ void __launch_bounds__(NT) k_lin_adjoint_axis(const void* __restrict_
     const size_t e = ((size_t)(o * L + l) * inner_items + ic) * VEC;
     if (VEC == 1) ((float*)dst)[e] = acc[0];
     else st_chunk<T>(dst, e, Elem<T>::pack(acc));
+  }
+}
+
+// ---- statistics of the virtual up-sampled tensor from the COARSE grid --------------------------------------------------------
+// up = (W_d (x) W_h (x) W_w) low with 1-D interpolation matrices whose rows hold <= 2 adjacent weights, so
+//     sum_f up_f   = sum_l cw_d[l_d] cw_h[l_h] cw_w[l_w] low_l                      (cw = column sums)
+//     sum_f up_f^2 = low^T (G_d (x) G_h (x) G_w) low,   G = W^T W tridiagonal      (a 27-point stencil on the coarse grid)
+// — 1/8 of the voxels of the fine grid and no interpolation at all (k_up_tile<0> recomputes the whole up-sampled tensor for
+// its statistics: 70 M vector instructions, 150 us at 64^3 -> 128^3 x 64 channels for 34 MB of input).  Both sums are taken
+// of low - shift[c] (interpolation reproduces constants, so up(low - s) = up(low) - s): E[x^2] - E[x]^2 stays well
+// conditioned.  A workgroup owns 4x8x8 coarse tiles (+1 halo, fp32 in LDS, 32 channels at a time); records (shift, sum,
+// sum of squares) per workgroup, combined in fp64 by k_stats_finalize mode 2.  The statistics are those of the fp32
+// interpolation; the tensor the next pass normalises is the same values rounded to the storage type (rounding noise only).
+struct GramAx { float gm, g0, gp, cw; };
+static constexpr int GR_D = 4, GR_H = 8, GR_W = 8, GR_ROWS = (GR_D + 2) * (GR_H + 2) * (GR_W + 2), GR_C = 32;
+static constexpr size_t GR_SMEM = (size_t)GR_ROWS * GR_C * 4 + (GR_D + GR_H + GR_W) * sizeof(GramAx);
+template <typename T>
+__global__ void __launch_bounds__(NT) k_up_gram_stats(const void* __restrict__ low, int Dl, int Hl, int Wl, int Cl, int D, int H,
+                                                      int W, int P, float* __restrict__ partials) {
+  constexpr int CPC = Elem<T>::CPC, GCH = GR_C / CPC, VLC = NT / GCH;
+#ifdef CBIM_EMU
+  unsigned char* smem = cbim_emu::dyn_smem();
+#else
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
+  float* box = (float*)smem;                                         // [6][10][10][32]
+  GramAx* ax = (GramAx*)(smem + (size_t)GR_ROWS * GR_C * 4);         // d[4] | h[8] | w[8]
+  const int tid = threadIdx.x, cc = tid % GCH, vl = tid / GCH, n = blockIdx.y;
+  const int tiles_d = (Dl + GR_D - 1) / GR_D, tiles_h = (Hl + GR_H - 1) / GR_H, tiles_w = (Wl + GR_W - 1) / GR_W;
+  const int tiles = tiles_d * tiles_h * tiles_w;
+  const float sd = lin_scale(Dl, D), sh = lin_scale(Hl, H), sw = lin_scale(Wl, W);
+  {
+    const int cg0 = (int)blockIdx.z * GR_C;          // one 32-channel group per workgroup (grid.z)
+    const int c0 = cg0 + cc * CPC;
+    const bool cok = c0 < Cl;
+    float shift[CPC], s1[CPC], s2[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) { shift[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    if (cok) Elem<T>::unpack(ld_chunk<T>(low, (size_t)n * Dl * Hl * Wl * Cl + c0), shift);   // the image's first voxel
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+      const int tw = t % tiles_w, q = t / tiles_w, th = q % tiles_h, td = q / tiles_h;
+      const int d0 = td * GR_D, h0 = th * GR_H, w0 = tw * GR_W;
+      __syncthreads();
+      // stage low - shift (zeros outside the grid / past Cl), five loads in flight per thread (bf16: two trips per tile)
+      for (int base = tid; base < GR_ROWS * GCH; base += NT * 5) {
+        u32x4 raw[5];
+        int ok[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int i = base + u * NT;
+          ok[u] = 0;
+          raw[u] = u32x4{0u, 0u, 0u, 0u};
+          if (i < GR_ROWS * GCH) {
+            const int r = i / GCH;
+            const int bw = r % (GR_W + 2), q2 = r / (GR_W + 2), bh = q2 % (GR_H + 2), bd = q2 / (GR_H + 2);
+            const int ld = d0 - 1 + bd, lh = h0 - 1 + bh, lw = w0 - 1 + bw;
+            ok[u] = 1;
+            if (cok && ld >= 0 && ld < Dl && lh >= 0 && lh < Hl && lw >= 0 && lw < Wl) {
+              raw[u] = ld_chunk<T>(low, ((((size_t)n * Dl + ld) * Hl + lh) * Wl + lw) * Cl + c0);
+              ok[u] = 2;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          if (!ok[u]) continue;
+          const int i = base + u * NT;
+          float f[CPC];
+          Elem<T>::unpack(raw[u], f);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) box[(size_t)(i / GCH) * GR_C + cc * CPC + j] = ok[u] == 2 ? f[j] - shift[j] : 0.f;
+        }
+      }
+      if (tid < 192) {                                   // (whole waves: the shuffles below need every lane of a wave)
+        // axis tables: entry e = tid / 8 (20 of the 24 exist), its fine indices dealt to 8 lanes
+        const int e = tid >> 3, k = tid & 7;
+        const bool ev = e < GR_D + GR_H + GR_W;
+        const int a = e < GR_D ? 0 : e < GR_D + GR_H ? 1 : 2;
+        const int l = (a == 0 ? d0 + e : a == 1 ? h0 + e - GR_D : w0 + e - GR_D - GR_H);
+        const int L = a == 0 ? Dl : a == 1 ? Hl : Wl, F = a == 0 ? D : a == 1 ? H : W;
+        const float sc = a == 0 ? sd : a == 1 ? sh : sw;
+        GramAx r = {0.f, 0.f, 0.f, 0.f};
+        if (ev && l < L) {
+          int lo, hi;
+          dst_range(l, sc, F, lo, hi);
+          for (int f = lo + k; f <= hi; f += 8) {
+            const float w0f = lin_weight_to(f, sc, L, l);
+            if (w0f == 0.f) continue;
+            r.g0 += w0f * w0f;
+            r.cw += w0f;
+            r.gm += w0f * lin_weight_to(f, sc, L, l - 1);
+            r.gp += w0f * lin_weight_to(f, sc, L, l + 1);
+          }
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+          r.g0 += __shfl_xor(r.g0, m, 8); r.cw += __shfl_xor(r.cw, m, 8);
+          r.gm += __shfl_xor(r.gm, m, 8); r.gp += __shfl_xor(r.gp, m, 8);
+        }
+        if (ev && k == 0) ax[e] = r;
+      }
+      __syncthreads();
+      for (int v = vl; v < GR_D * GR_H * GR_W; v += VLC) {
+        const int bw = v % GR_W, bh = (v / GR_W) % GR_H, bd = v / (GR_W * GR_H);
+        if (d0 + bd >= Dl || h0 + bh >= Hl || w0 + bw >= Wl) continue;
+        const GramAx gd = ax[bd], gh = ax[GR_D + bh], gw = ax[GR_D + GR_H + bw];
+        const float* ctr = box + (size_t)(((bd + 1) * (GR_H + 2) + bh + 1) * (GR_W + 2) + bw + 1) * GR_C + cc * CPC;
+        float tt[CPC];
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) tt[j] = 0.f;
+#pragma unroll
+        for (int a = -1; a <= 1; ++a) {
+          const float wa = a < 0 ? gd.gm : a == 0 ? gd.g0 : gd.gp;
+          float ua[CPC];
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) ua[j] = 0.f;
+#pragma unroll
+          for (int b = -1; b <= 1; ++b) {
+            const float wb = b < 0 ? gh.gm : b == 0 ? gh.g0 : gh.gp;
+            const float* row = ctr + (a * (GR_H + 2) + b) * (GR_W + 2) * GR_C;
+            float ub[CPC];
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) ub[j] = fmaf(gw.gp, row[GR_C + j], fmaf(gw.g0, row[j], gw.gm * row[-GR_C + j]));
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) ua[j] = fmaf(wb, ub[j], ua[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) tt[j] = fmaf(wa, ua[j], tt[j]);
+        }
+        const float cw3 = gd.cw * gh.cw * gw.cw;
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) { s1[j] = fmaf(cw3, ctr[j], s1[j]); s2[j] = fmaf(ctr[j], tt[j], s2[j]); }
+      }
+    }
+    // voxel lanes -> one record per channel and workgroup (fixed order)
+    __syncthreads();
+    float* red = (float*)smem;                                       // [NT][CPC][2] floats (the box is dead)
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) { red[(tid * CPC + j) * 2] = s1[j]; red[(tid * CPC + j) * 2 + 1] = s2[j]; }
+    __syncthreads();
+    // two levels: thread (channel ch, eighth e8) adds the voxel lanes e8, e8 + 8, ..; 32 threads add the eight sums
+    {
+      const int ch = tid & (GR_C - 1), e8 = tid >> 5, c2 = ch / CPC, j = ch % CPC;
+      float a1 = 0.f, a2 = 0.f;
+      for (int qv = e8; qv < VLC; qv += NT / GR_C) { a1 += red[((qv * GCH + c2) * CPC + j) * 2]; a2 += red[((qv * GCH + c2) * CPC + j) * 2 + 1]; }
+      __syncthreads();
+      red[(e8 * GR_C + ch) * 2] = a1; red[(e8 * GR_C + ch) * 2 + 1] = a2;
+      __syncthreads();
+    }
+    if (tid < GR_C && cg0 + tid < Cl) {
+      const int c2 = tid / CPC, j = tid % CPC;
+      float a1 = 0.f, a2 = 0.f;
+      for (int qv = 0; qv < NT / GR_C; ++qv) { a1 += red[(qv * GR_C + tid) * 2]; a2 += red[(qv * GR_C + tid) * 2 + 1]; }
+      float shc[CPC];
+      Elem<T>::unpack(ld_chunk<T>(low, (size_t)n * Dl * Hl * Wl * Cl + cg0 + c2 * CPC), shc);
+      const size_t o = (((size_t)n * P + blockIdx.x) * Cl + cg0 + tid) * 3;
+      partials[o] = shc[j]; partials[o + 1] = a1; partials[o + 2] = a2;
+    }
   }
 }
 
@@ -631,6 +787,34 @@ extern "C" int cbim_up_stats(int dtype, const void* low, int N, int Dl, int Hl, 
              partials);
   if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
   return cbim_stats_finalize(partials, N, P, Cl, (double)S, eps, 0, stats, stream);
+}
+
+/* statistics (eps) of the virtual up-sampled tensor from the coarse grid (k_up_gram_stats): partials float [N][P][Cl][3],
+   P = cbim_up_gram_parts(Dl, Hl, Wl) */
+extern "C" int cbim_up_gram_parts(int Dl, int Hl, int Wl) {
+  const int64_t tiles = (int64_t)((Dl + GR_D - 1) / GR_D) * ((Hl + GR_H - 1) / GR_H) * ((Wl + GR_W - 1) / GR_W);
+  return (int)(tiles < 1024 ? tiles : 1024);
+}
+extern "C" int cbim_up_stats_gram(int dtype, const void* low, int N, int Dl, int Hl, int Wl, int Cl, int D, int H, int W, float eps,
+                                  float* partials, int P, float* stats, void* stream) {
+  if (int e = check_c(dtype, Cl, "up_stats_gram low")) return e;
+  CBIM_CHECK(low && partials && stats && P == cbim_up_gram_parts(Dl, Hl, Wl), CBIM_EINVAL, "up_stats_gram: partials must have cbim_up_gram_parts records");
+  CBIM_CHECK(D >= Dl && H >= Hl && W >= Wl && (int64_t)D * H * W < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "up_stats_gram: an up-sampling is expected");
+  hipStream_t st = (hipStream_t)stream;
+#ifndef CBIM_EMU
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)k_up_gram_stats<bf16_tag>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_up_gram_stats<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CBIM_CHECK(e1 == hipSuccess && e2 == hipSuccess, CBIM_ELAUNCH, "up_stats_gram: cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+#endif
+  dim3 grid((unsigned)P, (unsigned)N, (unsigned)((Cl + GR_C - 1) / GR_C));
+  if (dtype == CBIM_BF16) CBIM_LAUNCH((k_up_gram_stats<bf16_tag>), grid, dim3(NT), GR_SMEM, st, low, Dl, Hl, Wl, Cl, D, H, W, P, partials);
+  else CBIM_LAUNCH((k_up_gram_stats<float>), grid, dim3(NT), GR_SMEM, st, low, Dl, Hl, Wl, Cl, D, H, W, P, partials);
+  if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+  return cbim_stats_finalize(partials, N, P, Cl, (double)D * H * W, eps, 2, stats, stream);
 }
 
 extern "C" int cbim_upcat_act_fwd(int dtype, const void* low, const void* skip, const float* stats, void* out, int N, int Dl,

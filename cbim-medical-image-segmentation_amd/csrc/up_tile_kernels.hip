@@ -108,8 +108,8 @@ __device__ __forceinline__ void stage_box(const UpTileParams& p, unsigned char* 
   }
 }
 
-// value of up(low) at tile voxel (fd, fh, fw), channel chunk `cl` (channels), rounded to the storage type exactly as a
-// stored copy would hold it (same summation order as k_upcat_fwd)
+// value of up(low) at tile voxel (fd, fh, fw), channel chunk `cl` (channels), in float32 (same arithmetic as up_chunk of
+// pool_up_kernels.hip; never rounded to the storage type: the up-sampled tensor is not stored)
 template <typename T>
 __device__ __forceinline__ void up_from_box(const UpTileParams& p, const unsigned char* smem, int fd, int fh, int fw, int cl, float* f) {
   constexpr int CPC = Elem<T>::CPC, ES = Elem<T>::SIZE;
@@ -125,9 +125,7 @@ __device__ __forceinline__ void up_from_box(const UpTileParams& p, const unsigne
       cn[(a * 2 + b) * 2] = *(const u32x4*)(smem + rbase + (unsigned)aw.r0);
       cn[(a * 2 + b) * 2 + 1] = *(const u32x4*)(smem + rbase + (unsigned)aw.r1);
     }
-  float acc[CPC];
-  trilerp<T>(cn, ad.l0, ad.l1, ah.l0, ah.l1, aw.l0, aw.l1, acc);
-  Elem<T>::unpack(Elem<T>::pack(acc), f);
+  trilerp<T>(cn, ad.l0, ad.l1, ah.l0, ah.l1, aw.l0, aw.l1, f);
 }
 
 // MODE 0: statistics of up(low) (partials)   MODE 1: a = act(IN([skip | up]))   MODE 2: IN backward -> dskip, dup

@@ -222,12 +222,21 @@ UP_TILES = __import__("os").environ.get("CBIM_UP_TILES", "1") not in ("", "0")  
 _UNSUPPORTED = -2   # CBIM_EUNSUPPORTED
 
 
+UP_GRAM = __import__("os").environ.get("CBIM_UP_GRAM", "1") not in ("", "0")   # statistics of the up-sampled tensor from the coarse grid (k_up_gram_stats)
+
+
 def up_stats(low, out_dhw, eps: float = IN_EPS):
     """InstanceNorm statistics of trilinear(low -> out_dhw, align_corners=True) without writing it."""
     _dev_ok(low)
     N, Dl, Hl, Wl, Cl = map(int, low.shape)
     D, H, W = (int(i) for i in out_dhw)
     L = _lib.lib()
+    if UP_GRAM and D >= Dl and H >= Hl and W >= Wl:
+        P = L.cbim_up_gram_parts(Dl, Hl, Wl)
+        part = torch.empty((N, P, Cl, 3), dtype=torch.float32, device=low.device)
+        stats = torch.empty((N, Cl, 2), dtype=torch.float32, device=low.device)
+        check(L.cbim_up_stats_gram(_dt(low), _p(low), N, Dl, Hl, Wl, Cl, D, H, W, eps, _p(part), P, _p(stats), _stream(low)), "up_stats_gram")
+        return stats
     if UP_TILES:
         P = L.cbim_up_tile_parts(D, H, W)
         part = torch.empty((N, P, Cl, 3), dtype=torch.float32, device=low.device)

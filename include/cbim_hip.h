@@ -125,6 +125,12 @@ int cbim_upcat_fwd_stats(int dtype, const void* low, const void* skip, void* out
  * trilinear gather — dlow (cbim_upcat_norm_bwd).  unet_utils.py:69-71 + conv_layers.py:40-49. */
 int cbim_up_stats(int dtype, const void* low, int N, int Dl, int Hl, int Wl, int Cl, int D, int H, int W,
                   float eps, float* partials, int P, float* stats, void* stream);
+/* The same statistics from the COARSE grid (sum and sum of squares of the up-sampled tensor as a weighted sum and a 27-point
+ * stencil over `low`; fp32 interpolation, no rounding to the storage type): partials float [N][P][Cl][3] with
+ * P = cbim_up_gram_parts(Dl, Hl, Wl). */
+int cbim_up_gram_parts(int Dl, int Hl, int Wl);
+int cbim_up_stats_gram(int dtype, const void* low, int N, int Dl, int Hl, int Wl, int Cl, int D, int H, int W,
+                       float eps, float* partials, int P, float* stats, void* stream);
 int cbim_upcat_act_fwd(int dtype, const void* low, const void* skip, const float* stats, void* out, int N,
                        int Dl, int Hl, int Wl, int Cl, int D, int H, int W, int Cs, int skip_first, int act,
                        void* stream);

@@ -97,6 +97,29 @@ def check_upcat(dev, dtype, N=1, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_
     assert torch.equal(from_cl(dskip.cpu()), skr.grad)
 
 
+def check_up_gram_stats(dev, dtype, N=2, Cl=16, low=(3, 4, 5), hi=(6, 8, 9), offset=0.2):
+    """Statistics of the virtual up-sampled tensor from the coarse grid (column sums + the tridiagonal Gram matrices of the
+    three 1-D interpolations) against F.interpolate + instance statistics in float64, and against the kernel that forms the
+    up-sampled values."""
+    torch.manual_seed(7)
+    lo = torch.randn(N, Cl, *low) * 1.5 + offset
+    lol = to_cl(lo, dtype).to(dev)
+    ref = F.interpolate(from_cl(lol.cpu()).double(), size=hi, mode="trilinear", align_corners=True)
+    mean = ref.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(ref.var(dim=(2, 3, 4), unbiased=False) + 1e-4)
+    keep = ops.UP_GRAM
+    try:
+        ops.UP_GRAM = True
+        st = ops.up_stats(lol, hi, 1e-4).cpu().double()
+        ops.UP_GRAM = False
+        st0 = ops.up_stats(lol, hi, 1e-4).cpu().double()
+    finally:
+        ops.UP_GRAM = keep
+    assert relerr(st[..., 0], mean) < 2e-6 + 1e-6 * abs(offset) and relerr(st[..., 1], rstd) < 1e-5
+    # the other kernel measures the values ROUNDED to the storage type
+    assert relerr(st[..., 0], st0[..., 0]) < tol(dtype, 1e-5, 1e-3) and relerr(st[..., 1], st0[..., 1]) < tol(dtype, 1e-5, 1e-3)
+
+
 def check_up_adjoint(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9), skip_first=True):
     """dup -> dlow as three 1-D reductions (cbim_lin_adjoint_axis) against the one-pass 64-candidate gather, for a
     strided slice of the concatenation's gradient and for float32 NCDHW planes."""
@@ -145,10 +168,14 @@ def check_upcat_fused(dev, dtype, N=2, Cl=16, Cs=8, low=(3, 4, 5), hi=(6, 8, 9),
     ops.UP_TILES = tiles
     st_up = ops.up_stats(lol, hi)
     up_slice = slice(Cs, None) if skip_first else slice(0, Cl)
-    assert relerr(st_up.cpu()[..., 0], st_cat.cpu()[:, up_slice, 0]) < 1e-5
-    assert relerr(st_up.cpu()[..., 1], st_cat.cpu()[:, up_slice, 1]) < 1e-5
+    # (bf16: the coarse-grid statistics are those of the fp32 interpolation, st_cat measured the values rounded to bf16)
+    assert relerr(st_up.cpu()[..., 0], st_cat.cpu()[:, up_slice, 0]) < tol(dtype, 1e-5, 1e-3)
+    assert relerr(st_up.cpu()[..., 1], st_cat.cpu()[:, up_slice, 1]) < tol(dtype, 1e-5, 1e-3)
     a = ops.upcat_act_fwd(lol, skl, st_cat, ops.ACT["relu"], skip_first)
-    assert torch.equal(a.cpu(), ops.norm_act_fwd(cat, st_cat, ops.ACT["relu"]).cpu())
+    # (the stored concatenation holds the up-sampled values rounded to the storage type, the fused pass normalises the fp32
+    #  interpolation: bit-identical in float32, within the bf16 rounding otherwise)
+    a_cat = ops.norm_act_fwd(cat, st_cat, ops.ACT["relu"])
+    assert torch.equal(a.cpu(), a_cat.cpu()) if dtype == torch.float32 else relerr(a.cpu().float(), a_cat.cpu().float()) < 2e-2
     # backward: g -> IN backward over the concatenation -> (trilinear adjoint, slice)
     g = torch.randn(N, Cs + Cl, *hi)
     gl = to_cl(g, dtype).to(dev)

@@ -39,6 +39,10 @@ def test_upcat(dev, dtype):
     oc.check_upcat_fused(dev, dtype, tiles=False)
     oc.check_upcat_fused(dev, dtype, N=1, Cl=8, Cs=8, low=(4, 7, 5), hi=(4, 14, 10))      # anisotropic scale [1, 2, 2]
     oc.check_upcat_fused(dev, dtype, N=1, low=(5, 4, 4), hi=(10, 8, 8), skip_first=False)
+    oc.check_up_gram_stats(dev, dtype)
+    oc.check_up_gram_stats(dev, dtype, N=1, Cl=40, low=(4, 7, 5), hi=(4, 14, 10), offset=50.0)   # [1, 2, 2], a 40-channel tail group, large mean
+    oc.check_up_gram_stats(dev, dtype, N=1, Cl=8, low=(5, 9, 10), hi=(17, 20, 31))              # ragged tiles, odd factors
+    oc.check_up_gram_stats(dev, dtype, N=1, Cl=64, low=(32, 32, 32), hi=(64, 64, 64), offset=30.0)
     oc.check_up_adjoint(dev, dtype)
     oc.check_up_adjoint(dev, dtype, N=1, Cl=8, Cs=8, low=(4, 7, 5), hi=(4, 14, 10), skip_first=False)   # [1, 2, 2]
     oc.check_up_adjoint(dev, dtype, N=1, low=(1, 3, 2), hi=(2, 6, 4))
