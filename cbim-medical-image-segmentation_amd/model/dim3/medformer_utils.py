@@ -21,7 +21,10 @@ _EPS_DEFAULT = 1e-5   # nn.InstanceNorm3d default, used by norm1/norm2 and Patch
 def pointwise(conv: nn.Conv3d, x):
     """1x1x1 nn.Conv3d on a semantic map [B, C, m0, m1, m2] as one matmul over the channel axis (torch's conv3d
     would pick a generic MIOpen kernel that costs ~0.3 ms for these 64-position tensors)."""
-    y = torch.matmul(conv.weight.flatten(1), x.flatten(2))
+    if x.shape[0] == 1:   # (2-D x 3-D matmul folds the batch through transposed clones: one mm, no copy, for one image)
+        y = torch.mm(conv.weight.flatten(1), x.flatten(2).squeeze(0)).unsqueeze(0)
+    else:
+        y = torch.matmul(conv.weight.flatten(1), x.flatten(2))
     if conv.bias is not None:
         y = y + conv.bias[None, :, None]
     return y.reshape(x.shape[0], -1, *x.shape[2:])
@@ -29,9 +32,10 @@ def pointwise(conv: nn.Conv3d, x):
 
 def map_instance_norm(x, eps=_EPS_DEFAULT):
     """nn.InstanceNorm3d (affine=False) over the <= 64 map positions."""
+    # = layer normalisation of each (image, channel) row over its positions, biased variance, no affine: ONE kernel forward
+    # and one backward (var_mean / sub / rsqrt / mul were 5 launches forward and 12 backward per block, 16 blocks)
     f = x.flatten(2)
-    var, mean = torch.var_mean(f, dim=2, unbiased=False, keepdim=True)
-    return ((f - mean) * torch.rsqrt(var + eps)).reshape(x.shape)
+    return torch.nn.functional.layer_norm(f, (f.shape[2],), None, None, eps).reshape(x.shape)
 
 
 class BidirectionAttention(nn.Module):
