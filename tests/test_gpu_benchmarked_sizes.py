@@ -2,8 +2,8 @@
 configs[4]): MedFormer (amos_ct/medformer_3d.yaml, aux loss) on 1x1x128^3 and SwinUNETR (feature 48, 4 modalities, 4
 classes) on 1x4x128^3.  fp32 engine mode against oracle/medformer_ref.py / oracle/swin_unetr_ref.py evaluated on the host
 cores with the same weights: logits within 1e-3 of the logit range, loss within 1e-4, every parameter-gradient norm within
-2 %.  Plus the trained-weights Dice bar of the bf16 mode for MedFormer (as tests/test_gpu_headline_parity.py does for the
-ResUNet).  The 64^3 / tiny goldens of tests/golden come from the REAL reference; these tests carry the same comparison to the
+2 %.  Plus the trained-weights Dice bar of the bf16 mode for MedFormer and SwinUNETR (as tests/test_gpu_headline_parity.py
+does for the ResUNet).  The 64^3 / tiny goldens of tests/golden come from the REAL reference; these tests carry the same comparison to the
 shape bench.py times."""
 import time
 from functools import partial
@@ -102,6 +102,53 @@ def test_medformer_amos_128_bf16_dice_within_0p002_of_oracle_on_trained_weights(
     tgt = lab.squeeze(1)
     d_o = loss_ref.hard_dice(lo.argmax(1), tgt, 16)
     d_e = loss_ref.hard_dice(lg.argmax(1), tgt, 16)
+    agree = float((lg.argmax(1) == lo.argmax(1)).float().mean())
+    ddice = float((d_o - d_e).abs().max())
+    print(f"200 bf16 AdamW steps, loss {losses}; oracle mean Dice {float(d_o.mean()):.4f}, engine {float(d_e.mean()):.4f}, "
+          f"max per-class |dDice| {ddice:.2e}, argmax agreement {agree:.5f}")
+    assert losses[-1] < 0.5 * losses[0]
+    assert float(d_o.mean()) > 0.5
+    assert ddice <= 0.002
+    assert agree > 0.995
+
+
+def test_swin_unetr_4x128_bf16_dice_within_0p002_of_oracle_on_trained_weights(dev):
+    """The same trained-weights bar for SwinUNETR (feature 48, 4 modalities, 4 classes) at the benchmarked 1x4x128^3."""
+    import cbim_amd
+    from cbim_amd.model.dim3 import SwinUNETR
+    from cbim_amd.training.losses import DiceCELoss
+    from cbim_amd.training.optim import FusedAdamW
+    from oracle import loss_ref
+    from oracle.swin_unetr_ref import swin_unetr_forward
+    x, lab, _ = _data(4, 4, 24, informative=True)
+    xd, ld = x.contiguous().to(dev), lab.to(dev)
+    cbim_amd.set_compute_dtype("bf16")
+    try:
+        torch.manual_seed(2023)
+        net = SwinUNETR((SIZE,) * 3, 4, 4, feature_size=48).to(dev)
+        crit = DiceCELoss(torch.ones(4, device=dev)).to(dev)
+        opt = FusedAdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-5)
+        losses = []
+        for i in range(200):
+            opt.zero_grad(set_to_none=True)
+            loss = crit(net(xd), ld)
+            loss.backward()
+            opt.step()
+            if i % 40 == 0 or i == 199:
+                losses.append(float(loss))
+        with torch.no_grad():
+            lg = net(xd).float().cpu()
+        sd = {k: v.detach().float().cpu().clone() for k, v in net.state_dict().items()}
+    finally:
+        cbim_amd.set_compute_dtype(None)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        lo = swin_unetr_forward(sd, x)
+        lo = lo[0] if isinstance(lo, (list, tuple)) else lo
+        print(f"oracle forward at 4x{SIZE}^3: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+    tgt = lab.squeeze(1)
+    d_o = loss_ref.hard_dice(lo.argmax(1), tgt, 4)
+    d_e = loss_ref.hard_dice(lg.argmax(1), tgt, 4)
     agree = float((lg.argmax(1) == lo.argmax(1)).float().mean())
     ddice = float((d_o - d_e).abs().max())
     print(f"200 bf16 AdamW steps, loss {losses}; oracle mean Dice {float(d_o.mean()):.4f}, engine {float(d_e.mean()):.4f}, "
