@@ -850,9 +850,27 @@ def colsoftmax_pool_fwd(fw, Cf: int):
     return mp, cs
 
 
+MAPPOOL_BWD_GEMM = __import__("os").environ.get("CBIM_MAPPOOL_BWD_GEMM", "1") not in ("", "0")   # backward as two library GEMMs (off: k_mappool_bwd4)
+MAPPOOL_BWD_GEMM_MAX_L = int(__import__("os").environ.get("CBIM_MAPPOOL_BWD_GEMM_MAX_L", "1024"))   # voxels per image up to which it is used
+
+
 def colsoftmax_pool_bwd(fw, Cf: int, mp, cs, dmap):
     _dev_ok(fw, mp, cs, dmap)
     N, Lr, M = int(fw.shape[0]), _spatial(fw), int(fw.shape[-1]) - Cf
+    if MAPPOOL_BWD_GEMM and Lr <= MAPPOOL_BWD_GEMM_MAX_L:
+        # the backward of map[c][j] = sum_l f[l][c] P[l][j], P = softmax over the voxels l of the logits z, is GEMM shaped:
+        #   df = P dmap^T  [L x M][M x C],   tt = F dmap  [L x C][C x M],   dz = P (tt - cj),  cj[j] = sum_c map[c][j] dmap[c][j]
+        # — two plain library GEMMs in float32 and a few element-wise launches, for the LOWEST-RESOLUTION stage: k_mappool_bwd4
+        # (one voxel per lane on the vector ALU) takes 435 us at 8^3, where its 8 workgroups leave the chip empty.  Measured
+        # (MedFormer step, same box): form up to 8^3 33.57 -> 33.22 ms, up to 16^3 33.30, everywhere 36.1 (the softmax over
+        # 32768 strided rows and the skinny float32 GEMMs cost more than the 195 us kernel).
+        f3 = fw.reshape(N, Lr, Cf + M)
+        P = torch.softmax(f3[..., Cf:].float(), dim=1)                      # [N, L, M]
+        dm = dmap.float()
+        G = torch.bmm(P, dm.transpose(1, 2))                                # [N, L, C]
+        tt = torch.bmm(f3[..., :Cf].float(), dm)                            # [N, L, M]
+        cj = (mp.float() * dm).sum(1, keepdim=True)                         # [N, 1, M]
+        return torch.cat([G, P * (tt - cj)], -1).to(fw.dtype).reshape(fw.shape)
     dfw = torch.empty(tuple(fw.shape), dtype=fw.dtype, device=fw.device)
     check(_lib.lib().cbim_colsoftmax_pool_bwd(_dt(fw), _p(fw), _rs(fw), _p(mp), _p(cs), _p(dmap), _p(dfw), _rs(dfw), N, Lr,
                                               Cf, M, _stream(fw)), "colsoftmax_pool_bwd")

@@ -651,8 +651,15 @@ def check_mappool(dev, dtype, N=2, C=24, M=8, dhw=(5, 6, 7), seed=14):
     assert relerr(mp.cpu(), ref.detach()) < 2e-5, "mappool fwd"
     dmap = torch.randn(N, C, M)
     ref.backward(dmap)
-    dfw = ops.colsoftmax_pool_bwd(fwl, C, mp, cs, dmap.to(dev))
-    assert relerr(from_cl(dfw.cpu()).reshape(N, C + M, L), fwr.grad) < tol(dtype, 2e-5, 1e-2), "mappool bwd"
+    keep = ops.MAPPOOL_BWD_GEMM
+    try:
+        for flag in (True, False):          # two library GEMMs (small volumes) | k_mappool_bwd / k_mappool_bwd4
+            ops.MAPPOOL_BWD_GEMM = flag
+            dfw = ops.colsoftmax_pool_bwd(fwl, C, mp, cs, dmap.to(dev))
+            assert dfw.shape == fwl.shape and dfw.dtype == fwl.dtype
+            assert relerr(from_cl(dfw.cpu()).reshape(N, C + M, L), fwr.grad) < tol(dtype, 2e-5, 1e-2), "mappool bwd"
+    finally:
+        ops.MAPPOOL_BWD_GEMM = keep
 
 
 def check_trilinear_planes(dev, N=1, C=3, lo=(3, 4, 5), hi=(7, 8, 9)):
