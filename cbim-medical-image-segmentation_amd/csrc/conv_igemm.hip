@@ -1086,7 +1086,10 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   if (pick_ksplit(d, c) > 1) return finish_parts((int64_t)d->Do * d->Ho * d->Wo);
   int64_t g = igemm_grid_x(d, c);   // one record per (image, persistent workgroup)
   // the same layer may run on conv_r32.hip (8x8x8 tiles whatever pick_cfg says): room for either grid
-  if (cbim_conv_r32_eligible(d, nullptr, 0, nullptr, nullptr, nullptr) && cbim_conv_r32_grid(d) > g) g = cbim_conv_r32_grid(d);
+  if (cbim_conv_r32_eligible(d, nullptr, 0, nullptr, nullptr, nullptr)) {
+    if (cbim_conv_r32_grid(d) > g) g = cbim_conv_r32_grid(d);
+    if (cbim_conv_rw_grid(d) > g) g = cbim_conv_rw_grid(d);
+  }
   return (int)g;
 }
 
@@ -1136,7 +1139,7 @@ static int dispatch_act(int act, bool k3, const TileCfg& c, const IgemmParams& p
   }
 }
 
-// which kernel the last cbim_conv3d_igemm call of this thread launched: 0 = k_conv_igemm, 1 = k_conv3_r32 (profiling labels)
+// which kernel the last cbim_conv3d_igemm call of this thread launched: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw (profiling labels)
 static thread_local int g_last_conv_kernel = 0;
 extern "C" int cbim_conv3d_last_kernel(void) { return g_last_conv_kernel; }
 
@@ -1153,6 +1156,11 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   CBIM_CHECK(!mask_x || mask_stats || d->act == CBIM_ACT_RELU, CBIM_EINVAL, "mask_x without mask_stats (an activated mask tensor) needs act = ReLU");
   g_last_conv_kernel = 0;
   if (cbim_conv_r32_eligible(d, x2, cin_split, in_stats, res, mask_x)) {  // channels in multiples of 32 at high resolution: weights in registers
+    if (cbim_conv_rw_eligible(d, x, x_stride, x2, x2_stride, in_stats, mask_x, mask_stats)) {   // round 4: conv_rw.hip
+      g_last_conv_kernel = 2;
+      return cbim_conv_rw_launch(d, x, x_stride, x2, x2_stride, cin_split, w_packed, res, res_stride, mask_x, mask_stride, y, y_stride, partials,
+                                 stream);
+    }
     g_last_conv_kernel = 1;
     return cbim_conv_r32_launch(d, x, x_stride, x2, x2_stride, cin_split, in_stats, w_packed, res, res_stride, mask_x, mask_stride, mask_stats, y,
                                 y_stride, partials, stream);

@@ -34,3 +34,13 @@ int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_strid
                          const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
                          int64_t mask_stride, const float* mask_stats, void* y, int64_t y_stride, float* partials,
                          void* stream);
+
+// conv_rw.hip (round 4): the same convolutions with plane-major buffer-addressed LDS-DMA pieces, statistics sums in LDS and
+// an optional WIDE form (64 output channels per workgroup).  Takes the calls whose input is used as it is (no in_stats) and
+// whose epilogue is the forward one or the activated-mask dgrad one; asked only after cbim_conv_r32_eligible said yes.
+bool cbim_conv_rw_eligible(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                           const float* in_stats, const void* mask_x, const float* mask_stats);
+int64_t cbim_conv_rw_grid(const cbim_conv_desc* d);
+int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                        int cin_split, const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
+                        int64_t mask_stride, void* y, int64_t y_stride, float* partials, void* stream);

@@ -207,10 +207,15 @@ int64_t cbim_conv_r32_min_voxels(int64_t v);
 /* Tile depth of that kernel: 8 = one 512-thread workgroup per CU on 8x8x8 tiles (default), 4 = two 256-thread workgroups
  * per CU on 4x8x8 tiles; any other value only queries.  Returns the previous value. */
 int cbim_conv_r32_tile_depth(int td);
+/* Round-4 form of that kernel (conv_rw.hip: plane-major buffer-addressed LDS-DMA, statistics sums in LDS, optional 64 output
+ * channels per workgroup): on = 0 keeps every call on k_conv3_r32 / k_conv_igemm, wide = 0 keeps 32-channel workgroups; a
+ * negative value leaves a switch as it is.  Returns the previous (on | wide << 1).  Process-wide knob for tests and tools
+ * (env CBIM_CONV_RW, CBIM_CONV_RW_WIDE give the defaults); both kernels compute the same function. */
+int cbim_conv_rw_enable(int on, int wide);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);
-/* Kernel launched by this thread's last cbim_conv3d_igemm call: 0 = k_conv_igemm, 1 = k_conv3_r32 (profiling labels). */
+/* Kernel launched by this thread's last cbim_conv3d_igemm call: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw (profiling labels). */
 int cbim_conv3d_last_kernel(void);
 /* Records per sample of the partial-sum buffer `partials` (one per persistent workgroup, or per finish part when the
  * launcher splits K). */

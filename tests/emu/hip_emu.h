@@ -227,5 +227,18 @@ inline void emu_global_load_lds16(const void* gsrc, void* lds_wave_base) {
   memcpy((unsigned char*)buf[0].base + (size_t)l * 16, gsrc, 16);
 }
 
+// buffer_load_dwordx4 ... offen lds model: per lane 16 bytes from base + soff + voff, ZEROS when the range check fails
+// (soff + voff + 16 > num_records: the scalar offset takes part in the check, measured on gfx950 — tools/ubench/lds_dma.hip);
+// LDS destination as above.
+inline void emu_buffer_load_lds16(const unsigned char* base, unsigned nrec, unsigned voff, unsigned soff, void* lds_wave_base) {
+  struct P { void* base; } mine = {lds_wave_base};
+  const P* buf = (const P*)cbim_emu::wave_exchange(&mine, sizeof(P));
+  int l = CBIM_EMU_LANE_ID();
+  unsigned char* dst = (unsigned char*)buf[0].base + (size_t)l * 16;
+  const unsigned long long off = (unsigned long long)voff + soff;
+  if (off + 16 > nrec) memset(dst, 0, 16);
+  else memcpy(dst, base + off, 16);
+}
+
 #define CBIM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   cbim_emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })

@@ -86,6 +86,19 @@ def test_conv_r32_weights_in_registers(dev):
     oc.check_conv_r32(dev, N=1, Cout=32, dhw=(64, 64, 64))          # the default threshold: picked without the knob
 
 
+def test_conv_rw_buffer_addressed_halo(dev):
+    """k_conv3_rw (conv_rw.hip) against k_conv3_r32 (bit for bit where the arithmetic is the same) and torch."""
+    oc.check_conv_rw(dev)                                                        # ragged tiles, two images, one chunk
+    oc.check_conv_rw(dev, N=1, Cin=64, Cout=32, dhw=(9, 8, 16))                  # streamed weights
+    oc.check_conv_rw(dev, N=1, Cin=96, Cout=64, dhw=(8, 9, 8), x_split=32)       # 64-cout weight blocks, [x | x2] input, narrow
+    oc.check_conv_rw(dev, N=2, Cin=96, Cout=64, dhw=(8, 9, 8), x_split=32, wide=2)   # the same on 64-cout workgroups
+    oc.check_conv_rw(dev, N=1, Cin=32, Cout=64, dhw=(8, 8, 16), wide=2)          # wide, one chunk
+    oc.check_conv_rw(dev, N=1, Cin=64, Cout=128, dhw=(8, 8, 8), wide=2)          # two 64-cout blocks
+    oc.check_conv_rw(dev, N=1, Cin=32, Cout=96, dhw=(8, 8, 8))                   # Cout 96: the last 64-block is half empty
+    oc.check_conv_rw(dev, N=1, Cin=96, Cout=64, dhw=(64, 64, 64), x_split=32)    # the default selection at a real size
+    oc.check_conv_rw(dev, N=1, Cin=32, Cout=32, dhw=(64, 64, 64))
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
