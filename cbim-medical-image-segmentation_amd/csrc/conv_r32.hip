@@ -793,7 +793,11 @@ int64_t cbim_conv_r32_grid(const cbim_conv_desc* d) {
   const int n_oc = (d->Cout + 31) / 32;
   int64_t cap = (td == 8 ? 256 : 512) / n_oc;      // about one workgroup per CU over all Cout chunks
   if (cap < 1) cap = 1;
-  return n_tiles < cap ? n_tiles : cap;
+  int64_t g = n_tiles < cap ? n_tiles : cap;
+  // several Cout chunks: strips in multiples of 8 keep the chunks of one strip on one XCD (workgroup b runs on XCD b % 8,
+  // b = x + grid.x * y): the second reader of a halo hits that XCD's L2 (conv_rw.hip: cbim_conv_rw_grid)
+  if (n_oc > 1 && g >= 8) g &= ~(int64_t)7;
+  return g;
 }
 
 template <int ACT, bool TR, bool MX, int TD, bool MC>

@@ -338,6 +338,42 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
 #pragma unroll
       for (int nt = 0; nt < NTL; ++nt) acc[nt] = w_f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // ---- epilogue addressing of this tile (used by the operand requests inside the MFMA loop and by the epilogue) ----------
+    const int n = cur.n;
+    const int od0 = cur.td * 8, oh0 = cur.th * 8, ow0 = cur.tw * 8;
+    const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
+    const unsigned y_sb = (unsigned)p.y_stride * 2u, q_sb = MX ? (unsigned)p.mx_stride * 2u : (unsigned)p.res_stride * 2u;
+    unsigned char* const y_tile = (unsigned char*)p.y + orow * (long long)y_sb;
+    const unsigned char* const q_tile = (MX ? (const unsigned char*)p.mx : (const unsigned char*)p.res) + orow * (long long)q_sb;
+    const bool has_q = MX || p.res != nullptr;           // workgroup-uniform
+    const unsigned cbyte = (unsigned)(oc * (4 * HP) + cidx) * 16u;
+    // pair pr = (hp, pp): after the exchange this lane owns chunk cidx of voxel (plane 2 pp + (lq & 1), thp[hp], tw)
+    // (the offsets below depend on the lane only: laundering the lane index keeps the compiler from hoisting them — and the
+    //  64-bit addresses built on them — out of the unit loop, where they would be spilled and reloaded in every epilogue)
+    const unsigned lane_l = w_launder((unsigned)lane);
+    const unsigned e_lq1 = (lane_l >> 4) & 1u, e_tw = lane_l & 7u, e_h8 = (lane_l >> 3) & 1u;
+    u32x4* const cell = (u32x4*)(smem + W_ACC) + (wave * 64 + lane_l);                        // (as cell0 / shf0 above)
+    const float* const shf = (const float*)(smem + W_SHF) + (wave * 2 + (lane_l >> 5)) * 8;
+    auto pair_rows = [&](int pr) -> unsigned {
+      const int hp = pr / 4, pp = pr % 4;
+      return w_mul24(w_mul24((unsigned)(2 * pp) + e_lq1, (unsigned)p.Ho) + (unsigned)(2 * (hp0 + hp)) + e_h8, (unsigned)p.Wo) + e_tw;
+    };
+    auto pair_in = [&](int pr) -> bool {
+      const int hp = pr / 4, pp = pr % 4;
+      return c_ok && oh0 + 2 * (hp0 + hp) + (int)e_h8 < p.Ho && ow0 + (int)e_tw < p.Wo && od0 + 2 * pp + (int)e_lq1 < p.Do;
+    };
+    // operand (residual / mask) rows of the lane's output voxels: requested INSIDE the MFMA loop (step RQ_STEP), so that their
+    // memory latency is over when the epilogue starts (requested after the loop they cost ~750 cycles of issue behind the LDS-DMA
+    // pieces and ~1700 of exposed latency per tile: profiles/r04_d_rw_phase_cycles.txt).  Every request is issued whatever the
+    // lane's position (a lane outside the tensor re-reads the tile's first row): the number of vector-memory operations behind
+    // the last LDS-DMA piece is then a constant the wait before the barrier can count on.
+    constexpr int QD = HP == 2 ? 2 : 4;                  // operand requests in flight
+    constexpr int RQ_STEP = 6;
+    u32x4 rq[QD];
+    auto request = [&](int pr) -> u32x4 {
+      const unsigned off = pair_in(pr) ? w_mul24(pair_rows(pr), q_sb) + cbyte : 0u;
+      return *(const u32x4*)(q_tile + off);
+    };
     const unsigned char* const w_next = w_lane + (size_t)nx.cc * 27u * w_tap;
     W_STAMP(0);                                          // unit set-up
     // 9 (kh, kw) steps x HP patches: the 10 plane fragments of a patch stream through a ring of 5 registers, plane i feeds
@@ -358,6 +394,10 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
         if (s < 5 && wave < 7) {
           dma_plane(hn, 2 * s, obuf);
           dma_plane(hn, 2 * s + 1, obuf);
+        }
+        if (s == RQ_STEP && last_cc && has_q) {   // (a branch, not a predicate: the units in between must not touch any of this)
+#pragma unroll
+          for (int pr = 0; pr < QD; ++pr) rq[pr] = request(pr);
         }
 #pragma unroll
         for (int hp = 0; hp < HP; ++hp) {
@@ -384,46 +424,12 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
         }
       }
     }
-    W_STAMP(1);                                          // MFMA loop (+ piece issue, weight reloads)
-    // ---- epilogue addressing (last chunk only) and the first operand requests, BEFORE the barrier ----------------------
-    const int n = cur.n;
-    const int od0 = cur.td * 8, oh0 = cur.th * 8, ow0 = cur.tw * 8;
-    const long long orow = (((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
-    const unsigned y_sb = (unsigned)p.y_stride * 2u, q_sb = MX ? (unsigned)p.mx_stride * 2u : (unsigned)p.res_stride * 2u;
-    unsigned char* const y_tile = (unsigned char*)p.y + orow * (long long)y_sb;
-    const unsigned char* const q_tile = (MX ? (const unsigned char*)p.mx : (const unsigned char*)p.res) + orow * (long long)q_sb;
-    const bool has_q = MX || p.res != nullptr;           // workgroup-uniform
-    const unsigned plane_rows = w_mul24((unsigned)p.Ho, (unsigned)p.Wo);
-    const unsigned cbyte = (unsigned)(oc * (4 * HP) + cidx) * 16u;
-    // pair pr = (hp, pp): after the exchange this lane owns chunk cidx of voxel (plane 2 pp + (lq & 1), thp[hp], tw)
-    // (the offsets below depend on the lane only: laundering the lane index keeps the compiler from hoisting them — and the
-    //  64-bit addresses built on them — out of the unit loop, where they would be spilled and reloaded in every epilogue)
-    const unsigned lane_l = w_launder((unsigned)lane);
-    const unsigned e_lq1 = (lane_l >> 4) & 1u, e_tw = lane_l & 7u, e_h8 = (lane_l >> 3) & 1u;
-    u32x4* const cell = (u32x4*)(smem + W_ACC) + (wave * 64 + lane_l);                        // (as cell0 / shf0 above)
-    const float* const shf = (const float*)(smem + W_SHF) + (wave * 2 + (lane_l >> 5)) * 8;
-    auto pair_rows = [&](int pr) -> unsigned {
-      const int hp = pr / 4, pp = pr % 4;
-      return w_mul24(w_mul24((unsigned)(2 * pp) + e_lq1, (unsigned)p.Ho) + (unsigned)(2 * (hp0 + hp)) + e_h8, (unsigned)p.Wo) + e_tw;
-    };
-    auto pair_in = [&](int pr) -> bool {
-      const int hp = pr / 4, pp = pr % 4;
-      return c_ok && oh0 + 2 * (hp0 + hp) + (int)e_h8 < p.Ho && ow0 + (int)e_tw < p.Wo && od0 + 2 * pp + (int)e_lq1 < p.Do;
-    };
-    (void)plane_rows;
-    constexpr int QD = HP == 2 ? 2 : 4;                  // operand requests in flight
-    u32x4 rq[QD];
-#pragma unroll
-    for (int q = 0; q < QD; ++q) rq[q] = u32x4{0u, 0u, 0u, 0u};
-    if (last_cc && has_q) {        // (a branch, not a predicate: the units in between must not touch any of this)
-#pragma unroll
-      for (int pr = 0; pr < QD; ++pr)
-        if (pair_in(pr)) rq[pr] = *(const u32x4*)(q_tile + (w_mul24(pair_rows(pr), q_sb) + cbyte));
-    }
     // ---- ONE barrier per unit: every wave is done with `buf`, the other buffer is complete (own pieces landed; vector
-    //      memory operations complete in order, so the 15 weight-fragment loads issued after the last piece may stay in flight)
-    W_STAMP(2);                                          // operand requests
+    //      memory operations complete in order, so the 15 weight-fragment loads / the QD operand requests issued after the last
+    //      piece may stay in flight)
+    W_STAMP(1);                                          // MFMA loop (+ piece issue, weight reloads, operand requests)
     if (MC) w_wait_vm<15>();
+    else if (last_cc && has_q) w_wait_vm<QD>();          // (the QD operand requests are the youngest operations)
     else w_wait_vm<0>();
     W_STAMP(3);                                          // own pieces landed
     __syncthreads();
@@ -447,7 +453,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
             w_swap16(a, b);
             v0[r] = a; v0[4 + r] = b;
           }
-          if (has_q) {
+          if (has_q && pair_in(0)) {
             const unsigned rw[4] = {rq[0].x, rq[0].y, rq[0].z, rq[0].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v0[2 * j] += __uint_as_float(rw[j] << 16); v0[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u); }
@@ -474,10 +480,10 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
           v[r] = a;
           v[4 + r] = b;
         }
-        const u32x4 q = rq[pr % QD];
-        if (has_q && pr + QD < NPAIR) {                  // next request into the slot just read
-          rq[pr % QD] = u32x4{0u, 0u, 0u, 0u};
-          if (pair_in(pr + QD)) rq[pr % QD] = *(const u32x4*)(q_tile + (w_mul24(pair_rows(pr + QD), q_sb) + cbyte));
+        u32x4 q = u32x4{0u, 0u, 0u, 0u};
+        if (has_q) {
+          if (in) q = rq[pr % QD];
+          if (pr + QD < NPAIR) rq[pr % QD] = request(pr + QD);      // next request into the slot just read
         }
         const float live = in ? 1.f : 0.f;
         const f2_t live2 = {live, live};
@@ -565,7 +571,7 @@ static int g_rw_on = getenv("CBIM_CONV_RW") ? atoi(getenv("CBIM_CONV_RW")) : 1;
 static int g_rw_wide = getenv("CBIM_CONV_RW_WIDE") ? atoi(getenv("CBIM_CONV_RW_WIDE")) : 1;
 extern "C" int cbim_conv_rw_enable(int on, int wide) {
   const int old = g_rw_on | (g_rw_wide << 1);
-  if (on >= 0) g_rw_on = on;
+  if (on >= 0) g_rw_on = on & 1;
   if (wide >= 0) g_rw_wide = wide;
   return old;
 }
@@ -599,7 +605,13 @@ int64_t cbim_conv_rw_grid(const cbim_conv_desc* d) {
   const int n_cb = rw_wide(d) ? d->Cout / 64 : (d->Cout + 31) / 32;
   int64_t cap = 256 / n_cb;      // about one workgroup per CU over all Cout blocks
   if (cap < 1) cap = 1;
-  return n_tiles < cap ? n_tiles : cap;
+  int64_t g = n_tiles < cap ? n_tiles : cap;
+  // several Cout blocks: strips in multiples of 8 put the blocks of one strip (the same input halo, Cout-block after
+  // Cout-block) on the same XCD (workgroup b runs on XCD b % 8, b = x + grid.x * y), where the second reader hits the L2.
+  // Measured on 64 -> 96 @128^3 dgrad, grid (85, 3): 3.66 GB fetched per launch for 0.67 GB of tensors — the launch ran at the
+  // HBM bandwidth (profiles/r04_f_pmc_traffic_rw.txt)
+  if (n_cb > 1 && g >= 8) g &= ~(int64_t)7;
+  return g;
 }
 
 template <bool MX, int HP, bool MC>

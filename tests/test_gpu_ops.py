@@ -89,6 +89,7 @@ def test_conv_r32_weights_in_registers(dev):
 def test_conv_rw_buffer_addressed_halo(dev):
     """k_conv3_rw (conv_rw.hip) against k_conv3_r32 (bit for bit where the arithmetic is the same) and torch."""
     oc.check_conv_rw(dev)                                                        # ragged tiles, two images, one chunk
+    oc.check_conv_rw(dev, N=3, dhw=(8, 8, 24), seed=62)                          # strips of one tile, three images
     oc.check_conv_rw(dev, N=1, Cin=64, Cout=32, dhw=(9, 8, 16))                  # streamed weights
     oc.check_conv_rw(dev, N=1, Cin=96, Cout=64, dhw=(8, 9, 8), x_split=32)       # 64-cout weight blocks, [x | x2] input, narrow
     oc.check_conv_rw(dev, N=2, Cin=96, Cout=64, dhw=(8, 9, 8), x_split=32, wide=2)   # the same on 64-cout workgroups
