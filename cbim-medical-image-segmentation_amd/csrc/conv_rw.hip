@@ -165,15 +165,6 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
   const unsigned char* const w_lane = (const unsigned char*)p.w +
       (size_t)(HP == 2 ? oc : (p.BN == 64 ? oc >> 1 : oc)) * (size_t)NC * 27u * w_tap +
       (unsigned)((lq * p.BN) + (HP == 1 && p.BN == 64 ? (oc & 1) * 32 : 0) + 16 * cb16 + lv) * 16;
-  {
-#pragma unroll
-    for (int tp = 0; tp < 27; ++tp) wf[tp] = *(const u32x4*)(w_lane + (size_t)tp * w_tap);
-#ifndef CBIM_EMU
-    // (the compiler waits for these once, here, and forgets them: conv_r32.hip)
-#pragma unroll
-    for (int tp = 0; tp < 27; ++tp) asm volatile("" : "+v"(wf[tp]));
-#endif
-  }
   // B operand (voxels): fragment of plane i at tap (kh, kw) = 16 bytes at row (i, th + kh, tw + kw), slot lq ^ swz(th + kh)
   int thp[HP];
   unsigned fb[HP][3];
@@ -317,6 +308,15 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
 #pragma unroll
       for (int pl = 0; pl < 10; ++pl) dma_plane(h, pl, 0);
     }
+    // the first unit's weight fragments, requested BEHIND the halo pieces: the two latencies overlap (requested first and
+    // waited for before the pieces were issued, they cost every launch a second memory round trip)
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) wf[tp] = *(const u32x4*)(w_lane + (size_t)tp * w_tap);
+#ifndef CBIM_EMU
+    // (the compiler waits for these once, here, and forgets them: conv_r32.hip)
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) asm volatile("" : "+v"(wf[tp]));
+#endif
     w_wait_vm<0>();
     __syncthreads();
   }
@@ -441,33 +441,6 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
       f2_t l0[4], l1[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { l0[j] = f2_t{0.f, 0.f}; l1[j] = f2_t{0.f, 0.f}; }
-      if (!MX && want_part) {
-        if (!shift_set) {
-          // common shift of the 32 lanes that hold a channel chunk: the first voxel of the group's first lane (any finite
-          // value near the data works).  Written and read by the same wave: no barrier.
-          shift_set = true;
-          float v0[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float a = acc[0][r], b = acc[1][r];
-            w_swap16(a, b);
-            v0[r] = a; v0[4 + r] = b;
-          }
-          if (has_q && pair_in(0)) {
-            const unsigned rw[4] = {rq[0].x, rq[0].y, rq[0].z, rq[0].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v0[2 * j] += __uint_as_float(rw[j] << 16); v0[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u); }
-          }
-          if ((lane & 31) == 0) {
-            float* sw = (float*)(smem + W_SHF) + (wave * 2 + (lane >> 5)) * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sw[j] = v0[j];
-          }
-#ifdef CBIM_EMU
-          (void)__shfl(0, 0, 64);                        // (the executor's lanes are not in lockstep: the write lands before the reads)
-#endif
-        }
-      }
 #pragma unroll
       for (int pr = 0; pr < NPAIR; ++pr) {
         const bool in = pair_in(pr);
@@ -513,6 +486,19 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
             v[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u);
           }
           if (want_part) {
+            if (pr == 0 && !shift_set) {
+              // common shift of the 32 lanes that hold a channel chunk: this tile's first voxel in the group's first lane (any
+              // finite value near the data works).  Written and read by the same wave (LDS operations of a wave are in order).
+              shift_set = true;
+              if ((lane_l & 31u) == 0u) {
+                float* sw = (float*)(smem + W_SHF) + (wave * 2 + (lane_l >> 5)) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sw[j] = v[j];
+              }
+#ifdef CBIM_EMU
+              (void)__shfl(0, 0, 64);                    // (the executor's lanes are not in lockstep: the write lands before the reads)
+#endif
+            }
             // (the shift is read per pair — two broadcast LDS reads — instead of living in 8 registers through the epilogue)
             const float* const shp = shf + w_launder(0u);   // (a fresh address per pair: the two reads are not merged into 8 live registers)
             const f32x4 sa = *(const f32x4*)shp, sb4 = *(const f32x4*)(shp + 4);
@@ -579,10 +565,14 @@ extern "C" int cbim_conv_rw_enable(int on, int wide) {
 static int64_t rw_tiles(const cbim_conv_desc* d) {
   return (int64_t)d->N * ((d->Do + 7) / 8) * ((d->Ho + 7) / 8) * ((d->Wo + 7) / 8);
 }
-// 64 output channels per workgroup: Cout in multiples of 64 and still >= 192 (strip, block) workgroups
+// 64 output channels per workgroup: Cout in multiples of 64, still >= 192 (strip, block) workgroups, and at least three
+// Cin chunks per tile — the wide epilogue (8 voxel pairs per lane, 64 accumulator registers next to the 108 weight registers)
+// is slower per output than the narrow one and has to be amortised: 96->64 @128^3 687 -> 609 us, 192->128 @64^3 269 -> 251,
+// 384->256 @32^3 136 -> 127, but 64->64 @64^3 59 -> 63 (profiles/r04_g_conv_rw_ab.txt)
 static bool rw_wide(const cbim_conv_desc* d) {
   if (!g_rw_wide || d->Cout % 64 != 0) return false;
-  return g_rw_wide == 2 || rw_tiles(d) * (d->Cout / 64) >= 192;    // (2: forced, tests)
+  if (g_rw_wide == 2) return true;                                  // (forced: tests)
+  return d->Cin >= 96 && rw_tiles(d) * (d->Cout / 64) >= 192;
 }
 
 // the calls k_conv3_rw takes from k_conv3_r32 (cbim_conv_r32_eligible has already said yes): the input used as it is, a
