@@ -30,7 +30,18 @@ def run_case(name, dev, mode):
         both[2].backward()
         params = dict(net.named_parameters())
         keys = [str(k) for k in g["keys"]]
+        # every parameter gradient element by element against the oracle (pinned to the reference by tests/test_oracle.py;
+        # the fixtures hold full gradients of the stem / head only): a permuted or sign-flipped interior weight gradient
+        # passes a norm comparison, not this one
+        from oracle import loss_ref, unet_ref
+        from tests.util import grad_compare
+        in_ch, base, classes, scale, ks, block, shape, batch, seed = CASES[name]
+        sdr = {k: v.clone().requires_grad_(True) for k, v in golden_state_dict(name).items()}
+        lo = unet_ref.unet_forward(sdr, torch.from_numpy(g["x"]), scale=scale, kernel_size=ks, block=block)
+        loss_ref.ce_dice_loss(lo, torch.from_numpy(g["label"]), torch.from_numpy(g["weight"])).backward()
+        gw, gcos, gok, gnt, gk = grad_compare({k: params[k].grad for k in keys}, {k: sdr[k].grad for k in keys})
         res = {
+            "grad_rel_worst": gw, "grad_cos_min": gcos, "grad_tensors_within_1e3": gok, "grad_tensors": gnt, "grad_rel_worst_tensor": gk,
             "logits_err": rel_err(logits.detach().cpu(), g["logits"]),
             "ce": float(both[0]), "dice": float(both[1]),
             "argmax_mismatch": int((logits.argmax(1).cpu() != torch.from_numpy(g["logits"]).argmax(1)).sum()),
@@ -46,7 +57,7 @@ def run_case(name, dev, mode):
         cbim_amd.set_compute_dtype(None)
 
 
-def assert_fp32_parity(name, dev, max_flips=0, g_stem_tol=2e-2):
+def assert_fp32_parity(name, dev, max_flips=0, g_stem_tol=2e-2, grad_tol=2e-2, cos_min=0.9999):
     """north_star: outputs within 1e-3 rel of the reference CPU path in fp32, argmax maps exact.
     max_flips / g_stem_tol: envelope of a fixture on which the REFERENCE's own fp32 run is measurably away from its fp64
     evaluation (resunet_bottleneck_b16: three convs per block and InstanceNorm over 8 voxels at the deepest level — the
@@ -58,4 +69,7 @@ def assert_fp32_parity(name, dev, max_flips=0, g_stem_tol=2e-2):
     assert abs(r["ce"] - float(g["ce"])) < 1e-4 and abs(r["dice"] - float(g["dice"])) < 1e-4, r
     # gradients: the reference's own fp32 is ~2e-3 away from fp64 on these tiny pyramids
     assert r["grad_norm_err"] < 1e-2 and r["g_stem"] < g_stem_tol and r["g_head"] < 1e-3 and r["g_bias"] < 1e-3, r
+    # every gradient tensor element-wise against the oracle: 2e-2 of the tensor's largest entry (the stem's envelope above:
+    # the reference's own fp32 is 0.8-1.4e-2 from fp64 on the deepest tiny pyramids), direction to 4 digits
+    assert r["grad_rel_worst"] < grad_tol and r["grad_cos_min"] > cos_min, r
     return r

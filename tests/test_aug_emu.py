@@ -9,7 +9,8 @@ def test_oracle_augmentation_matches_reference_golden():
     res = aug_checks.run("cpu", A=type("O", (), {k: staticmethod(getattr(augment_ref, k)) for k in dir(augment_ref)
                                              if not k.startswith("_")} | {"mirror": staticmethod(lambda t, axis=0: torch.flip(t, dims=[2 + axis]))}))
     for k, v in res.items():
-        assert v < 1e-6, (k, v)
+        if k != "affine_lab_tie_voxels":        # (a count of undecided voxels, not an error)
+            assert v < 1e-6, (k, v)
 
 
 def test_hip_augmentation_matches_reference_golden(dev):

@@ -49,7 +49,7 @@ def test_medformer_amos_128_fp32_engine_matches_oracle(dev):
     net = MedFormer(1, 16, **MEDFORMER_AMOS).to(dev)
     x, lab, w = _data(16, 1, 21)
     t0 = time.perf_counter()
-    _oracle_vs_engine(dev, net, _medformer_oracle(), x, lab, w)
+    _oracle_vs_engine(dev, net, _medformer_oracle(), x, lab, w, tag="medformer_amos_128_fp32")
     print(f"MedFormer AMOS 1x1x{SIZE}^3: oracle + engine fwd/loss/bwd compared in {time.perf_counter() - t0:.0f} s")
 
 
@@ -61,7 +61,7 @@ def test_swin_unetr_4x128_fp32_engine_matches_oracle(dev):
     net = SwinUNETR((SIZE,) * 3, 4, 4, feature_size=48).to(dev)
     x, lab, w = _data(4, 4, 22)
     t0 = time.perf_counter()
-    _oracle_vs_engine(dev, net, swin_unetr_forward, x, lab, w)
+    _oracle_vs_engine(dev, net, swin_unetr_forward, x, lab, w, tag="swin_unetr_4x128_fp32")
     print(f"SwinUNETR 1x4x{SIZE}^3: oracle + engine fwd/loss/bwd compared in {time.perf_counter() - t0:.0f} s")
 
 

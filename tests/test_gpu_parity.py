@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from tests.model_checks import assert_fp32_parity, run_case
-from tests.util import CASES
+from tests.util import CASES, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -22,12 +22,21 @@ def test_fp32_mode_matches_reference_golden(dev, name):
         pytest.skip("base_chan must be a multiple of 4 for whole 16-byte channel chunks")
     r = assert_fp32_parity(name, dev)
     print(name, r)
+    from tests.util import record_parity
+    record_parity("golden_" + name + "_fp32", dict(dtype="fp32", logits_rel=r["logits_err"], argmax_mismatch=r["argmax_mismatch"],
+                                                  ce_abs=abs(r["ce"] - float(load_golden(name)["ce"])), grad_rel_worst=r["grad_rel_worst"],
+                                                  grad_cos_min=r["grad_cos_min"], grad_norm_rel_worst=r["grad_norm_err"]))
 
 
 @pytest.mark.parametrize("name", ["resunet_b8_32", "resunet_b8_aniso", "unet_single_acdc"])
 def test_bf16_mode_inside_reference_bf16_envelope(dev, name):
     r, g = run_case(name, dev, "bf16")
     print(name, r)
+    from tests.util import record_parity
+    record_parity("golden_" + name + "_bf16", dict(dtype="bf16", logits_rel=r["logits_err"], argmax_mismatch=r["argmax_mismatch"],
+                                                  n_vox=r["n_vox"], grad_rel_worst=r["grad_rel_worst"], grad_cos_min=r["grad_cos_min"]))
+    # (bf16 gradients of an UNTRAINED tiny pyramid are recorded, not asserted: measured cosine 0.48-0.94 against the fp32 oracle
+    #  — the trained-weights tests are the bf16 bar)
     assert r["logits_err"] < 0.25, r
     assert r["argmax_mismatch"] < 0.2 * r["n_vox"], r
     assert abs(r["ce"] - float(g["ce"])) < 0.05 and abs(r["dice"] - float(g["dice"])) < 0.02, r
@@ -196,11 +205,18 @@ def test_sliding_window_inference_and_dice(dev):
 
 # ---- ragged / non-cubic volumes and batch > 1 against the oracle evaluated on the host ------------------
 
-def _oracle_vs_engine(dev, net, oracle_forward, x, lab, w, aux=False):
-    """fp32 engine mode vs the oracle (stock torch on the CPU) on the same weights: logits, loss, gradient norms."""
+def _oracle_vs_engine(dev, net, oracle_forward, x, lab, w, aux=False, tag=None, grad_tol=1e-1):
+    """fp32 engine mode vs the oracle (stock torch on the CPU) on the same weights: logits, loss, and EVERY parameter gradient
+    element by element (largest |difference| over the largest |reference| entry of the tensor <= grad_tol, cosine >= 0.999;
+    norms within 2 % as before).  Both sides are fp32 evaluations of a deep network: against a float64 evaluation of the oracle
+    the engine and the fp32 oracle sit at the SAME distance (5e-3 / 8e-3 on the tiny MedFormer: ReLU-mask flips at |x^| ~ 1e-6
+    land on different voxels in different implementations), and the distance grows with the voxel count (6e-2 at 128^3 on the
+    8^3-level weights), so the element-wise bar is a bound on outliers; the cosine is what a permuted / transposed /
+    sign-flipped gradient cannot pass.  The measured numbers go to the parity record."""
     import cbim_amd
     from cbim_amd import functional as Fn
     from oracle.loss_ref import ce_dice_loss
+    from tests.util import grad_compare, record_parity
     sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
     outs = oracle_forward(sd, x)
     outs = outs if isinstance(outs, (list, tuple)) else [outs]
@@ -214,14 +230,33 @@ def _oracle_vs_engine(dev, net, oracle_forward, x, lab, w, aux=False):
         loss.backward()
     finally:
         cbim_amd.set_compute_dtype(None)
+    e_logits = 0.0
     for o, r in zip(res, outs):
         e = float((o.detach().cpu() - r.detach()).abs().max() / r.detach().abs().max())
+        e_logits = max(e_logits, e)
         assert e < 1e-3, e
     assert abs(float(loss) - float(loss_ref)) < 1e-4
     scale = max(float(v.grad.norm()) for v in sd.values() if v.grad is not None)
+    e_norm = 0.0
     for k, p in net.named_parameters():
         a, b = float(p.grad.double().norm()), float(sd[k].grad.double().norm())
+        e_norm = max(e_norm, abs(a - b) / max(b, 1e-5 * scale))
         assert abs(a - b) <= 2e-2 * max(b, 1e-5 * scale), (k, a, b)
+    got = {k: p.grad for k, p in net.named_parameters()}
+    ref = {k: sd[k].grad for k in got}
+    worst, cos_min, n_ok, n_t, worst_k = grad_compare(got, ref)
+    top2 = outs[0].detach().topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-4
+    flips = int(((res[0].detach().cpu().argmax(1) != outs[0].detach().argmax(1)) & decided).sum())
+    print(f"fp32 engine vs oracle: logits rel {e_logits:.2e}, |dloss| {abs(float(loss) - float(loss_ref)):.1e}, argmax flips outside ties "
+          f"{flips}, gradients: worst element-wise rel {worst:.2e} ({worst_k}), lowest cosine {cos_min:.6f}, {n_ok}/{n_t} tensors "
+          f"within 1e-3, worst norm rel {e_norm:.2e}")
+    if tag:
+        record_parity(tag, dict(dtype="fp32", logits_rel=e_logits, loss_abs=abs(float(loss) - float(loss_ref)), argmax_mismatch=flips,
+                                grad_rel_worst=worst, grad_rel_worst_tensor=str(worst_k), grad_cos_min=cos_min,
+                                grad_tensors_within_1e3=n_ok, grad_tensors=n_t, grad_norm_rel_worst=e_norm))
+    assert flips == 0
+    assert worst <= grad_tol and cos_min >= 0.999, (worst, worst_k, cos_min)
 
 
 def _blocky(classes, shape, batch, seed):
@@ -243,7 +278,7 @@ def test_resunet_ragged_batch2_matches_oracle(dev):
     ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
     net = UNet(2, 8, scale=sc, kernel_size=ks, num_classes=5, block="BasicBlock", norm="in").to(dev)
     x, lab, w = _blocky(5, (2, 36, 52, 44), 2, 12)      # odd sizes at every pooling level, ragged 8x8x8 tiles
-    _oracle_vs_engine(dev, net, partial(unet_forward, scale=sc, kernel_size=ks, block="BasicBlock"), x, lab, w)
+    _oracle_vs_engine(dev, net, partial(unet_forward, scale=sc, kernel_size=ks, block="BasicBlock"), x, lab, w, tag="resunet_ragged_b2_fp32")
 
 
 def test_medformer_noncubic_batch2_matches_oracle(dev):
@@ -257,7 +292,7 @@ def test_medformer_noncubic_batch2_matches_oracle(dev):
     fwd = partial(medformer_forward, map_size=TINY["map_size"], num_heads=TINY["num_heads"], fusion_heads=TINY["fusion_heads"],
                   fusion_depth=TINY["fusion_depth"], kernel_size=TINY["kernel_size"], scale=TINY["scale"], act="relu",
                   aux_loss=True)
-    _oracle_vs_engine(dev, net, fwd, x, lab, w)
+    _oracle_vs_engine(dev, net, fwd, x, lab, w, tag="medformer_noncubic_b2_fp32")
 
 
 def test_swin_unetr_noncubic_batch2_matches_oracle(dev):
@@ -266,7 +301,7 @@ def test_swin_unetr_noncubic_batch2_matches_oracle(dev):
     torch.manual_seed(15)
     net = SwinUNETR((32, 64, 96), 2, 3, feature_size=24).to(dev)
     x, lab, w = _blocky(3, (2, 32, 64, 96), 2, 16)
-    _oracle_vs_engine(dev, net, swin_unetr_forward, x, lab, w)
+    _oracle_vs_engine(dev, net, swin_unetr_forward, x, lab, w, tag="swin_noncubic_b2_fp32")
 
 
 def test_unetpp_matches_reference_golden(dev):

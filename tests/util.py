@@ -40,3 +40,50 @@ def rel_err(a, b):
     a = torch.as_tensor(a).detach().double()
     b = torch.as_tensor(b).detach().double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def grad_compare(named_got, named_ref, bf16=False, verbose=True):
+    """Element-wise comparison of every parameter gradient: per tensor the largest |difference| relative
+    to the largest |reference| entry, and the cosine of the two flattened tensors.  Returns (worst relative error, lowest
+    cosine, number of tensors within 1e-3, number of tensors, name of the worst tensor).  A permuted, transposed or
+    sign-flipped interior gradient fails both numbers, which a norm comparison does not see.
+    Tensors whose reference gradient is at rounding-noise level (largest entry below 1e-4 of the largest gradient entry of the
+    model — e.g. a bias in front of an InstanceNorm, whose gradient is analytically zero: 3e-16 of the scale in float64) are
+    compared in absolute terms against that floor and left out of the cosine."""
+    scale = max(float(torch.as_tensor(r).double().abs().max()) for r in named_ref.values())
+    floor = 1e-4 * scale
+    rows = []
+    for k, r in named_ref.items():
+        g = torch.as_tensor(named_got[k]).detach().double().cpu().flatten()
+        r = torch.as_tensor(r).detach().double().cpu().flatten()
+        assert g.shape == r.shape, (k, g.shape, r.shape)
+        m = float(r.abs().max())
+        e = float((g - r).abs().max() / max(m, floor))
+        c = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-300)) if m >= floor else 1.0
+        rows.append((e, c, m / scale, k))
+    worst = max(rows)
+    cos_min = min(r[1] for r in rows)
+    if verbose:
+        for e, c, m, k in sorted(rows, reverse=True)[:5]:
+            print(f"  grad {k}: max|d| / max|ref| {e:.2e}, cosine {c:.6f}, max|ref| / model scale {m:.1e}")
+        for e, c, m, k in sorted(rows, key=lambda t: t[1])[:3]:
+            print(f"  grad (lowest cosine) {k}: cosine {c:.6f}, max|d| / max|ref| {e:.2e}, max|ref| / model scale {m:.1e}")
+    return worst[0], cos_min, sum(r[0] <= 1e-3 for r in rows), len(rows), worst[3]
+
+
+def record_parity(key, values):
+    """Append measured parity margins to the round's parity record (magnitudes, not dots).  On the GPU
+    box the file lands in gpurun_out/ (merged back by gpurun); the builder copies it to profiles/."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "r04_parity.json")
+    data = {}
+    if os.path.isfile(path):
+        try:
+            data = json.load(open(path))
+        except Exception:
+            data = {}
+    data[key] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in values.items()}
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
