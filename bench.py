@@ -362,7 +362,7 @@ def main():
                                + (", HBM-resident volumes + on-device augmentation (crop/affine/intensity, dataset_amos_ct recipe) prefetched on a side stream" if args.aug else "")
                                + (" (hipGraph replay)" if use_graph else "")
                                + (", bucketed in-place grad all-reduce (RCCL)" if ddp is not None else ""),
-                   "global_batch": world, "parallelism": f"dp{world}",
+                   "global_batch": world, "parallelism": f"dp{world}", "graph": bool(use_graph),
                    "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0, "final_loss": loss_val},
     }
 
@@ -374,29 +374,32 @@ def main():
             ops.PROFILE = []
             eager_step()
             torch.cuda.synchronize()
-            for name, flops, e0, e1, shape in ops.PROFILE:
-                d = per.setdefault(name, [0.0, 0.0, 0])
+            for name, flops, e0, e1, shape, nbytes in ops.PROFILE:
+                d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
                 d[0] += flops
                 d[1] += e0.elapsed_time(e1) * 1e-3
                 d[2] += 1
+                d[3] += nbytes
             ops.PROFILE = None
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         table = {k: {"launches_per_step": v[2] // reps, "avg_launch_ms": v[1] / v[2] * 1e3,
                      "alg_tflop_per_step": v[0] / reps / 1e12, "achieved_tflops": v[0] / v[1] / 1e12,
-                     "frac_of_peak": v[0] / v[1] / 1e12 / peak} for k, v in per.items()}
+                     "frac_of_peak": v[0] / v[1] / 1e12 / peak, "alg_bytes_per_launch": v[3] / v[2]} for k, v in per.items()}
         # the dominant kernel = the MFMA conv kernel with the largest share of the step (forward/dgrad kernels; the wgrad
         # entry sums k_conv_wgrad and its reduce)
         dom = max((k for k in per if k.startswith(("k_conv_igemm", "k_conv3_r32", "k_wgrad_r32"))), key=lambda k: per[k][1])
-        f, tsec, nl = per[dom]
+        f, tsec, nl, nby = per[dom]
         fwd128 = {"medformer": FWD_FLOPS_128_MEDFORMER, "swin_unetr": FWD_FLOPS_128_SWIN,
                   "resunet": FWD_FLOPS_128 * (args.base / 32.0) ** 2}[args.model]
         step_flops = 3.0 * fwd128 * (args.size / 128.0) ** 3
         # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run
         # inside this process); null when no recorded pass covers this kernel / dtype / model
         traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in ("r03_traffic.json", "r02_traffic.json", "r01_j_traffic.json", "r01_c_traffic.json"))
-                      if os.path.isfile(q)), "")
-        if args.model == "resunet" and args.size == 128 and os.path.isfile(tpath):
+        # (per model: profiles/r04_traffic.json holds the ResUNet passes, r04_traffic_<model>.json the two others)
+        names = {"resunet": ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_j_traffic.json", "r01_c_traffic.json"),
+                 "medformer": ("r04_traffic_medformer.json",), "swin_unetr": ("r04_traffic_swin_unetr.json",)}[args.model]
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in names) if os.path.isfile(q)), "")
+        if args.size == 128 and os.path.isfile(tpath):
             traffic = (json.load(open(tpath)).get(dom) or {}).get("hbm_bytes_per_launch")
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": f / tsec / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -404,6 +407,7 @@ def main():
             "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)" % os.path.basename(tpath)
                               if traffic else None,
             "alg_flops_per_launch": f / nl, "avg_launch_ms": tsec / nl * 1e3,
+            "alg_bytes_per_launch": nby / nl, "traffic_ratio": (traffic / (nby / nl)) if traffic else None,
             "step_flops": step_flops, "step_achieved": step_flops / (ms * 1e-3) / 1e12,
             "step_frac_mfma": step_flops / (ms * 1e-3) / 1e12 / peak,
             "step_frac_hbm": (ALG_BYTES_BF16 * (2 if args.dtype == "fp32" else 1) / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,

@@ -1072,10 +1072,20 @@ extern "C" int cbim_conv3d_tile_config(const cbim_conv_desc* d, int out[4]) {
   return CBIM_OK;
 }
 
+// bf16 3x3x3 layers in multiples of 32 channels with too few tiles for cbim_conv_r32_eligible: k_conv3_rw's split-K form
+// (conv_rw.hip) instead of k_conv_igemm's
+static int rw_split_of(const cbim_conv_desc* d) {
+  if (d->dtype != CBIM_BF16 || d->kD != 3 || d->kH != 3 || d->kW != 3 || d->Cin % 32 != 0 || d->Cout % 32 != 0) return 0;
+  if (d->Do < 8 || d->Ho < 8 || d->Wo < 8 || d->Do != d->Di || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
+  return cbim_conv_rw_ksplit(d);
+}
+
 extern "C" size_t cbim_conv3d_igemm_workspace(const cbim_conv_desc* d) {
   if (!d) return 0;
   TileCfg c = pick_cfg(d);
   int ks = pick_ksplit(d, c);
+  const int ks_rw = rw_split_of(d);
+  if (ks_rw > ks) ks = ks_rw;
   if (ks <= 1) return 0;
   return (size_t)ks * d->N * d->Do * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
@@ -1085,6 +1095,7 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
   TileCfg c = pick_cfg(d);
   if (pick_ksplit(d, c) > 1) return finish_parts((int64_t)d->Do * d->Ho * d->Wo);
   int64_t g = igemm_grid_x(d, c);   // one record per (image, persistent workgroup)
+  if (rw_split_of(d) > 1 && finish_parts((int64_t)d->Do * d->Ho * d->Wo) > g) g = finish_parts((int64_t)d->Do * d->Ho * d->Wo);
   // the same layer may run on conv_r32.hip (8x8x8 tiles whatever pick_cfg says): room for either grid
   if (cbim_conv_r32_eligible(d, nullptr, 0, nullptr, nullptr, nullptr)) {
     if (cbim_conv_r32_grid(d) > g) g = cbim_conv_r32_grid(d);
@@ -1139,9 +1150,31 @@ static int dispatch_act(int act, bool k3, const TileCfg& c, const IgemmParams& p
   }
 }
 
-// which kernel the last cbim_conv3d_igemm call of this thread launched: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw (profiling labels)
+// which kernel the last cbim_conv3d_igemm call of this thread launched: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw, 3 = k_conv3_rw split-K + finish (profiling labels)
 static thread_local int g_last_conv_kernel = 0;
 extern "C" int cbim_conv3d_last_kernel(void) { return g_last_conv_kernel; }
+
+// the finish pass of a split-K convolution (k_conv_igemm's or k_conv3_rw's): fixed-order sum of the `ksplit` fp32 slabs, then
+// the fused epilogue (residual, act' mask, statistics / InstanceNorm-backward sums into `P` records per image, store)
+static int launch_finish(const cbim_conv_desc* d, const void* workspace, int ksplit, const void* res, int64_t res_stride,
+                         const void* mask_x, int64_t mask_stride, const float* mask_stats, void* y, int64_t y_stride,
+                         float* partials, int P_records, hipStream_t st) {
+  const bool relu = d->act == CBIM_ACT_RELU;
+  int cpc = d->dtype == CBIM_BF16 ? 8 : 4;
+  CBIM_CHECK(d->Cout / cpc <= FT, CBIM_EUNSUPPORTED, "split-K finish: Cout %d too large", d->Cout);
+  const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
+  const int P = finish_parts(S);
+  CBIM_CHECK(!partials || P_records == P, CBIM_EINVAL, "split-K finish: %d partial records per image, %d parts", P_records, P);
+  dim3 fg((unsigned)P, (unsigned)d->N);
+  if (d->dtype == CBIM_BF16) {
+    if (relu) CBIM_LAUNCH((k_splitk_finish<bf16_tag, CBIM_ACT_RELU>), fg, dim3(FT), 0, st, (const float*)workspace, ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
+    else CBIM_LAUNCH((k_splitk_finish<bf16_tag, -1>), fg, dim3(FT), 0, st, (const float*)workspace, ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
+  } else {
+    if (relu) CBIM_LAUNCH((k_splitk_finish<float, CBIM_ACT_RELU>), fg, dim3(FT), 0, st, (const float*)workspace, ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
+    else CBIM_LAUNCH((k_splitk_finish<float, -1>), fg, dim3(FT), 0, st, (const float*)workspace, ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
+  }
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
 
 extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2,
                                  int64_t x2_stride, int cin_split,
@@ -1164,6 +1197,19 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
     g_last_conv_kernel = 1;
     return cbim_conv_r32_launch(d, x, x_stride, x2, x2_stride, cin_split, in_stats, w_packed, res, res_stride, mask_x, mask_stride, mask_stats, y,
                                 y_stride, partials, stream);
+  }
+  if (rw_split_of(d) > 1 && (!x2 || (cin_split > 0 && cin_split < d->Cin && cin_split % 32 == 0)) &&
+      cbim_conv_rw_eligible(d, x, x_stride, x2, x2_stride, in_stats, mask_x, mask_stats) &&
+      (!partials || cbim_conv3d_num_tiles(d) == finish_parts((int64_t)d->Do * d->Ho * d->Wo))) {
+    // low-resolution layer: k_conv3_rw over slices of the Cin chunks + the finish pass (round 4)
+    const int ks = rw_split_of(d);
+    const size_t need = (size_t)ks * d->N * d->Do * d->Ho * d->Wo * d->Cout * sizeof(float);
+    CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "conv split-K workspace %zu < %zu", ws_bytes, need);
+    const int P_records = cbim_conv3d_num_tiles(d);
+    g_last_conv_kernel = 3;
+    if (int rc = cbim_conv_rw_split_launch(d, x, x_stride, x2, x2_stride, cin_split, w_packed, (float*)workspace, stream)) return rc;
+    return launch_finish(d, workspace, ks, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, P_records,
+                         (hipStream_t)stream);
   }
   TileCfg c = pick_cfg(d);
   IgemmParams p;
@@ -1213,6 +1259,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   const int64_t G = igemm_grid_x(d, c);
   (void)n_tiles;
   p.P = cbim_conv3d_num_tiles(d);
+  const int P_records = p.P;
   p.ksplit = pick_ksplit(d, c);
   p.ws = (float*)workspace;
   if (p.ksplit > 1) {
@@ -1253,19 +1300,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
     int rc = d->dtype == CBIM_BF16 ? dispatch_act<bf16_tag>(d->act, k3s, c, q, grid, smem, st)
                                    : dispatch_act<float>(d->act, k3s, c, q, grid, smem, st);
     if (rc) return rc;
-    int cpc = d->dtype == CBIM_BF16 ? 8 : 4;
-    CBIM_CHECK(d->Cout / cpc <= FT, CBIM_EUNSUPPORTED, "split-K finish: Cout %d too large", d->Cout);
-    const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
-    const int P = finish_parts(S);
-    dim3 fg((unsigned)P, (unsigned)d->N);
-    if (d->dtype == CBIM_BF16) {
-      if (relu) CBIM_LAUNCH((k_splitk_finish<bf16_tag, CBIM_ACT_RELU>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
-      else CBIM_LAUNCH((k_splitk_finish<bf16_tag, -1>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
-    } else {
-      if (relu) CBIM_LAUNCH((k_splitk_finish<float, CBIM_ACT_RELU>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
-      else CBIM_LAUNCH((k_splitk_finish<float, -1>), fg, dim3(FT), 0, st, (const float*)workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, S, S * d->N, d->Cout, d->act, P);
-    }
-    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+    return launch_finish(d, workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, P_records, st);
   }
   static const bool k3_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : true;
   const bool k3 = k3_on && d->kH == 3 && d->kW == 3 && c.tH == 8;   // hW == hH == 10: compile-time tap offsets

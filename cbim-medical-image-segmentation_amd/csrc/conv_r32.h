@@ -20,6 +20,9 @@ struct R32Params {
   int tiles_d, tiles_h, tiles_w;
   int dbg; // timing ablations for tools/ (env CBIM_R32_DBG); 0 in production
   int P;   // records per image of `partials` (cbim_conv3d_num_tiles)
+  // k_conv3_rw split-K (low-resolution layers): blockIdx.z owns a slice of the Cin chunks and writes raw fp32 partial sums
+  // ws[ksplit][N*Do*Ho*Wo][Cout] for k_splitk_finish (conv_igemm.hip); 1 / nullptr otherwise
+  int ksplit; float* ws;
 };
 }  // namespace cbim
 
@@ -44,3 +47,9 @@ int64_t cbim_conv_rw_grid(const cbim_conv_desc* d);
 int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
                         int cin_split, const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
                         int64_t mask_stride, void* y, int64_t y_stride, float* partials, void* stream);
+// split-K form for layers with too few (tile, Cout block) pairs to fill the chip: the Cin chunks are shared out over
+// blockIdx.z, raw fp32 partials go to `ws` (cbim_conv_rw_ksplit(d) slabs), finished by k_splitk_finish (residual, mask,
+// statistics, store).  cbim_conv_rw_ksplit: 0 / 1 = not taken.
+int cbim_conv_rw_ksplit(const cbim_conv_desc* d);
+int cbim_conv_rw_split_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                              int cin_split, const void* w_packed, float* ws, void* stream);

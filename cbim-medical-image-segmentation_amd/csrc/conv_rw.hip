@@ -136,8 +136,11 @@ __device__ unsigned long long g_rw_prof[8][8];
 // HP: h-pairs per wave = 32-channel chunks of Cout per workgroup (1: wave = (cout half, h-pair); 2: wave = (cout quarter of
 //     64, half of the tile's rows))
 // MC: several 32-channel chunks of Cin (units = (tile, chunk), streamed weights, optional second input tensor)
-template <bool MX, int HP, bool MC>
+// SK: split-K — blockIdx.z owns the Cin chunks [NC z / ksplit, NC (z + 1) / ksplit) and writes its raw fp32 partial sums
+//     to p.ws (no residual, mask or statistics: k_splitk_finish owns the epilogue)
+template <bool MX, int HP, bool MC, bool SK = false>
 __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
+  static_assert(!SK || (MC && !MX), "split-K: forward-style epilogue over several Cin chunks");
   constexpr int NT = 512, NW = 8, NTL = 8 * HP, NPAIR = 4 * HP, CB = 32 * HP;
   W_DYN_SMEM(smem);
 #ifdef CBIM_EMU
@@ -154,6 +157,8 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
   if (t_begin >= t_end) return;
   const int oc = blockIdx.y;                          // this workgroup's block of CB output channels
   const int NC = MC ? p.NC : 1;
+  const int cc_lo = SK ? (int)(((long long)blockIdx.z * NC) / p.ksplit) : 0;         // this workgroup's Cin chunks
+  const int cc_hi = SK ? (int)(((long long)(blockIdx.z + 1) * NC) / p.ksplit) : NC;
 
   // ---- wave = (16-cout block cb16, h-pairs hp0 .. hp0 + HP - 1); lane = (voxel lv of a 2x8 patch, k-group lq) ---------
   const int cb16 = HP == 1 ? (wave & 1) : (wave & 3);
@@ -189,15 +194,15 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
 
   struct TilePos { int n, td, th, tw, cc; };            // a unit: tile + Cin chunk
   auto advance = [&](TilePos& u) {
-    if (++u.cc < NC) return;
-    u.cc = 0;
+    if (++u.cc < cc_hi) return;
+    u.cc = cc_lo;
     if (++u.tw == p.tiles_w) { u.tw = 0; if (++u.th == p.tiles_h) { u.th = 0; if (++u.td == p.tiles_d) { u.td = 0; ++u.n; } } }
   };
   TilePos cur, nxt;
   {
     const int tt = t_begin % tiles_per_n;
     cur.n = t_begin / tiles_per_n; cur.td = tt / (p.tiles_w * p.tiles_h); cur.th = (tt / p.tiles_w) % p.tiles_h; cur.tw = tt % p.tiles_w;
-    cur.cc = 0;
+    cur.cc = cc_lo;
     nxt = cur;
     advance(nxt);
   }
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
   // after the epilogue exchange a lane owns the 8-channel chunk cidx = 2 cb16 + (lq >> 1) of the workgroup's CB channels
   const int cidx = 2 * cb16 + (lq >> 1);
   const bool c_ok = oc * CB + cidx * 8 < p.Cout;
-  const bool want_part = p.partials != nullptr;
+  const bool want_part = !SK && p.partials != nullptr;
   float* const red = (float*)(smem + W_RED);
   u32x4* const cell0 = (u32x4*)(smem + W_ACC) + tid;                       // + 512 j, j = 0..3: (s0[0..3], s0[4..7], s1[0..3], s1[4..7])
   const float* const shf0 = (const float*)(smem + W_SHF) + (wave * 2 + (lane >> 5)) * 8;
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
     // the first unit's weight fragments, requested BEHIND the halo pieces: the two latencies overlap (requested first and
     // waited for before the pieces were issued, they cost every launch a second memory round trip)
 #pragma unroll
-    for (int tp = 0; tp < 27; ++tp) wf[tp] = *(const u32x4*)(w_lane + (size_t)tp * w_tap);
+    for (int tp = 0; tp < 27; ++tp) wf[tp] = *(const u32x4*)(w_lane + ((size_t)cc_lo * 27u + tp) * w_tap);
 #ifndef CBIM_EMU
     // (the compiler waits for these once, here, and forgets them: conv_r32.hip)
 #pragma unroll
@@ -322,14 +327,14 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
   }
 
   w_f32x4 acc[NTL];
-  const int n_my = (t_end - t_begin) * NC;              // units
+  const int n_my = (t_end - t_begin) * (cc_hi - cc_lo);  // units
 #ifdef CBIM_RW_PROF
   unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = __builtin_readcyclecounter();
 #endif
   for (int t = 0; t < n_my; ++t) {
     const unsigned buf = (unsigned)(t & 1) * W_HB, obuf = W_HB - buf;
     const bool more = t + 1 < n_my;
-    const bool first_cc = cur.cc == 0, last_cc = cur.cc == NC - 1;
+    const bool first_cc = cur.cc == cc_lo, last_cc = cur.cc == cc_hi - 1;
     TilePos nx;                                          // (the strip's last unit re-fetches itself into the idle buffer)
     nx.n = more ? nxt.n : cur.n; nx.td = more ? nxt.td : cur.td; nx.th = more ? nxt.th : cur.th; nx.tw = more ? nxt.tw : cur.tw;
     nx.cc = more ? nxt.cc : cur.cc;
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
     const unsigned y_sb = (unsigned)p.y_stride * 2u, q_sb = MX ? (unsigned)p.mx_stride * 2u : (unsigned)p.res_stride * 2u;
     unsigned char* const y_tile = (unsigned char*)p.y + orow * (long long)y_sb;
     const unsigned char* const q_tile = (MX ? (const unsigned char*)p.mx : (const unsigned char*)p.res) + orow * (long long)q_sb;
-    const bool has_q = MX || p.res != nullptr;           // workgroup-uniform
+    const bool has_q = !SK && (MX || p.res != nullptr);  // workgroup-uniform
     const unsigned cbyte = (unsigned)(oc * (4 * HP) + cidx) * 16u;
     // pair pr = (hp, pp): after the exchange this lane owns chunk cidx of voxel (plane 2 pp + (lq & 1), thp[hp], tw)
     // (the offsets below depend on the lane only: laundering the lane index keeps the compiler from hoisting them — and the
@@ -435,7 +440,27 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
     __syncthreads();
     W_STAMP(4);                                          // barrier
     // ---- epilogue of this tile: its stores drain under the next unit's MFMAs ---------------------------------------------
-    if (last_cc) {
+    if (SK && last_cc) {
+      // raw fp32 partial sums of this Cin slice: ws[z][row][Cout], 32 bytes (the lane's 8 channels of one voxel) per pair
+      float* const wz = p.ws + ((size_t)blockIdx.z * ((size_t)p.N * p.Do * p.Ho * p.Wo) + (size_t)orow) * p.Cout + oc * CB + cidx * 8;
+#pragma unroll
+      for (int pr = 0; pr < NPAIR; ++pr) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = acc[2 * pr][r], b = acc[2 * pr + 1][r];
+          w_swap16(a, b);
+          v[r] = a;
+          v[4 + r] = b;
+        }
+        if (pair_in(pr)) {
+          float* dst = wz + (size_t)pair_rows(pr) * p.Cout;
+          *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+          *(f32x4*)(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+      }
+    }
+    if (!SK && last_cc) {
       if (want_part && n != run_n) { flush_stats(run_n); run_n = n; }
       typedef float f2_t __attribute__((ext_vector_type(2)));
       f2_t l0[4], l1[4];
@@ -604,17 +629,17 @@ int64_t cbim_conv_rw_grid(const cbim_conv_desc* d) {
   return g;
 }
 
-template <bool MX, int HP, bool MC>
+template <bool MX, int HP, bool MC, bool SK = false>
 static int rw_launch_k(const R32Params& p, dim3 grid, hipStream_t st) {
 #ifndef CBIM_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv3_rw<MX, HP, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv3_rw<MX, HP, MC, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
 #endif
-  CBIM_LAUNCH((k_conv3_rw<MX, HP, MC>), grid, dim3(512), (size_t)W_SMEM, st, p);
+  CBIM_LAUNCH((k_conv3_rw<MX, HP, MC, SK>), grid, dim3(512), (size_t)W_SMEM, st, p);
 #ifdef CBIM_RW_PROF
   {
     (void)hipStreamSynchronize(st);
@@ -649,6 +674,7 @@ int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
   p.pD = d->pD; p.pH = d->pH; p.pW = d->pW; p.act = d->act;
   p.tiles_d = (d->Do + 7) / 8; p.tiles_h = (d->Ho + 7) / 8; p.tiles_w = (d->Wo + 7) / 8;
   p.dbg = 0;
+  p.ksplit = 1; p.ws = nullptr;
   p.P = cbim_conv3d_num_tiles(d);
   const bool wide = rw_wide(d);
   dim3 grid((unsigned)cbim_conv_rw_grid(d), (unsigned)(wide ? d->Cout / 64 : (d->Cout + 31) / 32));
@@ -670,6 +696,43 @@ int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
   }
   if (wide) return mc ? rw_launch_k<false, 2, true>(p, grid, st) : rw_launch_k<false, 2, false>(p, grid, st);
   return mc ? rw_launch_k<false, 1, true>(p, grid, st) : rw_launch_k<false, 1, false>(p, grid, st);
+}
+
+// split-K factor of a low-resolution layer: 0 when the layer already has >= 128 (tile, 32-cout block) workgroups or a single
+// Cin chunk; otherwise the divisor-free share-out of the Cin chunks that brings the launch closest to one workgroup per CU
+// (k_splitk_finish keeps one 16-byte output chunk per thread of 256: Cout <= 2048)
+// CBIM_CONV_RW_SPLIT=0 keeps those layers on k_conv_igemm's split-K
+static int g_rw_split = getenv("CBIM_CONV_RW_SPLIT") ? atoi(getenv("CBIM_CONV_RW_SPLIT")) : 1;
+int cbim_conv_rw_ksplit(const cbim_conv_desc* d) {
+  if (!g_rw_on || !g_rw_split || d->dtype != CBIM_BF16) return 0;
+  const int NC = d->Cin / 32;
+  const int64_t wgs = rw_tiles(d) * ((d->Cout + 31) / 32);
+  if (NC < 2 || wgs >= 128 || d->Cout / 8 > 256) return 0;
+  int64_t ks = (256 + wgs - 1) / wgs;
+  if (ks > NC) ks = NC;
+  if (ks > 32) ks = 32;
+  while (ks > 1 && wgs * ks > 288) --ks;       // (one round of workgroups)
+  return ks > 1 ? (int)ks : 0;
+}
+
+int cbim_conv_rw_split_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
+                              int cin_split, const void* w_packed, float* ws, void* stream) {
+  R32Params p;
+  p.x = x; p.x_stride = x_stride; p.in_stats = nullptr; p.w = w_packed;
+  p.NC = d->Cin / 32;
+  p.x2 = x2; p.x2_stride = x2 ? x2_stride : x_stride; p.c_split = x2 ? cin_split / 32 : p.NC;
+  p.BN = d->Cout <= 32 ? 32 : 64;
+  p.res = nullptr; p.res_stride = 0; p.mx = nullptr; p.mx_stride = 0; p.m_stats = nullptr;
+  p.y = nullptr; p.y_stride = d->Cout; p.partials = nullptr;
+  p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.pD = d->pD; p.pH = d->pH; p.pW = d->pW; p.act = d->act;
+  p.tiles_d = (d->Do + 7) / 8; p.tiles_h = (d->Ho + 7) / 8; p.tiles_w = (d->Wo + 7) / 8;
+  p.dbg = 0; p.P = 0;
+  p.ksplit = cbim_conv_rw_ksplit(d); p.ws = ws;
+  CBIM_CHECK(p.ksplit > 1 && ws, CBIM_EINVAL, "conv rw split-K: not a split-K layer");
+  CBIM_CHECK((int64_t)8 * d->Ho * d->Wo < (1 << 24), CBIM_EUNSUPPORTED, "conv rw split-K: output plane too large");
+  dim3 grid((unsigned)rw_tiles(d), (unsigned)((d->Cout + 31) / 32), (unsigned)p.ksplit);   // one tile per workgroup
+  return rw_launch_k<false, 1, true, true>(p, grid, (hipStream_t)stream);
 }
 
 CBIM_DEFINE_WARM(rw)

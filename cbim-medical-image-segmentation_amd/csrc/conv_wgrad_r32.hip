@@ -471,6 +471,7 @@ int cbim_wgrad_r32_dw_strips(const cbim_conv_desc* d) {
   wr32_tiles(d, td, th, tw);
   return wr32_strips_for((int64_t)d->N * td * th * tw, (int64_t)(d->Cout / 32), (int64_t)27 * d->Cout * 4);
 }
+static int g_wr32_small_strips = getenv("CBIM_WGRAD_R32_SMALL_STRIPS") ? atoi(getenv("CBIM_WGRAD_R32_SMALL_STRIPS")) : 1;
 static int wr32_strips_for(int64_t n_tiles, int64_t pairs, int64_t slab) {
   int64_t gmax = (96ll << 20) / slab;
   if (gmax < 1) gmax = 1;
@@ -481,9 +482,12 @@ static int wr32_strips_for(int64_t n_tiles, int64_t pairs, int64_t slab) {
   for (int64_t g = 1; g <= gmax; ++g) {
     // several pairs: strips in multiples of 8 put the pairs of one strip (same dy tile / same input halo) on the same
     // XCD (workgroup k runs on XCD k % 8), where the second reader hits the L2
-    if (pairs > 1 && gmax >= 8 && g % 8 != 0) continue;
+    // (small layers — at most 64 tiles, everything L2 / MALL resident — may break that rule when it saves a round of
+    //  workgroups: 256 -> 256 @16^3 = 8 tiles x 64 pairs ran as 512 one-tile workgroups in two rounds)
+    const bool off8 = pairs > 1 && gmax >= 8 && g % 8 != 0;
+    if (off8 && (n_tiles > 64 || !g_wr32_small_strips)) continue;
     const double rounds = (double)((pairs * g + 255) / 256);
-    const double cost = rounds * ((double)((n_tiles + g - 1) / g) + 1.5);
+    const double cost = rounds * ((double)((n_tiles + g - 1) / g) + 1.5) + (off8 ? 0.25 : 0.0);
     if (cost < best_cost - 1e-9) { best_cost = cost; best = (int)g; }
   }
   return best;

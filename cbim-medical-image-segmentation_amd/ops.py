@@ -569,14 +569,19 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
         e1.record()
         cfg = (C.c_int * 4)()
         L.cbim_conv3d_tile_config(C.byref(desc), C.byref(cfg))
-        if L.cbim_conv3d_last_kernel() in (1, 2):     # conv_r32.hip / its round-4 form conv_rw.hip: one roofline row
+        if L.cbim_conv3d_last_kernel() in (1, 2, 3):  # conv_r32.hip / its round-4 form conv_rw.hip (3: split-K + finish): one roofline row
             name = "k_conv3_r32<bf16>"
         else:
             if cfg[0] == 4:       # a shape the r32 kernel takes for other calls: k_conv_igemm runs its 8x8x8 configuration
                 cfg[0], cfg[1] = 2, (1 if desc.Cout <= 32 else 2)
             name = "k_conv_igemm<%s,%d,%d>" % ("bf16" if desc.dtype == 1 else "f32", cfg[0], cfg[1])
         flops = 2.0 * desc.N * desc.Do * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.kD * desc.kH * desc.kW
-        PROFILE.append((name, flops, e0, e1, (desc.Cin, desc.Cout, desc.Do, desc.Ho, desc.Wo)))
+        # algorithmic bytes of the launch: every operand tensor read once, the output written once, the packed weights once
+        es = x.element_size()
+        nbytes = (desc.N * desc.Di * desc.Hi * desc.Wi * desc.Cin * es +
+                  desc.N * desc.Do * desc.Ho * desc.Wo * desc.Cout * es * (1 + (res is not None) + (mask_x is not None)) +
+                  desc.Cin * desc.Cout * desc.kD * desc.kH * desc.kW * es)
+        PROFILE.append((name, flops, e0, e1, (desc.Cin, desc.Cout, desc.Do, desc.Ho, desc.Wo), nbytes))
     return y, part
 
 
@@ -627,8 +632,9 @@ def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None, x2=None) -> torch.Tens
         flops = 2.0 * d.N * d.Do * d.Ho * d.Wo * d.Cout * d.Cin * d.kD * d.kH * d.kW
         name = "k_wgrad_r32<bf16>+reduce" if L.cbim_conv3d_wgrad_last_kernel() == 1 else \
             "k_conv_wgrad<%s>+reduce" % ("bf16" if d.dtype == 1 else "f32")
+        nbytes = d.N * d.Do * d.Ho * d.Wo * (d.Cin + d.Cout) * x.element_size() + dw.numel() * 4
         PROFILE.append((name, flops, e0, e1,
-                        (d.Cin, d.Cout, d.Do, d.Ho, d.Wo)))
+                        (d.Cin, d.Cout, d.Do, d.Ho, d.Wo), nbytes))
     return dw
 
 

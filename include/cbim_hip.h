@@ -215,7 +215,7 @@ int cbim_conv_rw_enable(int on, int wide);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);
-/* Kernel launched by this thread's last cbim_conv3d_igemm call: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw (profiling labels). */
+/* Kernel launched by this thread's last cbim_conv3d_igemm call: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw, 3 = k_conv3_rw split-K + finish (profiling labels). */
 int cbim_conv3d_last_kernel(void);
 /* Records per sample of the partial-sum buffer `partials` (one per persistent workgroup, or per finish part when the
  * launcher splits K). */

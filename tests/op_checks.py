@@ -397,6 +397,59 @@ def check_conv_rw(dev, N=2, Cin=32, Cout=32, dhw=(9, 16, 11), wide=0, x_split=0,
         assert float((got[7][..., 1] - (gm * ar).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
 
 
+def check_conv_rw_split(dev, N=1, Cin=64, Cout=64, dhw=(8, 8, 8), seed=63):
+    """Low-resolution layers: k_conv3_rw over slices of the Cin chunks (blockIdx.z) + k_splitk_finish, against k_conv_igemm's
+    split-K on the same call (the same finish pass: residual, activated mask, statistics) and against torch."""
+    from cbim_amd import _lib
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    torch.manual_seed(seed)
+    k, pad = (3, 3, 3), (1, 1, 1)
+    a = torch.relu(torch.randn(N, Cin, *dhw) + 0.3)
+    al = to_cl(a, dtype).to(dev)
+    w = torch.randn(Cout, Cin, *k) * 0.1
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, ops.ACT["relu"])
+    wdev = w.to(dev)
+    wp, wpd = ops.pack_weights(wdev, geom, 0), ops.pack_weights(wdev, geom, 1)
+    resl = to_cl(torch.randn(N, Cout, *dhw) + 2.0, dtype).to(dev)
+    dyl = to_cl(torch.randn(N, Cout, *dhw), dtype).to(dev)
+    kern = []
+
+    def run():
+        y, ys = ops.conv_fwd(al, wp, geom, res=resl, want_stats=True)
+        kern.append(L.cbim_conv3d_last_kernel())
+        y1, _ = ops.conv_fwd(al, wp, geom)
+        out = [y, ys, y1]
+        if Cout >= 64:                      # the dgrad (Cout -> Cin) has several chunks to share out
+            g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=al, mask_stats=None)
+            kern.append(L.cbim_conv3d_last_kernel())
+            out += [g2, sums]
+        return [o.float().cpu() for o in out]
+
+    old = L.cbim_conv_rw_enable(0, -1)
+    try:
+        ref = run()                       # k_conv_igemm (split-K)
+        L.cbim_conv_rw_enable(1, -1)
+        got = run()                       # k_conv3_rw split-K
+    finally:
+        L.cbim_conv_rw_enable(old & 1, old >> 1)
+    n = len(kern) // 2
+    assert all(kk == 0 for kk in kern[:n]) and all(kk == 3 for kk in kern[n:]), f"kernels selected: {kern}"
+    for nm, r, g_ in zip(["fwd+res", "fwd stats", "raw fwd", "masked dgrad", "bwd sums"], ref, got):
+        lim = 1e-4 if nm in ("fwd stats", "bwd sums") else 1e-2        # (statistics / sums: fp32 records)
+        assert relerr(g_, r) < lim, f"rw split-K vs igemm: {nm} {relerr(g_, r):.3e}"
+    ar = from_cl(al.cpu())
+    wr = w.bfloat16().float()
+    yr = F.conv3d(ar, wr, None, 1, pad)
+    assert relerr(from_cl(got[2]), yr) < 1e-2, "raw fwd vs torch"
+    ysum = yr + from_cl(resl.cpu())
+    assert relerr(got[1][..., 0], ysum.mean((2, 3, 4))) < 1e-3
+    if Cout >= 64:
+        gm = F.conv_transpose3d(from_cl(dyl.cpu()), wr, None, 1, pad) * (ar > 0)
+        assert relerr(from_cl(got[3]), gm) < 1e-2, "masked dgrad vs torch"
+        assert float((got[4][..., 0] - gm.mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
+
+
 def check_wgrad_large(dev, N=2, Cin=64, Cout=32, dhw=(8, 64, 64), act="relu", raw=False, split=0, seed=5):
     """Weight gradient of a bf16 3x3x3 convolution at >= 32768 voxels (the 4x8x8-tile, fully unrolled path of
     k_conv_wgrad) against torch.  raw: no input transform (SingleConv's wgrad); split > 0: dy as two tensors (conv1 +

@@ -96,6 +96,12 @@ def test_conv_rw_buffer_addressed_halo(dev):
     oc.check_conv_rw(dev, N=1, Cin=32, Cout=64, dhw=(8, 8, 16), wide=2)          # wide, one chunk
     oc.check_conv_rw(dev, N=1, Cin=64, Cout=128, dhw=(8, 8, 8), wide=2)          # two 64-cout blocks
     oc.check_conv_rw(dev, N=1, Cin=32, Cout=96, dhw=(8, 8, 8))                   # Cout 96: the last 64-block is half empty
+    # low-resolution layers: split-K over the Cin chunks + the finish pass
+    oc.check_conv_rw_split(dev)                                                  # one tile, two chunks
+    oc.check_conv_rw_split(dev, N=2, Cin=96, Cout=32, dhw=(8, 8, 16))            # three chunks, two images
+    oc.check_conv_rw_split(dev, N=1, Cin=128, Cout=64, dhw=(9, 8, 8), seed=64)   # ragged depth
+    oc.check_conv_rw_split(dev, N=1, Cin=256, Cout=256, dhw=(16, 16, 16))        # the ResUNet's 16^3 level
+    oc.check_conv_rw_split(dev, N=1, Cin=320, Cout=320, dhw=(8, 8, 8))           # and its 8^3 level
     oc.check_conv_rw(dev, N=1, Cin=96, Cout=64, dhw=(64, 64, 64), x_split=32)    # the default selection at a real size
     oc.check_conv_rw(dev, N=1, Cin=32, Cout=32, dhw=(64, 64, 64))
 
