@@ -387,7 +387,7 @@ def main():
                      "frac_of_peak": v[0] / v[1] / 1e12 / peak, "alg_bytes_per_launch": v[3] / v[2]} for k, v in per.items()}
         # the dominant kernel = the MFMA conv kernel with the largest share of the step (forward/dgrad kernels; the wgrad
         # entry sums k_conv_wgrad and its reduce)
-        dom = max((k for k in per if k.startswith(("k_conv_igemm", "k_conv3_r32", "k_wgrad_r32"))), key=lambda k: per[k][1])
+        dom = max((k for k in per if k.startswith(("k_conv_igemm", "k_conv3_r32", "k_conv3_rw", "k_wgrad_r32"))), key=lambda k: per[k][1])
         f, tsec, nl, nby = per[dom]
         fwd128 = {"medformer": FWD_FLOPS_128_MEDFORMER, "swin_unetr": FWD_FLOPS_128_SWIN,
                   "resunet": FWD_FLOPS_128 * (args.base / 32.0) ** 2}[args.model]

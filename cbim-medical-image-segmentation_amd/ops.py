@@ -569,7 +569,10 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
         e1.record()
         cfg = (C.c_int * 4)()
         L.cbim_conv3d_tile_config(C.byref(desc), C.byref(cfg))
-        if L.cbim_conv3d_last_kernel() in (1, 2, 3):  # conv_r32.hip / its round-4 form conv_rw.hip (3: split-K + finish): one roofline row
+        lk = L.cbim_conv3d_last_kernel()
+        if lk == 3:              # low-resolution layers: k_conv3_rw over Cin slices + k_splitk_finish (the row k_conv_igemm<1,2> had)
+            name = "k_conv3_rw_splitk<bf16>+finish"
+        elif lk in (1, 2):       # conv_r32.hip / its round-4 form conv_rw.hip: one roofline row
             name = "k_conv3_r32<bf16>"
         else:
             if cfg[0] == 4:       # a shape the r32 kernel takes for other calls: k_conv_igemm runs its 8x8x8 configuration
