@@ -132,6 +132,7 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     case CBIM_ACT_LRELU: return x > 0.f ? x : 0.01f * x;
     case CBIM_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
     case CBIM_ACT_SILU: return x / (1.f + __expf(-x));
+    case CBIM_ACT_ELU: return x > 0.f ? x : __expf(x) - 1.f;
     default: return x;
   }
 }
@@ -148,6 +149,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {
       float s = 1.f / (1.f + __expf(-x));
       return s * (1.f + x * (1.f - s));
     }
+    case CBIM_ACT_ELU: return x > 0.f ? 1.f : __expf(x);
     default: return 1.f;
   }
 }

@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1) k_conv_igemm(IgemmPar
         unsigned char* ws_tile = (unsigned char*)p.ws + ((long long)blockIdx.z * ((long long)p.N * p.Do * p.Ho * p.Wo) + orow) * (long long)ws_sb;
         // scratch: the stage buffer just consumed (NTL=2: 36 KiB) or a dedicated region (NTL=1), so the
         // next halo can be written while other waves are still in their epilogue
-        float* scr = (float*)(smem + (((NTL == 1 && NTH == 512) || stage_bytes < NW * 4096u) ? scr_base : b_base + (unsigned)(stage & 1) * stage_bytes) +
+        float* scr = (float*)(smem + ((stage_bytes < NW * 4096u) ? scr_base : b_base + (unsigned)(stage & 1) * stage_bytes) +
                               (unsigned)wave * 4096);
         float* red = (float*)(smem + red_base);
         const int cc = lane % OCH;
@@ -878,9 +878,11 @@ __device__ __forceinline__ void pack_block(const PackGeom& g, int blk, unsigned 
 }
 // blocks of one weight: (32-cout blocks incl. the n-block padding of the forward layout) x (KC-cin blocks incl. that of
 // the dgrad layout)
-static int pack_blocks(int dtype, int Cout, int Cin) {
+// n-block width of a layer: 64 channels, 32 for narrow layers and for 5x5 planes (25 taps per weight stage: LDS)
+static int bn_of(int Ndim, int kplane) { return (Ndim <= 32 || kplane > 9) ? 32 : 64; }
+static int pack_blocks(int dtype, int Cout, int Cin, int kplane) {
   const int KC = RB / (dtype == CBIM_BF16 ? 2 : 4);
-  const int BN0 = Cout <= 32 ? 32 : 64, BN1 = Cin <= 32 ? 32 : 64;
+  const int BN0 = bn_of(Cout, kplane), BN1 = bn_of(Cin, kplane);
   return (((Cout + BN0 - 1) / BN0) * BN0 / 32) * (((Cin + BN1 - 1) / BN1) * BN1 / KC);
 }
 
@@ -914,13 +916,16 @@ struct TileCfg { int MT, NTL, tD, tH, lgH, nth; };
 
 static TileCfg pick_cfg(const cbim_conv_desc* d) {
   TileCfg c;
-  c.NTL = d->Cout <= 32 ? 1 : 2;
+  c.NTL = bn_of(d->Cout, d->kH * d->kW) / 32;
   int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
   // 8x8x8 tiles (BM = 512) when that still leaves >= 2 tiles per CU; otherwise 4x8x8 (BM = 256)
   c.MT = (S >= 262144 && d->Do >= 8 && d->Ho >= 8) ? 2 : 1;
   c.tH = 8; c.lgH = 3;
   c.tD = c.MT == 2 ? 8 : 4;
   c.nth = 512;
+  if (d->kH * d->kW > 9) {   // 5x5 planes (VNet): 25 taps per weight stage -> 32-cout blocks (bn_of) on 4x8x8 tiles to fit 160 KB of LDS
+    c.MT = 1; c.tD = 4;
+  }
   // two 256-thread workgroups per CU on 4x8x8 tiles (phase overlap): 3x3x3, Cout <= 32 layers at full resolution
   static const int half_on = getenv("CBIM_IGEMM_HALF") ? atoi(getenv("CBIM_IGEMM_HALF")) : 0;
   if (half_on && c.MT == 2 && c.NTL == 1 && d->dtype == CBIM_BF16 && d->kD == 3 && d->kH == 3 && d->kW == 3 &&
@@ -984,7 +989,7 @@ static int validate(const cbim_conv_desc* d) {
 extern "C" size_t cbim_conv3d_packed_bytes(const cbim_conv_desc* d, int mode) {
   if (!d) return 0;
   int Kdim = mode == 0 ? d->Cin : d->Cout, Ndim = mode == 0 ? d->Cout : d->Cin;
-  int NTL = Ndim <= 32 ? 1 : 2, BN = 32 * NTL;
+  int BN = bn_of(Ndim, d->kH * d->kW);
   int n_nblk = (Ndim + BN - 1) / BN;
   int KC = kc_of(d->dtype);
   int n_chunks = (Kdim + KC - 1) / KC;
@@ -1012,9 +1017,9 @@ static int pack_launch(const cbim_conv_desc* d, const float* w, void* p0, void* 
   const int KC = kc_of(d->dtype), taps = d->kD * d->kH * d->kW;
   PackGeom g;
   g.w0 = w; g.w1 = nullptr; g.p0 = p0; g.p1 = p1; g.rows0 = d->Cout; g.Cout = d->Cout; g.Cin = d->Cin; g.taps = taps;
-  g.BN0 = d->Cout <= 32 ? 32 : 64; g.BN1 = d->Cin <= 32 ? 32 : 64;
+  g.BN0 = bn_of(d->Cout, d->kH * d->kW); g.BN1 = bn_of(d->Cin, d->kH * d->kW);
   g.nch0 = (d->Cin + KC - 1) / KC; g.nch1 = (d->Cout + KC - 1) / KC;
-  const int blocks = pack_blocks(d->dtype, d->Cout, d->Cin);
+  const int blocks = pack_blocks(d->dtype, d->Cout, d->Cin, d->kH * d->kW);
   const size_t smem = (size_t)taps * 2048;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == CBIM_BF16) CBIM_LAUNCH((k_pack_weights<bf16_tag>), dim3((unsigned)blocks), dim3(256), smem, st, g);
@@ -1043,11 +1048,11 @@ extern "C" int cbim_conv3d_pack_item_fill(const cbim_conv_desc* d, const float* 
   const int KC = kc_of(d->dtype), es = elem_size(d->dtype);
   out->w0 = w0; out->w1 = w1; out->p0 = packed_fwd; out->p1 = packed_dgrad;
   out->rows0 = w1 ? rows0 : d->Cout; out->Cout = d->Cout; out->Cin = d->Cin; out->taps = d->kD * d->kH * d->kW;
-  out->BN0 = d->Cout <= 32 ? 32 : 64; out->BN1 = d->Cin <= 32 ? 32 : 64;
+  out->BN0 = bn_of(d->Cout, d->kH * d->kW); out->BN1 = bn_of(d->Cin, d->kH * d->kW);
   out->nch0 = (d->Cin + KC - 1) / KC; out->nch1 = (d->Cout + KC - 1) / KC;
   out->total0 = packed_fwd ? (int64_t)(cbim_conv3d_packed_bytes(d, 0) / es) : 0;
   out->total1 = packed_dgrad ? (int64_t)(cbim_conv3d_packed_bytes(d, 1) / es) : 0;
-  const int nb = pack_blocks(d->dtype, d->Cout, d->Cin);   // one workgroup per 32 couts x KC cins (k_pack_weights_table)
+  const int nb = pack_blocks(d->dtype, d->Cout, d->Cin, d->kH * d->kW);   // one workgroup per 32 couts x KC cins (k_pack_weights_table)
   out->block_begin = block_begin; out->n_blocks = (int)nb; out->dtype = d->dtype;
   return CBIM_OK;
 }
@@ -1252,7 +1257,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   int BN = 32 * c.NTL;
   size_t smem = (size_t)p.hD * p.hH * p.hW * RB + 2 * (size_t)d->kH * d->kW * KG * 2 * BN * 16 +
                 (size_t)nw * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float) +
-                (((c.NTL == 1 && c.nth == 512) || (size_t)d->kH * d->kW * KG * 2 * BN * 16 < (size_t)nw * 4096) ? (size_t)nw * 4096 : 0);
+                ((size_t)d->kH * d->kW * KG * 2 * BN * 16 < (size_t)nw * 4096 ? (size_t)nw * 4096 : 0);
   CBIM_CHECK(smem <= 160 * 1024, CBIM_EUNSUPPORTED, "conv tile needs %zu B of LDS", smem);
   int64_t n_tiles = (int64_t)d->N * p.tiles_d * p.tiles_h * p.tiles_w;
   int n_nblk = (d->Cout + BN - 1) / BN;

@@ -425,6 +425,68 @@ __global__ void __launch_bounds__(NT) k_stem_wgrad(StemParams p) {
   }
 }
 
+// ---- stem weight gradient for kernels beyond 3x3x3 (VNet's 5x5x5 input convolution, vnet.py:46: 125 taps) ----------------
+// thread = (tap slot 0..127, half of a 16-cout block): 8 accumulators; per output voxel of the 4x8x8 tile one halo value (its
+// own tap's) and the voxel's 8 dy values (two 16-byte LDS reads shared by the 128 threads of the half) feed 8 FMAs.  Strip
+// of tiles per workgroup, slab [Cin][taps][Cout] per strip, then k_stem_wgrad_reduce as for the small stems.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_stem_wgrad_taps(StemParams p) {
+  CBIM_DYN_SMEM(smem);
+  const int hV = p.hD * p.hH * p.hW;
+  const int hVp = (hV + 3) & ~3;
+  float* xL = (float*)smem;                           // [hVp]
+  float* dL = xL + hVp;                               // [256 voxels][16 couts]
+  const int tid = threadIdx.x, slot = tid & 127, half = tid >> 7;
+  const int n = blockIdx.x / p.strips_per_n, strip = blockIdx.x % p.strips_per_n;
+  const int co0 = blockIdx.y * 16;
+  const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+  const int t_begin = strip * p.tiles_per_strip;
+  int t_end = t_begin + p.tiles_per_strip;
+  if (t_end > tiles_per_n) t_end = tiles_per_n;
+  const size_t Sin = (size_t)p.Di * p.Hi * p.Wi;
+  const size_t slab = (size_t)p.Cin * p.taps * p.Cout;
+  const int tap = slot < p.taps ? slot : 0;
+  const int kw = tap % p.kW, kh = (tap / p.kW) % p.kH, kd = tap / (p.kW * p.kH);
+  const int toff = (kd * p.hH + kh) * p.hW + kw;
+  for (int ci = 0; ci < p.Cin; ++ci) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int t = t_begin; t < t_end; ++t) {
+      const int od0 = (t / (p.tiles_w * p.tiles_h)) * 4, oh0 = ((t / p.tiles_w) % p.tiles_h) * 8, ow0 = (t % p.tiles_w) * 8;
+      __syncthreads();
+      for (int hv = tid; hv < hV; hv += NT) {
+        int hw = hv % p.hW, r = hv / p.hW, hh = r % p.hH, hd = r / p.hH;
+        int id = od0 - p.pD + hd, ih = oh0 - p.pH + hh, iw = ow0 - p.pW + hw;
+        const bool in = id >= 0 && id < p.Di && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+        xL[hv] = in ? p.x[((size_t)n * p.Cin + ci) * Sin + ((size_t)id * p.Hi + ih) * p.Wi + iw] : 0.f;
+      }
+      {
+        const int tw = tid & 7, th = (tid >> 3) & 7, td = tid >> 6;
+        const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+        const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+        const size_t row = (size_t)n * p.Do * p.Ho * p.Wo + ((size_t)od * p.Ho + oh) * p.Wo + ow;
+        for (int j = 0; j < 16; ++j)
+          dL[tid * 16 + j] = (ok && co0 + j < p.Cout) ? Elem<T>::load1(p.dy, row * p.Cout + co0 + j) : 0.f;
+      }
+      __syncthreads();
+      for (int v = 0; v < 256; ++v) {
+        const int tw = v & 7, th = (v >> 3) & 7, td = v >> 6;
+        const float xv = xL[(td * p.hH + th) * p.hW + tw + toff];
+        const float* dv = dL + v * 16 + half * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(dv[j], xv, acc[j]);
+      }
+    }
+    if (slot < p.taps)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int co = co0 + half * 8 + j;
+        if (co < p.Cout) p.ws[(size_t)blockIdx.x * slab + ((size_t)ci * p.taps + slot) * p.Cout + co] = acc[j];
+      }
+  }
+}
+
 // 16 outputs per workgroup x 16 slab phases: thread (o, ph) adds slabs ph, ph+16, .. (two independent chains), the 16 phase
 // sums are combined through LDS in fixed order.  (One thread per output walking all 1024 slabs: 4 workgroups, 80 us.)
 __global__ void __launch_bounds__(NT) k_stem_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw,
@@ -992,7 +1054,7 @@ static int stem_check(int dtype, int Cin, int Cout, int kD, int kH, int kW) {
   int cpc = dtype == CBIM_BF16 ? 8 : 4;
   CBIM_CHECK(Cout % cpc == 0, CBIM_EUNSUPPORTED, "stem Cout %d is not a multiple of %d", Cout, cpc);
   CBIM_CHECK(Cin >= 1 && Cin <= 16, CBIM_EUNSUPPORTED, "stem Cin %d unsupported (1..16)", Cin);
-  CBIM_CHECK(kD <= 3 && kH <= 3 && kW <= 3, CBIM_EUNSUPPORTED, "stem kernel extent > 3 unsupported");
+  CBIM_CHECK(kD <= 5 && kH <= 5 && kW <= 5 && kD * kH * kW <= 128, CBIM_EUNSUPPORTED, "stem kernel extent > 5 unsupported");
   return 0;
 }
 
@@ -1017,7 +1079,8 @@ extern "C" int cbim_stem_conv_fwd(int dtype_out, const float* x, const float* w,
   CBIM_CHECK(smem <= 64 * 1024, CBIM_EUNSUPPORTED, "stem needs %zu B of LDS", smem);
   dim3 grid((unsigned)(N * p.tiles_d * p.tiles_h * p.tiles_w));
   hipStream_t st = (hipStream_t)stream;
-  if (g_stem_mfma && dtype_out == CBIM_BF16 && Cin == 1 && Cout % 32 == 0 && Cout <= 128) {   // matrix-core form
+  if (g_stem_mfma && dtype_out == CBIM_BF16 && Cin == 1 && Cout % 32 == 0 && Cout <= 128 && p.taps <= MAXTAPS &&
+      kD <= 3 && kH <= 3 && kW <= 3) {   // matrix-core form
     const size_t sm = (size_t)3 * NT * sizeof(unsigned);
     dim3 pg(grid.x < 2048u ? grid.x : 2048u);             // persistent workgroups: the weight fragments are built once
     switch (Cout / 32) {
@@ -1049,6 +1112,18 @@ extern "C" int cbim_stem_conv_wgrad(int dtype, const float* x, const void* dy, f
   StemParams p;
   p.x = x; p.w = nullptr; p.y = nullptr; p.dy = dy; p.ws = (float*)workspace;
   stem_fill(p, N, Cin, Di, Hi, Wi, Cout, kD, kH, kW, pD, pH, pW, Do, Ho, Wo);
+  if (kD > 3 || kH > 3 || kW > 3) {   // beyond the 3x3x3 lattice: one thread per tap
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(N * p.strips_per_n), (unsigned)((Cout + 15) / 16));
+    const size_t sm = ((size_t)((p.hD * p.hH * p.hW + 3) & ~3) + 256 * 16) * sizeof(float);
+    if (dtype == CBIM_BF16) CBIM_LAUNCH((k_stem_wgrad_taps<bf16_tag>), grid, dim3(NT), sm, st, p);
+    else CBIM_LAUNCH((k_stem_wgrad_taps<float>), grid, dim3(NT), sm, st, p);
+    if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+    const int total = Cin * p.taps * Cout;
+    CBIM_LAUNCH(k_stem_wgrad_reduce, dim3((total + 15) / 16), dim3(NT), 0, st, (const float*)workspace, dw,
+                N * p.strips_per_n, Cin, p.taps, Cout);
+    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  }
   if (g_stem_mfma && dtype == CBIM_BF16 && Cin == 1 && Cout % 32 == 0 && Cout <= 128) {   // matrix-core form
     const size_t tile = (size_t)p.hD * p.hH * 64 + (size_t)256 * Cout * 2, red = (size_t)4 * 32 * Cout * sizeof(float);
     const size_t sm = tile > red ? tile : red;

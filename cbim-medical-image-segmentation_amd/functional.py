@@ -659,6 +659,129 @@ class NormActFn(torch.autograd.Function):
         return ops.norm_bwd_apply(dy, z, stats, sums, ctx.act, masked=True), None, None
 
 
+class ActFn(torch.autograd.Function):
+    """y = act(x) as one streaming pass (the norm + activation kernel with identity statistics) — VNet's ELU after a
+    residual add (/root/reference/model/dim3/vnet.py:73,95,119)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        ident = torch.zeros((int(x.shape[0]), int(x.shape[-1]), 2), dtype=torch.float32, device=x.device)
+        ident[..., 1] = 1.0
+        ctx.save_for_backward(x, ident)
+        ctx.act = act
+        return ops.norm_act_fwd(x, ident, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ident = ctx.saved_tensors
+        zero = torch.zeros_like(ident)
+        return ops.norm_bwd_apply(dy.contiguous(), x, ident, zero, ctx.act, masked=True), None
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """ContBatchNorm3d (vnet.py:22-33: F.batch_norm with training=True ALWAYS — batch statistics over (N, D, H, W), affine,
+    running-statistics update) followed by an optional activation, on the InstanceNorm kernels: the per-(n, c) moments of
+    `k_partial_sums` are pooled over N, and gamma * xh + beta is folded into the statistics the streaming kernels take
+    (mean' = mean - beta / (gamma rstd), rstd' = gamma rstd: (x - mean') rstd' = gamma xh + beta = z), so forward is one pass
+    and backward one reduction + one pass: with dz = dy act'(z), a = mean(dz), b = mean(dz xh) over the batch,
+    dx = gamma rstd (dz - a - xh b) = rstd' (dz - (a - beta b / gamma) - z b / gamma), dgamma = sum dz xh, dbeta = sum dz."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act):
+        N, C = int(x.shape[0]), int(x.shape[-1])
+        S = 1
+        for d in x.shape[1:-1]:
+            S *= int(d)
+        st = ops.instnorm_stats(x, eps).double()                       # [N, C, (mean, rstd)] per image
+        mean_nc, var_nc = st[..., 0], 1.0 / (st[..., 1] * st[..., 1]) - eps
+        mean_b = mean_nc.mean(0)
+        var_b = (var_nc + mean_nc * mean_nc).mean(0) - mean_b * mean_b   # biased variance of the batch
+        var_b = var_b.clamp_min(0.0)
+        rstd_b = torch.rsqrt(var_b + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                n = float(N * S)
+                running_mean.mul_(1.0 - momentum).add_(mean_b.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1.0 - momentum).add_((var_b * (n / max(n - 1.0, 1.0))).to(running_var.dtype), alpha=momentum)
+        g64, b64 = weight.detach().double(), bias.detach().double()
+        if bool((g64.abs() < 1e-20).any()):
+            raise NotImplementedError("cbim_amd: BatchNorm weight of exactly zero (the affine fold divides by gamma)")
+        rstd_f = g64 * rstd_b
+        mean_f = mean_b - b64 / rstd_f
+        stats_f = torch.stack([mean_f, rstd_f], -1).float().unsqueeze(0).expand(N, C, 2).contiguous()
+        ctx.save_for_backward(x, stats_f, g64, b64)
+        ctx.act, ctx.S = act, S
+        return ops.norm_act_fwd(x, stats_f, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats_f, g64, b64 = ctx.saved_tensors
+        N, C = int(x.shape[0]), int(x.shape[-1])
+        dy = dy.contiguous()
+        sums = ops.norm_bwd_sums(dy, x, stats_f, ctx.act, masked=True).double()   # per image: mean(dz), mean(dz z)
+        a = sums[..., 0].mean(0)
+        bz = sums[..., 1].mean(0)
+        b = (bz - b64 * a) / g64                                        # mean(dz xh)
+        cnt = float(N * ctx.S)
+        dgamma, dbeta = (b * cnt).float(), (a * cnt).float()
+        sums_f = torch.stack([a - b64 * b / g64, b / g64], -1).float().unsqueeze(0).expand(N, C, 2).contiguous()
+        dx = ops.norm_bwd_apply(dy, x, stats_f, sums_f, ctx.act, masked=True)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class ConvSlicesFn(torch.autograd.Function):
+    """nn.Conv3d with a kernel of more than 64 taps (VNet's 5x5x5, vnet.py:40,60,126) as the sum over kd of (1, kH, kW)
+    convolutions of D-shifted slices on the implicit-GEMM kernel: slice kd reads the input planes d + kd - pD and accumulates
+    IN PLACE into the output planes they feed (k_conv_igemm's residual operand = its own output tensor).  Backward: the same
+    decomposition for the input gradient (accumulated in place) and one weight-gradient launch per (image, kd)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        N, D, H, W, Cin = map(int, x.shape)
+        Cout, _, kD, kH, kW = map(int, w.shape)
+        pD, pH, pW = kD // 2, kH // 2, kW // 2
+        wd = w.detach()
+        y = torch.empty((N, D, H, W, Cout), dtype=x.dtype, device=x.device)
+        plans = []
+        order = [pD] + [k for k in range(kD) if k != pD]          # the centre slice first: it covers every output plane
+        for kd in order:
+            o = kd - pD
+            d0, d1 = max(0, -o), min(D, D - o)
+            if d1 <= d0:
+                continue
+            geom = ConvGeom(x.dtype, 1, (d1 - d0, H, W), Cin, Cout, (1, kH, kW), (0, pH, pW), 0)
+            wk = wd[:, :, kd:kd + 1].contiguous()
+            wp = ops.pack_weights(wk, geom, 0)
+            for n in range(N):
+                ys = y[n:n + 1, d0:d1]
+                ops.conv_igemm(geom.fwd, x[n:n + 1, d0 + o:d1 + o], wp, tuple(ys.shape), res=None if kd == pD else ys, out=ys)
+            plans.append((kd, o, d0, d1, geom, wk))
+        if bias is not None:
+            y += bias.detach().to(y.dtype)
+        ctx.save_for_backward(x)
+        ctx.plans, ctx.w_shape, ctx.has_bias = plans, tuple(w.shape), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        N = int(x.shape[0])
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros(ctx.w_shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        for kd, o, d0, d1, geom, wk in ctx.plans:
+            wpd = ops.pack_weights(wk, geom, 1) if dx is not None else None
+            for n in range(N):
+                xs, dys = x[n:n + 1, d0 + o:d1 + o], dy[n:n + 1, d0:d1]
+                if dx is not None:
+                    dxs = dx[n:n + 1, d0 + o:d1 + o]
+                    ops.conv_igemm(geom.bwd, dys, wpd, tuple(dxs.shape), res=dxs, out=dxs)
+                if dw is not None:
+                    dw[:, :, kd:kd + 1] += ops.conv_wgrad(xs, None, dys, geom)
+        db = dy.float().sum((0, 1, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 class GateFn(torch.autograd.Function):
     """x * psi with one psi per voxel (AttentionBlock.forward, attention_unet_utils.py:35)."""
 

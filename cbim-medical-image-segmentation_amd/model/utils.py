@@ -8,6 +8,11 @@ def get_model(args, pretrain=False):
         raise NotImplementedError("cbim_amd: the 2D model zoo is outside the model/dim3 hot path")
     if args.dimension != "3d":
         raise ValueError("Invalid dimension, should be '2d' or '3d'")
+    if args.model == "vnet":   # model/utils.py:70-74 of the reference (note: `downsample_scale`, not `down_scale`)
+        from .dim3 import VNet
+        if pretrain:
+            raise ValueError("No pretrain model available")
+        return VNet(args.in_chan, args.classes, scale=args.downsample_scale, baseChans=args.base_chan)
     if args.model in ("resunet", "unet"):
         from .dim3 import UNet
         if pretrain and args.model == "resunet":

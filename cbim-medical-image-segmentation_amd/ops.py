@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, check
 
-ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "gelu": 3, "swish": 4, "silu": 4}
+ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "gelu": 3, "swish": 4, "silu": 4, "elu": 5}
 IN_EPS = 1e-4  # /root/reference/model/dim3/conv_layers.py:40,42
 
 # bench.py sets this to a list to collect (kernel, algorithmic flops, start event, end event, shape)
@@ -544,12 +544,17 @@ def packed_weights(ws, geom: ConvGeom, need_dgrad: bool):
 
 
 def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, mask_x=None, mask_stats=None,
-               want_partials: bool = False, x2=None):
+               want_partials: bool = False, x2=None, out=None):
     """x2: second input tensor; the conv's input is the channel concatenation [x | x2] (never
-    materialised), split at x.shape[-1]."""
-    _dev_ok(x, w_packed, in_stats, res, mask_x, mask_stats, x2)
+    materialised), split at x.shape[-1].  out: write into this (dense) tensor instead of a new one; it may be `res`
+    itself (in-place accumulation: every output chunk is read and written once, by the same thread)."""
+    _dev_ok(x, w_packed, in_stats, res, mask_x, mask_stats, x2, out)
     L = _lib.lib()
-    y = torch.empty(tuple(out_shape), dtype=x.dtype, device=x.device)
+    if out is not None:
+        assert tuple(out.shape) == tuple(out_shape) and out.dtype == x.dtype and out.is_contiguous()
+        y = out
+    else:
+        y = torch.empty(tuple(out_shape), dtype=x.dtype, device=x.device)
     part = None
     if want_partials:
         tiles = L.cbim_conv3d_num_tiles(C.byref(desc))

@@ -39,6 +39,7 @@ extern "C" {
 #define CBIM_ACT_LRELU 2  /* nn.LeakyReLU (model/dim3/utils.py:26), slope 0.01 */
 #define CBIM_ACT_GELU 3   /* nn.GELU      (model/dim3/utils.py:27) */
 #define CBIM_ACT_SILU 4   /* nn.SiLU      (model/dim3/utils.py:28) */
+#define CBIM_ACT_ELU 5    /* nn.ELU(alpha = 1) (model/dim3/vnet.py:12-16); streaming norm / activation kernels only */
 
 #define CBIM_OK 0
 #define CBIM_EINVAL (-1)

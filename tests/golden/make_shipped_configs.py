@@ -25,12 +25,12 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 import make_golden as mg  # noqa: E402
 
-MODELS = ("unet", "resunet", "unet++", "attention_unet", "medformer", "swin_unetr")
+MODELS = ("unet", "resunet", "unet++", "attention_unet", "medformer", "swin_unetr", "vnet")
 # the keys model/utils.py:70-122 reads for these models + what the step around them needs
 KEYS = ("dimension", "model", "in_chan", "base_chan", "classes", "down_scale", "kernel_size", "norm", "block", "map_size",
         "conv_block", "conv_num", "trans_num", "num_heads", "fusion_depth", "fusion_dim", "fusion_heads", "expansion",
         "attn_drop", "proj_drop", "proj_type", "act", "aux_loss", "aux_weight", "window_size", "training_size", "weight",
-        "pretrain")
+        "pretrain", "downsample_scale")
 
 
 def layout_digest(sd):
@@ -44,7 +44,7 @@ def main():
     mg.import_reference()
     dim3 = sys.modules["model.dim3"]
     for mod, cls in (("unet", "UNet"), ("unetpp", "UNetPlusPlus"), ("attention_unet", "AttentionUNet"),
-                     ("medformer", "MedFormer"), ("swin_unetr", "SwinUNETR")):
+                     ("medformer", "MedFormer"), ("swin_unetr", "SwinUNETR"), ("vnet", "VNet")):
         setattr(dim3, cls, getattr(importlib.import_module("model.dim3." + mod), cls))
     get_model = importlib.import_module("model.utils").get_model
     out = {}

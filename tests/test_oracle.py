@@ -184,3 +184,27 @@ def test_token_linear_split_k_weight_gradient_matches_nn_linear():
         (lin(x).sin().sum()).backward()
         for a, b in zip(got, (x.grad, lin.weight.grad, lin.bias.grad)):
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_vnet_oracle_matches_reference_golden():
+    """oracle/vnet_ref.py against the real reference VNet in TRAINING mode with its recorded Dropout3d masks
+    (tests/golden/make_golden_vnet.py): logits, loss, every gradient norm, the small gradient tensors in full."""
+    from tests.vnet_checks import oracle_vs_golden
+    print(oracle_vs_golden())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model/dim3"), reason="reference tree not mounted")
+def test_vnet_oracle_vs_live_reference():
+    """another width / shape / seed, dropout off (eval: ContBatchNorm3d still normalises with batch statistics)"""
+    import importlib
+    from oracle import vnet_ref
+    from tests.golden.make_golden import import_reference
+    import_reference()
+    VNet = importlib.import_module("model.dim3.vnet").VNet
+    torch.manual_seed(23)
+    sc = [[2, 2, 2]] * 4
+    net = VNet(2, 3, scale=sc, baseChans=4).eval()
+    x = torch.randn(2, 2, 16, 16, 32)
+    ref = net(x)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    assert rel_err(vnet_ref.vnet_forward(sd, x, sc), ref.detach()) < 1e-5

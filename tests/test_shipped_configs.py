@@ -25,8 +25,8 @@ def _digest(sd):
 
 def test_fixture_covers_the_shipped_zoo():
     models = sorted({v["args"]["model"] for v in SHIPPED.values()})
-    assert models == ["attention_unet", "medformer", "resunet", "swin_unetr", "unet", "unet++"]
-    assert len(SHIPPED) == 23
+    assert models == ["attention_unet", "medformer", "resunet", "swin_unetr", "unet", "unet++", "vnet"]
+    assert len(SHIPPED) == 24
 
 
 @pytest.mark.parametrize("cfg", sorted(SHIPPED))
@@ -81,7 +81,9 @@ def _step_properties(cfg, dev, size=None, dtype="bf16"):
                 return sum(aw * crit(o, lab) for aw, o in zip(a.get("aux_weight", [0.5, 0.5]), out))
             return crit(out, lab)
 
+        torch.manual_seed(11)                                  # VNet's Dropout3d masks: the same draw for both forwards
         first = float(loss_of(net(x)).detach())
+        torch.manual_seed(11)
         out = net(x)
         main = out[0] if isinstance(out, (list, tuple)) else out
         assert tuple(main.shape) == (1, a["classes"], *size), (cfg, tuple(main.shape))

@@ -46,3 +46,58 @@ def test_resunet_bottleneck_matches_reference_golden(dev):
     # (max-abs / max-abs) on the executor, yet CE 1.5315 vs 1.5256 and Dice 0.7636 vs 0.7615 — the losses are the criterion
     assert r["logits_err"] < 2.0 and abs(r["ce"] - float(g["ce"])) < 0.05 and abs(r["dice"] - float(g["dice"])) < 0.05, r
 
+
+
+# ---- VNet ------------------------------------------------------------------------------------------------
+
+def test_vnet_fp32_matches_reference_golden(dev):
+    from tests.util import record_parity
+    from tests.vnet_checks import assert_fp32
+    r = assert_fp32(dev)
+    print(r)
+    record_parity("vnet_b8_fp32", {k: (float(v) if not isinstance(v, str) else v) for k, v in r.items()})
+
+
+def test_vnet_bf16_inside_envelope(dev):
+    """bf16 engine mode against the reference's fp32 golden (untrained weights, BatchNorm over 16 values at the deepest
+    level): the losses are the criterion, the element-wise figures are recorded."""
+    from tests.util import load_golden, record_parity
+    from tests.vnet_checks import run
+    r = run(dev, "bf16")
+    print(r)
+    record_parity("vnet_b8_bf16", {k: (float(v) if not isinstance(v, str) else v) for k, v in r.items()})
+    g = load_golden("vnet_b8")
+    assert r["ce_err"] < 0.05 and r["dice_err"] < 0.05, r
+    assert r["logits_err"] < 0.5 and r["argmax_mismatch"] < 0.2 * g["logits"][:, 0].size, r
+
+
+def test_vnet_acdc_config_trains_in_bf16(dev):
+    """config/acdc/vnet_3d.yaml's model (base 16) on its training crop 16 x 192 x 192, batch 2: three AdamW steps reduce the
+    loss; every gradient finite"""
+    import cbim_amd
+    from cbim_amd.model.dim3 import VNet
+    from cbim_amd.training.losses import DiceCELoss
+    from cbim_amd.training.optim import FusedAdamW
+    torch.manual_seed(5)
+    net = VNet(1, 4, scale=[[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], baseChans=16).to(dev).train()
+    w = torch.tensor([0.5, 1, 1, 1.0], device=dev)
+    crit = DiceCELoss(w).to(dev)
+    opt = FusedAdamW(net.parameters(), lr=1e-3, weight_decay=0.05)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 1, 16, 192, 192, generator=g).to(dev)
+    lab = (torch.rand(2, 1, 2, 24, 24, generator=g) * 4).long().float()
+    lab = torch.nn.functional.interpolate(lab, size=(16, 192, 192), mode="nearest").long().to(dev)
+    cbim_amd.set_compute_dtype("bf16")
+    try:
+        losses = []
+        for _ in range(4):
+            opt.zero_grad(set_to_none=True)
+            loss = crit(net(x), lab)
+            loss.backward()
+            assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+            opt.step()
+            losses.append(float(loss))
+    finally:
+        cbim_amd.set_compute_dtype(None)
+    print(losses)
+    assert losses[-1] < losses[0], losses
