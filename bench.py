@@ -297,6 +297,10 @@ def main():
     eager_step = step
     for _ in range(args.warmup):
         step()
+    # gradient tensors per step that their kernel wrote straight into the all-reduce bucket / that were copied into it
+    grad_bucket = None
+    if ddp is not None and args.warmup > 0:
+        grad_bucket = {"written_in_place": ddp.direct_writes // args.warmup, "copied": ddp.copies // args.warmup}
     if use_graph:
         # launch-bound inner loop -> one hipGraph: every kernel of fwd+loss+bwd+AdamW is captured once
         # (all launches go to the capturing stream; buffers come from the graph's private pool).
@@ -365,6 +369,8 @@ def main():
                    "global_batch": world, "parallelism": f"dp{world}", "graph": bool(use_graph),
                    "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0, "final_loss": loss_val},
     }
+    if grad_bucket is not None:
+        out["config"]["grad_bucket"] = grad_bucket
 
     # ---- roofline of the dominant kernel: every launch of the conv kernels in one step, HIP events on the launch stream
     if not args.no_roofline and rank == 0:

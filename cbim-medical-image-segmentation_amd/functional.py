@@ -102,13 +102,13 @@ class StemFn(torch.autograd.Function):
         pad = tuple(int(i) // 2 for i in w.shape[2:])
         y = ops.stem_fwd(x, wd, pad, out_dtype)
         ctx.save_for_backward(x)
-        ctx.w_shape, ctx.pad = tuple(w.shape), pad
+        ctx.w_shape, ctx.pad, ctx.w_param = tuple(w.shape), pad, ops.slot_of(w)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        dw = ops.stem_wgrad(x, dy.contiguous(), ctx.w_shape, ctx.pad)
+        dw = ops.stem_wgrad(x, dy.contiguous(), ctx.w_shape, ctx.pad, out=ops.grad_slot(ctx.w_param))
         return None, dw, None
 
 
@@ -171,6 +171,7 @@ def _bb_fwd(ctx, xshape, xin, sin, ident, w1, w2, wsc, act, want_out_stats, mat,
     yin, s1in = (ops.norm_act_fwd(y1, s1, act), None) if mat else (y1, s1)
     out, so = ops.conv_fwd(yin, wp2, g2, in_stats=s1in, res=res, want_stats=want_out_stats)
     ctx.packed = (wd1, wd2, wdsc)
+    ctx.w_params = (ops.slot_of(w1), ops.slot_of(w2), ops.slot_of(wsc))
     ctx.geoms = (g1, g2, gsc, gc)
     ctx.act, ctx.mat = act, mat
     if so is None:
@@ -187,20 +188,22 @@ def _bb_bwd(ctx, dout, cx, cxs, mxs, y1, s1, cy, cys, mys, w1):
     g1, g2, gsc, gc = ctx.geoms
     wd1, wd2, wdsc = ctx.packed
     act = ctx.act
-    dw2 = ops.conv_wgrad(cy, cys, dout, g2)
+    p1, p2, psc = ctx.w_params
+    dw2 = ops.conv_wgrad(cy, cys, dout, g2, out=ops.grad_slot(p2))
     gy1, sums2 = ops.conv_dgrad(dout, wd2, g2, mask_x=cy, mask_stats=mys)
     dy1 = ops.norm_bwd_apply(gy1, y1, s1, sums2, act, masked=False)
     if gc is not None:
         # conv1 + shortcut as one GEMM: dy = [dy1 | dout]
         cout = int(w1.shape[0])
-        dwcat = ops.conv_wgrad(cx, cxs, dy1, gc, dy2=dout)
-        dw1, dwsc = dwcat[:cout], dwcat[cout:]
+        pair = ops.grad_slot_pair(p1, psc)
+        dwcat = ops.conv_wgrad(cx, cxs, dy1, gc, dy2=dout, out=None if pair is None else pair[0])
+        dw1, dwsc = (dwcat[:cout], dwcat[cout:]) if pair is None else pair[1:]
         gx, sums1 = ops.conv_dgrad(dy1, wd1, gc, mask_x=cx, mask_stats=mxs, dy2=dout)
         return gx, sums1, dw1, dw2, dwsc
     # conv1 (+ shortcut conv share act(IN(x)))
-    dw1 = ops.conv_wgrad(cx, cxs, dy1, g1)
+    dw1 = ops.conv_wgrad(cx, cxs, dy1, g1, out=ops.grad_slot(p1))
     if gsc is not None:
-        dwsc = ops.conv_wgrad(cx, cxs, dout, gsc)
+        dwsc = ops.conv_wgrad(cx, cxs, dout, gsc, out=ops.grad_slot(psc))
         gx_u, _ = ops.conv_dgrad(dy1, wd1, g1)
         gx, sums1 = ops.conv_dgrad(dout, wdsc, gsc, mask_x=cx, mask_stats=mxs, accumulate=gx_u)
     else:
@@ -290,7 +293,7 @@ class SingleConvFn(_GradAwareFunction):
         ctx.wpd = wpd
         y = ops.norm_act_fwd(z, sz, act)
         ctx.save_for_backward(x, z, sz, w)
-        ctx.geom, ctx.act, ctx.need_dx = g, act, need_dx
+        ctx.geom, ctx.act, ctx.need_dx, ctx.w_param = g, act, need_dx, ops.slot_of(w)
         return y
 
     @staticmethod
@@ -300,7 +303,7 @@ class SingleConvFn(_GradAwareFunction):
         dy = dy.contiguous()
         sums = ops.norm_bwd_sums(dy, z, sz, act, masked=True)
         dz = ops.norm_bwd_apply(dy, z, sz, sums, act, masked=True)
-        dw = ops.conv_wgrad(x, None, dz, g)
+        dw = ops.conv_wgrad(x, None, dz, g, out=ops.grad_slot(ctx.w_param))
         dx = None
         if ctx.need_dx:
             dx, _ = ops.conv_dgrad(dz, ctx.wpd, g)
@@ -349,14 +352,16 @@ class HeadFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         w2d = w.detach().reshape(w.shape[0], w.shape[1]).contiguous()
         ctx.save_for_backward(x, w2d)
-        ctx.w_shape = tuple(w.shape)
+        ctx.w_shape, ctx.w_param, ctx.b_param = tuple(w.shape), ops.slot_of(w), ops.slot_of(b)
         return ops.head_fwd(x, w2d, b.detach().contiguous())
 
     @staticmethod
     def backward(ctx, dlogits):
         x, w2d = ctx.saved_tensors
-        dx, dw, db = ops.head_bwd(x, w2d, dlogits.contiguous().float(), need_dx=ctx.needs_input_grad[0])
-        return dx, dw.reshape(ctx.w_shape), db
+        sw = ops.grad_slot(ctx.w_param)
+        dx, dw, db = ops.head_bwd(x, w2d, dlogits.contiguous().float(), need_dx=ctx.needs_input_grad[0],
+                                  out_w=None if sw is None else sw.view(w2d.shape), out_b=ops.grad_slot(ctx.b_param))
+        return dx, (sw if sw is not None else dw.reshape(ctx.w_shape)), db
 
 
 class DiceCEFn(torch.autograd.Function):
@@ -418,6 +423,7 @@ class NormConvFn(_GradAwareFunction):
         y, so = ops.conv_fwd(x, wp, g, in_stats=st, res=res, want_stats=want_stats, eps=eps_out)
         ctx.save_for_backward(x, st if st is not None else torch.empty(0), se if se is not None else torch.empty(0))
         ctx.geom, ctx.act, ctx.wpd, ctx.has = g, act, wpd, (stats is not None, res is not None, se is not None)
+        ctx.w_param = ops.slot_of(w)
         if so is None:
             so = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(so)
@@ -430,7 +436,7 @@ class NormConvFn(_GradAwareFunction):
         has_stats, has_res, has_se = ctx.has
         g, act = ctx.geom, ctx.act
         dy = dy.contiguous()
-        dw = ops.conv_wgrad(x, st if has_stats else None, dy, g) if ctx.needs_input_grad[2] else None
+        dw = ops.conv_wgrad(x, st if has_stats else None, dy, g, out=ops.grad_slot(ctx.w_param)) if ctx.needs_input_grad[2] else None
         dx = ds = None
         if ctx.needs_input_grad[0]:
             if has_stats:

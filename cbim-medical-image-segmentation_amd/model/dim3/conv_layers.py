@@ -70,6 +70,11 @@ class BasicBlock(nn.Module):
         if in_ch != out_ch:   # a FULL k-sized pre-act ConvNormAct, not 1x1 (conv_layers.py:83-84)
             self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=True)
 
+    def cbim_grad_pairs(self):
+        """(conv1, shortcut) weights: BasicBlockFn computes their gradients as ONE Cout-concatenated weight gradient —
+        parallel.GradAllReduce lays their bucket slots out back to back so that the kernel writes both in place"""
+        return [(self.conv1.conv.weight, self.shortcut.conv.weight)] if isinstance(self.shortcut, ConvNormAct) else []
+
     def forward_input(self, x, dtype, want_out_stats=True) -> Fn.FMap:
         """First layer of a network (UNet++ conv0_0): x is the NCDHW fp32 input.  The pre-activation
         act(IN(x)) of the in_ch-channel input (2 M values at 128^3) is two torch elementwise ops; conv1 and the

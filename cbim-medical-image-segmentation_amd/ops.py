@@ -617,14 +617,39 @@ def conv_dgrad(dy, w_packed_dgrad, geom: ConvGeom, mask_x=None, mask_stats=None,
     return g, sums
 
 
-def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None, x2=None) -> torch.Tensor:
+def slot_of(param):
+    """forward side: the gradient-slot handle a data-parallel wrapper attached to `param` (parallel.GradAllReduce), or None"""
+    return getattr(param, "_cbim_grad_slot", None) if param is not None else None
+
+
+def grad_slot(handle):
+    """backward side: the slot of the wrapper's flat gradient bucket behind `handle`, claimed for the running backward pass: a
+    weight-gradient kernel given this tensor as `out` writes the gradient where the collective reads it — no copy into the
+    bucket.  None: no wrapper, the slot was already written in this pass (shared weight), or the parameter holds an
+    accumulated gradient."""
+    return None if handle is None else handle.claim()
+
+
+def grad_slot_pair(h1, h2):
+    """the slots behind two handles as one Cout-concatenated tensor (parallel._GradSlot.claim_with) -> (cat, alias1, alias2) or None"""
+    return None if h1 is None or h2 is None else h1.claim_with(h2)
+
+
+def _dw_out(out, shape, device):
+    if out is None:
+        return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(shape), "cbim_amd: bad gradient slot"
+    return out
+
+
+def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None, x2=None, out=None) -> torch.Tensor:
     """dy2: gradient of the output channels >= dy.shape[-1] (Cout-concatenated convs); x2: the input channels
-    >= x.shape[-1] (virtual concatenation, raw bf16 3x3x3 inputs only)."""
+    >= x.shape[-1] (virtual concatenation, raw bf16 3x3x3 inputs only); out: where to write (ops.grad_slot)."""
     _dev_ok(x, in_stats, dy, dy2, x2)
     L = _lib.lib()
     nbytes = L.cbim_conv3d_wgrad_workspace(C.byref(geom.fwd))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-    dw = torch.empty((geom.Cout, geom.Cin) + geom.k, dtype=torch.float32, device=x.device)
+    dw = _dw_out(out, (geom.Cout, geom.Cin) + geom.k, x.device)
     prof = PROFILE is not None and x.device.type == "cuda"
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -662,7 +687,7 @@ def stem_fwd(x_ncdhw: torch.Tensor, w: torch.Tensor, pad, out_dtype: torch.dtype
     return y
 
 
-def stem_wgrad(x_ncdhw, dy, w_shape, pad):
+def stem_wgrad(x_ncdhw, dy, w_shape, pad, out=None):
     _dev_ok(x_ncdhw, dy)
     N, Cin, Di, Hi, Wi = map(int, x_ncdhw.shape)
     Cout, _, kD, kH, kW = map(int, w_shape)
@@ -671,7 +696,7 @@ def stem_wgrad(x_ncdhw, dy, w_shape, pad):
     L = _lib.lib()
     nbytes = L.cbim_stem_conv_wgrad_workspace(N, Cin, Cout, kD, kH, kW, Do, Ho, Wo)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dy.device)
-    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=dy.device)
+    dw = _dw_out(out, w_shape, dy.device)
     check(L.cbim_stem_conv_wgrad(_dt(dy), _p(x_ncdhw), _p(dy), _p(dw), N, Cin, Di, Hi, Wi, Cout, kD, kH, kW,
                                  pD, pH, pW, Do, Ho, Wo, _p(ws), nbytes, _stream(dy)), "stem_conv_wgrad")
     return dw
@@ -688,7 +713,7 @@ def head_fwd(x, w2d, b):
     return logits
 
 
-def head_bwd(x, w2d, dlogits, need_dx=True):
+def head_bwd(x, w2d, dlogits, need_dx=True, out_w=None, out_b=None):
     _dev_ok(x, w2d, dlogits)
     N, D, H, W, Cin = map(int, x.shape)
     K = int(w2d.shape[0])
@@ -697,8 +722,8 @@ def head_bwd(x, w2d, dlogits, need_dx=True):
     nbytes = L.cbim_head_bwd_workspace(S, N, Cin, K)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     dx = torch.empty_like(x) if need_dx else None
-    dw = torch.empty((K, Cin), dtype=torch.float32, device=x.device)
-    db = torch.empty((K,), dtype=torch.float32, device=x.device)
+    dw = _dw_out(out_w, (K, Cin), x.device)
+    db = _dw_out(out_b, (K,), x.device)
     check(L.cbim_head_bwd(_dt(x), _p(x), _p(w2d), _p(dlogits), _p(dx), _p(dw), _p(db), N, S, Cin, K, _p(ws), nbytes,
                           _stream(x)), "head_bwd")
     return dx, dw, db

@@ -6,8 +6,9 @@ The reference's only parallelism is ``torch.nn.parallel.DistributedDataParallel`
 ``find_unused_parameters=True``).  The models here have no unused parameters, so
 the exchange is static: parameters are grouped into fixed buckets in REVERSE registration order
 (the order the backward produces them: decoder first); every bucket owns ONE flat fp32 buffer and
-``param.grad`` IS a view into it: a gradient that arrives from autograd is copied once into its slot
-(no ``torch.cat``, no copy back), and when the last gradient of a bucket has landed the flat buffer
+``param.grad`` IS a view into it: the engine's weight-gradient kernels write their result straight into the slot
+(``ops.grad_slot``: no copy at all — all conv / stem / head weights of the UNet family), any other gradient that arrives from
+autograd is copied once into its slot (no ``torch.cat``, no copy back), and when the last gradient of a bucket has landed the flat buffer
 is all-reduced IN PLACE, asynchronously, on the process group's own stream while the backward of
 the earlier layers keeps the compute stream busy.  The optimizer then reads the averaged
 gradients straight from the views.  ``backend="nccl"`` is RCCL on ROCm; the same code runs on
@@ -40,6 +41,41 @@ class _Bucket:
         self.flat = None
         self.work = None
         self.fired = False
+
+
+class _GradSlot:
+    """Handle attached to a parameter (`param._cbim_grad_slot`): lets the engine's weight-gradient kernels write straight into
+    the parameter's slot of the flat bucket (ops.slot_of / ops.grad_slot)."""
+    __slots__ = ("owner", "param", "view", "flat", "off", "__weakref__")
+
+    def __init__(self, owner, param, view, flat, off):
+        self.owner, self.param, self.view, self.flat, self.off = owner, param, view, flat, off
+
+    def _free(self):
+        o = self.owner
+        return o._direct and self.param.grad is None and self.param not in o._claimed
+
+    def claim(self):
+        if not self._free():
+            return None                       # accumulated gradient present / slot already written in this pass
+        self.owner._claimed.add(self.param)
+        self.owner.direct_writes += 1
+        return self.view.detach()             # a fresh alias: autograd adopts it as param.grad without a copy
+
+    def claim_with(self, other):
+        """Both slots as ONE tensor [rows(self) + rows(other), ...] when `other` lies directly behind `self` in the same flat
+        buffer (GradAllReduce lays out the pairs a module names in `cbim_grad_pairs()` that way): the Cout-concatenated
+        weight gradient of conv1 | shortcut is then written in place.  -> (cat, alias_self, alias_other) or None."""
+        n = self.param.numel()
+        if (other is None or other.owner is not self.owner or other.flat is not self.flat or other.off != self.off + n
+                or tuple(other.param.shape[1:]) != tuple(self.param.shape[1:]) or not self._free() or not other._free()):
+            return None
+        o = self.owner
+        o._claimed.update((self.param, other.param))
+        o.direct_writes += 2
+        rows = int(self.param.shape[0]) + int(other.param.shape[0])
+        cat = self.flat[self.off:self.off + n + other.param.numel()].view((rows,) + tuple(self.param.shape[1:]))
+        return cat, self.view.detach(), other.view.detach()
 
 
 class GradAllReduce:
@@ -77,17 +113,30 @@ class GradAllReduce:
                 with torch.no_grad():
                     dist.broadcast(t.detach(), src=0, group=process_group)
         cap = int(bucket_mb * 1024 * 1024 / 4)
+        # parameter pairs whose gradients one kernel writes as a single tensor (conv1 | shortcut of a BasicBlock): the second
+        # is laid out directly behind the first
+        follower, paired = {}, set()                     # (Parameters hash by identity)
+        for m in module.modules():
+            for a, b in (m.cbim_grad_pairs() if hasattr(m, "cbim_grad_pairs") else ()):
+                if a.requires_grad and b.requires_grad and a.numel() % 4 == 0 and a not in paired and b not in paired:
+                    follower[a] = b
+                    paired.update((a, b))
+        second = set(follower.values())
         self.buckets: List[_Bucket] = []
         cur = _Bucket()
         for p in reversed(params):
-            if p.dtype != torch.float32:
+            if p in second:
+                continue
+            group = [p, follower[p]] if p in follower else [p]
+            if any(q.dtype != torch.float32 for q in group):
                 raise TypeError("cbim_amd: GradAllReduce expects float32 master parameters")
-            if cur.params and cur.numel + p.numel() > cap:
+            if cur.params and cur.numel + sum(q.numel() for q in group) > cap:
                 self.buckets.append(cur)
                 cur = _Bucket()
-            cur.params.append(p)
-            cur.offsets.append(cur.numel)
-            cur.numel += (p.numel() + 3) // 4 * 4          # 16-byte aligned slots
+            for q in group:
+                cur.params.append(q)
+                cur.offsets.append(cur.numel)
+                cur.numel += (q.numel() + 3) // 4 * 4      # 16-byte aligned slots
         if cur.params:
             self.buckets.append(cur)
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
@@ -95,6 +144,10 @@ class GradAllReduce:
         self._owner = {}
         self._views = {}
         self._handles = []
+        self._direct = True          # weight-gradient kernels may write into the bucket slots (False: always copy)
+        self._claimed = set()
+        self.direct_writes = 0       # counters (tests, diagnostics): gradients written in place / copied into their slot
+        self.copies = 0
         for b in self.buckets:
             dev = b.params[0].device
             b.flat = torch.zeros((b.numel,), dtype=torch.float32, device=dev)
@@ -102,6 +155,7 @@ class GradAllReduce:
             for p, off in zip(b.params, b.offsets):
                 self._owner[p] = b
                 self._views[p] = b.flat[off:off + p.numel()].view_as(p)
+                p._cbim_grad_slot = _GradSlot(self, p, self._views[p], b.flat, off)
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     # -- hooks ------------------------------------------------------------------------------------------
@@ -109,8 +163,11 @@ class GradAllReduce:
         b = self._owner[p]
         view = self._views[p]
         g = p.grad
-        if g is not view:                       # fresh tensor from autograd (grad was None): move it into its slot
-            view.copy_(g)                       # (a None grad means nothing was accumulated for p so far in this step)
+        if g is not view:
+            if g.data_ptr() != view.data_ptr():  # fresh tensor from autograd (grad was None): move it into its slot
+                view.copy_(g)                    # (a None grad means nothing was accumulated for p so far in this step)
+                self.copies += 1
+            # else: the weight-gradient kernel wrote the slot itself (_GradSlot.claim) and autograd adopted the alias
             p.grad = view
         # else: autograd accumulated in place into the view (grad was already the view)
         if not self._sync:
@@ -156,8 +213,12 @@ class GradAllReduce:
                     b.flat.div_(self.world)
             b.fired = False
             b.pending = len(b.params)
+        self._claimed.clear()
 
     def remove(self):
         for h in self._handles:
             h.remove()
         self._handles = []
+        for p in self._owner:
+            if getattr(p, "_cbim_grad_slot", None) is not None and p._cbim_grad_slot.owner is self:
+                del p._cbim_grad_slot

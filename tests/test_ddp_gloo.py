@@ -186,10 +186,15 @@ def _worker_engine(rank, world, port, q):
     crit = DiceCELoss(torch.tensor([0.5, 1.0, 1.0]))
     x, lab = _engine_data(rank)
     grads = None
+    n_params = len(list(net.parameters()))
     for it in range(2):
         opt.zero_grad(set_to_none=True)
+        c0, d0 = ddp.copies, ddp.direct_writes
         crit(net(x), lab).backward()
         ddp.synchronize()
+        # every gradient of this model (conv / stem / head weights, head bias) is written by its kernel straight into the
+        # bucket slot: no copy into the flat buffer on any step
+        assert ddp.copies - c0 == 0 and ddp.direct_writes - d0 == n_params, (ddp.copies - c0, ddp.direct_writes - d0, n_params)
         if it == 0:
             grads = [p.grad.clone().numpy() for p in net.parameters()]
             # param.grad IS a view of the bucket's flat buffer: no copy back after the exchange

@@ -30,6 +30,9 @@ def test_one_rank_rccl_step_is_graph_capturable_and_matches_eager():
     assert "hipGraph replay" in g["config"]["workload"], err_g[-2000:]     # the capture did not fall back to eager
     assert "hipGraph replay" not in e["config"]["workload"]
     assert g["n_gpus"] == 1 and g["config"]["rccl_ranks"] == 1
+    # all 45 gradients of the ResUNet (conv / stem / head weights, head bias; conv1 | shortcut pairs as one tensor) are written
+    # by their kernels straight into the all-reduce buckets: nothing is copied
+    assert g["config"]["grad_bucket"] == {"written_in_place": 45, "copied": 0}, g["config"]
     # same data, seeds and step count; every reduction in the engine has a fixed order, so replayed and eager launches
     # of the same kernels give the same loss
     import math
