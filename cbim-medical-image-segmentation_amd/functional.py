@@ -15,6 +15,7 @@ Fusion map (reference: /root/reference/model/dim3/conv_layers.py):
 from __future__ import annotations
 
 import os
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -80,16 +81,16 @@ class _GradAwareFunction(torch.autograd.Function):
     """autograd.Function whose forward can tell whether the CALLER ran under torch.no_grad() (inside forward() grad mode
     is always off, and ctx.needs_input_grad only mirrors the inputs' requires_grad flags): sliding-window inference and
     validation must not pack the dgrad weight layouts they never use."""
-    _caller_grad = True
+    _tls = threading.local()             # per thread: a validating thread under no_grad must not flip a training thread's flag
 
     @classmethod
     def apply(cls, *args):
-        _GradAwareFunction._caller_grad = torch.is_grad_enabled()
+        _GradAwareFunction._tls.caller_grad = torch.is_grad_enabled()
         return super().apply(*args)
 
 
 def _training(ctx) -> bool:
-    return _GradAwareFunction._caller_grad and any(ctx.needs_input_grad)
+    return getattr(_GradAwareFunction._tls, "caller_grad", True) and any(ctx.needs_input_grad)
 
 
 class StemFn(torch.autograd.Function):
@@ -597,7 +598,7 @@ class LayerNormFn(torch.autograd.Function):
         b = bias.detach().float().contiguous() if bias is not None else None
         y, rs = ops.layernorm_fwd(x, w, b, eps, out_dtype)
         ctx.save_for_backward(x, w if w is not None else torch.empty(0), rs)
-        ctx.has_w = w is not None
+        ctx.has_w, ctx.has_b = w is not None, b is not None
         return y
 
     @staticmethod
@@ -606,8 +607,10 @@ class LayerNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype not in (torch.float32, torch.bfloat16):
             dy = dy.float()
-        dx, dg, db = ops.layernorm_bwd(dy, x, w if ctx.has_w else None, rs, ctx.has_w)
-        return dx, dg, db, None, None
+        # weight and bias are independent (nn.LayerNorm(bias=False), or a bias-only affine): the column sums are computed
+        # when either is present, each gradient is returned only for the parameter that was given
+        dx, dg, db = ops.layernorm_bwd(dy, x, w if ctx.has_w else None, rs, ctx.has_w or ctx.has_b)
+        return dx, (dg if ctx.has_w else None), (db if ctx.has_b else None), None, None
 
 
 def layer_norm(x, weight, bias, eps, out_dtype=torch.float32):
