@@ -668,6 +668,21 @@ class NormActFn(torch.autograd.Function):
         return ops.norm_bwd_apply(dy, z, stats, sums, ctx.act, masked=True), None, None
 
 
+class BiasAddFn(torch.autograd.Function):
+    """x + bias over the channel axis of a channels-last tensor (a Conv3d / ConvTranspose3d bias applied after the GEMM:
+    /root/reference/model/dim3/vnet.py:40,80,100).  The bias gradient is the fixed-order column sum of the engine
+    (`k_colsum_partial` + finish), not an ATen reduction."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        return x + bias.detach().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = ops.colsum(dy.contiguous().reshape(-1, int(dy.shape[-1]))) if ctx.needs_input_grad[1] else None
+        return dy, db
+
+
 class ActFn(torch.autograd.Function):
     """y = act(x) as one streaming pass (the norm + activation kernel with identity statistics) — VNet's ELU after a
     residual add (/root/reference/model/dim3/vnet.py:73,95,119)."""
@@ -713,8 +728,9 @@ class BatchNormActFn(torch.autograd.Function):
                 running_mean.mul_(1.0 - momentum).add_(mean_b.to(running_mean.dtype), alpha=momentum)
                 running_var.mul_(1.0 - momentum).add_((var_b * (n / max(n - 1.0, 1.0))).to(running_var.dtype), alpha=momentum)
         g64, b64 = weight.detach().double(), bias.detach().double()
-        if bool((g64.abs() < 1e-20).any()):
-            raise NotImplementedError("cbim_amd: BatchNorm weight of exactly zero (the affine fold divides by gamma)")
+        # the affine fold divides by gamma: a weight of (numerically) zero is taken as +-1e-20 — z = beta to fp32 rounding, and
+        # no host synchronisation on the value (the step stays capturable in a hipGraph)
+        g64 = torch.where(g64.abs() < 1e-20, torch.where(g64 < 0, -1e-20, 1e-20).to(g64.dtype), g64)
         rstd_f = g64 * rstd_b
         mean_f = mean_b - b64 / rstd_f
         stats_f = torch.stack([mean_f, rstd_f], -1).float().unsqueeze(0).expand(N, C, 2).contiguous()
@@ -787,7 +803,7 @@ class ConvSlicesFn(torch.autograd.Function):
                     ops.conv_igemm(geom.bwd, dys, wpd, tuple(dxs.shape), res=dxs, out=dxs)
                 if dw is not None:
                     dw[:, :, kd:kd + 1] += ops.conv_wgrad(xs, None, dys, geom)
-        db = dy.float().sum((0, 1, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = ops.colsum(dy.reshape(-1, int(dy.shape[-1]))) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 

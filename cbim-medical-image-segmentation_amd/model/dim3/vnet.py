@@ -7,8 +7,8 @@ statistics ALWAYS, vnet.py:22-33) + ELU on the InstanceNorm streaming kernels wi
 (`BatchNormActFn`), the ELU after the residual adds as one streaming pass (`ActFn`).  Residual adds, bias adds, the channel
 concatenation and the Dropout3d channel mask (drawn with torch's RNG exactly as `F.dropout3d` draws it: one Bernoulli value per
 (sample, channel), vnet.py:83-84,105-110 — active in training mode only) are elementwise ATen ops.  The 4-class tail of the
-output transition (BatchNorm + ELU + 1x1x1 conv on `classes` channels, vnet.py:128-138) is below the 16-byte channel chunk of
-the kernels and runs as plain torch ops on the NCDHW float32 logits planes.  ELU only (`elu=True`, what `get_model` builds);
+output transition (BatchNorm + ELU + 1x1x1 conv on `classes` channels, vnet.py:128-138) runs on the same kernels with the
+channels zero-padded to one 16-byte chunk; the 1x1x1 convolution is the head kernel, which writes the NCDHW float32 logits.  ELU only (`elu=True`, what `get_model` builds);
 PReLU raises.
 """
 import torch
@@ -82,7 +82,7 @@ class InputTransition(nn.Module):
 
     def forward(self, x, dtype):
         t = Fn.StemFn.apply(x, self.conv1.weight, dtype)               # NCDHW fp32 -> channels-last
-        t = t + self.conv1.bias.to(t.dtype)
+        t = Fn.BiasAddFn.apply(t, self.conv1.bias)
         out = self.bn1(t, 0)
         num = int(self.outChans / self.inChans)
         x16 = x.permute(0, 2, 3, 4, 1).repeat(1, 1, 1, 1, num).to(out.dtype)   # x.repeat(1, num, 1, 1, 1), channels-last
@@ -106,7 +106,7 @@ class DownTransition(nn.Module):
         w_eq = w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1, 1, 1, 1)   # channel order of k_space_to_depth: ((i sH + j) sW + k) C + c
         m = Fn.SpaceToDepthFn.apply(t, tuple(self.scale))
         d, _ = Fn.NormConvFn.apply(m, None, w_eq, 0, None, False, None, 1e-5)
-        d = d + self.down_conv.bias.to(d.dtype)
+        d = Fn.BiasAddFn.apply(d, self.down_conv.bias)
         down = self.bn1(d, _ELU)
         out = _drop(down, self.do1.p, self.training) if self.do1 is not None else down
         for m_ in self.ops:
@@ -134,7 +134,7 @@ class UpTransition(nn.Module):
         w_eq = w.permute(2, 3, 4, 1, 0).reshape(-1, w.shape[0], 1, 1, 1)   # rows ((i sH + j) sW + k) Cout + co
         u, _ = Fn.NormConvFn.apply(out, None, w_eq, 0, None, False, None, 1e-5)
         u = Fn.DepthToSpaceFn.apply(u, tuple(self.scale))
-        u = u + self.up_conv.bias.to(u.dtype)
+        u = Fn.BiasAddFn.apply(u, self.up_conv.bias)
         assert int(u.shape[-1]) == cout
         u = self.bn1(u, _ELU)
         xcat = torch.cat((u, skipdo), -1)
@@ -154,19 +154,32 @@ class OutputTransition(nn.Module):
 
     def forward(self, t):
         # the 5x5x5 convolution down to `classes` channels runs on the kernels with the output channels padded to a whole
-        # 16-byte chunk (zero weight rows); BatchNorm + ELU + the 1x1x1 conv on those few planes are torch ops in NCDHW fp32
+        # 16-byte chunk (zero weight rows / bias: the padded channels are exactly 0 through BatchNorm [gamma 1, beta 0] and
+        # ELU); BatchNorm + ELU on the norm kernels, the 1x1x1 convolution on the head kernel (zero weight columns for the
+        # padding), which writes the NCDHW float32 logits.  (torch's conv3d on these 4-channel NCDHW planes would run MIOpen's
+        # fallback weight-gradient kernel: 176 ms per step at the ACDC crop.)
         w, b = self.conv1.weight, self.conv1.bias
         cout = int(w.shape[0])
         cpc = 8 if t.dtype == torch.bfloat16 else 4
         pad = (-cout) % cpc
+        bn = self.bn1
+        gamma, beta, rm, rv = bn.weight, bn.bias, bn.running_mean, bn.running_var
+        w2 = self.conv2.weight
         if pad:
             w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
             b = torch.cat([b, b.new_zeros(pad)], 0)
-        y = Fn.ConvSlicesFn.apply(t, w, b)[..., :cout].float().permute(0, 4, 1, 2, 3)
-        y = F.batch_norm(y, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight, self.bn1.bias, True,
-                         0.1 if self.bn1.momentum is None else self.bn1.momentum, self.bn1.eps)
-        y = F.elu(y)
-        return F.conv3d(y, self.conv2.weight, self.conv2.bias).contiguous()
+            gamma = torch.cat([gamma, gamma.new_ones(pad)], 0)
+            beta = torch.cat([beta, beta.new_zeros(pad)], 0)
+            rm = torch.cat([rm, rm.new_zeros(pad)], 0)
+            rv = torch.cat([rv, rv.new_ones(pad)], 0)
+            w2 = torch.cat([w2, w2.new_zeros((int(w2.shape[0]), pad) + tuple(w2.shape[2:]))], 1)
+        y = Fn.ConvSlicesFn.apply(t, w, b)
+        y = Fn.BatchNormActFn.apply(y, gamma, beta, rm, rv, 0.1 if bn.momentum is None else bn.momentum, bn.eps, _ELU)
+        if pad:
+            with torch.no_grad():
+                bn.running_mean.copy_(rm[:cout])
+                bn.running_var.copy_(rv[:cout])
+        return Fn.HeadFn.apply(y, w2, self.conv2.bias)
 
 
 class VNet(nn.Module):
