@@ -77,6 +77,15 @@ def _geom(x: torch.Tensor, w: torch.Tensor, act: int) -> ConvGeom:
     return ConvGeom(x.dtype, int(x.shape[0]), tuple(x.shape[1:4]), int(w.shape[1]), int(w.shape[0]), k, pad, act)
 
 
+def eager_only(fn):
+    """Decorator of the model classes' forward: under the reference's optional `net = torch.compile(net)` wrapper
+    (/root/reference/train.py:292-293) TorchDynamo must not trace into the engine — its operators are ctypes calls into
+    libcbim_hip.so behind autograd Functions; the wrapped module then simply runs them eagerly (`net._orig_mod` is the engine
+    module, train.py:106)."""
+    dis = getattr(getattr(torch, "compiler", None), "disable", None)
+    return dis(fn) if dis is not None else fn
+
+
 class _GradAwareFunction(torch.autograd.Function):
     """autograd.Function whose forward can tell whether the CALLER ran under torch.no_grad() (inside forward() grad mode
     is always off, and ctx.needs_input_grad only mirrors the inputs' requires_grad flags): sliding-window inference and

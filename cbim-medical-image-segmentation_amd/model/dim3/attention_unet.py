@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ... import functional as Fn
+from ...functional import eager_only
 from ...ops import ACT
 from .conv_layers import BasicBlock
 from .unet_utils import down_block, inconv
@@ -82,6 +83,7 @@ class AttentionUNet(nn.Module):
         self.up4 = attention_up_block(2 * b, b, num_block=num_block, block=block, up_scale=scale[0], kernel_size=kernel_size[0], norm=norm)
         self.outc = nn.Conv3d(b, num_classes, kernel_size=1)
 
+    @eager_only
     def forward(self, x):
         dtype = Fn.compute_dtype()
         with torch.autocast(device_type=x.device.type, enabled=False):

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from ... import functional as Fn
+from ...functional import eager_only
 from .medformer_utils import SemanticMapFusion, down_block, inconv, up_block
 from .utils import get_act, get_block, get_norm
 
@@ -47,6 +48,7 @@ class MedFormer(nn.Module):
             self.aux_out = nn.Conv3d(c[5], num_classes, kernel_size=1)
         self.outc = nn.Conv3d(c[7], num_classes, kernel_size=1)
 
+    @eager_only
     def forward(self, x):
         dtype = Fn.compute_dtype()
         with torch.autocast(device_type=x.device.type, enabled=False):

@@ -23,6 +23,7 @@ import os
 import torch.nn.functional as F
 
 from ... import functional as Fn
+from ...functional import eager_only
 from ...ops import ACT
 
 from ...ops import colsum as ops_colsum
@@ -404,6 +405,7 @@ class SwinUNETR(nn.Module):
     def load_from(self, weights):
         raise NotImplementedError("cbim_amd: loading the external self-supervised Swin-ViT checkpoint is not built")
 
+    @eager_only
     def forward(self, x_in):
         dtype = Fn.compute_dtype()
         with torch.autocast(device_type=x_in.device.type, enabled=False):

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from ... import functional as Fn
+from ...functional import eager_only
 from .unet_utils import down_block, inconv, up_block
 from .utils import get_block, get_norm
 
@@ -37,6 +38,7 @@ class UNet(nn.Module):
                             kernel_size=kernel_size[0], norm=norm)
         self.outc = nn.Conv3d(b, num_classes, kernel_size=1)
 
+    @eager_only
     def forward(self, x):
         dtype = Fn.compute_dtype()
         with torch.autocast(device_type=x.device.type, enabled=False):

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from ... import functional as Fn
+from ...functional import eager_only
 from .utils import get_block, get_norm
 
 
@@ -60,6 +61,7 @@ class UNetPlusPlus(nn.Module):
         sk = skips[0].t if len(skips) == 1 else torch.cat([s.t for s in skips], dim=-1)
         return self._run(layer, Fn.FMap(*Fn.UpCatFn.apply(low.t, sk, True, True)))   # concat + statistics in one pass
 
+    @eager_only
     def forward(self, x):
         dtype = Fn.compute_dtype()
         with torch.autocast(device_type=x.device.type, enabled=False):

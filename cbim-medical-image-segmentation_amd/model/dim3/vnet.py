@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import functional as Fn
+from ...functional import eager_only
 from ...ops import ACT
 
 _ELU = ACT["elu"]
@@ -196,6 +197,7 @@ class VNet(nn.Module):
         self.up_tr32 = UpTransition(baseChans * 4, baseChans * 2, 1, elu, scale=scale[0])
         self.out_tr = OutputTransition(baseChans * 2, outChans, elu, nll)
 
+    @eager_only
     def forward(self, x):
         dtype = Fn.compute_dtype()
         with torch.autocast(device_type=x.device.type, enabled=False):

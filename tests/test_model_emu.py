@@ -200,3 +200,28 @@ def test_vnet_fp32_matches_reference_golden(dev):
     losses, running statistics and all 98 parameter gradients element by element"""
     from tests.vnet_checks import assert_fp32
     print(assert_fp32(dev))
+
+
+def test_torch_compile_wrapper_runs_the_engine_eagerly(dev):
+    """/root/reference/train.py:292-293 optionally wraps the model in torch.compile and unwraps `_orig_mod` when saving (:106):
+    the engine's forward is marked eager-only (its operators are ctypes calls into libcbim_hip.so), so the wrapper neither
+    fails nor changes a bit of the result, and the state_dict round-trips through `_orig_mod`."""
+    import cbim_amd
+    from cbim_amd.model.dim3 import UNet
+    cbim_amd.set_compute_dtype("fp32")
+    try:
+        torch.manual_seed(0)
+        net = UNet(1, 4, scale=[[1, 2, 2]] * 4, kernel_size=[[3, 3, 3]] * 5, num_classes=3, block="BasicBlock", norm="in").to(dev)
+        x = torch.randn(1, 1, 2, 16, 16, device=dev)
+        y0 = net(x)
+        y0.square().sum().backward()
+        g0 = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad(set_to_none=True)
+        cn = torch.compile(net)
+        y1 = cn(x)
+        assert torch.equal(y0, y1) and cn._orig_mod is net
+        y1.square().sum().backward()
+        assert all(torch.equal(p.grad, g) for p, g in zip(net.parameters(), g0))
+        assert [k.replace("_orig_mod.", "") for k in cn.state_dict()] == list(net.state_dict())
+    finally:
+        cbim_amd.set_compute_dtype(None)
