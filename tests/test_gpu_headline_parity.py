@@ -170,8 +170,8 @@ def test_headline_bf16_interior_kernels_match_torch_inside_the_model_at_128(dev)
             log["dgrad"].append((dy, dy2, mask_x, mask_stats, accumulate, geom, out[0]))
         return out
 
-    def wgrad(xx, in_stats, dy, geom, dy2=None, x2=None):
-        out = orig[2](xx, in_stats, dy, geom, dy2=dy2, x2=x2)
+    def wgrad(xx, in_stats, dy, geom, dy2=None, x2=None, out=None):
+        out = orig[2](xx, in_stats, dy, geom, dy2=dy2, x2=x2, out=out)
         if geom.in_dhw[0] == SIZE:
             log["wgrad"].append((xx, in_stats, dy, dy2, x2, geom, out))
         return out
