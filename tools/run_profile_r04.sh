@@ -27,12 +27,12 @@ for m in medformer swin_unetr; do
   python $R/tools/rocpd_summary.py /tmp/pf_$m/p_results.db 7 > $O/${T}_${m}_kernels.txt 2>&1
 done
 # HBM-side traffic per kernel family (separate --pmc passes; FETCH_SIZE x 2 on gfx950): "k_conv3_r" = k_conv3_r32 + k_conv3_rw
-PATS=("k_conv3_r" "k_wgrad_r32<" "k_conv_igemm<cbim::bf16_tag, 1, 2," "k_norm_bwd_apply<" "k_norm_act_fwd<" "k_up_tile<" "k_splitk_finish<")
+PATS=("false>(cbim::R32Params)" "k_wgrad_r32<" "k_conv_igemm<cbim::bf16_tag, 1, 2," "k_norm_bwd_apply<" "k_norm_act_fwd<" "k_up_tile<" "k_splitk_finish<")
 for m in resunet medformer swin_unetr; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/p_$c
     rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o f -- python $R/bench.py --model $m --steps 2 --warmup 1 --graph 0 --no-roofline --no-cpu-baseline > /dev/null 2>&1
-    for pat in "${PATS[@]}" "k_conv_igemm<cbim::bf16_tag, 2, 2," "k_conv_wgrad<" "k_dwconv3" "k_winattn"; do echo "== $c $pat"; python $R/tools/pmc_query.py /tmp/p_$c/f_results.db "$pat"; done
+    for pat in "${PATS[@]}" "true>(cbim::R32Params)" "k_conv_igemm<cbim::bf16_tag, 2, 2," "k_conv_wgrad<" "k_dwconv3" "k_winattn"; do echo "== $c $pat"; python $R/tools/pmc_query.py /tmp/p_$c/f_results.db "$pat"; done
   done > $O/${T}_pmc_hbm_$m.txt 2>&1
 done
 rm -rf /tmp/p_mfma
