@@ -15,3 +15,10 @@ def set_compute_dtype(dtype):
     bf16/fp16 autocast -> bf16, otherwise fp32."""
     from . import functional
     functional.set_compute_dtype(dtype)
+
+
+def release_graph_refs():
+    """After destroying the hipGraphs that captured training steps (before capturing again for another model / input shape):
+    free the packed-weight tables and buffers that were kept alive for their replays (ops.PackedWeights.release_graphs)."""
+    from . import ops
+    ops.PACKED.release_graphs()

@@ -29,6 +29,22 @@ _COMPUTE_DTYPE: Optional[torch.dtype] = None
 # are checked (a wrong class count in a config shows up at once); CBIM_CHECK_LABELS=1 checks every call, =0 none.
 _CHECK_LABELS = os.environ.get("CBIM_CHECK_LABELS", "first")
 _label_checks_left = 4
+_label_bad = {}          # device -> float32[1]: labels outside [0, C) seen by the loss calls that were not checked on the spot
+
+
+def check_labels(reset: bool = True) -> int:
+    """One device synchronisation for a whole epoch / validation pass: the number of out-of-range labels the loss has seen since
+    the last call (the calls after the first few are not checked one by one — reading the count would stall the stream every
+    step); raises IndexError like the reference's CrossEntropyLoss / scatter_ would have at the offending step."""
+    global _label_checks_left
+    bad = sum(int(t.item()) for t in _label_bad.values())
+    if reset:
+        for t in _label_bad.values():
+            t.zero_()
+        _label_checks_left = 4
+    if bad:
+        raise IndexError(f"cbim_amd: {bad} label(s) outside the class range since the last check (Target out of bounds)")
+    return bad
 
 
 def set_compute_dtype(dtype):
@@ -393,6 +409,11 @@ class DiceCEFn(torch.autograd.Function):
             bad = int(out[3].item())
             if bad:
                 raise IndexError(f"cbim_amd: {bad} label(s) outside [0, {int(logits.shape[1])}) (Target out of bounds)")
+        elif _CHECK_LABELS not in ("", "0") and not (logits.is_cuda and torch.cuda.is_current_stream_capturing()):
+            acc = _label_bad.get(logits.device)      # unchecked call: keep the count on the device (functional.check_labels)
+            if acc is None:
+                acc = _label_bad[logits.device] = torch.zeros(1, dtype=torch.float32, device=logits.device)
+            acc += out[3:4].detach()
         ctx.save_for_backward(logits, labels, coef, weight if weight is not None else torch.empty(0))
         ctx.has_w = weight is not None
         return out

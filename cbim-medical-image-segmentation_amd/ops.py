@@ -506,6 +506,14 @@ class PackedWeights:
     def clear(self):
         self.__init__()
 
+    def release_graphs(self):
+        """Call after DESTROYING the hipGraphs that captured table launches (e.g. before re-capturing for another model or input
+        shape): drops the tables and packed buffers kept alive for their replays and lets the pinned entries age out like any
+        other.  Replaying a graph captured before this call afterwards is undefined (its raw pointers may be gone)."""
+        self._graph_refs.clear()
+        for e in self.entries.values():
+            e.pinned = False
+
 
 PACKED = PackedWeights()
 _REPLAY_HOOKED = False

@@ -31,3 +31,9 @@ class DiceCELoss(nn.Module):
     def forward(self, logits, label):
         with torch.autocast(device_type=logits.device.type, enabled=False):
             return Fn.DiceCEFn.apply(logits, label, self.weight)[2]
+
+
+def check_labels(reset: bool = True) -> int:
+    """Call once per epoch / validation pass: raises IndexError if any label outside [0, classes) reached the loss since the last
+    call (the per-step check of the first calls is not repeated every step: it is a device synchronisation)."""
+    return Fn.check_labels(reset)

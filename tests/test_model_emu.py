@@ -225,3 +225,23 @@ def test_torch_compile_wrapper_runs_the_engine_eagerly(dev):
         assert [k.replace("_orig_mod.", "") for k in cn.state_dict()] == list(net.state_dict())
     finally:
         cbim_amd.set_compute_dtype(None)
+
+
+def test_label_range_is_checked_per_step_at_first_and_per_epoch_afterwards(dev):
+    """the reference raises 'Target out of bounds' at the offending step; reading the count is a device synchronisation, so the
+    engine checks the first calls on the spot and keeps a device-side count afterwards (training.losses.check_labels)"""
+    from cbim_amd.training.losses import DiceCELoss, check_labels
+    crit = DiceCELoss(torch.ones(3)).to(dev)
+    lo = torch.randn(1, 3, 4, 4, 4, device=dev)
+    lab = torch.randint(0, 3, (1, 1, 4, 4, 4), device=dev)
+    check_labels()                                # re-arms the per-step check
+    bad = lab.clone()
+    bad[0, 0, 0, 0, 0] = 7
+    with pytest.raises(IndexError):
+        crit(lo, bad)                             # among the first calls: raised at once
+    for _ in range(5):
+        crit(lo, lab)
+    crit(lo, bad)                                 # past the first calls: counted on the device
+    with pytest.raises(IndexError):
+        check_labels()
+    assert check_labels() == 0
