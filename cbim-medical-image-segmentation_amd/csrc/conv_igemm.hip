@@ -1106,6 +1106,7 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
     if (cbim_conv_r32_grid(d) > g) g = cbim_conv_r32_grid(d);
     if (cbim_conv_rw_grid(d) > g) g = cbim_conv_rw_grid(d);
   }
+  if (cbim_conv_pw_records(d) > g) g = cbim_conv_pw_records(d);   // pointwise layers: conv_pw.hip's strips
   return (int)g;
 }
 
@@ -1193,6 +1194,11 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   // wherever the mask is open) — defined for ReLU only
   CBIM_CHECK(!mask_x || mask_stats || d->act == CBIM_ACT_RELU, CBIM_EINVAL, "mask_x without mask_stats (an activated mask tensor) needs act = ReLU");
   g_last_conv_kernel = 0;
+  if (cbim_conv_pw_eligible(d, x_stride, x2, res_stride, mask_stride, y_stride, res, mask_x, mask_stats)) {   // 1x1x1: conv_pw.hip (round 4)
+    g_last_conv_kernel = 4;
+    return cbim_conv_pw_launch(d, x, x_stride, in_stats, w_packed, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials,
+                               cbim_conv3d_num_tiles(d), stream);
+  }
   if (cbim_conv_r32_eligible(d, x2, cin_split, in_stats, res, mask_x)) {  // channels in multiples of 32 at high resolution: weights in registers
     if (cbim_conv_rw_eligible(d, x, x_stride, x2, x2_stride, in_stats, mask_x, mask_stats)) {   // round 4: conv_rw.hip
       g_last_conv_kernel = 2;

@@ -1,0 +1,346 @@
+// conv_pw.hip — pointwise (1x1x1) convolutions as a row GEMM on the matrix cores (round 4).
+//
+//   y[r][co] = sum_ci  act(IN(x))[r][ci] * w[co][ci]   (+ residual)         forward  (conv_layers.py:48-49, 1x1x1 ConvNormAct:
+//                                                                           MBConv expand / project, shortcuts, the pointwise
+//                                                                           half of DepthwiseSeparableConv, MedFormer / SwinUNETR /
+//                                                                           VNet down- and up-sampling GEMMs)
+//   g[r][ci] = (sum_co dy[r][co] * w[co][ci]) * act'(IN(x))[r][ci]          its input gradient, with the two InstanceNorm-backward sums
+//
+// Why not k_conv_igemm: its pipeline hides the global round trip of the NEXT (tile, Cin chunk) unit behind the 54 MFMA steps of a
+// 3x3x3 unit; a 1x1x1 unit has two, so every unit waits the round trip out (3.5 us per unit, profiles/r04_x_igemm_floor.txt: 56 us
+// for 32^3 128->512 = 42 MB).  A pointwise layer is a streaming GEMM: what it needs is loads in flight, i.e. occupancy.
+//
+//   * no LDS staging of the operands at all: the A fragment of v_mfma_f32_32x32x16_bf16 for (row, k-group, lane half) IS 16
+//     contiguous bytes of the channels-last row (slot 2 kg + half of the 64-byte chunk: the fragment order conv_igemm.hip packs
+//     the weights for), the B fragment is 16 contiguous bytes of the packed weight image; both are plain global loads, the
+//     weights stay in L1 / L2 (HBM-bound layers ask < 10 % of the matrix rate);
+//   * InstanceNorm + activation of the producer are applied to the fragment in registers (statistics of the image in LDS);
+//   * 256-thread workgroups (4 waves x 32 rows x NTW*32 output channels), <= 128 registers: four workgroups per CU;
+//   * epilogue as in conv_igemm.hip: accumulators transposed through a private 4 KiB LDS tile per wave into 16-byte channel
+//     chunks; residual add, activated mask, shifted moments / backward sums; one statistics record per (image, strip of row
+//     tiles), fixed merge order.
+#include "cbim_common.h"
+#include "conv_r32.h"
+#include <stdlib.h>
+
+namespace cbim {
+
+static constexpr int PW_NT = 256, PW_NW = 4, PW_ROWS = 32 * PW_NW;
+
+struct PwParams {
+  const void* x; int64_t x_stride; const float* in_stats; const void* w;
+  const void* res; int64_t res_stride; const void* mx; int64_t mx_stride; const float* m_stats;
+  void* y; int64_t y_stride; float* partials;
+  int N; int64_t S; int Cin, Cout, act;
+  int nch;                 // 32-channel chunks of Cin
+  int BNp;                 // n-block width of the packed weight image (32 | 64)
+  int P, Pn;               // records per image of `partials` (allocated / written by this launch)
+  int tiles_per_n, tiles_per_strip, n_wblk;
+};
+
+#ifdef CBIM_EMU
+#define PW_DYN_SMEM(name) unsigned char* name = cbim_emu::dyn_smem()
+#else
+#define PW_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+__device__ __forceinline__ void pw_wave_sync() {
+#ifdef CBIM_EMU
+  int z = 0;
+  (void)cbim_emu::wave_exchange(&z, sizeof(z));
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+template <int ACT> __device__ __forceinline__ float pw_actf(float x, int rt) {
+  if (ACT == CBIM_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (ACT == CBIM_ACT_NONE) return x;
+  return act_fwd(x, rt);
+}
+template <int ACT> __device__ __forceinline__ float pw_actg(float x, int rt) {
+  if (ACT == CBIM_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (ACT == CBIM_ACT_NONE) return 1.f;
+  return act_grad(x, rt);
+}
+
+// grid.x = N * Pn * n_wblk (output-channel block fastest: the workgroups that share rows are neighbours in time)
+template <int NTW, int ACT>
+__global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
+  typedef bf16_tag T;
+  constexpr int CPC = 8, OCH = 4, IT = 2;
+  PW_DYN_SMEM(smem);
+  float* scr_all = (float*)smem;                                  // [4 waves][32 x 32] fp32
+  float* red = (float*)(smem + PW_NW * 4096);                     // [4 waves][NTW * 32][3]
+  float* stL = (float*)(smem + PW_NW * 4096 + PW_NW * NTW * 32 * 3 * 4);   // [Cin][2]: mean, rstd of image n
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
+  float* scr = scr_all + wave * 1024;
+  const unsigned b = blockIdx.x;
+  const int nbw = (int)(b % (unsigned)p.n_wblk);
+  const unsigned t_ = b / (unsigned)p.n_wblk;
+  const int strip = (int)(t_ % (unsigned)p.Pn), n = (int)(t_ / (unsigned)p.Pn);
+  const int co_base = nbw * NTW * 32;
+  if (p.in_stats) {
+    for (int i = tid; i < p.Cin * 2; i += PW_NT) stL[i] = p.in_stats[(size_t)n * p.Cin * 2 + i];
+  }
+  __syncthreads();
+  const unsigned char* const xn = (const unsigned char*)p.x + (size_t)n * p.S * p.x_stride * 2;
+  const unsigned char* const wb = (const unsigned char*)p.w;
+  // byte offsets of the lane's B fragments inside a (chunk, k-group) slab of the packed image
+  unsigned boff[NTW];
+  bool bok[NTW];
+  const int cout_pad = (p.Cout + p.BNp - 1) / p.BNp * p.BNp;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int co0 = co_base + nt * 32;
+    bok[nt] = co0 < cout_pad;
+    const int nb = co0 / p.BNp, nn = co0 - nb * p.BNp;
+    // 16-byte index = (((nb * nch + q) * KG + kg) * 2 + half) * BNp + nn + li, KG = 2
+    boff[nt] = bok[nt] ? (unsigned)((((nb * p.nch) * 2) * 2 + half) * p.BNp + nn + li) * 16u : 0u;
+  }
+  const unsigned b_step = (unsigned)(2 * p.BNp) * 16u;            // one k-group further
+  const int nsteps = p.nch * 2;
+  const int t_begin = strip * p.tiles_per_strip;
+  int t_end = t_begin + p.tiles_per_strip;
+  if (t_end > p.tiles_per_n) t_end = p.tiles_per_n;
+  Moments run = {0.f, 0.f, 0.f};
+  const int cc = lane % OCH;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int64_t row0 = (int64_t)t * PW_ROWS + wave * 32;
+    const int64_t arow = row0 + li;
+    const bool a_in = arow < p.S;
+    const unsigned char* const ap = xn + (size_t)(a_in ? arow : 0) * p.x_stride * 2 + half * 16;
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    auto load_a = [&](int s) -> u32x4 {          // s = 2 * chunk + kg: slot (2 kg + half) of the chunk = bytes s * 32 + half * 16
+      const int c0 = s * 16 + half * 8;
+      if (!a_in || c0 >= p.Cin) return u32x4{0u, 0u, 0u, 0u};
+      return *(const u32x4*)(ap + (size_t)s * 32);
+    };
+    auto load_b = [&](int s, int nt) -> u32x4 {
+      if (!bok[nt]) return u32x4{0u, 0u, 0u, 0u};
+      return *(const u32x4*)(wb + boff[nt] + (size_t)s * b_step);
+    };
+    u32x4 a_n = load_a(0), b_n[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) b_n[nt] = load_b(0, nt);
+    for (int s = 0; s < nsteps; ++s) {
+      u32x4 a = a_n, bb[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) bb[nt] = b_n[nt];
+      if (s + 1 < nsteps) {
+        a_n = load_a(s + 1);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) b_n[nt] = load_b(s + 1, nt);
+      }
+      if (p.in_stats) {
+        const int c0 = s * 16 + half * 8;
+        if (a_in && c0 < p.Cin) {
+          float f[CPC];
+          Elem<T>::unpack(a, f);
+          const float* st = stL + c0 * 2;
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) f[j] = pw_actf<ACT>((f[j] - st[2 * j]) * st[2 * j + 1], p.act);
+          a = Elem<T>::pack(f);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb[nt]), acc[nt], 0, 0, 0);
+    }
+    // ---- epilogue -------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int cch0 = co_base + nt * 32 + cc * CPC;
+      const bool c_ok = cch0 < p.Cout;
+      float mm[CPC], mr[CPC], s0[CPC], s1[CPC], sh[CPC];
+      float cnt = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPC; ++j) { mm[j] = 0.f; mr[j] = 1.f; s0[j] = 0.f; s1[j] = 0.f; sh[j] = 0.f; }
+      if (p.mx && p.m_stats && c_ok) {
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          mm[j] = p.m_stats[((size_t)n * p.Cout + cch0 + j) * 2];
+          mr[j] = p.m_stats[((size_t)n * p.Cout + cch0 + j) * 2 + 1];
+        }
+      }
+      pw_wave_sync();                                   // the previous n-tile's scratch reads are done
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[nt][r];
+      pw_wave_sync();
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int vr = (lane + 64 * it) / OCH;
+        const int64_t row = row0 + vr;
+        const bool inb = c_ok && row < p.S;
+        float v[CPC];
+#pragma unroll
+        for (int j4 = 0; j4 < CPC; j4 += 4) {
+          const f32x4 q4 = *(const f32x4*)(scr + vr * 32 + cc * CPC + j4);
+          v[j4] = q4.x; v[j4 + 1] = q4.y; v[j4 + 2] = q4.z; v[j4 + 3] = q4.w;
+        }
+        if (it == 0 && !p.mx) {
+          // common shift per channel for the wave: the value lane `cc` holds for its first row
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) sh[j] = __shfl(v[j], cc, 64);
+        }
+        if (inb) {
+          const size_t grow = (size_t)n * p.S + (size_t)row;
+          if (p.res) {
+            float f[CPC];
+            Elem<T>::unpack(*(const u32x4*)((const unsigned char*)p.res + (grow * p.res_stride + cch0) * 2), f);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) v[j] += f[j];
+          }
+          if (p.mx) {
+            float f[CPC];
+            Elem<T>::unpack(*(const u32x4*)((const unsigned char*)p.mx + (grow * p.mx_stride + cch0) * 2), f);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) {
+              const float xh = (f[j] - mm[j]) * mr[j];
+              v[j] *= pw_actg<ACT>(xh, p.act);
+              s0[j] += v[j];
+              s1[j] += v[j] * xh;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) { const float d = v[j] - sh[j]; s0[j] += d; s1[j] += d * d; }
+          }
+          cnt += 1.f;
+          *(u32x4*)((unsigned char*)p.y + (grow * p.y_stride + cch0) * 2) = Elem<T>::pack(v);
+        }
+      }
+      if (p.partials) {
+#pragma unroll
+        for (int msk = OCH; msk < 64; msk <<= 1) {
+          cnt += __shfl_xor(cnt, msk, 64);
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) {
+            s0[j] += __shfl_xor(s0[j], msk, 64);
+            s1[j] += __shfl_xor(s1[j], msk, 64);
+          }
+        }
+        if (lane < OCH) {
+#pragma unroll
+          for (int j = 0; j < CPC; ++j) {
+            Moments a;
+            if (p.mx) { a.n = 0.f; a.mean = s0[j]; a.m2 = s1[j]; }
+            else a = moments_from_shifted(cnt, sh[j], s0[j], s1[j]);
+            float* rr = red + ((wave * NTW + nt) * 32 + cc * CPC + j) * 3;
+            rr[0] = a.n; rr[1] = a.mean; rr[2] = a.m2;
+          }
+        }
+      }
+    }
+    if (p.partials) {
+      __syncthreads();                                  // `red` complete
+      if (tid < NTW * 32) {
+        Moments a = {0.f, 0.f, 0.f};
+        for (int g = 0; g < PW_NW; ++g) {
+          const float* rr = red + ((g * NTW) * 32 + tid) * 3;
+          if (p.mx) { a.mean += rr[1]; a.m2 += rr[2]; }
+          else { const Moments bq = {rr[0], rr[1], rr[2]}; a = moments_merge(a, bq); }
+        }
+        if (p.mx) { run.mean += a.mean; run.m2 += a.m2; }
+        else run = moments_merge(run, a);
+      }
+      __syncthreads();                                  // before the next tile's records overwrite `red`
+    }
+  }
+  if (p.partials && tid < NTW * 32 && co_base + tid < p.Cout) {
+    const size_t o = (((size_t)n * p.P + strip) * p.Cout + co_base + tid) * 3;
+    p.partials[o] = run.n; p.partials[o + 1] = run.mean; p.partials[o + 2] = run.m2;
+    for (int r = strip + p.Pn; r < p.P; r += p.Pn) {      // buffer sized for another kernel's grid: empty records
+      const size_t o2 = (((size_t)n * p.P + r) * p.Cout + co_base + tid) * 3;
+      p.partials[o2] = 0.f; p.partials[o2 + 1] = 0.f; p.partials[o2 + 2] = 0.f;
+    }
+  }
+}
+
+}  // namespace cbim
+
+using namespace cbim;
+
+static int g_pw_on = getenv("CBIM_CONV_PW") ? atoi(getenv("CBIM_CONV_PW")) : 1;
+/* process-wide switch (tests, A/B): 0 = pointwise convolutions stay on k_conv_igemm; returns the old value */
+extern "C" int cbim_conv_pw_enable(int on) {
+  const int old = g_pw_on;
+  if (on >= 0) g_pw_on = on ? 1 : 0;
+  return old;
+}
+
+static void pw_strips(int64_t S, int* tiles, int* tps, int* Pn) {
+  const int64_t t = (S + PW_ROWS - 1) / PW_ROWS;
+  int64_t per = (t + 511) / 512;
+  if (per < 1) per = 1;
+  *tiles = (int)t; *tps = (int)per; *Pn = (int)((t + per - 1) / per);
+}
+
+static bool pw_desc_ok(const cbim_conv_desc* d) {
+  return g_pw_on && d->dtype == CBIM_BF16 && d->kD == 1 && d->kH == 1 && d->kW == 1 && d->pD == 0 && d->pH == 0 && d->pW == 0 &&
+         d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->Cin <= 4096 && d->Di == d->Do && d->Hi == d->Ho && d->Wi == d->Wo &&
+         (int64_t)d->Do * d->Ho * d->Wo * PW_ROWS < ((int64_t)1 << 40);
+}
+
+int cbim_conv_pw_records(const cbim_conv_desc* d) {
+  if (!pw_desc_ok(d)) return 0;
+  int tiles, tps, Pn;
+  pw_strips((int64_t)d->Do * d->Ho * d->Wo, &tiles, &tps, &Pn);
+  return Pn;
+}
+
+bool cbim_conv_pw_eligible(const cbim_conv_desc* d, int64_t x_stride, const void* x2, int64_t res_stride, int64_t mask_stride,
+                           int64_t y_stride, const void* res, const void* mask_x, const float* mask_stats) {
+  if (!pw_desc_ok(d) || x2) return false;
+  if (x_stride % 8 || y_stride % 8 || (res && res_stride % 8) || (mask_x && mask_stride % 8)) return false;
+  if (mask_x && !mask_stats && d->act != CBIM_ACT_RELU) return false;
+  return true;
+}
+
+template <int NTW>
+static int pw_launch_n(const PwParams& p, dim3 grid, size_t smem, int act, hipStream_t st) {
+  if (act == CBIM_ACT_RELU) CBIM_LAUNCH((k_conv_pw<NTW, CBIM_ACT_RELU>), grid, dim3(PW_NT), smem, st, p);
+  else if (act == CBIM_ACT_NONE) CBIM_LAUNCH((k_conv_pw<NTW, CBIM_ACT_NONE>), grid, dim3(PW_NT), smem, st, p);
+  else CBIM_LAUNCH((k_conv_pw<NTW, -1>), grid, dim3(PW_NT), smem, st, p);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+int cbim_conv_pw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats, const void* w_packed,
+                        const void* res, int64_t res_stride, const void* mask_x, int64_t mask_stride, const float* mask_stats,
+                        void* y, int64_t y_stride, float* partials, int P, void* stream) {
+  PwParams p;
+  p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.w = w_packed;
+  p.res = res; p.res_stride = res_stride; p.mx = mask_x; p.mx_stride = mask_stride; p.m_stats = mask_stats;
+  p.y = y; p.y_stride = y_stride; p.partials = partials;
+  p.N = d->N; p.S = (int64_t)d->Do * d->Ho * d->Wo; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
+  p.nch = (d->Cin + 31) / 32;
+  p.BNp = d->Cout <= 32 ? 32 : 64;
+  pw_strips(p.S, &p.tiles_per_n, &p.tiles_per_strip, &p.Pn);
+  p.P = P > p.Pn ? P : p.Pn;
+  CBIM_CHECK(!partials || P >= p.Pn, CBIM_EINVAL, "pointwise conv: %d statistics records < %d", P, p.Pn);
+  // output channels per wave: 128 when that still gives every CU a few workgroups, else 64 / 32
+  const int64_t row_wgs = (int64_t)d->N * p.Pn;
+  int ntw = d->Cout <= 32 ? 1 : (d->Cout <= 64 ? 2 : 4);
+  if (ntw == 4 && row_wgs * ((d->Cout + 127) / 128) < 512) ntw = 2;
+  static const int ntw_env = getenv("CBIM_PW_NTW") ? atoi(getenv("CBIM_PW_NTW")) : 0;     // tools/ only: force 1 | 2 | 4
+  if (ntw_env == 1 || ntw_env == 2 || ntw_env == 4) ntw = ntw_env > (d->Cout + 31) / 32 ? ntw : ntw_env;
+  p.n_wblk = (d->Cout + ntw * 32 - 1) / (ntw * 32);
+  const size_t smem = (size_t)PW_NW * 4096 + (size_t)PW_NW * ntw * 32 * 3 * 4 + (size_t)d->Cin * 2 * 4;
+  CBIM_CHECK(row_wgs * p.n_wblk < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "pointwise conv: grid too large");
+  dim3 grid((unsigned)(row_wgs * p.n_wblk));
+  hipStream_t st = (hipStream_t)stream;
+  // a mask tensor without statistics is the activated tensor itself (ReLU): xh := a, as in conv_igemm.hip
+  switch (ntw) {
+    case 1: return pw_launch_n<1>(p, grid, smem, d->act, st);
+    case 2: return pw_launch_n<2>(p, grid, smem, d->act, st);
+    default: return pw_launch_n<4>(p, grid, smem, d->act, st);
+  }
+}
+
+CBIM_DEFINE_WARM(pw)

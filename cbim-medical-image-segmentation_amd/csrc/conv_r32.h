@@ -53,3 +53,13 @@ int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
 int cbim_conv_rw_ksplit(const cbim_conv_desc* d);
 int cbim_conv_rw_split_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
                               int cin_split, const void* w_packed, float* ws, void* stream);
+
+// conv_pw.hip (round 4): bf16 1x1x1 convolutions as a row GEMM without operand staging (forward with InstanceNorm + activation
+// on load, residual, statistics; activated-mask dgrad with the two backward sums).  cbim_conv_pw_records: statistics records per
+// image it writes (0: the descriptor is not a pointwise layer it takes).
+int cbim_conv_pw_records(const cbim_conv_desc* d);
+bool cbim_conv_pw_eligible(const cbim_conv_desc* d, int64_t x_stride, const void* x2, int64_t res_stride, int64_t mask_stride,
+                           int64_t y_stride, const void* res, const void* mask_x, const float* mask_stats);
+int cbim_conv_pw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats, const void* w_packed,
+                        const void* res, int64_t res_stride, const void* mask_x, int64_t mask_stride, const float* mask_stats,
+                        void* y, int64_t y_stride, float* partials, int P, void* stream);

@@ -213,10 +213,13 @@ int cbim_conv_r32_tile_depth(int td);
  * negative value leaves a switch as it is.  Returns the previous (on | wide << 1).  Process-wide knob for tests and tools
  * (env CBIM_CONV_RW, CBIM_CONV_RW_WIDE give the defaults); both kernels compute the same function. */
 int cbim_conv_rw_enable(int on, int wide);
+/* bf16 1x1x1 convolutions on the row-GEMM kernel (conv_pw.hip) instead of k_conv_igemm: on = 0 | 1, < 0 only queries; returns the
+ * previous value (default 1; env CBIM_CONV_PW).  The two kernels compute the same function. */
+int cbim_conv_pw_enable(int on);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);
-/* Kernel launched by this thread's last cbim_conv3d_igemm call: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw, 3 = k_conv3_rw split-K + finish (profiling labels). */
+/* Kernel launched by this thread's last cbim_conv3d_igemm call: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw, 3 = k_conv3_rw split-K + finish, 4 = k_conv_pw (profiling labels). */
 int cbim_conv3d_last_kernel(void);
 /* Records per sample of the partial-sum buffer `partials` (one per persistent workgroup, or per finish part when the
  * launcher splits K). */

@@ -1004,3 +1004,69 @@ def check_colsum(dev, dtype, rows=1000, C=48, seed=51):
     got = ops.colsum(x.to(dev))
     ref = x.float().sum(0)
     assert relerr(got.cpu(), ref) < 1e-5
+
+
+def check_conv_pw(dev, N=2, Cin=64, Cout=96, dhw=(5, 6, 7), act="relu", seed=71):
+    """conv_pw.hip (bf16 1x1x1 convolutions as a row GEMM without operand staging) against k_conv_igemm on the same calls and
+    against torch: forward with InstanceNorm + activation on load, residual and output statistics; raw forward; plain dgrad;
+    dgrad masked through the pre-activation (statistics given) with the two InstanceNorm-backward sums; dgrad masked by an
+    activated tensor."""
+    from cbim_amd import _lib
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    torch.manual_seed(seed)
+    k, pad = (1, 1, 1), (0, 0, 0)
+    S = dhw[0] * dhw[1] * dhw[2]
+    x = torch.randn(N, Cin, *dhw) * 1.5 + 0.4
+    xl = to_cl(x, dtype).to(dev)
+    xs = ops.instnorm_stats(xl, ops.IN_EPS)
+    w = torch.randn(Cout, Cin, *k) * 0.1
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, ops.ACT[act])
+    wdev = w.to(dev)
+    wp, wpd = ops.pack_weights(wdev, geom, 0), ops.pack_weights(wdev, geom, 1)
+    resl = to_cl(torch.randn(N, Cout, *dhw) + 2.0, dtype).to(dev)
+    dyl = to_cl(torch.randn(N, Cout, *dhw), dtype).to(dev)
+    accl = to_cl(torch.randn(N, Cin, *dhw), dtype).to(dev)
+    al = ops.norm_act_fwd(xl, xs, ops.ACT[act])
+    kern = []
+
+    def run():
+        y, ys = ops.conv_fwd(xl, wp, geom, in_stats=xs, res=resl, want_stats=True)
+        kern.append(L.cbim_conv3d_last_kernel())
+        y0, ys0 = ops.conv_fwd(xl, wp, geom, want_stats=True)
+        y1, _ = ops.conv_fwd(xl, wp, geom, in_stats=xs)
+        g, _ = ops.conv_dgrad(dyl, wpd, geom)
+        g1, sums1 = ops.conv_dgrad(dyl, wpd, geom, mask_x=xl, mask_stats=xs, accumulate=accl)
+        kern.append(L.cbim_conv3d_last_kernel())
+        out = [y, ys, y0, ys0, y1, g, g1, sums1]
+        if act == "relu":
+            g2, sums2 = ops.conv_dgrad(dyl, wpd, geom, mask_x=al, mask_stats=None)
+            out += [g2, sums2]
+        return [o.float().cpu() for o in out]
+
+    old = L.cbim_conv_pw_enable(0)
+    try:
+        ref = run()                       # k_conv_igemm
+        L.cbim_conv_pw_enable(1)
+        got = run()                       # k_conv_pw
+    finally:
+        L.cbim_conv_pw_enable(old)
+    n = len(kern) // 2
+    assert all(kk != 4 for kk in kern[:n]) and all(kk == 4 for kk in kern[n:]), f"kernels selected: {kern}"
+    names = ["fwd+IN+res", "fwd stats", "raw fwd", "raw stats", "fwd+IN (no stats)", "dgrad", "masked dgrad+acc", "bwd sums",
+             "dgrad masked by a", "bwd sums (a)"]
+    for nm, r, g_ in zip(names, ref, got):
+        tol = 1e-4 if nm in ("fwd stats", "raw stats", "bwd sums", "bwd sums (a)") else 4e-3   # bf16 outputs: one rounding apart at most
+        scale = float(r.abs().max()) + 1e-12
+        err = float((g_ - r).abs().max()) / scale
+        assert err < tol, f"pw vs igemm: {nm} {err:.3e}"
+    # against torch in fp32 on the bf16-rounded operands
+    xr, wr = from_cl(xl.float().cpu()), w.bfloat16().float()
+    xh = F.instance_norm(xr, eps=ops.IN_EPS)
+    a = {"relu": torch.relu, "none": lambda t: t, "gelu": F.gelu}[act](xh).bfloat16().float()
+    yr = F.conv3d(a, wr) + from_cl(resl.float().cpu())
+    assert relerr(from_cl(got[0]), yr) < 1e-2, "fwd vs torch"
+    assert relerr(got[1][..., 0], yr.mean((2, 3, 4))) < 2e-3
+    assert relerr(from_cl(got[2]), F.conv3d(xr, wr)) < 1e-2, "raw fwd vs torch"
+    gr = F.conv_transpose3d(from_cl(dyl.float().cpu()), wr)
+    assert relerr(from_cl(got[5]), gr) < 1e-2, "dgrad vs torch"

@@ -288,3 +288,9 @@ def test_dgrad_masked_by_the_activated_tensor(dev):
     oc.check_dgrad_mask_by_activated(dev, torch.bfloat16)                                  # k_conv3_r32, single chunk
     oc.check_dgrad_mask_by_activated(dev, torch.bfloat16, Cin=64, Cout=32, dhw=(8, 8, 16))   # k_conv3_r32, several chunks
     oc.check_dgrad_mask_by_activated(dev, torch.float32, Cin=8, Cout=12, dhw=(5, 6, 7))      # k_conv_igemm
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(N=1, Cin=48, Cout=24, dhw=(3, 5, 9), act="none"), dict(N=1, Cin=128, Cout=320, dhw=(4, 8, 8)),
+                                 dict(N=2, Cin=32, Cout=32, dhw=(2, 3, 5), act="gelu"), dict(N=1, Cin=8, Cout=136, dhw=(1, 1, 130))])
+def test_pointwise_conv_row_gemm(dev, cfg):
+    oc.check_conv_pw(dev, **cfg)
