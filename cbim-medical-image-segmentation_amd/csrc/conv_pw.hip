@@ -16,6 +16,10 @@
 //     weights stay in L1 / L2 (HBM-bound layers ask < 10 % of the matrix rate);
 //   * InstanceNorm + activation of the producer are applied to the fragment in registers (statistics of the image in LDS);
 //   * 256-thread workgroups (4 waves x 32 rows x NTW*32 output channels), <= 128 registers: four workgroups per CU;
+//   * measured and left out (profiles/r04_y_pw_*.txt): the whole A row block of a tile requested at once with the weight block in
+//     LDS (Cin <= 128: 64^3 64->256 53.7 -> 49.4 us, 32^3 128->512 23.2 -> 25.3, MedFormer step unchanged), the next tile's first
+//     fragments requested before the epilogue (no change), 32 / 64 / 128 output channels per wave forced (step within 0.2 ms):
+//     what remains is the store path — 134 MB of 16-byte stores in 50 us is 2.7 TB/s of a ~4.3 TB/s drain rate;
 //   * epilogue as in conv_igemm.hip: accumulators transposed through a private 4 KiB LDS tile per wave into 16-byte channel
 //     chunks; residual add, activated mask, shifted moments / backward sums; one statistics record per (image, strip of row
 //     tiles), fixed merge order.
@@ -328,8 +332,6 @@ int cbim_conv_pw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
   const int64_t row_wgs = (int64_t)d->N * p.Pn;
   int ntw = d->Cout <= 32 ? 1 : (d->Cout <= 64 ? 2 : 4);
   if (ntw == 4 && row_wgs * ((d->Cout + 127) / 128) < 512) ntw = 2;
-  static const int ntw_env = getenv("CBIM_PW_NTW") ? atoi(getenv("CBIM_PW_NTW")) : 0;     // tools/ only: force 1 | 2 | 4
-  if (ntw_env == 1 || ntw_env == 2 || ntw_env == 4) ntw = ntw_env > (d->Cout + 31) / 32 ? ntw : ntw_env;
   p.n_wblk = (d->Cout + ntw * 32 - 1) / (ntw * 32);
   const size_t smem = (size_t)PW_NW * 4096 + (size_t)PW_NW * ntw * 32 * 3 * 4 + (size_t)d->Cin * 2 * 4;
   CBIM_CHECK(row_wgs * p.n_wblk < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "pointwise conv: grid too large");

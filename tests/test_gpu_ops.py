@@ -312,7 +312,7 @@ def test_dgrad_masked_by_the_activated_tensor(dev):
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(N=1, Cin=48, Cout=24, dhw=(3, 5, 9), act="none"), dict(N=1, Cin=128, Cout=512, dhw=(16, 16, 16)),
-                                 dict(N=2, Cin=32, Cout=32, dhw=(2, 3, 5), act="gelu"), dict(N=1, Cin=8, Cout=136, dhw=(1, 1, 130)),
+                                 dict(N=2, Cin=32, Cout=32, dhw=(2, 3, 5), act="gelu"), dict(N=1, Cin=8, Cout=136, dhw=(1, 1, 130)), dict(N=1, Cin=160, Cout=64, dhw=(2, 4, 8), act="relu"),
                                  dict(N=1, Cin=320, Cout=1280, dhw=(8, 8, 8)), dict(N=1, Cin=64, Cout=256, dhw=(32, 32, 32))])
 def test_pointwise_conv_row_gemm(dev, cfg):
     oc.check_conv_pw(dev, **cfg)
