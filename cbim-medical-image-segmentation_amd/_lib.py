@@ -76,6 +76,7 @@ _SIGS = {
     "cbim_conv_r32_tile_depth": (i32, [i32]),
     "cbim_conv_rw_enable": (i32, [i32, i32]),
     "cbim_conv_pw_enable": (i32, [i32]),
+    "cbim_dwconv_lds_enable": (i32, [i32]),
     "cbim_conv3d_num_tiles": (i32, [_dp]),
     "cbim_conv3d_tile_config": (i32, [_dp, C.POINTER(C.c_int * 4)]),
     "cbim_conv3d_igemm": (i32, [_dp, vp, i64, vp, i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, sz, vp]),

@@ -290,6 +290,149 @@ __global__ void __launch_bounds__(NT) k_dwconv3(const void* __restrict__ x, int6
   }
 }
 
+// ---- depthwise 3x3x3 (kD, kH <= 3, kW == 3), LDS-tiled (round 4) ---------------------------------------------------------
+// k_dwconv3 reads every input row segment straight from global memory once per (kd, kh) it feeds and normalises it there:
+// nine dependent round trips per strip and the InstanceNorm + activation of every input value nine times over (276 us on the
+// 64^3 x 256 PatchMerging tensor against 45 us of HBM time, and ~20 us of serial latency on the 8^3 .. 16^3 tensors of the deep
+// stages: 114 of the 120 launches of a MedFormer step).  Here a workgroup owns a 4 x 8 x 8 output tile of LG channel chunks:
+// the (4+kD-1) x (8+kH-1) x 10 input halo is requested in ONE sweep (every load of a thread in flight together), transformed
+// once — InstanceNorm, activation, bias, literal zeros for the padding — and kept in LDS in the storage type; thread = (chunk,
+// strip of 4 outputs along W) as before, its 6-chunk row segments and the tap weights now come from LDS.
+static constexpr int LG = 4;                          // channel chunks per workgroup (64 contiguous bytes per halo voxel; 42 KB of LDS: three workgroups per CU)
+static constexpr int LTD = 4, LTH = 8, LTW = 8;
+template <typename T, int MODE>
+__global__ void __launch_bounds__(NT) k_dwconv3_lds(const void* __restrict__ x, int64_t xs, const float* __restrict__ in_stats, int act,
+                                                    const float* __restrict__ bias, const float* __restrict__ w, int flip,
+                                                    void* __restrict__ y, int64_t ys, int N, int D, int H, int W, int C, int kD, int kH,
+                                                    int tiles_d, int tiles_h, int tiles_w) {
+  constexpr int CPC = Elem<T>::CPC, NP = DwPairs<T>::NP;
+  __shared__ __attribute__((aligned(16))) unsigned char halo_s[(LTD + 2) * (LTH + 2) * (LTW + 2) * LG * 16];
+  __shared__ __attribute__((aligned(16))) float w_s[27 * LG * CPC];
+  const int cch = C / CPC;
+  const int g0 = blockIdx.y * LG;
+  const int G = cch - g0 < LG ? cch - g0 : LG;
+  const int TT = kD * kH * 3, pD = kD / 2, pH = kH / 2;
+  const int hD = LTD + kD - 1, hH = LTH + kH - 1, hW = LTW + 2;
+  unsigned bt = blockIdx.x;
+  const int tw = (int)(bt % (unsigned)tiles_w); bt /= (unsigned)tiles_w;
+  const int th = (int)(bt % (unsigned)tiles_h); bt /= (unsigned)tiles_h;
+  const int td = (int)(bt % (unsigned)tiles_d);
+  const int n = (int)(bt / (unsigned)tiles_d);
+  const int d0 = td * LTD, h0 = th * LTH, w0t = tw * LTW;
+  const int tid = threadIdx.x;
+  // ---- weights of the chunk group: [tap][LG * CPC] -------------------------------------------------------------------
+  {
+    constexpr int WU = (27 * LG * CPC + NT - 1) / NT;   // every weight load of the thread in flight together
+    float wv[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int i = tid + u * NT;
+      const int tap = i / (LG * CPC), ch = i % (LG * CPC);
+      wv[u] = (i < TT * LG * CPC && ch < G * CPC) ? w[(size_t)(g0 * CPC + ch) * TT + (flip ? TT - 1 - tap : tap)] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u)
+      if (tid + u * NT < TT * LG * CPC) w_s[tid + u * NT] = wv[u];
+  }
+  // ---- halo: item = (halo voxel, chunk); a thread always meets the same chunk (NT % LG == 0) -----------------------
+  const int cl = tid % LG, v0 = tid / LG;
+  constexpr int VPT = NT / LG;                        // halo voxels per sweep of the workgroup
+  const bool c_ok = cl < G;
+  const int c0 = (g0 + (c_ok ? cl : 0)) * CPC;
+  dw_f2 nmean[NP], rstd[NP], bs[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    nmean[j] = dw_f2{0.f, 0.f}; rstd[j] = dw_f2{1.f, 1.f}; bs[j] = dw_f2{0.f, 0.f};
+    if (MODE != 0) {
+      const float* st = in_stats + ((size_t)n * C + c0 + 2 * j) * 2;
+      nmean[j] = dw_f2{-st[0], -st[2]};
+      rstd[j] = dw_f2{st[1], st[3]};
+    }
+    if (bias) bs[j] = dw_f2{bias[(size_t)n * C + c0 + 2 * j], bias[(size_t)n * C + c0 + 2 * j + 1]};
+  }
+  const int hV = hD * hH * hW;
+  constexpr int UL = 10;                              // loads in flight per thread and trip: the 600-voxel halo in one sweep
+  for (int base = v0; base < hV; base += VPT * UL) {
+    u32x4 raw[UL];
+    bool in[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int hv = base + u * VPT;
+      const int hw = hv % hW, r = hv / hW, hh = r % hH, hd = r / hH;
+      const int dd = d0 - pD + hd, hy = h0 - pH + hh, wx = w0t - 1 + hw;
+      in[u] = c_ok && hv < hV && dd >= 0 && dd < D && hy >= 0 && hy < H && wx >= 0 && wx < W;
+      raw[u] = u32x4{0u, 0u, 0u, 0u};
+      if (in[u]) raw[u] = *(const u32x4*)((const unsigned char*)x + (((((int64_t)n * D + dd) * H + hy) * W + wx) * xs + c0) * (int64_t)Elem<T>::SIZE);
+    }
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int hv = base + u * VPT;
+      if (hv < hV) {
+        u32x4 o = u32x4{0u, 0u, 0u, 0u};
+        if (in[u]) {
+          dw_f2 f[NP];
+          DwPairs<T>::unpack(raw[u], f);
+          float g[CPC];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            dw_f2 v = f[j];
+            if (MODE != 0) {
+              v = (v + nmean[j]) * rstd[j];
+              if (MODE == 1) v = __builtin_elementwise_max(v, dw_f2{0.f, 0.f});
+              if (MODE == 3) v = dw_f2{act_fwd(v.x, act), act_fwd(v.y, act)};
+            }
+            v = v + bs[j];
+            g[2 * j] = v.x; g[2 * j + 1] = v.y;
+          }
+          o = Elem<T>::pack(g);
+        }
+        *(u32x4*)(halo_s + ((size_t)hv * LG + cl) * 16) = o;
+      }
+    }
+  }
+  __syncthreads();
+  if (!c_ok) return;
+  // ---- outputs: thread = (chunk cl, strips v0, v0 + VPT, ...) of the 64 strips of the tile ---------------------------
+  constexpr int STRIPS = LTD * LTH * (LTW / WT);
+  for (int sidx = v0; sidx < STRIPS; sidx += VPT) {
+    const int sw = sidx % (LTW / WT), r = sidx / (LTW / WT), sh = r % LTH, sd = r / LTH;
+    const int dz = d0 + sd, ho = h0 + sh, wo = w0t + sw * WT;
+    if (dz >= D || ho >= H || wo >= W) continue;
+    dw_f2 acc[WT][NP];
+#pragma unroll
+    for (int o = 0; o < WT; ++o)
+#pragma unroll
+      for (int j = 0; j < NP; ++j) acc[o][j] = dw_f2{0.f, 0.f};
+    for (int a = 0; a < kD; ++a)
+      for (int b = 0; b < kH; ++b) {
+        const unsigned char* rp = halo_s + ((size_t)(((sd + a) * hH + sh + b) * hW + sw * WT) * LG + cl) * 16;
+        dw_f2 inr[WT + 2][NP];
+#pragma unroll
+        for (int q = 0; q < WT + 2; ++q) DwPairs<T>::unpack(*(const u32x4*)(rp + (size_t)q * LG * 16), inr[q]);
+        const float* wt = w_s + ((a * kH + b) * 3) * (LG * CPC) + cl * CPC;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          dw_f2 wv[NP];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) wv[j] = dw_f2{wt[c * (LG * CPC) + 2 * j], wt[c * (LG * CPC) + 2 * j + 1]};
+#pragma unroll
+          for (int o = 0; o < WT; ++o)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) acc[o][j] = __builtin_elementwise_fma(inr[o + c][j], wv[j], acc[o][j]);
+        }
+      }
+    const size_t obase = (((size_t)n * D + dz) * H + ho) * W;
+#pragma unroll
+    for (int o = 0; o < WT; ++o)
+      if (wo + o < W) {
+        float f[CPC];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { f[2 * j] = acc[o][j].x; f[2 * j + 1] = acc[o][j].y; }
+        st_chunk<T>(y, (obase + wo + o) * ys + (size_t)(g0 + cl) * CPC, Elem<T>::pack(f));
+      }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(NT) k_dwconv3_wgrad(const void* __restrict__ x, int64_t xs,
                                                       const float* __restrict__ in_stats, int act,
@@ -1162,6 +1305,15 @@ static int check_k(int kD, int kH, int kW) {
   return 0;
 }
 
+static int g_dw_lds = 1;
+/* process-wide switch (tests, A/B): 0 = the streaming depthwise kernel also where the LDS-tiled one applies; < 0 only queries;
+ * returns the old value */
+extern "C" int cbim_dwconv_lds_enable(int on) {
+  const int old = g_dw_lds;
+  if (on >= 0) g_dw_lds = on ? 1 : 0;
+  return old;
+}
+
 extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const float* in_stats, int act,
                              const float* bias, const float* w, int flip, void* y, int64_t y_stride, int N, int D,
                              int H, int W, int C, int kD, int kH, int kW, void* stream) {
@@ -1178,6 +1330,20 @@ extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const f
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     const int mode = !in_stats ? 0 : act == CBIM_ACT_RELU ? 1 : act == CBIM_ACT_NONE ? 2 : 3;
+    static const int lds_on = getenv("CBIM_DWCONV_LDS") ? atoi(getenv("CBIM_DWCONV_LDS")) : 1;
+    if (lds_on && g_dw_lds) {      // LDS-tiled form (round 4): one sweep of loads, the input transformed once
+      const int tiles_d = (D + LTD - 1) / LTD, tiles_h = (H + LTH - 1) / LTH, tiles_w = (W + LTW - 1) / LTW;
+      const int64_t tiles = (int64_t)N * tiles_d * tiles_h * tiles_w;
+      const int lgroups = (cch + LG - 1) / LG;
+      if (tiles < ((int64_t)1 << 31) && lgroups <= 65535) {
+#define DW3L_LAUNCH(TT, MM) CBIM_LAUNCH((k_dwconv3_lds<TT, MM>), dim3((unsigned)tiles, (unsigned)lgroups), dim3(NT), 0, (hipStream_t)stream, x, x_stride, \
+                                        in_stats, act, bias, w, flip, y, y_stride, N, D, H, W, C, kD, kH, tiles_d, tiles_h, tiles_w)
+        if (dtype == CBIM_BF16) { if (mode == 0) DW3L_LAUNCH(bf16_tag, 0); else if (mode == 1) DW3L_LAUNCH(bf16_tag, 1); else if (mode == 2) DW3L_LAUNCH(bf16_tag, 2); else DW3L_LAUNCH(bf16_tag, 3); }
+        else { if (mode == 0) DW3L_LAUNCH(float, 0); else if (mode == 1) DW3L_LAUNCH(float, 1); else if (mode == 2) DW3L_LAUNCH(float, 2); else DW3L_LAUNCH(float, 3); }
+#undef DW3L_LAUNCH
+        return launch_ok("dwconv3d (LDS)");
+      }
+    }
 #define DW3_LAUNCH(TT, MM) CBIM_LAUNCH((k_dwconv3<TT, MM>), dim3((unsigned)bx, groups), dim3(NT), 0, (hipStream_t)stream, x, x_stride, in_stats, act, \
                                        bias, w, flip, y, y_stride, N, D, H, W, C, kD, kH)
     if (dtype == CBIM_BF16) { if (mode == 0) DW3_LAUNCH(bf16_tag, 0); else if (mode == 1) DW3_LAUNCH(bf16_tag, 1); else if (mode == 2) DW3_LAUNCH(bf16_tag, 2); else DW3_LAUNCH(bf16_tag, 3); }

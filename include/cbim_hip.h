@@ -350,6 +350,9 @@ int cbim_gaussian_blur3d(const float* x, float* y, float* tmp, int C, int D, int
 int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const float* in_stats, int act,
                   const float* bias, const float* w, int flip, void* y, int64_t y_stride, int N, int D,
                   int H, int W, int C, int kD, int kH, int kW, void* stream);
+/* 3x3x3-class depthwise convolutions on the LDS-tiled kernel (round 4) instead of the streaming one: on = 0 | 1, < 0 only queries;
+ * returns the previous value (default 1; env CBIM_DWCONV_LDS).  Same function; in bf16 the transformed input is rounded to bf16. */
+int cbim_dwconv_lds_enable(int on);
 /* dw[c][t] = sum_{n,l} a(x)[n,l+off(t),c] * (dy[n,l,c] + dy_bias[n][c]); deterministic two-stage sum. */
 size_t cbim_dwconv3d_wgrad_workspace(int N, int D, int H, int W, int C, int kD, int kH, int kW);
 int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, const float* in_stats, int act,

@@ -294,3 +294,20 @@ def test_dgrad_masked_by_the_activated_tensor(dev):
                                  dict(N=2, Cin=32, Cout=32, dhw=(2, 3, 5), act="gelu"), dict(N=1, Cin=8, Cout=136, dhw=(1, 1, 130)), dict(N=1, Cin=160, Cout=64, dhw=(2, 4, 8), act="relu")])
 def test_pointwise_conv_row_gemm(dev, cfg):
     oc.check_conv_pw(dev, **cfg)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("lds", [0, 1])
+def test_dwconv_lds_tiled_and_streaming_kernels(dev, dtype, lds):
+    """k_dwconv3_lds (round 4: halo staged once, transformed once) and the streaming k_dwconv3 on the same cases, ragged tiles
+    and several tiles per axis included"""
+    from cbim_amd import _lib
+    old = _lib.lib().cbim_dwconv_lds_enable(lds)
+    try:
+        oc.check_dwconv(dev, dtype)
+        oc.check_dwconv(dev, dtype, N=1, C=40, dhw=(2, 2, 2), act="none")
+        oc.check_dwconv(dev, dtype, N=1, C=72, dhw=(9, 10, 19))
+        oc.check_dwconv(dev, dtype, N=1, C=16, dhw=(3, 6, 9), k=(1, 3, 3))
+        oc.check_dwconv(dev, dtype, N=1, C=24, dhw=(5, 9, 8), k=(3, 1, 3), act="none")
+    finally:
+        _lib.lib().cbim_dwconv_lds_enable(old)
