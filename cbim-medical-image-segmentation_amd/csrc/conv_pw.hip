@@ -131,32 +131,46 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
       if (!bok[nt]) return u32x4{0u, 0u, 0u, 0u};
       return *(const u32x4*)(wb + boff[nt] + (size_t)s * b_step);
     };
-    u32x4 a_n = load_a(0), b_n[NTW];
+    // fragments of PD k-groups in flight (a ring of PD register sets, the step loop unrolled by PD): with one k-group of
+    // lookahead the deep-stage layers (Cin 1280: 80 steps of a few hundred cycles of MFMA work) waited out an L2 round trip per
+    // step — 30 us for 8^3 1280->320
+    constexpr int PD = NTW == 4 ? 2 : 4;           // (four sets of the 128-channel form do not fit 256 registers)
+    u32x4 a_q[PD], b_q[PD][NTW];
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) b_n[nt] = load_b(0, nt);
-    for (int s = 0; s < nsteps; ++s) {
-      u32x4 a = a_n, bb[NTW];
+    for (int u = 0; u < PD; ++u) {
+      a_q[u] = u < nsteps ? load_a(u) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) bb[nt] = b_n[nt];
-      if (s + 1 < nsteps) {
-        a_n = load_a(s + 1);
+      for (int nt = 0; nt < NTW; ++nt) b_q[u][nt] = u < nsteps ? load_b(u, nt) : u32x4{0u, 0u, 0u, 0u};
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += PD) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) b_n[nt] = load_b(s + 1, nt);
-      }
-      if (p.in_stats) {
-        const int c0 = s * 16 + half * 8;
-        if (a_in && c0 < p.Cin) {
-          float f[CPC];
-          Elem<T>::unpack(a, f);
-          const float* st = stL + c0 * 2;
+      for (int u = 0; u < PD; ++u) {
+        const int s = s0 + u;
+        if (s < nsteps) {                              // wave-uniform
+          u32x4 a = a_q[u], bb[NTW];
 #pragma unroll
-          for (int j = 0; j < CPC; ++j) f[j] = pw_actf<ACT>((f[j] - st[2 * j]) * st[2 * j + 1], p.act);
-          a = Elem<T>::pack(f);
+          for (int nt = 0; nt < NTW; ++nt) bb[nt] = b_q[u][nt];
+          if (s + PD < nsteps) {
+            a_q[u] = load_a(s + PD);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) b_q[u][nt] = load_b(s + PD, nt);
+          }
+          if (p.in_stats) {
+            const int c0 = s * 16 + half * 8;
+            if (a_in && c0 < p.Cin) {
+              float f[CPC];
+              Elem<T>::unpack(a, f);
+              const float* st = stL + c0 * 2;
+#pragma unroll
+              for (int j = 0; j < CPC; ++j) f[j] = pw_actf<ACT>((f[j] - st[2 * j]) * st[2 * j + 1], p.act);
+              a = Elem<T>::pack(f);
+            }
+          }
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb[nt]), acc[nt], 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb[nt]), acc[nt], 0, 0, 0);
     }
     // ---- epilogue -------------------------------------------------------------------------------------------------------
 #pragma unroll
