@@ -1032,14 +1032,19 @@ __global__ void __launch_bounds__(NT) k_attn_bwd_reduce(const float* __restrict_
 // ---- semantic map generation: column softmax over L + pooling ---------------------------------------
 // fw rows = [feat (C) | weight logits (M)]; part record per (n, block): [M][2 + C]
 template <typename T>
+// blockIdx.y = (code group, channel group of `cw` channels): low-resolution stages have a handful of row blocks (8^3: two), the
+// channel groups give the chip something to do (each recomputes the 128 x 64 exponentials of its rows: cheap)
 __global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw, int64_t rs, float* __restrict__ part,
-                                                    int L, int C, int M, int nblk) {
+                                                    int L, int C, int M, int nblk, int cw) {
   __shared__ float E_s[AT][MM + 1];
   __shared__ float f_s[AT][33];
   __shared__ float red[2][MM];
   __shared__ float colm[MM];
   const int t = threadIdx.x, blk = blockIdx.x, n = blockIdx.z;
-  const int j0 = blockIdx.y * MM;   // code group (column softmaxes of different codes are independent)
+  const int n_jg = (M + MM - 1) / MM;
+  const int j0 = (int)(blockIdx.y % (unsigned)n_jg) * MM;   // code group (column softmaxes of different codes are independent)
+  const int cg = (int)(blockIdx.y / (unsigned)n_jg);
+  const int c_lo = cg * cw, c_hi = c_lo + cw < C ? c_lo + cw : C;
   const int l = blk * AT + t;
   const bool valid = l < L;
   const size_t row = ((size_t)n * L + (valid ? l : 0)) * rs;
@@ -1064,9 +1069,9 @@ __global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw,
     red[hf][j] = s;
   }
   __syncthreads();
-  if (t < MM && j0 + t < M) { pb[(size_t)(j0 + t) * (2 + C)] = colm[t]; pb[(size_t)(j0 + t) * (2 + C) + 1] = red[0][t] + red[1][t]; }
+  if (cg == 0 && t < MM && j0 + t < M) { pb[(size_t)(j0 + t) * (2 + C)] = colm[t]; pb[(size_t)(j0 + t) * (2 + C) + 1] = red[0][t] + red[1][t]; }
   const int jq = t & 15, cq = t >> 4;  // 4 codes x 4 channels per thread
-  for (int c0 = 0; c0 < C; c0 += 32) {
+  for (int c0 = c_lo; c0 < c_hi; c0 += 32) {
     __syncthreads();
     for (int k = 0; k < 32; ++k) f_s[t][k] = (valid && c0 + k < C) ? Elem<T>::load1(fw, row + c0 + k) : 0.f;
     __syncthreads();
@@ -1094,24 +1099,54 @@ __global__ void __launch_bounds__(AT) k_mappool_fwd(const void* __restrict__ fw,
   }
 }
 
-// map[n][c][j], colstat[n][j] = (max, sum)
+// map[n][c][j], colstat[n][j] = (max, sum).  One workgroup per (code j, image): the column maximum and the rescale factors
+// exp(max_b - max) of the nblk partial records are formed by the threads in parallel (fixed tree), kept in LDS, and thread c then
+// walks the records with coalesced reads of p[2 + c], eight loads in flight.  (The first form gave one thread one (c, j) pair
+// and walked the records twice with a strided load -> expf -> add chain: 208 us for 128 records.)
+static constexpr int MRG_MAXB = 8192;
 __global__ void __launch_bounds__(NT) k_mappool_merge(const float* __restrict__ part, float* __restrict__ map,
                                                       float* __restrict__ colstat, int C, int M, int nblk) {
-  const int n = blockIdx.y;
-  const float* base = part + (size_t)n * nblk * M * (2 + C);
-  for (int idx = blockIdx.x * NT + threadIdx.x; idx < C * M; idx += gridDim.x * NT) {
-    int c = idx / M, j = idx % M;
-    float mx = -INFINITY;
-    for (int b = 0; b < nblk; ++b) mx = fmaxf(mx, base[((size_t)b * M + j) * (2 + C)]);
-    float S = 0.f, A = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-      const float* p = base + ((size_t)b * M + j) * (2 + C);
-      float sc = expf(p[0] - mx);
-      S += p[1] * sc;
-      A += p[2 + c] * sc;
+  __shared__ float sc_s[MRG_MAXB];
+  __shared__ float red[NT];
+  const int j = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
+  const float* base = part + ((size_t)n * nblk * M + j) * (2 + C);
+  const size_t bstride = (size_t)M * (2 + C);
+  float m = -INFINITY;
+  for (int b = t; b < nblk; b += NT) m = fmaxf(m, base[(size_t)b * bstride]);
+  red[t] = m;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+    __syncthreads();
+  }
+  const float mx = red[0];
+  __syncthreads();
+  float S = 0.f;
+  for (int b = t; b < nblk; b += NT) {
+    const float sc = expf(base[(size_t)b * bstride] - mx);
+    sc_s[b] = sc;
+    S += base[(size_t)b * bstride + 1] * sc;
+  }
+  red[t] = S;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  S = red[0];
+  if (t == 0) { colstat[((size_t)n * M + j) * 2] = mx; colstat[((size_t)n * M + j) * 2 + 1] = S; }
+  for (int c = t; c < C; c += NT) {
+    float A = 0.f;
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(b + u) * bstride + 2 + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) A = fmaf(v[u], sc_s[b + u], A);
     }
+    for (; b < nblk; ++b) A = fmaf(base[(size_t)b * bstride + 2 + c], sc_s[b], A);
     map[((size_t)n * C + c) * M + j] = A / S;
-    if (c == 0) { colstat[((size_t)n * M + j) * 2] = mx; colstat[((size_t)n * M + j) * 2 + 1] = S; }
   }
 }
 
@@ -1216,11 +1251,28 @@ __global__ void __launch_bounds__(MP4_T) k_mappool_bwd4(const void* __restrict__
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, n = blockIdx.z;
   const int l = blockIdx.x * 64 + lane;
   const bool valid = l < L;
-  if (t < MM) {
+  {
+    // cj[j] = sum_k map[k][j] dmap[k][j]: thread (code j = lane, quarter w of the channels), eight products in flight, the four
+    // quarters added in wave order.  (64 threads walking all C channels with a dependent load -> fma chain were 260 of the
+    // kernel's 340 us at C = 256.)
     float c = 0.f;
-    if (t < M)
-      for (int k = 0; k < C; ++k) c = fmaf(map[((size_t)n * C + k) * M + t], dmap[((size_t)n * C + k) * M + t], c);
-    cj[t] = c;
+    if (lane < M) {
+      const float* mp_ = map + (size_t)n * C * M + lane;
+      const float* dp_ = dmap + (size_t)n * C * M + lane;
+      int k = w;
+      for (; k + 28 < C; k += 32) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = mp_[(size_t)(k + 4 * u) * M]; b[u] = dp_[(size_t)(k + 4 * u) * M]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c = fmaf(a[u], b[u], c);
+      }
+      for (; k < C; k += 4) c = fmaf(mp_[(size_t)k * M], dp_[(size_t)k * M], c);
+    }
+    TTs[w * 64 + lane] = c;
+    __syncthreads();
+    if (t < MM) cj[t] = ((TTs[t] + TTs[64 + t]) + TTs[128 + t]) + TTs[192 + t];
+    __syncthreads();       // TTs is reused for the tt partials below
   }
   const size_t row = ((size_t)n * L + (valid ? l : 0)) * rs, drow = ((size_t)n * L + (valid ? l : 0)) * drs;
   constexpr int CPC = Elem<T>::CPC;
@@ -1607,14 +1659,25 @@ extern "C" int cbim_colsoftmax_pool_fwd(int dtype, const void* fw, int64_t fw_st
              "colsoftmax_pool workspace too small");
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(nblk, (M + MM - 1) / MM, N);   // y = group of 64 codes
+  const int n_jg = (M + MM - 1) / MM;
+  // channels per workgroup: all of them when the row blocks alone fill the chip, else groups of 32 (multiples of 32: the kernel's
+  // channel step)
+  int cw = ((C + 31) / 32) * 32;
+  if ((int64_t)nblk * n_jg * N < 512) {
+    const int64_t want = 512 / ((int64_t)nblk * n_jg * N);
+    int groups = (int)(want < (C + 31) / 32 ? want : (C + 31) / 32);
+    if (groups < 1) groups = 1;
+    cw = (((C + 31) / 32 + groups - 1) / groups) * 32;
+  }
+  const int n_cg = (C + cw - 1) / cw;
+  dim3 grid(nblk, n_jg * n_cg, N);   // y = (group of 64 codes, group of cw channels)
   if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_mappool_fwd<bf16_tag>), grid, dim3(AT), 0, st, fw, fw_stride, (float*)workspace, L, C, M, nblk);
+    CBIM_LAUNCH((k_mappool_fwd<bf16_tag>), grid, dim3(AT), 0, st, fw, fw_stride, (float*)workspace, L, C, M, nblk, cw);
   else
-    CBIM_LAUNCH((k_mappool_fwd<float>), grid, dim3(AT), 0, st, fw, fw_stride, (float*)workspace, L, C, M, nblk);
+    CBIM_LAUNCH((k_mappool_fwd<float>), grid, dim3(AT), 0, st, fw, fw_stride, (float*)workspace, L, C, M, nblk, cw);
   if (int e = launch_ok("colsoftmax_pool_fwd")) return e;
-  int gb = (C * M + NT - 1) / NT;
-  CBIM_LAUNCH(k_mappool_merge, dim3(gb, N), dim3(NT), 0, st, (const float*)workspace, map, colstat, C, M, nblk);
+  CBIM_CHECK(nblk <= MRG_MAXB, CBIM_EUNSUPPORTED, "colsoftmax_pool: %d partial records per image (max %d)", nblk, MRG_MAXB);
+  CBIM_LAUNCH(k_mappool_merge, dim3(M, N), dim3(NT), 0, st, (const float*)workspace, map, colstat, C, M, nblk);
   return launch_ok("colsoftmax_pool_merge");
 }
 
