@@ -1288,7 +1288,15 @@ __global__ void __launch_bounds__(MP4_T) k_mappool_bwd4(const void* __restrict__
     }
   }
   if (valid) {
-    for (int c0 = w * CPC; c0 < C; c0 += 4 * CPC) {
+    // the wave index as a SCALAR: the dmap row pointer is then provably wave-uniform and its 64 values arrive by scalar loads
+    // (as a function of threadIdx the compiler issued 64 vector loads of one address each per channel: 4096 per thread at
+    // C = 256, most of the kernel's time)
+#ifdef CBIM_EMU
+    const int wu = w;
+#else
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+#endif
+    for (int c0 = wu * CPC; c0 < C; c0 += 4 * CPC) {
       float f[CPC], g[CPC];
       Elem<T>::unpack(ld_chunk<T>(fw, row + c0), f);
 #pragma unroll
