@@ -281,6 +281,139 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
   }
 }
 
+
+// ---- weight gradient of the pointwise layers ------------------------------------------------------------------------------
+//   dw[co][ci] = sum_r dy[r][co] * act(IN(x))[r][ci]
+// k_conv_wgrad (conv_wgrad.hip) gives a workgroup ONE (32 co x 32 ci) block, stages a 4x8x8 tile of both tensors per barrier pair
+// and lets its four waves split the tile's 16 k-steps: every dy / x element is re-read by Cin/32 resp. Cout/32 workgroups and a
+// stage is 4 MFMAs per wave.  Here a workgroup owns a (64 co x 64 ci) block (wave = one 32 x 32 quadrant), stages 128 rows of
+// both tensors per barrier (the next stage's sixteen 16-byte loads per thread in flight while the current one computes, the
+// InstanceNorm + activation applied on the way into LDS) and runs 8 k-steps per stage; both MFMA operands are transposed LDS
+// reads (ds_read_b64_tr_b16, the fragment scheme of conv_wgrad.hip).  Strips of rows -> slabs [strip][Cout_pad][Cin_pad] -> the
+// fixed-order k_wgrad_reduce of conv_wgrad.hip.
+static constexpr int PWG_VT = 128;                    // rows per stage
+__device__ __forceinline__ u32x2 pw_lds_tr16_b64(const unsigned char* p) {
+#ifdef CBIM_EMU
+  unsigned short o[4];
+  emu_ds_read_tr16_b64(p, o);
+  u32x2 r;
+  r.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+  r.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+  return r;
+#else
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  u32x2 r;
+  r.x = (unsigned)(unsigned short)v.x | ((unsigned)(unsigned short)v.y << 16);
+  r.y = (unsigned)(unsigned short)v.z | ((unsigned)(unsigned short)v.w << 16);
+  return r;
+#endif
+}
+
+struct PwgParams {
+  const void* x; int64_t x_stride; const float* in_stats; const void* dy; int64_t dy_stride; float* ws;
+  int N; int64_t S; int Cin, Cout, act;
+  int strips, rows_per_strip, ci_blocks, Cout_pad, Cin_pad;
+};
+
+template <int ACT>
+__global__ void __launch_bounds__(PW_NT, 2) k_pw_wgrad(PwgParams p) {
+  typedef bf16_tag T;
+  constexpr int CPC = 8;
+  // LDS: two buffers x (dy sub-tiles co 0-31 | co 32-63, x sub-tiles ci 0-31 | ci 32-63), each [PWG_VT rows][64 B]
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][4][PWG_VT * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
+  const int n = blockIdx.x / p.strips, strip = blockIdx.x % p.strips;
+  const int cb = blockIdx.y / p.ci_blocks, ib = blockIdx.y % p.ci_blocks;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t r_begin = (int64_t)strip * p.rows_per_strip;
+  int64_t r_end = r_begin + p.rows_per_strip;
+  if (r_end > p.S) r_end = p.S;
+  // staging: chunk q = tid + 256 u -> row (tid >> 3) + 32 u, 16-byte slot s = tid & 7 of the 64-channel row segment
+  const int slot = tid & 7, vrow = tid >> 3;
+  const int co_c = cb * 64 + slot * CPC, ci_c = ib * 64 + slot * CPC;
+  const bool co_ok = co_c < p.Cout, ci_ok = ci_c < p.Cin;
+  float mean[CPC], rstd[CPC];
+#pragma unroll
+  for (int j = 0; j < CPC; ++j) { mean[j] = 0.f; rstd[j] = 1.f; }
+  if (p.in_stats && ci_ok) {
+#pragma unroll
+    for (int j = 0; j < CPC; ++j) {
+      mean[j] = p.in_stats[((size_t)n * p.Cin + ci_c + j) * 2];
+      rstd[j] = p.in_stats[((size_t)n * p.Cin + ci_c + j) * 2 + 1];
+    }
+  }
+  const unsigned char* const dyn = (const unsigned char*)p.dy + ((size_t)n * p.S * p.dy_stride + co_c) * 2;
+  const unsigned char* const xn = (const unsigned char*)p.x + ((size_t)n * p.S * p.x_stride + ci_c) * 2;
+  const unsigned sub_off = (unsigned)(slot >> 2), in_off = (unsigned)(slot & 3) * 16u;
+  u32x4 gd[4], gx[4];
+  auto issue = [&](int64_t r0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + vrow + 32 * u;
+      const bool in = r < r_end;
+      gd[u] = (in && co_ok) ? *(const u32x4*)(dyn + (size_t)r * p.dy_stride * 2) : u32x4{0u, 0u, 0u, 0u};
+      gx[u] = (in && ci_ok) ? *(const u32x4*)(xn + (size_t)r * p.x_stride * 2) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto commit = [&](int buf, int64_t r0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = vrow + 32 * u;
+      const int64_t r = r0 + v;
+      u32x4 xa = gx[u];
+      if (p.in_stats && r < r_end && ci_ok) {
+        float f[CPC];
+        Elem<T>::unpack(xa, f);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) f[j] = pw_actf<ACT>((f[j] - mean[j]) * rstd[j], p.act);
+        xa = Elem<T>::pack(f);
+      }
+      *(u32x4*)(&lds[buf][sub_off][v * 64 + in_off]) = gd[u];
+      *(u32x4*)(&lds[buf][2 + sub_off][v * 64 + in_off]) = xa;
+    }
+  };
+  // fragment addressing of ds_read_b64_tr_b16 (conv_wgrad.hip): a 16-lane group reads a [4 rows][16 channels] block, lane i
+  // receives channel i's 4 rows; two reads (rows m, m + 4) give the lane 8 consecutive k of its channel
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const unsigned colb = (unsigned)(16 * g16 + 4 * (i16 & 3)) * 2;
+  const int mq = 8 * half + (i16 >> 2);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  issue(r_begin);
+  commit(0, r_begin);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += PWG_VT) {
+    const bool more = r0 + PWG_VT < r_end;
+    if (more) issue(r0 + PWG_VT);
+    const unsigned char* A = &lds[buf][wm][0];
+    const unsigned char* B = &lds[buf][2 + wn][0];
+#pragma unroll
+    for (int ks = 0; ks < PWG_VT / 16; ++ks) {
+      const unsigned m0 = (unsigned)(ks * 16 + mq) * 64u + colb, m1 = m0 + 4u * 64u;
+      const u32x2 a0 = pw_lds_tr16_b64(A + m0), a1 = pw_lds_tr16_b64(A + m1);
+      const u32x2 b0 = pw_lds_tr16_b64(B + m0), b1 = pw_lds_tr16_b64(B + m1);
+      const u32x4 af = u32x4{a0.x, a0.y, a1.x, a1.y}, bf = u32x4{b0.x, b0.y, b1.x, b1.y};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+    }
+    if (more) commit(buf ^ 1, r0 + PWG_VT);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // slab of this strip: ws[(n * strips + strip)][Cout_pad][Cin_pad]
+  float* wsb = p.ws + (size_t)blockIdx.x * p.Cout_pad * p.Cin_pad;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = cb * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int ci = ib * 64 + wn * 32 + li;
+    wsb[(size_t)co * p.Cin_pad + ci] = acc[r];
+  }
+}
+
 }  // namespace cbim
 
 using namespace cbim;
@@ -357,6 +490,54 @@ int cbim_conv_pw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
     case 2: return pw_launch_n<2>(p, grid, smem, d->act, st);
     default: return pw_launch_n<4>(p, grid, smem, d->act, st);
   }
+}
+
+
+// ---- pointwise weight gradient: host side (the reduce pass is conv_wgrad.hip's k_wgrad_reduce) -----------------------------
+static void pwg_cfg(const cbim_conv_desc* d, int* strips, int* rps, int* co_blocks, int* ci_blocks) {
+  const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
+  *co_blocks = (d->Cout + 63) / 64; *ci_blocks = (d->Cin + 63) / 64;
+  const int64_t pairs = (int64_t)*co_blocks * *ci_blocks * d->N;
+  const int64_t stages = (S + PWG_VT - 1) / PWG_VT;
+  int64_t want = (768 + pairs - 1) / pairs;                 // ~3 workgroups per CU
+  if (want > stages) want = stages;
+  const size_t slab = (size_t)*co_blocks * 64 * *ci_blocks * 64 * sizeof(float);
+  int64_t cap = (int64_t)((64ull << 20) / (slab * d->N));   // slab workspace <= 64 MiB
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  const int64_t per = (stages + want - 1) / want;           // stages per strip
+  *rps = (int)(per * PWG_VT);
+  *strips = (int)((stages + per - 1) / per);
+}
+
+bool cbim_conv_pw_wgrad_eligible(const cbim_conv_desc* d, int64_t x_stride, const void* x2, int64_t dy_stride, const void* dy2) {
+  return pw_desc_ok(d) && !x2 && !dy2 && x_stride % 8 == 0 && dy_stride % 8 == 0 && (int64_t)d->Do * d->Ho * d->Wo < ((int64_t)1 << 31);
+}
+
+size_t cbim_conv_pw_wgrad_workspace(const cbim_conv_desc* d) {
+  if (!pw_desc_ok(d)) return 0;
+  int strips, rps, cob, cib;
+  pwg_cfg(d, &strips, &rps, &cob, &cib);
+  return (size_t)d->N * strips * cob * 64 * cib * 64 * sizeof(float);
+}
+
+int cbim_conv_pw_wgrad_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats, const void* dy,
+                              int64_t dy_stride, float* ws, int* n_slabs, int* Cout_pad, int* Cin_pad, void* stream) {
+  PwgParams p;
+  p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.dy = dy; p.dy_stride = dy_stride; p.ws = ws;
+  p.N = d->N; p.S = (int64_t)d->Do * d->Ho * d->Wo; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
+  int cob;
+  pwg_cfg(d, &p.strips, &p.rows_per_strip, &cob, &p.ci_blocks);
+  p.Cout_pad = cob * 64; p.Cin_pad = p.ci_blocks * 64;
+  *n_slabs = d->N * p.strips; *Cout_pad = p.Cout_pad; *Cin_pad = p.Cin_pad;
+  dim3 grid((unsigned)(d->N * p.strips), (unsigned)(cob * p.ci_blocks));
+  hipStream_t st = (hipStream_t)stream;
+  const int act = in_stats ? d->act : CBIM_ACT_NONE;
+  if (act == CBIM_ACT_RELU) CBIM_LAUNCH((k_pw_wgrad<CBIM_ACT_RELU>), grid, dim3(PW_NT), 0, st, p);
+  else if (act == CBIM_ACT_NONE) CBIM_LAUNCH((k_pw_wgrad<CBIM_ACT_NONE>), grid, dim3(PW_NT), 0, st, p);
+  else CBIM_LAUNCH((k_pw_wgrad<-1>), grid, dim3(PW_NT), 0, st, p);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
 CBIM_DEFINE_WARM(pw)

@@ -63,3 +63,9 @@ bool cbim_conv_pw_eligible(const cbim_conv_desc* d, int64_t x_stride, const void
 int cbim_conv_pw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats, const void* w_packed,
                         const void* res, int64_t res_stride, const void* mask_x, int64_t mask_stride, const float* mask_stats,
                         void* y, int64_t y_stride, float* partials, int P, void* stream);
+// weight gradient of those layers: (64 co x 64 ci) blocks, 128 rows per stage, transposed LDS reads; writes slabs
+// ws[slab][Cout_pad][Cin_pad] for conv_wgrad.hip's k_wgrad_reduce
+bool cbim_conv_pw_wgrad_eligible(const cbim_conv_desc* d, int64_t x_stride, const void* x2, int64_t dy_stride, const void* dy2);
+size_t cbim_conv_pw_wgrad_workspace(const cbim_conv_desc* d);
+int cbim_conv_pw_wgrad_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const float* in_stats, const void* dy,
+                              int64_t dy_stride, float* ws, int* n_slabs, int* Cout_pad, int* Cin_pad, void* stream);

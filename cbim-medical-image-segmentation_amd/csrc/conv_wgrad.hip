@@ -19,6 +19,7 @@
 // (/root/reference/model/dim3/conv_layers.py:29-38).
 #include "cbim_common.h"
 #include "conv_wgrad_r32.h"
+#include "conv_r32.h"
 
 namespace cbim {
 
@@ -442,6 +443,7 @@ extern "C" size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* d) {
     size_t r = cbim_wgrad_r32_workspace(d);
     if (r > need) need = r;
   }
+  if (cbim_conv_pw_wgrad_workspace(d) > need) need = cbim_conv_pw_wgrad_workspace(d);   // pointwise layers: conv_pw.hip
   return need;
 }
 
@@ -492,6 +494,19 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
                                        (float*)workspace, dw, stream))
       return rc;
     return cbim_wgrad_r32_reduce(d, (const float*)workspace, dw, stream);
+  }
+  if (cbim_conv_pw_wgrad_eligible(d, x_stride, x2, dy_stride, dy2)) {      // bf16 1x1x1: conv_pw.hip (round 4)
+    size_t need = cbim_conv_pw_wgrad_workspace(d);
+    CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "wgrad workspace %zu < %zu", ws_bytes, need);
+    g_last_wgrad_kernel = 2;
+    int n_slabs = 0, cop = 0, cip = 0;
+    if (int rc = cbim_conv_pw_wgrad_launch(d, x, x_stride, in_stats, dy, dy_stride, (float*)workspace, &n_slabs, &cop, &cip, stream)) return rc;
+    const int64_t total = (int64_t)d->Cout * d->Cin;
+    int64_t blocks = (total + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, (const float*)workspace, dw, n_slabs, 1, d->Cout,
+                d->Cin, cop, cip, total);
+    return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
   }
   CBIM_CHECK(!x2, CBIM_EUNSUPPORTED, "wgrad: a second input tensor is only taken by the bf16 3x3x3 kernel on raw (un-normalised) "
              "inputs with channel counts in multiples of 32");

@@ -673,7 +673,8 @@ def conv_wgrad(x, in_stats, dy, geom: ConvGeom, dy2=None, x2=None, out=None) -> 
         e1.record()
         d = geom.fwd
         flops = 2.0 * d.N * d.Do * d.Ho * d.Wo * d.Cout * d.Cin * d.kD * d.kH * d.kW
-        name = "k_wgrad_r32<bf16>+reduce" if L.cbim_conv3d_wgrad_last_kernel() == 1 else \
+        lkw = L.cbim_conv3d_wgrad_last_kernel()
+        name = "k_wgrad_r32<bf16>+reduce" if lkw == 1 else "k_pw_wgrad<bf16>+reduce" if lkw == 2 else \
             "k_conv_wgrad<%s>+reduce" % ("bf16" if d.dtype == 1 else "f32")
         nbytes = d.N * d.Do * d.Ho * d.Wo * (d.Cin + d.Cout) * x.element_size() + dw.numel() * 4
         PROFILE.append((name, flops, e0, e1,

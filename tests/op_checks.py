@@ -1042,6 +1042,12 @@ def check_conv_pw(dev, N=2, Cin=64, Cout=96, dhw=(5, 6, 7), act="relu", seed=71)
         if act == "relu":
             g2, sums2 = ops.conv_dgrad(dyl, wpd, geom, mask_x=al, mask_stats=None)
             out += [g2, sums2]
+        else:
+            out += [g, sums1]
+        dw = ops.conv_wgrad(xl, xs, dyl, geom)                   # k_pw_wgrad + reduce | k_conv_wgrad + reduce
+        kern.append(10 + L.cbim_conv3d_wgrad_last_kernel())
+        dw0 = ops.conv_wgrad(xl, None, dyl, geom)
+        out += [dw, dw0]
         return [o.float().cpu() for o in out]
 
     old = L.cbim_conv_pw_enable(0)
@@ -1052,11 +1058,11 @@ def check_conv_pw(dev, N=2, Cin=64, Cout=96, dhw=(5, 6, 7), act="relu", seed=71)
     finally:
         L.cbim_conv_pw_enable(old)
     n = len(kern) // 2
-    assert all(kk != 4 for kk in kern[:n]) and all(kk == 4 for kk in kern[n:]), f"kernels selected: {kern}"
+    assert all(kk not in (4, 12) for kk in kern[:n]) and all(kk in (4, 12) for kk in kern[n:]), f"kernels selected: {kern}"
     names = ["fwd+IN+res", "fwd stats", "raw fwd", "raw stats", "fwd+IN (no stats)", "dgrad", "masked dgrad+acc", "bwd sums",
-             "dgrad masked by a", "bwd sums (a)"]
+             "dgrad masked by a", "bwd sums (a)", "wgrad (IN + act on load)", "wgrad (raw input)"]
     for nm, r, g_ in zip(names, ref, got):
-        tol = 1e-4 if nm in ("fwd stats", "raw stats", "bwd sums", "bwd sums (a)") else 4e-3   # bf16 outputs: one rounding apart at most
+        tol = 1e-4 if nm in ("fwd stats", "raw stats", "bwd sums", "bwd sums (a)") or nm.startswith("wgrad") else 4e-3   # bf16 outputs: one rounding apart
         scale = float(r.abs().max()) + 1e-12
         err = float((g_ - r).abs().max()) / scale
         assert err < tol, f"pw vs igemm: {nm} {err:.3e}"
@@ -1070,3 +1076,7 @@ def check_conv_pw(dev, N=2, Cin=64, Cout=96, dhw=(5, 6, 7), act="relu", seed=71)
     assert relerr(from_cl(got[2]), F.conv3d(xr, wr)) < 1e-2, "raw fwd vs torch"
     gr = F.conv_transpose3d(from_cl(dyl.float().cpu()), wr)
     assert relerr(from_cl(got[5]), gr) < 1e-2, "dgrad vs torch"
+    dyr = from_cl(dyl.float().cpu())
+    dwr = torch.einsum("ncdhw,nkdhw->ck", dyr, a)
+    assert relerr(got[10].reshape(Cout, Cin), dwr) < 2e-3, "wgrad vs torch"
+    assert relerr(got[11].reshape(Cout, Cin), torch.einsum("ncdhw,nkdhw->ck", dyr, xr)) < 2e-3, "raw wgrad vs torch"
