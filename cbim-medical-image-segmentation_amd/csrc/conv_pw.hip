@@ -71,7 +71,11 @@ template <int ACT> __device__ __forceinline__ float pw_actg(float x, int rt) {
 }
 
 // grid.x = N * Pn * n_wblk (output-channel block fastest: the workgroups that share rows are neighbours in time)
-template <int NTW, int ACT>
+// KS = 1: a workgroup tile is 128 rows, wave w owns rows 32 w .. 32 w + 31 over the whole K.
+// KS = 4 (low-resolution layers with a long K — 8^3 1280->320 is 4 row tiles x 5 channel blocks = 20 workgroups of 80 dependent
+//         k-groups each): a tile is 32 rows, the four waves split the k-groups, their partial accumulators meet in the LDS
+//         transposition tiles and wave (nt mod 4) finishes n-tile nt — four times the workgroups, a quarter of the chain.
+template <int NTW, int ACT, int KS>
 __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
   typedef bf16_tag T;
   constexpr int CPC = 8, OCH = 4, IT = 2;
@@ -89,6 +93,8 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
   if (p.in_stats) {
     for (int i = tid; i < p.Cin * 2; i += PW_NT) stL[i] = p.in_stats[(size_t)n * p.Cin * 2 + i];
   }
+  if (KS == 4)      // only the wave that finishes an n-tile writes its record: the other waves' slots stay empty
+    for (int i = tid; i < PW_NW * NTW * 32 * 3; i += PW_NT) red[i] = 0.f;
   __syncthreads();
   const unsigned char* const xn = (const unsigned char*)p.x + (size_t)n * p.S * p.x_stride * 2;
   const unsigned char* const wb = (const unsigned char*)p.w;
@@ -106,6 +112,10 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
   }
   const unsigned b_step = (unsigned)(2 * p.BNp) * 16u;            // one k-group further
   const int nsteps = p.nch * 2;
+  constexpr int ROWS = KS == 4 ? 32 : PW_ROWS;
+  const int spw = (nsteps + 3) / 4;
+  const int s_lo = KS == 4 ? wave * spw : 0;
+  const int s_hi = KS == 4 ? (s_lo + spw < nsteps ? s_lo + spw : nsteps) : nsteps;
   const int t_begin = strip * p.tiles_per_strip;
   int t_end = t_begin + p.tiles_per_strip;
   if (t_end > p.tiles_per_n) t_end = p.tiles_per_n;
@@ -113,7 +123,7 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
   const int cc = lane % OCH;
 
   for (int t = t_begin; t < t_end; ++t) {
-    const int64_t row0 = (int64_t)t * PW_ROWS + wave * 32;
+    const int64_t row0 = (int64_t)t * ROWS + (KS == 4 ? 0 : wave * 32);
     const int64_t arow = row0 + li;
     const bool a_in = arow < p.S;
     const unsigned char* const ap = xn + (size_t)(a_in ? arow : 0) * p.x_stride * 2 + half * 16;
@@ -138,19 +148,19 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
     u32x4 a_q[PD], b_q[PD][NTW];
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
-      a_q[u] = u < nsteps ? load_a(u) : u32x4{0u, 0u, 0u, 0u};
+      a_q[u] = s_lo + u < s_hi ? load_a(s_lo + u) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) b_q[u][nt] = u < nsteps ? load_b(u, nt) : u32x4{0u, 0u, 0u, 0u};
+      for (int nt = 0; nt < NTW; ++nt) b_q[u][nt] = s_lo + u < s_hi ? load_b(s_lo + u, nt) : u32x4{0u, 0u, 0u, 0u};
     }
-    for (int s0 = 0; s0 < nsteps; s0 += PD) {
+    for (int s0 = s_lo; s0 < s_hi; s0 += PD) {
 #pragma unroll
       for (int u = 0; u < PD; ++u) {
         const int s = s0 + u;
-        if (s < nsteps) {                              // wave-uniform
+        if (s < s_hi) {                                // wave-uniform
           u32x4 a = a_q[u], bb[NTW];
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) bb[nt] = b_q[u][nt];
-          if (s + PD < nsteps) {
+          if (s + PD < s_hi) {
             a_q[u] = load_a(s + PD);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) b_q[u][nt] = load_b(s + PD, nt);
@@ -188,19 +198,28 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
           mr[j] = p.m_stats[((size_t)n * p.Cout + cch0 + j) * 2 + 1];
         }
       }
-      pw_wave_sync();                                   // the previous n-tile's scratch reads are done
+      if (KS == 4) __syncthreads(); else pw_wave_sync();   // the previous n-tile's scratch reads are done
 #pragma unroll
       for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[nt][r];
-      pw_wave_sync();
+      if (KS == 4) __syncthreads(); else pw_wave_sync();
+      const bool mine = KS != 4 || wave == (nt & 3);        // KS: wave (nt mod 4) adds the four partial tiles and finishes nt
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
+        if (!mine) continue;
         const int vr = (lane + 64 * it) / OCH;
         const int64_t row = row0 + vr;
         const bool inb = c_ok && row < p.S;
         float v[CPC];
 #pragma unroll
         for (int j4 = 0; j4 < CPC; j4 += 4) {
-          const f32x4 q4 = *(const f32x4*)(scr + vr * 32 + cc * CPC + j4);
+          f32x4 q4 = *(const f32x4*)((KS == 4 ? scr_all : scr) + vr * 32 + cc * CPC + j4);
+          if (KS == 4) {
+#pragma unroll
+            for (int g = 1; g < PW_NW; ++g) {             // wave order
+              const f32x4 o4 = *(const f32x4*)(scr_all + g * 1024 + vr * 32 + cc * CPC + j4);
+              q4.x += o4.x; q4.y += o4.y; q4.z += o4.z; q4.w += o4.w;
+            }
+          }
           v[j4] = q4.x; v[j4 + 1] = q4.y; v[j4 + 2] = q4.z; v[j4 + 3] = q4.w;
         }
         if (it == 0 && !p.mx) {
@@ -234,7 +253,7 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
           *(u32x4*)((unsigned char*)p.y + (grow * p.y_stride + cch0) * 2) = Elem<T>::pack(v);
         }
       }
-      if (p.partials) {
+      if (p.partials && mine) {
 #pragma unroll
         for (int msk = OCH; msk < 64; msk <<= 1) {
           cnt += __shfl_xor(cnt, msk, 64);
@@ -426,8 +445,8 @@ extern "C" int cbim_conv_pw_enable(int on) {
   return old;
 }
 
-static void pw_strips(int64_t S, int* tiles, int* tps, int* Pn) {
-  const int64_t t = (S + PW_ROWS - 1) / PW_ROWS;
+static void pw_strips(int64_t S, int rows, int* tiles, int* tps, int* Pn) {
+  const int64_t t = (S + rows - 1) / rows;
   int64_t per = (t + 511) / 512;
   if (per < 1) per = 1;
   *tiles = (int)t; *tps = (int)per; *Pn = (int)((t + per - 1) / per);
@@ -439,10 +458,25 @@ static bool pw_desc_ok(const cbim_conv_desc* d) {
          (int64_t)d->Do * d->Ho * d->Wo * PW_ROWS < ((int64_t)1 << 40);
 }
 
+// output channels per wave and the K-split form, from the descriptor alone (cbim_conv_pw_records must agree with the launch)
+static void pw_plan(const cbim_conv_desc* d, int* ntw, int* ks) {
+  static const int ks_env = getenv("CBIM_PW_KSPLIT") ? atoi(getenv("CBIM_PW_KSPLIT")) : 1;   // tools/ only: 0 = never split K
+  const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
+  const int64_t row_wgs = (int64_t)d->N * ((S + PW_ROWS - 1) / PW_ROWS);
+  int n = d->Cout <= 32 ? 1 : (d->Cout <= 64 ? 2 : 4);
+  // 128 channels per wave when that still gives every CU a few workgroups, else 64 / 32
+  if (n == 4 && row_wgs * ((d->Cout + 127) / 128) < 512) n = 2;
+  const int nsteps = (d->Cin + 31) / 32 * 2;
+  *ks = 1;
+  if (ks_env && n <= 2 && nsteps >= 8 && row_wgs * ((d->Cout + n * 32 - 1) / (n * 32)) < 384) *ks = 4;
+  *ntw = n;
+}
+
 int cbim_conv_pw_records(const cbim_conv_desc* d) {
   if (!pw_desc_ok(d)) return 0;
-  int tiles, tps, Pn;
-  pw_strips((int64_t)d->Do * d->Ho * d->Wo, &tiles, &tps, &Pn);
+  int tiles, tps, Pn, ntw, ks;
+  pw_plan(d, &ntw, &ks);
+  pw_strips((int64_t)d->Do * d->Ho * d->Wo, ks == 4 ? 32 : PW_ROWS, &tiles, &tps, &Pn);
   return Pn;
 }
 
@@ -454,11 +488,11 @@ bool cbim_conv_pw_eligible(const cbim_conv_desc* d, int64_t x_stride, const void
   return true;
 }
 
-template <int NTW>
+template <int NTW, int KS>
 static int pw_launch_n(const PwParams& p, dim3 grid, size_t smem, int act, hipStream_t st) {
-  if (act == CBIM_ACT_RELU) CBIM_LAUNCH((k_conv_pw<NTW, CBIM_ACT_RELU>), grid, dim3(PW_NT), smem, st, p);
-  else if (act == CBIM_ACT_NONE) CBIM_LAUNCH((k_conv_pw<NTW, CBIM_ACT_NONE>), grid, dim3(PW_NT), smem, st, p);
-  else CBIM_LAUNCH((k_conv_pw<NTW, -1>), grid, dim3(PW_NT), smem, st, p);
+  if (act == CBIM_ACT_RELU) CBIM_LAUNCH((k_conv_pw<NTW, CBIM_ACT_RELU, KS>), grid, dim3(PW_NT), smem, st, p);
+  else if (act == CBIM_ACT_NONE) CBIM_LAUNCH((k_conv_pw<NTW, CBIM_ACT_NONE, KS>), grid, dim3(PW_NT), smem, st, p);
+  else CBIM_LAUNCH((k_conv_pw<NTW, -1, KS>), grid, dim3(PW_NT), smem, st, p);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
@@ -472,23 +506,23 @@ int cbim_conv_pw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
   p.N = d->N; p.S = (int64_t)d->Do * d->Ho * d->Wo; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
   p.nch = (d->Cin + 31) / 32;
   p.BNp = d->Cout <= 32 ? 32 : 64;
-  pw_strips(p.S, &p.tiles_per_n, &p.tiles_per_strip, &p.Pn);
+  int ntw, ks;
+  pw_plan(d, &ntw, &ks);
+  pw_strips(p.S, ks == 4 ? 32 : PW_ROWS, &p.tiles_per_n, &p.tiles_per_strip, &p.Pn);
   p.P = P > p.Pn ? P : p.Pn;
   CBIM_CHECK(!partials || P >= p.Pn, CBIM_EINVAL, "pointwise conv: %d statistics records < %d", P, p.Pn);
-  // output channels per wave: 128 when that still gives every CU a few workgroups, else 64 / 32
   const int64_t row_wgs = (int64_t)d->N * p.Pn;
-  int ntw = d->Cout <= 32 ? 1 : (d->Cout <= 64 ? 2 : 4);
-  if (ntw == 4 && row_wgs * ((d->Cout + 127) / 128) < 512) ntw = 2;
   p.n_wblk = (d->Cout + ntw * 32 - 1) / (ntw * 32);
   const size_t smem = (size_t)PW_NW * 4096 + (size_t)PW_NW * ntw * 32 * 3 * 4 + (size_t)d->Cin * 2 * 4;
   CBIM_CHECK(row_wgs * p.n_wblk < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "pointwise conv: grid too large");
   dim3 grid((unsigned)(row_wgs * p.n_wblk));
   hipStream_t st = (hipStream_t)stream;
   // a mask tensor without statistics is the activated tensor itself (ReLU): xh := a, as in conv_igemm.hip
+  if (ks == 4) return ntw == 1 ? pw_launch_n<1, 4>(p, grid, smem, d->act, st) : pw_launch_n<2, 4>(p, grid, smem, d->act, st);
   switch (ntw) {
-    case 1: return pw_launch_n<1>(p, grid, smem, d->act, st);
-    case 2: return pw_launch_n<2>(p, grid, smem, d->act, st);
-    default: return pw_launch_n<4>(p, grid, smem, d->act, st);
+    case 1: return pw_launch_n<1, 1>(p, grid, smem, d->act, st);
+    case 2: return pw_launch_n<2, 1>(p, grid, smem, d->act, st);
+    default: return pw_launch_n<4, 1>(p, grid, smem, d->act, st);
   }
 }
 
