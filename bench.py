@@ -11,7 +11,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with
   roofline     : matrix-core roofline of the dominant kernel (all launches of that conv kernel in a step),
                  algorithmic FLOPs / HIP-event time measured live on the launch stream
   cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/) timed on this box's
-                 host cores on one 1x1x128^3 volume (rank 0, N=1 only)
+                 host cores on one 1x1x128^3 volume (rank 0, N=1 only): one warm-up pass + two timed passes, median
+  secondary    : (default N=1 run only) configs[2] MedFormer, configs[4] SwinUNETR and configs[3] ResUNet + on-device
+                 augmentation timed in the same process for 10 replayed steps each (--secondary 0 skips them)
 """
 import argparse
 import json
@@ -63,6 +65,10 @@ def parse():
                     help="fused: cbim_amd FusedAdamW (one multi-tensor launch); torch: torch.optim.AdamW(fused=True)")
     ap.add_argument("--model", default="resunet", choices=["resunet", "medformer", "swin_unetr"],
                     help="resunet = BASELINE configs[1] (the headline); medformer = configs[2] (AMOS yaml, aux loss); swin_unetr = configs[4] (4-modality input, feature 48, 4 classes)")
+    ap.add_argument("--secondary", type=int, default=1,
+                    help="1 (default; N=1 headline run only): after the headline timing, also time MedFormer (configs[2]), SwinUNETR "
+                         "(configs[4]) and --aug 1 (configs[3]) for --secondary-steps replayed steps each and report them in `secondary`")
+    ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--aug", type=int, default=0,
                     help="1: draw each step's volume with the on-device augmentation pipeline (configs[3]): affine "
                          "scale/rotate + centre crop from a (size+40)^3 source, then the intensity ops")
@@ -77,10 +83,23 @@ def synthetic(batch, classes, size, device, seed):
     return x.to(device), lab.to(device)
 
 
+def _timed_reps(one, size, cores, kind, what):
+    """one warm-up pass (a 64^3 volume: thread pool, allocator, oneDNN primitive caches) + two timed passes of
+    the real sample; the MEDIAN of the timed passes (= their mean for two) is reported, every pass is listed."""
+    warm = one(min(64, size))
+    reps = [one(size), one(size)]
+    dt = sorted(reps)[len(reps) // 2 - 1] * 0.5 + sorted(reps)[len(reps) // 2] * 0.5
+    scale = (128.0 / size) ** 3 if size != 128 else 1.0
+    return {"value": 1.0 / (dt * scale), "unit": "volumes/s", "cores": cores, "threads": torch.get_num_threads(), "kind": kind,
+            "reps_s": [round(t, 2) for t in reps], "warmup_s": round(warm, 2),
+            "sample": f"1 volume 1x1x{size}^3 fwd+loss+bwd, {what}, fp32, torch {torch.__version__} CPU, median of 2 timed passes "
+                      f"{dt:.1f} s after one 64^3 warm-up pass" + ("" if size == 128 else f" (scaled x{scale:.2f} to 128^3)")}
+
+
 def cpu_baseline(args):
-    """fwd + loss + bwd of ONE 1x1x128^3 volume on the host cores (bounded sample: ~20-30 s).  When the reference
-    checkout is mounted (the build container) its own modules are timed (kind "reference"); on the GPU box, where
-    /root/reference does not exist, the oracle — the restatement pinned to it by tests/golden — is (kind "port")."""
+    """fwd + loss + bwd of ONE 1x1x128^3 volume on the host cores (bounded sample: 2 x ~20-30 s + a 64^3 warm-up).  When the
+    reference checkout is mounted (the build container) its own modules are timed (kind "reference"); on the GPU box, where
+    /root/reference does not exist, the oracle - the restatement pinned to it by tests/golden - is (kind "port")."""
     from oracle import loss_ref, medformer_ref, unet_ref
     cores = min(os.cpu_count() or 1, 128)
     torch.set_num_threads(cores)
@@ -89,52 +108,51 @@ def cpu_baseline(args):
         if r is not None:
             return r
     ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
-    s = args.cpu_size
-    x, lab = synthetic(1, args.classes, s, "cpu", 2023)
-    w = torch.ones(args.classes)
-    w[0] = 0.5
-    if args.model == "swin_unetr":
-        from cbim_amd.model.dim3 import SwinUNETR   # only as the weight initialiser (reference parameter layout)
-        from oracle import swin_unetr_ref
-        torch.manual_seed(2023)
-        sd = {k: v.detach() for k, v in SwinUNETR((s,) * 3, 4, 4, feature_size=48).state_dict().items()}
-        for v in sd.values():
-            if v.is_floating_point():
-                v.requires_grad_(True)
-        x = torch.cat([x] + [synthetic(1, 4, s, "cpu", 3000 + i)[0] for i in range(3)], 1)
-        lab = lab.clamp_(max=3)
-        w = w[:4]
-        t0 = time.perf_counter()
-        loss = loss_ref.ce_dice_loss(swin_unetr_ref.swin_unetr_forward(sd, x), lab, w)
-    elif args.model == "medformer":
-        from cbim_amd.model.dim3 import MedFormer   # only as the weight initialiser (reference parameter layout)
-        torch.manual_seed(2023)
-        sd = {k: v.detach().requires_grad_(True) for k, v in MedFormer(1, args.classes, **MEDFORMER_AMOS).state_dict().items()}
-        m = MEDFORMER_AMOS
-        t0 = time.perf_counter()
-        outs = medformer_ref.medformer_forward(sd, x, map_size=m["map_size"], num_heads=m["num_heads"],
-                                               fusion_heads=m["fusion_heads"], fusion_depth=m["fusion_depth"],
-                                               kernel_size=m["kernel_size"], scale=m["scale"], act="relu", aux_loss=True)
-        loss = sum(0.5 * loss_ref.ce_dice_loss(o, lab, w) for o in outs)
-    else:
-        sd = unet_ref.make_unet_state_dict(1, args.base, args.classes, ks, "BasicBlock", seed=2023)
-        sd = {k: v.requires_grad_(True) for k, v in sd.items()}
-        t0 = time.perf_counter()
-        logits = unet_ref.unet_forward(sd, x, scale=sc, kernel_size=ks, block="BasicBlock")
-        loss = loss_ref.ce_dice_loss(logits, lab, w)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    scale = (128.0 / s) ** 3 if s != 128 else 1.0
-    return {"value": 1.0 / (dt * scale), "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"1 volume 1x1x{s}^3 fwd+loss+bwd, fp32, torch {torch.__version__} CPU, {dt:.1f} s"
-                      + ("" if s == 128 else f" (scaled x{scale:.2f} to 128^3)")}
+
+    def one(s):
+        x, lab = synthetic(1, args.classes, s, "cpu", 2023)
+        w = torch.ones(args.classes)
+        w[0] = 0.5
+        if args.model == "swin_unetr":
+            from cbim_amd.model.dim3 import SwinUNETR   # only as the weight initialiser (reference parameter layout)
+            from oracle import swin_unetr_ref
+            torch.manual_seed(2023)
+            sd = {k: v.detach() for k, v in SwinUNETR((s,) * 3, 4, 4, feature_size=48).state_dict().items()}
+            for v in sd.values():
+                if v.is_floating_point():
+                    v.requires_grad_(True)
+            x = torch.cat([x] + [synthetic(1, 4, s, "cpu", 3000 + i)[0] for i in range(3)], 1)
+            lab = lab.clamp_(max=3)
+            w = w[:4]
+            t0 = time.perf_counter()
+            loss = loss_ref.ce_dice_loss(swin_unetr_ref.swin_unetr_forward(sd, x), lab, w)
+        elif args.model == "medformer":
+            from cbim_amd.model.dim3 import MedFormer   # only as the weight initialiser (reference parameter layout)
+            torch.manual_seed(2023)
+            sd = {k: v.detach().requires_grad_(True) for k, v in MedFormer(1, args.classes, **MEDFORMER_AMOS).state_dict().items()}
+            m = MEDFORMER_AMOS
+            t0 = time.perf_counter()
+            outs = medformer_ref.medformer_forward(sd, x, map_size=m["map_size"], num_heads=m["num_heads"],
+                                                   fusion_heads=m["fusion_heads"], fusion_depth=m["fusion_depth"],
+                                                   kernel_size=m["kernel_size"], scale=m["scale"], act="relu", aux_loss=True)
+            loss = sum(0.5 * loss_ref.ce_dice_loss(o, lab, w) for o in outs)
+        else:
+            sd = unet_ref.make_unet_state_dict(1, args.base, args.classes, ks, "BasicBlock", seed=2023)
+            sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+            t0 = time.perf_counter()
+            logits = unet_ref.unet_forward(sd, x, scale=sc, kernel_size=ks, block="BasicBlock")
+            loss = loss_ref.ce_dice_loss(logits, lab, w)
+        loss.backward()
+        return time.perf_counter() - t0
+
+    return _timed_reps(one, args.cpu_size, cores, "port", "oracle/ (the CPU restatement of the reference)")
 
 
 def _reference_cpu_baseline(args, cores):
-    """The reference's own UNet + CrossEntropyLoss + DiceLoss (BASELINE.md §4.1) on the host cores."""
+    """The reference's own UNet + CrossEntropyLoss + DiceLoss (BASELINE.md 4.1) on the host cores."""
     # the reference's package __init__ files import the whole model zoo (monai, torchvision: not installed): the
-    # import shim of SURVEY.md §8c (also used by tests/golden/make_golden.py) registers the two packages as bare
-    # namespaces, so only model/dim3/unet.py and its own imports are executed — unmodified reference code
+    # import shim of SURVEY.md 8c (also used by tests/golden/make_golden.py) registers the two packages as bare
+    # namespaces, so only model/dim3/unet.py and its own imports are executed - unmodified reference code
     import importlib
     import types
     ref = "/root/reference"
@@ -159,23 +177,22 @@ def _reference_cpu_baseline(args, cores):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
-    torch.manual_seed(2023)
-    s = args.cpu_size
-    net = RefUNet(1, args.base, scale=[[2, 2, 2]] * 4, kernel_size=[[3, 3, 3]] * 5, num_classes=args.classes,
-                  block="BasicBlock", norm="in")
-    x, lab = synthetic(1, args.classes, s, "cpu", 2023)
-    w = torch.ones(args.classes)
-    w[0] = 0.5
-    ce, dl = torch.nn.CrossEntropyLoss(weight=w), RefDice()
-    t0 = time.perf_counter()
-    out = net(x)
-    loss = ce(out, lab.squeeze(1)) + dl(out, lab)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    scale = (128.0 / s) ** 3 if s != 128 else 1.0
-    return {"value": 1.0 / (dt * scale), "unit": "volumes/s", "cores": cores, "kind": "reference",
-            "sample": f"1 volume 1x1x{s}^3 fwd+loss+bwd, /root/reference model.dim3.unet.UNet + CE + DiceLoss, fp32, "
-                      f"torch {torch.__version__} CPU, {dt:.1f} s" + ("" if s == 128 else f" (scaled x{scale:.2f} to 128^3)")}
+
+    def one(s):
+        torch.manual_seed(2023)
+        net = RefUNet(1, args.base, scale=[[2, 2, 2]] * 4, kernel_size=[[3, 3, 3]] * 5, num_classes=args.classes,
+                      block="BasicBlock", norm="in")
+        x, lab = synthetic(1, args.classes, s, "cpu", 2023)
+        w = torch.ones(args.classes)
+        w[0] = 0.5
+        ce, dl = torch.nn.CrossEntropyLoss(weight=w), RefDice()
+        t0 = time.perf_counter()
+        out = net(x)
+        loss = ce(out, lab.squeeze(1)) + dl(out, lab)
+        loss.backward()
+        return time.perf_counter() - t0
+
+    return _timed_reps(one, args.cpu_size, cores, "reference", "/root/reference model.dim3.unet.UNet + CE + DiceLoss")
 
 
 def spawn_ranks(args):
@@ -199,38 +216,14 @@ def spawn_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
-    assert local < torch.cuda.device_count(), f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} GPU(s) visible"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
-    elif args.ddp1:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-
+def time_model(args, dev, rank, world):
+    """Build the model `args.model` names, warm up, capture the step into a hipGraph (args.graph) and time args.steps steps
+    between barrier + synchronize pairs.  Returns a dict: ms per step (max over ranks), the step callables, the model facts."""
     import cbim_amd
-    from cbim_amd import _lib, ops
+    from cbim_amd import ops
     from cbim_amd.model.dim3 import MedFormer, SwinUNETR, UNet
-    from cbim_amd.training import augmentation as aug
     from cbim_amd.parallel import GradAllReduce
     from cbim_amd.training.losses import DiceCELoss
-    assert _lib.backend() == "hip-gfx950"
-    cbim_amd.set_compute_dtype(args.dtype)
-
     torch.manual_seed(2023)
     ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
     in_ch = 1
@@ -351,8 +344,88 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
-    value = world * 1.0 / (dt / args.steps)       # 1 volume per GPU per step (train_ddp.py:330)
     loss_val = float(loss.item())
+
+    return {"ms": ms, "dt": dt, "graph": bool(use_graph), "loss": loss_val, "in_ch": in_ch, "classes": args.classes,
+            "eager_step": eager_step, "ddp": ddp, "grad_bucket": grad_bucket, "keep": (net, opt, crit, x, lab)}
+
+
+def _release(dev):
+    """drop the previous model's graph, buffers and packed-weight table before the next model is built"""
+    import gc
+    from cbim_amd import ops
+    gc.collect()
+    ops.PACKED.clear()
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+
+
+def secondary(args, dev):
+    """BASELINE.json configs[2] (MedFormer), configs[4] (SwinUNETR, per-GPU part) and configs[3] (ResUNet with the on-device
+    augmentation pipeline, per-GPU part) timed in THIS process after the headline: `--secondary-steps` replayed steps each
+    (same step definition: forward + CE/Dice loss + backward + fused AdamW under hipGraph replay).  A failure of one of them is
+    reported in its row and never costs the headline line."""
+    import argparse as _ap
+    rows = {}
+    peak = PEAK_BF16_TFLOPS
+    for key, model, aug, fwd in (("medformer", "medformer", 0, FWD_FLOPS_128_MEDFORMER),
+                                 ("swin_unetr", "swin_unetr", 0, FWD_FLOPS_128_SWIN),
+                                 ("resunet_aug", "resunet", 1, FWD_FLOPS_128)):
+        a = _ap.Namespace(**vars(args))
+        a.model, a.aug, a.steps, a.warmup = model, aug, args.secondary_steps, 3
+        _release(dev)
+        t0 = time.perf_counter()
+        try:
+            rr = time_model(a, dev, 0, 1)
+            row = {"ms_per_step": rr["ms"], "volumes_per_s": 1e3 / rr["ms"], "steps": a.steps, "warmup": a.warmup,
+                   "graph": rr["graph"], "final_loss": rr["loss"], "step_flops": 3.0 * fwd,
+                   "step_frac_mfma": 3.0 * fwd / (rr["ms"] * 1e-3) / 1e12 / peak,
+                   "workload": {"medformer": "configs[2]: 3D MedFormer (amos_ct/medformer_3d.yaml, aux loss), 1x1x128^3, 16 classes",
+                                "swin_unetr": "configs[4] per GPU: SwinUNETR feature 48, 1x4x128^3, 4 classes (the five MONAI conv "
+                                              "blocks of its oracle are parity-unpinned: monai is not installable here)",
+                                "resunet_aug": "configs[3] per GPU: ResUNet 1x1x128^3 + HBM-resident volumes, affine / crop / "
+                                               "intensity augmentation on the device, prefetched on a side stream"}[key]}
+            del rr
+        except Exception as e:      # noqa: BLE001 - the row says what happened
+            row = {"error": f"{type(e).__name__}: {e}"[:300]}
+        row["wall_s"] = round(time.perf_counter() - t0, 1)
+        rows[key] = row
+    _release(dev)
+    return rows
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    assert local < torch.cuda.device_count(), f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} GPU(s) visible"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    elif args.ddp1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+
+    import cbim_amd
+    from cbim_amd import _lib, ops
+    assert _lib.backend() == "hip-gfx950"
+    cbim_amd.set_compute_dtype(args.dtype)
+
+    r = time_model(args, dev, rank, world)
+    ms, use_graph, loss_val, in_ch, eager_step, ddp, grad_bucket = (r["ms"], r["graph"], r["loss"], r["in_ch"], r["eager_step"],
+                                                                     r["ddp"], r["grad_bucket"])
+    value = world * 1.0 / (ms * 1e-3)             # 1 volume per GPU per step (train_ddp.py:330)
 
     out = {
         "metric": "3D volumes/sec (fwd+bwd) at 128^3", "value": value, "unit": "volumes/s",
@@ -360,7 +433,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": {"medformer": "3D MedFormer (amos_ct/medformer_3d.yaml, aux loss)",
-                                "swin_unetr": "SwinUNETR (feature 48, 4-modality BraTS-style input)",
+                                "swin_unetr": "SwinUNETR (feature 48, 4-modality BraTS-style input; MONAI conv blocks of its oracle parity-unpinned)",
                                 "resunet": "3D UNet ResBasicBlock (amos_ct/resunet_3d.yaml)"}[args.model]
                                + f", 1x{in_ch}x{args.size}^3 per GPU, {args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
                                + (", HBM-resident volumes + on-device augmentation (crop/affine/intensity, dataset_amos_ct recipe) prefetched on a side stream" if args.aug else "")
@@ -402,11 +475,17 @@ def main():
         # inside this process); null when no recorded pass covers this kernel / dtype / model
         traffic = None
         # (per model: profiles/r04_traffic.json holds the ResUNet passes, r04_traffic_<model>.json the two others)
-        names = {"resunet": ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_j_traffic.json", "r01_c_traffic.json"),
-                 "medformer": ("r04_traffic_medformer.json",), "swin_unetr": ("r04_traffic_swin_unetr.json",)}[args.model]
+        names = {"resunet": ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_j_traffic.json", "r01_c_traffic.json"),
+                 "medformer": ("r05_traffic_medformer.json", "r04_traffic_medformer.json"),
+                 "swin_unetr": ("r05_traffic_swin_unetr.json", "r04_traffic_swin_unetr.json")}[args.model]
         tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in names) if os.path.isfile(q)), "")
+        step_traffic = None
         if args.size == 128 and os.path.isfile(tpath):
-            traffic = (json.load(open(tpath)).get(dom) or {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            # (rounds 2-4 recorded the k_conv3_rw row under the name of the kernel it grew out of)
+            row = tj.get(dom) or tj.get({"k_conv3_rw<bf16>": "k_conv3_r32<bf16>"}.get(dom, dom)) or {}
+            traffic = row.get("hbm_bytes_per_launch")
+            step_traffic = (tj.get("_step") or {}).get("hbm_bytes_per_step")
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": f / tsec / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": f / tsec / 1e12 / peak, "traffic": traffic,
@@ -417,8 +496,17 @@ def main():
             "step_flops": step_flops, "step_achieved": step_flops / (ms * 1e-3) / 1e12,
             "step_frac_mfma": step_flops / (ms * 1e-3) / 1e12 / peak,
             "step_frac_hbm": (ALG_BYTES_BF16 * (2 if args.dtype == "fp32" else 1) / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+            # HBM bytes of ONE step summed over every kernel of the step (the same committed PMC passes, all kernel families)
+            # over the 11.6 GB compulsory model of SURVEY.md 8d; null until a pass that covers every kernel is recorded
+            "step_traffic_bytes": step_traffic if args.model == "resunet" and args.dtype == "bf16" else None,
+            "step_traffic_ratio": (step_traffic / ALG_BYTES_BF16) if (step_traffic and args.model == "resunet" and args.dtype == "bf16") else None,
             "kernels": table,
         }
+    # ---- configs[2], [4], [3] on the same clock (same process, same box): 10 replayed steps each -----------------------------
+    if (args.secondary and rank == 0 and world == 1 and not dist.is_initialized() and args.model == "resunet" and not args.aug
+            and args.size == 128 and args.dtype == "bf16"):
+        del r, eager_step
+        out["secondary"] = secondary(args, dev)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -40,6 +40,9 @@ struct PwParams {
   int BNp;                 // n-block width of the packed weight image (32 | 64)
   int P, Pn;               // records per image of `partials` (allocated / written by this launch)
   int tiles_per_n, tiles_per_strip, n_wblk;
+  // token mode (TK: nn.Linear over channels-last token rows, cbim_token_linear): bias float [Cout]; fp32 residual rows; the
+  // activation whose derivative at the mask tensor (the pre-activation h of the MLP) multiplies the result; fp32 output rows
+  const float* bias; const float* res32; int64_t res32_stride; int mask_act; int y32;
 };
 
 #ifdef CBIM_EMU
@@ -75,8 +78,15 @@ template <int ACT> __device__ __forceinline__ float pw_actg(float x, int rt) {
 // KS = 4 (low-resolution layers with a long K — 8^3 1280->320 is 4 row tiles x 5 channel blocks = 20 workgroups of 80 dependent
 //         k-groups each): a tile is 32 rows, the four waves split the k-groups, their partial accumulators meet in the LDS
 //         transposition tiles and wave (nt mod 4) finishes n-tile nt — four times the workgroups, a quarter of the chain.
-template <int NTW, int ACT, int KS>
+// TK (round 5): token mode — the same row GEMM as nn.Linear of the SwinUNETR trunk (qkv / proj / MLP / patch merging,
+//   /root/reference/model/dim3/swin_unetr.py:467-490,552,640-643,707-731): x rows in bf16 or fp32 (X32: converted in
+//   registers, the fp32 residual-stream gradient feeds the input-gradient GEMMs as it is), ACT applied to x on load WITHOUT
+//   statistics (GELU of the MLP: the activated tensor is never stored), epilogue = + bias, * act'(mask) (the MLP's GELU' at the
+//   stored pre-activation), + fp32 residual, bf16 or fp32 store — replaces aten::linear (hipBLASLt), aten::gelu(_backward),
+//   the bias / residual adds and the fp32 <-> bf16 casts around them
+template <int NTW, int ACT, int KS, bool TK = false, bool X32 = false>
 __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
+  static_assert(TK || !X32, "fp32 rows: token mode only");
   typedef bf16_tag T;
   constexpr int CPC = 8, OCH = 4, IT = 2;
   PW_DYN_SMEM(smem);
@@ -96,7 +106,8 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
   if (KS == 4)      // only the wave that finishes an n-tile writes its record: the other waves' slots stay empty
     for (int i = tid; i < PW_NW * NTW * 32 * 3; i += PW_NT) red[i] = 0.f;
   __syncthreads();
-  const unsigned char* const xn = (const unsigned char*)p.x + (size_t)n * p.S * p.x_stride * 2;
+  constexpr int XES = X32 ? 4 : 2;                                 // bytes per element of an x row
+  const unsigned char* const xn = (const unsigned char*)p.x + (size_t)n * p.S * p.x_stride * XES;
   const unsigned char* const wb = (const unsigned char*)p.w;
   // byte offsets of the lane's B fragments inside a (chunk, k-group) slab of the packed image
   unsigned boff[NTW];
@@ -126,7 +137,7 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
     const int64_t row0 = (int64_t)t * ROWS + (KS == 4 ? 0 : wave * 32);
     const int64_t arow = row0 + li;
     const bool a_in = arow < p.S;
-    const unsigned char* const ap = xn + (size_t)(a_in ? arow : 0) * p.x_stride * 2 + half * 16;
+    const unsigned char* const ap = xn + (size_t)(a_in ? arow : 0) * p.x_stride * XES + half * (8 * XES);
     f32x16 acc[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -135,7 +146,12 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
     auto load_a = [&](int s) -> u32x4 {          // s = 2 * chunk + kg: slot (2 kg + half) of the chunk = bytes s * 32 + half * 16
       const int c0 = s * 16 + half * 8;
       if (!a_in || c0 >= p.Cin) return u32x4{0u, 0u, 0u, 0u};
-      return *(const u32x4*)(ap + (size_t)s * 32);
+      return *(const u32x4*)(ap + (size_t)s * (16 * XES));
+    };
+    auto load_a2 = [&](int s) -> u32x4 {         // X32: channels 4..7 of the lane's 8 (the second 16 bytes of its fp32 slot)
+      const int c0 = s * 16 + half * 8;
+      if (!X32 || !a_in || c0 >= p.Cin) return u32x4{0u, 0u, 0u, 0u};
+      return *(const u32x4*)(ap + (size_t)s * (16 * XES) + 16);
     };
     auto load_b = [&](int s, int nt) -> u32x4 {
       if (!bok[nt]) return u32x4{0u, 0u, 0u, 0u};
@@ -145,10 +161,11 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
     // lookahead the deep-stage layers (Cin 1280: 80 steps of a few hundred cycles of MFMA work) waited out an L2 round trip per
     // step — 30 us for 8^3 1280->320
     constexpr int PD = NTW == 4 ? 2 : 4;           // (four sets of the 128-channel form do not fit 256 registers)
-    u32x4 a_q[PD], b_q[PD][NTW];
+    u32x4 a_q[PD], a_q2[X32 ? PD : 1], b_q[PD][NTW];
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       a_q[u] = s_lo + u < s_hi ? load_a(s_lo + u) : u32x4{0u, 0u, 0u, 0u};
+      if (X32) a_q2[u] = s_lo + u < s_hi ? load_a2(s_lo + u) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) b_q[u][nt] = s_lo + u < s_hi ? load_b(s_lo + u, nt) : u32x4{0u, 0u, 0u, 0u};
     }
@@ -158,14 +175,31 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
         const int s = s0 + u;
         if (s < s_hi) {                                // wave-uniform
           u32x4 a = a_q[u], bb[NTW];
+          if (X32) {                                   // fp32 row slot -> the bf16 fragment (raw values ride the ring: the
+            const u32x4 a2 = a_q2[u];                  //  conversion waits for the load only here, one ring depth later)
+            const float f8[CPC] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                                   __uint_as_float(a2.x), __uint_as_float(a2.y), __uint_as_float(a2.z), __uint_as_float(a2.w)};
+            a = Elem<T>::pack(f8);
+          }
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) bb[nt] = b_q[u][nt];
           if (s + PD < s_hi) {
             a_q[u] = load_a(s + PD);
+            if (X32) a_q2[u] = load_a2(s + PD);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) b_q[u][nt] = load_b(s + PD, nt);
           }
-          if (p.in_stats) {
+          if (TK && ACT != CBIM_ACT_NONE) {            // activation on load, no statistics (the MLP's GELU)
+            const int c0 = s * 16 + half * 8;
+            if (a_in && c0 < p.Cin) {
+              float f[CPC];
+              Elem<T>::unpack(a, f);
+#pragma unroll
+              for (int j = 0; j < CPC; ++j) f[j] = pw_actf<ACT>(f[j], p.act);
+              a = Elem<T>::pack(f);
+            }
+          }
+          if (!TK && p.in_stats) {
             const int c0 = s * 16 + half * 8;
             if (a_in && c0 < p.Cin) {
               float f[CPC];
@@ -198,6 +232,11 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
           mr[j] = p.m_stats[((size_t)n * p.Cout + cch0 + j) * 2 + 1];
         }
       }
+      float bv[CPC];
+      if (TK) {
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) bv[j] = (p.bias && c_ok) ? p.bias[cch0 + j] : 0.f;
+      }
       if (KS == 4) __syncthreads(); else pw_wave_sync();   // the previous n-tile's scratch reads are done
 #pragma unroll
       for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[nt][r];
@@ -226,6 +265,33 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
           // common shift per channel for the wave: the value lane `cc` holds for its first row
 #pragma unroll
           for (int j = 0; j < CPC; ++j) sh[j] = __shfl(v[j], cc, 64);
+        }
+        if (TK) {
+          if (inb) {
+            const size_t grow = (size_t)n * p.S + (size_t)row;
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) v[j] += bv[j];
+            if (p.mx) {                                 // * act'(h): the input gradient of the MLP's second Linear at the stored
+              float f[CPC];                             //   pre-activation (d/dh of act(h) . W2)
+              Elem<T>::unpack(*(const u32x4*)((const unsigned char*)p.mx + (grow * p.mx_stride + cch0) * 2), f);
+#pragma unroll
+              for (int j = 0; j < CPC; ++j) v[j] *= act_grad(f[j], p.mask_act);
+            }
+            if (p.res32) {
+              const float* rp = p.res32 + grow * p.res32_stride + cch0;
+              const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+              v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+            if (p.y32) {
+              float* yp = (float*)p.y + grow * p.y_stride + cch0;
+              *(f32x4*)yp = f32x4{v[0], v[1], v[2], v[3]};
+              *(f32x4*)(yp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+              *(u32x4*)((unsigned char*)p.y + (grow * p.y_stride + cch0) * 2) = Elem<T>::pack(v);
+            }
+          }
+          continue;
         }
         if (inb) {
           const size_t grow = (size_t)n * p.S + (size_t)row;
@@ -334,9 +400,12 @@ struct PwgParams {
   const void* x; int64_t x_stride; const float* in_stats; const void* dy; int64_t dy_stride; float* ws;
   int N; int64_t S; int Cin, Cout, act;
   int strips, rows_per_strip, ci_blocks, Cout_pad, Cin_pad;
+  int act_raw;             // token mode: ACT applied to x without statistics (the MLP's GELU on the stored pre-activation)
 };
 
-template <int ACT>
+// X32 / DY32 (round 5, token Linears): the operand rows are fp32 (the residual-stream gradient; the patch-embedding input) and
+// are rounded to bf16 on the way into LDS — no separate cast pass
+template <int ACT, bool X32 = false, bool DY32 = false>
 __global__ void __launch_bounds__(PW_NT, 2) k_pw_wgrad(PwgParams p) {
   typedef bf16_tag T;
   constexpr int CPC = 8;
@@ -363,26 +432,35 @@ __global__ void __launch_bounds__(PW_NT, 2) k_pw_wgrad(PwgParams p) {
       rstd[j] = p.in_stats[((size_t)n * p.Cin + ci_c + j) * 2 + 1];
     }
   }
-  const unsigned char* const dyn = (const unsigned char*)p.dy + ((size_t)n * p.S * p.dy_stride + co_c) * 2;
-  const unsigned char* const xn = (const unsigned char*)p.x + ((size_t)n * p.S * p.x_stride + ci_c) * 2;
+  constexpr int DES = DY32 ? 4 : 2, XES = X32 ? 4 : 2;
+  const unsigned char* const dyn = (const unsigned char*)p.dy + ((size_t)n * p.S * p.dy_stride + co_c) * DES;
+  const unsigned char* const xn = (const unsigned char*)p.x + ((size_t)n * p.S * p.x_stride + ci_c) * XES;
   const unsigned sub_off = (unsigned)(slot >> 2), in_off = (unsigned)(slot & 3) * 16u;
-  u32x4 gd[4], gx[4];
+  u32x4 gd[4], gx[4], gd2[DY32 ? 4 : 1], gx2[X32 ? 4 : 1];
   auto issue = [&](int64_t r0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t r = r0 + vrow + 32 * u;
       const bool in = r < r_end;
-      gd[u] = (in && co_ok) ? *(const u32x4*)(dyn + (size_t)r * p.dy_stride * 2) : u32x4{0u, 0u, 0u, 0u};
-      gx[u] = (in && ci_ok) ? *(const u32x4*)(xn + (size_t)r * p.x_stride * 2) : u32x4{0u, 0u, 0u, 0u};
+      gd[u] = (in && co_ok) ? *(const u32x4*)(dyn + (size_t)r * p.dy_stride * DES) : u32x4{0u, 0u, 0u, 0u};
+      gx[u] = (in && ci_ok) ? *(const u32x4*)(xn + (size_t)r * p.x_stride * XES) : u32x4{0u, 0u, 0u, 0u};
+      if (DY32) gd2[u] = (in && co_ok) ? *(const u32x4*)(dyn + (size_t)r * p.dy_stride * DES + 16) : u32x4{0u, 0u, 0u, 0u};
+      if (X32) gx2[u] = (in && ci_ok) ? *(const u32x4*)(xn + (size_t)r * p.x_stride * XES + 16) : u32x4{0u, 0u, 0u, 0u};
     }
+  };
+  auto to_bf16 = [](const u32x4& a, const u32x4& b) -> u32x4 {      // 8 fp32 -> 8 bf16
+    const float f8[CPC] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                           __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+    return Elem<T>::pack(f8);
   };
   auto commit = [&](int buf, int64_t r0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int v = vrow + 32 * u;
       const int64_t r = r0 + v;
-      u32x4 xa = gx[u];
-      if (p.in_stats && r < r_end && ci_ok) {
+      if (DY32) gd[u] = to_bf16(gd[u], gd2[u]);
+      u32x4 xa = X32 ? to_bf16(gx[u], gx2[u]) : gx[u];
+      if ((p.in_stats || p.act_raw) && r < r_end && ci_ok) {
         float f[CPC];
         Elem<T>::unpack(xa, f);
 #pragma unroll
@@ -506,6 +584,7 @@ int cbim_conv_pw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
   p.N = d->N; p.S = (int64_t)d->Do * d->Ho * d->Wo; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
   p.nch = (d->Cin + 31) / 32;
   p.BNp = d->Cout <= 32 ? 32 : 64;
+  p.bias = nullptr; p.res32 = nullptr; p.res32_stride = 0; p.mask_act = 0; p.y32 = 0;
   int ntw, ks;
   pw_plan(d, &ntw, &ks);
   pw_strips(p.S, ks == 4 ? 32 : PW_ROWS, &p.tiles_per_n, &p.tiles_per_strip, &p.Pn);
@@ -561,6 +640,7 @@ int cbim_conv_pw_wgrad_launch(const cbim_conv_desc* d, const void* x, int64_t x_
   PwgParams p;
   p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.dy = dy; p.dy_stride = dy_stride; p.ws = ws;
   p.N = d->N; p.S = (int64_t)d->Do * d->Ho * d->Wo; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
+  p.act_raw = 0;
   int cob;
   pwg_cfg(d, &p.strips, &p.rows_per_strip, &cob, &p.ci_blocks);
   p.Cout_pad = cob * 64; p.Cin_pad = p.ci_blocks * 64;
@@ -572,6 +652,110 @@ int cbim_conv_pw_wgrad_launch(const cbim_conv_desc* d, const void* x, int64_t x_
   else if (act == CBIM_ACT_NONE) CBIM_LAUNCH((k_pw_wgrad<CBIM_ACT_NONE>), grid, dim3(PW_NT), 0, st, p);
   else CBIM_LAUNCH((k_pw_wgrad<-1>), grid, dim3(PW_NT), 0, st, p);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+// ---- token mode: nn.Linear over channels-last token rows (SwinUNETR trunk) ---------------------------------------------------
+int cbim_wgrad_reduce_launch(const float* ws, float* dw, int n_slabs, int taps, int Cout, int Cin, int Cout_pad, int Cin_pad,
+                             void* stream);      // conv_wgrad.hip
+
+static void tok_desc(cbim_conv_desc* d, int64_t rows, int Cin, int Cout) {
+  // rows as a [1][D][H][W] volume (the descriptor carries 32-bit extents)
+  int64_t W = rows, H = 1, D = 1;
+  while (W >= ((int64_t)1 << 30)) { W = (W + 1) / 2; H *= 2; }
+  d->dtype = CBIM_BF16; d->N = 1; d->Di = d->Do = (int)D; d->Hi = d->Ho = (int)H; d->Wi = d->Wo = (int)W;
+  d->Cin = Cin; d->Cout = Cout; d->kD = d->kH = d->kW = 1; d->pD = d->pH = d->pW = 0; d->act = CBIM_ACT_NONE;
+}
+
+template <int NTW, int KS, int ACT, bool X32>
+static int tok_launch_a(const PwParams& p, dim3 grid, size_t smem, hipStream_t st) {
+  CBIM_LAUNCH((k_conv_pw<NTW, ACT, KS, true, X32>), grid, dim3(PW_NT), smem, st, p);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+template <int NTW, int KS>
+static int tok_launch_n(const PwParams& p, dim3 grid, size_t smem, int act_in, int x32, hipStream_t st) {
+  if (x32) return tok_launch_a<NTW, KS, CBIM_ACT_NONE, true>(p, grid, smem, st);
+  if (act_in == CBIM_ACT_NONE) return tok_launch_a<NTW, KS, CBIM_ACT_NONE, false>(p, grid, smem, st);
+  return tok_launch_a<NTW, KS, -1, false>(p, grid, smem, st);
+}
+
+extern "C" int cbim_token_linear(const void* x, int x_dtype, int64_t x_stride, int act_in, const void* w_packed, const float* bias,
+                                 const float* res, int64_t res_stride, const void* mask, int64_t mask_stride, int mask_act,
+                                 void* y, int y_dtype, int64_t y_stride, int64_t rows, int Cin, int Cout, void* stream) {
+  CBIM_CHECK(x && w_packed && y && rows >= 1, CBIM_EINVAL, "token linear: null operand / no rows");
+  CBIM_CHECK((x_dtype == CBIM_F32 || x_dtype == CBIM_BF16) && (y_dtype == CBIM_F32 || y_dtype == CBIM_BF16), CBIM_EINVAL, "token linear: bad dtype");
+  CBIM_CHECK(Cin % 8 == 0 && Cout % 8 == 0 && Cin >= 8 && Cout >= 8 && Cin <= 4096, CBIM_EUNSUPPORTED,
+             "token linear: %d -> %d features (multiples of 8, at most 4096 inputs)", Cin, Cout);
+  CBIM_CHECK(x_stride % 8 == 0 && y_stride % 8 == 0 && (!res || res_stride % 4 == 0) && (!mask || mask_stride % 8 == 0), CBIM_EUNSUPPORTED,
+             "token linear: row strides must keep 16-byte chunks aligned");
+  CBIM_CHECK(!(x_dtype == CBIM_F32 && act_in != CBIM_ACT_NONE), CBIM_EUNSUPPORTED, "token linear: activation on load takes bf16 rows");
+  cbim_conv_desc d;
+  tok_desc(&d, rows, Cin, Cout);
+  PwParams p;
+  p.x = x; p.x_stride = x_stride; p.in_stats = nullptr; p.w = w_packed;
+  p.res = nullptr; p.res_stride = 0; p.mx = mask; p.mx_stride = mask_stride; p.m_stats = nullptr;
+  p.y = y; p.y_stride = y_stride; p.partials = nullptr;
+  p.N = 1; p.S = rows; p.Cin = Cin; p.Cout = Cout; p.act = act_in;
+  p.nch = (Cin + 31) / 32;
+  p.BNp = Cout <= 32 ? 32 : 64;
+  p.bias = bias; p.res32 = res; p.res32_stride = res_stride; p.mask_act = mask_act; p.y32 = y_dtype == CBIM_F32;
+  int ntw, ks;
+  pw_plan(&d, &ntw, &ks);
+  pw_strips(p.S, ks == 4 ? 32 : PW_ROWS, &p.tiles_per_n, &p.tiles_per_strip, &p.Pn);
+  p.P = p.Pn;
+  p.n_wblk = (Cout + ntw * 32 - 1) / (ntw * 32);
+  const size_t smem = (size_t)PW_NW * 4096 + (size_t)PW_NW * ntw * 32 * 3 * 4 + (size_t)Cin * 2 * 4;
+  CBIM_CHECK((int64_t)p.Pn * p.n_wblk < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "token linear: grid too large");
+  dim3 grid((unsigned)((int64_t)p.Pn * p.n_wblk));
+  hipStream_t st = (hipStream_t)stream;
+  const int x32 = x_dtype == CBIM_F32;
+  if (ks == 4) return ntw == 1 ? tok_launch_n<1, 4>(p, grid, smem, act_in, x32, st) : tok_launch_n<2, 4>(p, grid, smem, act_in, x32, st);
+  switch (ntw) {
+    case 1: return tok_launch_n<1, 1>(p, grid, smem, act_in, x32, st);
+    case 2: return tok_launch_n<2, 1>(p, grid, smem, act_in, x32, st);
+    default: return tok_launch_n<4, 1>(p, grid, smem, act_in, x32, st);
+  }
+}
+
+extern "C" size_t cbim_token_linear_wgrad_workspace(int64_t rows, int Cin, int Cout) {
+  cbim_conv_desc d;
+  tok_desc(&d, rows, Cin, Cout);
+  int strips, rps, cob, cib;
+  pwg_cfg(&d, &strips, &rps, &cob, &cib);
+  return (size_t)strips * cob * 64 * cib * 64 * sizeof(float);
+}
+
+extern "C" int cbim_token_linear_wgrad(const void* x, int x_dtype, int64_t x_stride, int act_in, const void* dy, int dy_dtype,
+                                       int64_t dy_stride, float* dw, void* workspace, size_t ws_bytes, int64_t rows, int Cin,
+                                       int Cout, void* stream) {
+  CBIM_CHECK(x && dy && dw && rows >= 1 && rows < ((int64_t)1 << 31), CBIM_EINVAL, "token linear wgrad: null operand / bad row count");
+  CBIM_CHECK(Cin % 8 == 0 && Cout % 8 == 0 && x_stride % 8 == 0 && dy_stride % 8 == 0, CBIM_EUNSUPPORTED,
+             "token linear wgrad: %d -> %d features, strides %lld / %lld", Cin, Cout, (long long)x_stride, (long long)dy_stride);
+  CBIM_CHECK(!(x_dtype == CBIM_F32 && act_in != CBIM_ACT_NONE), CBIM_EUNSUPPORTED, "token linear wgrad: activation on load takes bf16 rows");
+  const size_t need = cbim_token_linear_wgrad_workspace(rows, Cin, Cout);
+  CBIM_CHECK(workspace && ws_bytes >= need, CBIM_EWORKSPACE, "token linear wgrad workspace %zu < %zu", ws_bytes, need);
+  cbim_conv_desc d;
+  tok_desc(&d, rows, Cin, Cout);
+  PwgParams p;
+  p.x = x; p.x_stride = x_stride; p.in_stats = nullptr; p.dy = dy; p.dy_stride = dy_stride; p.ws = (float*)workspace;
+  p.N = 1; p.S = rows; p.Cin = Cin; p.Cout = Cout; p.act = act_in; p.act_raw = act_in != CBIM_ACT_NONE;
+  int cob;
+  pwg_cfg(&d, &p.strips, &p.rows_per_strip, &cob, &p.ci_blocks);
+  p.Cout_pad = cob * 64; p.Cin_pad = p.ci_blocks * 64;
+  dim3 grid((unsigned)p.strips, (unsigned)(cob * p.ci_blocks));
+  hipStream_t st = (hipStream_t)stream;
+  const bool x32 = x_dtype == CBIM_F32, d32 = dy_dtype == CBIM_F32;
+  if (act_in != CBIM_ACT_NONE) {
+    if (d32) CBIM_LAUNCH((k_pw_wgrad<-1, false, true>), grid, dim3(PW_NT), 0, st, p);
+    else CBIM_LAUNCH((k_pw_wgrad<-1, false, false>), grid, dim3(PW_NT), 0, st, p);
+  } else if (x32) {
+    if (d32) CBIM_LAUNCH((k_pw_wgrad<CBIM_ACT_NONE, true, true>), grid, dim3(PW_NT), 0, st, p);
+    else CBIM_LAUNCH((k_pw_wgrad<CBIM_ACT_NONE, true, false>), grid, dim3(PW_NT), 0, st, p);
+  } else {
+    if (d32) CBIM_LAUNCH((k_pw_wgrad<CBIM_ACT_NONE, false, true>), grid, dim3(PW_NT), 0, st, p);
+    else CBIM_LAUNCH((k_pw_wgrad<CBIM_ACT_NONE, false, false>), grid, dim3(PW_NT), 0, st, p);
+  }
+  if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
+  return cbim_wgrad_reduce_launch((const float*)workspace, dw, p.strips, 1, Cout, Cin, p.Cout_pad, p.Cin_pad, stream);
 }
 
 CBIM_DEFINE_WARM(pw)

@@ -590,4 +590,15 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
+// the fixed-order slab reduce for launchers in other files (conv_pw.hip's token Linears): slabs [n_slabs][taps][Cout_pad][Cin_pad]
+int cbim_wgrad_reduce_launch(const float* ws, float* dw, int n_slabs, int taps, int Cout, int Cin, int Cout_pad, int Cin_pad,
+                             void* stream) {
+  const int64_t total = (int64_t)taps * Cout * Cin;
+  int64_t blocks = (total + 63) / 64;
+  if (blocks > 4096) blocks = 4096;
+  CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, ws, dw, n_slabs, taps, Cout, Cin, Cout_pad,
+              Cin_pad, total);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
 CBIM_DEFINE_WARM(wgrad)

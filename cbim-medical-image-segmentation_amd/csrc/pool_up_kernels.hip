@@ -59,10 +59,11 @@ __global__ void __launch_bounds__(NT) k_maxpool_bwd(const void* __restrict__ dy,
                                                     int D, int H, int W, int C, int sD, int sH, int sW,
                                                     int Do, int Ho, int Wo, int64_t total) {
   constexpr int CPC = Elem<T>::CPC;
-  (void)total;
   const unsigned cch = (unsigned)(C / CPC);
   const unsigned per_plane = (unsigned)H * (unsigned)W * cch;
-  const unsigned n = blockIdx.y / (unsigned)D, d = blockIdx.y % (unsigned)D;
+  // gridDim.y is capped at 65535: a block strides over the (image, depth) planes (N * D of any size)
+  for (unsigned plane = blockIdx.y; plane < (unsigned)total; plane += gridDim.y) {
+  const unsigned n = plane / (unsigned)D, d = plane % (unsigned)D;
   const unsigned dz = d / (unsigned)sD;
   for (unsigned j = blockIdx.x * NT + threadIdx.x; j < per_plane; j += gridDim.x * NT) {
     const unsigned cc = j % cch, hw = j / cch;
@@ -85,6 +86,7 @@ __global__ void __launch_bounds__(NT) k_maxpool_bwd(const void* __restrict__ dy,
     }
     const size_t row = (((size_t)n * D + d) * H + h) * W + w;
     st_chunk<T>(dx, row * C + (size_t)cc * CPC, Elem<T>::pack(f));
+  }
   }
 }
 
@@ -726,11 +728,13 @@ extern "C" int cbim_maxpool3d_bwd(int dtype, const void* dy, const uint8_t* idx,
   int cpc = dtype == CBIM_BF16 ? 8 : 4;
   int64_t total = (int64_t)N * D * H * W * (C / cpc);
   const int64_t per_plane = (int64_t)H * W * (C / cpc);
-  CBIM_CHECK(per_plane < ((int64_t)1 << 31) && (int64_t)N * D < 65536, CBIM_EUNSUPPORTED, "maxpool_bwd: plane of %lld chunks x %lld planes", (long long)per_plane, (long long)N * D);
+  const int64_t planes = (int64_t)N * D;
+  CBIM_CHECK(per_plane < ((int64_t)1 << 31) && planes < ((int64_t)1 << 31), CBIM_EUNSUPPORTED, "maxpool_bwd: plane of %lld chunks x %lld planes", (long long)per_plane, (long long)planes);
+  (void)total;
   int64_t bx = (per_plane + NT - 1) / NT;
   if (bx > 64) bx = 64;
-  DISPATCH_T(dtype, k_maxpool_bwd, dim3((unsigned)bx, (unsigned)(N * D)), (hipStream_t)stream, dy, idx, dx, D, H, W, C, sD,
-             sH, sW, Do, Ho, Wo, total);
+  DISPATCH_T(dtype, k_maxpool_bwd, dim3((unsigned)bx, (unsigned)(planes < 65535 ? planes : 65535)), (hipStream_t)stream, dy, idx, dx, D, H, W, C, sD,
+             sH, sW, Do, Ho, Wo, planes);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

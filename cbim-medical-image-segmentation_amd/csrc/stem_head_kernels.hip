@@ -872,11 +872,14 @@ __global__ void __launch_bounds__(NT, 1) k_head_bwd_k(const void* __restrict__ x
 // Registers ~64, 8 waves per workgroup, steps are wave-private (no workgroup barrier inside the loop); the next step's
 // global loads are in flight while a step is computed.  Slab per workgroup [K][Cin+1] as before (k_head_bwd_reduce4).
 static constexpr int HM_NW = 8;     // waves per workgroup
-template <int CP>
+// HC = 16-channel tiles of a row (Cin = 16 HC: round 5 — the 48-channel head of SwinUNETR ran the vector-ALU kernel because this one
+// counted whole 32-channel units); CP = 32-channel units of the dx product (its lane layout is 4 groups x 8 consecutive channels):
+// the half unit of an odd HC has zero weight rows and no stores
+template <int HC>
 __global__ void __launch_bounds__(HM_NW * 64) k_head_bwd_mfma(const void* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ dz, void* __restrict__ dx,
                                                               float* __restrict__ ws, int64_t S, int K, int64_t vox_per_block) {
-  constexpr int Cin = 32 * CP, ROWB = Cin * 2, XT = 32 * ROWB, DZT = 16 * 64, WT = XT + DZT, NX = 2 * CP;
+  constexpr int CP = (HC + 1) / 2, Cin = 16 * HC, ROWB = Cin * 2, XT = 32 * ROWB, DZT = 16 * 64, WT = XT + DZT, NX = HC;
   CBIM_DYN_SMEM(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
   unsigned char* xs = smem + wave * WT;
@@ -890,12 +893,12 @@ __global__ void __launch_bounds__(HM_NW * 64) k_head_bwd_mfma(const void* __rest
       const int c = 32 * p + 8 * (li >> 2) + 4 * t + (li & 3);
       float f[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = 8 * g + j < K ? w[(size_t)(8 * g + j) * Cin + c] : 0.f;
+      for (int j = 0; j < 8; ++j) f[j] = (8 * g + j < K && c < Cin) ? w[(size_t)(8 * g + j) * Cin + c] : 0.f;
       wa[p][t] = Elem<bf16_tag>::pack(f);
     }
-  f32x4 acc[2 * CP];
+  f32x4 acc[HC];
 #pragma unroll
-  for (int ct = 0; ct < 2 * CP; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ct = 0; ct < HC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbv = 0.f;
   const int64_t v_begin = (int64_t)blockIdx.x * vox_per_block;
   int64_t v_end = v_begin + vox_per_block;
@@ -936,7 +939,7 @@ __global__ void __launch_bounds__(HM_NW * 64) k_head_bwd_mfma(const void* __rest
     hd_wave_sync();
     // dw: contraction over the 32 voxels
 #pragma unroll
-    for (int ct = 0; ct < 2 * CP; ++ct) {
+    for (int ct = 0; ct < HC; ++ct) {
       const unsigned char* a = xs + (8 * g + (li >> 2)) * ROWB + ct * 32 + (li & 3) * 8;
       const u32x2 b0 = hd_tr16_b64(a), b1 = hd_tr16_b64(a + 4 * ROWB);
       const u32x4 bf = u32x4{b0.x, b0.y, b1.x, b1.y};
@@ -957,7 +960,8 @@ __global__ void __launch_bounds__(HM_NW * 64) k_head_bwd_mfma(const void* __rest
           const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[p][0]), __builtin_bit_cast(bf16x8, ef), z, 0, 0, 0);
           const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[p][1]), __builtin_bit_cast(bf16x8, ef), z, 0, 0, 0);
           const float f[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-          *(u32x4*)(dxn + (size_t)(v + 16 * h + li) * ROWB + (size_t)(32 * p + 8 * g) * 2) = Elem<bf16_tag>::pack(f);
+          if (32 * p + 8 * g < Cin)      // (the half unit of an odd HC)
+            *(u32x4*)(dxn + (size_t)(v + 16 * h + li) * ROWB + (size_t)(32 * p + 8 * g) * 2) = Elem<bf16_tag>::pack(f);
         }
       }
     }
@@ -975,7 +979,7 @@ __global__ void __launch_bounds__(HM_NW * 64) k_head_bwd_mfma(const void* __rest
   float* red = (float*)smem;                         // [wave][16][Cin]
   float* rdb = red + HM_NW * 16 * Cin;               // [wave][16]
 #pragma unroll
-  for (int ct = 0; ct < 2 * CP; ++ct)
+  for (int ct = 0; ct < HC; ++ct)
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[(wave * 16 + 4 * g + i) * Cin + 16 * ct + li] = acc[ct][i];
   dbv += __shfl_xor(dbv, 16);
@@ -993,6 +997,13 @@ __global__ void __launch_bounds__(HM_NW * 64) k_head_bwd_mfma(const void* __rest
   }
 }
 static_assert(HM_NW * (32 * 256 + 16 * 64) <= 160 * 1024, "LDS");
+template <int HC> static bool hm_raise_lds() {       // more than 64 KiB of dynamic LDS needs the attribute (HC >= 7)
+#ifndef CBIM_EMU
+  return hipFuncSetAttribute((const void*)k_head_bwd_mfma<HC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+#else
+  return true;
+#endif
+}
 
 // slabs -> dw, db: 64 outputs x 4 slab phases per workgroup, fixed order
 __global__ void __launch_bounds__(NT) k_head_bwd_reduce4(const float* __restrict__ ws, float* __restrict__ dw,
@@ -1231,31 +1242,30 @@ extern "C" int cbim_head_bwd(int dtype, const void* x, const float* w, const flo
     const int cpc = dtype == CBIM_BF16 ? 8 : 4, cch = Cin / cpc;
     // (bf16: one chunk per wave — two would need 2 x 16 x 8 accumulators + as many weight registers per lane: spills;
     //  wider rows, e.g. MedFormer's aux head on 128 channels, run as blockIdx.z groups of 4 chunks)
-    if (K <= 16 && g_head_mfma && dtype == CBIM_BF16 && Cin % 32 == 0 && Cin <= 128 && S % 32 == 0) {
+    if (K <= 16 && g_head_mfma && dtype == CBIM_BF16 && Cin % 16 == 0 && Cin <= 128 && S % 32 == 0) {
       // matrix-core form (k_head_bwd_mfma): workgroups of 8 waves x 32-voxel steps, two per CU at full size
       int nb = head_bwd_blocks(S);
       int64_t vpb = (S + nb - 1) / nb;
       vpb = (vpb + HM_NW * 32 - 1) / (HM_NW * 32) * (HM_NW * 32);
       nb = (int)((S + vpb - 1) / vpb);
-      const int CP = Cin / 32;
+      const int HC = Cin / 16;
       const size_t sm = (size_t)HM_NW * (32 * Cin * 2 + 16 * 64);
       dim3 grid((unsigned)nb, (unsigned)N);
       float* wsf = (float*)workspace;
-      static bool attr_done = false;
-      if (!attr_done) {
-#ifndef CBIM_EMU
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_head_bwd_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipError_t e2 = hipFuncSetAttribute((const void*)k_head_bwd_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        CBIM_CHECK(e1 == hipSuccess && e2 == hipSuccess, CBIM_ELAUNCH, "head bwd: cannot raise the dynamic LDS limit");
-#endif
-        attr_done = true;
+#define HM_LAUNCH(H)                                                                                                       \
+      case H: {                                                                                                            \
+        static bool attr_done = false;                                                                                     \
+        if (!attr_done && sm > 64 * 1024) {                                                                                \
+          CBIM_CHECK(hm_raise_lds<H>(), CBIM_ELAUNCH, "head bwd: cannot raise the dynamic LDS limit");                     \
+          attr_done = true;                                                                                                \
+        }                                                                                                                  \
+        CBIM_LAUNCH((k_head_bwd_mfma<H>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb);              \
+      } break;
+      switch (HC) {
+        HM_LAUNCH(1) HM_LAUNCH(2) HM_LAUNCH(3) HM_LAUNCH(4) HM_LAUNCH(5) HM_LAUNCH(6) HM_LAUNCH(7)
+        default: HM_LAUNCH(8)
       }
-      switch (CP) {
-        case 1: CBIM_LAUNCH((k_head_bwd_mfma<1>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb); break;
-        case 2: CBIM_LAUNCH((k_head_bwd_mfma<2>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb); break;
-        case 3: CBIM_LAUNCH((k_head_bwd_mfma<3>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb); break;
-        default: CBIM_LAUNCH((k_head_bwd_mfma<4>), grid, dim3(HM_NW * 64), sm, st, x, w, dlogits, dx, wsf, S, K, vpb); break;
-      }
+#undef HM_LAUNCH
       if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
       const int npairs = K * (Cin + 1);
       CBIM_LAUNCH(k_head_bwd_reduce4, dim3((npairs + 63) / 64), dim3(NT), 0, st, (const float*)workspace, dw, db,

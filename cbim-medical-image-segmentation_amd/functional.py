@@ -97,9 +97,30 @@ def eager_only(fn):
     """Decorator of the model classes' forward: under the reference's optional `net = torch.compile(net)` wrapper
     (/root/reference/train.py:292-293) TorchDynamo must not trace into the engine — its operators are ctypes calls into
     libcbim_hip.so behind autograd Functions; the wrapped module then simply runs them eagerly (`net._orig_mod` is the engine
-    module, train.py:106)."""
-    dis = getattr(getattr(torch, "compiler", None), "disable", None)
-    return dis(fn) if dis is not None else fn
+    module, train.py:106).
+    The mark is dynamo's own attribute (`_torchdynamo_disable`, what torch.compiler.disable sets on the function it wraps),
+    attached WITHOUT importing torch._dynamo: `import cbim_amd.model` then neither pays for that import (seconds) nor fails when
+    it does; torch.compiler.disable itself is applied lazily, the first time the forward runs while dynamo is loaded."""
+    import functools
+    import sys
+    state = {"wrapped": None}
+
+    @functools.wraps(fn)
+    def forward(*args, **kwargs):
+        if "torch._dynamo" in sys.modules:          # someone (torch.compile) loaded dynamo: hand it the disabled function
+            w = state["wrapped"]
+            if w is None:
+                dis = getattr(getattr(torch, "compiler", None), "disable", None)
+                try:
+                    w = dis(fn) if dis is not None else fn
+                except Exception:                    # a broken dynamo install must not take eager training down with it
+                    w = fn
+                state["wrapped"] = w
+            return w(*args, **kwargs)
+        return fn(*args, **kwargs)
+
+    forward._torchdynamo_disable = True             # dynamo skips frames of functions carrying this mark
+    return forward
 
 
 class _GradAwareFunction(torch.autograd.Function):
@@ -403,16 +424,21 @@ class DiceCEFn(torch.autograd.Function):
         # out[3] = number of labels outside [0, C): the reference raises (scatter_ / CrossEntropyLoss); reading the
         # count is a device synchronisation, so it is only checked on request
         global _label_checks_left
+        capturing = logits.is_cuda and torch.cuda.is_current_stream_capturing()
         want = _CHECK_LABELS == "1" or (_CHECK_LABELS not in ("", "0") and _label_checks_left > 0)
-        if want and not (logits.is_cuda and torch.cuda.is_current_stream_capturing()):
+        acc = _label_bad.get(logits.device)
+        if acc is None and not capturing and _CHECK_LABELS not in ("", "0"):
+            # the device-side count of out-of-range labels (functional.check_labels), allocated on the FIRST eager call so that it
+            # exists — outside any graph's private pool — before a training step is captured into a hipGraph
+            acc = _label_bad[logits.device] = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        if want and not capturing:
             _label_checks_left -= 1
             bad = int(out[3].item())
             if bad:
                 raise IndexError(f"cbim_amd: {bad} label(s) outside [0, {int(logits.shape[1])}) (Target out of bounds)")
-        elif _CHECK_LABELS not in ("", "0") and not (logits.is_cuda and torch.cuda.is_current_stream_capturing()):
-            acc = _label_bad.get(logits.device)      # unchecked call: keep the count on the device (functional.check_labels)
-            if acc is None:
-                acc = _label_bad[logits.device] = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        elif acc is not None:
+            # unchecked call: keep the count on the device.  Under hipGraph capture the add is captured with the step, so every
+            # REPLAY keeps counting (the benchmarked mode); training.losses.check_labels() / the validation entry points read it
             acc += out[3:4].detach()
         ctx.save_for_backward(logits, labels, coef, weight if weight is not None else torch.empty(0))
         ctx.has_w = weight is not None
@@ -645,6 +671,69 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, weight, bias, eps, out_dtype=torch.float32):
     return LayerNormFn.apply(x, weight, bias, eps, out_dtype)
+
+
+class TokenLinearFn(_GradAwareFunction):
+    """nn.Linear over channels-last token rows on the engine's row-GEMM kernel (ops.token_linear, bf16 operands, fp32
+    accumulation) with the neighbouring element-wise work fused — the SwinUNETR trunk's qkv / proj / MLP / patch-merging /
+    patch-embedding Linears (/root/reference/model/dim3/swin_unetr.py:467-490,552,640-643,707-731):
+
+        y = act_in(x) @ W^T + b  [+ res]          act_in: GELU when x is the MLP's stored pre-activation h (the activated
+                                                  tensor is never written); res: the fp32 residual stream (y is then fp32)
+
+    x [..., Cin] bf16 (LayerNorm output / attention output / h) or fp32 (patch tokens); W fp32 [Cout, Cin(, 1...)] master
+    weights re-packed once per optimizer step (ops.PACKED).  Backward: dW = dy^T act_in(x) and db = column sums of dy on the
+    engine's kernels (dy taken in fp32 or bf16 as it arrives: no cast pass), dx = (dy @ W) * act_in'(x) in bf16, and dy itself
+    as the gradient of `res`."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act_in, res, out_dtype, need_dx):
+        Cout, Cin = int(w.shape[0]), int(w.numel() // w.shape[0])
+        shape = tuple(x.shape[:-1])
+        x2 = x.reshape(-1, Cin)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        g = ops.linear_geom(Cin, Cout)
+        train = _training(ctx)
+        wp, wpd = ops.packed_weights((w,), g, bool(need_dx) and train)
+        r2 = None
+        if res is not None:
+            r2 = res.reshape(-1, Cout)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        bias = b.detach().float().contiguous() if b is not None else None
+        y = ops.token_linear(x2, wp, bias, Cout, act_in=act_in, res=r2, out_dtype=torch.float32 if res is not None else out_dtype)
+        ctx.save_for_backward(x2)
+        ctx.cfg = (act_in, wpd, Cin, Cout, b is not None, res is not None, tuple(x.shape), tuple(w.shape), bool(need_dx))
+        ctx.w_param, ctx.b_param = ops.slot_of(w), ops.slot_of(b)
+        return y.view(shape + (Cout,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        act_in, wpd, Cin, Cout, has_b, has_res, x_shape, w_shape, need_dx = ctx.cfg
+        d2 = dy.reshape(-1, Cout)
+        if d2.dtype not in (torch.float32, torch.bfloat16):
+            d2 = d2.float()
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        dw = db = dx = None
+        if ctx.needs_input_grad[1]:
+            sw = ops.grad_slot(ctx.w_param)
+            dw = ops.token_linear_wgrad(x2, d2, act_in, out=None if sw is None else sw.view(Cout, Cin))
+            dw = sw if sw is not None else dw.view(w_shape)
+        if has_b and ctx.needs_input_grad[2]:
+            cp = 8 if d2.dtype == torch.bfloat16 else 4
+            db = ops.colsum(d2) if (Cout % cp == 0 and Cout // cp <= 256) else d2.float().sum(0)
+        if need_dx and ctx.needs_input_grad[0]:
+            # the forward layer's dgrad image is a [Cin x Cout] "weight": dx = dy @ W, times act_in'(x) where x is the stored
+            # pre-activation (the MLP's second Linear)
+            dx = ops.token_linear(d2, wpd, None, Cin, mask=x2 if act_in else None, mask_act=act_in, out_dtype=torch.bfloat16)
+            dx = dx.view(x_shape)
+        return dx, dw, db, None, (dy if has_res else None), None, None
+
+
+def token_linear(x, weight, bias, act_in=0, res=None, out_dtype=torch.bfloat16, need_dx=True):
+    return TokenLinearFn.apply(x, weight, bias, act_in, res, out_dtype, need_dx)
 
 
 class ResNormFn(torch.autograd.Function):

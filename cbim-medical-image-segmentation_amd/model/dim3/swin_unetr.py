@@ -32,6 +32,7 @@ from ...ops import ncdhw_to_ndhwc as ops_ncdhw_to_ndhwc
 _STEM_MFMA = os.environ.get("CBIM_SWIN_STEM_MFMA", "1") != "0"
 _EPS = 1e-5          # nn.InstanceNorm3d default (monai get_norm_layer("instance"))
 _LRELU = ACT["lrelu"]  # monai UnetResBlock act: LeakyReLU(0.01)
+_GELU = ACT["gelu"]    # monai MLPBlock act
 
 
 def _tup3(v):
@@ -156,6 +157,9 @@ class PatchEmbed(nn.Module):
             _, _, D, H, W = x.shape
         x = x.reshape(B, Cc, D // p[0], p[0], H // p[1], p[1], W // p[2], p[2]).permute(0, 2, 4, 6, 1, 3, 5, 7)
         tok = x.reshape(B, D // p[0], H // p[1], W // p[2], -1)
+        if _in_tree(tok, self.proj):
+            # the fp32 patch rows feed the row GEMM as they are (rounded to bf16 in registers); fp32 out = the residual stream
+            return Fn.token_linear(tok.contiguous(), self.proj.weight, self.proj.bias, out_dtype=torch.float32, need_dx=False)
         if _SPLITK_DW and tok.is_cuda and torch.is_grad_enabled() and self.proj.weight.requires_grad:
             # (the weight gradient is a 48 x 32 output over 262 144 tokens: one workgroup and 612 us in the library's
             #  default tiling; the split-K form of the other token Linears fills the chip)
@@ -165,6 +169,28 @@ class PatchEmbed(nn.Module):
 
 _TRUNK_AMP = os.environ.get("CBIM_SWIN_TRUNK_AMP", "1") != "0"
 _SPLITK_DW = os.environ.get("CBIM_SWIN_SPLITK_DW", "1") != "0"
+# round 5: the token Linears of the trunk on the engine's own row-GEMM kernel (functional.TokenLinearFn: bias, GELU-on-load,
+# GELU' mask and the fp32 residual add in the kernel) instead of F.linear (hipBLASLt) + ATen element-wise launches; bf16 engine
+# mode only (the fp32 parity mode keeps torch's fp32 GEMMs).  CBIM_SWIN_TOKEN_GEMM=0: the round-4 path (A/B)
+_TOKEN_GEMM = os.environ.get("CBIM_SWIN_TOKEN_GEMM", "1") != "0"
+
+
+def _on_engine_device(x) -> bool:
+    from ... import _lib
+    return x.device.type == ("cpu" if _lib.backend() == "emu" else "cuda")
+
+
+def _trunk_bf16(x) -> bool:
+    """True when the trunk's token Linears / GELU / window attention run in bf16 (the bf16 engine mode, like the reference under
+    AMP): LayerNorm and the residual stream stay fp32"""
+    return _on_engine_device(x) and Fn.compute_dtype() == torch.bfloat16 and _TRUNK_AMP
+
+
+def _in_tree(x, lin) -> bool:
+    w = lin.weight
+    cin = w.numel() // w.shape[0]
+    return (_TOKEN_GEMM and _trunk_bf16(x) and x.dtype in (torch.bfloat16, torch.float32) and cin % 8 == 0 and w.shape[0] % 8 == 0
+            and cin <= 4096 and w.dtype == torch.float32)
 
 
 class _TokenLinearFn(torch.autograd.Function):
@@ -229,8 +255,14 @@ class MLPBlock(nn.Module):
         self.linear1 = nn.Linear(hidden_size, mlp_dim)
         self.linear2 = nn.Linear(mlp_dim, hidden_size)
 
-    def forward(self, x):
-        return _token_linear(self.linear2, F.gelu(_token_linear(self.linear1, x)))
+    def forward(self, x, res=None):
+        """res: the fp32 residual stream to add (the block's `x + mlp(norm2(x))`, swin_unetr.py:552,640-643)"""
+        if _in_tree(x, self.linear1) and _in_tree(x, self.linear2):
+            h = Fn.token_linear(x, self.linear1.weight, self.linear1.bias)                       # pre-activation, bf16
+            return Fn.token_linear(h, self.linear2.weight, self.linear2.bias, act_in=_GELU, res=res,   # GELU on load, + res
+                                   out_dtype=torch.float32 if res is not None else torch.bfloat16)
+        y = _token_linear(self.linear2, F.gelu(_token_linear(self.linear1, x)))
+        return y if res is None else res + y
 
 
 def _relative_position_index(ws):
@@ -258,11 +290,17 @@ class WindowAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
-    def forward(self, h, window, shift):
-        qkv = _token_linear(self.qkv, h)
+    def forward(self, h, window, shift, res=None):
+        """res: the fp32 residual stream to add (the block's `x + attn(norm1(x))`, swin_unetr.py:539-549)"""
+        tree = _in_tree(h, self.qkv) and _in_tree(h, self.proj)
+        qkv = Fn.token_linear(h, self.qkv.weight, self.qkv.bias) if tree else _token_linear(self.qkv, h)
         o = Fn.WindowAttnFn.apply(qkv, self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
                                   self.window_size)
-        return _token_linear(self.proj, o)
+        if tree:
+            return Fn.token_linear(o, self.proj.weight, self.proj.bias, res=res,
+                                   out_dtype=torch.float32 if res is not None else torch.bfloat16)
+        y = _token_linear(self.proj, o)
+        return y if res is None else res + y
 
 
 class SwinTransformerBlock(nn.Module):
@@ -282,11 +320,11 @@ class SwinTransformerBlock(nn.Module):
         ss = tuple(0 if d <= w else s for d, w, s in zip(dims, self.window_size, self.shift_size))
         # bf16 engine mode: the token Linears (qkv, proj, MLP), GELU and the window-attention kernel run in bf16 like
         # the reference under AMP (LayerNorm and the residual stream stay fp32); fp32 mode is untouched
-        amp = x.is_cuda and Fn.compute_dtype() == torch.bfloat16 and _TRUNK_AMP
+        amp = _trunk_bf16(x)
         nd = torch.bfloat16 if amp else torch.float32       # the LayerNorm kernel stores what the Linears consume
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            x = x + self.attn(_layer_norm(self.norm1, x, nd), ws, ss)
-            return x + self.mlp(_layer_norm(self.norm2, x, nd))
+        with torch.autocast(x.device.type, dtype=torch.bfloat16, enabled=amp):      # (the Linears that stay on torch: odd widths)
+            x = self.attn(_layer_norm(self.norm1, x, nd), ws, ss, res=x)
+            return self.mlp(_layer_norm(self.norm2, x, nd), res=x)
 
 
 class PatchMerging(nn.Module):
@@ -324,6 +362,9 @@ class PatchMerging(nn.Module):
             x = m.index_select(4, self._sel_index(x.device)).reshape(B, d2, h2, w2, 8 * Cc)
         else:
             x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self._SEL], -1)
+        if _in_tree(x, self.reduction):
+            # LayerNorm stores bf16 (what the Linear reads under AMP in the reference too); fp32 out = the next stage's stream
+            return Fn.token_linear(_layer_norm(self.norm, x, torch.bfloat16), self.reduction.weight, None, out_dtype=torch.float32)
         return _token_linear(self.reduction, _layer_norm(self.norm, x, torch.float32))
 
 

@@ -585,7 +585,9 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
         lk = L.cbim_conv3d_last_kernel()
         if lk == 3:              # low-resolution layers: k_conv3_rw over Cin slices + k_splitk_finish (the row k_conv_igemm<1,2> had)
             name = "k_conv3_rw_splitk<bf16>+finish"
-        elif lk in (1, 2):       # conv_r32.hip / its round-4 form conv_rw.hip: one roofline row
+        elif lk == 2:            # conv_rw.hip (raw input: every 3x3x3 launch of the ResUNet step at >= 32^3) — the name rocprofv3 prints
+            name = "k_conv3_rw<bf16>"
+        elif lk == 1:            # conv_r32.hip (normalise-on-load calls)
             name = "k_conv3_r32<bf16>"
         elif lk == 4:            # 1x1x1 layers: conv_pw.hip
             name = "k_conv_pw<bf16>"
@@ -1028,6 +1030,57 @@ def layernorm_bwd(dy, x, gamma, rowstats, want_affine: bool):
     check(L.cbim_layernorm_bwd(_dt(dy), _p(dy), _p(x), _p(gamma), _p(rowstats), _p(dx), _p(dg), _p(db), _p(ws), nbytes, rows, Cc,
                                _stream(x)), "layernorm_bwd")
     return dx, dg, db
+
+
+_LIN_GEOM = {}
+
+
+def linear_geom(Cin: int, Cout: int) -> ConvGeom:
+    """the 1x1x1-convolution descriptor whose packed weight images the token Linear kernels read (bf16)"""
+    g = _LIN_GEOM.get((Cin, Cout))
+    if g is None:
+        g = _LIN_GEOM[(Cin, Cout)] = ConvGeom(torch.bfloat16, 1, (1, 1, 1), Cin, Cout, (1, 1, 1), (0, 0, 0), 0)
+    return g
+
+
+def token_linear(x2d, w_packed, bias, Cout: int, act_in: int = 0, res=None, mask=None, mask_act: int = 0,
+                 out_dtype: torch.dtype = torch.bfloat16):
+    """y = (act_in(x) @ W^T + bias) * act'(mask) + res over token rows (include/cbim_hip.h cbim_token_linear).
+    x2d [rows, Cin] bf16 | fp32, res fp32 [rows, Cout] | None, mask bf16 [rows, Cout] | None -> y [rows, Cout] in out_dtype."""
+    _dev_ok(x2d, w_packed, bias, res, mask)
+    rows, Cin = int(x2d.shape[0]), int(x2d.shape[1])
+    if res is not None and res.dtype != torch.float32:
+        raise TypeError("cbim_amd: token_linear takes the float32 residual stream as `res`")
+    if mask is not None and mask.dtype != torch.bfloat16:
+        raise TypeError("cbim_amd: token_linear takes the bf16 pre-activation as `mask`")
+    y = torch.empty((rows, Cout), dtype=out_dtype, device=x2d.device)
+    prof = PROFILE is not None and x2d.device.type == "cuda"
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.lib().cbim_token_linear(_p(x2d), _dt(x2d), int(x2d.stride(0)), act_in, _p(w_packed), _p(bias),
+                                       _p(res), int(res.stride(0)) if res is not None else 0,
+                                       _p(mask), int(mask.stride(0)) if mask is not None else 0, mask_act,
+                                       _p(y), _dt(y), Cout, rows, Cin, Cout, _stream(x2d)), "token_linear")
+    if prof:
+        e1.record()
+        nbytes = rows * (Cin * x2d.element_size() + Cout * y.element_size() + (4 * Cout if res is not None else 0) +
+                         (2 * Cout if mask is not None else 0)) + 2 * Cin * Cout
+        PROFILE.append(("k_conv_pw<token>", 2.0 * rows * Cin * Cout, e0, e1, (Cin, Cout, rows, 1, 1), nbytes))
+    return y
+
+
+def token_linear_wgrad(x2d, dy2d, act_in: int = 0, out=None):
+    """dW[co][ci] = sum_r dy[r][co] * act_in(x[r][ci]) -> float32 [Cout, Cin] (fixed summation order)."""
+    _dev_ok(x2d, dy2d)
+    rows, Cin, Cout = int(x2d.shape[0]), int(x2d.shape[1]), int(dy2d.shape[1])
+    L = _lib.lib()
+    nbytes = L.cbim_token_linear_wgrad_workspace(rows, Cin, Cout)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x2d.device)
+    dw = _dw_out(out, (Cout, Cin), x2d.device)
+    check(L.cbim_token_linear_wgrad(_p(x2d), _dt(x2d), int(x2d.stride(0)), act_in, _p(dy2d), _dt(dy2d), int(dy2d.stride(0)),
+                                    _p(dw), _p(ws), nbytes, rows, Cin, Cout, _stream(x2d)), "token_linear_wgrad")
+    return dw
 
 
 def colsum(x2d):

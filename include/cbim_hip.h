@@ -506,6 +506,34 @@ int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, const float
                        const float* rowstats, float* dx, float* dgamma, float* dbeta, void* workspace,
                        size_t ws_bytes, int64_t rows, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Token Linear (round 5) — nn.Linear over channels-last token rows on the matrix cores, the SwinUNETR trunk's
+ * WindowAttention.qkv / .proj (model/dim3/swin_unetr.py:467-490), MLPBlock linear1 -> GELU -> linear2 (:552, monai
+ * MLPBlock), PatchMerging.reduction (:707-731) and PatchEmbed.proj; replaces aten::linear (hipBLASLt), aten::gelu /
+ * gelu_backward, the bias and residual adds and the fp32 <-> bf16 casts around them:
+ *
+ *     y[r][co] = ( sum_ci act_in(x[r][ci]) * w[co][ci] + bias[co] ) * act'(mask[r][co]) + res[r][co]
+ *
+ *   x        [rows][Cin], x_dtype CBIM_BF16 or CBIM_F32 (fp32 rows are rounded to bf16 in registers: the fp32
+ *            residual-stream gradient feeds the input-gradient GEMM as it is); act_in (CBIM_ACT_*, bf16 rows only) is
+ *            applied on load — linear2 reads the stored pre-activation h, GELU(h) is never written;
+ *   w_packed cbim_conv3d_pack_weights image of the weight seen as a 1x1x1 convolution [Cout][Cin] (mode 0; mode 1 of the
+ *            FORWARD layer's weight for its input gradient, with Cin / Cout exchanged here);
+ *   bias     float [Cout] or NULL;  mask: bf16 [rows][Cout] or NULL, mask_act the activation whose derivative is taken
+ *            (input gradient of linear2 at the stored h);  res: float [rows][Cout] or NULL (the residual stream);
+ *   y        [rows][Cout] in y_dtype.  Cin, Cout multiples of 8, Cin <= 4096; strides in elements.
+ * Weight gradient dw[co][ci] = sum_r dy[r][co] * act_in(x[r][ci]) (float [Cout][Cin], fixed summation order), either
+ * operand in bf16 or fp32; workspace cbim_token_linear_wgrad_workspace(rows, Cin, Cout) bytes.  The bias gradient is
+ * cbim_colsum of dy.
+ * ------------------------------------------------------------------------------------------ */
+int cbim_token_linear(const void* x, int x_dtype, int64_t x_stride, int act_in, const void* w_packed, const float* bias,
+                      const float* res, int64_t res_stride, const void* mask, int64_t mask_stride, int mask_act,
+                      void* y, int y_dtype, int64_t y_stride, int64_t rows, int Cin, int Cout, void* stream);
+size_t cbim_token_linear_wgrad_workspace(int64_t rows, int Cin, int Cout);
+int cbim_token_linear_wgrad(const void* x, int x_dtype, int64_t x_stride, int act_in, const void* dy, int dy_dtype,
+                            int64_t dy_stride, float* dw, void* workspace, size_t ws_bytes, int64_t rows, int Cin,
+                            int Cout, void* stream);
+
 /* Column sums of token rows, out[c] = sum_r x[r][c] (fp32, fixed order): the bias gradient of the trunk's token Linears
  * (swin_unetr.py:467-490,640-643).  x [rows][C] in dtype; workspace: cbim_colsum_workspace(rows, C) bytes. */
 size_t cbim_colsum_workspace(int64_t rows, int C);

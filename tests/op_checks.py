@@ -1080,3 +1080,79 @@ def check_conv_pw(dev, N=2, Cin=64, Cout=96, dhw=(5, 6, 7), act="relu", seed=71)
     dwr = torch.einsum("ncdhw,nkdhw->ck", dyr, a)
     assert relerr(got[10].reshape(Cout, Cin), dwr) < 2e-3, "wgrad vs torch"
     assert relerr(got[11].reshape(Cout, Cin), torch.einsum("ncdhw,nkdhw->ck", dyr, xr)) < 2e-3, "raw wgrad vs torch"
+
+
+def check_token_linear(dev, rows=300, Cin=48, Cout=144, seed=91):
+    """cbim_token_linear / cbim_token_linear_wgrad (conv_pw.hip, token mode) against torch in fp32 on the bf16-rounded
+    operands: plain Linear + bias (bf16 and fp32 rows in, bf16 and fp32 out), GELU on load + fp32 residual (the MLP's second
+    Linear), the input gradient with the GELU' mask at the stored pre-activation, the weight gradient with either operand in
+    fp32 and with GELU on load; and the autograd Function end to end against F.linear / F.gelu."""
+    import torch.nn.functional as F
+    from cbim_amd import functional as Fn
+    BF = torch.bfloat16
+    torch.manual_seed(seed)
+    rt = lambda t: t.to(BF).float()                      # what the kernel sees of an fp32 operand
+    x32 = torch.randn(rows, Cin) * 1.3
+    xb = x32.to(BF)
+    w = torch.randn(Cout, Cin) * 0.2
+    b = torch.randn(Cout)
+    res = torch.randn(rows, Cout) * 3.0
+    h = (torch.randn(rows, Cout) * 1.5).to(BF)          # a pre-activation tensor for the mask
+    g = ops.linear_geom(Cin, Cout)
+    wdev = w.to(dev)
+    wp, wpd = ops.pack_weights(wdev.view(Cout, Cin, 1, 1, 1), g, 0), ops.pack_weights(wdev.view(Cout, Cin, 1, 1, 1), g, 1)
+    wr = rt(w)
+
+    def close(got, ref, tol, what):
+        err = float((got.float().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < tol, f"token_linear {what}: {err:.3e} (rows {rows}, {Cin} -> {Cout})"
+
+    # forward: bf16 rows, bias, bf16 out / fp32 out
+    ref = xb.float() @ wr.t() + b
+    close(ops.token_linear(xb.to(dev), wp, b.to(dev), Cout), ref, 6e-3, "bf16 -> bf16")
+    close(ops.token_linear(xb.to(dev), wp, b.to(dev), Cout, out_dtype=torch.float32), ref, 2e-5, "bf16 -> fp32")
+    close(ops.token_linear(xb.to(dev), wp, None, Cout, out_dtype=torch.float32), xb.float() @ wr.t(), 2e-5, "no bias")
+    # fp32 rows (rounded to bf16 in registers)
+    close(ops.token_linear(x32.to(dev), wp, b.to(dev), Cout, out_dtype=torch.float32), rt(x32) @ wr.t() + b, 2e-5, "fp32 rows")
+    # GELU on load + fp32 residual (the activated tensor is rounded to bf16 like any MFMA operand)
+    ref = rt(F.gelu(xb.float())) @ wr.t() + b + res
+    close(ops.token_linear(xb.to(dev), wp, b.to(dev), Cout, act_in=ops.ACT["gelu"], res=res.to(dev), out_dtype=torch.float32), ref, 2e-5,
+          "gelu on load + residual")
+    # input gradient: dy (fp32 rows) @ W, times gelu'(mask) — the dgrad image of the FORWARD weight, roles of Cin / Cout swapped
+    dy32 = torch.randn(rows, Cout)
+    hin = (torch.randn(rows, Cin) * 1.5).to(BF)
+    hh = hin.float().requires_grad_(True)
+    F.gelu(hh).backward(torch.ones_like(hh))
+    ref = (rt(dy32) @ wr) * hh.grad
+    close(ops.token_linear(dy32.to(dev), wpd, None, Cin, mask=hin.to(dev), mask_act=ops.ACT["gelu"]), ref, 6e-3, "dgrad * gelu'(h)")
+    close(ops.token_linear(dy32.to(BF).to(dev), wpd, None, Cin), rt(dy32) @ wr, 6e-3, "dgrad bf16 rows")
+    # weight gradient: operands in bf16 / fp32, GELU on load
+    dyb = dy32.to(BF)
+    close(ops.token_linear_wgrad(xb.to(dev), dyb.to(dev)), dyb.float().t() @ xb.float(), 2e-5, "wgrad bf16 / bf16")
+    close(ops.token_linear_wgrad(xb.to(dev), dy32.to(dev)), rt(dy32).t() @ xb.float(), 2e-5, "wgrad bf16 x, fp32 dy")
+    close(ops.token_linear_wgrad(x32.to(dev), dy32.to(dev)), rt(dy32).t() @ rt(x32), 2e-5, "wgrad fp32 / fp32")
+    close(ops.token_linear_wgrad(xb.to(dev), dy32.to(dev), act_in=ops.ACT["gelu"]), rt(dy32).t() @ rt(F.gelu(xb.float())), 2e-5,
+          "wgrad gelu on load")
+    # the autograd Function: an MLP half block  x + W2 gelu(W1 y + b1) + b2  end to end against torch
+    hid = 2 * Cout
+    w1 = torch.nn.Parameter((torch.randn(hid, Cin) * 0.2).to(dev))
+    b1 = torch.nn.Parameter(torch.randn(hid).to(dev))
+    w2 = torch.nn.Parameter((torch.randn(Cin, hid) * 0.2).to(dev))
+    b2 = torch.nn.Parameter(torch.randn(Cin).to(dev))
+    yb = xb.detach().clone().to(dev).requires_grad_(True)
+    stream = (torch.randn(rows, Cin) * 2).to(dev).requires_grad_(True)
+    hpre = Fn.token_linear(yb, w1, b1)
+    out = Fn.token_linear(hpre, w2, b2, act_in=ops.ACT["gelu"], res=stream, out_dtype=torch.float32)
+    gout = torch.randn(rows, Cin)
+    out.backward(gout.to(dev))
+    yr = xb.detach().float().requires_grad_(True)
+    sr = stream.detach().cpu().clone().requires_grad_(True)
+    p = [t.detach().cpu().clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    hr = rt((yr @ rt(p[0]).t() + p[1]).detach())                                  # the stored bf16 pre-activation
+    hr = hr + ((yr @ rt(p[0]).t() + p[1]) - (yr @ rt(p[0]).t() + p[1]).detach())  # (straight-through: gradients as in fp32)
+    outr = sr + F.gelu(hr) @ rt(p[2]).t() + p[3]
+    outr.backward(gout)
+    close(out.detach(), outr.detach(), 2e-2, "MLP half block forward")
+    for nm, got, refg, tol in (("dW1", w1.grad, p[0].grad, 2e-2), ("db1", b1.grad, p[1].grad, 2e-2), ("dW2", w2.grad, p[2].grad, 2e-2),
+                               ("db2", b2.grad, p[3].grad, 1e-4), ("d stream", stream.grad, sr.grad, 1e-6), ("dy", yb.grad, yr.grad, 3e-2)):
+        close(got, refg, tol, "MLP half block " + nm)

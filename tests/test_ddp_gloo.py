@@ -213,46 +213,127 @@ def _worker_engine(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_engine_replicas_exchange_gradients_in_place():
-    """world_size 2, gloo: both replicas run the HIP kernel sources (host-side executor) end to end — forward, fused
-    Dice+CE, backward, bucketed in-place all-reduce, fused AdamW — and must agree with one process that averages the two
-    volumes' gradients itself."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_engine_replicas_exchange_gradients_in_place(world):
+    """world_size 2 and 4, gloo: every replica runs the HIP kernel sources (host-side executor) end to end — forward, fused
+    Dice+CE, backward, bucketed in-place all-reduce, fused AdamW — and must agree with one process that averages the
+    volumes' gradients itself (the 1 -> 2 -> 4 -> 8 path of /root/reference/train_ddp.py:330,353 differs only in the size of
+    the process group; world 4 is what this container's 8 cores can run)."""
     if not os.environ.get("CBIM_HIP_LIBRARY"):
         pytest.skip("needs the host-side kernel executor (CPU suite)")
     from cbim_amd.training.losses import DiceCELoss
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_engine, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_engine, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
-    for _ in range(2):
-        r, g, w, loc, acc = q.get(timeout=900)
+    for _ in range(world):
+        r, g, w, loc, acc = q.get(timeout=1800)
         got[r] = (g, w, loc, acc)
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    # single process: mean of the two volumes' gradients at the initial weights
+    # single process: mean of the volumes' gradients at the initial weights
     crit = DiceCELoss(torch.tensor([0.5, 1.0, 1.0]))
     ref = None
-    for r in range(2):
+    for r in range(world):
         net = _engine_net()
         x, lab = _engine_data(r)
         crit(net(x), lab).backward()
         gs = [p.grad.clone() for p in net.parameters()]
         ref = gs if ref is None else [a + b for a, b in zip(ref, gs)]
-    for a, b, g in zip(got[0][0], got[1][0], ref):
-        assert (a == b).all()                                   # both ranks hold the same averaged gradient
-        assert torch.allclose(torch.from_numpy(a), g / 2, rtol=1e-5, atol=1e-7)
-    for a, b in zip(got[0][1], got[1][1]):
-        assert (a == b).all()                                   # replicas stay bit-identical after the optimizer steps
+    for i, g in enumerate(ref):
+        for r in range(1, world):
+            assert (got[0][0][i] == got[r][0][i]).all()         # every rank holds the same averaged gradient
+        assert torch.allclose(torch.from_numpy(got[0][0][i]), g / world, rtol=1e-5, atol=1e-7)
+    for i in range(len(got[0][1])):
+        for r in range(1, world):
+            assert (got[0][1][i] == got[r][1][i]).all()         # replicas stay bit-identical after the optimizer steps
     # no_sync: averaged (local sum over the two backward passes) == 2 x the per-pass mean gradient over ranks
-    for r in range(2):
+    for r in range(world):
         assert all(np_l.any() for np_l in got[r][2][:3])
-    mean_local = [(torch.from_numpy(a) + torch.from_numpy(b)) / 2 for a, b in zip(got[0][2], got[1][2])]
+    mean_local = [sum(torch.from_numpy(got[r][2][i]) for r in range(world)) / world for i in range(len(got[0][2]))]
     for acc, ml in zip(got[0][3], mean_local):
         assert torch.allclose(torch.from_numpy(acc), 2 * ml, rtol=1e-4, atol=1e-6)
+
+
+# ---- overlap: the property SURVEY.md 8e relies on — buckets are handed to the collective WHILE the backward is still
+#      launching kernels, the first one early, not all of them at the end ------------------------------------------------
+
+def _worker_overlap(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    from cbim_amd import ops
+    from cbim_amd.parallel import GradAllReduce
+    from cbim_amd.training.losses import DiceCELoss
+    net = _engine_net()
+    ddp = GradAllReduce(net, bucket_mb=0.002)
+    crit = DiceCELoss(torch.tensor([0.5, 1.0, 1.0]))
+    x, lab = _engine_data(rank)
+    events = []                     # ("launch", t) per engine kernel launch, ("bucket", index, t) per all-reduce handed over
+    orig_check, orig_launch = ops.check, GradAllReduce._launch
+
+    def counting_check(rc, what):   # every C-ABI launch of the engine passes its return code through ops.check
+        events.append(("launch", time.perf_counter()))
+        return orig_check(rc, what)
+
+    def recording_launch(self, b):
+        events.append(("bucket", self.buckets.index(b), time.perf_counter()))
+        return orig_launch(self, b)
+
+    loss = crit(net(x), lab)
+    ops.check, GradAllReduce._launch = counting_check, recording_launch
+    try:
+        t0 = time.perf_counter()
+        loss.backward()
+        t1 = time.perf_counter()
+    finally:
+        ops.check, GradAllReduce._launch = orig_check, orig_launch
+    ddp.synchronize()
+    n_launch = sum(e[0] == "launch" for e in events)
+    fired, seen = [], 0
+    for e in events:
+        if e[0] == "launch":
+            seen += 1
+        else:
+            fired.append((e[1], seen, (e[2] - t0) / (t1 - t0)))     # (bucket, launches issued before it, fraction of backward time)
+    q.put((rank, n_launch, len(ddp.buckets), fired))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_first_bucket_is_exchanged_early_in_the_backward():
+    """The bucketed exchange overlaps the backward (/root/reference/train_ddp.py:353 relies on DDP's reducer for
+    the same): recorded per rank — the position of every bucket's all-reduce launch in the stream of the backward's kernel
+    launches.  Asserted: buckets fire in bucket order (reverse registration = the order the backward completes them), the
+    FIRST fires before the last third of the backward's launches, no two thirds of the buckets wait for the end, and the last
+    bucket (the encoder stem's) is the only one that fires after the final kernel launch."""
+    if not os.environ.get("CBIM_HIP_LIBRARY"):
+        pytest.skip("needs the host-side kernel executor (CPU suite)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    for rank, n_launch, n_buckets, fired in got:
+        print(f"rank {rank}: {n_launch} backward launches, {n_buckets} buckets; (bucket, launches before it, fraction of backward time):",
+              [(b, k, round(f, 3)) for b, k, f in fired])
+        assert n_buckets > 3 and len(fired) == n_buckets                      # every bucket fired from a hook, inside backward()
+        assert [b for b, _, _ in fired] == list(range(n_buckets))            # in bucket order
+        assert fired[0][1] <= (2 * n_launch) // 3, (fired[0], n_launch)       # the first one before the last third
+        early = sum(k < n_launch for _, k, _ in fired)                        # handed over while kernels were still to be launched
+        assert early >= n_buckets - 1, (early, n_buckets)
+        assert fired[n_buckets // 2][1] <= (5 * n_launch) // 6                # and they are spread over the pass, not bunched at its end
 
 
 # ---- the wrapper the reference's trainer really uses: stock DistributedDataParallel(find_unused_parameters=True) ------

@@ -65,6 +65,38 @@ def test_swin_unetr_4x128_fp32_engine_matches_oracle(dev):
     print(f"SwinUNETR 1x4x{SIZE}^3: oracle + engine fwd/loss/bwd compared in {time.perf_counter() - t0:.0f} s")
 
 
+@pytest.mark.parametrize("model", ["resunet", "medformer", "swin_unetr"])
+def test_benchmarked_architectures_64_fp32_engine_inside_the_f64_bar(dev, model):
+    """The three benchmarked architectures (configs[1], [2], [4]: full widths, 16 / 16 / 4 classes) at 1xCx64^3, where the oracle
+    can also be evaluated in FLOAT64 within seconds: every parameter gradient of the fp32 engine is at most twice as far from
+    the float64 gradient as the stock-torch fp32 evaluation of the same network is (tests.util.f64_bar).
+    The 128^3 tests above keep the fp32-vs-fp32 numbers (cosine, norms, logits, loss, argmax)."""
+    from functools import partial
+    from cbim_amd.model.dim3 import MedFormer, SwinUNETR, UNet
+    from oracle.swin_unetr_ref import swin_unetr_forward
+    from oracle.unet_ref import unet_forward
+    from tests.test_gpu_parity import _oracle_vs_engine
+    torch.manual_seed(2023)
+    S = 64
+    if model == "resunet":
+        ks, sc = [[3, 3, 3]] * 5, [[2, 2, 2]] * 4
+        net, classes, in_ch = UNet(1, 32, scale=sc, kernel_size=ks, num_classes=16, block="BasicBlock", norm="in").to(dev), 16, 1
+        fwd = partial(unet_forward, scale=sc, kernel_size=ks, block="BasicBlock")
+    elif model == "medformer":
+        net, classes, in_ch, fwd = MedFormer(1, 16, **MEDFORMER_AMOS).to(dev), 16, 1, _medformer_oracle()
+    else:
+        net, classes, in_ch, fwd = SwinUNETR((S,) * 3, 4, 4, feature_size=48).to(dev), 4, 4, swin_unetr_forward
+    g = torch.Generator().manual_seed(31)
+    coarse = torch.randint(0, classes, (1, 1, S // 8, S // 8, S // 8), generator=g)
+    lab = torch.nn.functional.interpolate(coarse.float(), size=(S,) * 3, mode="nearest").long()
+    x = torch.randn(1, in_ch, S, S, S, generator=g).clamp_(-7.4, 2.2)
+    w = torch.ones(classes)
+    w[0] = 0.5
+    t0 = time.perf_counter()
+    _oracle_vs_engine(dev, net, fwd, x, lab, w, tag=f"{model}_64_fp32", f64=True)
+    print(f"{model} 1x{in_ch}x{S}^3: fp32 + float64 oracle and engine compared in {time.perf_counter() - t0:.0f} s")
+
+
 def test_medformer_amos_128_bf16_dice_within_0p002_of_oracle_on_trained_weights(dev):
     """~200 bf16 AdamW steps on a learnable synthetic volume (class margins become real), then the engine's hard Dice must
     be within 0.002 of the fp32 oracle's on the same weights and input (SURVEY.md §8d ii)."""

@@ -93,6 +93,9 @@ def test_headline_config_fp32_engine_matches_oracle_at_128(dev):
     assert int((diff & decided).sum()) == 0 and int(diff.sum()) <= 1e-4 * diff.numel()
     assert ddice <= 0.002
     assert dloss < 1e-4
+    # (the float64-relative gradient bar is asserted on this architecture at 64^3, where a float64 oracle takes seconds:
+    #  tests/test_gpu_benchmarked_sizes.py::test_benchmarked_architectures_64_fp32_engine_inside_the_f64_bar; here the
+    #  element-wise number is an outlier guard and the cosine the structural check)
     assert worst <= 1e-1 and cos_min >= 0.999, (worst, worst_k, cos_min)
 
 
@@ -132,19 +135,37 @@ def test_headline_config_bf16_gradients_point_where_the_oracles_do_at_128(dev):
     record_parity("resunet_headline_128_bf16", dict(dtype="bf16", logits_rel=err, argmax_agreement=agree,
                                                    loss_abs=abs(float(loss_e) - float(loss_o)), grad_rel_worst=worst,
                                                    grad_rel_worst_tensor=str(worst_k), grad_cos_min=cos_min, grad_tensors=n_t))
-    assert err < 0.25 and abs(float(loss_e) - float(loss_o)) < 0.05
-    # (untrained weights, sixteen 3x3x3 convolutions deep: the bf16 gradient of the stem — the end of the backward chain — has
-    #  cosine ~0.74 against the fp32 oracle's; recorded, and bounded only loosely here.  What the bf16 KERNELS compute inside this
-    #  model at this shape is checked tensor by tensor in the next test, and the trained-weights Dice bar below is the bf16 bar
-    #  of BASELINE.json.)
-    assert cos_min >= 0.5, (cos_min, worst_k)
+    # the envelope is COMPUTED (round 5): the oracle under torch.autocast('cpu', bfloat16) on the same weights and input is the
+    # reference's own reduced-precision run (train.py --amp); the engine's logit error, argmax disagreements and the cosine
+    # deficit of EVERY parameter gradient against the fp32 oracle must be no worse than 1.25 x that run's
+    # (untrained weights, sixteen 3x3x3 convolutions deep: the stem gradient — the end of the backward chain — sits at cosine
+    #  ~0.74 on both sides, which is why a constant cannot be the bar.  What the bf16 KERNELS compute inside this model is
+    #  checked tensor by tensor, level by level, in the next test; the trained-weights Dice bar below is BASELINE.json's.)
+    from tests.util import bf16_envelope
+    sdb = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    t0 = time.perf_counter()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lob = unet_ref.unet_forward(sdb, x, scale=SC, kernel_size=KS, block="BasicBlock")
+    loss_ref.ce_dice_loss(lob.float(), lab, w).backward()
+    print(f"oracle under autocast(bf16) at {SIZE}^3: {time.perf_counter() - t0:.1f} s")
+    env, bad = bf16_envelope(lg, lo, lob.detach().float(), got, {k: sdr[k].grad for k in got}, {k: sdb[k].grad for k in got})
+    record_parity("resunet_headline_128_bf16_envelope", env)
+    assert not bad, bad
+    assert abs(float(loss_e) - float(loss_o)) < 0.05
 
 
 def test_headline_bf16_interior_kernels_match_torch_inside_the_model_at_128(dev):
-    """k_conv3_rw (forward, masked dgrad; single-chunk and the Cout-concatenated 96 -> 64 launch) and k_wgrad_r32 checked INSIDE
-    one bf16 training step of the benchmarked model at 1x1x128^3: the operands the engine handed to the kernels are captured
-    and the same convolutions are evaluated by torch in fp32 on exactly those (bf16) tensors — outputs within 1e-2 of the
-    tensor's largest entry (bf16 output rounding) and cosine >= 0.9999, weight gradients (fp32 accumulation) within 2e-3."""
+    """The bf16 convolution kernels checked INSIDE one bf16 training step of the benchmarked model at 1x1x128^3, one layer (or
+    two) PER LEVEL of the pyramid: the operands the engine handed to the kernels are captured and the same convolutions are
+    evaluated by torch in fp32 on exactly those (bf16) tensors.
+      128^3: k_conv3_rw forward 32 -> 32 (single chunk) and 96 -> 64 (wide, three Cin chunks), masked dgrad 32 -> 32 and
+             64 -> 96, k_wgrad_r32 32 -> 32 and 96 -> 64 (round 4);
+      64^3 / 32^3 (round 5): the decoder level's Cout-concatenated first convolution (192 -> 128, 384 -> 256): forward, masked
+             dgrad over [dy1 | dout], weight gradient with a second dy tensor;
+      16^3 / 8^3 (round 5): the split-K path (k_conv3_rw over Cin slices + k_splitk_finish) forward and masked dgrad, and the
+             weight gradient of the widest layer of the level.
+    Outputs within 1e-2 of the tensor's largest entry (bf16 output rounding) and cosine >= 0.9999, weight gradients (fp32
+    accumulation) within 2e-3."""
     import torch.nn.functional as F
     import cbim_amd
     from cbim_amd import functional as Fn, ops
@@ -156,28 +177,33 @@ def test_headline_bf16_interior_kernels_match_torch_inside_the_model_at_128(dev)
     w[0] = 0.5
     sd = unet_ref.make_unet_state_dict(1, BASE, CLASSES, KS, "BasicBlock", seed=2023)
     log = {"fwd": [], "dgrad": [], "wgrad": []}
-    orig = (ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad)
+    raw_of = {}                        # data_ptr of a packed weight image -> the fp32 weights it was packed from
+    orig = (ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad, ops.packed_weights)
+
+    def packed(ws, geom, need_dgrad):
+        p0, p1 = orig[3](ws, geom, need_dgrad)
+        for p in (p0, p1):
+            if p is not None:
+                raw_of[p.data_ptr()] = tuple(ws)
+        return p0, p1
 
     def fwd(xx, wp, geom, in_stats=None, res=None, want_stats=False, **kw):
         out = orig[0](xx, wp, geom, in_stats=in_stats, res=res, want_stats=want_stats, **kw)
-        if geom.out_dhw[0] == SIZE:
-            log["fwd"].append((xx, res, geom, out[0]))
+        log["fwd"].append((xx, res, geom, out[0], raw_of[wp.data_ptr()], in_stats))
         return out
 
     def dgrad(dy, wpd, geom, mask_x=None, mask_stats=None, accumulate=None, dy2=None):
         out = orig[1](dy, wpd, geom, mask_x=mask_x, mask_stats=mask_stats, accumulate=accumulate, dy2=dy2)
-        if geom.in_dhw[0] == SIZE:
-            log["dgrad"].append((dy, dy2, mask_x, mask_stats, accumulate, geom, out[0]))
+        log["dgrad"].append((dy, dy2, mask_x, mask_stats, accumulate, geom, out[0], raw_of[wpd.data_ptr()]))
         return out
 
     def wgrad(xx, in_stats, dy, geom, dy2=None, x2=None, out=None):
         out = orig[2](xx, in_stats, dy, geom, dy2=dy2, x2=x2, out=out)
-        if geom.in_dhw[0] == SIZE:
-            log["wgrad"].append((xx, in_stats, dy, dy2, x2, geom, out))
+        log["wgrad"].append((xx, in_stats, dy, dy2, x2, geom, out))
         return out
 
     cbim_amd.set_compute_dtype("bf16")
-    ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = fwd, dgrad, wgrad
+    ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad, ops.packed_weights = fwd, dgrad, wgrad, packed
     try:
         net = UNet(1, BASE, scale=SC, kernel_size=KS, num_classes=CLASSES, block="BasicBlock", norm="in").to(dev)
         net.load_state_dict(sd)
@@ -185,51 +211,69 @@ def test_headline_bf16_interior_kernels_match_torch_inside_the_model_at_128(dev)
         loss.backward()
         torch.cuda.synchronize()
     finally:
-        ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = orig
+        ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad, ops.packed_weights = orig
         cbim_amd.set_compute_dtype(None)
 
     def ncdhw(t):                      # channels-last bf16 on the device -> NCDHW fp32 on the host
         return t.float().permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+    def wcat(ws):                      # the weights as the kernel saw them: Cout-concatenated, rounded to bf16
+        return torch.cat([t.detach() for t in ws], 0).bfloat16().float().cpu()
 
     def cmp(got, ref):
         got, ref = got.double().flatten(), ref.double().flatten()
         return (float((got - ref).abs().max() / ref.abs().max()),
                 float(torch.dot(got, ref) / (got.norm() * ref.norm())))
 
-    blk = net.inc.conv2                                  # BasicBlock 32 -> 32 at 128^3 (first in forward, last in backward)
-    up = net.up4.conv[0]                                 # BasicBlock 96 -> 32 with a shortcut conv: conv1 | shortcut as one GEMM
-    w1 = blk.conv1.conv.weight.detach().bfloat16().float().cpu()
-    wcat = torch.cat([up.conv1.conv.weight, up.shortcut.conv.weight], 0).detach().bfloat16().float().cpu()
+    def check_fwd(e):
+        xx, res, geom, y, ws, in_stats = e
+        assert in_stats is None                       # materialised inputs: the kernels read the tensor as it is
+        ref = F.conv3d(ncdhw(xx), wcat(ws), None, 1, 1)
+        if res is not None:
+            ref = ref + ncdhw(res)
+        return cmp(ncdhw(y), ref)
+
+    def check_dgrad(e):
+        dy, dy2, mask_x, mask_stats, acc, geom, g, ws = e
+        assert mask_stats is None and acc is None and mask_x is not None
+        dycat = ncdhw(dy) if dy2 is None else torch.cat([ncdhw(dy), ncdhw(dy2)], 1)
+        return cmp(ncdhw(g), F.conv_transpose3d(dycat, wcat(ws), None, 1, 1) * (ncdhw(mask_x) > 0))
+
+    def check_wgrad(e):
+        xx, st, dy, dy2, x2, geom, dw = e
+        assert st is None and x2 is None
+        dycat = ncdhw(dy) if dy2 is None else torch.cat([ncdhw(dy), ncdhw(dy2)], 1)
+        return cmp(dw.cpu(), torch.nn.grad.conv3d_weight(ncdhw(xx), (geom.Cout, geom.Cin, 3, 3, 3), dycat, 1, 1))
+
     rec = {}
-    # forward, single chunk: the first 128^3 launch with 32 input channels is inc.conv2.conv1 on a = relu(IN(stem))
-    xx, res, geom, y = next(e for e in log["fwd"] if e[2].Cin == 32 and e[2].Cout == 32)
-    assert res is None
-    rec["fwd_32_32"] = cmp(ncdhw(y), F.conv3d(ncdhw(xx), w1, None, 1, 1))
-    # forward, 96 -> 64 (wide workgroups, three Cin chunks)
-    xx, res, geom, y = next(e for e in log["fwd"] if e[2].Cin == 96 and e[2].Cout == 64)
-    rec["fwd_96_64"] = cmp(ncdhw(y), F.conv3d(ncdhw(xx), wcat, None, 1, 1))
-    # masked dgrad, single chunk: the LAST dgrad launch is inc.conv2.conv1's: g = conv_transpose(dy1, w1) * [a > 0]
-    dy, dy2, mask_x, mask_stats, acc, geom, g = log["dgrad"][-1]
-    assert dy2 is None and acc is None and mask_stats is None and geom.Cin == 32 and geom.Cout == 32
-    a = ncdhw(mask_x)
-    rec["dgrad_32_32"] = cmp(ncdhw(g), F.conv_transpose3d(ncdhw(dy), w1, None, 1, 1) * (a > 0))
-    # masked dgrad over [dy1 | dout] (64 -> 96 channels)
-    dy, dy2, mask_x, mask_stats, acc, geom, g = next(e for e in log["dgrad"] if e[1] is not None)
-    assert geom.Cin == 96 and geom.Cout == 64 and mask_stats is None
-    a96 = ncdhw(mask_x)
-    rec["dgrad_64_96"] = cmp(ncdhw(g), F.conv_transpose3d(torch.cat([ncdhw(dy), ncdhw(dy2)], 1), wcat, None, 1, 1) * (a96 > 0))
-    # weight gradients (fp32 out): the last launch is inc.conv2.conv1's, the one with a second dy tensor the 96 -> 64 pair's
-    xx, st, dy, dy2, x2, geom, dw = log["wgrad"][-1]
-    assert st is None and dy2 is None and geom.Cin == 32 and geom.Cout == 32
-    rec["wgrad_32_32"] = cmp(dw.cpu(), torch.nn.grad.conv3d_weight(ncdhw(xx), (32, 32, 3, 3, 3), ncdhw(dy), 1, 1))
-    xx, st, dy, dy2, x2, geom, dw = next(e for e in log["wgrad"] if e[3] is not None)
-    assert geom.Cin == 96 and geom.Cout == 64
-    rec["wgrad_96_64"] = cmp(dw.cpu(), torch.nn.grad.conv3d_weight(ncdhw(xx), (64, 96, 3, 3, 3), torch.cat([ncdhw(dy), ncdhw(dy2)], 1), 1, 1))
+    lvl = lambda e_geom: e_geom.out_dhw[0]
+    # ---- 128^3 (as round 4) ----
+    e = next(e for e in log["fwd"] if lvl(e[2]) == SIZE and e[2].Cin == 32 and e[2].Cout == 32)
+    assert e[1] is None
+    rec["fwd_32_32"] = check_fwd(e)
+    rec["fwd_96_64"] = check_fwd(next(e for e in log["fwd"] if lvl(e[2]) == SIZE and e[2].Cin == 96 and e[2].Cout == 64))
+    e = log["dgrad"][-1]                                 # the LAST dgrad launch is inc.conv2.conv1's
+    assert e[1] is None and e[5].Cin == 32 and e[5].Cout == 32 and e[5].in_dhw[0] == SIZE
+    rec["dgrad_32_32"] = check_dgrad(e)
+    rec["dgrad_64_96"] = check_dgrad(next(e for e in log["dgrad"] if e[5].in_dhw[0] == SIZE and e[1] is not None))
+    e = log["wgrad"][-1]
+    assert e[3] is None and e[5].Cin == 32 and e[5].Cout == 32 and e[5].in_dhw[0] == SIZE
+    rec["wgrad_32_32"] = check_wgrad(e)
+    rec["wgrad_96_64"] = check_wgrad(next(e for e in log["wgrad"] if e[5].in_dhw[0] == SIZE and e[3] is not None))
+    # ---- one (widest) layer per lower level: forward, masked dgrad, weight gradient ----
+    for L in (64, 32, 16, 8):
+        f = max((e for e in log["fwd"] if lvl(e[2]) == L and e[2].k == (3, 3, 3)), key=lambda e: e[2].Cin * e[2].Cout)
+        d = max((e for e in log["dgrad"] if e[5].in_dhw[0] == L and e[2] is not None and e[3] is None and e[4] is None),
+                key=lambda e: e[5].Cin * e[5].Cout)
+        g = max((e for e in log["wgrad"] if e[5].in_dhw[0] == L and e[1] is None and e[4] is None), key=lambda e: e[5].Cin * e[5].Cout)
+        rec[f"L{L}_fwd_{f[2].Cin}_{f[2].Cout}"] = check_fwd(f)
+        rec[f"L{L}_dgrad_{d[5].Cout}_{d[5].Cin}"] = check_dgrad(d)
+        rec[f"L{L}_wgrad_{g[5].Cin}_{g[5].Cout}"] = check_wgrad(g)
     for k, (e, c) in rec.items():
         print(f"inside the bf16 model at {SIZE}^3: {k}: max|d| / max|ref| {e:.2e}, cosine {c:.7f}")
     record_parity("resunet_headline_128_bf16_interior_kernels", {k + "_rel": v[0] for k, v in rec.items()} | {k + "_cos": v[1] for k, v in rec.items()})
     for k, (e, c) in rec.items():
-        assert e < (2e-3 if k.startswith("wgrad") else 1e-2) and c > 0.9999, (k, e, c)
+        assert e < (2e-3 if "wgrad" in k else 1e-2) and c > 0.9999, (k, e, c)
 
 
 def test_headline_config_bf16_dice_within_0p002_of_oracle_on_trained_weights(dev):

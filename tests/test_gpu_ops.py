@@ -28,6 +28,7 @@ def test_maxpool(dev, dtype):
     oc.check_maxpool(dev, dtype)
     oc.check_maxpool(dev, dtype, dhw=(4, 9, 7), scale=(1, 2, 2))
     oc.check_maxpool(dev, dtype, C=64, dhw=(32, 32, 32))
+    oc.check_maxpool(dev, dtype, N=2, C=8, dhw=(40000, 2, 2))   # N * D = 80 000 planes > gridDim.y's 65 535: blocks stride over them
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
@@ -130,6 +131,10 @@ def test_head_backward_on_matrix_cores(dev):
     oc.check_head_mfma(dev, N=1, base=64, K=16, dhw=(8, 8, 9))              # 18 steps over 8 waves: ragged last round
     oc.check_head_mfma(dev, N=1, base=96, K=3, dhw=(2, 4, 8))
     oc.check_head_mfma(dev, N=1, base=128, K=13, dhw=(4, 4, 8), need_dx=False)
+    oc.check_head_mfma(dev, N=1, base=48, K=4, dhw=(32, 64, 64))            # 16-channel tiles (round 5): SwinUNETR's 48-channel head
+    oc.check_head_mfma(dev, N=2, base=16, K=2, dhw=(2, 4, 8))
+    oc.check_head_mfma(dev, N=1, base=80, K=5, dhw=(4, 8, 8))
+    oc.check_head_mfma(dev, N=1, base=112, K=7, dhw=(2, 4, 8))
     oc.check_head_mfma(dev, N=1, base=32, K=16, dhw=(32, 64, 64))          # several steps per wave, 256 workgroups
     oc.check_head_mfma(dev, N=1, base=128, K=16, dhw=(16, 32, 32))         # MedFormer's aux head
 
@@ -333,3 +338,13 @@ def test_dwconv_lds_tiled_and_streaming_kernels(dev, dtype, lds):
         oc.check_dwconv(dev, dtype, N=1, C=24, dhw=(5, 9, 8), k=(3, 1, 3), act="none")
     finally:
         _lib.lib().cbim_dwconv_lds_enable(old)
+
+
+def test_token_linear(dev):
+    """the SwinUNETR trunk's token Linears on the engine's row GEMM (round 5)"""
+    oc.check_token_linear(dev)
+    oc.check_token_linear(dev, rows=64, Cin=384, Cout=96)        # few rows, long K: the four waves split K (KS = 4)
+    oc.check_token_linear(dev, rows=130, Cin=32, Cout=48)        # patch embedding width; ragged last row tile
+    oc.check_token_linear(dev, rows=257, Cin=96, Cout=384)       # 128 output channels per wave
+    oc.check_token_linear(dev, rows=262144, Cin=48, Cout=192)   # stage-1 MLP of the benchmarked SwinUNETR
+    oc.check_token_linear(dev, rows=512, Cin=3072, Cout=768)     # stage-4 MLP: K = 3072

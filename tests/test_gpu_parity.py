@@ -25,7 +25,10 @@ def test_fp32_mode_matches_reference_golden(dev, name):
     from tests.util import record_parity
     record_parity("golden_" + name + "_fp32", dict(dtype="fp32", logits_rel=r["logits_err"], argmax_mismatch=r["argmax_mismatch"],
                                                   ce_abs=abs(r["ce"] - float(load_golden(name)["ce"])), grad_rel_worst=r["grad_rel_worst"],
-                                                  grad_cos_min=r["grad_cos_min"], grad_norm_rel_worst=r["grad_norm_err"]))
+                                                  grad_cos_min=r["grad_cos_min"], grad_norm_rel_worst=r["grad_norm_err"],
+                                                  f64_ratio_worst=r["f64_ratio_worst"], f64_ratio_worst_tensor=str(r["f64_ratio_worst_tensor"]),
+                                                  f64_err_engine=r["f64_err_engine"], f64_err_oracle32=r["f64_err_oracle32"],
+                                                  f64_maxabs_ratio_worst=r["f64_maxabs_ratio_worst"]))
 
 
 @pytest.mark.parametrize("name", ["resunet_b8_32", "resunet_b8_aniso", "unet_single_acdc"])
@@ -33,12 +36,15 @@ def test_bf16_mode_inside_reference_bf16_envelope(dev, name):
     r, g = run_case(name, dev, "bf16")
     print(name, r)
     from tests.util import record_parity
+    env = r["bf16_envelope"]
     record_parity("golden_" + name + "_bf16", dict(dtype="bf16", logits_rel=r["logits_err"], argmax_mismatch=r["argmax_mismatch"],
-                                                  n_vox=r["n_vox"], grad_rel_worst=r["grad_rel_worst"], grad_cos_min=r["grad_cos_min"]))
-    # (bf16 gradients of an UNTRAINED tiny pyramid are recorded, not asserted: measured cosine 0.48-0.94 against the fp32 oracle
-    #  — the trained-weights tests are the bf16 bar)
-    assert r["logits_err"] < 0.25, r
-    assert r["argmax_mismatch"] < 0.2 * r["n_vox"], r
+                                                  n_vox=r["n_vox"], grad_rel_worst=r["grad_rel_worst"], grad_cos_min=r["grad_cos_min"],
+                                                  **{"env_" + k: v for k, v in env.items()}))
+    # the envelope is COMPUTED: the oracle under torch.autocast('cpu', bfloat16) on the same weights is the reference's own
+    # reduced-precision run; the engine's logit error, argmax disagreements and every gradient's cosine deficit against the fp32
+    # oracle must be no worse than 1.25 x that run's (tests.util.bf16_envelope) — untrained weights, so the numbers are large
+    # on BOTH sides (cosines 0.5-0.95), which is exactly why a constant cannot be the bar
+    assert not r["bf16_envelope_violations"], r["bf16_envelope_violations"]
     assert abs(r["ce"] - float(g["ce"])) < 0.05 and abs(r["dice"] - float(g["dice"])) < 0.02, r
 
 
@@ -205,14 +211,20 @@ def test_sliding_window_inference_and_dice(dev):
 
 # ---- ragged / non-cubic volumes and batch > 1 against the oracle evaluated on the host ------------------
 
-def _oracle_vs_engine(dev, net, oracle_forward, x, lab, w, aux=False, tag=None, grad_tol=1e-1):
-    """fp32 engine mode vs the oracle (stock torch on the CPU) on the same weights: logits, loss, and EVERY parameter gradient
-    element by element (largest |difference| over the largest |reference| entry of the tensor <= grad_tol, cosine >= 0.999;
-    norms within 2 % as before).  Both sides are fp32 evaluations of a deep network: against a float64 evaluation of the oracle
-    the engine and the fp32 oracle sit at the SAME distance (5e-3 / 8e-3 on the tiny MedFormer: ReLU-mask flips at |x^| ~ 1e-6
-    land on different voxels in different implementations), and the distance grows with the voxel count (6e-2 at 128^3 on the
-    8^3-level weights), so the element-wise bar is a bound on outliers; the cosine is what a permuted / transposed /
-    sign-flipped gradient cannot pass.  The measured numbers go to the parity record."""
+F64_MAX_VOXELS = 64 ** 3 * 4     # the float64 oracle is evaluated up to this many input elements (a 4-modality 64^3 volume)
+
+
+def _oracle_vs_engine(dev, net, oracle_forward, x, lab, w, aux=False, tag=None, grad_tol=1e-1, f64=None):
+    """fp32 engine mode vs the oracle (stock torch on the CPU) on the same weights: logits, loss, and EVERY parameter gradient.
+    Both sides are fp32 evaluations of a deep network, so neither is the truth: up to 64^3 (f64, default by size) the oracle is
+    ALSO evaluated in float64 and every gradient tensor of the engine must be at most twice as far from that truth as the
+    stock-torch fp32 evaluation is (tests.util.f64_bar) — this replaces the blanket element-wise 1e-1 of round 4.  Above 64^3
+    (the 128^3 benchmarked shapes, where a float64 CPU evaluation takes minutes) the engine-vs-fp32-oracle numbers are
+    recorded, the cosine (>= 0.999: what a permuted / transposed / sign-flipped gradient cannot pass) and the norms (2 %) are
+    asserted, and the element-wise distance is bounded by `grad_tol` as an outlier guard only — the same architectures carry
+    the float64 bar at 64^3 (test_*_64_fp32_engine_inside_the_f64_bar)."""
+    if f64 is None:
+        f64 = x.numel() <= F64_MAX_VOXELS
     import cbim_amd
     from cbim_amd import functional as Fn
     from oracle.loss_ref import ce_dice_loss
@@ -256,7 +268,23 @@ def _oracle_vs_engine(dev, net, oracle_forward, x, lab, w, aux=False, tag=None, 
                                 grad_rel_worst=worst, grad_rel_worst_tensor=str(worst_k), grad_cos_min=cos_min,
                                 grad_tensors_within_1e3=n_ok, grad_tensors=n_t, grad_norm_rel_worst=e_norm))
     assert flips == 0
-    assert worst <= grad_tol and cos_min >= 0.999, (worst, worst_k, cos_min)
+    assert cos_min >= 0.999, (cos_min, worst_k)
+    if f64:
+        from tests.util import f64_bar
+        sd64 = {k: v.detach().cpu().clone().double().requires_grad_(v.is_floating_point()) if v.is_floating_point() else v.detach().cpu().clone()
+                for k, v in net.state_dict().items()}
+        outs64 = oracle_forward(sd64, x.double())
+        outs64 = outs64 if isinstance(outs64, (list, tuple)) else [outs64]
+        (sum(ce_dice_loss(o, lab, w.double()) for o in outs64) / len(outs64)).backward()
+        ratio, rk, e_eng, e_o32, amax, _ = f64_bar(got, ref, {k: sd64[k].grad for k in got})
+        print(f"float64 bar: worst L2 err(engine) / (2 err(fp32 oracle) + floor) = {ratio:.2f} ({rk}); largest distance from the float64 "
+              f"gradient: engine {e_eng:.2e}, fp32 oracle {e_o32:.2e} (of the tensor's norm); same ratio on the largest entry: {amax:.2f}")
+        if tag:
+            record_parity(tag + "_f64", dict(dtype="fp32", f64_ratio_worst=ratio, f64_ratio_worst_tensor=str(rk), f64_err_engine=e_eng,
+                                             f64_err_oracle32=e_o32, f64_maxabs_ratio_worst=amax))
+        assert ratio <= 1.0, (ratio, rk, e_eng, e_o32)
+    else:
+        assert worst <= grad_tol, (worst, worst_k)
 
 
 def _blocky(classes, shape, batch, seed):

@@ -184,6 +184,9 @@ def test_head_backward_on_matrix_cores(dev):
     oc.check_head_mfma(dev, N=1, base=64, K=16, dhw=(8, 8, 9))              # 18 steps over 8 waves: ragged last round
     oc.check_head_mfma(dev, N=1, base=96, K=3, dhw=(2, 4, 8))
     oc.check_head_mfma(dev, N=1, base=128, K=13, dhw=(4, 4, 8), need_dx=False)
+    oc.check_head_mfma(dev, N=1, base=48, K=4, dhw=(4, 8, 8))               # 16-channel tiles (round 5): SwinUNETR's 48-channel head
+    oc.check_head_mfma(dev, N=1, base=16, K=2, dhw=(2, 4, 8))
+    oc.check_head_mfma(dev, N=1, base=112, K=7, dhw=(2, 4, 8))
 
 
 def test_loss(dev):
@@ -311,3 +314,11 @@ def test_dwconv_lds_tiled_and_streaming_kernels(dev, dtype, lds):
         oc.check_dwconv(dev, dtype, N=1, C=24, dhw=(5, 9, 8), k=(3, 1, 3), act="none")
     finally:
         _lib.lib().cbim_dwconv_lds_enable(old)
+
+
+def test_token_linear(dev):
+    """the SwinUNETR trunk's token Linears on the engine's row GEMM (round 5)"""
+    oc.check_token_linear(dev)
+    oc.check_token_linear(dev, rows=64, Cin=384, Cout=96)        # few rows, long K: the four waves split K (KS = 4)
+    oc.check_token_linear(dev, rows=130, Cin=32, Cout=48)        # patch embedding width; ragged last row tile
+    oc.check_token_linear(dev, rows=257, Cin=96, Cout=384)       # 128 output channels per wave
