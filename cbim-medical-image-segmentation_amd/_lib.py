@@ -69,6 +69,7 @@ _SIGS = {
     "cbim_conv3d_packed_bytes": (sz, [_dp, i32]),
     "cbim_conv3d_pack_weights": (i32, [_dp, i32, vp, vp, vp]),
     "cbim_conv3d_pack_weights_both": (i32, [_dp, vp, vp, vp, vp]),
+    "cbim_conv3d_pack_weights_lo": (i32, [_dp, vp, vp, vp, vp]),
     "cbim_conv3d_pack_item_fill": (i32, [_dp, vp, vp, i32, vp, vp, i32, vp]),
     "cbim_conv3d_pack_weights_table": (i32, [vp, i32, i32, i32, vp]),
     "cbim_conv3d_last_kernel": (i32, []),
@@ -134,7 +135,7 @@ _SIGS = {
     "cbim_layernorm_fwd": (i32, [vp, vp, vp, f32, i32, vp, vp, i64, i32, vp]),
     "cbim_layernorm_bwd_workspace": (sz, [i64, i32]),
     "cbim_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, vp]),
-    "cbim_token_linear": (i32, [vp, i32, i64, i32, vp, vp, vp, i64, vp, i64, i32, vp, i32, i64, i64, i32, i32, vp]),
+    "cbim_token_linear": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, vp, i32, i64, i64, i32, i32, vp]),
     "cbim_token_linear_wgrad_workspace": (sz, [i64, i32, i32]),
     "cbim_token_linear_wgrad": (i32, [vp, i32, i64, i32, vp, i32, i64, vp, vp, sz, i64, i32, i32, vp]),
     "cbim_colsum_workspace": (sz, [i64, i32]),

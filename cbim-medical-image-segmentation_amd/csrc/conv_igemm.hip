@@ -789,7 +789,9 @@ __global__ void __launch_bounds__(FT) k_splitk_finish(const float* __restrict__ 
 // stride of `taps` floats and re-fetched each cache line ~27 times: 778 us for the ResUNet's 19 M weights, 0.1 TB/s,
 // 4.5 % of the training step) and leaves as runs of 32 (KC) sixteen-byte chunks = 512 contiguous bytes per (tap, k-slot),
 // in BOTH layouts from the one staged copy.
-struct PackGeom { const float* w0; const float* w1; void* p0; void* p1; int rows0, Cout, Cin, taps, BN0, nch0, BN1, nch1; };
+// lo (bf16 only, round 5): pack the ROUNDING RESIDUE w - bf16(w) instead of w — the second image of a weight whose GEMM keeps
+// fp32 accuracy (x . w = x . w_hi + x . w_lo: the token Linears outside SwinUNETR's autocast region, cbim_token_linear)
+struct PackGeom { const float* w0; const float* w1; void* p0; void* p1; int rows0, Cout, Cin, taps, BN0, nch0, BN1, nch1; int lo; };
 
 template <typename T>
 __device__ __forceinline__ void pack_block(const PackGeom& g, int blk, unsigned char* smem) {
@@ -835,8 +837,10 @@ __device__ __forceinline__ void pack_block(const PackGeom& g, int blk, unsigned 
           const int idx = idxv[u] + j;
           const int ci_l = (int)(((unsigned)idx * mdiv) >> 20), tap = idx - ci_l * taps;
           unsigned char* cell = smem + (size_t)((tap * 32 + rowv[u]) * KC + ci_l) * ES;
-          if (ES == 2) *(bf16_t*)cell = (bf16_t)pk_bf16(vv[j], 0.f);
-          else *(float*)cell = vv[j];
+          if (ES == 2) {
+            const bf16_t hi = (bf16_t)pk_bf16(vv[j], 0.f);
+            *(bf16_t*)cell = g.lo ? (bf16_t)pk_bf16(vv[j] - bf2f(hi), 0.f) : hi;
+          } else *(float*)cell = vv[j];
         }
       }
     }
@@ -906,7 +910,7 @@ __global__ void __launch_bounds__(256) k_pack_weights_table(const cbim_pack_item
   const cbim_pack_item it = items[lo];
   PackGeom g;
   g.w0 = it.w0; g.w1 = it.w1; g.p0 = it.p0; g.p1 = it.p1; g.rows0 = it.rows0; g.Cout = it.Cout; g.Cin = it.Cin;
-  g.taps = it.taps; g.BN0 = it.BN0; g.nch0 = it.nch0; g.BN1 = it.BN1; g.nch1 = it.nch1;
+  g.taps = it.taps; g.BN0 = it.BN0; g.nch0 = it.nch0; g.BN1 = it.BN1; g.nch1 = it.nch1; g.lo = 0;
   const int blk = (int)blockIdx.x - it.block_begin;
   if (it.dtype == CBIM_BF16) pack_block<bf16_tag>(g, blk, smem);
   else pack_block<float>(g, blk, smem);
@@ -1011,14 +1015,14 @@ static int pack_smem_attr() {
   return CBIM_OK;
 }
 
-static int pack_launch(const cbim_conv_desc* d, const float* w, void* p0, void* p1, void* stream) {
+static int pack_launch(const cbim_conv_desc* d, const float* w, void* p0, void* p1, void* stream, int lo = 0) {
   if (int e = validate(d)) return e;
   if (int e = pack_smem_attr()) return e;
   const int KC = kc_of(d->dtype), taps = d->kD * d->kH * d->kW;
   PackGeom g;
   g.w0 = w; g.w1 = nullptr; g.p0 = p0; g.p1 = p1; g.rows0 = d->Cout; g.Cout = d->Cout; g.Cin = d->Cin; g.taps = taps;
   g.BN0 = bn_of(d->Cout, d->kH * d->kW); g.BN1 = bn_of(d->Cin, d->kH * d->kW);
-  g.nch0 = (d->Cin + KC - 1) / KC; g.nch1 = (d->Cout + KC - 1) / KC;
+  g.nch0 = (d->Cin + KC - 1) / KC; g.nch1 = (d->Cout + KC - 1) / KC; g.lo = lo;
   const int blocks = pack_blocks(d->dtype, d->Cout, d->Cin, d->kH * d->kW);
   const size_t smem = (size_t)taps * 2048;
   hipStream_t st = (hipStream_t)stream;
@@ -1038,6 +1042,13 @@ extern "C" int cbim_conv3d_pack_weights_both(const cbim_conv_desc* d, const floa
                                              void* packed_dgrad, void* stream) {
   CBIM_CHECK(w && packed_fwd && packed_dgrad, CBIM_EINVAL, "null argument");
   return pack_launch(d, w, packed_fwd, packed_dgrad, stream);
+}
+
+extern "C" int cbim_conv3d_pack_weights_lo(const cbim_conv_desc* d, const float* w, void* packed_fwd, void* packed_dgrad,
+                                           void* stream) {
+  CBIM_CHECK(d && d->dtype == CBIM_BF16, CBIM_EINVAL, "residue images exist for bf16 only");
+  CBIM_CHECK(w && (packed_fwd || packed_dgrad), CBIM_EINVAL, "null argument");
+  return pack_launch(d, w, packed_fwd, packed_dgrad, stream, 1);
 }
 
 extern "C" int cbim_conv3d_pack_item_fill(const cbim_conv_desc* d, const float* w0, const float* w1, int rows0,

@@ -43,6 +43,7 @@ struct PwParams {
   // token mode (TK: nn.Linear over channels-last token rows, cbim_token_linear): bias float [Cout]; fp32 residual rows; the
   // activation whose derivative at the mask tensor (the pre-activation h of the MLP) multiplies the result; fp32 output rows
   const float* bias; const float* res32; int64_t res32_stride; int mask_act; int y32;
+  const void* w_lo;        // X32 only: the residue image of the weight (cbim_conv3d_pack_weights_lo) or NULL
 };
 
 #ifdef CBIM_EMU
@@ -157,6 +158,11 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
       if (!bok[nt]) return u32x4{0u, 0u, 0u, 0u};
       return *(const u32x4*)(wb + boff[nt] + (size_t)s * b_step);
     };
+    const unsigned char* const wlo = X32 ? (const unsigned char*)p.w_lo : nullptr;    // (workgroup-uniform)
+    auto load_b_lo = [&](int s, int nt) -> u32x4 {
+      if (!X32 || !wlo || !bok[nt]) return u32x4{0u, 0u, 0u, 0u};
+      return *(const u32x4*)(wlo + boff[nt] + (size_t)s * b_step);
+    };
     // fragments of PD k-groups in flight (a ring of PD register sets, the step loop unrolled by PD): with one k-group of
     // lookahead the deep-stage layers (Cin 1280: 80 steps of a few hundred cycles of MFMA work) waited out an L2 round trip per
     // step — 30 us for 8^3 1280->320
@@ -174,12 +180,17 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
       for (int u = 0; u < PD; ++u) {
         const int s = s0 + u;
         if (s < s_hi) {                                // wave-uniform
-          u32x4 a = a_q[u], bb[NTW];
-          if (X32) {                                   // fp32 row slot -> the bf16 fragment (raw values ride the ring: the
-            const u32x4 a2 = a_q2[u];                  //  conversion waits for the load only here, one ring depth later)
-            const float f8[CPC] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
-                                   __uint_as_float(a2.x), __uint_as_float(a2.y), __uint_as_float(a2.z), __uint_as_float(a2.w)};
-            a = Elem<T>::pack(f8);
+          u32x4 a = a_q[u], a_lo = u32x4{0u, 0u, 0u, 0u}, bb[NTW];
+          if (X32) {                                   // fp32 row slot -> bf16 hi + lo fragments: the rows keep fp32 accuracy (two
+            const u32x4 a2 = a_q2[u];                  //  MFMAs per n-tile: these GEMMs are bound by their row traffic).  Raw values
+            const float f8[CPC] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),   // ride the ring:
+                                   __uint_as_float(a2.x), __uint_as_float(a2.y), __uint_as_float(a2.z), __uint_as_float(a2.w)};  // the conversion
+            a = Elem<T>::pack(f8);                     //  waits for the load only here, one ring depth later
+            float fh[CPC], fl[CPC];
+            Elem<T>::unpack(a, fh);
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) fl[j] = f8[j] - fh[j];
+            a_lo = Elem<T>::pack(fl);
           }
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) bb[nt] = b_q[u][nt];
@@ -211,8 +222,12 @@ __global__ void __launch_bounds__(PW_NT, 2) k_conv_pw(PwParams p) {
             }
           }
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
+          for (int nt = 0; nt < NTW; ++nt) {
+            if (X32 && wlo)     // (the residue image is read where it is used: L1 / L2 hits next to the hi image, few layers)
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, load_b_lo(s, nt)), acc[nt], 0, 0, 0);
+            if (X32) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lo), __builtin_bit_cast(bf16x8, bb[nt]), acc[nt], 0, 0, 0);
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb[nt]), acc[nt], 0, 0, 0);
+          }
         }
       }
     }
@@ -584,7 +599,7 @@ int cbim_conv_pw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
   p.N = d->N; p.S = (int64_t)d->Do * d->Ho * d->Wo; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
   p.nch = (d->Cin + 31) / 32;
   p.BNp = d->Cout <= 32 ? 32 : 64;
-  p.bias = nullptr; p.res32 = nullptr; p.res32_stride = 0; p.mask_act = 0; p.y32 = 0;
+  p.bias = nullptr; p.res32 = nullptr; p.res32_stride = 0; p.mask_act = 0; p.y32 = 0; p.w_lo = nullptr;
   int ntw, ks;
   pw_plan(d, &ntw, &ks);
   pw_strips(p.S, ks == 4 ? 32 : PW_ROWS, &p.tiles_per_n, &p.tiles_per_strip, &p.Pn);
@@ -678,7 +693,8 @@ static int tok_launch_n(const PwParams& p, dim3 grid, size_t smem, int act_in, i
   return tok_launch_a<NTW, KS, -1, false>(p, grid, smem, st);
 }
 
-extern "C" int cbim_token_linear(const void* x, int x_dtype, int64_t x_stride, int act_in, const void* w_packed, const float* bias,
+extern "C" int cbim_token_linear(const void* x, int x_dtype, int64_t x_stride, int act_in, const void* w_packed, const void* w_lo_packed,
+                                 const float* bias,
                                  const float* res, int64_t res_stride, const void* mask, int64_t mask_stride, int mask_act,
                                  void* y, int y_dtype, int64_t y_stride, int64_t rows, int Cin, int Cout, void* stream) {
   CBIM_CHECK(x && w_packed && y && rows >= 1, CBIM_EINVAL, "token linear: null operand / no rows");
@@ -688,9 +704,11 @@ extern "C" int cbim_token_linear(const void* x, int x_dtype, int64_t x_stride, i
   CBIM_CHECK(x_stride % 8 == 0 && y_stride % 8 == 0 && (!res || res_stride % 4 == 0) && (!mask || mask_stride % 8 == 0), CBIM_EUNSUPPORTED,
              "token linear: row strides must keep 16-byte chunks aligned");
   CBIM_CHECK(!(x_dtype == CBIM_F32 && act_in != CBIM_ACT_NONE), CBIM_EUNSUPPORTED, "token linear: activation on load takes bf16 rows");
+  CBIM_CHECK(!w_lo_packed || x_dtype == CBIM_F32, CBIM_EUNSUPPORTED, "token linear: a residue weight image goes with fp32 rows");
   cbim_conv_desc d;
   tok_desc(&d, rows, Cin, Cout);
   PwParams p;
+  p.w_lo = w_lo_packed;
   p.x = x; p.x_stride = x_stride; p.in_stats = nullptr; p.w = w_packed;
   p.res = nullptr; p.res_stride = 0; p.mx = mask; p.mx_stride = mask_stride; p.m_stats = nullptr;
   p.y = y; p.y_stride = y_stride; p.partials = nullptr;

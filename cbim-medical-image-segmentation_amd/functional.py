@@ -687,7 +687,7 @@ class TokenLinearFn(_GradAwareFunction):
     as the gradient of `res`."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act_in, res, out_dtype, need_dx):
+    def forward(ctx, x, w, b, act_in, res, out_dtype, need_dx, exact):
         Cout, Cin = int(w.shape[0]), int(w.numel() // w.shape[0])
         shape = tuple(x.shape[:-1])
         x2 = x.reshape(-1, Cin)
@@ -696,21 +696,26 @@ class TokenLinearFn(_GradAwareFunction):
         g = ops.linear_geom(Cin, Cout)
         train = _training(ctx)
         wp, wpd = ops.packed_weights((w,), g, bool(need_dx) and train)
+        # exact (fp32 rows only): also the residue image w - bf16(w) — the product keeps fp32 accuracy (the Linears the reference
+        # evaluates in fp32 when only the blocks run under reduced precision: patch embedding, patch merging)
+        exact = bool(exact) and x2.dtype == torch.float32
+        wl, wld = ops.lo_weights(w, g, bool(need_dx) and train) if exact else (None, None)
         r2 = None
         if res is not None:
             r2 = res.reshape(-1, Cout)
             r2 = r2 if r2.is_contiguous() else r2.contiguous()
         bias = b.detach().float().contiguous() if b is not None else None
-        y = ops.token_linear(x2, wp, bias, Cout, act_in=act_in, res=r2, out_dtype=torch.float32 if res is not None else out_dtype)
+        y = ops.token_linear(x2, wp, bias, Cout, act_in=act_in, res=r2, out_dtype=torch.float32 if res is not None else out_dtype,
+                             w_lo=wl)
         ctx.save_for_backward(x2)
-        ctx.cfg = (act_in, wpd, Cin, Cout, b is not None, res is not None, tuple(x.shape), tuple(w.shape), bool(need_dx))
+        ctx.cfg = (act_in, wpd, Cin, Cout, b is not None, res is not None, tuple(x.shape), tuple(w.shape), bool(need_dx), wld)
         ctx.w_param, ctx.b_param = ops.slot_of(w), ops.slot_of(b)
         return y.view(shape + (Cout,))
 
     @staticmethod
     def backward(ctx, dy):
         (x2,) = ctx.saved_tensors
-        act_in, wpd, Cin, Cout, has_b, has_res, x_shape, w_shape, need_dx = ctx.cfg
+        act_in, wpd, Cin, Cout, has_b, has_res, x_shape, w_shape, need_dx, wld = ctx.cfg
         d2 = dy.reshape(-1, Cout)
         if d2.dtype not in (torch.float32, torch.bfloat16):
             d2 = d2.float()
@@ -727,13 +732,15 @@ class TokenLinearFn(_GradAwareFunction):
         if need_dx and ctx.needs_input_grad[0]:
             # the forward layer's dgrad image is a [Cin x Cout] "weight": dx = dy @ W, times act_in'(x) where x is the stored
             # pre-activation (the MLP's second Linear)
-            dx = ops.token_linear(d2, wpd, None, Cin, mask=x2 if act_in else None, mask_act=act_in, out_dtype=torch.bfloat16)
+            exact = wld is not None and d2.dtype == torch.float32
+            dx = ops.token_linear(d2, wpd, None, Cin, mask=x2 if act_in else None, mask_act=act_in,
+                                  out_dtype=torch.float32 if exact else torch.bfloat16, w_lo=wld if exact else None)
             dx = dx.view(x_shape)
-        return dx, dw, db, None, (dy if has_res else None), None, None
+        return dx, dw, db, None, (dy if has_res else None), None, None, None
 
 
-def token_linear(x, weight, bias, act_in=0, res=None, out_dtype=torch.bfloat16, need_dx=True):
-    return TokenLinearFn.apply(x, weight, bias, act_in, res, out_dtype, need_dx)
+def token_linear(x, weight, bias, act_in=0, res=None, out_dtype=torch.bfloat16, need_dx=True, exact=False):
+    return TokenLinearFn.apply(x, weight, bias, act_in, res, out_dtype, need_dx, exact)
 
 
 class ResNormFn(torch.autograd.Function):

@@ -158,8 +158,10 @@ class PatchEmbed(nn.Module):
         x = x.reshape(B, Cc, D // p[0], p[0], H // p[1], p[1], W // p[2], p[2]).permute(0, 2, 4, 6, 1, 3, 5, 7)
         tok = x.reshape(B, D // p[0], H // p[1], W // p[2], -1)
         if _in_tree(tok, self.proj):
-            # the fp32 patch rows feed the row GEMM as they are (rounded to bf16 in registers); fp32 out = the residual stream
-            return Fn.token_linear(tok.contiguous(), self.proj.weight, self.proj.bias, out_dtype=torch.float32, need_dx=False)
+            # the fp32 patch rows feed the row GEMM as they are (bf16 hi + lo fragments of rows AND weights: this Linear lies
+            # outside the blocks' reduced-precision region and keeps fp32 accuracy); fp32 out = the residual stream
+            return Fn.token_linear(tok.contiguous(), self.proj.weight, self.proj.bias, out_dtype=torch.float32, need_dx=False,
+                                   exact=True)
         if _SPLITK_DW and tok.is_cuda and torch.is_grad_enabled() and self.proj.weight.requires_grad:
             # (the weight gradient is a 48 x 32 output over 262 144 tokens: one workgroup and 612 us in the library's
             #  default tiling; the split-K form of the other token Linears fills the chip)
@@ -363,8 +365,9 @@ class PatchMerging(nn.Module):
         else:
             x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self._SEL], -1)
         if _in_tree(x, self.reduction):
-            # LayerNorm stores bf16 (what the Linear reads under AMP in the reference too); fp32 out = the next stage's stream
-            return Fn.token_linear(_layer_norm(self.norm, x, torch.bfloat16), self.reduction.weight, None, out_dtype=torch.float32)
+            # fp32 LayerNorm rows feed the row GEMM as they are (bf16 hi + lo fragments); fp32 out = the next stage's stream
+            return Fn.token_linear(_layer_norm(self.norm, x, torch.float32), self.reduction.weight, None, out_dtype=torch.float32,
+                                   exact=True)
         return _token_linear(self.reduction, _layer_norm(self.norm, x, torch.float32))
 
 

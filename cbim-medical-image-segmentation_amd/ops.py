@@ -389,6 +389,7 @@ class PackedWeights:
     def __init__(self):
         self.entries = {}
         self.stale = False     # set after a hipGraph replay (the captured optimizer moved the weights unseen)
+        self.epoch = getattr(self, "epoch", 0) + 1     # moves with every whole-table re-pack (ops.lo_weights follows it)
         self.table = None      # device copy of the cbim_pack_item array
         self.n_blocks = 0
         self.max_taps = 1
@@ -488,6 +489,7 @@ class PackedWeights:
         if capturing:
             _hook_graph_replay()
         self.stale = False
+        self.epoch += 1
         if self.dirty_table:
             if self.table is not None and self.table.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("cbim_amd: a new convolution weight appeared during hipGraph capture; run one "
@@ -1043,8 +1045,28 @@ def linear_geom(Cin: int, Cout: int) -> ConvGeom:
     return g
 
 
+_LO_CACHE = {}
+
+
+def lo_weights(w: torch.Tensor, geom: ConvGeom, need_dgrad: bool):
+    """(forward, dgrad | None) packed images of the rounding residue w - bf16(w) of a weight (cbim_conv3d_pack_weights_lo),
+    re-packed when the parameter's version moved (once per optimizer step; under hipGraph capture the launch is captured)."""
+    _dev_ok(w)
+    key = (w.data_ptr(), tuple(w.shape))
+    e = _LO_CACHE.get(key)
+    stale = PACKED.stale or e is None or e[0] != (w._version, PACKED.epoch) or (need_dgrad and e[2] is None)
+    if stale:
+        L = _lib.lib()
+        p0 = e[1] if e is not None else torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 0),), dtype=torch.uint8, device=w.device)
+        p1 = e[2] if e is not None and e[2] is not None else (
+            torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 1),), dtype=torch.uint8, device=w.device) if need_dgrad else None)
+        check(L.cbim_conv3d_pack_weights_lo(C.byref(geom.fwd), _p(w.detach()), _p(p0), _p(p1), _stream(w)), "pack_weights_lo")
+        e = _LO_CACHE[key] = ((w._version, PACKED.epoch), p0, p1, w)       # (keeps the parameter alive: data_ptr stays unique)
+    return e[1], (e[2] if need_dgrad else None)
+
+
 def token_linear(x2d, w_packed, bias, Cout: int, act_in: int = 0, res=None, mask=None, mask_act: int = 0,
-                 out_dtype: torch.dtype = torch.bfloat16):
+                 out_dtype: torch.dtype = torch.bfloat16, w_lo=None):
     """y = (act_in(x) @ W^T + bias) * act'(mask) + res over token rows (include/cbim_hip.h cbim_token_linear).
     x2d [rows, Cin] bf16 | fp32, res fp32 [rows, Cout] | None, mask bf16 [rows, Cout] | None -> y [rows, Cout] in out_dtype."""
     _dev_ok(x2d, w_packed, bias, res, mask)
@@ -1058,7 +1080,7 @@ def token_linear(x2d, w_packed, bias, Cout: int, act_in: int = 0, res=None, mask
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().cbim_token_linear(_p(x2d), _dt(x2d), int(x2d.stride(0)), act_in, _p(w_packed), _p(bias),
+    check(_lib.lib().cbim_token_linear(_p(x2d), _dt(x2d), int(x2d.stride(0)), act_in, _p(w_packed), _p(w_lo), _p(bias),
                                        _p(res), int(res.stride(0)) if res is not None else 0,
                                        _p(mask), int(mask.stride(0)) if mask is not None else 0, mask_act,
                                        _p(y), _dt(y), Cout, rows, Cin, Cout, _stream(x2d)), "token_linear")

@@ -186,6 +186,10 @@ int cbim_conv3d_pack_weights(const cbim_conv_desc* fwd_desc, int mode, const flo
 /* Both layouts in one launch (training: the dgrad layout is needed in the backward of the same step). */
 int cbim_conv3d_pack_weights_both(const cbim_conv_desc* fwd_desc, const float* w, void* packed_fwd,
                                   void* packed_dgrad, void* stream);
+/* The rounding residue w - bf16(w) in the same two layouts (either pointer may be NULL; bf16 descriptors only): the second
+ * weight image of a GEMM that keeps fp32 accuracy, x . w = x . w_hi + x . w_lo (cbim_token_linear's w_lo_packed). */
+int cbim_conv3d_pack_weights_lo(const cbim_conv_desc* d, const float* w, void* packed_fwd, void* packed_dgrad,
+                                void* stream);
 /* All convolution weights of a model in one launch.  The host fills one cbim_pack_item per weight with
  * cbim_conv3d_pack_item_fill (w1 != NULL: forward output channels >= rows0 come from w1 — the Cout-concatenated
  * conv1|shortcut pair of BasicBlock, conv_layers.py:86-94, packed without a torch.cat; block_begin = running sum of the
@@ -514,11 +518,15 @@ int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, const float
  *
  *     y[r][co] = ( sum_ci act_in(x[r][ci]) * w[co][ci] + bias[co] ) * act'(mask[r][co]) + res[r][co]
  *
- *   x        [rows][Cin], x_dtype CBIM_BF16 or CBIM_F32 (fp32 rows are rounded to bf16 in registers: the fp32
- *            residual-stream gradient feeds the input-gradient GEMM as it is); act_in (CBIM_ACT_*, bf16 rows only) is
+ *   x        [rows][Cin], x_dtype CBIM_BF16 or CBIM_F32 (fp32 rows are split into bf16 hi + lo fragments in registers
+ *            and keep their fp32 accuracy: the patch rows and the fp32 residual-stream gradient feed the GEMM as they
+ *            are, no cast pass); act_in (CBIM_ACT_*, bf16 rows only) is
  *            applied on load — linear2 reads the stored pre-activation h, GELU(h) is never written;
  *   w_packed cbim_conv3d_pack_weights image of the weight seen as a 1x1x1 convolution [Cout][Cin] (mode 0; mode 1 of the
  *            FORWARD layer's weight for its input gradient, with Cin / Cout exchanged here);
+ *   w_lo_packed  NULL, or (fp32 rows only) the cbim_conv3d_pack_weights_lo image of the same weight: three MFMAs per
+ *            fragment pair (x_hi w_hi + x_lo w_hi + x_hi w_lo) give the product fp32 accuracy — the Linears the reference
+ *            runs outside any reduced-precision region of ours (PatchEmbed.proj, PatchMerging.reduction);
  *   bias     float [Cout] or NULL;  mask: bf16 [rows][Cout] or NULL, mask_act the activation whose derivative is taken
  *            (input gradient of linear2 at the stored h);  res: float [rows][Cout] or NULL (the residual stream);
  *   y        [rows][Cout] in y_dtype.  Cin, Cout multiples of 8, Cin <= 4096; strides in elements.
@@ -526,7 +534,8 @@ int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, const float
  * operand in bf16 or fp32; workspace cbim_token_linear_wgrad_workspace(rows, Cin, Cout) bytes.  The bias gradient is
  * cbim_colsum of dy.
  * ------------------------------------------------------------------------------------------ */
-int cbim_token_linear(const void* x, int x_dtype, int64_t x_stride, int act_in, const void* w_packed, const float* bias,
+int cbim_token_linear(const void* x, int x_dtype, int64_t x_stride, int act_in, const void* w_packed, const void* w_lo_packed,
+                      const float* bias,
                       const float* res, int64_t res_stride, const void* mask, int64_t mask_stride, int mask_act,
                       void* y, int y_dtype, int64_t y_stride, int64_t rows, int Cin, int Cout, void* stream);
 size_t cbim_token_linear_wgrad_workspace(int64_t rows, int Cin, int Cout);

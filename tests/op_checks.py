@@ -1112,8 +1112,18 @@ def check_token_linear(dev, rows=300, Cin=48, Cout=144, seed=91):
     close(ops.token_linear(xb.to(dev), wp, b.to(dev), Cout), ref, 6e-3, "bf16 -> bf16")
     close(ops.token_linear(xb.to(dev), wp, b.to(dev), Cout, out_dtype=torch.float32), ref, 2e-5, "bf16 -> fp32")
     close(ops.token_linear(xb.to(dev), wp, None, Cout, out_dtype=torch.float32), xb.float() @ wr.t(), 2e-5, "no bias")
-    # fp32 rows (rounded to bf16 in registers)
-    close(ops.token_linear(x32.to(dev), wp, b.to(dev), Cout, out_dtype=torch.float32), rt(x32) @ wr.t() + b, 2e-5, "fp32 rows")
+    # fp32 rows (split into bf16 hi + lo in registers: ~2^-17 on the row side)
+    close(ops.token_linear(x32.to(dev), wp, b.to(dev), Cout, out_dtype=torch.float32), x32 @ wr.t() + b, 3e-5, "fp32 rows (hi + lo)")
+    # fp32 rows + the residue weight image: the product at fp32 accuracy (three MFMAs per fragment pair)
+    wl0 = torch.empty_like(wp)
+    wl1 = torch.empty_like(wpd)
+    from cbim_amd import _lib as _L
+    import ctypes as _C
+    _L.check(_L.lib().cbim_conv3d_pack_weights_lo(_C.byref(g.fwd), _C.c_void_p(wdev.data_ptr()), _C.c_void_p(wl0.data_ptr()),
+                                                  _C.c_void_p(wl1.data_ptr()), None if dev == "cpu" else _C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pack lo")
+    close(ops.token_linear(x32.to(dev), wp, b.to(dev), Cout, out_dtype=torch.float32, w_lo=wl0), x32 @ w.t() + b, 3e-5, "exact: fp32 rows, hi + lo weights")
+    dye = torch.randn(rows, Cout)
+    close(ops.token_linear(dye.to(dev), wpd, None, Cin, out_dtype=torch.float32, w_lo=wl1), dye @ w, 3e-5, "exact: input gradient")
     # GELU on load + fp32 residual (the activated tensor is rounded to bf16 like any MFMA operand)
     ref = rt(F.gelu(xb.float())) @ wr.t() + b + res
     close(ops.token_linear(xb.to(dev), wp, b.to(dev), Cout, act_in=ops.ACT["gelu"], res=res.to(dev), out_dtype=torch.float32), ref, 2e-5,
@@ -1123,7 +1133,7 @@ def check_token_linear(dev, rows=300, Cin=48, Cout=144, seed=91):
     hin = (torch.randn(rows, Cin) * 1.5).to(BF)
     hh = hin.float().requires_grad_(True)
     F.gelu(hh).backward(torch.ones_like(hh))
-    ref = (rt(dy32) @ wr) * hh.grad
+    ref = (dy32 @ wr) * hh.grad
     close(ops.token_linear(dy32.to(dev), wpd, None, Cin, mask=hin.to(dev), mask_act=ops.ACT["gelu"]), ref, 6e-3, "dgrad * gelu'(h)")
     close(ops.token_linear(dy32.to(BF).to(dev), wpd, None, Cin), rt(dy32) @ wr, 6e-3, "dgrad bf16 rows")
     # weight gradient: operands in bf16 / fp32, GELU on load
