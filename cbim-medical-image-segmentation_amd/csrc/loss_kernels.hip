@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(NT) k_dice_ce_finalize(const float* __restrict
     double ddice_dSP = -q * dden_dSP;
     coef[c] = (float)(-ddice_dTP / C);
     coef[C + c] = (float)(-ddice_dSP / C);
+    coef[2 * C + 1 + c] = (float)(1.0 - dice);        // per-class loss term: DiceLoss(reduce=False) (losses.py:48-50)
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -22,12 +22,15 @@ struct RowMap {  // thread -> (channel chunk, voxel lane)
 // ---- partial sums: (sum u, sum u*v) per channel over a slab of voxels -----------------------------
 // MODE 0: u = x, v = x                      (forward statistics)
 // MODE 1: u = g', v = xh  with xh=(x-mean)*rstd, g' = masked ? g*act'(xh) : g
-template <typename T, int MODE>
+// AFF (MODE 1, round 5): a per-channel affine between the normalisation and the activation, z = gamma * xh + beta
+//      (affine float [Cl][2]): the mask is act'(z); the sums stay those of g' and g' * xh (d beta, d gamma of BatchNorm)
+template <typename T, int MODE, bool AFF = false>
 __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a, int64_t a_stride,
                                                      const void* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ stats, int64_t S, int C,
                                                      int P, int act, int masked,
-                                                     float* __restrict__ partials, int Cl, int c_off) {
+                                                     float* __restrict__ partials, int Cl, int c_off,
+                                                     const float* __restrict__ affine = nullptr) {
   // C = channels handled by this launch (<= NT chunks), starting at channel c_off of a Cl-channel tensor
   constexpr int CPC = Elem<T>::CPC;
   const int cch = C / CPC;
@@ -40,16 +43,17 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
   int64_t v1 = v0 + per;
   if (v1 > S) v1 = S;
 
-  float s0[CPC], s1[CPC], mean[CPC], rstd[CPC], shift[CPC];
+  float s0[CPC], s1[CPC], mean[CPC], rstd[CPC], shift[CPC], gam[CPC], bet[CPC];
   float cnt = 0.f;
 #pragma unroll
-  for (int j = 0; j < CPC; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f; shift[j] = 0.f; }
+  for (int j = 0; j < CPC; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f; shift[j] = 0.f; gam[j] = 1.f; bet[j] = 0.f; }
   const bool active = vl < vlc;
   if (MODE == 1 && active) {
 #pragma unroll
     for (int j = 0; j < CPC; ++j) {
       mean[j] = stats[((size_t)n * Cl + c_off + cc * CPC + j) * 2 + 0];
       rstd[j] = stats[((size_t)n * Cl + c_off + cc * CPC + j) * 2 + 1];
+      if (AFF) { gam[j] = affine[(size_t)(c_off + cc * CPC + j) * 2]; bet[j] = affine[(size_t)(c_off + cc * CPC + j) * 2 + 1]; }
     }
   }
   const size_t nb = (size_t)n * S;
@@ -73,7 +77,7 @@ __global__ void __launch_bounds__(NT) k_partial_sums(const void* __restrict__ a,
 #pragma unroll
         for (int j = 0; j < CPC; ++j) {
           float xh = (fx[j] - mean[j]) * rstd[j];
-          float g = masked ? fa[j] * act_grad(xh, act) : fa[j];
+          float g = masked ? fa[j] * act_grad(AFF ? fmaf(gam[j], xh, bet[j]) : xh, act) : fa[j];
           s0[j] += g;
           s1[j] = fmaf(g, xh, s1[j]);
         }
@@ -202,11 +206,13 @@ __global__ void __launch_bounds__(FIN_T) k_stats_finalize(const float* __restric
 // over voxel rows, 4 rows per trip so that 4 independent 16-byte loads per tensor are in flight;
 // no integer division in the loop.  grid = (row blocks, N).
 static constexpr int RU = 4;
-template <typename T>
+// AFF (round 5): y = act(gamma * (x-mean)*rstd + beta), affine float [Cl][2] — nn.BatchNorm3d / ContBatchNorm3d (affine norms of
+//      the `norm: bn` constructor branch, /root/reference/model/dim3/utils.py:15-21; vnet.py:22-33)
+template <typename T, bool AFF = false>
 __global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ stats, void* __restrict__ y,
                                                      int64_t y_stride, int64_t S, int C, int act, int Cl,
-                                                     int c_off) {
+                                                     int c_off, const float* __restrict__ affine = nullptr) {
   constexpr int CPC = Elem<T>::CPC;
   const int cch = C / CPC, vlc = NT / cch;
   const int cc = threadIdx.x % cch + c_off / CPC, vl = threadIdx.x / cch;
@@ -217,6 +223,11 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x,
   for (int j = 0; j < CPC; ++j) {
     mean[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2];
     rstd[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2 + 1];
+    if (AFF) {      // folded in fp32 registers: (x - mean') * rstd' with rstd' = gamma rstd, mean' rstd' = mean rstd' - beta
+      const float ga = affine[(size_t)(cc * CPC + j) * 2], be = affine[(size_t)(cc * CPC + j) * 2 + 1];
+      rstd[j] *= ga;
+      mean[j] = mean[j] * rstd[j] - be;             // now: y = x * rstd' - mean[j]
+    }
   }
   const size_t nb = (size_t)n * S;
   const int64_t step = (int64_t)gridDim.x * vlc;
@@ -231,7 +242,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x,
         float f[CPC];
         Elem<T>::unpack(raw[u], f);
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) f[j] = act_fwd((f[j] - mean[j]) * rstd[j], act);
+        for (int j = 0; j < CPC; ++j) f[j] = act_fwd(AFF ? fmaf(f[j], rstd[j], -mean[j]) : (f[j] - mean[j]) * rstd[j], act);
         st_chunk<T>(y, (nb + v + u * step) * y_stride + (size_t)cc * CPC, Elem<T>::pack(f));
       }
     }
@@ -239,26 +250,31 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x,
 }
 
 // ---- dx = rstd*(g' - m1 - xh*m2) [+ add] --------------------------------------------------------------
-template <typename T>
+// AFF: z = gamma * xh + beta between normalisation and activation: g' = g * act'(z) * gamma, and `sums` are the means of
+//      gamma g' and gamma g' xh (the caller scales the batch means of cbim_norm_affine_bwd_reduce by gamma — no division)
+template <typename T, bool AFF = false>
 __global__ void __launch_bounds__(NT) k_norm_bwd_apply(const void* __restrict__ g, int64_t g_stride,
                                                        const void* __restrict__ x, int64_t x_stride,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ sums,
                                                        const void* __restrict__ add, int64_t add_stride,
                                                        void* __restrict__ dx, int64_t dx_stride, int64_t S,
-                                                       int C, int act, int masked, int Cl, int c_off) {
+                                                       int C, int act, int masked, int Cl, int c_off,
+                                                       const float* __restrict__ affine = nullptr) {
   constexpr int CPC = Elem<T>::CPC;
   const int cch = C / CPC, vlc = NT / cch;
   const int cc = threadIdx.x % cch + c_off / CPC, vl = threadIdx.x / cch;
   if (vl >= vlc) return;
   const int n = blockIdx.y;
-  float mean[CPC], rstd[CPC], m1[CPC], m2[CPC];
+  float mean[CPC], rstd[CPC], m1[CPC], m2[CPC], gam[CPC], bet[CPC];
 #pragma unroll
   for (int j = 0; j < CPC; ++j) {
     mean[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2];
     rstd[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2 + 1];
     m1[j] = sums[((size_t)n * Cl + cc * CPC + j) * 2];
     m2[j] = sums[((size_t)n * Cl + cc * CPC + j) * 2 + 1];
+    gam[j] = AFF ? affine[(size_t)(cc * CPC + j) * 2] : 1.f;
+    bet[j] = AFF ? affine[(size_t)(cc * CPC + j) * 2 + 1] : 0.f;
   }
   const size_t nb = (size_t)n * S;
   const int64_t step = (int64_t)gridDim.x * vlc;
@@ -282,7 +298,8 @@ __global__ void __launch_bounds__(NT) k_norm_bwd_apply(const void* __restrict__ 
 #pragma unroll
         for (int j = 0; j < CPC; ++j) {
           float xh = (fx[j] - mean[j]) * rstd[j];
-          float gg = masked ? fg[j] * act_grad(xh, act) : fg[j];
+          float gg = masked ? fg[j] * act_grad(AFF ? fmaf(gam[j], xh, bet[j]) : xh, act) : fg[j];
+          if (AFF) gg *= gam[j];
           float d = rstd[j] * (gg - m1[j] - xh * m2[j]);
           fg[j] = add ? d + fa[j] : d;
         }
@@ -548,10 +565,10 @@ extern "C" int cbim_instnorm_stats(int dtype, const void* x, int64_t x_stride, i
   FOR_CHANNEL_GROUPS(dtype, C) {
     if (dtype == CBIM_BF16)
       CBIM_LAUNCH((k_partial_sums<bf16_tag, 0>), grid, dim3(NT), 0, st, x, x_stride, x, x_stride,
-                  (const float*)nullptr, S, Cg, P, 0, 0, partials, C, c_off);
+                  (const float*)nullptr, S, Cg, P, 0, 0, partials, C, c_off, (const float*)nullptr);
     else
       CBIM_LAUNCH((k_partial_sums<float, 0>), grid, dim3(NT), 0, st, x, x_stride, x, x_stride,
-                  (const float*)nullptr, S, Cg, P, 0, 0, partials, C, c_off);
+                  (const float*)nullptr, S, Cg, P, 0, 0, partials, C, c_off, (const float*)nullptr);
   }
   return cbim_stats_finalize(partials, N, P, C, (double)S, eps, 0, stats, stream);
 }
@@ -572,10 +589,10 @@ extern "C" int cbim_norm_act_fwd(int dtype, const void* x, int64_t x_stride, con
     dim3 grid(row_blocks(dtype, S, Cg), N);
     if (dtype == CBIM_BF16)
       CBIM_LAUNCH((k_norm_act_fwd<bf16_tag>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, Cg, act, C,
-                  c_off);
+                  c_off, (const float*)nullptr);
     else
       CBIM_LAUNCH((k_norm_act_fwd<float>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, Cg, act, C,
-                  c_off);
+                  c_off, (const float*)nullptr);
   }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
@@ -589,10 +606,10 @@ extern "C" int cbim_norm_bwd_reduce(int dtype, const void* g, int64_t g_stride, 
   FOR_CHANNEL_GROUPS(dtype, C) {
     if (dtype == CBIM_BF16)
       CBIM_LAUNCH((k_partial_sums<bf16_tag, 1>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, Cg,
-                  P, act, masked, partials, C, c_off);
+                  P, act, masked, partials, C, c_off, (const float*)nullptr);
     else
       CBIM_LAUNCH((k_partial_sums<float, 1>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, Cg, P,
-                  act, masked, partials, C, c_off);
+                  act, masked, partials, C, c_off, (const float*)nullptr);
   }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
@@ -607,10 +624,63 @@ extern "C" int cbim_norm_bwd_apply(int dtype, const void* g, int64_t g_stride, c
     dim3 grid(row_blocks(dtype, S, Cg), N);
     if (dtype == CBIM_BF16)
       CBIM_LAUNCH((k_norm_bwd_apply<bf16_tag>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
-                  add_stride, dx, dx_stride, S, Cg, act, masked, C, c_off);
+                  add_stride, dx, dx_stride, S, Cg, act, masked, C, c_off, (const float*)nullptr);
     else
       CBIM_LAUNCH((k_norm_bwd_apply<float>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, add,
-                  add_stride, dx, dx_stride, S, Cg, act, masked, C, c_off);
+                  add_stride, dx, dx_stride, S, Cg, act, masked, C, c_off, (const float*)nullptr);
+  }
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+
+// ---- the same three passes with a per-channel affine (gamma, beta) between normalisation and activation (round 5) ---------
+extern "C" int cbim_norm_affine_act_fwd(int dtype, const void* x, int64_t x_stride, const float* stats, const float* affine,
+                                        void* y, int64_t y_stride, int N, int64_t S, int C, int act, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  CBIM_CHECK(affine, CBIM_EINVAL, "norm_affine_act_fwd: null affine");
+  hipStream_t st = (hipStream_t)stream;
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    dim3 grid(row_blocks(dtype, S, Cg), N);
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_norm_act_fwd<bf16_tag, true>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, Cg, act, C, c_off, affine);
+    else
+      CBIM_LAUNCH((k_norm_act_fwd<float, true>), grid, dim3(NT), 0, st, x, x_stride, stats, y, y_stride, S, Cg, act, C, c_off, affine);
+  }
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_norm_affine_bwd_reduce(int dtype, const void* g, int64_t g_stride, const void* x, int64_t x_stride,
+                                           const float* stats, const float* affine, int N, int64_t S, int C, int act, int masked,
+                                           float* partials, int P, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  CBIM_CHECK(affine, CBIM_EINVAL, "norm_affine_bwd_reduce: null affine");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(P, N);
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_partial_sums<bf16_tag, 1, true>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, Cg, P, act, masked,
+                  partials, C, c_off, affine);
+    else
+      CBIM_LAUNCH((k_partial_sums<float, 1, true>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, S, Cg, P, act, masked,
+                  partials, C, c_off, affine);
+  }
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_norm_affine_bwd_apply(int dtype, const void* g, int64_t g_stride, const void* x, int64_t x_stride,
+                                          const float* stats, const float* affine, const float* sums, void* dx, int64_t dx_stride,
+                                          int N, int64_t S, int C, int act, int masked, void* stream) {
+  if (int e = check_c(dtype, C)) return e;
+  CBIM_CHECK(affine, CBIM_EINVAL, "norm_affine_bwd_apply: null affine");
+  hipStream_t st = (hipStream_t)stream;
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    dim3 grid(row_blocks(dtype, S, Cg), N);
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_norm_bwd_apply<bf16_tag, true>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, (const void*)nullptr,
+                  (int64_t)0, dx, dx_stride, S, Cg, act, masked, C, c_off, affine);
+    else
+      CBIM_LAUNCH((k_norm_bwd_apply<float, true>), grid, dim3(NT), 0, st, g, g_stride, x, x_stride, stats, sums, (const void*)nullptr,
+                  (int64_t)0, dx, dx_stride, S, Cg, act, masked, C, c_off, affine);
   }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }

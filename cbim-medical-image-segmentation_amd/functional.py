@@ -452,6 +452,35 @@ class DiceCEFn(torch.autograd.Function):
         return dz, None, None
 
 
+class DicePerClassFn(torch.autograd.Function):
+    """DiceLoss(reduce=False): the vector of per-class terms 1 - dice_c (training/losses.py:48-50).  The mean Dice loss is linear
+    in the per-class coefficients the forward kernel leaves for the backward (coef[c] = -d dice_c / dTP_c / C, ...), so an
+    upstream gradient g_c per class is the same backward kernel with coefficients scaled by C g_c."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = logits.contiguous().float()
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        out, coef = ops.dice_ce_fwd(logits, labels, None)
+        Cc = int(logits.shape[1])
+        ctx.save_for_backward(logits, labels, coef)
+        return coef[2 * Cc + 1:3 * Cc + 1].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, coef = ctx.saved_tensors
+        Cc = int(logits.shape[1])
+        scaled = coef.clone()
+        gc = g.float() * Cc
+        scaled[:Cc] *= gc
+        scaled[Cc:2 * Cc] *= gc
+        g2 = torch.zeros(2, dtype=torch.float32, device=logits.device)
+        g2[1] = 1.0                                   # (device-side fill: capturable)
+        return ops.dice_ce_bwd(logits, labels, None, scaled, g2), None
+
+
 # ------------------------------------------------------------------------------------------------
 # MedFormer blocks (reference: /root/reference/model/dim3/medformer_utils.py, conv_layers.py:126-238)
 # ------------------------------------------------------------------------------------------------
@@ -829,55 +858,61 @@ class ActFn(torch.autograd.Function):
 
 
 class BatchNormActFn(torch.autograd.Function):
-    """ContBatchNorm3d (vnet.py:22-33: F.batch_norm with training=True ALWAYS — batch statistics over (N, D, H, W), affine,
-    running-statistics update) followed by an optional activation, on the InstanceNorm kernels: the per-(n, c) moments of
-    `k_partial_sums` are pooled over N, and gamma * xh + beta is folded into the statistics the streaming kernels take
-    (mean' = mean - beta / (gamma rstd), rstd' = gamma rstd: (x - mean') rstd' = gamma xh + beta = z), so forward is one pass
-    and backward one reduction + one pass: with dz = dy act'(z), a = mean(dz), b = mean(dz xh) over the batch,
-    dx = gamma rstd (dz - a - xh b) = rstd' (dz - (a - beta b / gamma) - z b / gamma), dgamma = sum dz xh, dbeta = sum dz."""
+    """nn.BatchNorm3d / ContBatchNorm3d followed by an optional activation on the streaming norm kernels with a per-channel
+    affine (round 5: cbim_norm_affine_*): batch statistics over (N, D, H, W) pooled from the per-(n, c) moments of
+    `k_partial_sums`, z = gamma * xh + beta, y = act(z), running-statistics update as F.batch_norm does.
+    `use_batch_stats`: True = training-mode statistics (ContBatchNorm3d ALWAYS, vnet.py:22-33: F.batch_norm(training=True);
+    nn.BatchNorm3d in train()), False = the running statistics (nn.BatchNorm3d in eval()).
+    Backward, with dz = dy act'(z): a = mean(dz), b = mean(dz xh) over the batch; d beta = sum dz, d gamma = sum dz xh,
+    dx = gamma rstd (dz - a - xh b) under batch statistics, gamma rstd dz under running statistics.  The affine is NOT folded
+    into the statistics (round 4 did: its backward divided by gamma): a zero or tiny gamma is exact."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, use_batch_stats=True):
         N, C = int(x.shape[0]), int(x.shape[-1])
         S = 1
         for d in x.shape[1:-1]:
             S *= int(d)
-        st = ops.instnorm_stats(x, eps).double()                       # [N, C, (mean, rstd)] per image
-        mean_nc, var_nc = st[..., 0], 1.0 / (st[..., 1] * st[..., 1]) - eps
-        mean_b = mean_nc.mean(0)
-        var_b = (var_nc + mean_nc * mean_nc).mean(0) - mean_b * mean_b   # biased variance of the batch
-        var_b = var_b.clamp_min(0.0)
+        if use_batch_stats:
+            st = ops.instnorm_stats(x, eps).double()                       # [N, C, (mean, rstd)] per image
+            mean_nc, var_nc = st[..., 0], 1.0 / (st[..., 1] * st[..., 1]) - eps
+            mean_b = mean_nc.mean(0)
+            var_b = (var_nc + mean_nc * mean_nc).mean(0) - mean_b * mean_b   # biased variance of the batch
+            var_b = var_b.clamp_min(0.0)
+            if running_mean is not None:
+                with torch.no_grad():
+                    n = float(N * S)
+                    running_mean.mul_(1.0 - momentum).add_(mean_b.to(running_mean.dtype), alpha=momentum)
+                    running_var.mul_(1.0 - momentum).add_((var_b * (n / max(n - 1.0, 1.0))).to(running_var.dtype), alpha=momentum)
+        else:
+            mean_b, var_b = running_mean.detach().double(), running_var.detach().double()
         rstd_b = torch.rsqrt(var_b + eps)
-        if running_mean is not None:
-            with torch.no_grad():
-                n = float(N * S)
-                running_mean.mul_(1.0 - momentum).add_(mean_b.to(running_mean.dtype), alpha=momentum)
-                running_var.mul_(1.0 - momentum).add_((var_b * (n / max(n - 1.0, 1.0))).to(running_var.dtype), alpha=momentum)
-        g64, b64 = weight.detach().double(), bias.detach().double()
-        # the affine fold divides by gamma: a weight of (numerically) zero is taken as +-1e-20 — z = beta to fp32 rounding, and
-        # no host synchronisation on the value (the step stays capturable in a hipGraph)
-        g64 = torch.where(g64.abs() < 1e-20, torch.where(g64 < 0, -1e-20, 1e-20).to(g64.dtype), g64)
-        rstd_f = g64 * rstd_b
-        mean_f = mean_b - b64 / rstd_f
-        stats_f = torch.stack([mean_f, rstd_f], -1).float().unsqueeze(0).expand(N, C, 2).contiguous()
-        ctx.save_for_backward(x, stats_f, g64, b64)
-        ctx.act, ctx.S = act, S
-        return ops.norm_act_fwd(x, stats_f, act)
+        stats = torch.stack([mean_b, rstd_b], -1).float().unsqueeze(0).expand(N, C, 2).contiguous()
+        g32 = weight.detach().float() if weight is not None else torch.ones(C, device=x.device)
+        b32 = bias.detach().float() if bias is not None else torch.zeros(C, device=x.device)
+        affine = torch.stack([g32, b32], -1).contiguous()
+        ctx.save_for_backward(x, stats, affine)
+        ctx.act, ctx.S, ctx.batch = act, S, bool(use_batch_stats)
+        ctx.has = (weight is not None, bias is not None)
+        return ops.norm_affine_act_fwd(x, stats, affine, act)
 
     @staticmethod
     def backward(ctx, dy):
-        x, stats_f, g64, b64 = ctx.saved_tensors
+        x, stats, affine = ctx.saved_tensors
         N, C = int(x.shape[0]), int(x.shape[-1])
         dy = dy.contiguous()
-        sums = ops.norm_bwd_sums(dy, x, stats_f, ctx.act, masked=True).double()   # per image: mean(dz), mean(dz z)
-        a = sums[..., 0].mean(0)
-        bz = sums[..., 1].mean(0)
-        b = (bz - b64 * a) / g64                                        # mean(dz xh)
+        sums = ops.norm_affine_bwd_sums(dy, x, stats, affine, ctx.act, masked=True).double()   # per image: mean(dz), mean(dz xh)
+        a, b = sums[..., 0].mean(0), sums[..., 1].mean(0)
         cnt = float(N * ctx.S)
         dgamma, dbeta = (b * cnt).float(), (a * cnt).float()
-        sums_f = torch.stack([a - b64 * b / g64, b / g64], -1).float().unsqueeze(0).expand(N, C, 2).contiguous()
-        dx = ops.norm_bwd_apply(dy, x, stats_f, sums_f, ctx.act, masked=True)
-        return dx, dgamma, dbeta, None, None, None, None, None
+        g64 = affine[:, 0].double()
+        if ctx.batch:
+            sums_f = torch.stack([g64 * a, g64 * b], -1)
+        else:
+            sums_f = torch.zeros((C, 2), dtype=torch.float64, device=x.device)     # fixed statistics: no mean terms
+        sums_f = sums_f.float().unsqueeze(0).expand(N, C, 2).contiguous()
+        dx = ops.norm_affine_bwd_apply(dy, x, stats, affine, sums_f, ctx.act, masked=True) if ctx.needs_input_grad[0] else None
+        return dx, (dgamma if ctx.has[0] else None), (dbeta if ctx.has[1] else None), None, None, None, None, None, None
 
 
 class ConvSlicesFn(torch.autograd.Function):

@@ -316,6 +316,26 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MLPBlock(dim, int(dim * mlp_ratio))
 
+    # checkpoint name -> attribute path here (the checkpoint's MLP is `fc1` / `fc2`, monai's MLPBlock calls them linear1 / linear2)
+    _CKPT = (("norm1.weight", "norm1.weight"), ("norm1.bias", "norm1.bias"),
+             ("attn.relative_position_bias_table", "attn.relative_position_bias_table"),
+             ("attn.relative_position_index", "attn.relative_position_index"),
+             ("attn.qkv.weight", "attn.qkv.weight"), ("attn.qkv.bias", "attn.qkv.bias"),
+             ("attn.proj.weight", "attn.proj.weight"), ("attn.proj.bias", "attn.proj.bias"),
+             ("norm2.weight", "norm2.weight"), ("norm2.bias", "norm2.bias"),
+             ("mlp.fc1.weight", "mlp.linear1.weight"), ("mlp.fc1.bias", "mlp.linear1.bias"),
+             ("mlp.fc2.weight", "mlp.linear2.weight"), ("mlp.fc2.bias", "mlp.linear2.bias"))
+
+    def load_from(self, weights, n_block, layer):
+        """swin_unetr.py:610-643: the fourteen tensors of block `n_block` of `layer` from a Swin-ViT checkpoint"""
+        root = f"module.{layer}.0.blocks.{n_block}."
+        with torch.no_grad():
+            for src, dst in self._CKPT:
+                t = self
+                for part in dst.split("."):
+                    t = getattr(t, part)
+                t.copy_(weights["state_dict"][root + src])
+
     def forward(self, x):
         dims = tuple(x.shape[1:4])
         ws = tuple(d if d <= w else w for d, w in zip(dims, self.window_size))            # get_window_size (:358-381)
@@ -447,7 +467,21 @@ class SwinUNETR(nn.Module):
         self.out = UnetOutBlock(spatial_dims=3, in_channels=f, out_channels=out_channels)
 
     def load_from(self, weights):
-        raise NotImplementedError("cbim_amd: loading the external self-supervised Swin-ViT checkpoint is not built")
+        """Copy a self-supervised Swin-ViT checkpoint (`weights["state_dict"]`, keys `module.<swinViT path>`) into the trunk —
+        /root/reference/model/dim3/swin_unetr.py:230-277: the patch embedding, every block of layers1..4 (SwinTransformerBlock
+        .load_from, :610-643) and each stage's PatchMerging reduction + norm.  Missing keys raise KeyError, mismatched shapes
+        RuntimeError, as the reference's copy_ calls do."""
+        sd = weights["state_dict"]
+        with torch.no_grad():
+            self.swinViT.patch_embed.proj.weight.copy_(sd["module.patch_embed.proj.weight"])
+            self.swinViT.patch_embed.proj.bias.copy_(sd["module.patch_embed.proj.bias"])
+            for layer in ("layers1", "layers2", "layers3", "layers4"):
+                stage = getattr(self.swinViT, layer)[0]
+                for bname, block in stage.blocks.named_children():
+                    block.load_from(weights, n_block=bname, layer=layer)
+                for name in ("reduction.weight", "norm.weight", "norm.bias"):
+                    mod, attr = name.split(".")
+                    getattr(getattr(stage.downsample, mod), attr).copy_(sd[f"module.{layer}.0.downsample.{name}"])
 
     @eager_only
     def forward(self, x_in):

@@ -37,7 +37,14 @@ def get_model(args, pretrain=False):
                          kernel_size=args.kernel_size, scale=args.down_scale, aux_loss=args.aux_loss)
     if args.model == "swin_unetr":   # model/utils.py:111-119 of the reference (window_size is passed as img_size)
         from .dim3 import SwinUNETR
-        if pretrain or getattr(args, "pretrain", False):
-            raise NotImplementedError("cbim_amd: the external Swin-ViT pretraining checkpoint (load_from) is not built")
-        return SwinUNETR(args.window_size, args.in_chan, args.classes, feature_size=args.base_chan)
+        model = SwinUNETR(args.window_size, args.in_chan, args.classes, feature_size=args.base_chan)
+        if getattr(args, "pretrain", False):   # model/utils.py:115-117: the self-supervised Swin-ViT checkpoint
+            import torch
+            # the reference hard-codes its authors' cluster path; `args.swin_pretrain_path` (or CBIM_SWIN_PRETRAIN) names the file
+            # here, a missing file is torch.load's FileNotFoundError exactly as there
+            import os
+            path = getattr(args, "swin_pretrain_path", None) or os.environ.get(
+                "CBIM_SWIN_PRETRAIN", "/research/cbim/vast/yg397/ConvFormer/ConvFormer/initmodel/model_swinvit.pt")
+            model.load_from(weights=torch.load(path, map_location="cpu"))
+        return model
     raise NotImplementedError(f"cbim_amd: 3D model '{args.model}' is not built yet")

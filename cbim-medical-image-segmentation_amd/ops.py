@@ -163,6 +163,38 @@ def norm_bwd_apply(g, x, stats, sums, act: int, masked: bool, add=None):
     return dx
 
 
+def norm_affine_act_fwd(x, stats, affine, act: int):
+    """y = act(gamma * (x - mean) * rstd + beta); affine float32 [C, 2] = (gamma, beta)."""
+    _dev_ok(x, stats, affine)
+    N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
+    y = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
+    check(_lib.lib().cbim_norm_affine_act_fwd(_dt(x), _p(x), _rs(x), _p(stats), _p(affine), _p(y), Cc, N, S, Cc, act, _stream(x)),
+          "norm_affine_act_fwd")
+    return y
+
+
+def norm_affine_bwd_sums(g, x, stats, affine, act: int, masked: bool):
+    """per (n, c): (mean(g'), mean(g' * xh)), g' = g * act'(gamma xh + beta) when masked."""
+    _dev_ok(g, x, stats, affine)
+    N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
+    L = _lib.lib()
+    P = L.cbim_stats_parts(S, Cc)
+    part = torch.empty((N, P, Cc, 3), dtype=torch.float32, device=x.device)
+    check(L.cbim_norm_affine_bwd_reduce(_dt(x), _p(g), _rs(g), _p(x), _rs(x), _p(stats), _p(affine), N, S, Cc, act, int(masked),
+                                        _p(part), P, _stream(x)), "norm_affine_bwd_reduce")
+    return stats_finalize(part, S, 0.0, 1)
+
+
+def norm_affine_bwd_apply(g, x, stats, affine, sums, act: int, masked: bool):
+    """dx = rstd * (gamma g' - m1 - xh m2), sums = (m1, m2) = gamma * (mean g', mean g' xh)."""
+    _dev_ok(g, x, stats, affine, sums)
+    N, Cc, S = int(x.shape[0]), int(x.shape[-1]), _spatial(x)
+    dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
+    check(_lib.lib().cbim_norm_affine_bwd_apply(_dt(x), _p(g), _rs(g), _p(x), _rs(x), _p(stats), _p(affine), _p(sums), _p(dx), Cc,
+                                                N, S, Cc, act, int(masked), _stream(x)), "norm_affine_bwd_apply")
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------
 # pooling / upsample+concat
 # ------------------------------------------------------------------------------------------------
@@ -749,7 +781,8 @@ def head_bwd(x, w2d, dlogits, need_dx=True, out_w=None, out_b=None):
 # ------------------------------------------------------------------------------------------------
 
 def dice_ce_fwd(logits, labels, weight=None):
-    """-> out float32[4] = (CE, Dice, CE+Dice, #labels outside [0,C)), coef float32[2C+1] (for the backward)."""
+    """-> out float32[4] = (CE, Dice, CE+Dice, #labels outside [0,C)), coef float32[3C+1] (2C+1 backward coefficients, then the
+    C per-class terms 1 - dice_c)."""
     _dev_ok(logits, labels, weight)
     N, Cc = int(logits.shape[0]), int(logits.shape[1])
     S = logits.numel() // (N * Cc)
@@ -757,7 +790,7 @@ def dice_ce_fwd(logits, labels, weight=None):
     nbytes = L.cbim_dice_ce_workspace(N, Cc, S)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=logits.device)
     out = torch.empty((4,), dtype=torch.float32, device=logits.device)
-    coef = torch.empty((2 * Cc + 1,), dtype=torch.float32, device=logits.device)
+    coef = torch.empty((3 * Cc + 1,), dtype=torch.float32, device=logits.device)    # [2C + 1] backward coefficients + [C] per-class terms
     check(L.cbim_dice_ce_fwd(_p(logits), _p(labels), _p(weight), N, Cc, S, _p(out), _p(coef), _p(ws), nbytes,
                              _stream(logits)), "dice_ce_fwd")
     return out, coef

@@ -12,12 +12,15 @@ class DiceLoss(nn.Module):
 
     def __init__(self, alpha=0.5, beta=0.5, size_average=True, reduce=True):
         super().__init__()
-        if not (size_average and reduce):
-            raise NotImplementedError("cbim_amd: DiceLoss(size_average=False / reduce=False) is not built")
+        self.size_average, self.reduce = size_average, reduce
 
     def forward(self, preds, targets):
         with torch.autocast(device_type=preds.device.type, enabled=False):
-            return Fn.DiceCEFn.apply(preds, targets, None)[1]
+            if not self.reduce:                    # losses.py:48-50: the per-class vector 1 - dice_c
+                return Fn.DicePerClassFn.apply(preds, targets)
+            loss = Fn.DiceCEFn.apply(preds, targets, None)[1]
+            # losses.py:52-56: the sum over classes, divided by C only under size_average
+            return loss if self.size_average else loss * int(preds.shape[1])
 
 
 class DiceCELoss(nn.Module):

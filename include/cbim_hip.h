@@ -95,6 +95,22 @@ int cbim_norm_bwd_apply(int dtype, const void* g, int64_t g_stride, const void* 
                         void* dx, int64_t dx_stride, int N, int64_t S, int C, int act, int masked,
                         void* stream);
 
+/* The same three streaming passes with a per-channel AFFINE between normalisation and activation (round 5):
+ *     z = gamma_c * (x - mean) * rstd + beta_c,  y = act(z)            affine float [C][2] = (gamma, beta)
+ * — nn.BatchNorm3d(affine) of the `norm: bn` constructor branch (model/dim3/utils.py:15-21) and VNet's ContBatchNorm3d
+ * (model/dim3/vnet.py:22-33); `stats` then holds the BATCH statistics, repeated per image.
+ * bwd_reduce: partial sums of g' = g * act'(z) and g' * xh per (n, c) (their batch totals are d beta, d gamma);
+ * bwd_apply:  dx = rstd * (gamma g' - m1 - xh m2) with sums = (m1, m2) = gamma * (mean g', mean g' xh) given by the
+ *             caller — nothing is divided by gamma, so a zero or tiny gamma is exact. */
+int cbim_norm_affine_act_fwd(int dtype, const void* x, int64_t x_stride, const float* stats, const float* affine,
+                             void* y, int64_t y_stride, int N, int64_t S, int C, int act, void* stream);
+int cbim_norm_affine_bwd_reduce(int dtype, const void* g, int64_t g_stride, const void* x, int64_t x_stride,
+                                const float* stats, const float* affine, int N, int64_t S, int C, int act, int masked,
+                                float* partials, int P, void* stream);
+int cbim_norm_affine_bwd_apply(int dtype, const void* g, int64_t g_stride, const void* x, int64_t x_stride,
+                               const float* stats, const float* affine, const float* sums, void* dx, int64_t dx_stride,
+                               int N, int64_t S, int C, int act, int masked, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * nn.MaxPool3d(scale) — unet_utils.py:36 (kernel = stride = scale, floor mode).
  * idx: uint8 [N][Do][Ho][Wo][C] window position of the first maximum (scan order d,h,w).
@@ -302,8 +318,9 @@ int cbim_stem_mfma_enable(int on);
  * logits float [N][C][S] (NCDHW), labels int64 [N][S].
  * fwd: out float[4]: out[0]=CE, out[1]=Dice, out[2]=CE+Dice, out[3]=number of labels outside [0,C) (the reference
  *      raises for those in scatter_/CrossEntropyLoss; here such a voxel is excluded from CE / TP / CNT, never used
- *      as an index, and counted so the host can raise); coef float [2][C] = (dL/dTP_c, dL/dSP_c) and
- *      coef[2C] = 1/sum_i w[y_i] for the backward.  workspace: cbim_dice_ce_workspace(N,C,S).
+ *      as an index, and counted so the host can raise); coef float [3C + 1]: [2][C] = (dL/dTP_c, dL/dSP_c) and
+ *      coef[2C] = 1/sum_i w[y_i] for the backward, coef[2C+1 .. 3C] = the per-class terms 1 - dice_c
+ *      (DiceLoss(reduce=False), losses.py:48-50).  workspace: cbim_dice_ce_workspace(N,C,S).
  * bwd: dlogits = grad_out[0] * d(CE+Dice)/dlogits  (grad_out is a DEVICE scalar).
  * ------------------------------------------------------------------------------------------ */
 size_t cbim_dice_ce_workspace(int N, int C, int64_t S);

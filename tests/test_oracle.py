@@ -72,6 +72,9 @@ def test_oracle_vs_live_reference():
     out = unet_ref.unet_forward(sd, x, scale=sc, kernel_size=ks, block="BasicBlock")
     assert rel_err(out, ref.detach()) < 1e-5
     assert abs(float(DiceLoss()(ref, lab)) - float(loss_ref.dice_loss(out, lab))) < 1e-6
+    # the two non-default reductions of the reference's DiceLoss (losses.py:48-56)
+    assert abs(float(DiceLoss(size_average=False)(ref, lab)) - float(loss_ref.dice_loss(out, lab, size_average=False))) < 1e-5
+    assert rel_err(loss_ref.dice_loss(out, lab, reduce=False), DiceLoss(reduce=False)(ref, lab).detach()) < 1e-5
 
 
 def test_medformer_oracle_matches_reference_golden():
