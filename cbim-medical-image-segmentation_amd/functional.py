@@ -183,7 +183,7 @@ def fused_up_block(block) -> bool:
     (UpBlockFirstFn): a ReLU BasicBlock with a shortcut conv, materialisation on."""
     from .model.dim3.conv_layers import BasicBlock, ConvNormAct
     return (_MATERIALIZE and _FUSED_UP and isinstance(block, BasicBlock) and isinstance(block.shortcut, ConvNormAct)
-            and block.conv1.act_code == ACT["relu"])
+            and block.conv1.act_code == ACT["relu"] and block.conv1.norm_kind == "in")
 
 
 _FUSED_UP = os.environ.get("CBIM_FUSED_UP", "1") not in ("", "0")

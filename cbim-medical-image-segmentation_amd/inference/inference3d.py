@@ -34,8 +34,19 @@ def _finalize(acc, counter, want_labels=False):
     return labels
 
 
+def _label_gate():
+    """The validation entry points are the engine's per-epoch hook for the deferred label check (functional.check_labels): the
+    fused loss counts out-of-range labels on the device — also inside a replayed hipGraph — and this is where the count is read
+    (one synchronisation per validated volume) and raised as the reference's CrossEntropyLoss / scatter_ would have at the
+    offending training step."""
+    from .. import functional as Fn
+    if Fn._CHECK_LABELS not in ("", "0"):
+        Fn.check_labels()
+
+
 def inference_whole_image(net, img, args=None):
     """softmax(net(img), 1) — inference3d.py:8-26."""
+    _label_gate()
     net.eval()
     with torch.no_grad():
         logits = _logits(net, img)
@@ -47,6 +58,7 @@ def inference_whole_image(net, img, args=None):
 def inference_sliding_window(net, img, args, return_labels=False):
     """Half-overlapping windows of args.window_size, probabilities averaged over the windows covering a voxel
     (inference3d.py:28-99).  With return_labels also the argmax map of validation.py:44 from the same pass."""
+    _label_gate()
     net.eval()
     B, Cc, D, H, W = img.shape
     win_d, win_h, win_w = args.window_size

@@ -31,10 +31,47 @@ class ConvNormAct(nn.Module):
         k = _k3(kernel_size)
         self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=k, stride=1, padding=[i // 2 for i in k], groups=groups,
                               bias=False)
-        self.norm = nn.Identity()   # InstanceNorm3d(eps=1e-4): no parameters, fused into the kernels
+        if norm == "bn":
+            # `norm: bn` (model/dim3/utils.py:15-21 of the reference): nn.BatchNorm3d(eps=1e-4) over in_ch (pre-activation) or
+            # out_ch (conv_layers.py:40-43) — a PARAMETER / BUFFER holder with the reference's state_dict keys; its arithmetic
+            # runs on the affine norm kernels (functional.BatchNormActFn)
+            if groups != 1:
+                raise NotImplementedError("cbim_amd: norm 'bn' is built for the dense convolutions of the UNet family")
+            self.norm = nn.BatchNorm3d(in_ch if preact else out_ch, eps=IN_EPS)
+        elif norm in ("in", None, False, True):
+            self.norm = nn.Identity()   # InstanceNorm3d(eps=1e-4): no parameters, fused into the kernels
+        else:
+            raise NotImplementedError(f"cbim_amd: norm '{norm}' is not built")
+        self.norm_kind = "bn" if norm == "bn" else "in"
         self.act = nn.Identity()
         self.act_code = ACT[act]
         self.preact = preact
+
+    def _bn_act(self, t):
+        """act(BatchNorm3d(t)) on a channels-last tensor: batch statistics + running-statistics update in train(), the running
+        statistics in eval() (or when they are not tracked: always batch statistics) — nn.BatchNorm3d.forward semantics"""
+        bn = self.norm
+        batch = bn.training or bn.running_mean is None
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        mom = bn.momentum
+        if mom is None:                                   # cumulative moving average
+            mom = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        return Fn.BatchNormActFn.apply(t, bn.weight, bn.bias, rm, rv, mom, bn.eps, self.act_code, batch)
+
+    def apply_generic(self, t, res=None):
+        """The composed (unfused) form of ConvNormAct.forward for `norm: bn`: conv(act(BN(t))) [+ res] (pre-activation) or
+        act(BN(conv(t))) — the activated tensor is materialised by one streaming pass and the convolution reads it as it is."""
+        if self.norm_kind != "bn":
+            raise RuntimeError("apply_generic is the BatchNorm path")
+        if self.preact:
+            a = self._bn_act(t)
+            y, _ = Fn.NormConvFn.apply(a, None, self.conv.weight, 0, res, False, None, IN_EPS)
+            return y
+        z, _ = Fn.NormConvFn.apply(t, None, self.conv.weight, 0, None, False, None, IN_EPS)
+        y = self._bn_act(z)
+        return y if res is None else y + res
 
 
 class SingleConv(nn.Module):
@@ -47,12 +84,16 @@ class SingleConv(nn.Module):
         self.conv = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=False)
 
     def forward(self, f: Fn.FMap, need_dx=True) -> Fn.FMap:
+        if self.conv.norm_kind == "bn":
+            return Fn.FMap(self.conv.apply_generic(f.t), None)
         y = Fn.SingleConvFn.apply(f.t, self.conv.conv.weight, self.conv.act_code, need_dx)
         return Fn.FMap(y, None)
 
     def forward_input(self, x, dtype) -> Fn.FMap:
         """First layer of a network: x is the NCDHW fp32 input (any channel count <= 16)."""
         z = Fn.StemFn.apply(x, self.conv.conv.weight, dtype)
+        if self.conv.norm_kind == "bn":
+            return Fn.FMap(self.conv._bn_act(z), None)
         zs = Fn.ensure_stats(Fn.FMap(z, None)).stats
         return Fn.FMap(Fn.NormActFn.apply(z, zs, self.conv.act_code), None)
 
@@ -80,6 +121,8 @@ class BasicBlock(nn.Module):
         act(IN(x)) of the in_ch-channel input (2 M values at 128^3) is two torch elementwise ops; conv1 and the
         shortcut conv read it through the stem kernel."""
         import torch.nn.functional as F
+        if self.conv1.norm_kind == "bn":
+            raise NotImplementedError("cbim_amd: a BatchNorm BasicBlock on the raw network input (UNet++ conv0_0) is not built")
         if not isinstance(self.shortcut, ConvNormAct):
             raise NotImplementedError("cbim_amd: identity-shortcut BasicBlock on the raw network input is not built")
         if self.conv1.act_code != ACT["relu"]:
@@ -92,6 +135,9 @@ class BasicBlock(nn.Module):
         return Fn.FMap(out, so if want_out_stats else None)
 
     def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
+        if self.conv1.norm_kind == "bn":       # composed path: conv2(conv1(x)) + shortcut(x), the add in conv2's epilogue
+            res = self.shortcut.apply_generic(f.t) if isinstance(self.shortcut, ConvNormAct) else f.t
+            return Fn.FMap(self.conv2.apply_generic(self.conv1.apply_generic(f.t), res=res), None)
         f = Fn.ensure_stats(f)
         wsc = self.shortcut.conv.weight if isinstance(self.shortcut, ConvNormAct) else None
         out, so = Fn.BasicBlockFn.apply(f.t, f.stats, self.conv1.conv.weight, self.conv2.conv.weight, wsc,
@@ -119,6 +165,10 @@ class Bottleneck(nn.Module):
             self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=True)
 
     def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
+        if self.conv1.norm_kind == "bn":
+            res = self.shortcut.apply_generic(f.t) if isinstance(self.shortcut, ConvNormAct) else f.t
+            y = self.conv2.apply_generic(self.conv1.apply_generic(f.t))
+            return Fn.FMap(self.conv3.apply_generic(y, res=res), None)
         f = Fn.ensure_stats(f)
         a = self.conv1.act_code
         y1, s1 = Fn.NormConvFn.apply(f.t, f.stats, self.conv1.conv.weight, a, None, True, None, IN_EPS)

@@ -1,7 +1,7 @@
 """Name -> class maps with the reference's keys (/root/reference/model/dim3/utils.py:7-30)."""
 from .conv_layers import BasicBlock, Bottleneck, SingleConv
 
-_NORMS = ("in",)           # every shipped 3D config uses `norm: in`
+_NORMS = ("in", "bn")      # every shipped 3D config uses `norm: in`; `bn` = nn.BatchNorm3d (round 5: UNet family)
 _ACTS = ("relu", "lrelu", "gelu", "swish")
 
 
@@ -10,12 +10,15 @@ def get_block(name):
     return blocks[name]  # KeyError for unknown names, like the reference
 
 
-def get_norm(name):
+def get_norm(name, allow=_NORMS):
+    """`allow`: the norms the calling model family is built for (UNet / ResUNet: in, bn; the others: in)"""
+    if name in _NORMS and name not in allow:
+        raise NotImplementedError(f"cbim_amd: norm '{name}' is built for the UNet / ResUNet blocks only")
     if name in _NORMS:
         return name
-    if name in ("bn", "ln"):
+    if name == "ln":
         raise NotImplementedError(
-            f"cbim_amd: norm '{name}' is not built; all shipped 3D configs use InstanceNorm ('in')")
+            "cbim_amd: norm 'ln' is not built; all shipped 3D configs use InstanceNorm ('in'), BatchNorm ('bn') is available")
     raise KeyError(name)
 
 

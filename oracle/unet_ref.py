@@ -46,39 +46,54 @@ def instance_norm(x, eps=IN_EPS_CONV):
     return F.instance_norm(x, None, None, None, None, True, 0.0, eps)
 
 
-def conv_norm_act(sd, prefix, x, k, preact, act="relu"):
+BN_MOMENTUM = 0.1   # nn.BatchNorm3d default (model/dim3/utils.py:16: norm_map['bn'] = nn.BatchNorm3d, built with eps=1e-4 only)
+
+
+def _norm(sd, prefix, x, training=True):
+    """self.norm of a ConvNormAct (conv_layers.py:40-43): InstanceNorm3d(eps=1e-4, affine=False) when the state_dict holds no
+    norm parameters (`norm: in`), else nn.BatchNorm3d(eps=1e-4) (`norm: bn`): batch statistics + in-place running-statistics
+    update in training mode, the running statistics in eval mode (F.batch_norm semantics; num_batches_tracked counted)."""
+    if prefix + "norm.weight" not in sd:
+        return instance_norm(x)
+    rm, rv = sd[prefix + "norm.running_mean"], sd[prefix + "norm.running_var"]
+    if training and prefix + "norm.num_batches_tracked" in sd:
+        sd[prefix + "norm.num_batches_tracked"] += 1
+    return F.batch_norm(x, rm, rv, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], training, BN_MOMENTUM, IN_EPS_CONV)
+
+
+def conv_norm_act(sd, prefix, x, k, preact, act="relu", training=True):
     """ConvNormAct.forward (conv_layers.py:46-53); conv has bias=False (:23)."""
     w = sd[prefix + "conv.weight"]
     b = sd.get(prefix + "conv.bias")
     if preact:  # :48-49  conv(act(norm(x)))
-        return F.conv3d(_act(instance_norm(x), act), w, b, 1, _pad(k))
-    return _act(instance_norm(F.conv3d(x, w, b, 1, _pad(k))), act)  # :51
+        return F.conv3d(_act(_norm(sd, prefix, x, training), act), w, b, 1, _pad(k))
+    return _act(_norm(sd, prefix, F.conv3d(x, w, b, 1, _pad(k)), training), act)  # :51
 
 
-def single_conv(sd, prefix, x, k):
+def single_conv(sd, prefix, x, k, training=True):
     """SingleConv.forward (conv_layers.py:56-68): one post-activation ConvNormAct."""
-    return conv_norm_act(sd, prefix + "conv.", x, k, preact=False)
+    return conv_norm_act(sd, prefix + "conv.", x, k, preact=False, training=training)
 
 
-def basic_block(sd, prefix, x, k):
+def basic_block(sd, prefix, x, k, training=True):
     """BasicBlock.forward (conv_layers.py:86-94), preact=True default (:72).
     shortcut is a full k-sized pre-act ConvNormAct when in_ch != out_ch (:83-84)."""
-    out = conv_norm_act(sd, prefix + "conv1.", x, k, preact=True)
-    out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True)
+    out = conv_norm_act(sd, prefix + "conv1.", x, k, preact=True, training=training)
+    out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True, training=training)
     if prefix + "shortcut.conv.weight" in sd:
-        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True)
+        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True, training=training)
     else:
         res = x
     return out + res  # :92
 
 
-def bottleneck(sd, prefix, x, k):
+def bottleneck(sd, prefix, x, k, training=True):
     """Bottleneck.forward (conv_layers.py:116-125): 1x1 -> kxk -> 1x1, all pre-act."""
-    out = conv_norm_act(sd, prefix + "conv1.", x, [1, 1, 1], preact=True)
-    out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True)
-    out = conv_norm_act(sd, prefix + "conv3.", out, [1, 1, 1], preact=True)
+    out = conv_norm_act(sd, prefix + "conv1.", x, [1, 1, 1], preact=True, training=training)
+    out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True, training=training)
+    out = conv_norm_act(sd, prefix + "conv3.", out, [1, 1, 1], preact=True, training=training)
     if prefix + "shortcut.conv.weight" in sd:
-        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True)
+        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True, training=training)
     else:
         res = x
     return out + res
@@ -88,7 +103,7 @@ _BLOCKS = {"SingleConv": single_conv, "BasicBlock": basic_block, "Bottleneck": b
 
 
 def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size,
-                 block: str = "BasicBlock", return_features: bool = False):
+                 block: str = "BasicBlock", return_features: bool = False, training: bool = True):
     """UNet.forward (unet.py:50-64).
 
     inconv      unet_utils.py:18-21   raw Conv3d (bias False) then one block
@@ -97,7 +112,8 @@ def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_
                                       cat([skip, up]) -> block -> block
     outc        unet.py:47            1x1x1 conv with bias
     """
-    blk = _BLOCKS[block]
+    from functools import partial
+    blk = partial(_BLOCKS[block], training=training)   # (only `norm: bn` state_dicts depend on the mode)
     ks = [_k3(k) for k in kernel_size]
     sc = [_k3(s) for s in scale]
     feats = OrderedDict()
@@ -135,6 +151,22 @@ def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_
 # reset_parameters is used (kaiming_uniform(a=sqrt(5)) + uniform bias).
 # ----------------------------------------------------------------------------------------
 
+def _bn(sd, name, ch):
+    """nn.BatchNorm3d(ch) entries in state_dict order (its reset_parameters draws no random numbers)"""
+    sd[name + "weight"] = torch.ones(ch)
+    sd[name + "bias"] = torch.zeros(ch)
+    sd[name + "running_mean"] = torch.zeros(ch)
+    sd[name + "running_var"] = torch.ones(ch)
+    sd[name + "num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+
+def _cna(sd, prefix, cin, cout, k, norm, preact):
+    """a ConvNormAct's entries (conv_layers.py:16-43): conv first, then the norm over in_ch (preact) or out_ch"""
+    _conv(sd, prefix + "conv.", cin, cout, k)
+    if norm == "bn":
+        _bn(sd, prefix + "norm.", cin if preact else cout)
+
+
 def _conv(sd, name, cin, cout, k, bias=False):
     m = torch.nn.Conv3d(cin, cout, kernel_size=k, padding=_pad(k), bias=bias)
     sd[name + "weight"] = m.weight.detach().clone()
@@ -142,40 +174,40 @@ def _conv(sd, name, cin, cout, k, bias=False):
         sd[name + "bias"] = m.bias.detach().clone()
 
 
-def _make_block(sd, prefix, block, cin, cout, k):
+def _make_block(sd, prefix, block, cin, cout, k, norm="in"):
     if block == "SingleConv":
-        _conv(sd, prefix + "conv.conv.", cin, cout, k)
+        _cna(sd, prefix + "conv.", cin, cout, k, norm, False)
     elif block == "BasicBlock":  # conv_layers.py:79-84 creation order conv1, conv2, shortcut
-        _conv(sd, prefix + "conv1.conv.", cin, cout, k)
-        _conv(sd, prefix + "conv2.conv.", cout, cout, k)
+        _cna(sd, prefix + "conv1.", cin, cout, k, norm, True)
+        _cna(sd, prefix + "conv2.", cout, cout, k, norm, True)
         if cin != cout:
-            _conv(sd, prefix + "shortcut.conv.", cin, cout, k)
+            _cna(sd, prefix + "shortcut.", cin, cout, k, norm, True)
     elif block == "Bottleneck":  # conv_layers.py:106-113
-        _conv(sd, prefix + "conv1.conv.", cin, cout // 2, [1, 1, 1])
-        _conv(sd, prefix + "conv2.conv.", cout // 2, cout // 2, k)
-        _conv(sd, prefix + "conv3.conv.", cout // 2, cout, [1, 1, 1])
+        _cna(sd, prefix + "conv1.", cin, cout // 2, [1, 1, 1], norm, True)
+        _cna(sd, prefix + "conv2.", cout // 2, cout // 2, k, norm, True)
+        _cna(sd, prefix + "conv3.", cout // 2, cout, [1, 1, 1], norm, True)
         if cin != cout:
-            _conv(sd, prefix + "shortcut.conv.", cin, cout, k)
+            _cna(sd, prefix + "shortcut.", cin, cout, k, norm, True)
     else:
         raise KeyError(block)
 
 
-def make_unet_state_dict(in_ch, base_ch, num_classes, kernel_size, block="BasicBlock", seed=None):
+def make_unet_state_dict(in_ch, base_ch, num_classes, kernel_size, block="BasicBlock", seed=None, norm="in"):
     if seed is not None:
         torch.manual_seed(seed)
     ks = [_k3(k) for k in kernel_size]
     sd = OrderedDict()
     b = base_ch
     _conv(sd, "inc.conv1.", in_ch, b, ks[0])
-    _make_block(sd, "inc.conv2.", block, b, b, ks[0])
+    _make_block(sd, "inc.conv2.", block, b, b, ks[0], norm)
     chans = [b, 2 * b, 4 * b, 8 * b, 10 * b]  # unet.py:37-40
     for lvl in range(4):
-        _make_block(sd, f"down{lvl+1}.conv.1.", block, chans[lvl], chans[lvl + 1], ks[lvl + 1])
-        _make_block(sd, f"down{lvl+1}.conv.2.", block, chans[lvl + 1], chans[lvl + 1], ks[lvl + 1])
+        _make_block(sd, f"down{lvl+1}.conv.1.", block, chans[lvl], chans[lvl + 1], ks[lvl + 1], norm)
+        _make_block(sd, f"down{lvl+1}.conv.2.", block, chans[lvl + 1], chans[lvl + 1], ks[lvl + 1], norm)
     for i in range(4):  # up1: (10b -> 8b) ... up4: (2b -> b); block in = in+out (unet_utils.py:62)
         cin, cout = chans[4 - i], chans[3 - i]
-        _make_block(sd, f"up{i+1}.conv.0.", block, cin + cout, cout, ks[3 - i])
-        _make_block(sd, f"up{i+1}.conv.1.", block, cout, cout, ks[3 - i])
+        _make_block(sd, f"up{i+1}.conv.0.", block, cin + cout, cout, ks[3 - i], norm)
+        _make_block(sd, f"up{i+1}.conv.1.", block, cout, cout, ks[3 - i], norm)
     _conv(sd, "outc.", b, num_classes, [1, 1, 1], bias=True)
     return sd
 

@@ -59,7 +59,8 @@ def test_same_seed_draws_reference_weights():
 def test_unbuilt_options_fail_loudly():
     from cbim_amd.model.utils import get_model
     with pytest.raises(NotImplementedError):
-        get_model(_args(norm="bn"))
+        get_model(_args(model="medformer", norm="bn", **{k: v for k, v in __import__("tests.medformer_checks", fromlist=["TINY"]).TINY.items()
+                                                          if k not in ("norm",)}, down_scale=[[2, 2, 2]] * 4))
     with pytest.raises(NotImplementedError):
         get_model(_args(block="Bottleneck", norm="ln"))
     with pytest.raises(NotImplementedError):
@@ -277,3 +278,11 @@ def test_label_range_is_checked_per_step_at_first_and_per_epoch_afterwards(dev):
     with pytest.raises(IndexError):
         check_labels()
     assert check_labels() == 0
+
+
+@pytest.mark.parametrize("name", ["resunet_bn_b8", "unet_single_bn_b8"])
+def test_norm_bn_branch_fp32_matches_reference_golden(dev, name):
+    """`norm: bn` (round 5): UNet with nn.BatchNorm3d in every ConvNormAct against one training step + the eval-mode forward of
+    the REAL reference (tests/golden/make_golden_bn.py): perturbed affine parameters incl. a 1e-3 and a negative gamma."""
+    from tests.bn_checks import assert_fp32
+    print(assert_fp32(name, dev))

@@ -211,3 +211,50 @@ def test_vnet_oracle_vs_live_reference():
     ref = net(x)
     sd = {k: v.detach() for k, v in net.state_dict().items()}
     assert rel_err(vnet_ref.vnet_forward(sd, x, sc), ref.detach()) < 1e-5
+
+
+BN_CASES = {
+    # name: (in_ch, base_ch, classes, scale, kernel_size, block, seed)   (tests/golden/make_golden_bn.py)
+    "resunet_bn_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", 3031),
+    "unet_single_bn_b8": (2, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", 3032),
+}
+
+
+def bn_state_dict(name):
+    """the `norm: bn` state_dict of a golden case: reference-order keys from the seed + the fixture's perturbed affine parameters"""
+    in_ch, base, classes, scale, ks, block, seed = BN_CASES[name]
+    g = load_golden(name)
+    sd = unet_ref.make_unet_state_dict(in_ch, base, classes, ks, block, seed=seed, norm="bn")
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    for k in g.files:
+        if k.startswith("p:"):
+            sd[k[2:]] = torch.from_numpy(g[k]).clone()
+    chk = unet_ref.state_dict_checksum({k: v for k, v in sd.items() if v.is_floating_point()})
+    assert abs(chk - float(g["sd_checksum"])) <= 1e-9 * max(1.0, abs(chk)), (chk, float(g["sd_checksum"]))
+    return sd, g
+
+
+@pytest.mark.parametrize("name", list(BN_CASES))
+def test_oracle_batchnorm_branch_matches_reference_golden(name):
+    """`norm: bn` (nn.BatchNorm3d in every ConvNormAct): one training step and the eval-mode forward of the REAL reference."""
+    in_ch, base, classes, scale, ks, block, seed = BN_CASES[name]
+    sd, g = bn_state_dict(name)
+    pk = [str(k) for k in g["param_keys"]]
+    sdr = {k: (v.clone().requires_grad_(True) if k in pk else v.clone()) for k, v in sd.items()}
+    x, lab, w = torch.from_numpy(g["x"]), torch.from_numpy(g["label"]), torch.from_numpy(g["weight"])
+    lo = unet_ref.unet_forward(sdr, x, scale=scale, kernel_size=ks, block=block, training=True)
+    assert rel_err(lo.detach(), g["logits"]) < 2e-5
+    ce, dl = loss_ref.cross_entropy(lo, lab.squeeze(1), w), loss_ref.dice_loss(lo, lab)
+    assert abs(float(ce) - float(g["ce"])) < 1e-5 and abs(float(dl) - float(g["dice"])) < 1e-5
+    (ce + dl).backward()
+    gn = [float(sdr[k].grad.double().norm()) for k in pk]
+    assert max(abs(a - b) / max(b, 1e-6) for a, b in zip(gn, g["grad_norms"])) < 2e-3
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel_err(sdr[k[2:]].grad, g[k]) < 5e-3, k
+        if k.startswith("r:"):
+            assert rel_err(sdr[k[2:]].double(), g[k].astype("float64")) < 1e-5, k
+    with torch.no_grad():
+        le = unet_ref.unet_forward(sdr, x, scale=scale, kernel_size=ks, block=block, training=False)
+    assert rel_err(le, g["logits_eval"]) < 2e-5
