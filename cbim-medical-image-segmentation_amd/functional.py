@@ -968,6 +968,96 @@ class ConvSlicesFn(torch.autograd.Function):
         return dx, dw, db
 
 
+# ------------------------------------------------------------------------------------------------
+# strided convolution (down_block(pool=False), /root/reference/model/dim3/unet_utils.py:36-39)
+# ------------------------------------------------------------------------------------------------
+
+_STRIDE_IDX = {}
+
+
+def _stride_plan(k, stride):
+    """Per axis: (phases, taps', pad', {(tap', phase): original tap}) of the space-to-depth form of a strided convolution.
+    y[o] = sum_t w[t] x[s o + t - p], p = k // 2.  With x index i = s q + phase: for s = 2, k = 3: t = 0 -> (q = o - 1, phase 1),
+    t = 1 -> (o, 0), t = 2 -> (o, 1): a 2-tap kernel over q in {o - 1, o} with one leading pad row; k = 1: (o, 0) only."""
+    plan = []
+    for kk, ss in zip(k, stride):
+        if ss == 1:
+            plan.append((1, kk, kk // 2, {(t, 0): t for t in range(kk)}))
+        elif ss == 2 and kk == 3:
+            plan.append((2, 2, 1, {(0, 1): 0, (1, 0): 1, (1, 1): 2}))
+        elif ss == 2 and kk == 1:
+            plan.append((2, 1, 0, {(0, 0): 0}))
+        else:
+            raise NotImplementedError(f"cbim_amd: strided convolution with kernel {kk} / stride {ss} along an axis is not built")
+    return plan
+
+
+def strided_conv(a, w, stride):
+    """Conv3d(stride, padding = k // 2, bias = False) of a channels-last tensor used AS IT IS (the caller has normalised /
+    activated it): space-to-depth turns the stride into channels — y = conv_{stride 1}(s2d(a), W') with the taps of w scattered over
+    (phase, tap') and zeros elsewhere — so the dense stride-1 kernels, their input gradient and their weight gradient do the work;
+    W' is built from the fp32 master weight by one differentiable gather.  Odd extents are zero-padded to even first (= the
+    convolution's own zero padding).  Returns the channels-last output [N, ceil(D / sD), ..., Cout]."""
+    import torch.nn.functional as F
+    k = tuple(int(i) for i in w.shape[2:])
+    stride = tuple(int(i) for i in stride)
+    plan = _stride_plan(k, stride)
+    N, D, H, W_, Cin = map(int, a.shape)
+    pads = [(-D) % stride[0], (-H) % stride[1], (-W_) % stride[2]]
+    if any(pads):
+        a = F.pad(a, (0, 0, 0, pads[2], 0, pads[1], 0, pads[0]))
+    out_dhw = tuple((e + p_) // s_ for e, p_, s_ in zip((D, H, W_), pads, stride))
+    key = (k, stride, str(w.device))
+    idx = _STRIDE_IDX.get(key)
+    if idx is None:
+        K = k[0] * k[1] * k[2]
+        ph = [p[0] for p in plan]
+        tp = [p[1] for p in plan]
+        rows = []
+        for pd in range(ph[0]):
+            for p_h in range(ph[1]):
+                for pw in range(ph[2]):                                   # phase order of k_space_to_depth: 4 pd + 2 ph + pw
+                    row = []
+                    for td in range(tp[0]):
+                        for th in range(tp[1]):
+                            for tw in range(tp[2]):
+                                ko = [plan[0][3].get((td, pd)), plan[1][3].get((th, p_h)), plan[2][3].get((tw, pw))]
+                                row.append(K if None in ko else (ko[0] * k[1] + ko[1]) * k[2] + ko[2])
+                    rows.append(row)
+        idx = _STRIDE_IDX[key] = torch.tensor(rows, dtype=torch.long, device=w.device)     # [phases, taps'], K = "no tap"
+    Cout = int(w.shape[0])
+    w_ext = torch.cat([w.reshape(Cout, Cin, -1), w.new_zeros(Cout, Cin, 1)], -1)          # [Co, Ci, K + 1]
+    tp = [p[1] for p in plan]
+    w2 = w_ext[:, :, idx].permute(0, 2, 1, 3).reshape(Cout, idx.shape[0] * Cin, tp[0], tp[1], tp[2]).contiguous()
+    x2 = SpaceToDepthFn.apply(a.contiguous(), stride) if stride != (1, 1, 1) else a
+    pad2 = tuple(p[2] for p in plan)
+    g = ConvGeom(x2.dtype, N, tuple(int(i) for i in x2.shape[1:4]), int(x2.shape[-1]), Cout, tuple(tp), pad2, 0)
+    y = RawConvFn.apply(x2, w2, g)
+    # a leading pad row with a 2-tap kernel yields one output row too many at the end of a strided axis
+    return y[:, :out_dhw[0], :out_dhw[1], :out_dhw[2]].contiguous()
+
+
+class RawConvFn(_GradAwareFunction):
+    """y = conv(x) with an explicit geometry (any padding the kernels take), no normalisation, residual or statistics — the
+    stride-1 convolution under strided_conv."""
+
+    @staticmethod
+    def forward(ctx, x, w, geom):
+        wp, wpd = ops.packed_weights((w,), geom, bool(ctx.needs_input_grad[0]) and _training(ctx))
+        y, _ = ops.conv_fwd(x, wp, geom)
+        ctx.save_for_backward(x)
+        ctx.geom, ctx.wpd = geom, wpd
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dw = ops.conv_wgrad(x, None, dy, ctx.geom) if ctx.needs_input_grad[1] else None
+        dx = ops.conv_dgrad(dy, ctx.wpd, ctx.geom)[0] if ctx.needs_input_grad[0] else None
+        return dx, dw, None
+
+
 class GateFn(torch.autograd.Function):
     """x * psi with one psi per voxel (AttentionBlock.forward, attention_unet_utils.py:35)."""
 

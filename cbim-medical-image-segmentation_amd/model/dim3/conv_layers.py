@@ -24,12 +24,15 @@ class ConvNormAct(nn.Module):
     def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, padding=1, groups=1, norm="in", act="relu",
                  preact=False):
         super().__init__()
-        if stride not in (1, [1, 1, 1], (1, 1, 1)):
-            raise NotImplementedError("cbim_amd: strided ConvNormAct (pool=False) is not built")
+        self.stride = tuple(_k3(stride))
+        if any(s not in (1, 2) for s in self.stride):
+            raise NotImplementedError("cbim_amd: ConvNormAct strides other than 1 and 2 are not built")
+        if self.stride != (1, 1, 1) and groups != 1:
+            raise NotImplementedError("cbim_amd: strided grouped convolutions are not built")
         if groups not in (1, in_ch):
             raise NotImplementedError("cbim_amd: grouped convolutions other than depthwise are not built")
         k = _k3(kernel_size)
-        self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=k, stride=1, padding=[i // 2 for i in k], groups=groups,
+        self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=k, stride=self.stride, padding=[i // 2 for i in k], groups=groups,
                               bias=False)
         if norm == "bn":
             # `norm: bn` (model/dim3/utils.py:15-21 of the reference): nn.BatchNorm3d(eps=1e-4) over in_ch (pre-activation) or
@@ -66,12 +69,22 @@ class ConvNormAct(nn.Module):
         if self.norm_kind != "bn":
             raise RuntimeError("apply_generic is the BatchNorm path")
         if self.preact:
-            a = self._bn_act(t)
-            y, _ = Fn.NormConvFn.apply(a, None, self.conv.weight, 0, res, False, None, IN_EPS)
+            y = self.raw_conv(self._bn_act(t), res)
             return y
-        z, _ = Fn.NormConvFn.apply(t, None, self.conv.weight, 0, None, False, None, IN_EPS)
-        y = self._bn_act(z)
+        y = self._bn_act(self.raw_conv(t))
         return y if res is None else y + res
+
+    def raw_conv(self, a, res=None):
+        """conv(a) [+ res] of a tensor used as it is: the stride-1 kernels directly, a stride of 2 through its space-to-depth form
+        (functional.strided_conv; down_block(pool=False), unet_utils.py:36-39 of the reference)"""
+        if self.stride == (1, 1, 1):
+            return Fn.NormConvFn.apply(a, None, self.conv.weight, 0, res, False, None, IN_EPS)[0]
+        y = Fn.strided_conv(a, self.conv.weight, self.stride)
+        return y if res is None else y + res
+
+    @property
+    def strided(self):
+        return self.stride != (1, 1, 1)
 
 
 class SingleConv(nn.Module):
@@ -86,6 +99,10 @@ class SingleConv(nn.Module):
     def forward(self, f: Fn.FMap, need_dx=True) -> Fn.FMap:
         if self.conv.norm_kind == "bn":
             return Fn.FMap(self.conv.apply_generic(f.t), None)
+        if self.conv.strided:                   # down_block(pool=False): act(IN(conv_stride(x)))
+            z = self.conv.raw_conv(f.t)
+            zs = Fn.ensure_stats(Fn.FMap(z, None)).stats
+            return Fn.FMap(Fn.NormActFn.apply(z, zs, self.conv.act_code), None)
         y = Fn.SingleConvFn.apply(f.t, self.conv.conv.weight, self.conv.act_code, need_dx)
         return Fn.FMap(y, None)
 
@@ -108,13 +125,14 @@ class BasicBlock(nn.Module):
         self.conv1 = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=True)
         self.conv2 = ConvNormAct(out_ch, out_ch, kernel_size, stride=1, norm=norm, act=act, preact=True)
         self.shortcut = nn.Sequential()
-        if in_ch != out_ch:   # a FULL k-sized pre-act ConvNormAct, not 1x1 (conv_layers.py:83-84)
+        if in_ch != out_ch or self.conv1.strided:   # a FULL k-sized pre-act ConvNormAct, not 1x1 (conv_layers.py:83-84)
             self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=True)
 
     def cbim_grad_pairs(self):
         """(conv1, shortcut) weights: BasicBlockFn computes their gradients as ONE Cout-concatenated weight gradient —
         parallel.GradAllReduce lays their bucket slots out back to back so that the kernel writes both in place"""
-        return [(self.conv1.conv.weight, self.shortcut.conv.weight)] if isinstance(self.shortcut, ConvNormAct) else []
+        fused = isinstance(self.shortcut, ConvNormAct) and self.conv1.norm_kind == "in" and not self.conv1.strided
+        return [(self.conv1.conv.weight, self.shortcut.conv.weight)] if fused else []
 
     def forward_input(self, x, dtype, want_out_stats=True) -> Fn.FMap:
         """First layer of a network (UNet++ conv0_0): x is the NCDHW fp32 input.  The pre-activation
@@ -139,6 +157,15 @@ class BasicBlock(nn.Module):
             res = self.shortcut.apply_generic(f.t) if isinstance(self.shortcut, ConvNormAct) else f.t
             return Fn.FMap(self.conv2.apply_generic(self.conv1.apply_generic(f.t), res=res), None)
         f = Fn.ensure_stats(f)
+        if self.conv1.strided:
+            # down_block(pool=False): conv1 and the shortcut are strided and read the same act(IN(x)), written once
+            act = self.conv1.act_code
+            a = Fn.NormActFn.apply(f.t, f.stats, act)
+            y1 = self.conv1.raw_conv(a)
+            sc = self.shortcut.raw_conv(a)
+            s1 = Fn.ensure_stats(Fn.FMap(y1, None)).stats
+            out, so = Fn.NormConvFn.apply(y1, s1, self.conv2.conv.weight, act, sc, want_out_stats, None, IN_EPS)
+            return Fn.FMap(out, so if want_out_stats else None)
         wsc = self.shortcut.conv.weight if isinstance(self.shortcut, ConvNormAct) else None
         out, so = Fn.BasicBlockFn.apply(f.t, f.stats, self.conv1.conv.weight, self.conv2.conv.weight, wsc,
                                         self.conv1.act_code, want_out_stats)
@@ -161,10 +188,19 @@ class Bottleneck(nn.Module):
         self.conv2 = ConvNormAct(mid, mid, kernel_size, stride=stride, norm=norm, act=act, preact=True)
         self.conv3 = ConvNormAct(mid, out_ch, 1, stride=1, padding=0, norm=norm, act=act, preact=True)
         self.shortcut = nn.Sequential()
-        if in_ch != out_ch:
+        if in_ch != out_ch or self.conv2.strided:
             self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=True)
 
     def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
+        if self.conv1.norm_kind == "in" and self.conv2.strided:
+            f = Fn.ensure_stats(f)
+            a = self.conv1.act_code
+            y1, s1 = Fn.NormConvFn.apply(f.t, f.stats, self.conv1.conv.weight, a, None, True, None, IN_EPS)
+            y2 = self.conv2.raw_conv(Fn.NormActFn.apply(y1, s1, a))
+            s2 = Fn.ensure_stats(Fn.FMap(y2, None)).stats
+            sc = self.shortcut.raw_conv(Fn.NormActFn.apply(f.t, f.stats, a))
+            out, so = Fn.NormConvFn.apply(y2, s2, self.conv3.conv.weight, a, sc, want_out_stats, None, IN_EPS)
+            return Fn.FMap(out, so if want_out_stats else None)
         if self.conv1.norm_kind == "bn":
             res = self.shortcut.apply_generic(f.t) if isinstance(self.shortcut, ConvNormAct) else f.t
             y = self.conv2.apply_generic(self.conv1.apply_generic(f.t))

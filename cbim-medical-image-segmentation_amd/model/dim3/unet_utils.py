@@ -41,10 +41,11 @@ class down_block(nn.Module):
     def __init__(self, in_ch, out_ch, num_block, block=BasicBlock, kernel_size=(3, 3, 3), down_scale=(2, 2, 2),
                  pool=True, norm="in"):
         super().__init__()
-        if not pool:
-            raise NotImplementedError("cbim_amd: down_block(pool=False) (strided conv) is not built")
         k = _k3(kernel_size)
-        mods = [_PoolSlot(down_scale), block(in_ch, out_ch, kernel_size=k, norm=norm)]
+        if pool:
+            mods = [_PoolSlot(down_scale), block(in_ch, out_ch, kernel_size=k, norm=norm)]
+        else:   # unet_utils.py:38-39 of the reference: the first block strides instead of a MaxPool3d in front of it
+            mods = [block(in_ch, out_ch, stride=_k3(down_scale), kernel_size=k, norm=norm)]
         for _ in range(num_block - 1):
             mods.append(block(out_ch, out_ch, kernel_size=k, norm=norm))
         self.conv = nn.Sequential(*mods)

@@ -61,39 +61,39 @@ def _norm(sd, prefix, x, training=True):
     return F.batch_norm(x, rm, rv, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], training, BN_MOMENTUM, IN_EPS_CONV)
 
 
-def conv_norm_act(sd, prefix, x, k, preact, act="relu", training=True):
-    """ConvNormAct.forward (conv_layers.py:46-53); conv has bias=False (:23)."""
+def conv_norm_act(sd, prefix, x, k, preact, act="relu", training=True, stride=1):
+    """ConvNormAct.forward (conv_layers.py:46-53); conv has bias=False (:23); `stride` as given to nn.Conv3d (:29-38)."""
     w = sd[prefix + "conv.weight"]
     b = sd.get(prefix + "conv.bias")
     if preact:  # :48-49  conv(act(norm(x)))
-        return F.conv3d(_act(_norm(sd, prefix, x, training), act), w, b, 1, _pad(k))
-    return _act(_norm(sd, prefix, F.conv3d(x, w, b, 1, _pad(k)), training), act)  # :51
+        return F.conv3d(_act(_norm(sd, prefix, x, training), act), w, b, stride, _pad(k))
+    return _act(_norm(sd, prefix, F.conv3d(x, w, b, stride, _pad(k)), training), act)  # :51
 
 
-def single_conv(sd, prefix, x, k, training=True):
+def single_conv(sd, prefix, x, k, training=True, stride=1):
     """SingleConv.forward (conv_layers.py:56-68): one post-activation ConvNormAct."""
-    return conv_norm_act(sd, prefix + "conv.", x, k, preact=False, training=training)
+    return conv_norm_act(sd, prefix + "conv.", x, k, preact=False, training=training, stride=stride)
 
 
-def basic_block(sd, prefix, x, k, training=True):
+def basic_block(sd, prefix, x, k, training=True, stride=1):
     """BasicBlock.forward (conv_layers.py:86-94), preact=True default (:72).
     shortcut is a full k-sized pre-act ConvNormAct when in_ch != out_ch (:83-84)."""
-    out = conv_norm_act(sd, prefix + "conv1.", x, k, preact=True, training=training)
+    out = conv_norm_act(sd, prefix + "conv1.", x, k, preact=True, training=training, stride=stride)   # :79 stride on conv1 ...
     out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True, training=training)
     if prefix + "shortcut.conv.weight" in sd:
-        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True, training=training)
+        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True, training=training, stride=stride)   # ... and the shortcut (:83-84)
     else:
         res = x
     return out + res  # :92
 
 
-def bottleneck(sd, prefix, x, k, training=True):
+def bottleneck(sd, prefix, x, k, training=True, stride=1):
     """Bottleneck.forward (conv_layers.py:116-125): 1x1 -> kxk -> 1x1, all pre-act."""
     out = conv_norm_act(sd, prefix + "conv1.", x, [1, 1, 1], preact=True, training=training)
-    out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True, training=training)
+    out = conv_norm_act(sd, prefix + "conv2.", out, k, preact=True, training=training, stride=stride)   # :108 stride on the k^3 conv
     out = conv_norm_act(sd, prefix + "conv3.", out, [1, 1, 1], preact=True, training=training)
     if prefix + "shortcut.conv.weight" in sd:
-        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True, training=training)
+        res = conv_norm_act(sd, prefix + "shortcut.", x, k, preact=True, training=training, stride=stride)
     else:
         res = x
     return out + res
@@ -103,7 +103,7 @@ _BLOCKS = {"SingleConv": single_conv, "BasicBlock": basic_block, "Bottleneck": b
 
 
 def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size,
-                 block: str = "BasicBlock", return_features: bool = False, training: bool = True):
+                 block: str = "BasicBlock", return_features: bool = False, training: bool = True, pool: bool = True):
     """UNet.forward (unet.py:50-64).
 
     inconv      unet_utils.py:18-21   raw Conv3d (bias False) then one block
@@ -124,9 +124,13 @@ def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_
     skips = [x1]
     cur = x1
     for lvl in range(4):  # down1..down4 use kernel_size[lvl+1], scale[lvl]  (unet.py:37-40)
-        cur = F.max_pool3d(cur, sc[lvl])
-        cur = blk(sd, f"down{lvl+1}.conv.1.", cur, ks[lvl + 1])
-        cur = blk(sd, f"down{lvl+1}.conv.2.", cur, ks[lvl + 1])
+        if pool:   # unet_utils.py:35-37  MaxPool3d -> block -> block  (Sequential indices 1, 2)
+            cur = F.max_pool3d(cur, sc[lvl])
+            cur = blk(sd, f"down{lvl+1}.conv.1.", cur, ks[lvl + 1])
+            cur = blk(sd, f"down{lvl+1}.conv.2.", cur, ks[lvl + 1])
+        else:      # unet_utils.py:38-39  block(stride=down_scale) -> block  (Sequential indices 0, 1)
+            cur = blk(sd, f"down{lvl+1}.conv.0.", cur, ks[lvl + 1], stride=tuple(sc[lvl]))
+            cur = blk(sd, f"down{lvl+1}.conv.1.", cur, ks[lvl + 1])
         feats[f"x{lvl+2}"] = cur
         skips.append(cur)
     out = skips[4]
@@ -174,25 +178,25 @@ def _conv(sd, name, cin, cout, k, bias=False):
         sd[name + "bias"] = m.bias.detach().clone()
 
 
-def _make_block(sd, prefix, block, cin, cout, k, norm="in"):
+def _make_block(sd, prefix, block, cin, cout, k, norm="in", strided=False):
     if block == "SingleConv":
         _cna(sd, prefix + "conv.", cin, cout, k, norm, False)
     elif block == "BasicBlock":  # conv_layers.py:79-84 creation order conv1, conv2, shortcut
         _cna(sd, prefix + "conv1.", cin, cout, k, norm, True)
         _cna(sd, prefix + "conv2.", cout, cout, k, norm, True)
-        if cin != cout:
+        if cin != cout or strided:   # conv_layers.py:83  `if stride != 1 or in_ch != out_ch`
             _cna(sd, prefix + "shortcut.", cin, cout, k, norm, True)
     elif block == "Bottleneck":  # conv_layers.py:106-113
         _cna(sd, prefix + "conv1.", cin, cout // 2, [1, 1, 1], norm, True)
         _cna(sd, prefix + "conv2.", cout // 2, cout // 2, k, norm, True)
         _cna(sd, prefix + "conv3.", cout // 2, cout, [1, 1, 1], norm, True)
-        if cin != cout:
+        if cin != cout or strided:
             _cna(sd, prefix + "shortcut.", cin, cout, k, norm, True)
     else:
         raise KeyError(block)
 
 
-def make_unet_state_dict(in_ch, base_ch, num_classes, kernel_size, block="BasicBlock", seed=None, norm="in"):
+def make_unet_state_dict(in_ch, base_ch, num_classes, kernel_size, block="BasicBlock", seed=None, norm="in", pool=True):
     if seed is not None:
         torch.manual_seed(seed)
     ks = [_k3(k) for k in kernel_size]
@@ -202,8 +206,9 @@ def make_unet_state_dict(in_ch, base_ch, num_classes, kernel_size, block="BasicB
     _make_block(sd, "inc.conv2.", block, b, b, ks[0], norm)
     chans = [b, 2 * b, 4 * b, 8 * b, 10 * b]  # unet.py:37-40
     for lvl in range(4):
-        _make_block(sd, f"down{lvl+1}.conv.1.", block, chans[lvl], chans[lvl + 1], ks[lvl + 1], norm)
-        _make_block(sd, f"down{lvl+1}.conv.2.", block, chans[lvl + 1], chans[lvl + 1], ks[lvl + 1], norm)
+        i0 = 1 if pool else 0      # nn.Sequential index of the level's first block (a MaxPool3d occupies 0 when pooling)
+        _make_block(sd, f"down{lvl+1}.conv.{i0}.", block, chans[lvl], chans[lvl + 1], ks[lvl + 1], norm, strided=not pool)
+        _make_block(sd, f"down{lvl+1}.conv.{i0 + 1}.", block, chans[lvl + 1], chans[lvl + 1], ks[lvl + 1], norm)
     for i in range(4):  # up1: (10b -> 8b) ... up4: (2b -> b); block in = in+out (unet_utils.py:62)
         cin, cout = chans[4 - i], chans[3 - i]
         _make_block(sd, f"up{i+1}.conv.0.", block, cin + cout, cout, ks[3 - i], norm)

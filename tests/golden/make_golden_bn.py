@@ -1,4 +1,4 @@
-"""Golden fixtures for the `norm: bn` constructor branch (nn.BatchNorm3d in every ConvNormAct, /root/reference/model/dim3/
+"""Golden fixtures for the non-default constructor branches `norm: bn` and `pool=False` — the `norm: bn` constructor branch (nn.BatchNorm3d in every ConvNormAct, /root/reference/model/dim3/
 utils.py:15-21, conv_layers.py:40-43), produced by EXECUTING THE REAL REFERENCE on CPU (build container only):
 
     python tests/golden/make_golden_bn.py
@@ -18,9 +18,14 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from tests.golden.make_golden import import_reference, make_labels  # noqa: E402
 
 CASES = {
-    # name: (in_ch, base_ch, classes, scale, kernel_size, block, spatial, batch, seed)
-    "resunet_bn_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", (32, 32, 32), 2, 3031),
-    "unet_single_bn_b8": (2, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", (8, 32, 32), 2, 3032),
+    # name: (in_ch, base_ch, classes, scale, kernel_size, block, spatial, batch, seed, norm, pool)
+    "resunet_bn_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", (32, 32, 32), 2, 3031, "bn", True),
+    "unet_single_bn_b8": (2, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", (8, 32, 32), 2, 3032, "bn", True),
+    # down_block(pool=False): the first block of every level strides (unet_utils.py:36-39) — InstanceNorm ResUNet, an odd extent
+    # along W at the second level (36 -> 18 -> 9 -> 5 -> 3), and a BatchNorm SingleConv UNet with an anisotropic first stride
+    "resunet_nopool_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", (32, 32, 36), 1, 3033, "in", False),
+    "unet_single_nopool_bn": (1, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", (8, 32, 32), 2, 3034, "bn", False),
+    "resunet_bottleneck_nopool_b16": (1, 16, 3, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "Bottleneck", (32, 32, 32), 1, 3035, "in", False),
 }
 
 
@@ -28,9 +33,12 @@ def main():
     UNet, DiceLoss = import_reference()
     from oracle.unet_ref import state_dict_checksum
     torch.set_num_threads(8)
-    for name, (in_ch, base, classes, scale, ks, block, shape, batch, seed) in CASES.items():
+    only = sys.argv[1:]
+    for name, (in_ch, base, classes, scale, ks, block, shape, batch, seed, norm, pool) in CASES.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(seed)
-        net = UNet(in_ch, base, scale=scale, kernel_size=ks, num_classes=classes, block=block, norm="bn")
+        net = UNet(in_ch, base, scale=scale, kernel_size=ks, num_classes=classes, block=block, norm=norm, pool=pool)
         gen = torch.Generator().manual_seed(seed + 1)
         affine = {}
         with torch.no_grad():
@@ -70,7 +78,7 @@ def main():
         for k, v in affine.items():
             out["p:" + k] = v.numpy()
         for k, g in grads.items():                        # full gradients of every BatchNorm parameter, the stem and the head
-            if "norm." in k or k in ("inc.conv1.weight", "outc.weight", "outc.bias"):
+            if "norm." in k or k in ("inc.conv1.weight", "outc.weight", "outc.bias") or ".conv.1." in k and k.startswith("down1"):
                 out["g:" + k] = g.numpy()
         for k, v in sd1.items():                          # running statistics after the training step
             if "running_" in k or "num_batches" in k:

@@ -214,17 +214,20 @@ def test_vnet_oracle_vs_live_reference():
 
 
 BN_CASES = {
-    # name: (in_ch, base_ch, classes, scale, kernel_size, block, seed)   (tests/golden/make_golden_bn.py)
-    "resunet_bn_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", 3031),
-    "unet_single_bn_b8": (2, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", 3032),
+    # name: (in_ch, base_ch, classes, scale, kernel_size, block, seed, norm, pool)   (tests/golden/make_golden_bn.py)
+    "resunet_bn_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", 3031, "bn", True),
+    "unet_single_bn_b8": (2, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", 3032, "bn", True),
+    "resunet_nopool_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", 3033, "in", False),
+    "unet_single_nopool_bn": (1, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", 3034, "bn", False),
+    "resunet_bottleneck_nopool_b16": (1, 16, 3, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "Bottleneck", 3035, "in", False),
 }
 
 
 def bn_state_dict(name):
     """the `norm: bn` state_dict of a golden case: reference-order keys from the seed + the fixture's perturbed affine parameters"""
-    in_ch, base, classes, scale, ks, block, seed = BN_CASES[name]
+    in_ch, base, classes, scale, ks, block, seed, norm, pool = BN_CASES[name]
     g = load_golden(name)
-    sd = unet_ref.make_unet_state_dict(in_ch, base, classes, ks, block, seed=seed, norm="bn")
+    sd = unet_ref.make_unet_state_dict(in_ch, base, classes, ks, block, seed=seed, norm=norm, pool=pool)
     assert list(sd.keys()) == [str(k) for k in g["keys"]]
     assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
     for k in g.files:
@@ -237,13 +240,14 @@ def bn_state_dict(name):
 
 @pytest.mark.parametrize("name", list(BN_CASES))
 def test_oracle_batchnorm_branch_matches_reference_golden(name):
-    """`norm: bn` (nn.BatchNorm3d in every ConvNormAct): one training step and the eval-mode forward of the REAL reference."""
-    in_ch, base, classes, scale, ks, block, seed = BN_CASES[name]
+    """`norm: bn` (nn.BatchNorm3d in every ConvNormAct) and `pool=False` (strided first block per level): one training step and the
+    eval-mode forward of the REAL reference."""
+    in_ch, base, classes, scale, ks, block, seed, norm, pool = BN_CASES[name]
     sd, g = bn_state_dict(name)
     pk = [str(k) for k in g["param_keys"]]
     sdr = {k: (v.clone().requires_grad_(True) if k in pk else v.clone()) for k, v in sd.items()}
     x, lab, w = torch.from_numpy(g["x"]), torch.from_numpy(g["label"]), torch.from_numpy(g["weight"])
-    lo = unet_ref.unet_forward(sdr, x, scale=scale, kernel_size=ks, block=block, training=True)
+    lo = unet_ref.unet_forward(sdr, x, scale=scale, kernel_size=ks, block=block, training=True, pool=pool)
     assert rel_err(lo.detach(), g["logits"]) < 2e-5
     ce, dl = loss_ref.cross_entropy(lo, lab.squeeze(1), w), loss_ref.dice_loss(lo, lab)
     assert abs(float(ce) - float(g["ce"])) < 1e-5 and abs(float(dl) - float(g["dice"])) < 1e-5
@@ -256,5 +260,5 @@ def test_oracle_batchnorm_branch_matches_reference_golden(name):
         if k.startswith("r:"):
             assert rel_err(sdr[k[2:]].double(), g[k].astype("float64")) < 1e-5, k
     with torch.no_grad():
-        le = unet_ref.unet_forward(sdr, x, scale=scale, kernel_size=ks, block=block, training=False)
+        le = unet_ref.unet_forward(sdr, x, scale=scale, kernel_size=ks, block=block, training=False, pool=pool)
     assert rel_err(le, g["logits_eval"]) < 2e-5
