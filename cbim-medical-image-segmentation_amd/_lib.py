@@ -137,7 +137,7 @@ _SIGS = {
     "cbim_gate_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, vp]),
     "cbim_layernorm_fwd": (i32, [vp, vp, vp, f32, i32, vp, vp, i64, i32, vp]),
     "cbim_layernorm_bwd_workspace": (sz, [i64, i32]),
-    "cbim_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, vp]),
+    "cbim_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, vp]),
     "cbim_token_linear": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, vp, i32, i64, i64, i32, i32, vp]),
     "cbim_token_linear_wgrad_workspace": (sz, [i64, i32, i32]),
     "cbim_token_linear_wgrad": (i32, [vp, i32, i64, i32, vp, i32, i64, vp, vp, sz, i64, i32, i32, vp]),

@@ -627,7 +627,8 @@ static void pwg_cfg(const cbim_conv_desc* d, int* strips, int* rps, int* co_bloc
   *co_blocks = (d->Cout + 63) / 64; *ci_blocks = (d->Cin + 63) / 64;
   const int64_t pairs = (int64_t)*co_blocks * *ci_blocks * d->N;
   const int64_t stages = (S + PWG_VT - 1) / PWG_VT;
-  int64_t want = (768 + pairs - 1) / pairs;                 // ~3 workgroups per CU
+  static const int64_t wgs = getenv("CBIM_PWG_WGS") ? atoi(getenv("CBIM_PWG_WGS")) : 768;   // (tools: A/B of the strip count)
+  int64_t want = (wgs + pairs - 1) / pairs;                 // ~3 workgroups per CU
   if (want > stages) want = stages;
   const size_t slab = (size_t)*co_blocks * 64 * *ci_blocks * 64 * sizeof(float);
   int64_t cap = (int64_t)((64ull << 20) / (slab * d->N));   // slab workspace <= 64 MiB

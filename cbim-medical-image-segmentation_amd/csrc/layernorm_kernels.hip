@@ -83,7 +83,7 @@ template <int K, bool BF16_IN>
 __global__ void __launch_bounds__(LN_T) k_layernorm_bwd(const void* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ rowstats,
                                                         float* __restrict__ dx, float* __restrict__ partials, int64_t rows,
-                                                        int C, int lpr) {
+                                                        int C, int lpr, const float* __restrict__ add) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rpw = 64 / lpr, sub = lane / lpr, l = lane % lpr;
   const int chunks = C / 4;
@@ -132,8 +132,13 @@ __global__ void __launch_bounds__(LN_T) k_layernorm_bwd(const void* __restrict__
     for (int k = 0; k < K; ++k) {
       const int c = l + k * lpr;
       if (c >= chunks) continue;
-      *(f32x4*)(dx + r0 * C + 4 * c) = f32x4{rstd * (g[k].x - ma - xh[k].x * mb), rstd * (g[k].y - ma - xh[k].y * mb),
-                                             rstd * (g[k].z - ma - xh[k].z * mb), rstd * (g[k].w - ma - xh[k].w * mb)};
+      f32x4 o = f32x4{rstd * (g[k].x - ma - xh[k].x * mb), rstd * (g[k].y - ma - xh[k].y * mb),
+                      rstd * (g[k].z - ma - xh[k].z * mb), rstd * (g[k].w - ma - xh[k].w * mb)};
+      if (add) {      // + the gradient that reached the same rows past the norm (the residual stream: x + f(LN(x)))
+        const f32x4 a4 = *(const f32x4*)(add + r0 * C + 4 * c);
+        o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+      }
+      *(f32x4*)(dx + r0 * C + 4 * c) = o;
     }
   }
   if (!partials) return;
@@ -271,8 +276,8 @@ extern "C" int cbim_layernorm_fwd(const float* x, const float* gamma, const floa
 }
 
 extern "C" int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, const float* gamma, const float* rowstats,
-                                  float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int64_t rows, int C,
-                                  void* stream) {
+                                  const float* add, float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
+                                  int64_t rows, int C, void* stream) {
   CBIM_CHECK(dy && x && rowstats && dx && rows > 0, CBIM_EINVAL, "null argument");
   CBIM_CHECK(dy_dtype == CBIM_F32 || dy_dtype == CBIM_BF16, CBIM_EINVAL, "bad dtype %d", dy_dtype);
   CBIM_CHECK(C >= 4 && C % 4 == 0 && C <= 3072, CBIM_EUNSUPPORTED, "layernorm: %d channels (a multiple of 4 up to 3072)", C);
@@ -284,8 +289,8 @@ extern "C" int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, 
   dim3 grid((unsigned)P);
   hipStream_t st = (hipStream_t)stream;
   float* part = want_p ? (float*)workspace : nullptr;
-  if (dy_dtype == CBIM_BF16) LN_DISPATCH_K(k_layernorm_bwd, true, dy, x, gamma, rowstats, dx, part, rows, C, lpr);
-  else LN_DISPATCH_K(k_layernorm_bwd, false, dy, x, gamma, rowstats, dx, part, rows, C, lpr);
+  if (dy_dtype == CBIM_BF16) LN_DISPATCH_K(k_layernorm_bwd, true, dy, x, gamma, rowstats, dx, part, rows, C, lpr, add);
+  else LN_DISPATCH_K(k_layernorm_bwd, false, dy, x, gamma, rowstats, dx, part, rows, C, lpr, add);
   if (CBIM_LAST_LAUNCH() != hipSuccess) return CBIM_ELAUNCH;
   if (want_p) {
     CBIM_LAUNCH(k_layernorm_bwd_finish, dim3((unsigned)((2 * C + 63) / 64)), dim3(LNF_T), 0, st, (const float*)part, P, C, dgamma, dbeta);

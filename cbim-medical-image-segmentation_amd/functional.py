@@ -521,7 +521,7 @@ class NormConvFn(_GradAwareFunction):
         x, st, se = ctx.saved_tensors
         has_stats, has_res, has_se = ctx.has
         g, act = ctx.geom, ctx.act
-        dy = dy.contiguous()
+        dy = ops.as_rows(dy)                # (a channel-slice view from torch.cat's backward is read in place)
         dw = ops.conv_wgrad(x, st if has_stats else None, dy, g, out=ops.grad_slot(ctx.w_param)) if ctx.needs_input_grad[2] else None
         dx = ds = None
         if ctx.needs_input_grad[0]:
@@ -702,6 +702,39 @@ def layer_norm(x, weight, bias, eps, out_dtype=torch.float32):
     return LayerNormFn.apply(x, weight, bias, eps, out_dtype)
 
 
+class LayerNormResFn(torch.autograd.Function):
+    """(LN(x), x): the pre-norm residual pattern x + f(LN(x)) of a transformer block (swin_unetr.py:539-552) as ONE autograd node
+    with two outputs — the second is x itself, handed on to the branch's last Linear as its residual operand.  Backward then
+    receives the gradient of both paths at once and the LayerNorm backward kernel adds the residual one to its dx
+    (cbim_layernorm_bwd's `add`): the separate fp32 add pass autograd would run over the stream is gone."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        x = x.contiguous()
+        w = weight.detach().float().contiguous() if weight is not None else None
+        b = bias.detach().float().contiguous() if bias is not None else None
+        y, rs = ops.layernorm_fwd(x, w, b, eps, out_dtype)
+        ctx.save_for_backward(x, w if w is not None else torch.empty(0), rs)
+        ctx.has_w, ctx.has_b = w is not None, b is not None
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, gx):
+        x, w, rs = ctx.saved_tensors
+        if dy is None:                      # only the pass-through was used
+            return gx, None, None, None, None
+        dy = dy.contiguous()
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        add = None
+        if gx is not None:
+            add = gx.contiguous()
+            add = add if add.dtype == torch.float32 else add.float()
+        dx, dg, db = ops.layernorm_bwd(dy, x, w if ctx.has_w else None, rs, ctx.has_w or ctx.has_b, add=add)
+        return dx, (dg if ctx.has_w else None), (db if ctx.has_b else None), None, None
+
+
 class TokenLinearFn(_GradAwareFunction):
     """nn.Linear over channels-last token rows on the engine's row-GEMM kernel (ops.token_linear, bf16 operands, fp32
     accumulation) with the neighbouring element-wise work fused — the SwinUNETR trunk's qkv / proj / MLP / patch-merging /
@@ -786,7 +819,7 @@ class ResNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         a, sa, b, sb = ctx.saved_tensors
-        da, db = ops.resnorm_bwd(dy.contiguous(), a, sa, b, sb if ctx.has_b else None, ctx.act,
+        da, db = ops.resnorm_bwd(ops.as_rows(dy), a, sa, b, sb if ctx.has_b else None, ctx.act,
                                  need_db=ctx.needs_input_grad[2])
         return da, None, db, None, None
 

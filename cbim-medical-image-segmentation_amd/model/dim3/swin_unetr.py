@@ -242,6 +242,7 @@ def _token_linear(lin, x):
 
 _FUSED_LN = os.environ.get("CBIM_SWIN_FUSED_LN", "1") != "0"
 _FUSED_MERGE = os.environ.get("CBIM_SWIN_FUSED_MERGE", "1") != "0"
+_FUSED_RES = os.environ.get("CBIM_SWIN_FUSED_RES", "1") != "0"     # round 5: residual-stream gradient added inside k_layernorm_bwd
 
 
 def _layer_norm(ln, x, out_dtype):
@@ -345,6 +346,12 @@ class SwinTransformerBlock(nn.Module):
         amp = _trunk_bf16(x)
         nd = torch.bfloat16 if amp else torch.float32       # the LayerNorm kernel stores what the Linears consume
         with torch.autocast(x.device.type, dtype=torch.bfloat16, enabled=amp):      # (the Linears that stay on torch: odd widths)
+            if _FUSED_LN and _FUSED_RES and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 3072:
+                # (LN(x), x) as one autograd node: its backward adds the residual-stream gradient inside the LayerNorm kernel
+                y, xr = Fn.LayerNormResFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, nd)
+                x = self.attn(y, ws, ss, res=xr)
+                y, xr = Fn.LayerNormResFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, nd)
+                return self.mlp(y, res=xr)
             x = self.attn(_layer_norm(self.norm1, x, nd), ws, ss, res=x)
             return self.mlp(_layer_norm(self.norm2, x, nd), res=x)
 

@@ -1048,9 +1048,11 @@ def layernorm_fwd(x, gamma, beta, eps: float, out_dtype: torch.dtype):
     return y, rs
 
 
-def layernorm_bwd(dy, x, gamma, rowstats, want_affine: bool):
-    """-> (dx float32, dgamma | None, dbeta | None)."""
-    _dev_ok(dy, x, gamma, rowstats)
+def layernorm_bwd(dy, x, gamma, rowstats, want_affine: bool, add=None):
+    """-> (dx float32 [+ add], dgamma | None, dbeta | None)."""
+    _dev_ok(dy, x, gamma, rowstats, add)
+    if add is not None and (add.dtype != torch.float32 or add.numel() != x.numel()):
+        raise TypeError("cbim_amd: layernorm_bwd `add` is the float32 gradient of the same rows")
     Cc = int(x.shape[-1])
     rows = x.numel() // Cc
     L = _lib.lib()
@@ -1062,7 +1064,7 @@ def layernorm_bwd(dy, x, gamma, rowstats, want_affine: bool):
         db = torch.empty((Cc,), dtype=torch.float32, device=x.device)
         nbytes = L.cbim_layernorm_bwd_workspace(rows, Cc)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-    check(L.cbim_layernorm_bwd(_dt(dy), _p(dy), _p(x), _p(gamma), _p(rowstats), _p(dx), _p(dg), _p(db), _p(ws), nbytes, rows, Cc,
+    check(L.cbim_layernorm_bwd(_dt(dy), _p(dy), _p(x), _p(gamma), _p(rowstats), _p(add), _p(dx), _p(dg), _p(db), _p(ws), nbytes, rows, Cc,
                                _stream(x)), "layernorm_bwd")
     return dx, dg, db
 
@@ -1136,6 +1138,12 @@ def token_linear_wgrad(x2d, dy2d, act_in: int = 0, out=None):
     check(L.cbim_token_linear_wgrad(_p(x2d), _dt(x2d), int(x2d.stride(0)), act_in, _p(dy2d), _dt(dy2d), int(dy2d.stride(0)),
                                     _p(dw), _p(ws), nbytes, rows, Cin, Cout, _stream(x2d)), "token_linear_wgrad")
     return dw
+
+
+def as_rows(t):
+    """a gradient as the kernels can read it: the tensor itself when it is contiguous or a channel-slice view of a wider
+    channels-last tensor (row stride > channel count: what torch.cat's backward hands out — no copy), else a contiguous copy"""
+    return t if (t.is_contiguous() or _is_row_view(t)) else t.contiguous()
 
 
 def colsum(x2d):

@@ -518,14 +518,15 @@ int cbim_gate_bwd(int dtype, const void* dy, const void* x, const float* psi, vo
  * out_dtype (CBIM_F32 | CBIM_BF16); rowstats float [rows][2] = (mean, rstd) for the backward.
  * Backward: dx float [rows][C] = rstd*(g - mean(g) - xh*mean(g*xh)), g = dy*gamma; dgamma / dbeta
  * (float [C], NULL to skip) are summed in fixed order through
- * cbim_layernorm_bwd_workspace(rows, C) bytes of scratch.
+ * cbim_layernorm_bwd_workspace(rows, C) bytes of scratch.  add (float [rows][C] or NULL, round 5) is added to dx: the
+ * gradient of the residual stream x + f(LN(x)) that bypasses the norm (swin_unetr.py:539-552) — no separate add pass.
  * ------------------------------------------------------------------------------------------ */
 int cbim_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int out_dtype,
                        void* y, float* rowstats, int64_t rows, int C, void* stream);
 size_t cbim_layernorm_bwd_workspace(int64_t rows, int C);
 int cbim_layernorm_bwd(int dy_dtype, const void* dy, const float* x, const float* gamma,
-                       const float* rowstats, float* dx, float* dgamma, float* dbeta, void* workspace,
-                       size_t ws_bytes, int64_t rows, int C, void* stream);
+                       const float* rowstats, const float* add, float* dx, float* dgamma, float* dbeta,
+                       void* workspace, size_t ws_bytes, int64_t rows, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Token Linear (round 5) — nn.Linear over channels-last token rows on the matrix cores, the SwinUNETR trunk's

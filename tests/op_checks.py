@@ -982,6 +982,18 @@ def check_layernorm(dev, rows=(3, 5, 7), C=48, affine=True, out_bf16=False, seed
     assert relerr(xe.grad.cpu(), xr.grad) < 2e-5
     if affine:
         assert relerr(we.grad.cpu(), wr.grad) < 2e-5 and relerr(be.grad.cpu(), br.grad) < 2e-5
+    # the two-output form (LN(x), x) of a pre-norm residual branch: out = x + 0.7 * LN(x) * v, both gradients in one kernel
+    v = torch.randn(C)
+    xr2 = x.clone().requires_grad_(True)
+    (xr2 + 0.7 * F.layer_norm(xr2, (C,), w, b, 1e-5) * v).backward(g)
+    xe2 = x.clone().to(dev).requires_grad_(True)
+    y2, xp = Fn.LayerNormResFn.apply(xe2, we.detach() if affine else None, be.detach() if affine else None, 1e-5, torch.float32)
+    (xp + 0.7 * y2 * v.to(dev)).backward(g.to(dev))
+    assert relerr(xe2.grad.cpu(), xr2.grad) < 2e-5
+    xe3 = x.clone().to(dev).requires_grad_(True)                       # only the pass-through used: the gradient is handed on as it is
+    _, xp3 = Fn.LayerNormResFn.apply(xe3, None, None, 1e-5, torch.float32)
+    (xp3 * 2.0).sum().backward()
+    assert torch.equal(xe3.grad.cpu(), torch.full_like(x, 2.0))
 
 
 def check_dgrad_mask_by_activated(dev, dtype, N=1, Cin=32, Cout=32, dhw=(8, 16, 8), seed=41):
