@@ -536,6 +536,44 @@ class NormConvFn(_GradAwareFunction):
         return dx, None, dw, None, (dy if has_res else None), None, ds, None
 
 
+class DualRawConvFn(_GradAwareFunction):
+    """Two bias-free convolutions of the SAME raw tensor — monai's UnetResBlock with a channel change reads x through conv1 (k^3)
+    and through the 1x1x1 residual conv3 (/root/reference/model/dim3/swin_unetr.py:129-226) — as one autograd node: forward is the
+    two launches (each with its output statistics), backward computes the second input gradient INTO the first (the kernels'
+    accumulate operand) instead of leaving autograd an element-wise add over the block input (400 MB at 128^3 x 96 channels)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w3, eps):
+        g1, g3 = _geom(x, w1, 0), _geom(x, w3, 0)
+        train = bool(ctx.needs_input_grad[0]) and _training(ctx)
+        wp1, wd1 = ops.packed_weights((w1,), g1, train)
+        wp3, wd3 = ops.packed_weights((w3,), g3, train)
+        z1, s1 = ops.conv_fwd(x, wp1, g1, want_stats=True, eps=eps)
+        r, s3 = ops.conv_fwd(x, wp3, g3, want_stats=True, eps=eps)
+        ctx.save_for_backward(x)
+        ctx.cfg = (g1, g3, wd1, wd3)
+        ctx.w_params = (ops.slot_of(w1), ops.slot_of(w3))
+        ctx.mark_non_differentiable(s1, s3)
+        ctx.set_materialize_grads(False)
+        return z1, s1, r, s3
+
+    @staticmethod
+    def backward(ctx, dz1, _ds1, dr, _ds3):
+        (x,) = ctx.saved_tensors
+        g1, g3, wd1, wd3 = ctx.cfg
+        dz1 = ops.as_rows(dz1) if dz1 is not None else None
+        dr = ops.as_rows(dr) if dr is not None else None
+        dw1 = ops.conv_wgrad(x, None, dz1, g1, out=ops.grad_slot(ctx.w_params[0])) if (dz1 is not None and ctx.needs_input_grad[1]) else None
+        dw3 = ops.conv_wgrad(x, None, dr, g3, out=ops.grad_slot(ctx.w_params[1])) if (dr is not None and ctx.needs_input_grad[2]) else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if dz1 is not None:
+                dx, _ = ops.conv_dgrad(dz1, wd1, g1)
+            if dr is not None:
+                dx, _ = ops.conv_dgrad(dr, wd3, g3, accumulate=dx)
+        return dx, dw1, dw3, None
+
+
 class DWConvFn(torch.autograd.Function):
     """Depthwise conv of act(IN(x)) (stats=None: of x) — DepthwiseSeparableConv.depthwise
     (conv_layers.py:137-145) / MBConv.depthwise (:211).  Also returns the per-(n,c) mean of the output
@@ -948,6 +986,30 @@ class BatchNormActFn(torch.autograd.Function):
         return dx, (dgamma if ctx.has[0] else None), (dbeta if ctx.has[1] else None), None, None, None, None, None, None
 
 
+_SLICE_PACK = {}
+
+
+def _packed_slice(w, kd, geom, need_dgrad):
+    """(weight slice [Cout, Cin, 1, kH, kW], packed forward image, packed dgrad image | None) of one kd plane of a 5x5x5 weight,
+    re-packed only when the parameter moved (its version, or a hipGraph replay / whole-table re-pack: ops.PACKED.epoch) — ADVICE
+    r04: the slices were re-packed on every forward AND backward (10 launches per convolution and step)."""
+    if not isinstance(w, torch.nn.Parameter):      # a temporary (e.g. the zero-padded weight of VNet's output tail): pack on the spot
+        wk = w.detach()[:, :, kd:kd + 1].contiguous()
+        wp, wpd = (ops.pack_weights_both(wk, geom) if need_dgrad else (ops.pack_weights(wk, geom, 0), None))
+        return wk, wp, wpd
+    key = (w.data_ptr(), tuple(w.shape), kd, geom.dtype)
+    tag = (w._version, ops.PACKED.epoch, ops.PACKED.stale)
+    e = _SLICE_PACK.get(key)
+    # (stale: a hipGraph replay moved the weights unseen; capturing: the pack launch must be IN the graph — a replay re-packs from the
+    #  weights its own captured optimizer step left)
+    capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
+    if e is None or e[0] != tag or ops.PACKED.stale or capturing or (need_dgrad and e[3] is None):
+        wk = w.detach()[:, :, kd:kd + 1].contiguous()
+        wp, wpd = (ops.pack_weights_both(wk, geom) if need_dgrad else (ops.pack_weights(wk, geom, 0), None))
+        e = _SLICE_PACK[key] = (tag, wk, wp, wpd, w)          # (keeps the parameter alive: data_ptr stays unique)
+    return e[1], e[2], e[3]
+
+
 class ConvSlicesFn(torch.autograd.Function):
     """nn.Conv3d with a kernel of more than 64 taps (VNet's 5x5x5, vnet.py:40,60,126) as the sum over kd of (1, kH, kW)
     convolutions of D-shifted slices on the implicit-GEMM kernel: slice kd reads the input planes d + kd - pD and accumulates
@@ -969,8 +1031,7 @@ class ConvSlicesFn(torch.autograd.Function):
             if d1 <= d0:
                 continue
             geom = ConvGeom(x.dtype, 1, (d1 - d0, H, W), Cin, Cout, (1, kH, kW), (0, pH, pW), 0)
-            wk = wd[:, :, kd:kd + 1].contiguous()
-            wp = ops.pack_weights(wk, geom, 0)
+            wk, wp, _ = _packed_slice(w, kd, geom, bool(ctx.needs_input_grad[0]))
             for n in range(N):
                 ys = y[n:n + 1, d0:d1]
                 ops.conv_igemm(geom.fwd, x[n:n + 1, d0 + o:d1 + o], wp, tuple(ys.shape), res=None if kd == pD else ys, out=ys)
@@ -978,7 +1039,7 @@ class ConvSlicesFn(torch.autograd.Function):
         if bias is not None:
             y += bias.detach().to(y.dtype)
         ctx.save_for_backward(x)
-        ctx.plans, ctx.w_shape, ctx.has_bias = plans, tuple(w.shape), bias is not None
+        ctx.plans, ctx.w_shape, ctx.has_bias, ctx.w_ref = plans, tuple(w.shape), bias is not None, w
         return y
 
     @staticmethod
@@ -989,7 +1050,7 @@ class ConvSlicesFn(torch.autograd.Function):
         dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.zeros(ctx.w_shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
         for kd, o, d0, d1, geom, wk in ctx.plans:
-            wpd = ops.pack_weights(wk, geom, 1) if dx is not None else None
+            wpd = _packed_slice(ctx.w_ref, kd, geom, True)[2] if dx is not None else None
             for n in range(N):
                 xs, dys = x[n:n + 1, d0 + o:d1 + o], dy[n:n + 1, d0:d1]
                 if dx is not None:

@@ -87,6 +87,12 @@ class UnetResBlock(nn.Module):
         if stem_dtype is not None:
             z1 = Fn.StemFn.apply(x, self.conv1.conv.weight, stem_dtype)
             s1 = Fn.ensure_stats(Fn.FMap(z1, None), _EPS).stats
+        elif self.downsample and _DUAL_CONV:
+            # conv1 and the 1x1x1 residual conv3 read the same tensor: one autograd node, the two input gradients accumulated in
+            # the kernel (functional.DualRawConvFn)
+            z1, s1, r, s3 = Fn.DualRawConvFn.apply(x, self.conv1.conv.weight, self.conv3.conv.weight, _EPS)
+            z2, s2 = Fn.NormConvFn.apply(z1, s1, self.conv2.conv.weight, _LRELU, None, True, None, _EPS)
+            return Fn.ResNormFn.apply(z2, s2, r, s3, _LRELU)
         else:
             z1, s1 = Fn.NormConvFn.apply(x, None, self.conv1.conv.weight, 0, None, True, None, _EPS)
         z2, s2 = Fn.NormConvFn.apply(z1, s1, self.conv2.conv.weight, _LRELU, None, True, None, _EPS)
@@ -242,6 +248,7 @@ def _token_linear(lin, x):
 
 _FUSED_LN = os.environ.get("CBIM_SWIN_FUSED_LN", "1") != "0"
 _FUSED_MERGE = os.environ.get("CBIM_SWIN_FUSED_MERGE", "1") != "0"
+_DUAL_CONV = os.environ.get("CBIM_SWIN_DUAL_CONV", "1") != "0"     # round 5: conv1 | conv3 of a UnetResBlock as one autograd node
 _FUSED_RES = os.environ.get("CBIM_SWIN_FUSED_RES", "1") != "0"     # round 5: residual-stream gradient added inside k_layernorm_bwd
 
 

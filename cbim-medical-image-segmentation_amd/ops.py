@@ -1089,7 +1089,8 @@ def lo_weights(w: torch.Tensor, geom: ConvGeom, need_dgrad: bool):
     _dev_ok(w)
     key = (w.data_ptr(), tuple(w.shape))
     e = _LO_CACHE.get(key)
-    stale = PACKED.stale or e is None or e[0] != (w._version, PACKED.epoch) or (need_dgrad and e[2] is None)
+    capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()      # (the pack launch must be IN a captured step)
+    stale = PACKED.stale or capturing or e is None or e[0] != (w._version, PACKED.epoch) or (need_dgrad and e[2] is None)
     if stale:
         L = _lib.lib()
         p0 = e[1] if e is not None else torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 0),), dtype=torch.uint8, device=w.device)
