@@ -1240,3 +1240,39 @@ def check_batchnorm_affine(dev, dtype, N=2, C=16, dhw=(4, 6, 8), act="elu"):
         assert relerr(we.grad.cpu(), wr.grad) < tol(dtype, 1e-4, 2e-2) and relerr(be.grad.cpu(), br.grad) < tol(dtype, 1e-4, 2e-2)
         assert relerr(rm_e.cpu(), rm) < 1e-5 and relerr(rv_e.cpu(), rv) < tol(dtype, 1e-5, 1e-2)
         assert bool(torch.isfinite(xe.grad).all())
+
+
+def check_dual_raw_conv(dev, dtype, N=1, Cin=16, Cout=8, dhw=(4, 8, 8)):
+    """functional.DualRawConvFn (conv1 k^3 | conv3 1x1x1 of a monai UnetResBlock reading the same tensor, the two input
+    gradients accumulated in the kernel) against the two separate NormConvFn nodes it replaces and against torch."""
+    from cbim_amd import functional as Fn
+    torch.manual_seed(61)
+    x = torch.randn(N, Cin, *dhw)
+    w1 = torch.nn.Parameter((torch.randn(Cout, Cin, 3, 3, 3) * 0.1).to(dev))
+    w3 = torch.nn.Parameter((torch.randn(Cout, Cin, 1, 1, 1) * 0.3).to(dev))
+    g1, g3 = torch.randn(N, Cout, *dhw), torch.randn(N, Cout, *dhw)
+    xl = to_cl(x, dtype).to(dev)
+    res = []
+    for dual in (True, False):
+        xe = xl.clone().requires_grad_(True)
+        for p in (w1, w3):
+            p.grad = None
+        if dual:
+            z1, s1, r, s3 = Fn.DualRawConvFn.apply(xe, w1, w3, 1e-5)
+        else:
+            z1, s1 = Fn.NormConvFn.apply(xe, None, w1, 0, None, True, None, 1e-5)
+            r, s3 = Fn.NormConvFn.apply(xe, None, w3, 0, None, True, None, 1e-5)
+        (z1.float() * to_cl(g1, dtype).to(dev).float()).sum().backward(retain_graph=True)
+        (r.float() * to_cl(g3, dtype).to(dev).float()).sum().backward()
+        res.append([t.detach().float().cpu() for t in (z1, s1, r, s3, xe.grad, w1.grad, w3.grad)])
+    for a, b, nm in zip(res[0], res[1], ("z1", "stats1", "r", "stats3", "dx", "dw1", "dw3")):
+        assert relerr(a, b) < tol(dtype, 1e-6, 8e-3), (nm, relerr(a, b))       # (dx: one bf16 rounding of the sum instead of two)
+    xr = from_cl(xl.cpu()).requires_grad_(True)
+    w1r, w3r = w1.detach().cpu().clone().requires_grad_(True), w3.detach().cpu().clone().requires_grad_(True)
+    if dtype == torch.bfloat16:
+        w1q, w3q = w1r.bfloat16().float(), w3r.bfloat16().float()
+    else:
+        w1q, w3q = w1r, w3r
+    (F.conv3d(xr, w1q, None, 1, 1) * from_cl(to_cl(g1, dtype))).sum().backward()
+    (F.conv3d(xr, w3q, None, 1, 0) * from_cl(to_cl(g3, dtype))).sum().backward()
+    assert relerr(from_cl(res[0][4].to(dtype) if False else res[0][4]), xr.grad) < tol(dtype, 2e-5, 1e-2)

@@ -356,3 +356,9 @@ def test_batchnorm_affine(dev, dtype):
     oc.check_batchnorm_affine(dev, dtype)
     oc.check_batchnorm_affine(dev, dtype, N=1, C=8, dhw=(3, 5, 7), act="relu")
     oc.check_batchnorm_affine(dev, dtype, N=3, C=24, dhw=(2, 4, 4), act="none")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_dual_raw_conv(dev, dtype):
+    oc.check_dual_raw_conv(dev, dtype)
+    oc.check_dual_raw_conv(dev, dtype, N=2, Cin=96, Cout=48, dhw=(16, 16, 16))     # a decoder block of the benchmarked SwinUNETR

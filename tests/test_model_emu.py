@@ -280,7 +280,7 @@ def test_label_range_is_checked_per_step_at_first_and_per_epoch_afterwards(dev):
     assert check_labels() == 0
 
 
-@pytest.mark.parametrize("name", ["resunet_bn_b8", "resunet_nopool_b8", "unet_single_nopool_bn"])   # (all five on the GPU: test_u_late_gpu_cases.py)
+@pytest.mark.parametrize("name", ["unet_single_nopool_bn"])   # BatchNorm + anisotropic strides in 40 s here; all five fixtures on the GPU (test_u_late_gpu_cases.py), all five pin the oracle (test_oracle.py)
 def test_norm_bn_and_pool_false_branches_fp32_match_reference_golden(dev, name):
     """`norm: bn` and `pool=False` (round 5): UNet with nn.BatchNorm3d in every ConvNormAct / with a strided first block per level
     against one training step + the eval-mode forward of the REAL reference (tests/golden/make_golden_bn.py): perturbed affine

@@ -330,3 +330,8 @@ def test_batchnorm_affine(dev, dtype):
     oc.check_batchnorm_affine(dev, dtype)
     oc.check_batchnorm_affine(dev, dtype, N=1, C=8, dhw=(3, 5, 7), act="relu")
     oc.check_batchnorm_affine(dev, dtype, N=3, C=24, dhw=(2, 4, 4), act="none")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_dual_raw_conv(dev, dtype):
+    oc.check_dual_raw_conv(dev, dtype)
