@@ -616,6 +616,23 @@ class DWConvFn(torch.autograd.Function):
         return dx, None, dw, None, None
 
 
+class ChannelMeanFn(torch.autograd.Function):
+    """The SEBlock squeeze (conv_layers.py:163,171) of a tensor whose InstanceNorm statistics are already known: mean = stats[..., 0]
+    (no pass over x); backward hands x the per-channel constant dmean / S as a broadcast view, which autograd adds to x's other
+    gradient in one pass.  (MBConv gets the same term through DWConvFn's gradient bias; this is FusedMBConv's, proj_type 'linear'.)"""
+
+    @staticmethod
+    def forward(ctx, x, stats):
+        ctx.shape, ctx.dtype = tuple(x.shape), x.dtype
+        return stats[..., 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, dmean):
+        N, D, H, W, Cc = ctx.shape
+        g = (dmean.float() / float(D * H * W)).to(ctx.dtype)
+        return g[:, None, None, None, :].expand(ctx.shape), None
+
+
 class SpaceToDepthFn(torch.autograd.Function):
     """PatchMerging's 8 strided slices + channel concat (medformer_utils.py:163-171)."""
 

@@ -283,3 +283,31 @@ class MBConv(nn.Module):
         gate = self.se.gate(mean)
         y, so = Fn.NormConvFn.apply(d, ds, self.pointwise.conv.weight, 0, f.t, want_out_stats, gate, IN_EPS)
         return Fn.FMap(y, so if want_out_stats else None)
+
+
+class FusedMBConv(nn.Module):
+    """conv (k = 1 as MedFormer builds it) -> SE -> project 1x1, pre-activated ConvNormActs, identity shortcut —
+    conv_layers.py:240-281 of the reference, the feed-forward of BidirectionAttentionBlock under proj_type 'linear'
+    (medformer_utils.py:121-122).  Two launches of the row GEMM (InstanceNorm + act on load; the SE gate folded into the
+    second one's normalisation) + the [N, C] excitation."""
+
+    def __init__(self, in_ch, out_ch, expansion=4, kernel_size=3, stride=1, ratio=4, p=0, se=True, norm="in", act="relu"):
+        super().__init__()
+        k = _k3(kernel_size)
+        if in_ch != out_ch or stride != 1 or p or not se or k != [1, 1, 1]:
+            raise NotImplementedError("cbim_amd: only the MedFormer FusedMBConv variant (in==out, 1x1x1, stride 1, SE, p=0) is built")
+        expanded = expansion * in_ch
+        self.stride = stride
+        self.conv3x3 = ConvNormAct(in_ch, expanded, kernel_size=k, padding=0, norm=norm, act=act, preact=True)
+        self.se_block = SEBlock(expanded, ratio=ratio)
+        self.pointwise = ConvNormAct(expanded, out_ch, kernel_size=1, padding=0, norm=norm, act=None, preact=True)
+        self.drop_path = nn.Identity()
+        self.shortcut = nn.Sequential()
+
+    def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
+        f = Fn.ensure_stats(f)
+        act = self.conv3x3.act_code
+        e, se_ = Fn.NormConvFn.apply(f.t, f.stats, self.conv3x3.conv.weight, act, None, True, None, IN_EPS)
+        gate = self.se_block.gate(Fn.ChannelMeanFn.apply(e, se_))
+        y, so = Fn.NormConvFn.apply(e, se_, self.pointwise.conv.weight, 0, f.t, want_out_stats, gate, IN_EPS)
+        return Fn.FMap(y, so if want_out_stats else None)

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from ... import functional as Fn
 from ...ops import ACT, IN_EPS
-from .conv_layers import BasicBlock, ConvNormAct, DepthwiseSeparableConv, MBConv, _k3
+from .conv_layers import BasicBlock, ConvNormAct, DepthwiseSeparableConv, FusedMBConv, MBConv, _k3
 from .trans_layers import TransformerBlock
 
 _EPS_DEFAULT = 1e-5   # nn.InstanceNorm3d default, used by norm1/norm2 and PatchMerging.norm (:112-113,:158)
@@ -44,26 +44,38 @@ class BidirectionAttention(nn.Module):
     def __init__(self, feat_dim, map_dim, out_dim, heads=4, dim_head=64, attn_drop=0., proj_drop=0.,
                  map_size=(8, 8, 8), proj_type="depthwise", kernel_size=(3, 3, 3), no_map_out=False):
         super().__init__()
-        if proj_type != "depthwise":
-            raise NotImplementedError("cbim_amd: BidirectionAttention(proj_type='linear') is not built")
+        if proj_type not in ("linear", "depthwise"):
+            raise ValueError(proj_type)
         if attn_drop or proj_drop:
             raise NotImplementedError("cbim_amd: attention dropout is not built (0 in every shipped config)")
         self.inner_dim, self.heads, self.dim_head = dim_head * heads, heads, dim_head
         self.scale = dim_head ** (-0.5)
-        self.feat_qv = DepthwiseSeparableConv(feat_dim, self.inner_dim * 2, kernel_size=kernel_size)
-        self.feat_out = DepthwiseSeparableConv(self.inner_dim, out_dim, kernel_size=kernel_size)
+        self.linear = proj_type == "linear"
+        if self.linear:   # medformer_utils.py:26-28: bias-free 1x1x1 feature projections
+            self.feat_qv = nn.Conv3d(feat_dim, self.inner_dim * 2, kernel_size=1, stride=1, padding=0, bias=False)
+            self.feat_out = nn.Conv3d(self.inner_dim, out_dim, kernel_size=1, stride=1, padding=0, bias=False)
+        else:
+            self.feat_qv = DepthwiseSeparableConv(feat_dim, self.inner_dim * 2, kernel_size=kernel_size)
+            self.feat_out = DepthwiseSeparableConv(self.inner_dim, out_dim, kernel_size=kernel_size)
         self.map_qv = nn.Conv3d(map_dim, self.inner_dim * 2, kernel_size=1, bias=False)
         self.map_out = nn.Identity() if no_map_out else nn.Conv3d(self.inner_dim, map_dim, kernel_size=1, bias=False)
 
     def forward(self, x, x_stats, mapp, res, want_stats):
         """x (raw) with InstanceNorm stats (eps 1e-5) fused into the depthwise load; mapp already normalised.
         Returns (feat_out + res as FMap, map_out [B, *, m...])."""
-        qv = self.feat_qv(x, x_stats, 0).t
+        if self.linear:   # IN (the block's norm1) on load of the row GEMM, no activation
+            qv = Fn.NormConvFn.apply(x, x_stats, self.feat_qv.weight, 0, None, False, None, IN_EPS)[0]
+        else:
+            qv = self.feat_qv(x, x_stats, 0).t
         B, ms = mapp.shape[0], tuple(mapp.shape[2:])
         mqv = pointwise(self.map_qv, mapp).flatten(2).transpose(1, 2)   # [B, M, 2*inner]
         mq, mv = mqv[..., :self.inner_dim], mqv[..., self.inner_dim:]
         fo, mo = Fn.BidirAttnFn.apply(qv, mq, mv, self.heads, self.scale)
-        out = self.feat_out(fo, None, 0, res=res, want_stats=want_stats)
+        if self.linear:
+            y, so = Fn.NormConvFn.apply(fo, None, self.feat_out.weight, 0, res, want_stats, None, IN_EPS)
+            out = Fn.FMap(y, so if want_stats else None)
+        else:
+            out = self.feat_out(fo, None, 0, res=res, want_stats=want_stats)
         mo = mo.transpose(1, 2).reshape(B, self.inner_dim, *ms)
         return out, (mo if isinstance(self.map_out, nn.Identity) else pointwise(self.map_out, mo))
 
@@ -83,7 +95,10 @@ class BidirectionAttentionBlock(nn.Module):
         self.shortcut = nn.Sequential()
         if feat_dim != out_dim:
             self.shortcut = ConvNormAct(feat_dim, out_dim, 1, padding=0, norm=norm, act=act, preact=True)
-        self.feedforward = MBConv(out_dim, out_dim, expansion=expansion, kernel_size=kernel_size, act=act, norm=norm)
+        if proj_type == "linear":   # medformer_utils.py:121-122
+            self.feedforward = FusedMBConv(out_dim, out_dim, expansion=expansion, kernel_size=1, act=act, norm=norm)
+        else:
+            self.feedforward = MBConv(out_dim, out_dim, expansion=expansion, kernel_size=kernel_size, act=act, norm=norm)
 
     def forward(self, f: Fn.FMap, semantic_map, want_out_stats=True):
         f = Fn.ensure_stats(f)                                   # eps 1e-4 (ConvNormAct convention)
@@ -104,18 +119,25 @@ class PatchMerging(nn.Module):
 
     def __init__(self, dim, out_dim, norm="in", proj_type="linear", down_scale=(2, 2, 2), kernel_size=(3, 3, 3)):
         super().__init__()
-        if proj_type != "depthwise":
-            raise NotImplementedError("cbim_amd: PatchMerging(proj_type='linear') is not built")
+        if proj_type not in ("linear", "depthwise"):
+            raise ValueError(proj_type)
         self.down_scale = _k3(down_scale)
         merged = 2 ** self.down_scale.count(2) * dim
         if any(s not in (1, 2) for s in self.down_scale):
             raise NotImplementedError("cbim_amd: PatchMerging scales other than 1/2 are not built")
-        self.reduction = DepthwiseSeparableConv(merged, out_dim, kernel_size=kernel_size)
+        self.linear = proj_type == "linear"
+        if self.linear:   # medformer_utils.py:153-154
+            self.reduction = nn.Conv3d(merged, out_dim, kernel_size=1, bias=False)
+        else:
+            self.reduction = DepthwiseSeparableConv(merged, out_dim, kernel_size=kernel_size)
         self.norm = nn.Identity()   # InstanceNorm3d(merged), eps 1e-5: fused into the depthwise load
 
     def forward(self, f: Fn.FMap) -> Fn.FMap:
         m = Fn.SpaceToDepthFn.apply(f.t, tuple(self.down_scale))
         ms = Fn.ensure_stats(Fn.FMap(m, None), _EPS_DEFAULT).stats
+        if self.linear:
+            y, so = Fn.NormConvFn.apply(m, ms, self.reduction.weight, 0, None, True, None, IN_EPS)
+            return Fn.FMap(y, so)
         return self.reduction(m, ms, 0, want_stats=True)
 
 

@@ -7,8 +7,8 @@ trans_layers}.py`` over a ``state_dict`` with the reference's own parameter name
 ``torch`` ops in NCDHW layout on the CPU; dtype-generic (run it in float64 for a ground truth).
 Pinned against ``tests/golden/medformer_tiny_32.npz`` (outputs + every gradient of the REAL reference,
 ``tests/golden/make_golden_medformer.py``) by ``tests/test_oracle.py``.  Line numbers are in
-``/root/reference/model/dim3``.  Only the shipped variant is restated: conv_block BasicBlock,
-proj_type 'depthwise', norm 'in', dropout 0.
+``/root/reference/model/dim3``.  Restated: conv_block BasicBlock, proj_type 'depthwise' (every shipped yaml) and 'linear'
+(round 5, pinned by ``medformer_linear_tiny.npz``), norm 'in', dropout 0.
 """
 from __future__ import annotations
 
@@ -23,7 +23,11 @@ EPS_DEFAULT = 1e-5   # nn.InstanceNorm3d / nn.LayerNorm default (medformer_utils
 
 
 def dw_separable(sd, p, x, k):
-    """DepthwiseSeparableConv.forward (conv_layers.py:152-156): depthwise k^3 (groups=C) -> pointwise 1^3."""
+    """The feature-side projection of the configured proj_type (medformer_utils.py:26-31,153-156): 'depthwise' =
+    DepthwiseSeparableConv.forward (conv_layers.py:152-156): depthwise k^3 (groups=C) -> pointwise 1^3; 'linear' = one bias-free
+    1x1x1 nn.Conv3d (its state_dict holds `<p>weight` instead of `<p>depthwise.weight` / `<p>pointwise.weight`)."""
+    if p + "depthwise.weight" not in sd:
+        return F.conv3d(x, sd[p + "weight"])
     w = sd[p + "depthwise.weight"]
     return F.conv3d(F.conv3d(x, w, None, 1, _pad(k), 1, w.shape[0]), sd[p + "pointwise.weight"])
 
@@ -47,6 +51,17 @@ def mbconv(sd, p, x, k, act):
     h = h * s                                                                           # :175
     h = cna_preact(sd, p + "pointwise.", h, 1, None)                                    # :232 (act=False)
     return h + x                                                                        # :236, identity shortcut
+
+
+def fused_mbconv(sd, p, x, act):
+    """FusedMBConv.forward (conv_layers.py:268-281) as BidirectionAttentionBlock builds it for proj_type 'linear'
+    (medformer_utils.py:121-122: kernel_size 1, in == out, stride 1, SE, p = 0)."""
+    h = cna_preact(sd, p + "conv3x3.", x, 1, act)                                       # :271
+    s = h.mean((2, 3, 4), keepdim=True)                                                 # SEBlock :171
+    s = F.conv3d(s, sd[p + "se_block.excitation.0.weight"], sd[p + "se_block.excitation.0.bias"])
+    s = torch.sigmoid(F.conv3d(F.relu(s), sd[p + "se_block.excitation.2.weight"], sd[p + "se_block.excitation.2.bias"]))
+    h = cna_preact(sd, p + "pointwise.", h * s, 1, None)                                # :273-275
+    return h + x                                                                        # :279, identity shortcut
 
 
 def _split_heads(t, heads):
@@ -86,6 +101,8 @@ def attention_block(sd, p, x, smap, heads, k, act, no_map_out):
         out = out + cna_preact(sd, p + "shortcut.", x, 1, act)
     else:
         out = out + x
+    if (p + "feedforward.conv3x3.conv.weight") in sd:                                  # proj_type 'linear': FusedMBConv (:121-122)
+        return fused_mbconv(sd, p + "feedforward.", out, act), mapp + smap
     return mbconv(sd, p + "feedforward.", out, k, act), mapp + smap                     # :134-136
 
 

@@ -17,6 +17,7 @@ Same import shim as make_golden.py.  Cases
   medformer_bcv_tiny  the STRUCTURE of config/bcv/medformer_3d.yaml: 27 map codes (odd: padded code rows), 14 classes
   medformer_lits_tiny the STRUCTURE of config/lits/medformer_3d.yaml: num_heads all 1 (d_head = channels: 32, 64,
                       80), aux_loss False (forward returns one tensor)
+  medformer_linear_tiny  proj_type 'linear' at TINY's widths: 1x1x1 feature projections, FusedMBConv feed-forward
 No reference source is copied; only tensors it produced.
 """
 import importlib
@@ -60,8 +61,12 @@ LITS_T = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num
               num_heads=[1, 1, 1, 1, 1, 1, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
               attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
               scale=[[2, 2, 2]] * 4, aux_loss=False)
+# proj_type 'linear' (medformer_utils.py:26-28,121-122,153-154: 1x1x1 feature projections, FusedMBConv(kernel_size=1) feed-forward,
+# 1x1x1 patch-merging reduction) at the reduced widths of TINY — no shipped yaml uses it; a constructor branch of the drop-in
+LIN_T = dict(TINY, proj_type="linear")
 CASES = {
     # name: (in_chan, classes, kwargs, spatial, batch, seed, full)
+    "medformer_linear_tiny": (1, 4, LIN_T, (32, 32, 32), 1, 3051, 20000),
     "medformer_tiny_32": (1, 4, TINY, (32, 32, 32), 1, 3031, True),
     "medformer_amos_64": (1, 16, AMOS, (64, 64, 64), 1, 3032, False),
     # full = 20000: full gradients of every tensor with at most that many elements (all attention / map-side tensors),

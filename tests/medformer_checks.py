@@ -39,7 +39,8 @@ LITS_T = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num
               num_heads=[1, 1, 1, 1, 1, 1, 1, 1], fusion_depth=2, fusion_dim=40, fusion_heads=5, expansion=4,
               attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
               scale=[[2, 2, 2]] * 4, aux_loss=False)
-MF_CASES = {"medformer_tiny_32": (1, 4, TINY), "medformer_amos_64": (1, 16, AMOS),
+LIN_T = dict(TINY, proj_type="linear")
+MF_CASES = {"medformer_tiny_32": (1, 4, TINY), "medformer_linear_tiny": (1, 4, LIN_T), "medformer_amos_64": (1, 16, AMOS),
             "medformer_acdc_tiny": (1, 4, ACDC_T), "medformer_lits_tiny": (1, 3, LITS_T),
             "medformer_bcv_tiny": (1, 14, BCV_T)}
 AUX_WEIGHT = (0.5, 0.5)

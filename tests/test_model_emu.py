@@ -123,6 +123,13 @@ def test_medformer_fp32_matches_reference_golden(dev):
     assert_fp32_parity("medformer_tiny_32", dev)
 
 
+def test_medformer_linear_projections_fp32_match_reference_golden(dev):
+    """proj_type 'linear' (medformer_utils.py:26-28,121-122,153-154): 1x1x1 q/v and out projections, FusedMBConv feed-forward and the
+    linear PatchMerging reduction, all on the row GEMM with InstanceNorm on load — against the real reference."""
+    from tests.medformer_checks import assert_fp32_parity
+    print(assert_fp32_parity("medformer_linear_tiny", dev))
+
+
 def test_medformer_acdc_structure_fp32_matches_reference_golden(dev):
     """config/acdc/medformer_3d.yaml's structure (72 map codes, anisotropic stem, d_head 8|16|20) at reduced widths
     against the real reference: attn_wide.hip + the >64-code map pooling, forward and backward."""

@@ -100,6 +100,34 @@ def test_medformer_oracle_matches_reference_golden():
         assert float((v.grad - r).abs().max()) <= 1e-3 * float(r.abs().max()) + 1e-7 * scale, k
 
 
+def test_medformer_linear_oracle_matches_reference_golden():
+    """proj_type 'linear' (1x1x1 projections, FusedMBConv feed-forward, linear PatchMerging): the oracle against the real reference's
+    outputs + gradients.  The fixture stores no weights: they come from the seeded engine constructor, checksum-checked against the
+    reference's state_dict (tests.medformer_checks.build)."""
+    from oracle.loss_ref import ce_dice_loss
+    from oracle.medformer_ref import medformer_forward
+    from tests.medformer_checks import LIN_T, build
+    net, g = build("medformer_linear_tiny", "cpu")
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x, lab, w = torch.from_numpy(g["x"]), torch.from_numpy(g["label"]), torch.from_numpy(g["weight"])
+    outs = medformer_forward(sd, x, map_size=LIN_T["map_size"], num_heads=LIN_T["num_heads"],
+                             fusion_heads=LIN_T["fusion_heads"], fusion_depth=LIN_T["fusion_depth"],
+                             kernel_size=LIN_T["kernel_size"], scale=LIN_T["scale"], act="relu", aux_loss=True)
+    st = int(g["stride"])
+    assert rel_err(outs[0][..., ::st, ::st, ::st], g["logits"]) < 1e-5 and rel_err(outs[1][..., ::st, ::st, ::st], g["aux_logits"]) < 1e-5
+    loss = sum(0.5 * ce_dice_loss(o, lab, w) for o in outs)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    scale = float(np.max(g["grad_norms"]))
+    keys = [str(k) for k in g["keys"]]
+    gn = np.array([float(sd[k].grad.double().norm()) for k in keys])
+    assert float(np.max(np.abs(gn - g["grad_norms"]) / np.maximum(g["grad_norms"], 1e-5 * scale))) < 2e-2
+    for k in keys:
+        if "g:" + k in g.files:
+            r = torch.from_numpy(g["g:" + k])
+            assert float((sd[k].grad - r).abs().max()) <= 4e-2 * max(float(r.abs().max()), 1e-5 * scale), k
+
+
 def test_swin_oracle_matches_reference_golden():
     """oracle/swin_unetr_ref.py against the reference's swin_unetr.py executed on the monai stand-in
     (transformer part pinned; monai conv blocks parity-unpinned, see the oracle's header)."""

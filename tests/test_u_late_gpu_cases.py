@@ -174,3 +174,17 @@ def test_norm_bn_and_pool_false_branches_match_reference_golden(dev, name):
     #  logits of UNTRAINED weights scatter most, see test_resunet_bottleneck_matches_reference_golden: the losses are its criterion)
     lim = 2.0 if "bottleneck" in name else 0.25
     assert rb["logits_err"] < lim and abs(rb["ce"] - float(g["ce"])) < 0.05 and abs(rb["dice"] - float(g["dice"])) < 0.03, rb
+
+
+def test_medformer_linear_projections_match_reference_golden(dev):
+    """proj_type 'linear' (round 5): fp32 parity with the real reference, then the bf16 engine mode inside the MedFormer envelope."""
+    from tests.medformer_checks import assert_fp32_parity, run_case
+    from tests.util import record_parity
+    r = assert_fp32_parity("medformer_linear_tiny", dev)
+    print(r)
+    record_parity("golden_medformer_linear_tiny_fp32", {k: v for k, v in r.items() if not isinstance(v, list)})
+    rb, g = run_case("medformer_linear_tiny", dev, "bf16")
+    print(rb)
+    record_parity("golden_medformer_linear_tiny_bf16", {k: v for k, v in rb.items() if not isinstance(v, list)})
+    assert rb["logits_err"] < 0.4 and rb["aux_err"] < 0.4, rb
+    assert max(abs(a - b) for a, b in zip(rb["ce"] + rb["dice"], list(g["ce"]) + list(g["dice"]))) < 0.05, rb
