@@ -41,14 +41,28 @@ class ConvNormAct(nn.Module):
             if groups != 1:
                 raise NotImplementedError("cbim_amd: norm 'bn' is built for the dense convolutions of the UNet family")
             self.norm = nn.BatchNorm3d(in_ch if preact else out_ch, eps=IN_EPS)
+        elif norm == "ln":
+            # `norm: ln`: the reference's channels-first LayerNorm(eps=1e-4) (trans_layers.py:120-149) — per voxel over the
+            # channels, which in the engine's channels-last layout is the token-row LayerNorm kernel
+            if groups != 1:
+                raise NotImplementedError("cbim_amd: norm 'ln' is built for the dense convolutions of the UNet family")
+            from .trans_layers import LayerNorm
+            self.norm = LayerNorm(in_ch if preact else out_ch, eps=IN_EPS)
         elif norm in ("in", None, False, True):
             self.norm = nn.Identity()   # InstanceNorm3d(eps=1e-4): no parameters, fused into the kernels
         else:
             raise NotImplementedError(f"cbim_amd: norm '{norm}' is not built")
-        self.norm_kind = "bn" if norm == "bn" else "in"
+        self.norm_kind = norm if norm in ("bn", "ln") else "in"
         self.act = nn.Identity()
         self.act_code = ACT[act]
         self.preact = preact
+
+    def _norm_act(self, t):
+        """act(norm(t)) of the composed path: BatchNorm3d or the channel LayerNorm, one streaming pass each"""
+        if self.norm_kind == "ln":
+            y = self.norm.rows(t)
+            return y if self.act_code == 0 else Fn.ActFn.apply(y, self.act_code)
+        return self._bn_act(t)
 
     def _bn_act(self, t):
         """act(BatchNorm3d(t)) on a channels-last tensor: batch statistics + running-statistics update in train(), the running
@@ -66,12 +80,12 @@ class ConvNormAct(nn.Module):
     def apply_generic(self, t, res=None):
         """The composed (unfused) form of ConvNormAct.forward for `norm: bn`: conv(act(BN(t))) [+ res] (pre-activation) or
         act(BN(conv(t))) — the activated tensor is materialised by one streaming pass and the convolution reads it as it is."""
-        if self.norm_kind != "bn":
-            raise RuntimeError("apply_generic is the BatchNorm path")
+        if self.norm_kind == "in":
+            raise RuntimeError("apply_generic is the BatchNorm / LayerNorm path")
         if self.preact:
-            y = self.raw_conv(self._bn_act(t), res)
+            y = self.raw_conv(self._norm_act(t), res)
             return y
-        y = self._bn_act(self.raw_conv(t))
+        y = self._norm_act(self.raw_conv(t))
         return y if res is None else y + res
 
     def raw_conv(self, a, res=None):
@@ -97,7 +111,7 @@ class SingleConv(nn.Module):
         self.conv = ConvNormAct(in_ch, out_ch, kernel_size, stride=stride, norm=norm, act=act, preact=False)
 
     def forward(self, f: Fn.FMap, need_dx=True) -> Fn.FMap:
-        if self.conv.norm_kind == "bn":
+        if self.conv.norm_kind != "in":
             return Fn.FMap(self.conv.apply_generic(f.t), None)
         if self.conv.strided:                   # down_block(pool=False): act(IN(conv_stride(x)))
             z = self.conv.raw_conv(f.t)
@@ -109,8 +123,8 @@ class SingleConv(nn.Module):
     def forward_input(self, x, dtype) -> Fn.FMap:
         """First layer of a network: x is the NCDHW fp32 input (any channel count <= 16)."""
         z = Fn.StemFn.apply(x, self.conv.conv.weight, dtype)
-        if self.conv.norm_kind == "bn":
-            return Fn.FMap(self.conv._bn_act(z), None)
+        if self.conv.norm_kind != "in":
+            return Fn.FMap(self.conv._norm_act(z), None)
         zs = Fn.ensure_stats(Fn.FMap(z, None)).stats
         return Fn.FMap(Fn.NormActFn.apply(z, zs, self.conv.act_code), None)
 
@@ -139,8 +153,8 @@ class BasicBlock(nn.Module):
         act(IN(x)) of the in_ch-channel input (2 M values at 128^3) is two torch elementwise ops; conv1 and the
         shortcut conv read it through the stem kernel."""
         import torch.nn.functional as F
-        if self.conv1.norm_kind == "bn":
-            raise NotImplementedError("cbim_amd: a BatchNorm BasicBlock on the raw network input (UNet++ conv0_0) is not built")
+        if self.conv1.norm_kind != "in":
+            raise NotImplementedError("cbim_amd: a BatchNorm / LayerNorm BasicBlock on the raw network input (UNet++ conv0_0) is not built")
         if not isinstance(self.shortcut, ConvNormAct):
             raise NotImplementedError("cbim_amd: identity-shortcut BasicBlock on the raw network input is not built")
         if self.conv1.act_code != ACT["relu"]:
@@ -153,7 +167,7 @@ class BasicBlock(nn.Module):
         return Fn.FMap(out, so if want_out_stats else None)
 
     def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
-        if self.conv1.norm_kind == "bn":       # composed path: conv2(conv1(x)) + shortcut(x), the add in conv2's epilogue
+        if self.conv1.norm_kind != "in":       # composed path: conv2(conv1(x)) + shortcut(x), the add in conv2's epilogue
             res = self.shortcut.apply_generic(f.t) if isinstance(self.shortcut, ConvNormAct) else f.t
             return Fn.FMap(self.conv2.apply_generic(self.conv1.apply_generic(f.t), res=res), None)
         f = Fn.ensure_stats(f)
@@ -201,7 +215,7 @@ class Bottleneck(nn.Module):
             sc = self.shortcut.raw_conv(Fn.NormActFn.apply(f.t, f.stats, a))
             out, so = Fn.NormConvFn.apply(y2, s2, self.conv3.conv.weight, a, sc, want_out_stats, None, IN_EPS)
             return Fn.FMap(out, so if want_out_stats else None)
-        if self.conv1.norm_kind == "bn":
+        if self.conv1.norm_kind != "in":
             res = self.shortcut.apply_generic(f.t) if isinstance(self.shortcut, ConvNormAct) else f.t
             y = self.conv2.apply_generic(self.conv1.apply_generic(f.t))
             return Fn.FMap(self.conv3.apply_generic(y, res=res), None)

@@ -60,3 +60,32 @@ class TransformerBlock(nn.Module):
             x = attn(x) + x
             x = ffn(x) + x
         return x
+
+
+class LayerNorm(nn.Module):
+    """The reference's channels-first LayerNorm (trans_layers.py:120-149), what `norm: ln` puts into ConvNormAct
+    (model/dim3/utils.py:15-21, built with eps 1e-4 by conv_layers.py:40-42): per voxel, over the channel axis, with a per-channel
+    affine.  A parameter holder with the reference's state_dict keys — the engine's tensors are channels-last, so the arithmetic is
+    the token-row LayerNorm kernel (functional.LayerNormFn); forward() takes an NCDHW tensor like the reference's."""
+
+    def __init__(self, normalized_shape, eps=1e-5, data_format="channels_first"):
+        super().__init__()
+        if data_format not in ("channels_last", "channels_first"):
+            raise NotImplementedError
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps, self.data_format = eps, data_format
+        self.normalized_shape = (normalized_shape,)
+
+    def rows(self, t):
+        """channels-last tensor [..., C] -> LN over C (the engine-side call)"""
+        from ... import functional as Fn
+        y = Fn.layer_norm(t if t.dtype == torch.float32 else t.float(), self.weight, self.bias, self.eps, out_dtype=t.dtype)
+        return y
+
+    def forward(self, x):
+        if self.data_format == "channels_last":
+            return self.rows(x)
+        perm = [0] + list(range(2, x.dim())) + [1]
+        inv = [0, x.dim() - 1] + list(range(1, x.dim() - 1))
+        return self.rows(x.permute(perm).contiguous()).permute(inv)

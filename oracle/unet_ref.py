@@ -55,6 +55,12 @@ def _norm(sd, prefix, x, training=True):
     update in training mode, the running statistics in eval mode (F.batch_norm semantics; num_batches_tracked counted)."""
     if prefix + "norm.weight" not in sd:
         return instance_norm(x)
+    if prefix + "norm.running_mean" not in sd:
+        # `norm: ln`: the channels-first LayerNorm of trans_layers.py:120-149 (eps 1e-4 from conv_layers.py:40-42) — per voxel over C
+        u = x.mean(1, keepdim=True)
+        v = (x - u).pow(2).mean(1, keepdim=True)
+        shape = (1, -1) + (1,) * (x.dim() - 2)
+        return sd[prefix + "norm.weight"].view(shape) * ((x - u) / torch.sqrt(v + IN_EPS_CONV)) + sd[prefix + "norm.bias"].view(shape)
     rm, rv = sd[prefix + "norm.running_mean"], sd[prefix + "norm.running_var"]
     if training and prefix + "norm.num_batches_tracked" in sd:
         sd[prefix + "norm.num_batches_tracked"] += 1
@@ -169,6 +175,9 @@ def _cna(sd, prefix, cin, cout, k, norm, preact):
     _conv(sd, prefix + "conv.", cin, cout, k)
     if norm == "bn":
         _bn(sd, prefix + "norm.", cin if preact else cout)
+    elif norm == "ln":       # LayerNorm(ch): weight = ones, bias = zeros (trans_layers.py:130-131), no random draws
+        ch = cin if preact else cout
+        sd[prefix + "norm.weight"], sd[prefix + "norm.bias"] = torch.ones(ch), torch.zeros(ch)
 
 
 def _conv(sd, name, cin, cout, k, bias=False):

@@ -26,6 +26,9 @@ CASES = {
     "resunet_nopool_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", (32, 32, 36), 1, 3033, "in", False),
     "unet_single_nopool_bn": (1, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", (8, 32, 32), 2, 3034, "bn", False),
     "resunet_bottleneck_nopool_b16": (1, 16, 3, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "Bottleneck", (32, 32, 32), 1, 3035, "in", False),
+    # `norm: ln`: the channels-first LayerNorm (trans_layers.py:120-149) in every ConvNormAct
+    "resunet_ln_b8": (1, 8, 4, [[2, 2, 2]] * 4, [[3, 3, 3]] * 5, "BasicBlock", (32, 32, 32), 1, 3036, "ln", True),
+    "unet_single_ln_b8": (2, 8, 3, [[1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 5, "SingleConv", (8, 32, 32), 2, 3037, "ln", True),
 }
 
 

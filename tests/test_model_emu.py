@@ -62,7 +62,8 @@ def test_unbuilt_options_fail_loudly():
         get_model(_args(model="medformer", norm="bn", **{k: v for k, v in __import__("tests.medformer_checks", fromlist=["TINY"]).TINY.items()
                                                           if k not in ("norm",)}, down_scale=[[2, 2, 2]] * 4))
     with pytest.raises(NotImplementedError):
-        get_model(_args(block="Bottleneck", norm="ln"))
+        get_model(_args(model="unet++", norm="ln"))            # bn / ln are built for the UNet / ResUNet blocks
+    assert get_model(_args(block="Bottleneck", norm="ln")).state_dict()["down1.conv.1.conv1.norm.weight"].shape == (32,)
     with pytest.raises(NotImplementedError):
         get_model(_args(model="vtunet"))
     with pytest.raises(KeyError):
@@ -287,7 +288,7 @@ def test_label_range_is_checked_per_step_at_first_and_per_epoch_afterwards(dev):
     assert check_labels() == 0
 
 
-@pytest.mark.parametrize("name", ["unet_single_nopool_bn"])   # BatchNorm + anisotropic strides in 40 s here; all five fixtures on the GPU (test_u_late_gpu_cases.py), all five pin the oracle (test_oracle.py)
+@pytest.mark.parametrize("name", ["unet_single_nopool_bn", "unet_single_ln_b8"])   # BatchNorm + anisotropic strides in 40 s here; the channels-first LayerNorm in 25 s; all seven fixtures on the GPU (test_u_late_gpu_cases.py), all seven pin the oracle (test_oracle.py)
 def test_norm_bn_and_pool_false_branches_fp32_match_reference_golden(dev, name):
     """`norm: bn` and `pool=False` (round 5): UNet with nn.BatchNorm3d in every ConvNormAct / with a strided first block per level
     against one training step + the eval-mode forward of the REAL reference (tests/golden/make_golden_bn.py): perturbed affine

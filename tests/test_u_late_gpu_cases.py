@@ -158,9 +158,9 @@ def test_label_count_survives_graph_replay(dev):
 
 
 @pytest.mark.parametrize("name", ["resunet_bn_b8", "unet_single_bn_b8", "resunet_nopool_b8", "unet_single_nopool_bn",
-                                  "resunet_bottleneck_nopool_b16"])
+                                  "resunet_bottleneck_nopool_b16", "resunet_ln_b8", "unet_single_ln_b8"])
 def test_norm_bn_and_pool_false_branches_match_reference_golden(dev, name):
-    """`norm: bn`, `pool=False` (round 5): fp32 parity with the real reference's UNet (training step + eval forward); the bf16 mode
+    """`norm: bn`, `norm: ln`, `pool=False` (round 5): fp32 parity with the real reference's UNet (training step + eval forward); the bf16 mode
     runs the same composed path — logits inside the usual bf16 distance, losses close."""
     from tests.bn_checks import assert_fp32, run_case
     from tests.util import record_parity
