@@ -195,6 +195,12 @@ def _reference_cpu_baseline(args, cores):
     return _timed_reps(one, args.cpu_size, cores, "reference", "/root/reference model.dim3.unet.UNet + CE + DiceLoss")
 
 
+def _share_gpu():
+    """CBIM_BENCH_SHARE_GPU=1 (tests only, never a bench line): ranks may share a device, rendezvous over CBIM_BENCH_BACKEND=gloo —
+    the N > 1 control flow of this script (eager timing, graph agreement, fallback, every-rank roofline steps) on a 1-GPU box."""
+    return os.environ.get("CBIM_BENCH_SHARE_GPU", "0") == "1"
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (one process per GPU,
     RCCL rendezvous on 127.0.0.1) the way the reference's trainer spawns its own workers
@@ -203,7 +209,7 @@ def spawn_ranks(args):
     import socket
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    if have < args.gpus and not _share_gpu():
         sys.exit(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to report a "
                  f"{args.gpus}-GPU number from fewer devices")
     with socket.socket() as sk:
@@ -216,9 +222,32 @@ def spawn_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def time_model(args, dev, rank, world):
+def _timed(step, steps, world, dev):
+    """`steps` steps between barrier + synchronize pairs; the MAX over ranks -> (seconds, last loss)"""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, loss
+
+
+def time_model(args, dev, rank, world, on_hang=None):
     """Build the model `args.model` names, warm up, capture the step into a hipGraph (args.graph) and time args.steps steps
-    between barrier + synchronize pairs.  Returns a dict: ms per step (max over ranks), the step callables, the model facts."""
+    between barrier + synchronize pairs.  Returns a dict: ms per step (max over ranks), the step callables, the model facts.
+    N > 1: the eager step is timed FIRST; the graph attempt (RCCL collectives captured with the kernels) then runs under a
+    watchdog and behind an all-ranks agreement — a rank whose capture failed takes every rank back to eager launches, and a
+    capture / replay that does not return within CBIM_BENCH_GRAPH_TIMEOUT seconds (default 240) makes rank 0 report the eager
+    timing through `on_hang` and every rank exit, instead of hanging the node."""
     import cbim_amd
     from cbim_amd import ops
     from cbim_amd.model.dim3 import MedFormer, SwinUNETR, UNet
@@ -294,60 +323,98 @@ def time_model(args, dev, rank, world):
     grad_bucket = None
     if ddp is not None and args.warmup > 0:
         grad_bucket = {"written_in_place": ddp.direct_writes // args.warmup, "copied": ddp.copies // args.warmup}
-    if use_graph:
-        # launch-bound inner loop -> one hipGraph: every kernel of fwd+loss+bwd+AdamW is captured once
-        # (all launches go to the capturing stream; buffers come from the graph's private pool).
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        try:
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    step()
-                opt.zero_grad(set_to_none=True)
-                # the RCCL collectives of the gradient exchange are captured with the kernels (N > 1): every rank
-                # captures and replays the same sequence
-                aug_on, args.aug = args.aug, 0      # the captured step reads the static buffers x / lab
-                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if ddp is not None else "global"):
-                    static_loss = eager_step()
-                args.aug = aug_on
-            torch.cuda.current_stream().wait_stream(side)
+    facts = {"in_ch": in_ch, "classes": args.classes, "grad_bucket": grad_bucket}
+    eager_res, watchdog = None, None
+    if world > 1 and use_graph:
+        dt_e, loss_e = _timed(eager_step, args.steps, world, dev)
+        eager_res = dict(facts, ms=dt_e / args.steps * 1e3, dt=dt_e, graph=False, loss=float(loss_e.item()), ddp=ddp,
+                         note="hipGraph capture / replay with RCCL did not return: eager launches reported")
+        import threading
 
-            def step():
-                if args.aug:
-                    xs, ls = draw()
-                    x.copy_(xs)
-                    lab.copy_(ls)
-                graph.replay()
-                return static_loss
-            step()
-        except Exception as e:   # capture refused (e.g. an RCCL build without graph support): eager launches
+        def _hung():
             if rank == 0:
-                print(f"bench.py: hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+                print("bench.py: the hipGraph attempt did not return; reporting the eager timing", file=sys.stderr, flush=True)
+                if on_hang is not None:
+                    on_hang(eager_res)
+            else:
+                time.sleep(3.0)
+            os._exit(0 if on_hang is not None else 3)
+        watchdog = threading.Timer(float(os.environ.get("CBIM_BENCH_GRAPH_TIMEOUT", "240")), _hung)
+        watchdog.daemon = True
+        watchdog.start()
+
+    def graph_phase(step, use_graph):
+        if use_graph:
+            # launch-bound inner loop -> one hipGraph: every kernel of fwd+loss+bwd+AdamW is captured once
+            # (all launches go to the capturing stream; buffers come from the graph's private pool).
             torch.cuda.synchronize()
-            use_graph = False
-            step = eager_step
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            aug_on = args.aug
+            try:
+                if world > 1 and dist.get_backend() != "nccl":
+                    # (the shared-GPU test vehicle: a gloo collective inside a capture takes the process down, it does not raise)
+                    raise RuntimeError(f"the {dist.get_backend()} backend cannot be captured into a hipGraph")
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        step()
+                    opt.zero_grad(set_to_none=True)
+                    # the RCCL collectives of the gradient exchange are captured with the kernels (N > 1): every rank
+                    # captures and replays the same sequence
+                    args.aug = 0                        # the captured step reads the static buffers x / lab
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if ddp is not None else "global"):
+                        static_loss = eager_step()
+                    args.aug = aug_on
+                torch.cuda.current_stream().wait_stream(side)
+            except Exception as e:   # capture refused (e.g. an RCCL build without graph support): eager launches
+                print(f"bench.py[rank {rank}]: hipGraph capture failed ({type(e).__name__}: {str(e)[:300]}); timing eager launches",
+                      file=sys.stderr, flush=True)
+                use_graph = False
+                args.aug = aug_on
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+                if ddp is not None:
+                    ddp.reset()
+            if world > 1:
+                # every rank replays or none does: a replayed graph holds collectives the other ranks must replay too
+                flag = torch.tensor([1.0 if use_graph else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                use_graph = bool(flag.item() > 0.5)
+            if use_graph:
+                def step():
+                    if args.aug:
+                        xs, ls = draw()
+                        x.copy_(xs)
+                        lab.copy_(ls)
+                    graph.replay()
+                    return static_loss
+            else:
+                opt.zero_grad(set_to_none=True)
+                step = eager_step
             step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, loss = _timed(step, args.steps, world, dev)
+        return use_graph, dt, loss
+
+    try:
+        use_graph, dt, loss = graph_phase(step, use_graph)
+    except BaseException:
+        # N > 1: an error here is most likely a peer whose watchdog fired (the group is gone) or a failed replay — this rank's own
+        # watchdog reports the eager timing (rank 0) and exits; without a watchdog (N = 1) the error is the result
+        if watchdog is not None:
+            print(f"bench.py[rank {rank}]: the graph phase raised; waiting for the watchdog", file=sys.stderr, flush=True)
+            watchdog.join()
+        raise
+    if watchdog is not None:
+        watchdog.cancel()
     ms = dt / args.steps * 1e3
     loss_val = float(loss.item())
-
-    return {"ms": ms, "dt": dt, "graph": bool(use_graph), "loss": loss_val, "in_ch": in_ch, "classes": args.classes,
-            "eager_step": eager_step, "ddp": ddp, "grad_bucket": grad_bucket, "keep": (net, opt, crit, x, lab)}
+    res = dict(facts, ms=ms, dt=dt, graph=bool(use_graph), loss=loss_val, eager_step=eager_step, ddp=ddp, keep=(net, opt, crit, x, lab))
+    if eager_res is not None:
+        res["eager_ms"] = eager_res["ms"]
+    return res
 
 
 def _release(dev):
@@ -404,11 +471,17 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    if _share_gpu():
+        local = local % torch.cuda.device_count()
     assert local < torch.cuda.device_count(), f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} GPU(s) visible"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("CBIM_BENCH_BACKEND", "nccl") if _share_gpu() else "nccl"
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     elif args.ddp1:
         import socket
@@ -422,11 +495,24 @@ def main():
     assert _lib.backend() == "hip-gfx950"
     cbim_amd.set_compute_dtype(args.dtype)
 
-    r = time_model(args, dev, rank, world)
-    ms, use_graph, loss_val, in_ch, eager_step, ddp, grad_bucket = (r["ms"], r["graph"], r["loss"], r["in_ch"], r["eager_step"],
-                                                                     r["ddp"], r["grad_bucket"])
-    value = world * 1.0 / (ms * 1e-3)             # 1 volume per GPU per step (train_ddp.py:330)
+    def build_out(r):
+        ms, use_graph, loss_val, in_ch, ddp, grad_bucket = r["ms"], r["graph"], r["loss"], r["in_ch"], r["ddp"], r["grad_bucket"]
+        value = world * 1.0 / (ms * 1e-3)             # 1 volume per GPU per step (train_ddp.py:330)
+        out = _headline(args, world, ms, value, use_graph, loss_val, in_ch, ddp, grad_bucket)
+        if r.get("eager_ms") is not None:
+            out["config"]["eager_ms_per_step"] = r["eager_ms"]
+        if r.get("note"):
+            out["config"]["note"] = r["note"]
+        return out
 
+    def on_hang(r):
+        print(json.dumps(build_out(r)), flush=True)
+
+    box = [time_model(args, dev, rank, world, on_hang=on_hang)]
+    _finish(args, build_out(box[0]), box, rank, world, dev)
+
+
+def _headline(args, world, ms, value, use_graph, loss_val, in_ch, ddp, grad_bucket):
     out = {
         "metric": "3D volumes/sec (fwd+bwd) at 128^3", "value": value, "unit": "volumes/s",
         "n_gpus": dist.get_world_size() if dist.is_initialized() and not args.ddp1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -438,28 +524,38 @@ def main():
                                + f", 1x{in_ch}x{args.size}^3 per GPU, {args.classes} classes, fwd+CE/Dice loss+bwd+AdamW step"
                                + (", HBM-resident volumes + on-device augmentation (crop/affine/intensity, dataset_amos_ct recipe) prefetched on a side stream" if args.aug else "")
                                + (" (hipGraph replay)" if use_graph else "")
-                               + (", bucketed in-place grad all-reduce (RCCL)" if ddp is not None else ""),
+                               + (f", bucketed in-place grad all-reduce ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ', TEST VEHICLE'})" if ddp is not None else ""),
                    "global_batch": world, "parallelism": f"dp{world}", "graph": bool(use_graph),
                    "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0, "final_loss": loss_val},
     }
     if grad_bucket is not None:
         out["config"]["grad_bucket"] = grad_bucket
+    return out
 
+
+def _finish(args, out, box, rank, world, dev):
+    """roofline of the dominant kernel, the secondary block, the CPU baseline; rank 0 prints the line.  `box` = [time_model's result]:
+    the only reference to the headline model, dropped before the secondary models are built."""
+    from cbim_amd import ops
+    r = box.pop()
+    ms, eager_step = r["ms"], r["eager_step"]
     # ---- roofline of the dominant kernel: every launch of the conv kernels in one step, HIP events on the launch stream
-    if not args.no_roofline and rank == 0:
+    # (N > 1: EVERY rank runs the three eager steps — they hold the gradient collectives — rank 0 alone records)
+    if not args.no_roofline:
         per = {}
         reps = 3
         for _ in range(reps):
-            ops.PROFILE = []
+            ops.PROFILE = [] if rank == 0 else None
             eager_step()
             torch.cuda.synchronize()
-            for name, flops, e0, e1, shape, nbytes in ops.PROFILE:
+            for name, flops, e0, e1, shape, nbytes in (ops.PROFILE or ()):
                 d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
                 d[0] += flops
                 d[1] += e0.elapsed_time(e1) * 1e-3
                 d[2] += 1
                 d[3] += nbytes
             ops.PROFILE = None
+    if not args.no_roofline and rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         table = {k: {"launches_per_step": v[2] // reps, "avg_launch_ms": v[1] / v[2] * 1e3,
                      "alg_tflop_per_step": v[0] / reps / 1e12, "achieved_tflops": v[0] / v[1] / 1e12,

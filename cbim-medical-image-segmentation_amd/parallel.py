@@ -215,6 +215,20 @@ class GradAllReduce:
             b.pending = len(b.params)
         self._claimed.clear()
 
+    def reset(self):
+        """Forget a step that was abandoned half-way (an exception inside forward / backward, a failed hipGraph capture): pending
+        collectives are waited for where they can be, counters re-armed.  Every rank must abandon the same step."""
+        for b in self.buckets:
+            if b.work is not None:
+                try:
+                    b.work.wait()
+                except Exception:
+                    pass
+                b.work = None
+            b.fired = False
+            b.pending = len(b.params)
+        self._claimed.clear()
+
     def remove(self):
         for h in self._handles:
             h.remove()

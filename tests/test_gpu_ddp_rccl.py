@@ -50,6 +50,40 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout, (r.stdout, r.stderr[-500:])
 
 
+def _bench2(env_extra, *extra):
+    env = dict(os.environ, CBIM_BENCH_SHARE_GPU="1", CBIM_BENCH_BACKEND="gloo", **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # ONE line, from rank 0
+    return json.loads(lines[0]), r.stderr
+
+
+def test_two_rank_control_flow_of_bench_on_one_gpu():
+    """The N > 1 control flow of bench.py on the 1-GPU box (CBIM_BENCH_SHARE_GPU: both ranks on cuda:0, gloo rendezvous — a test
+    vehicle, never a bench line): self-spawn through torch.distributed.run, rank-0 broadcast, bucketed exchange from the backward hooks,
+    the eager timing taken first, a graph attempt that gloo refuses on every rank -> the all-ranks agreement falls back to eager
+    launches, the roofline's eager steps run on EVERY rank (they hold collectives), one JSON line."""
+    d, err = _bench2({})
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2
+    assert d["config"]["graph"] is False and "eager_ms_per_step" in d["config"], (d["config"], err[-1500:])
+    assert d["value"] == pytest.approx(2.0 / (d["ms_per_step"] * 1e-3))
+    assert d["config"]["grad_bucket"] == {"written_in_place": 45, "copied": 0}
+    assert d["roofline"]["kernel"].startswith(("k_conv3_rw", "k_wgrad_r32")) and 0 < d["roofline"]["frac"] < 1   # (64^3: the wgrad row leads)
+    assert "TEST VEHICLE" in d["config"]["workload"]
+    import math
+    assert math.isfinite(d["config"]["final_loss"])
+
+
+def test_graph_attempt_that_does_not_return_reports_the_eager_timing():
+    """the watchdog of the N > 1 graph attempt: with a 10 ms limit it fires inside the attempt — rank 0 prints the eager line
+    (config.note says so), every rank exits 0"""
+    d, err = _bench2({"CBIM_BENCH_GRAPH_TIMEOUT": "0.01"}, "--no-roofline")
+    assert d["n_gpus"] == 2 and d["config"]["graph"] is False and "did not return" in d["config"]["note"], d["config"]
+    assert "reporting the eager timing" in err
+
+
 def test_stock_ddp_wrapper_on_one_rank_rccl():
     """train_ddp.py:353: DistributedDataParallel(net, device_ids=[gpu], find_unused_parameters=True) over the engine
     module, here on a 1-rank RCCL group: the reducer's hooks fire from the HIP-kernel backward and leave the same
