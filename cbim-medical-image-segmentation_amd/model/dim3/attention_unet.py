@@ -70,7 +70,7 @@ class AttentionUNet(nn.Module):
         super().__init__()
         num_block = 2
         block = get_block(block)
-        norm = get_norm(norm, allow=("in",))
+        norm = get_norm(norm)      # in | bn | ln reach the BLOCKS; the gates keep nn.InstanceNorm3d (attention_unet_utils.py:10-21)
         b = base_ch
         self.inc = inconv(in_ch, b, block=block, kernel_size=kernel_size[0], norm=norm)
         self.down1 = down_block(b, 2 * b, num_block=num_block, block=block, pool=pool, down_scale=scale[0], kernel_size=kernel_size[1], norm=norm)

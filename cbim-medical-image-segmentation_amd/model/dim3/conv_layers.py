@@ -18,6 +18,34 @@ def _k3(k):
     return [k] * 3 if isinstance(k, int) else list(k)
 
 
+def _torch_act(code, z):
+    """the activation of a ConvNormAct as a torch op (raw-input paths: a 1 - 3 channel volume)"""
+    import torch.nn.functional as F
+    if code == ACT["relu"]:
+        return F.relu(z)
+    if code == ACT["lrelu"]:
+        return F.leaky_relu(z)          # nn.LeakyReLU() default slope 0.01 (model/dim3/utils.py:24-30)
+    if code == ACT["gelu"]:
+        return F.gelu(z)
+    if code == ACT["swish"]:
+        return F.silu(z)
+    if code == 0:
+        return z
+    raise NotImplementedError(f"cbim_amd: activation code {code} on the raw input")
+
+
+def _raw_input_conv(cna, a, dtype):
+    """conv(a) of an NCDHW fp32 tensor with 1 - 7 channels whose producer HAS parameters (the pre-activation norm of `norm: bn | ln`
+    on the network input): the stem kernel returns no input gradient, so the tensor goes channels-last, zero-padded to one 8-channel
+    chunk, through the dense convolution (weight padded to match; autograd slices its gradient back)."""
+    import torch.nn.functional as F
+    c = int(a.shape[1])
+    cp = (c + 7) // 8 * 8
+    t = F.pad(a.permute(0, 2, 3, 4, 1), (0, cp - c)).to(dtype).contiguous()
+    w = F.pad(cna.conv.weight, (0, 0, 0, 0, 0, 0, 0, cp - c))
+    return Fn.NormConvFn.apply(t, None, w, 0, None, False, None, IN_EPS)[0]
+
+
 class ConvNormAct(nn.Module):
     """Parameter holder for one conv + (norm, act) description (conv_layers.py:16-53)."""
 
@@ -154,7 +182,15 @@ class BasicBlock(nn.Module):
         shortcut conv read it through the stem kernel."""
         import torch.nn.functional as F
         if self.conv1.norm_kind != "in":
-            raise NotImplementedError("cbim_amd: a BatchNorm / LayerNorm BasicBlock on the raw network input (UNet++ conv0_0) is not built")
+            # `norm: bn | ln`: conv1 and the shortcut own SEPARATE norm parameters over the in_ch-channel input — the holders'
+            # own forward (nn.BatchNorm3d: batch / running statistics and their update; the channels-first LayerNorm) on the raw
+            # NCDHW volume, the activation as a torch op, then the stem kernel; conv2 + the residual add on the composed path
+            if not isinstance(self.shortcut, ConvNormAct):
+                raise NotImplementedError("cbim_amd: identity-shortcut BasicBlock on the raw network input is not built")
+            xf = x.float()
+            y1 = _raw_input_conv(self.conv1, _torch_act(self.conv1.act_code, self.conv1.norm(xf)), dtype)
+            sc = _raw_input_conv(self.shortcut, _torch_act(self.shortcut.act_code, self.shortcut.norm(xf)), dtype)
+            return Fn.FMap(self.conv2.apply_generic(y1, res=sc), None)
         if not isinstance(self.shortcut, ConvNormAct):
             raise NotImplementedError("cbim_amd: identity-shortcut BasicBlock on the raw network input is not built")
         if self.conv1.act_code != ACT["relu"]:

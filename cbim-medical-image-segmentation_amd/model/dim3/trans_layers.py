@@ -86,6 +86,14 @@ class LayerNorm(nn.Module):
     def forward(self, x):
         if self.data_format == "channels_last":
             return self.rows(x)
+        C = int(x.shape[1])
+        if C < 4 or C % 4:
+            # a raw network input (1 - 3 channels: UNet++ conv0_0 with a pre-activated first block): the reference's own formula
+            # on the device, a few elementwise torch ops over one volume (the row kernel takes channel counts in multiples of 4)
+            u = x.mean(1, keepdim=True)
+            v = (x - u).pow(2).mean(1, keepdim=True)
+            shape = (1, -1) + (1,) * (x.dim() - 2)
+            return self.weight.view(shape) * ((x - u) / torch.sqrt(v + self.eps)) + self.bias.view(shape)
         perm = [0] + list(range(2, x.dim())) + [1]
         inv = [0, x.dim() - 1] + list(range(1, x.dim() - 1))
         return self.rows(x.permute(perm).contiguous()).permute(inv)

@@ -18,7 +18,7 @@ class UNetPlusPlus(nn.Module):
         super().__init__()
         num_block = 2
         block = get_block(block)
-        norm = get_norm(norm, allow=("in",))
+        norm = get_norm(norm)      # in | bn | ln: the blocks' composed paths (round 5)
         n_ch = [base_ch, base_ch * 2, base_ch * 4, base_ch * 8, base_ch * 10]
         self.scale = [tuple(_k3(s)) for s in scale]
         for i in range(4):   # parameter-free slots with the reference's attribute names

@@ -236,7 +236,7 @@ def state_dict_checksum(sd) -> float:
     return acc
 
 
-def unetpp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size, block="BasicBlock") -> torch.Tensor:
+def unetpp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size, block="BasicBlock", training=True) -> torch.Tensor:
     """UNetPlusPlus.forward (/root/reference/model/dim3/unetpp.py:52-76); layers are nn.Sequential of two blocks
     (make_layer :79-88), pooling nn.MaxPool3d(scale[i]), upsampling nn.Upsample(scale_factor, trilinear,
     align_corners=True)."""
@@ -245,8 +245,8 @@ def unetpp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kerne
     sc = [tuple(_k3(s)) for s in scale]
 
     def layer(name, t, lvl):
-        t = blk(sd, f"{name}.0.", t, ks[lvl])
-        return blk(sd, f"{name}.1.", t, ks[lvl])
+        t = blk(sd, f"{name}.0.", t, ks[lvl], training=training)
+        return blk(sd, f"{name}.1.", t, ks[lvl], training=training)
 
     def up(t, i):
         return F.interpolate(t, scale_factor=tuple(float(v) for v in sc[i]), mode="trilinear", align_corners=True)
@@ -269,10 +269,12 @@ def unetpp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kerne
     return F.conv3d(x0_4, sd["output.weight"], sd["output.bias"])
 
 
-def attention_unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size, block="BasicBlock") -> torch.Tensor:
+def attention_unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, *, scale, kernel_size, block="BasicBlock",
+                           training=True) -> torch.Tensor:
     """AttentionUNet.forward (/root/reference/model/dim3/attention_unet.py:30-45) with attention_up_block /
     AttentionBlock (attention_unet_utils.py:6-66): nn.InstanceNorm3d default eps 1e-5 inside the gate."""
-    blk = _BLOCKS[block]
+    from functools import partial
+    blk = partial(_BLOCKS[block], training=training)      # (`norm: bn` state_dicts depend on the mode; the gates do not)
     ks = [_k3(k) for k in kernel_size]
     sc = [_k3(s) for s in scale]
 

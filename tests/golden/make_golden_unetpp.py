@@ -50,5 +50,72 @@ def main():
     print("logits", tuple(logits.shape), float(ce + dl), int(out["n_params"]), os.path.getsize(path) // 1024, "KB")
 
 
+NORM_CASES = {
+    # name: (block, norm, batch, seed)   — round 5: `norm: bn | ln` (the reference constructor's own default is 'bn', unetpp.py:9)
+    "unetpp_bn_b8": ("BasicBlock", "bn", 2, 6071),
+    "unetpp_ln_b8": ("SingleConv", "ln", 1, 6072),
+}
+
+
+def main_norms(only=()):
+    """UNet++ with nn.BatchNorm3d / the channels-first LayerNorm in every ConvNormAct: perturbed affine parameters, one training step
+    (forward + CE + Dice + backward, running-statistics update) and the eval-mode logits of the REAL reference."""
+    _, DiceLoss = mg.import_reference()
+    UNetPP = importlib.import_module("model.dim3.unetpp").UNetPlusPlus
+    from oracle.unet_ref import state_dict_checksum
+    torch.set_num_threads(8)
+    for name, (block, norm, batch, seed) in NORM_CASES.items():
+        if only and name not in only:
+            continue
+        torch.manual_seed(seed)
+        net = UNetPP(1, BASE, scale=SCALE, kernel_size=KS, num_classes=CLASSES, block=block, norm=norm)
+        gen = torch.Generator().manual_seed(seed + 1)
+        affine = {}
+        with torch.no_grad():
+            for k, p in net.named_parameters():
+                if k.endswith("norm.weight"):
+                    p.copy_(1.0 + 0.5 * torch.randn(p.shape, generator=gen))
+                    affine[k] = p.detach().clone()
+                elif k.endswith("norm.bias"):
+                    p.copy_(0.3 * torch.randn(p.shape, generator=gen))
+                    affine[k] = p.detach().clone()
+        sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        net.train()
+        x = torch.randn((batch, 1) + SHAPE, generator=gen).clamp_(-7.4, 2.2)
+        lab = mg.make_labels(CLASSES, SHAPE, batch, gen)
+        weight = torch.ones(CLASSES)
+        weight[0] = 0.5
+        logits = net(x)
+        ce = torch.nn.CrossEntropyLoss(weight=weight)(logits, lab.squeeze(1))
+        dl = DiceLoss()(logits, lab)
+        (ce + dl).backward()
+        grads = {k: p.grad for k, p in net.named_parameters()}
+        sd1 = net.state_dict()
+        net.eval()
+        with torch.no_grad():
+            logits_eval = net(x)
+        out = dict(x=x.numpy(), label=lab.numpy().astype(np.int64), weight=weight.numpy(), logits=logits.detach().numpy(),
+                   logits_eval=logits_eval.numpy(), ce=np.float64(ce.item()), dice=np.float64(dl.item()),
+                   keys=np.array(list(sd0.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd0.values()]),
+                   param_keys=np.array([k for k, _ in net.named_parameters()]),
+                   grad_norms=np.array([float(grads[k].double().norm()) for k in grads]),
+                   sd_checksum=np.float64(state_dict_checksum({k: v for k, v in sd0.items() if v.is_floating_point()})),
+                   seed=np.int64(seed))
+        for k, v in affine.items():
+            out["p:" + k] = v.numpy()
+        for k, g in grads.items():           # full gradients of the first layer (norms over the raw input included) and the head
+            if k.startswith("conv0_0.0.") or k.startswith("output."):
+                out["g:" + k] = g.numpy()
+        for k, v in sd1.items():
+            if k.startswith("conv0_0.0.") and ("running_" in k or "num_batches" in k):
+                out["r:" + k] = v.numpy()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "logits", tuple(logits.shape), float(ce + dl), len(sd0), "tensors", os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "norms":
+        main_norms(sys.argv[2:])
+    else:
+        main()

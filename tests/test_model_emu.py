@@ -62,7 +62,8 @@ def test_unbuilt_options_fail_loudly():
         get_model(_args(model="medformer", norm="bn", **{k: v for k, v in __import__("tests.medformer_checks", fromlist=["TINY"]).TINY.items()
                                                           if k not in ("norm",)}, down_scale=[[2, 2, 2]] * 4))
     with pytest.raises(NotImplementedError):
-        get_model(_args(model="unet++", norm="ln"))            # bn / ln are built for the UNet / ResUNet blocks
+        get_model(_args(model="medformer", norm="ln", **{k: v for k, v in __import__("tests.medformer_checks", fromlist=["TINY"]).TINY.items()
+                                                          if k not in ("norm",)}, down_scale=[[2, 2, 2]] * 4))   # bn / ln: the UNet-family blocks
     assert get_model(_args(block="Bottleneck", norm="ln")).state_dict()["down1.conv.1.conv1.norm.weight"].shape == (32,)
     with pytest.raises(NotImplementedError):
         get_model(_args(model="vtunet"))
@@ -204,6 +205,19 @@ def test_swin_unetr_fp32_matches_reference_golden(dev):
     # test_ops_emu.py and end to end on the GPU in test_gpu_parity.py; it would add ~90 s here)
     from tests.swin_checks import assert_fp32_parity
     print(assert_fp32_parity("swin_tiny", dev, backward=False))
+
+
+def test_unetpp_layernorm_branch_fp32_matches_reference_golden(dev):
+    """UNet++ with `norm: ln` (SingleConv blocks; the BatchNorm / BasicBlock fixture — norms over the raw input, separate for conv1
+    and the shortcut — runs on the GPU, both pin the oracle): one training step + eval logits of the real reference."""
+    from tests.unetpp_checks import assert_norm_fp32
+    print(assert_norm_fp32("unetpp_ln_b8", dev))
+
+
+def test_attention_unet_batchnorm_branch_fp32_matches_reference_golden(dev):
+    """AttentionUNet with `norm: bn` in its blocks (SingleConv, batch 2; gates keep InstanceNorm): training step + eval logits"""
+    from tests.norm_branch_checks import assert_norm_fp32
+    print(assert_norm_fp32("attunet_bn_b8", dev))
 
 
 def test_unetpp_fp32_matches_reference_golden(dev):

@@ -189,6 +189,39 @@ def test_unetpp_oracle_matches_reference_golden():
     assert rel_err(logits, g["logits"]) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["unetpp_bn_b8", "unetpp_ln_b8", "attunet_bn_b8", "attunet_ln_b8"])
+def test_norm_branches_of_unetpp_and_attention_unet_oracle_matches_reference_golden(name):
+    """UNet++ / AttentionUNet with `norm: bn | ln` (the reference constructors' own default is 'bn'): the oracle against one training
+    step (logits, losses, gradient norms, full first-layer / gate / head gradients, running statistics) and the eval-mode logits of
+    the real reference."""
+    from tests.norm_branch_checks import NORM_CASES, build_norm_case, geometry
+    net, g = build_norm_case(name)
+    model, block, _ = NORM_CASES[name]
+    fwd = unet_ref.unetpp_forward if model == "unetpp" else unet_ref.attention_unet_forward
+    pk = [str(k) for k in g["param_keys"]]
+    sd = {k: (v.detach().clone().requires_grad_(True) if k in pk else v.detach().clone()) for k, v in net.state_dict().items()}
+    x, lab, w = torch.from_numpy(g["x"]), torch.from_numpy(g["label"]), torch.from_numpy(g["weight"])
+    lo = fwd(sd, x, block=block, training=True, **geometry(name))
+    assert rel_err(lo.detach(), g["logits"]) < 2e-5
+    ce, dl = loss_ref.cross_entropy(lo, lab.squeeze(1), w), loss_ref.dice_loss(lo, lab)
+    assert abs(float(ce) - float(g["ce"])) < 1e-5 and abs(float(dl) - float(g["dice"])) < 1e-5
+    (ce + dl).backward()
+    scale = float(g["grad_norms"].max())
+    for k, b in zip(pk, g["grad_norms"]):
+        if b < 0:
+            assert sd[k].grad is None, k
+        else:
+            assert abs(float(sd[k].grad.double().norm()) - b) / max(b, 1e-6 * scale) < 2e-3, k
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel_err(sd[k[2:]].grad, g[k]) < 5e-3, k
+        if k.startswith("r:"):
+            assert rel_err(sd[k[2:]].double(), g[k].astype("float64")) < 1e-5, k
+    with torch.no_grad():
+        le = fwd(sd, x, block=block, training=False, **geometry(name))
+    assert rel_err(le, g["logits_eval"]) < 2e-5
+
+
 def test_attention_unet_oracle_matches_reference_golden():
     from tests.attunet_checks import KS, SCALE, build
     net, g = build()

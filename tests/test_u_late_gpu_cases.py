@@ -188,3 +188,22 @@ def test_medformer_linear_projections_match_reference_golden(dev):
     record_parity("golden_medformer_linear_tiny_bf16", {k: v for k, v in rb.items() if not isinstance(v, list)})
     assert rb["logits_err"] < 0.4 and rb["aux_err"] < 0.4, rb
     assert max(abs(a - b) for a, b in zip(rb["ce"] + rb["dice"], list(g["ce"]) + list(g["dice"]))) < 0.05, rb
+
+
+@pytest.mark.parametrize("name", ["unetpp_bn_b8", "unetpp_ln_b8", "attunet_bn_b8", "attunet_ln_b8"])
+def test_norm_branches_of_unetpp_and_attention_unet_match_reference_golden(dev, name):
+    """UNet++ / AttentionUNet with `norm: bn | ln` (round 5; the reference constructors' own default is 'bn'): fp32 parity with one
+    training step + the eval-mode forward of the real reference — the UNet++ BasicBlock fixture puts separate BatchNorms over the
+    1-channel network input in front of conv1 and the shortcut (input gradient of the first convolution needed); AttentionUNet's gates
+    keep nn.InstanceNorm3d.  bf16 mode: logits and losses (UNet++ fixtures; the base-8 AttentionUNet fixtures have a 4-channel gate
+    projection, below the 8-channel chunk of the bf16 kernels — the shipped yaml's base 32 gives 16)."""
+    from tests.norm_branch_checks import assert_norm_fp32, run_norm_case
+    from tests.util import record_parity
+    r = assert_norm_fp32(name, dev)
+    print(r)
+    record_parity("golden_" + name + "_fp32", r)
+    if name.startswith("unetpp"):
+        rb, g = run_norm_case(name, dev, "bf16")
+        print(rb)
+        record_parity("golden_" + name + "_bf16", rb)
+        assert rb["logits_err"] < 0.25 and abs(rb["ce"] - float(g["ce"])) < 0.05 and abs(rb["dice"] - float(g["dice"])) < 0.03, rb

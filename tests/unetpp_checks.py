@@ -57,3 +57,7 @@ def assert_fp32(dev, backward=True):
     if backward:
         assert r["grad_norm_err"] < 1e-2 and r["g_first"] < 2e-2 and r["g_head"] < 1e-3, r
     return r
+
+
+# ---- `norm: bn | ln` (round 5): tests/norm_branch_checks.py holds the shared code -------------------------------------------------
+from tests.norm_branch_checks import NORM_CASES, assert_norm_fp32, build_norm_case, run_norm_case  # noqa: E402,F401
