@@ -506,10 +506,20 @@ def main():
         return out
 
     def on_hang(r):
+        _flush_c_stdio()
         print(json.dumps(build_out(r)), flush=True)
 
     box = [time_model(args, dev, rank, world, on_hang=on_hang)]
     _finish(args, build_out(box[0]), box, rank, world, dev)
+
+
+def _flush_c_stdio():
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def _headline(args, world, ms, value, use_graph, loss_val, in_ch, ddp, grad_bucket):
@@ -605,10 +615,16 @@ def _finish(args, out, box, rank, world, dev):
         out["secondary"] = secondary(args, dev)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)
+    # RCCL prints a version banner through C stdio: buffered when stdout is a pipe / file, it would land AFTER the JSON line at
+    # process exit.  Every rank flushes its C buffers, the ranks meet, then rank 0 prints — the JSON line is the last line of stdout.
+    _flush_c_stdio()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+        _flush_c_stdio()
 
 
 if __name__ == "__main__":
