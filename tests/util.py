@@ -170,13 +170,24 @@ def record_parity(key, values):
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_dir = os.path.join(root, "gpurun_out")
-    os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r05_parity.json")
-    data = {}
-    if os.path.isfile(path):
+
+    def plain(v):
+        if isinstance(v, (str, bool)) or v is None:
+            return v
         try:
-            data = json.load(open(path))
+            return float(v)
         except Exception:
-            data = {}
-    data[key] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in values.items()}
-    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+            return str(v)
+    try:        # (a record, never a reason for a parity test to fail: read-only checkouts, odd value types)
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "r05_parity.json")
+        data = {}
+        if os.path.isfile(path):
+            try:
+                data = json.load(open(path))
+            except Exception:
+                data = {}
+        data[key] = {k: plain(v) for k, v in values.items()}
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except Exception as e:
+        print(f"record_parity({key}): not written ({type(e).__name__}: {e})")
