@@ -79,6 +79,8 @@ _SIGS = {
     "cbim_conv_r32_min_voxels": (i64, [i64]),
     "cbim_conv_r32_tile_depth": (i32, [i32]),
     "cbim_conv_rw_enable": (i32, [i32, i32]),
+    "cbim_conv_rw48_enable": (i32, [i32]),
+    "cbim_conv_rw48_takes": (i32, [_dp]),
     "cbim_conv_pw_enable": (i32, [i32]),
     "cbim_dwconv_lds_enable": (i32, [i32]),
     "cbim_conv3d_num_tiles": (i32, [_dp]),

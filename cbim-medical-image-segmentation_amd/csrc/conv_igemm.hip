@@ -1118,6 +1118,7 @@ extern "C" int cbim_conv3d_num_tiles(const cbim_conv_desc* d) {
     if (cbim_conv_rw_grid(d) > g) g = cbim_conv_rw_grid(d);
   }
   if (cbim_conv_pw_records(d) > g) g = cbim_conv_pw_records(d);   // pointwise layers: conv_pw.hip's strips
+  if (cbim_conv_rw48_takes(d) && cbim_conv_rw_grid(d) > g) g = cbim_conv_rw_grid(d);   // k_conv3_rw48
   return (int)g;
 }
 
@@ -1167,7 +1168,7 @@ static int dispatch_act(int act, bool k3, const TileCfg& c, const IgemmParams& p
   }
 }
 
-// which kernel the last cbim_conv3d_igemm call of this thread launched: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw, 3 = k_conv3_rw split-K + finish (profiling labels)
+// which kernel the last cbim_conv3d_igemm call of this thread launched: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw, 3 = k_conv3_rw split-K + finish, 4 = k_conv_pw, 5 = k_conv3_rw48 (profiling labels)
 static thread_local int g_last_conv_kernel = 0;
 extern "C" int cbim_conv3d_last_kernel(void) { return g_last_conv_kernel; }
 
@@ -1203,8 +1204,15 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   CBIM_CHECK(x && w_packed && y, CBIM_EINVAL, "null tensor");
   // mask_x without statistics: the mask tensor is the caller's materialised a = relu(IN(x)) (act'(xh) = [a > 0], xh = a
   // wherever the mask is open) — defined for ReLU only
-  CBIM_CHECK(!mask_x || mask_stats || d->act == CBIM_ACT_RELU, CBIM_EINVAL, "mask_x without mask_stats (an activated mask tensor) needs act = ReLU");
+  const bool rw48 = cbim_conv_rw48_eligible(d, x, x_stride, x2, x2_stride, cin_split, in_stats, mask_x, mask_stats);
+  CBIM_CHECK(!mask_x || mask_stats || d->act == CBIM_ACT_RELU || rw48, CBIM_EINVAL,
+             "mask_x without mask_stats (an activated mask tensor) needs act = ReLU (LeakyReLU: k_conv3_rw48 layers only)");
   g_last_conv_kernel = 0;
+  if (rw48) {   // round 6: 48-channel-granular layers (conv_rw.hip k_conv3_rw48)
+    g_last_conv_kernel = 5;
+    return cbim_conv_rw_launch(d, x, x_stride, x2, x2_stride, cin_split, w_packed, res, res_stride, mask_x, mask_stride, y, y_stride, partials,
+                               stream);
+  }
   if (cbim_conv_pw_eligible(d, x_stride, x2, res_stride, mask_stride, y_stride, res, mask_x, mask_stats)) {   // 1x1x1: conv_pw.hip (round 4)
     g_last_conv_kernel = 4;
     return cbim_conv_pw_launch(d, x, x_stride, in_stats, w_packed, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials,

@@ -23,6 +23,7 @@ struct R32Params {
   // k_conv3_rw split-K (low-resolution layers): blockIdx.z owns a slice of the Cin chunks and writes raw fp32 partial sums
   // ws[ksplit][N*Do*Ho*Wo][Cout] for k_splitk_finish (conv_igemm.hip); 1 / nullptr otherwise
   int ksplit; float* ws;
+  int cin_bytes;  // 2 Cin: k_conv3_rw zero-fills the 16-byte slots of a last chunk past it (Cin = 48: chunk 1 holds 16 channels)
 };
 }  // namespace cbim
 
@@ -44,6 +45,10 @@ int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_strid
 bool cbim_conv_rw_eligible(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
                            const float* in_stats, const void* mask_x, const float* mask_stats);
 int64_t cbim_conv_rw_grid(const cbim_conv_desc* d);
+// round 6: Cout in multiples of 48 (Cin any multiple of 8) where the 32-channel kernels do not apply — k_conv3_rw48, launched
+// through cbim_conv_rw_launch; the activated-mask dgrad also with a LeakyReLU(0.01) mask tensor
+bool cbim_conv_rw48_eligible(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride, int cin_split,
+                             const float* in_stats, const void* mask_x, const float* mask_stats);
 int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride,
                         int cin_split, const void* w_packed, const void* res, int64_t res_stride, const void* mask_x,
                         int64_t mask_stride, void* y, int64_t y_stride, float* partials, void* stream);

@@ -827,7 +827,7 @@ int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_strid
                          void* stream) {
   R32Params p;
   p.x = x; p.x_stride = x_stride; p.in_stats = in_stats; p.w = w_packed;
-  p.NC = d->Cin / 32;
+  p.NC = d->Cin / 32; p.cin_bytes = d->Cin * 2;
   p.x2 = x2; p.x2_stride = x2 ? x2_stride : x_stride; p.c_split = x2 ? cin_split / 32 : p.NC;
   p.BN = d->Cout <= 32 ? 32 : 64;
   p.res = res; p.res_stride = res_stride; p.mx = mask_x; p.mx_stride = mask_stride; p.m_stats = mask_stats;

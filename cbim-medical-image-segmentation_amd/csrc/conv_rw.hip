@@ -138,16 +138,18 @@ __device__ unsigned long long g_rw_prof[8][8];
 // MC: several 32-channel chunks of Cin (units = (tile, chunk), streamed weights, optional second input tensor)
 // SK: split-K — blockIdx.z owns the Cin chunks [NC z / ksplit, NC (z + 1) / ksplit) and writes its raw fp32 partial sums
 //     to p.ws (no residual, mask or statistics: k_splitk_finish owns the epilogue)
-template <bool MX, int HP, bool MC, bool SK = false>
-__global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
+// CBW: output channels per workgroup — 32 HP for the symmetric kernels (every wave the same share), 48 for the round-6 form
+//     (k_conv3_rw48 below: the body is instantiated twice in one kernel, HP = 2 for waves 0..3 and HP = 1 for waves 4..7)
+// LR: the dgrad mask tensor is a = lrelu(IN(x)), slope 0.01 (monai's UnetResBlock): act'(xh) = a > 0 ? 1 : 0.01 and
+//     xh = a > 0 ? a : a / 0.01
+// cb16 / hp0 / pj: the wave's role — its 16-cout block inside the workgroup's CBW channels, its first h-pair, and the index of
+//     the LDS-DMA piece it fetches of every halo plane (7: none)
+template <bool MX, int HP, bool MC, bool SK, int CBW, bool LR>
+__device__ __forceinline__ void rw_body(const R32Params& p, unsigned char* const smem, const unsigned lds_base, const int cb16, const int hp0,
+                                        const int pj) {
   static_assert(!SK || (MC && !MX), "split-K: forward-style epilogue over several Cin chunks");
-  constexpr int NT = 512, NW = 8, NTL = 8 * HP, NPAIR = 4 * HP, CB = 32 * HP;
-  W_DYN_SMEM(smem);
-#ifdef CBIM_EMU
-  const unsigned lds_base = 0;
-#else
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-#endif
+  static_assert(!LR || MX, "the leaky mask belongs to the dgrad epilogue");
+  constexpr int NT = 512, NW = 8, NTL = 8 * HP, NPAIR = 4 * HP, CB = CBW;
   const int tid = threadIdx.x, wave = w_uniform(tid >> 6), lane = tid & 63, lv = lane & 15, lq = lane >> 4;
   const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
   const int n_tiles = p.N * tiles_per_n;
@@ -161,15 +163,13 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
   const int cc_hi = SK ? (int)(((long long)(blockIdx.z + 1) * NC) / p.ksplit) : NC;
 
   // ---- wave = (16-cout block cb16, h-pairs hp0 .. hp0 + HP - 1); lane = (voxel lv of a 2x8 patch, k-group lq) ---------
-  const int cb16 = HP == 1 ? (wave & 1) : (wave & 3);
-  const int hp0 = HP == 1 ? (wave >> 1) : 2 * (wave >> 2);
   const int tw = lv & 7;
   // weights: packed image [cout block of BN][Cin chunk][tap][kg = lq >> 1][half = lq & 1][BN couts][8] (conv_igemm.hip)
   u32x4 wf[27];
   const unsigned w_tap = 4u * (unsigned)p.BN * 16u;    // bytes per tap
-  const unsigned char* const w_lane = (const unsigned char*)p.w +
-      (size_t)(HP == 2 ? oc : (p.BN == 64 ? oc >> 1 : oc)) * (size_t)NC * 27u * w_tap +
-      (unsigned)((lq * p.BN) + (HP == 1 && p.BN == 64 ? (oc & 1) * 32 : 0) + 16 * cb16 + lv) * 16;
+  const int co0 = oc * CB + 16 * cb16;                 // the wave's first output channel
+  const unsigned char* const w_lane = (const unsigned char*)p.w + (size_t)(co0 / p.BN) * (size_t)NC * 27u * w_tap +
+                                      (unsigned)((lq * p.BN) + co0 % p.BN + lv) * 16;
   // B operand (voxels): fragment of plane i at tap (kh, kw) = 16 bytes at row (i, th + kh, tw + kw), slot lq ^ swz(th + kh)
   int thp[HP];
   unsigned fb[HP][3];
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
 
   // ---- this lane's halo item: row r = r0 + (lane >> 2) of a plane, physical slot lane & 3 ------------------------------
   const unsigned x_sb = (unsigned)p.x_stride * 2u, x2_sb = (unsigned)p.x2_stride * 2u;
-  const int r0 = wave < 6 ? 16 * wave : 84;
+  const int r0 = pj < 6 ? 16 * pj : 84;
   const unsigned hrow = (unsigned)r0 + ((unsigned)lane >> 2);
   const unsigned hh = (hrow * 205u) >> 11, hw = hrow - hh * 10u;           // hrow / 10, hrow % 10 (hrow < 100)
   const unsigned slot_src = (((unsigned)lane & 3u) ^ w_swz(hh)) << 4;
@@ -220,7 +220,10 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
     h.plane_b = (unsigned)(p.Hi * p.Wi) * sb;
     h.base = (unsigned long long)t0 + (unsigned long long)tp.n * p.Di * h.plane_b - (unsigned long long)(p.Wi + 1) * sb;
     h.soff0 = (unsigned)((ih0 + 1) * p.Wi + iw0 + 1) * sb;              // + (id0 + plane) * plane_b
-    const bool ok = (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi;
+    // (a last chunk of fewer than 32 channels — Cin = 48: the slots past the tensor's channels are the next voxel's, their
+    //  weights are zero in the packed image, and zeros land in LDS instead: no 0 x NaN)
+    const bool ok = (unsigned)(ih0 + (int)hh) < (unsigned)p.Hi && (unsigned)(iw0 + (int)hw) < (unsigned)p.Wi &&
+                    (unsigned)(tp.cc * 64) + slot_src < (unsigned)p.cin_bytes;
     h.voff = ok ? (second ? lane_off2 : lane_off) : W_OOB;
     return h;
   };
@@ -283,8 +286,11 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
     if (tid < CB && oc * CB + tid < p.Cout) {
       Moments a = {0.f, 0.f, 0.f};
       const int blk = tid >> 4;                         // the 16-cout block of this channel
-      for (int g = 0; g < NW / (2 * HP); ++g) {         // the waves that hold it
-        const int wv = HP == 1 ? 2 * g + blk : 4 * g + blk;
+      // the waves that hold it (CBW = 48: blocks 0 / 1 on waves {0, 1} / {2, 3}, block 2 on waves 4..7)
+      const int wv0 = CBW == 48 ? (blk < 2 ? 2 * blk : 4) : blk, wvn = CBW == 48 ? (blk < 2 ? 2 : 4) : NW / (2 * HP);
+      const int wvs = CBW == 48 ? 1 : 2 * HP;
+      for (int g = 0; g < wvn; ++g) {
+        const int wv = wv0 + g * wvs;
         const float* rr = red + ((wv * 16) + (tid & 15)) * 3;
         if (MX) { a.mean += rr[1]; a.m2 += rr[2]; }
         else { Moments b = {rr[0], rr[1], rr[2]}; a = moments_merge(a, b); }
@@ -309,7 +315,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
   // ---- prologue: first unit's halo ------------------------------------------------------------------------------------
   {
     const Halo h = halo_of(cur);
-    if (wave < 7) {
+    if (pj < 7) {
 #pragma unroll
       for (int pl = 0; pl < 10; ++pl) dma_plane(h, pl, 0);
     }
@@ -351,7 +357,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
     unsigned char* const y_tile = (unsigned char*)p.y + orow * (long long)y_sb;
     const unsigned char* const q_tile = (MX ? (const unsigned char*)p.mx : (const unsigned char*)p.res) + orow * (long long)q_sb;
     const bool has_q = !SK && (MX || p.res != nullptr);  // workgroup-uniform
-    const unsigned cbyte = (unsigned)(oc * (4 * HP) + cidx) * 16u;
+    const unsigned cbyte = (unsigned)(oc * (CB / 8) + cidx) * 16u;
     // pair pr = (hp, pp): after the exchange this lane owns chunk cidx of voxel (plane 2 pp + (lq & 1), thp[hp], tw)
     // (the offsets below depend on the lane only: laundering the lane index keeps the compiler from hoisting them — and the
     //  64-bit addresses built on them — out of the unit loop, where they would be spilled and reloaded in every epilogue)
@@ -396,7 +402,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
         const int kh = s / 3, kw = s % 3;
-        if (s < 5 && wave < 7) {
+        if (s < 5 && pj < 7) {
           dma_plane(hn, 2 * s, obuf);
           dma_plane(hn, 2 * s + 1, obuf);
         }
@@ -489,10 +495,20 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
         if (MX) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const f2_t a = {__uint_as_float(rw[j] << 16), __uint_as_float(rw[j] & 0xffff0000u)};
+            f2_t a = {__uint_as_float(rw[j] << 16), __uint_as_float(rw[j] & 0xffff0000u)};
             f2_t g;
-            g.x = (rw[j] & 0xffffu) != 0u ? v[2 * j] : 0.f;
-            g.y = (rw[j] >> 16) != 0u ? v[2 * j + 1] : 0.f;
+            if (LR) {
+              // a = lrelu(xh): a > 0 passes the gradient, anything else (negative, -0, 0) takes the slope — torch's
+              // leaky_relu_backward tests x > 0; xh is recovered from a for the InstanceNorm-backward sum
+              const bool p0 = (int)(rw[j] << 16) > 0, p1 = (int)(rw[j] & 0xffff0000u) > 0;
+              g.x = p0 ? v[2 * j] : 0.01f * v[2 * j];
+              g.y = p1 ? v[2 * j + 1] : 0.01f * v[2 * j + 1];
+              a.x = p0 ? a.x : 100.f * a.x;
+              a.y = p1 ? a.y : 100.f * a.y;
+            } else {
+              g.x = (rw[j] & 0xffffu) != 0u ? v[2 * j] : 0.f;
+              g.y = (rw[j] >> 16) != 0u ? v[2 * j + 1] : 0.f;
+            }
             v[2 * j] = g.x;
             v[2 * j + 1] = g.y;
             const f2_t gl = g * live2;
@@ -571,6 +587,38 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
 #endif
 }
 
+template <bool MX, int HP, bool MC, bool SK = false>
+__global__ void __launch_bounds__(512, 1) k_conv3_rw(R32Params p) {
+  W_DYN_SMEM(smem);
+#ifdef CBIM_EMU
+  const unsigned lds_base = 0;
+#else
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#endif
+  const int wave = w_uniform((int)threadIdx.x >> 6);
+  rw_body<MX, HP, MC, SK, 32 * HP, false>(p, smem, lds_base, HP == 1 ? (wave & 1) : (wave & 3), HP == 1 ? (wave >> 1) : 2 * (wave >> 2), wave);
+}
+
+// Round 6 — 48 output channels per workgroup (SwinUNETR's feature_size = 48 layers: monai UnetResBlock convolutions 48 -> 48 and
+// 96 -> 48 at 128^3 / 64^3, /root/reference/model/dim3/swin_unetr.py:129-228).  Three 16-cout blocks do not divide over eight
+// equal waves, and a wave holds the 27 weight fragments of ONE block; what has to balance is the matrix pipe of each SIMD, and
+// waves w and w + 4 of a 512-thread workgroup share a SIMD (tools/ubench/simd_map.hip, profiles/r06_a_simd_map.txt).  So the tile's
+// twelve (cout block, h-pair) jobs go 2 + 1 per SIMD: waves 0..3 take two h-pairs of block 0 / 1 (the HP = 2 register image: 64
+// accumulators), waves 4..7 one h-pair of block 2 (HP = 1) — every SIMD issues 3 x 216 MFMAs per unit, none of them on padding.
+// The halo pieces go to the light waves first (pieces 0..3 on waves 4..7, 4..6 on waves 0..2).
+template <bool MX, bool LR>
+__global__ void __launch_bounds__(512, 1) k_conv3_rw48(R32Params p) {
+  W_DYN_SMEM(smem);
+#ifdef CBIM_EMU
+  const unsigned lds_base = 0;
+#else
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#endif
+  const int wave = w_uniform((int)threadIdx.x >> 6);
+  if (wave < 4) rw_body<MX, 2, true, false, 48, LR>(p, smem, lds_base, wave >> 1, 2 * (wave & 1), wave + 4);
+  else rw_body<MX, 1, true, false, 48, LR>(p, smem, lds_base, 2, wave - 4, wave - 4);
+}
+
 }  // namespace cbim
 
 using namespace cbim;
@@ -615,9 +663,43 @@ bool cbim_conv_rw_eligible(const cbim_conv_desc* d, const void* x, int64_t x_str
   return true;
 }
 
+// Round 6: 48 output channels per workgroup (k_conv3_rw48) — Cout in multiples of 48 where the 32-channel kernels do not apply
+// (Cin or Cout not a multiple of 32: SwinUNETR's 48 -> 48, 96 -> 48 and the 48 -> 96 input gradient), Cin any multiple of 8
+// (the last 32-channel chunk is zero-filled past Cin).  CBIM_CONV_RW48=0 keeps those layers on k_conv_igemm (A/B runs).
+static int g_rw48 = getenv("CBIM_CONV_RW48") ? atoi(getenv("CBIM_CONV_RW48")) : 1;
+extern "C" int cbim_conv_rw48_enable(int on) {
+  const int old = g_rw48;
+  if (on >= 0) g_rw48 = on;
+  return old;
+}
+static bool rw48_shape(const cbim_conv_desc* d) {
+  if (!g_rw_on || !g_rw48 || d->dtype != CBIM_BF16 || d->kD != 3 || d->kH != 3 || d->kW != 3) return false;
+  if (d->Cout % 48 != 0 || d->Cin % 8 != 0 || (d->Cin % 32 == 0 && d->Cout % 32 == 0)) return false;
+  if (d->Do < 8 || d->Ho < 8 || d->Wo < 8) return false;
+  if (g_rw48 == 2) return true;                                     // (forced: tests)
+  return rw_tiles(d) * (d->Cout / 48) >= 128;
+}
+bool cbim_conv_rw48_eligible(const cbim_conv_desc* d, const void* x, int64_t x_stride, const void* x2, int64_t x2_stride, int cin_split,
+                             const float* in_stats, const void* mask_x, const float* mask_stats) {
+  if (!rw48_shape(d) || in_stats) return false;
+  if (mask_x && (mask_stats || !(d->act == CBIM_ACT_RELU || d->act == CBIM_ACT_LRELU))) return false;
+  if (x2 && (cin_split <= 0 || cin_split >= d->Cin || cin_split % 32 != 0)) return false;
+  const int keep = g_rw_on;                                          // (the addressing limits of k_conv3_rw)
+  const bool ok = cbim_conv_rw_eligible(d, x, x_stride, x2, x2_stride, nullptr, nullptr, nullptr);
+  (void)keep;
+  return ok;
+}
+// the same question without the call's tensors (Python picks the materialised-activation path of a block by it)
+extern "C" int cbim_conv_rw48_takes(const cbim_conv_desc* d) {
+  if (!d || !rw48_shape(d)) return 0;
+  if (d->pD > 1 || d->pH > 1 || d->pW > 1 || d->pD < 0 || d->pH < 0 || d->pW < 0) return 0;
+  const int64_t sb = (int64_t)d->Cin * 2, img = ((int64_t)d->Di + 2) * d->Hi * d->Wi * sb;
+  return img < ((int64_t)1 << 31) - 65536 && (int64_t)10 * d->Wi + 10 < (1 << 24);
+}
+
 int64_t cbim_conv_rw_grid(const cbim_conv_desc* d) {
   const int64_t n_tiles = rw_tiles(d);
-  const int n_cb = rw_wide(d) ? d->Cout / 64 : (d->Cout + 31) / 32;
+  const int n_cb = rw48_shape(d) ? d->Cout / 48 : rw_wide(d) ? d->Cout / 64 : (d->Cout + 31) / 32;
   int64_t cap = 256 / n_cb;      // about one workgroup per CU over all Cout blocks
   if (cap < 1) cap = 1;
   int64_t g = n_tiles < cap ? n_tiles : cap;
@@ -627,6 +709,22 @@ int64_t cbim_conv_rw_grid(const cbim_conv_desc* d) {
   // HBM bandwidth (profiles/r04_f_pmc_traffic_rw.txt)
   if (n_cb > 1 && g >= 8) g &= ~(int64_t)7;
   return g;
+}
+
+template <bool MX, bool LR>
+static int rw48_launch_k(const R32Params& p, dim3 grid, hipStream_t st) {
+#ifndef CBIM_EMU
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv3_rw48<MX, LR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+#endif
+  CBIM_LAUNCH((k_conv3_rw48<MX, LR>), grid, dim3(512), (size_t)W_SMEM, st, p);
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv rw48 launch: %s", hipGetErrorString(e));
+  return CBIM_OK;
 }
 
 template <bool MX, int HP, bool MC, bool SK = false>
@@ -665,7 +763,7 @@ int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
                         int64_t mask_stride, void* y, int64_t y_stride, float* partials, void* stream) {
   R32Params p;
   p.x = x; p.x_stride = x_stride; p.in_stats = nullptr; p.w = w_packed;
-  p.NC = d->Cin / 32;
+  p.NC = (d->Cin + 31) / 32; p.cin_bytes = d->Cin * 2;
   p.x2 = x2; p.x2_stride = x2 ? x2_stride : x_stride; p.c_split = x2 ? cin_split / 32 : p.NC;
   p.BN = d->Cout <= 32 ? 32 : 64;
   p.res = res; p.res_stride = res_stride; p.mx = mask_x; p.mx_stride = mask_stride; p.m_stats = nullptr;
@@ -676,8 +774,9 @@ int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
   p.dbg = 0;
   p.ksplit = 1; p.ws = nullptr;
   p.P = cbim_conv3d_num_tiles(d);
-  const bool wide = rw_wide(d);
-  dim3 grid((unsigned)cbim_conv_rw_grid(d), (unsigned)(wide ? d->Cout / 64 : (d->Cout + 31) / 32));
+  const bool c48 = rw48_shape(d);
+  const bool wide = !c48 && rw_wide(d);
+  dim3 grid((unsigned)cbim_conv_rw_grid(d), (unsigned)(c48 ? d->Cout / 48 : wide ? d->Cout / 64 : (d->Cout + 31) / 32));
   CBIM_CHECK(!partials || p.P >= (int)grid.x, CBIM_EINVAL, "conv rw: %d partial records < grid", p.P);
   {
     // 32-bit byte offsets inside one output tile, built from 24-bit multiplies
@@ -689,6 +788,10 @@ int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
                "conv rw: output plane %dx%d with row stride %lld B exceeds the 32-bit epilogue addressing", d->Ho, d->Wo, (long long)so);
   }
   hipStream_t st = (hipStream_t)stream;
+  if (c48) {
+    if (mask_x) return d->act == CBIM_ACT_LRELU ? rw48_launch_k<true, true>(p, grid, st) : rw48_launch_k<true, false>(p, grid, st);
+    return rw48_launch_k<false, false>(p, grid, st);
+  }
   const bool mc = p.NC > 1;
   if (mask_x) {
     if (wide) return mc ? rw_launch_k<true, 2, true>(p, grid, st) : rw_launch_k<true, 2, false>(p, grid, st);
@@ -719,7 +822,7 @@ int cbim_conv_rw_split_launch(const cbim_conv_desc* d, const void* x, int64_t x_
                               int cin_split, const void* w_packed, float* ws, void* stream) {
   R32Params p;
   p.x = x; p.x_stride = x_stride; p.in_stats = nullptr; p.w = w_packed;
-  p.NC = d->Cin / 32;
+  p.NC = d->Cin / 32; p.cin_bytes = d->Cin * 2;
   p.x2 = x2; p.x2_stride = x2 ? x2_stride : x_stride; p.c_split = x2 ? cin_split / 32 : p.NC;
   p.BN = d->Cout <= 32 ? 32 : 64;
   p.res = nullptr; p.res_stride = 0; p.mx = nullptr; p.mx_stride = 0; p.m_stats = nullptr;

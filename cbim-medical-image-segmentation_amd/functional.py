@@ -506,8 +506,18 @@ class NormConvFn(_GradAwareFunction):
         if se is not None:
             assert act == 0 and stats is not None
             st, ctx.rz2 = ops.se_fold_fwd(stats.contiguous(), se.detach().float().contiguous(), IN_EPS)
-        y, so = ops.conv_fwd(x, wp, g, in_stats=st, res=res, want_stats=want_stats, eps=eps_out)
-        ctx.save_for_backward(x, st if st is not None else torch.empty(0), se if se is not None else torch.empty(0))
+        # round 6: a layer k_conv3_rw48 takes (SwinUNETR's 48-channel monai blocks) reads a = act(IN(x)) written ONCE by a
+        # streaming pass — forward, weight gradient and the dgrad's mask all use `a` as it is (pure LDS-DMA operands)
+        ctx.mat = (stats is not None and se is None and x.dtype == torch.bfloat16 and act in (ACT["relu"], ACT["lrelu"])
+                   and ops.rw48_takes(g))
+        a = None
+        if ctx.mat:
+            a = ops.norm_act_fwd(x, st, act)
+            y, so = ops.conv_fwd(a, wp, g, res=res, want_stats=want_stats, eps=eps_out)
+        else:
+            y, so = ops.conv_fwd(x, wp, g, in_stats=st, res=res, want_stats=want_stats, eps=eps_out)
+        ctx.save_for_backward(x, st if st is not None else torch.empty(0), se if se is not None else torch.empty(0),
+                              a if (a is not None and _training(ctx)) else torch.empty(0))
         ctx.geom, ctx.act, ctx.wpd, ctx.has = g, act, wpd, (stats is not None, res is not None, se is not None)
         ctx.w_param = ops.slot_of(w)
         if so is None:
@@ -518,10 +528,17 @@ class NormConvFn(_GradAwareFunction):
 
     @staticmethod
     def backward(ctx, dy, _dso):
-        x, st, se = ctx.saved_tensors
+        x, st, se, a = ctx.saved_tensors
         has_stats, has_res, has_se = ctx.has
         g, act = ctx.geom, ctx.act
         dy = ops.as_rows(dy)                # (a channel-slice view from torch.cat's backward is read in place)
+        if ctx.mat:
+            dw = ops.conv_wgrad(a, None, dy, g, out=ops.grad_slot(ctx.w_param)) if ctx.needs_input_grad[2] else None
+            dx = None
+            if ctx.needs_input_grad[0]:
+                gx, sums = ops.conv_dgrad(dy, ctx.wpd, g, mask_x=a, mask_stats=None)
+                dx = ops.norm_bwd_apply(gx, x, st, sums, act, masked=False)
+            return dx, None, dw, None, (dy if has_res else None), None, None, None
         dw = ops.conv_wgrad(x, st if has_stats else None, dy, g, out=ops.grad_slot(ctx.w_param)) if ctx.needs_input_grad[2] else None
         dx = ds = None
         if ctx.needs_input_grad[0]:

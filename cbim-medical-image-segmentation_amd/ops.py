@@ -650,6 +650,15 @@ def conv_fwd(x, w_packed, geom: ConvGeom, in_stats=None, res=None, want_stats=Fa
     return y, stats
 
 
+def rw48_takes(geom: ConvGeom, masked_dgrad: bool = True) -> bool:
+    """True when the engine runs this layer's forward (and, masked_dgrad, its input gradient with an activated mask tensor) on
+    k_conv3_rw48 (round 6: Cout in multiples of 48, input used as it is): the caller then materialises act(IN(x)) once."""
+    L = _lib.lib()
+    if not L.cbim_conv_rw48_takes(C.byref(geom.fwd)):
+        return False
+    return (not masked_dgrad) or bool(L.cbim_conv_rw48_takes(C.byref(geom.bwd)))
+
+
 def conv_dgrad(dy, w_packed_dgrad, geom: ConvGeom, mask_x=None, mask_stats=None, accumulate=None, dy2=None):
     """g = dgrad(dy) [+ accumulate] [* act'(xh(mask_x))]; with a mask also returns the two
     InstanceNorm-backward means (m1, m2) computed in the epilogue."""

@@ -233,13 +233,23 @@ int cbim_conv_r32_tile_depth(int td);
  * negative value leaves a switch as it is.  Returns the previous (on | wide << 1).  Process-wide knob for tests and tools
  * (env CBIM_CONV_RW, CBIM_CONV_RW_WIDE give the defaults); both kernels compute the same function. */
 int cbim_conv_rw_enable(int on, int wide);
+/* Round 6 — 3x3x3 layers with Cout in multiples of 48 that the 32-channel kernels do not take (Cin or Cout not a multiple of
+ * 32; Cin any multiple of 8): k_conv3_rw48 of conv_rw.hip, 48 output channels per workgroup with the tile's twelve (16-cout
+ * block, h-pair) jobs dealt 2 + 1 to the two waves of every SIMD.  Replaces aten::convolution / convolution_backward(input) of
+ * the monai UnetResBlock convolutions of SwinUNETR (/root/reference/model/dim3/swin_unetr.py:129-228, feature_size 48).
+ * cbim_conv_rw48_enable: on = 0 keeps those layers on k_conv_igemm, 1 (default; env CBIM_CONV_RW48) takes them when the launch
+ * has >= 128 workgroups, 2 always (tests); < 0 only queries; returns the previous value.
+ * cbim_conv_rw48_takes: 1 when cbim_conv3d_igemm runs `desc` on that kernel for an input used as it is (in_stats = NULL) — the
+ * caller then materialises act(IN(x)) once and may pass it as the dgrad's mask tensor with act = ReLU or LeakyReLU. */
+int cbim_conv_rw48_enable(int on);
+int cbim_conv_rw48_takes(const cbim_conv_desc* desc);
 /* bf16 1x1x1 convolutions on the row-GEMM kernel (conv_pw.hip) instead of k_conv_igemm: on = 0 | 1, < 0 only queries; returns the
  * previous value (default 1; env CBIM_CONV_PW).  The two kernels compute the same function. */
 int cbim_conv_pw_enable(int on);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
 int cbim_conv3d_tile_config(const cbim_conv_desc* desc, int out[4]);
-/* Kernel launched by this thread's last cbim_conv3d_igemm call: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw, 3 = k_conv3_rw split-K + finish, 4 = k_conv_pw (profiling labels). */
+/* Kernel launched by this thread's last cbim_conv3d_igemm call: 0 = k_conv_igemm, 1 = k_conv3_r32, 2 = k_conv3_rw, 3 = k_conv3_rw split-K + finish, 4 = k_conv_pw, 5 = k_conv3_rw48 (profiling labels). */
 int cbim_conv3d_last_kernel(void);
 /* Records per sample of the partial-sum buffer `partials` (one per persistent workgroup, or per finish part when the
  * launcher splits K). */

@@ -397,6 +397,120 @@ def check_conv_rw(dev, N=2, Cin=32, Cout=32, dhw=(9, 16, 11), wide=0, x_split=0,
         assert float((got[7][..., 1] - (gm * ar).mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
 
 
+def check_conv_rw48(dev, N=1, Cin=48, Cout=48, dhw=(8, 9, 16), act="lrelu", seed=71):
+    """k_conv3_rw48 (round 6: 48 output channels per workgroup, two h-pairs on waves 0..3 and one on waves 4..7, a zero-filled last
+    Cin chunk) against k_conv_igemm on the same calls and against torch: raw forward (+ residual, + statistics), plain dgrad, the
+    dgrad masked by the activated tensor a = act(xh) with the two InstanceNorm-backward sums — act relu or lrelu (monai's
+    UnetResBlock, /root/reference/model/dim3/swin_unetr.py:129-228).  The layer (Cin -> Cout) and its input-gradient layer
+    (Cout -> Cin) are both exercised when both qualify."""
+    from cbim_amd import _lib
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    torch.manual_seed(seed)
+    k, pad = (3, 3, 3), (1, 1, 1)
+    slope = 0.01
+    xh = torch.randn(N, Cin, *dhw) + 0.3
+    a = torch.relu(xh) if act == "relu" else F.leaky_relu(xh, slope)
+    al = to_cl(a, dtype).to(dev)
+    w = torch.randn(Cout, Cin, *k) * 0.1
+    geom = ops.ConvGeom(dtype, N, dhw, Cin, Cout, k, pad, ops.ACT[act])
+    wdev = w.to(dev)
+    wp, wpd = ops.pack_weights(wdev, geom, 0), ops.pack_weights(wdev, geom, 1)
+    resl = to_cl(torch.randn(N, Cout, *dhw) + 2.0, dtype).to(dev)
+    dyl = to_cl(torch.randn(N, Cout, *dhw), dtype).to(dev)
+    fwd48 = Cout % 48 == 0
+    bwd48 = Cin % 48 == 0          # the dgrad launch has Cout' = Cin
+    kern = []
+
+    def run(masked):
+        out = []
+        y, ys = ops.conv_fwd(al, wp, geom, res=resl, want_stats=True)
+        kern.append(L.cbim_conv3d_last_kernel())
+        y1, _ = ops.conv_fwd(al, wp, geom)
+        out += [y, ys, y1]
+        g, _ = ops.conv_dgrad(dyl, wpd, geom)
+        kern.append(L.cbim_conv3d_last_kernel())
+        out += [g]
+        if masked:
+            g2, sums = ops.conv_dgrad(dyl, wpd, geom, mask_x=al, mask_stats=None)
+            out += [g2, sums]
+        return [o.float().cpu() for o in out]
+
+    old = L.cbim_conv_rw48_enable(0)
+    try:
+        ref = run(False)                  # k_conv_igemm (it has no activated-mask epilogue for LeakyReLU: torch is the reference there)
+        L.cbim_conv_rw48_enable(2)
+        got = run(bwd48)
+    finally:
+        L.cbim_conv_rw48_enable(old)
+    assert kern[0] != 5 and kern[1] != 5, f"kernels selected with the switch off: {kern}"
+    assert kern[2] == (5 if fwd48 else kern[0]) and kern[3] == (5 if bwd48 else kern[1]), f"kernels selected: {kern}"
+    for nm, r, g_ in zip(["fwd+res", "fwd stats", "raw fwd", "dgrad"], ref, got):
+        lim = 1e-4 if nm == "fwd stats" else 1e-2       # (bf16 outputs of two different summation orders)
+        assert relerr(g_, r) < lim, f"rw48 vs igemm: {nm} {relerr(g_, r):.3e}"
+    ar = from_cl(al.cpu())
+    wr = w.bfloat16().float()
+    yr = F.conv3d(ar, wr, None, 1, pad)
+    assert relerr(from_cl(got[2]), yr) < 1e-2, "raw fwd vs torch"
+    ysum = yr + from_cl(resl.cpu())
+    assert relerr(from_cl(got[0]), ysum) < 1e-2, "fwd + residual vs torch"
+    assert relerr(got[1][..., 0], ysum.mean((2, 3, 4))) < 1e-3
+    assert relerr(got[1][..., 1], 1 / torch.sqrt(ysum.var((2, 3, 4), unbiased=False) + 1e-4)) < 2e-3
+    gr = F.conv_transpose3d(from_cl(dyl.cpu()), wr, None, 1, pad)
+    assert relerr(from_cl(got[3]), gr) < 1e-2, "dgrad vs torch"
+    if bwd48:
+        pos = ar > 0
+        gm = gr * pos if act == "relu" else torch.where(pos, gr, slope * gr)
+        xhr = ar if act == "relu" else torch.where(pos, ar, ar / slope)
+        assert relerr(from_cl(got[4]), gm) < 1e-2, "masked dgrad vs torch"
+        assert float((got[5][..., 0] - gm.mean((2, 3, 4))).abs().max()) < 5e-3 * float(gm.abs().max())
+        assert float((got[5][..., 1] - (gm * xhr).mean((2, 3, 4))).abs().max()) < 5e-3 * float((gm * xhr).abs().max())
+
+
+def check_norm_conv_mat48(dev, N=1, C=48, dhw=(8, 8, 16), seed=76):
+    """functional.NormConvFn on a layer k_conv3_rw48 takes: y = conv(lrelu(IN(z))) as monai's UnetResBlock.conv2 runs it in
+    SwinUNETR (/root/reference/model/dim3/swin_unetr.py:129-228) — the materialised path (a = lrelu(IN(z)) written once; raw
+    forward, raw weight gradient, dgrad masked by `a`) against the normalise-on-load path of k_conv_igemm (same function, one
+    bf16 rounding of `a` apart) and against torch autograd in fp32: y, its statistics, dz, dw."""
+    from cbim_amd import _lib, functional as Fn
+    L = _lib.lib()
+    torch.manual_seed(seed)
+    eps = 1e-5
+    z = torch.randn(N, C, *dhw) * 1.5 + 0.2
+    w = torch.randn(C, C, 3, 3, 3) * 0.08
+    gy = torch.randn(N, C, *dhw)
+    zl = to_cl(z, torch.bfloat16).to(dev)
+    gl = to_cl(gy, torch.bfloat16).to(dev)
+
+    def run(force):
+        old = L.cbim_conv_rw48_enable(2 if force else 0)
+        try:
+            zz = zl.clone().requires_grad_(True)
+            ww = w.detach().clone().to(dev).requires_grad_(True)
+            st = ops.instnorm_stats(zz.detach(), eps)
+            y, so = Fn.NormConvFn.apply(zz, st, ww, ops.ACT["lrelu"], None, True, None, eps)
+            kern = L.cbim_conv3d_last_kernel()
+            y.backward(gl)
+            return [t.detach().float().cpu() for t in (y, so, zz.grad, ww.grad)], kern
+        finally:
+            L.cbim_conv_rw48_enable(old)
+
+    ref, k0 = run(False)
+    got, k1 = run(True)
+    assert k0 != 5 and k1 == 5, (k0, k1)
+    for nm, r, g_ in zip(["y", "stats", "dz", "dw"], ref, got):
+        assert relerr(g_, r) < (2e-2 if nm in ("y", "dz") else 1e-2), f"materialised vs normalise-on-load: {nm} {relerr(g_, r):.3e}"
+    # torch fp32 on the bf16-rounded operands
+    zr = from_cl(zl.cpu()).requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    a = F.leaky_relu(F.instance_norm(zr, eps=eps), 0.01)
+    yr = F.conv3d(a, wr, None, 1, 1)
+    yr.backward(from_cl(gl.cpu()))
+    assert relerr(from_cl(got[0]), yr.detach()) < 2e-2, "y vs torch"
+    assert relerr(from_cl(got[2]), zr.grad) < 3e-2, f"dz vs torch {relerr(from_cl(got[2]), zr.grad):.3e}"
+    assert relerr(got[3], wr.grad) < 2e-2, f"dw vs torch {relerr(got[3], wr.grad):.3e}"
+
+
 def check_conv_rw_split(dev, N=1, Cin=64, Cout=64, dhw=(8, 8, 8), seed=63):
     """Low-resolution layers: k_conv3_rw over slices of the Cin chunks (blockIdx.z) + k_splitk_finish, against k_conv_igemm's
     split-K on the same call (the same finish pass: residual, activated mask, statistics) and against torch."""

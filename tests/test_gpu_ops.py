@@ -107,6 +107,19 @@ def test_conv_rw_buffer_addressed_halo(dev):
     oc.check_conv_rw(dev, N=1, Cin=32, Cout=32, dhw=(64, 64, 64))
 
 
+def test_conv_rw48_forty_eight_channel_workgroups(dev):
+    """k_conv3_rw48 (round 6; SwinUNETR's 48-channel monai blocks) against k_conv_igemm and torch, and functional.NormConvFn's
+    materialised path on it."""
+    oc.check_conv_rw48(dev)                                                      # 48 -> 48, LeakyReLU mask, ragged tiles
+    oc.check_conv_rw48(dev, Cin=96, Cout=48, dhw=(8, 8, 8), act="relu", seed=72)  # three chunks; its dgrad has two 48-cout workgroups
+    oc.check_conv_rw48(dev, N=2, Cin=48, Cout=96, dhw=(9, 8, 8), seed=73)        # two images, ragged depth
+    oc.check_conv_rw48(dev, Cin=8, Cout=48, dhw=(8, 8, 16), seed=74)             # the padded network input: one quarter-filled chunk
+    oc.check_norm_conv_mat48(dev)
+    oc.check_conv_rw48(dev, Cin=48, Cout=48, dhw=(64, 64, 64), seed=75)          # the default selection at a real size
+    oc.check_conv_rw48(dev, Cin=96, Cout=48, dhw=(32, 64, 64), seed=77)
+    oc.check_norm_conv_mat48(dev, dhw=(64, 64, 64), seed=78)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
