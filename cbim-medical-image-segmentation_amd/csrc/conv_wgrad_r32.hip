@@ -51,7 +51,8 @@ struct WR32Params {
   float* ws;
   int N, Di, Hi, Wi, Do, Ho, Wo;
   int tiles_d, tiles_h, tiles_w;
-  int ci_blocks, Cout_pad, Cin_pad;
+  int ci_blocks, Cout_pad, Cin_pad;   // 32-channel blocks of Cin; the gradient's own Cout, Cin (slab layout [Cout][Cin][27])
+  int cin_bytes, cout_bytes;          // 2 Cin, 2 Cout: the 16-byte slots of a last block past them are zero-filled (round 6: 48 channels)
   int dbg;   // timing ablations for tools/ (env CBIM_WR32_DBG, wrong results); 0 in production
   int diag;  // depthwise form: blockIdx.y = 32-channel group, only the diagonal (co == ci) of the 32 x 32 block is kept
 };
@@ -216,14 +217,20 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
     const unsigned row = (unsigned)r0 + ((unsigned)lane >> 2);
     h_hh[q] = (row * 205u) >> 11;                     // row / 10 (row < 100)
     h_hw[q] = row - h_hh[q] * 10u;
-    h_off[q] = wr_mul24(wr_mul24(h_hh[q], (unsigned)p.Wi) + h_hw[q], x_sb) + ((((unsigned)lane & 3u) ^ wr_swz(h_hh[q])) << 4);
+    const unsigned slot_src = (((unsigned)lane & 3u) ^ wr_swz(h_hh[q])) << 4;
+    h_off[q] = wr_mul24(wr_mul24(h_hh[q], (unsigned)p.Wi) + h_hw[q], x_sb) + slot_src;
+    // (a last block of fewer than 32 channels — Cin = 48: the slots past the tensor's channels hold the next voxel's; zeros land in
+    //  LDS instead and the gradient rows / columns they feed are not written)
+    if ((unsigned)(ib * 64) + slot_src >= (unsigned)p.cin_bytes) h_off[q] = WR_OOB;
     h_lds[q] = (unsigned)r0 * 64u;
   }
   // dy: WV = 8: piece j = wave & 3 of the planes (wave >> 2) + 2 k; WV = 4: piece j = wave of every plane
   const int dj = WV == 8 ? (wv_u & 3) : wv_u, dp0 = WV == 8 ? (wv_u >> 2) : 0, dstep = WV == 8 ? 2 : 1;
   const unsigned d_row = 16u * (unsigned)dj + ((unsigned)lane >> 2);        // row (h, w) of the 8x8 plane
   const unsigned d_h = d_row >> 3, d_w = d_row & 7u;
-  const unsigned d_off = wr_mul24(wr_mul24(d_h, (unsigned)p.Wo) + d_w, dy_sb) + ((((unsigned)lane & 3u) ^ wr_swz(d_h)) << 4);
+  const unsigned d_slot_src = (((unsigned)lane & 3u) ^ wr_swz(d_h)) << 4;
+  const unsigned d_off = (unsigned)(cb * 64) + d_slot_src < (unsigned)p.cout_bytes
+                             ? wr_mul24(wr_mul24(d_h, (unsigned)p.Wo) + d_w, dy_sb) + d_slot_src : WR_OOB;
 
   struct TilePos { int n, td, th, tw; };
   auto advance = [&](TilePos& u) {
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
 #pragma unroll
     for (int q = 0; q < HS; ++q) {
       const bool ok = (unsigned)(ih0 + (int)h_hh[q]) < (unsigned)p.Hi && (unsigned)(iw0 + (int)h_hw[q]) < (unsigned)p.Wi;
-      r.hv[q] = ok ? h_off[q] : WR_OOB;
+      r.hv[q] = ok ? h_off[q] : WR_OOB;                                     // (h_off itself may be WR_OOB: channel tail)
     }
     r.dv = (oh0 + (int)d_h < p.Ho && ow0 + (int)d_w < p.Wo) ? d_off : WR_OOB;
     return r;
@@ -453,9 +460,11 @@ __global__ void __launch_bounds__(WV * 64, 1) k_wgrad_r32(WR32Params p) {
     const size_t total = (size_t)27 * p.Cout_pad * p.Cin_pad;
     float* dst = p.ws + (size_t)lb * total;              // (a single strip: p.ws is dw itself)
     constexpr int ROW4 = 32 * 27 / 4;                    // float4 per co row of the tile
+    const int ci_n = p.Cin_pad - ib * 32 < 32 ? p.Cin_pad - ib * 32 : 32;   // channels of this block inside the gradient (a multiple of 4)
     for (int i = tid; i < 32 * ROW4; i += WR_NT) {
       const int co = i / ROW4, k = i % ROW4;
-      *(f32x4*)(dst + ((size_t)(cb * 32 + co) * p.Cin_pad + ib * 32) * 27 + 4 * k) = *(const f32x4*)(T + co * 864 + 4 * k);
+      if (cb * 32 + co < p.Cout_pad && 4 * k < ci_n * 27)
+        *(f32x4*)(dst + ((size_t)(cb * 32 + co) * p.Cin_pad + ib * 32) * 27 + 4 * k) = *(const f32x4*)(T + co * 864 + 4 * k);
     }
   }
 }
@@ -499,6 +508,8 @@ using namespace cbim;
 // CBIM_WGRAD_R32=0 keeps every weight gradient on k_conv_wgrad (A/B runs)
 static int g_wr32_on = getenv("CBIM_WGRAD_R32") ? atoi(getenv("CBIM_WGRAD_R32")) : 1;
 static int wr32_on() { return g_wr32_on; }
+// CBIM_WGRAD_R32_C16=0 keeps the layers whose channel counts are not multiples of 32 on k_conv_wgrad (A/B runs)
+static int g_wr32_c16 = getenv("CBIM_WGRAD_R32_C16") ? atoi(getenv("CBIM_WGRAD_R32_C16")) : 1;
 extern "C" int cbim_wgrad_r32_enable(int on) {
   const int old = g_wr32_on;
   if (on >= 0) g_wr32_on = on;
@@ -518,7 +529,11 @@ bool cbim_wgrad_r32_eligible(const cbim_conv_desc* d, const float* in_stats, con
                              int cout_split) {
   if (!wr32_on() || d->dtype != CBIM_BF16 || in_stats) return false;
   if (d->kD != 3 || d->kH != 3 || d->kW != 3 || d->pD != 1 || d->pH != 1 || d->pW != 1) return false;
-  if (d->Cin % 32 != 0 || d->Cout % 32 != 0) return false;
+  // round 6: channel counts in multiples of 16 run with a zero-filled last 32-channel block (SwinUNETR's 48 / 96-channel layers:
+  // 48 x 48 = four (32 x 32) pairs, nine sixteenths of them inside the gradient) — still ahead of k_conv_wgrad, which pads the same way
+  if (d->Cin % 32 != 0 || d->Cout % 32 != 0) {
+    if (!g_wr32_c16 || d->Cin % 16 != 0 || d->Cout % 16 != 0 || d->Cin < 32 || d->Cout < 32) return false;
+  }
   if (x2 && (cin_split <= 0 || cin_split >= d->Cin || cin_split % 32 != 0)) return false;
   if (dy2 && (cout_split <= 0 || cout_split >= d->Cout || cout_split % 32 != 0)) return false;
   if (d->Do != d->Di || d->Ho != d->Hi || d->Wo != d->Wi) return false;
@@ -536,7 +551,7 @@ static int wr32_strips_for(int64_t n_tiles, int64_t pairs, int64_t slab);
 int cbim_wgrad_r32_strips(const cbim_conv_desc* d) {
   int td, th, tw;
   wr32_tiles(d, td, th, tw);
-  return wr32_strips_for((int64_t)d->N * td * th * tw, (int64_t)(d->Cout / 32) * (d->Cin / 32), (int64_t)27 * d->Cout * d->Cin * 4);
+  return wr32_strips_for((int64_t)d->N * td * th * tw, (int64_t)((d->Cout + 31) / 32) * ((d->Cin + 31) / 32), (int64_t)27 * d->Cout * d->Cin * 4);
 }
 // depthwise form: one (group, group) pair per 32 channels, slabs [C][27]
 int cbim_wgrad_r32_dw_strips(const cbim_conv_desc* d) {
@@ -598,7 +613,8 @@ static int wr32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride,
   p.ws = strips == 1 ? dw : workspace;     // a single strip writes the gradient itself
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
   wr32_tiles(d, p.tiles_d, p.tiles_h, p.tiles_w);
-  p.ci_blocks = d->Cin / 32; p.Cout_pad = d->Cout; p.Cin_pad = d->Cin;
+  p.ci_blocks = (d->Cin + 31) / 32; p.Cout_pad = d->Cout; p.Cin_pad = d->Cin;
+  p.cin_bytes = d->Cin * 2; p.cout_bytes = d->Cout * 2;
   { const char* e = getenv("CBIM_WR32_DBG"); p.dbg = e ? atoi(e) : 0; }
   {
     // 32-bit byte offsets inside one halo box / one dy tile, built from 24-bit multiplies
@@ -620,7 +636,7 @@ static int wr32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride,
     attr_done = true;
   }
 #endif
-  dim3 grid((unsigned)strips, (unsigned)(diag ? d->Cout / 32 : (d->Cout / 32) * (d->Cin / 32)));
+  dim3 grid((unsigned)strips, (unsigned)(diag ? d->Cout / 32 : ((d->Cout + 31) / 32) * ((d->Cin + 31) / 32)));
 #ifdef CBIM_WR32_ABLATE
 #define WR_ABL(W, D)                                                                                                   \
   if (wr32_waves() == W && p.dbg == D) {                                                                               \

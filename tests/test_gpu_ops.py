@@ -300,6 +300,10 @@ def test_wgrad_r32_accumulators_in_registers(dev):
             oc.check_wgrad_r32(dev, N=1, Cin=96, Cout=64, dhw=(32, 40, 24), split=32, xsplit=32)
             oc.check_wgrad_r32(dev, N=1, Cin=320, Cout=320, dhw=(8, 8, 8))
             oc.check_wgrad_r32(dev, N=1, Cin=576, Cout=512, dhw=(16, 16, 16), split=256, xsplit=256)
+            # round 6: SwinUNETR's 48 / 96-channel layers (zero-filled last 32-channel block, cropped gradient rows)
+            oc.check_wgrad_r32(dev, N=1, Cin=48, Cout=48, dhw=(64, 64, 64), seed=11)
+            oc.check_wgrad_r32(dev, N=2, Cin=96, Cout=48, dhw=(17, 24, 33), seed=12)
+            oc.check_wgrad_r32(dev, N=1, Cin=48, Cout=96, dhw=(8, 8, 16), seed=13)
     finally:
         L.cbim_wgrad_r32_waves(8)
 

@@ -277,6 +277,10 @@ def test_wgrad_r32_accumulators_in_registers(dev):
             oc.check_wgrad_r32(dev, N=2, Cin=64, Cout=64, dhw=(9, 11, 17), split=32)
         oc.check_wgrad_r32(dev, N=1, Cin=96, Cout=32, dhw=(8, 8, 24), xsplit=32)
         oc.check_wgrad_r32(dev, N=1, Cin=64, Cout=32, dhw=(8, 8, 8))      # one tile = one strip: written straight into dw
+        # round 6: channel counts in multiples of 16 (SwinUNETR's 48 / 96): a zero-filled last block, cropped gradient rows
+        oc.check_wgrad_r32(dev, Cin=48, Cout=48, dhw=(8, 16, 8), seed=11)
+        oc.check_wgrad_r32(dev, N=2, Cin=96, Cout=48, dhw=(9, 8, 8), seed=12)
+        oc.check_wgrad_r32(dev, Cin=48, Cout=96, dhw=(8, 8, 16), seed=13)
     finally:
         L.cbim_wgrad_r32_waves(8)
 

@@ -59,5 +59,12 @@ for cin, cout, s in SHAPES:
         t_dr48 = timeit(lambda: ops.conv_dgrad(dy, wd, geom))
     else:
         t_d48 = t_dr48 = float("nan"); k2 = -1
+    L.cbim_wgrad_r32_enable(0)
+    t_wT = timeit(lambda: ops.conv_wgrad(x, st, dy, geom))
+    t_wR = timeit(lambda: ops.conv_wgrad(a, None, dy, geom))
+    L.cbim_wgrad_r32_enable(1)
+    t_w32 = timeit(lambda: ops.conv_wgrad(a, None, dy, geom)) if cin % 16 == 0 else float("nan")
+    kw = L.cbim_conv3d_wgrad_last_kernel()
+    print(f"   wgrad: k_conv_wgrad on load {t_wT:7.1f}  raw {t_wR:7.1f}  k_wgrad_r32 {t_w32:7.1f} us = {gf / t_w32 * 1e3:7.1f} TF/s (kernel {kw})")
     print(f"{cin:4d}->{cout:4d} @{s:3d}^3 {gf:7.1f} | {t_fT:7.1f} {t_pass:6.1f} {t_fR:7.1f} {t_f48:7.1f} {t_f48r:7.1f} | {t_dT:7.1f} {t_d48:7.1f} {t_dr48:7.1f} | "
           f"{gf / t_f48 * 1e3:9.1f} {gf / t_d48 * 1e3:9.1f}   kernels {k1} {k2}", flush=True)
