@@ -722,6 +722,23 @@ static int rw48_launch_k(const R32Params& p, dim3 grid, hipStream_t st) {
   }
 #endif
   CBIM_LAUNCH((k_conv3_rw48<MX, LR>), grid, dim3(512), (size_t)W_SMEM, st, p);
+#ifdef CBIM_RW_PROF
+  {
+    (void)hipStreamSynchronize(st);
+    unsigned long long h[8][8];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rw_prof), sizeof(h));
+    static const char* nm[7] = {"setup", "mfma", "requests", "wait_vm", "barrier", "epilogue", "flush"};
+    fprintf(stderr, "[rw48 prof] MX %d Cin %d Cout %d @%d units %llu | cycles per unit, waves 0..3 (two h-pairs) / 4..7 (one):", (int)MX,
+            p.cin_bytes / 2, p.Cout, p.Do, h[0][7]);
+    for (int i = 0; i < 7; ++i) {
+      unsigned long long a = 0, b = 0;
+      for (int w = 0; w < 4; ++w) { a += h[w][i]; b += h[w + 4][i]; }
+      const unsigned long long n = h[0][7] ? h[0][7] : 1;
+      fprintf(stderr, " %s %llu / %llu", nm[i], a / 4 / n, b / 4 / n);
+    }
+    fprintf(stderr, "\n");
+  }
+#endif
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "conv rw48 launch: %s", hipGetErrorString(e));
   return CBIM_OK;

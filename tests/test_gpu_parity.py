@@ -166,9 +166,28 @@ def test_medformer_bf16_inside_envelope(dev):
     print(r)
     # the reference itself under torch.autocast(bfloat16) on this case (same weights, CPU): max rel 0.366 (logits) /
     # 0.235 (aux), 23 % argmax flips — measured with tests/golden/make_golden_medformer.py's model
+    # absolute backstop (the relative envelope alone passes a regression that also degrades the autocast oracle)
     assert r["logits_err"] < 0.4 and r["aux_err"] < 0.4, r
     assert max(abs(a - b) for a, b in zip(r["ce"] + r["dice"], list(g["ce"]) + list(g["dice"]))) < 0.05, r
     assert r["grad_norm_err"] < 0.5, r
+    # round 6: the bar itself is COMPUTED — the oracle under CPU autocast(bf16) on the same weights is the reference's own
+    # reduced-precision run; logits, argmax flips and every gradient tensor's cosine deficit within 1.5 x of it
+    _medformer_envelope(dev, "medformer_amos_64")
+
+
+def _medformer_envelope(dev, name):
+    from functools import partial
+    from oracle.medformer_ref import medformer_forward
+    from tests.medformer_checks import AUX_WEIGHT, MF_CASES, build
+    from tests.util import bf16_envelope_vs_oracle
+    net, g = build(name, dev)
+    m = MF_CASES[name][2]
+    fwd = partial(medformer_forward, map_size=m["map_size"], num_heads=m["num_heads"], fusion_heads=m["fusion_heads"],
+                  fusion_depth=m["fusion_depth"], kernel_size=m["kernel_size"], scale=m["scale"], act=m["act"], aux_loss=m["aux_loss"])
+    env, bad = bf16_envelope_vs_oracle(dev, net, fwd, torch.from_numpy(g["x"]), torch.from_numpy(g["label"]), torch.from_numpy(g["weight"]),
+                                       tag=name + "_bf16_envelope", loss_weights=AUX_WEIGHT)
+    assert not bad, bad
+    return env
 
 
 @pytest.mark.parametrize("name", ["medformer_acdc_tiny", "medformer_lits_tiny"])
@@ -179,9 +198,10 @@ def test_medformer_wide_heads_bf16_inside_envelope(dev, name):
     from tests.medformer_checks import run_case as mf_run
     r, g = mf_run(name, dev, "bf16")
     print(r)
-    assert r["logits_err"] < 0.4 and r["aux_err"] < 0.4, r
+    assert r["logits_err"] < 0.4 and r["aux_err"] < 0.4, r          # (absolute backstop; the computed envelope follows)
     assert max(abs(a - b) for a, b in zip(r["ce"] + r["dice"], list(g["ce"]) + list(g["dice"]))) < 0.05, r
     assert r["grad_norm_err"] < 0.5, r
+    _medformer_envelope(dev, name)
 
 
 # ---- SwinUNETR -------------------------------------------------------------
@@ -196,9 +216,18 @@ def test_swin_unetr_bf16_inside_envelope(dev):
     from tests.swin_checks import run_case as sw_run
     r, g = sw_run("swin_brats_64", dev, "bf16")
     print(r)
-    assert r["logits_err"] < 0.25 and r["argmax_mismatch"] < 0.2 * r["n_vox"], r
+    assert r["logits_err"] < 0.25 and r["argmax_mismatch"] < 0.2 * r["n_vox"], r     # (absolute backstop)
     assert abs(r["ce"] - float(g["ce"])) < 0.05 and abs(r["dice"] - float(g["dice"])) < 0.02, r
     assert r["grad_norm_err"] < 0.5, r
+    # round 6: the computed envelope (oracle under CPU autocast(bf16) = the reference's own reduced-precision run); the 64^3
+    # feature-48 case runs the 48-channel convolution kernels (k_conv3_rw48, k_wgrad_r32 on 16-multiples) inside the model
+    from oracle.swin_unetr_ref import swin_unetr_forward
+    from tests.swin_checks import build as sw_build
+    from tests.util import bf16_envelope_vs_oracle
+    net, g = sw_build("swin_brats_64", dev)
+    env, bad = bf16_envelope_vs_oracle(dev, net, swin_unetr_forward, torch.from_numpy(g["x"]), torch.from_numpy(g["label"]),
+                                       torch.from_numpy(g["weight"]), tag="swin_brats_64_bf16_envelope")
+    assert not bad, bad
 
 
 # ---- sliding-window inference + evaluation Dice -------------------------------
@@ -336,7 +365,20 @@ def test_unetpp_matches_reference_golden(dev):
     from tests.unetpp_checks import assert_fp32, run
     print(assert_fp32(dev))
     r = run(dev, "bf16")
-    assert r["logits_err"] < 0.25 and r["ce_err"] < 0.05 and r["dice_err"] < 0.02, r
+    assert r["logits_err"] < 0.25 and r["ce_err"] < 0.05 and r["dice_err"] < 0.02, r      # (absolute backstop)
+    # round 6: the computed envelope against oracle/unet_ref.unetpp_forward (fp32 and under CPU autocast(bf16))
+    from functools import partial
+    from cbim_amd.model.dim3 import UNetPlusPlus
+    from oracle.unet_ref import unetpp_forward
+    from tests.unetpp_checks import KS, SCALE
+    from tests.util import bf16_envelope_vs_oracle, load_golden
+    g = load_golden("unetpp_b8_acdc")
+    torch.manual_seed(int(g["seed"]))
+    net = UNetPlusPlus(1, 8, scale=SCALE, kernel_size=KS, num_classes=4, block="BasicBlock", norm="in").to(dev)
+    env, bad = bf16_envelope_vs_oracle(dev, net, partial(unetpp_forward, scale=SCALE, kernel_size=KS, block="BasicBlock"),
+                                       torch.from_numpy(g["x"]), torch.from_numpy(g["label"]), torch.from_numpy(g["weight"]),
+                                       tag="unetpp_b8_acdc_bf16_envelope")
+    assert not bad, bad
 
 
 def test_attention_unet_matches_reference_golden(dev):
