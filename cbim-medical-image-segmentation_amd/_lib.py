@@ -35,6 +35,17 @@ class PackItem(C.Structure):
                                        "n_blocks", "dtype", "_pad")]
 
 
+class MapGemmDesc(C.Structure):
+    """cbim_map_gemm_desc of include/cbim_hip.h (the small float32 GEMM of MedFormer's semantic-map branch)."""
+    _fields_ = [("A", C.c_void_p), ("A2", C.c_void_p), ("lda", C.c_int64), ("a_batch", C.c_int64), ("a_t", C.c_int), ("a_split", C.c_int),
+                ("X", C.c_void_p), ("X2", C.c_void_p), ("ldx", C.c_int64), ("x_batch", C.c_int64), ("x_t", C.c_int), ("x_split", C.c_int),
+                ("OUT", C.c_void_p), ("OUT2", C.c_void_p), ("ldo", C.c_int64), ("o_batch", C.c_int64), ("o_t", C.c_int), ("o_split", C.c_int),
+                ("R", C.c_void_p), ("ldr", C.c_int64), ("r_batch", C.c_int64),
+                ("O", C.c_int), ("K", C.c_int), ("Nn", C.c_int), ("batch", C.c_int), ("reduce_batch", C.c_int), ("ln_mode", C.c_int),
+                ("eps", C.c_float), ("_pad", C.c_int),
+                ("Xn", C.c_void_p), ("rstd_out", C.c_void_p), ("XH", C.c_void_p), ("rstd_in", C.c_void_p)]
+
+
 # name -> (restype, argtypes)   (mirrors include/cbim_hip.h one to one)
 _SIGS = {
     "cbim_version": (i32, []),
@@ -117,6 +128,7 @@ _SIGS = {
     "cbim_bidir_attn_workspace": (sz, [i32] * 5),
     "cbim_bidir_attn_fwd": (i32, [i32, vp, i64, vp, vp, vp, vp, vp] + [i32] * 5 + [f32, vp, sz, vp]),
     "cbim_bidir_attn_bwd": (i32, [i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 5 + [f32, vp, sz, vp]),
+    "cbim_map_gemm": (i32, [C.POINTER(MapGemmDesc), vp]),
     "cbim_colsoftmax_pool_workspace": (sz, [i32] * 4),
     "cbim_colsoftmax_pool_fwd": (i32, [i32, vp, i64, vp, vp] + [i32] * 4 + [vp, sz, vp]),
     "cbim_colsoftmax_pool_bwd": (i32, [i32, vp, i64, vp, vp, vp, vp, i64] + [i32] * 4 + [vp]),

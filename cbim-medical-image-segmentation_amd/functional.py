@@ -684,6 +684,43 @@ class BidirAttnFn(torch.autograd.Function):
         return dqv, dmq, dmv, None, None
 
 
+class MapQVFn(torch.autograd.Function):
+    """norm2 + map_qv of BidirectionAttentionBlock on the semantic map (medformer_utils.py:36,66,113,127): smap float32 [B, C, M],
+    w [2 inner, C] -> (map_q, map_v) float32 [B, M, inner] — one launch forward (InstanceNorm over the positions on load), two
+    backward (weight gradient; input gradient with the InstanceNorm backward as its epilogue)."""
+
+    @staticmethod
+    def forward(ctx, smap, w, eps):
+        w = w.contiguous()
+        mq, mv, mapp, rstd = ops.map_qv_fwd(smap.contiguous(), w, eps)
+        ctx.save_for_backward(w, mapp, rstd)
+        return mq, mv
+
+    @staticmethod
+    def backward(ctx, dmq, dmv):
+        w, mapp, rstd = ctx.saved_tensors
+        ds, dw = ops.map_qv_bwd(dmq.float().contiguous(), dmv.float().contiguous(), w, mapp, rstd, need_dw=ctx.needs_input_grad[1])
+        return (ds if ctx.needs_input_grad[0] else None), dw, None
+
+
+class MapOutFn(torch.autograd.Function):
+    """map_out projection of BidirectionAttention + the block's `+ semantic_map` (medformer_utils.py:40,93,137): mo float32
+    [B, M, inner], w [C, inner], smap [B, C, M] -> [B, C, M].  One launch forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, mo, w, smap):
+        w, mo = w.contiguous(), mo.contiguous()
+        ctx.save_for_backward(w, mo)
+        return ops.map_out_fwd(mo, w, smap.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        w, mo = ctx.saved_tensors
+        g = g.float().contiguous()
+        dmo, dw = ops.map_out_bwd(g, w, mo, need_dw=ctx.needs_input_grad[1])
+        return dmo, dw, (g if ctx.needs_input_grad[2] else None)
+
+
 class MapPoolFn(torch.autograd.Function):
     """SemanticMapGeneration tail (medformer_utils.py:218-228): fw = [feat | weight logits] rows ->
     float32 [N, Cf, M]."""

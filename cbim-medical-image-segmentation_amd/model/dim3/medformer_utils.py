@@ -7,15 +7,19 @@ maps are ``[B, C, m0, m1, m2]`` float32 torch tensors with m0*m1*m2 <= 64 positi
 projections / InstanceNorm / residuals are a few KFLOP each and stay ordinary torch ops (autograd
 differentiates them); everything that touches L voxels is a kernel.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from ... import functional as Fn
-from ...ops import ACT, IN_EPS
+from ...ops import ACT, IN_EPS, MAP_MAX_POSITIONS
 from .conv_layers import BasicBlock, ConvNormAct, DepthwiseSeparableConv, FusedMBConv, MBConv, _k3
 from .trans_layers import TransformerBlock
 
 _EPS_DEFAULT = 1e-5   # nn.InstanceNorm3d default, used by norm1/norm2 and PatchMerging.norm (:112-113,:158)
+# the map branch of a block on k_map_gemm (round 6); CBIM_MAP_KERNELS=0: the torch ops of rounds 1-5 (same-box A/B runs)
+_MAP_KERNELS = os.environ.get("CBIM_MAP_KERNELS", "1") != "0"
 
 
 def pointwise(conv: nn.Conv3d, x):
@@ -60,13 +64,30 @@ class BidirectionAttention(nn.Module):
         self.map_qv = nn.Conv3d(map_dim, self.inner_dim * 2, kernel_size=1, bias=False)
         self.map_out = nn.Identity() if no_map_out else nn.Conv3d(self.inner_dim, map_dim, kernel_size=1, bias=False)
 
-    def forward(self, x, x_stats, mapp, res, want_stats):
-        """x (raw) with InstanceNorm stats (eps 1e-5) fused into the depthwise load; mapp already normalised.
+    def forward(self, x, x_stats, mapp, res, want_stats, raw_map=None):
+        """x (raw) with InstanceNorm stats (eps 1e-5) fused into the depthwise load; mapp already normalised — or (round 6)
+        raw_map given: the block's un-normalised semantic map, whose norm2, map_qv, map_out and `+ semantic_map` run on the
+        engine's small-GEMM kernel (functional.MapQVFn / MapOutFn); the second return value is then the block's NEW map.
         Returns (feat_out + res as FMap, map_out [B, *, m...])."""
         if self.linear:   # IN (the block's norm1) on load of the row GEMM, no activation
             qv = Fn.NormConvFn.apply(x, x_stats, self.feat_qv.weight, 0, None, False, None, IN_EPS)[0]
         else:
             qv = self.feat_qv(x, x_stats, 0).t
+        if raw_map is not None:
+            B, ms = raw_map.shape[0], tuple(raw_map.shape[2:])
+            sm = raw_map.flatten(2)
+            mq, mv = Fn.MapQVFn.apply(sm, self.map_qv.weight.flatten(1), _EPS_DEFAULT)
+            fo, mo = Fn.BidirAttnFn.apply(qv, mq, mv, self.heads, self.scale)
+            if self.linear:
+                y, so = Fn.NormConvFn.apply(fo, None, self.feat_out.weight, 0, res, want_stats, None, IN_EPS)
+                out = Fn.FMap(y, so if want_stats else None)
+            else:
+                out = self.feat_out(fo, None, 0, res=res, want_stats=want_stats)
+            if isinstance(self.map_out, nn.Identity):
+                new_map = mo.transpose(1, 2) + sm
+            else:
+                new_map = Fn.MapOutFn.apply(mo, self.map_out.weight.flatten(1), sm)
+            return out, new_map.reshape(B, -1, *ms)
         B, ms = mapp.shape[0], tuple(mapp.shape[2:])
         mqv = pointwise(self.map_qv, mapp).flatten(2).transpose(1, 2)   # [B, M, 2*inner]
         mq, mv = mqv[..., :self.inner_dim], mqv[..., self.inner_dim:]
@@ -103,12 +124,17 @@ class BidirectionAttentionBlock(nn.Module):
     def forward(self, f: Fn.FMap, semantic_map, want_out_stats=True):
         f = Fn.ensure_stats(f)                                   # eps 1e-4 (ConvNormAct convention)
         s5 = Fn.restat(f.stats, IN_EPS, _EPS_DEFAULT)
-        mapp = map_instance_norm(semantic_map)
         if isinstance(self.shortcut, ConvNormAct):
             res, _ = Fn.NormConvFn.apply(f.t, f.stats, self.shortcut.conv.weight, self.shortcut.act_code, None, False,
                                          None, IN_EPS)
         else:
             res = f.t
+        M = semantic_map.shape[2] * semantic_map.shape[3] * semantic_map.shape[4]
+        if _MAP_KERNELS and semantic_map.dtype == torch.float32 and M <= MAP_MAX_POSITIONS and semantic_map.device == f.t.device:
+            # round 6: norm2 -> map_qv -> (attention) -> map_out -> + semantic_map on the engine's own small-GEMM kernel
+            out, new_map = self.attn(f.t, s5, None, res, True, raw_map=semantic_map)
+            return self.feedforward(out, want_out_stats), new_map
+        mapp = map_instance_norm(semantic_map)
         out, mapp = self.attn(f.t, s5, mapp, res, True)
         out = self.feedforward(out, want_out_stats)
         return out, mapp + semantic_map

@@ -932,6 +932,80 @@ def bidir_attn_bwd(qv, mq, mv, cs, mo, dfo, dmo, heads: int, scale: float):
     return dqv, dmq, dmv
 
 
+def map_gemm(A, X, OUT, O: int, K: int, Nn: int, batch: int, *, lda, ldx, ldo, a_t=0, x_t=0, o_t=0, A2=None, a_split=0, X2=None,
+             x_split=0, OUT2=None, o_split=0, R=None, ldr=0, a_batch=0, x_batch=0, o_batch=0, r_batch=0, reduce_batch=0,
+             ln_eps=None, Xn=None, rstd_out=None, XH=None, rstd_in=None):
+    """OUT[o][n] = sum_k A[o][k] X[k][n] (+ R) in float32 on the engine's small-GEMM kernel (map_kernels.hip; operand layouts and
+    the fused InstanceNorm steps: include/cbim_hip.h cbim_map_gemm_desc) — MedFormer's semantic-map branch."""
+    ts = [t for t in (A, A2, X, X2, OUT, OUT2, R, Xn, rstd_out, XH, rstd_in) if t is not None]
+    _dev_ok(*ts)
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in ts), "cbim_amd: map_gemm takes contiguous float32 tensors"
+    d = _lib.MapGemmDesc()
+    d.A, d.A2, d.lda, d.a_batch, d.a_t, d.a_split = _p(A), _p(A2), lda, a_batch, a_t, a_split
+    d.X, d.X2, d.ldx, d.x_batch, d.x_t, d.x_split = _p(X), _p(X2), ldx, x_batch, x_t, x_split
+    d.OUT, d.OUT2, d.ldo, d.o_batch, d.o_t, d.o_split = _p(OUT), _p(OUT2), ldo, o_batch, o_t, o_split
+    d.R, d.ldr, d.r_batch = _p(R), ldr, r_batch
+    d.O, d.K, d.Nn, d.batch, d.reduce_batch, d.ln_mode = O, K, Nn, batch, reduce_batch, int(ln_eps is not None)
+    d.eps = float(ln_eps) if ln_eps is not None else 0.0
+    d.Xn, d.rstd_out, d.XH, d.rstd_in = _p(Xn), _p(rstd_out), _p(XH), _p(rstd_in)
+    check(_lib.lib().cbim_map_gemm(C.byref(d), _stream(A)), "map_gemm")
+    return OUT
+
+
+MAP_MAX_POSITIONS = 128     # columns of one k_map_gemm tile: the normalisation steps need a map row inside it
+
+
+def map_qv_fwd(smap, wqv, eps: float):
+    """norm2 + map_qv of a BidirectionAttentionBlock: smap [B, C, M], wqv [2I, C] -> (mq [B, M, I], mv [B, M, I], normalised map
+    [B, C, M], rstd [B, C])."""
+    B, Cm, M = (int(v) for v in smap.shape)
+    I = int(wqv.shape[0]) // 2
+    mq = torch.empty((B, M, I), dtype=torch.float32, device=smap.device)
+    mv = torch.empty_like(mq)
+    mapp = torch.empty_like(smap)
+    rstd = torch.empty((B, Cm), dtype=torch.float32, device=smap.device)
+    map_gemm(wqv, smap, mq, 2 * I, Cm, M, B, lda=Cm, ldx=M, ldo=I, o_t=1, OUT2=mv, o_split=I, x_batch=Cm * M, o_batch=M * I,
+             ln_eps=eps, Xn=mapp, rstd_out=rstd)
+    return mq, mv, mapp, rstd
+
+
+def map_qv_bwd(dmq, dmv, wqv, mapp, rstd, need_dw=True):
+    """-> (d smap [B, C, M] through map_qv and norm2, d wqv [2I, C])."""
+    B, Cm, M = (int(v) for v in mapp.shape)
+    I = int(wqv.shape[0]) // 2
+    dw = None
+    if need_dw:
+        dw = torch.empty((2 * I, Cm), dtype=torch.float32, device=mapp.device)
+        map_gemm(dmq, mapp, dw, 2 * I, M, Cm, B, lda=I, ldx=M, ldo=Cm, a_t=1, A2=dmv, a_split=I, x_t=1, a_batch=M * I, x_batch=Cm * M,
+                 reduce_batch=1)
+    ds = torch.empty_like(mapp)
+    map_gemm(wqv, dmq, ds, Cm, 2 * I, M, B, lda=Cm, ldx=I, ldo=M, a_t=1, x_t=1, X2=dmv, x_split=I, x_batch=M * I, o_batch=Cm * M,
+             XH=mapp, rstd_in=rstd)
+    return ds, dw
+
+
+def map_out_fwd(mo, wout, smap):
+    """map_out projection + residual: mo [B, M, I], wout [C, I], smap [B, C, M] -> [B, C, M]."""
+    B, M, I = (int(v) for v in mo.shape)
+    Cm = int(wout.shape[0])
+    out = torch.empty((B, Cm, M), dtype=torch.float32, device=mo.device)
+    map_gemm(wout, mo, out, Cm, I, M, B, lda=I, ldx=I, ldo=M, x_t=1, x_batch=M * I, o_batch=Cm * M, R=smap, ldr=M, r_batch=Cm * M)
+    return out
+
+
+def map_out_bwd(g, wout, mo, need_dw=True):
+    """g [B, C, M] -> (d mo [B, M, I], d wout [C, I])."""
+    B, M, I = (int(v) for v in mo.shape)
+    Cm = int(wout.shape[0])
+    dmo = torch.empty_like(mo)
+    map_gemm(wout, g, dmo, I, Cm, M, B, lda=I, ldx=M, ldo=I, a_t=1, o_t=1, x_batch=Cm * M, o_batch=M * I)
+    dw = None
+    if need_dw:
+        dw = torch.empty((Cm, I), dtype=torch.float32, device=mo.device)
+        map_gemm(g, mo, dw, Cm, M, I, B, lda=M, ldx=I, ldo=I, a_batch=Cm * M, x_batch=M * I, reduce_batch=1)
+    return dmo, dw
+
+
 def colsoftmax_pool_fwd(fw, Cf: int):
     """fw [N,D,H,W,Cf+M] -> map float32 [N,Cf,M], colstat float32 [N,M,2]."""
     _dev_ok(fw)

@@ -413,6 +413,32 @@ int cbim_bidir_attn_bwd(int dtype, const void* qv, int64_t qv_stride, const floa
                         const float* d_map_out, void* d_qv, float* d_mq, float* d_mv, int N, int L,
                         int heads, int dh, int M, float scale, void* workspace, size_t ws_bytes,
                         void* stream);
+/* Round 6 — the semantic-map side of BidirectionAttentionBlock (medformer_utils.py:63-97, 102-138): norm2 (nn.InstanceNorm3d over
+ * the <= 128 map positions), the map_qv / map_out 1x1x1 projections and the `map_out + semantic_map` residual, forward and
+ * backward, as launches of ONE small float32 GEMM (map_kernels.hip) instead of the aten::mm / layer_norm / add / slice launches
+ * of rounds 1-5:   OUT[o][n] = sum_k A[o][k] X[k][n]  (+ R[o][n]),  batched.
+ *   a_t = 0: A[o*lda + k];  1: A[k*lda + o], and the rows o >= a_split of A come from A2[k*lda + o - a_split] when A2 != NULL
+ *   x_t = 0: X[k*ldx + n];  1: X[n*ldx + k], and k >= x_split from X2[n*ldx + k - x_split] when X2 != NULL
+ *   o_t = 0: OUT[o*ldo + n]; 1: OUT[n*ldo + o], and o >= o_split to OUT2[n*ldo + o - o_split] when OUT2 != NULL
+ *   (the attention kernels take and return q and v as two [M, inner] tensors)
+ *   R: residual in OUT's [o][n] layout (o_t = 0).  *_batch: element strides between the images (0 = shared, e.g. a weight).
+ *   reduce_batch = 1: the products of all images are summed into one OUT (a weight gradient).
+ *   ln_mode = 1 (x_t = 0, Nn <= 128): the rows of X are normalised over n on load — (x - mean) * rsqrt(var + eps), biased
+ *     variance; the normalised rows are also written to Xn (X's layout) and their rstd to rstd_out[batch][K].
+ *   XH != NULL (o_t = 0, Nn <= 128): the epilogue applies the normalisation's backward to each row,
+ *     OUT = rstd_in[o] * (acc - mean_n(acc) - XH[o][n] * mean_n(acc * XH[o][n])) (+ R), XH in OUT's layout.
+ * Fixed summation order (bit-reproducible); launch-only on `stream`; caller-owned memory. */
+typedef struct {
+  const float* A; const float* A2; int64_t lda, a_batch; int a_t, a_split;
+  const float* X; const float* X2; int64_t ldx, x_batch; int x_t, x_split;
+  float* OUT; float* OUT2; int64_t ldo, o_batch; int o_t, o_split;
+  const float* R; int64_t ldr, r_batch;
+  int O, K, Nn, batch, reduce_batch, ln_mode;
+  float eps; int _pad;
+  float* Xn; float* rstd_out;
+  const float* XH; const float* rstd_in;
+} cbim_map_gemm_desc;
+int cbim_map_gemm(const cbim_map_gemm_desc* desc, void* stream);
 /* SemanticMapGeneration tail (medformer_utils.py:218-228) on fw rows = [feat (C) | weight logits (M)]:
  * map[n][c][j] = sum_l feat[l,c] * softmax_L(logit[:,j])[l].  colstat: float [N][M][2].
  * M <= cbim_attn_wide_max_codes(). */

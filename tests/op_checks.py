@@ -511,6 +511,41 @@ def check_norm_conv_mat48(dev, N=1, C=48, dhw=(8, 8, 16), seed=76):
     assert relerr(got[3], wr.grad) < 2e-2, f"dw vs torch {relerr(got[3], wr.grad):.3e}"
 
 
+def check_map_branch(dev, B=1, C=40, I=48, M=64, seed=81):
+    """functional.MapQVFn / MapOutFn (k_map_gemm, round 6) against the torch ops they replace in BidirectionAttentionBlock
+    (/root/reference/model/dim3/medformer_utils.py:36,40,66,93,113,127,137): InstanceNorm of the semantic map over its M positions
+    -> map_qv -> [stand-in for the attention: any differentiable function of (mq, mv)] -> map_out -> + semantic_map; outputs and
+    every gradient (map, both weights) in float32."""
+    from cbim_amd import functional as Fn
+    torch.manual_seed(seed)
+    smap = torch.randn(B, C, M) * 1.3 + 0.4
+    wqv = torch.randn(2 * I, C) * 0.2
+    wout = torch.randn(C, I) * 0.2
+    mix = torch.randn(M, M) * 0.3                  # stand-in for the attention: mo = mix @ (mq * tanh(mv))
+    g = torch.randn(B, C, M)
+
+    def tail(mq, mv, mixm):
+        return torch.matmul(mixm, mq * torch.tanh(mv))
+
+    # torch reference
+    sr, wq, wo = smap.clone().requires_grad_(True), wqv.clone().requires_grad_(True), wout.clone().requires_grad_(True)
+    mapp = F.layer_norm(sr, (M,), None, None, 1e-5)
+    mqv = torch.matmul(wq, mapp).transpose(1, 2)                       # [B, M, 2I]
+    mo = tail(mqv[..., :I], mqv[..., I:], mix)
+    out = torch.matmul(wo, mo.transpose(1, 2)) + sr
+    out.backward(g)
+    # engine
+    se, we, woe = smap.clone().to(dev).requires_grad_(True), wqv.clone().to(dev).requires_grad_(True), wout.clone().to(dev).requires_grad_(True)
+    mq, mv = Fn.MapQVFn.apply(se, we, 1e-5)
+    moe = tail(mq, mv, mix.to(dev))
+    oute = Fn.MapOutFn.apply(moe, woe, se)
+    oute.backward(g.to(dev))
+    assert relerr(mq.detach().cpu(), mqv[..., :I].detach()) < 2e-5 and relerr(mv.detach().cpu(), mqv[..., I:].detach()) < 2e-5
+    assert relerr(oute.detach().cpu(), out.detach()) < 2e-5, relerr(oute.detach().cpu(), out.detach())
+    for nm, a, b in (("d map", se.grad, sr.grad), ("d w_qv", we.grad, wq.grad), ("d w_out", woe.grad, wo.grad)):
+        assert relerr(a.cpu(), b) < 5e-5, f"{nm}: {relerr(a.cpu(), b):.3e}"
+
+
 def check_conv_rw_split(dev, N=1, Cin=64, Cout=64, dhw=(8, 8, 8), seed=63):
     """Low-resolution layers: k_conv3_rw over slices of the Cin chunks (blockIdx.z) + k_splitk_finish, against k_conv_igemm's
     split-K on the same call (the same finish pass: residual, activated mask, statistics) and against torch."""

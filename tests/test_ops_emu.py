@@ -171,6 +171,14 @@ def test_conv_rw48_forty_eight_channel_workgroups(dev):
     oc.check_norm_conv_mat48(dev)
 
 
+def test_map_branch_small_gemm(dev):
+    """k_map_gemm (round 6): norm2 / map_qv / map_out / residual of MedFormer's BidirectionAttentionBlock, forward and backward."""
+    oc.check_map_branch(dev)                                          # 64 positions (AMOS)
+    oc.check_map_branch(dev, B=2, C=72, I=40, M=27, seed=82)          # 27 positions (BCV), two images: batch-summed weight gradients
+    oc.check_map_branch(dev, B=1, C=136, I=160, M=72, seed=83)        # 72 positions (ACDC): both column halves of a lane, several tiles
+    oc.check_map_branch(dev, B=1, C=32, I=32, M=128, seed=84)         # the largest map
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
