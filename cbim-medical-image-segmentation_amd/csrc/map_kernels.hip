@@ -16,128 +16,252 @@
 // steps folded in: InstanceNorm of the rows of X on load (forward) and its backward as the epilogue of the GEMM that produces
 // d(mapp).  Forward 2 launches, backward 4 per block instead of ~35.
 //
-// Tile: 256 threads, 32 output rows x 128 columns per workgroup, K in chunks of 32 through LDS; wave w owns rows 8 w .. 8 w + 7,
-// lane l the columns l and l + 64 (16 accumulators), so a row's reduction over the columns is one wave butterfly.  fp32 FMA
-// chains in a fixed order: bit-reproducible.
+// Tile: 256 threads, 16 output rows x 64 (128) columns per workgroup, K in chunks of 64 through LDS.  Inside a chunk the four
+// waves split the K steps (16 each) and every lane keeps a 4 x 4 (4 x 8) register tile of the WHOLE workgroup tile: a k-step is two
+// 16-byte LDS reads for 16 (32) FMAs; the four partial tiles meet in LDS at the end and are added in wave order.  These GEMMs are
+// parallelism- and latency-starved (13 MFLOP over 20-120 workgroups), and the round-6 measurements say where the time goes:
+//   v1  operands staged by scalar loads and waited for, wave = 8 rows x all columns                         73 us per launch
+//   v2  register prefetch of the next chunk, 16-byte loads, 16-row tiles                                    22 us
+//   v3  the A rows by wave-uniform scalar loads (s_load_dwordx8/16 straight from global memory)             51 us  (rejected)
+//   v4  v2 + the row normalisation by quad DPP sums instead of twelve ds_bpermute per row                   18 us  (G1 58 -> 25)
+//   v5  v4 + four chunks in flight                                                                          18 us  (not the loads)
+//   v6  register tiles + K split over the waves: v2-v5 read A as a 64-lane broadcast ds_read_b128 per four FMAs — the LDS
+//       pipe, not the FMA pipe or the loads, set the 2-5 us per chunk                                        10 us  (this)
+//   v7  v6 + four chunks in flight                                                                          11 us  (rejected)
+// What is left is ~4.5 us of launch-to-first-result per kernel (an empty-ish kernel such as k_stats_finalize measures 5 us in the
+// same trace) and ~1.2 us per chunk of barrier / staging / dependent-load chain at one workgroup per CU.
+// (profiles/r06_h .. r06_n_medformer_kernels.txt; the aten::mm launches it replaces take ~11 us each.)  fp32 FMA chains in a fixed
+// order: bit-reproducible.
 #include "cbim_common.h"
 
 namespace cbim {
 
-static constexpr int MG_T = 256, MG_OT = 32, MG_NT = 128, MG_KC = 32, MG_PA = 36, MG_PX = 129;
+static constexpr int MG_T = 256, MG_OT = 16, MG_KC = 64, MG_PA = 20;
 
+// butterfly partner inside a quad / a row of 16 lanes by DPP (no LDS round trip; __shfl_xor is a ds_bpermute: ~100 cycles each —
+// twelve dependent ones per map row made the normalisation 10 us per chunk), across rows by ds_bpermute
+template <int MSK>
+__device__ __forceinline__ float mg_bfly(float v) {
+#ifdef CBIM_EMU
+  return __shfl_xor(v, MSK, 64);
+#else
+  if (MSK >= 16) return __shfl_xor(v, MSK, 64);
+  constexpr int ctrl = MSK == 1 ? 0xB1 : MSK == 2 ? 0x4E : MSK == 4 ? 0x141 : 0x140;   // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false));
+#endif
+}
 __device__ __forceinline__ float mg_wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v += mg_bfly<1>(v); v += mg_bfly<2>(v); v += mg_bfly<4>(v); v += mg_bfly<8>(v); v += mg_bfly<16>(v); v += mg_bfly<32>(v);
+  return v;
+}
+__device__ __forceinline__ float mg_quad_sum(float v) {
+  v += mg_bfly<1>(v); v += mg_bfly<2>(v);
   return v;
 }
 
-__global__ void __launch_bounds__(MG_T) k_map_gemm(cbim_map_gemm_desc d) {
-  __shared__ float At[MG_KC * MG_PA];      // [k][o]
-  __shared__ float Xs[MG_KC * MG_PX];      // [k][n]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int o0 = blockIdx.x * MG_OT, n0 = blockIdx.y * MG_NT;
+// the integers of cbim_map_gemm_desc (the pointers travel as __restrict__ kernel arguments)
+struct MgDims {
+  int64_t lda, a_batch, ldx, x_batch, ldo, o_batch, ldr, r_batch;
+  int a_t, a_split, x_t, x_split, o_t, o_split;
+  int O, K, Nn, batch, reduce_batch, ln_mode;
+  float eps;
+};
+
+// NC: 64-column blocks per tile (1: n-tile 64, 2: n-tile 128); VEC: every operand row is a whole number of aligned 16-byte groups
+template <int NC, bool VEC>
+__global__ void __launch_bounds__(MG_T) k_map_gemm(const float* __restrict__ gA, const float* __restrict__ gA2, const float* __restrict__ gX,
+                                                   const float* __restrict__ gX2, float* __restrict__ gOUT, float* __restrict__ gOUT2,
+                                                   const float* __restrict__ gR, float* __restrict__ gXn, float* __restrict__ g_rstd_out,
+                                                   const float* __restrict__ gXH, const float* __restrict__ g_rstd_in, MgDims d) {
+  constexpr int NT = 64 * NC, XR = 16 * NC, PX = NT + 4;   // columns per tile; X values per thread and chunk; pitch of Xs
+  __shared__ __attribute__((aligned(16))) float At[MG_KC * MG_PA];   // [k][o]
+  __shared__ __attribute__((aligned(16))) float Xs[MG_KC * PX];      // [k][n]; at the end: the waves' partial tiles [4][16][NT]
+  static_assert(4 * MG_OT * NT <= MG_KC * PX, "partial tiles fit the X tile");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ty = lane >> 4, tx = lane & 15;            // register tile: rows 4 ty .. + 3, columns 4 tx .. + 3 (+ 64 h)
+  const int o0 = blockIdx.x * MG_OT, n0 = blockIdx.y * NT;
   const int b0 = d.reduce_batch ? 0 : (int)blockIdx.z, b1 = d.reduce_batch ? d.batch : b0 + 1;
-  float acc[8][2];
+  f32x4 acc[4][NC];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j][0] = acc[j][1] = 0.f;
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int h = 0; h < NC; ++h) acc[j][h] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float inv_n = 1.f / (float)d.Nn;
-  for (int b = b0; b < b1; ++b) {
-    const float* const A = d.A + (int64_t)b * d.a_batch;
-    const float* const A2 = d.A2 ? d.A2 + (int64_t)b * d.a_batch : nullptr;
-    const float* const X = d.X + (int64_t)b * d.x_batch;
-    const float* const X2 = d.X2 ? d.X2 + (int64_t)b * d.x_batch : nullptr;
-    for (int k0 = 0; k0 < d.K; k0 += MG_KC) {
+  const int nchunk = (d.K + MG_KC - 1) / MG_KC, nunits = (b1 - b0) * nchunk;
+  float ra[4], rx[XR];
+  // ---- the operand values of unit u = (image, K chunk) this thread stages ------------------------------------------------------
+  // A: 16 o x 64 k = 256 groups of 4 (along k for a_t = 0, along o for a_t = 1: consecutive addresses either way)
+  // X: 64 k x NT n = XR / 4 groups of 4 per thread — along n for x_t = 0; along k for x_t = 1, where the lanes of a wave take 64
+  //    consecutive n so that their LDS stores are conflict free
+  auto fetch = [&](int u) {
+    const int b = b0 + u / nchunk, k0 = (u % nchunk) * MG_KC;
+    const float* const X = gX + (int64_t)b * d.x_batch;
+    const float* const X2 = gX2 ? gX2 + (int64_t)b * d.x_batch : nullptr;
+    {
+      const float* const A = gA + (int64_t)b * d.a_batch;
+      const float* const A2 = gA2 ? gA2 + (int64_t)b * d.a_batch : nullptr;
+      int o, k;
+      if (d.a_t) { k = tid >> 2; o = (tid & 3) * 4; } else { o = tid >> 4; k = (tid & 15) * 4; }
+      const int go = o0 + o, gk = k0 + k;
+      const float* src;
+      if (!d.a_t) src = A + (int64_t)go * d.lda + gk;
+      else if (A2 && go >= d.a_split) src = A2 + (int64_t)gk * d.lda + go - d.a_split;   // (splits are multiples of 4: whole groups)
+      else src = A + (int64_t)gk * d.lda + go;
+      const int lim = d.a_t ? d.O - go : d.K - gk;          // valid elements of the group
+      const bool row_ok = d.a_t ? gk < d.K : go < d.O;
+      if (VEC) {
+        const f32x4 v = (row_ok && lim > 0) ? *(const f32x4*)src : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = (row_ok && i < lim) ? src[i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XR / 4; ++i) {
+      const int e = tid + MG_T * i;
+      int k, n;
+      if (d.x_t) { n = e % NT; k = (e / NT) * 4; } else { k = e / (NT / 4); n = (e % (NT / 4)) * 4; }
+      const int gk = k0 + k, gn = n0 + n;
+      const float* src;
+      if (!d.x_t) src = X + (int64_t)gk * d.ldx + gn;
+      else if (X2 && gk >= d.x_split) src = X2 + (int64_t)gn * d.ldx + gk - d.x_split;
+      else src = X + (int64_t)gn * d.ldx + gk;
+      const int lim = d.x_t ? d.K - gk : d.Nn - gn;
+      const bool row_ok = d.x_t ? gn < d.Nn : gk < d.K;
+      if (VEC) {
+        const f32x4 v = (row_ok && lim > 0) ? *(const f32x4*)src : f32x4{0.f, 0.f, 0.f, 0.f};
+        rx[4 * i] = v.x; rx[4 * i + 1] = v.y; rx[4 * i + 2] = v.z; rx[4 * i + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rx[4 * i + j] = (row_ok && j < lim) ? src[j] : 0.f;
+      }
+    }
+  };
+  auto stage = [&]() {
+    {
+      int o, k;
+      if (d.a_t) { k = tid >> 2; o = (tid & 3) * 4; *(f32x4*)(At + k * MG_PA + o) = f32x4{ra[0], ra[1], ra[2], ra[3]}; }
+      else {
+        o = tid >> 4; k = (tid & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) At[(k + i) * MG_PA + o] = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XR / 4; ++i) {
+      const int e = tid + MG_T * i;
+      if (d.x_t) {
+        const int n = e % NT, k = (e / NT) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Xs[(k + j) * PX + n] = rx[4 * i + j];
+      } else {
+        const int k = e / (NT / 4), n = (e % (NT / 4)) * 4;
+        *(f32x4*)(Xs + k * PX + n) = f32x4{rx[4 * i], rx[4 * i + 1], rx[4 * i + 2], rx[4 * i + 3]};
+      }
+    }
+  };
+  if (nunits > 0) fetch(0);
+  for (int u = 0; u < nunits; ++u) {
+    const int b = b0 + u / nchunk, k0 = (u % nchunk) * MG_KC;
+    __syncthreads();                                   // the previous unit's products are done with the tiles
+    stage();
+    __syncthreads();
+    if (d.ln_mode) {
+      // InstanceNorm of the rows over the n columns (all of them are in the tile: Nn <= 128), biased variance from centred
+      // values; the first workgroup column keeps the normalised rows and their rstd for the backward pass.  A row = one quad:
+      // thread t owns the columns (t & 3) + 4 i of row t >> 2 (conflict-free LDS walks), two quad butterflies per pass
+      constexpr int CPT = NT / 4;
+      const int k = tid >> 2, gk = k0 + k, c0 = tid & 3;
+      float v[CPT];
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        v[i] = c0 + 4 * i < d.Nn ? Xs[k * PX + c0 + 4 * i] : 0.f;
+        sum += v[i];
+      }
+      const float mean = mg_quad_sum(sum) * inv_n;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        v[i] = c0 + 4 * i < d.Nn ? v[i] - mean : 0.f;
+        sq += v[i] * v[i];
+      }
+      const float rstd = 1.f / sqrtf(mg_quad_sum(sq) * inv_n + d.eps);
+      const bool keep = blockIdx.x == 0 && gk < d.K;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        Xs[k * PX + c0 + 4 * i] = v[i] * rstd;
+        if (keep && c0 + 4 * i < d.Nn) gXn[(int64_t)b * d.x_batch + (int64_t)gk * d.ldx + c0 + 4 * i] = v[i] * rstd;
+      }
+      if (keep && c0 == 0) g_rstd_out[(int64_t)b * d.K + gk] = rstd;
       __syncthreads();
-      // ---- A tile: At[k][o] -----------------------------------------------------------------------------------------------
+    }
+    if (u + 1 < nunits) fetch(u + 1);                  // in flight while this unit is multiplied out
+    // ---- this wave's 16 k-steps of the chunk: two (NC + 1) 16-byte reads, 16 NC FMAs each ----------------------------------------
 #pragma unroll
-      for (int e = tid; e < MG_OT * MG_KC; e += MG_T) {
-        int o, k;
-        if (d.a_t) { k = e >> 5; o = e & 31; } else { o = e >> 5; k = e & 31; }
-        float v = 0.f;
-        const int go = o0 + o, gk = k0 + k;
-        if (go < d.O && gk < d.K) {
-          if (!d.a_t) v = A[(int64_t)go * d.lda + gk];
-          else if (A2 && go >= d.a_split) v = A2[(int64_t)gk * d.lda + go - d.a_split];
-          else v = A[(int64_t)gk * d.lda + go];
-        }
-        At[k * MG_PA + o] = v;
-      }
-      // ---- X tile: Xs[k][n] -----------------------------------------------------------------------------------------------
-#pragma unroll 4
-      for (int e = tid; e < MG_KC * MG_NT; e += MG_T) {
-        int k, n;
-        if (d.x_t) { n = e >> 5; k = e & 31; } else { k = e >> 7; n = e & 127; }
-        float v = 0.f;
-        const int gk = k0 + k, gn = n0 + n;
-        if (gk < d.K && gn < d.Nn) {
-          if (!d.x_t) v = X[(int64_t)gk * d.ldx + gn];
-          else if (X2 && gk >= d.x_split) v = X2[(int64_t)gn * d.ldx + gk - d.x_split];
-          else v = X[(int64_t)gn * d.ldx + gk];
-        }
-        Xs[k * MG_PX + n] = v;
-      }
-      __syncthreads();
-      if (d.ln_mode) {
-        // InstanceNorm of the rows over the n columns (all of them are in the tile: Nn <= 128), biased variance from centred
-        // values; the first workgroup column keeps the normalised rows and their rstd for the backward pass
+    for (int i = 0; i < MG_KC / 4; ++i) {
+      const int k = (MG_KC / 4) * wave + i;
+      const f32x4 a4 = *(const f32x4*)(At + k * MG_PA + 4 * ty);
+      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = 8 * wave + j, gk = k0 + k;
-          const bool in0 = lane < d.Nn, in1 = lane + 64 < d.Nn;
-          const float v0 = Xs[k * MG_PX + lane], v1 = Xs[k * MG_PX + lane + 64];
-          const float mean = mg_wave_sum((in0 ? v0 : 0.f) + (in1 ? v1 : 0.f)) * inv_n;
-          const float c0 = in0 ? v0 - mean : 0.f, c1 = in1 ? v1 - mean : 0.f;
-          const float var = mg_wave_sum(c0 * c0 + c1 * c1) * inv_n;
-          const float rstd = 1.f / sqrtf(var + d.eps);
-          Xs[k * MG_PX + lane] = c0 * rstd;
-          Xs[k * MG_PX + lane + 64] = c1 * rstd;
-          if (blockIdx.x == 0 && gk < d.K) {
-            float* xn = d.Xn + (int64_t)b * d.x_batch + (int64_t)gk * d.ldx;
-            if (in0) xn[lane] = c0 * rstd;
-            if (in1) xn[lane + 64] = c1 * rstd;
-            if (lane == 0) d.rstd_out[(int64_t)b * d.K + gk] = rstd;
-          }
-        }
-        __syncthreads();
-      }
-      // ---- 32 k-steps: two broadcast float4 of A, two floats of X, 16 FMAs --------------------------------------------------
-#pragma unroll 8
-      for (int k = 0; k < MG_KC; ++k) {
-        const f32x4 a0 = *(const f32x4*)(At + k * MG_PA + 8 * wave), a1 = *(const f32x4*)(At + k * MG_PA + 8 * wave + 4);
-        const float x0 = Xs[k * MG_PX + lane], x1 = Xs[k * MG_PX + lane + 64];
-        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      for (int h = 0; h < NC; ++h) {
+        const f32x4 x4 = *(const f32x4*)(Xs + k * PX + 4 * tx + 64 * h);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          acc[j][0] = fmaf(a[j], x0, acc[j][0]);
-          acc[j][1] = fmaf(a[j], x1, acc[j][1]);
+        for (int j = 0; j < 4; ++j) {
+          acc[j][h].x = fmaf(a[j], x4.x, acc[j][h].x);
+          acc[j][h].y = fmaf(a[j], x4.y, acc[j][h].y);
+          acc[j][h].z = fmaf(a[j], x4.z, acc[j][h].z);
+          acc[j][h].w = fmaf(a[j], x4.w, acc[j][h].w);
         }
       }
     }
   }
-  // ---- epilogue ----------------------------------------------------------------------------------------------------------------
+  // ---- the four waves' partial tiles meet in LDS: P[wave][row][col] ---------------------------------------------------------------
+  __syncthreads();
+  float* const P = Xs;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int h = 0; h < NC; ++h) *(f32x4*)(P + (wave * MG_OT + 4 * ty + j) * NT + 4 * tx + 64 * h) = acc[j][h];
+  __syncthreads();
+  // ---- epilogue: wave w finishes rows 4 w .. 4 w + 3, lane l the columns l (+ 64) -------------------------------------------------
   const int bo = d.reduce_batch ? 0 : (int)blockIdx.z;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int go = o0 + 8 * wave + j;
+  for (int j = 0; j < 4; ++j) {
+    const int row = 4 * wave + j, go = o0 + row;
     if (go >= d.O) continue;                         // (wave-uniform)
+    float v[NC];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int gn = n0 + lane + 64 * h;
-      const bool in = gn < d.Nn;
-      float v = acc[j][h];
-      if (d.XH) {
-        // InstanceNorm backward over the row: rstd (g - mean(g) - xh mean(g xh)); both halves of the row are in this lane pair
-        const float xh0 = lane < d.Nn ? d.XH[(int64_t)bo * d.o_batch + (int64_t)go * d.ldo + lane] : 0.f;
-        const float xh1 = lane + 64 < d.Nn ? d.XH[(int64_t)bo * d.o_batch + (int64_t)go * d.ldo + lane + 64] : 0.f;
-        const float g0 = lane < d.Nn ? acc[j][0] : 0.f, g1 = lane + 64 < d.Nn ? acc[j][1] : 0.f;
-        const float m1 = mg_wave_sum(g0 + g1) * inv_n, m2 = mg_wave_sum(g0 * xh0 + g1 * xh1) * inv_n;
-        v = d.rstd_in[(int64_t)bo * d.O + go] * (v - m1 - (h ? xh1 : xh0) * m2);
+    for (int h = 0; h < NC; ++h) {
+      const float* q = P + row * NT + lane + 64 * h;
+      v[h] = ((q[0] + q[MG_OT * NT]) + q[2 * MG_OT * NT]) + q[3 * MG_OT * NT];     // wave order
+    }
+    if (gXH) {
+      // InstanceNorm backward over the row: rstd (g - mean(g) - xh mean(g xh)); the whole row lives in this wave
+      float xh[NC];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int h = 0; h < NC; ++h) {
+        const bool in = lane + 64 * h < d.Nn;
+        xh[h] = in ? gXH[(int64_t)bo * d.o_batch + (int64_t)go * d.ldo + lane + 64 * h] : 0.f;
+        s1 += in ? v[h] : 0.f;
+        s2 += in ? v[h] * xh[h] : 0.f;
       }
-      if (!in) continue;
-      if (d.R) v += d.R[(int64_t)bo * d.r_batch + (int64_t)go * d.ldr + gn];
-      if (!d.o_t) d.OUT[(int64_t)bo * d.o_batch + (int64_t)go * d.ldo + gn] = v;
-      else if (d.OUT2 && go >= d.o_split) d.OUT2[(int64_t)bo * d.o_batch + (int64_t)gn * d.ldo + go - d.o_split] = v;
-      else d.OUT[(int64_t)bo * d.o_batch + (int64_t)gn * d.ldo + go] = v;
+      const float m1 = mg_wave_sum(s1) * inv_n, m2 = mg_wave_sum(s2) * inv_n;
+      const float rs = g_rstd_in[(int64_t)bo * d.O + go];
+#pragma unroll
+      for (int h = 0; h < NC; ++h) v[h] = rs * (v[h] - m1 - xh[h] * m2);
+    }
+#pragma unroll
+    for (int h = 0; h < NC; ++h) {
+      const int gn = n0 + lane + 64 * h;
+      if (gn >= d.Nn) continue;
+      float r = v[h];
+      if (gR) r += gR[(int64_t)bo * d.r_batch + (int64_t)go * d.ldr + gn];
+      if (!d.o_t) gOUT[(int64_t)bo * d.o_batch + (int64_t)go * d.ldo + gn] = r;
+      else if (gOUT2 && go >= d.o_split) gOUT2[(int64_t)bo * d.o_batch + (int64_t)gn * d.ldo + go - d.o_split] = r;
+      else gOUT[(int64_t)bo * d.o_batch + (int64_t)gn * d.ldo + go] = r;
     }
   }
 }
@@ -146,20 +270,48 @@ __global__ void __launch_bounds__(MG_T) k_map_gemm(cbim_map_gemm_desc d) {
 
 using namespace cbim;
 
+static bool mg_al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <int NC, bool VEC>
+static void mg_launch(const cbim_map_gemm_desc* d, const MgDims& m, dim3 grid, hipStream_t st) {
+  CBIM_LAUNCH((k_map_gemm<NC, VEC>), grid, dim3(MG_T), 0, st, d->A, d->A2, d->X, d->X2, d->OUT, d->OUT2, d->R, d->Xn, d->rstd_out, d->XH,
+              d->rstd_in, m);
+}
+
 extern "C" int cbim_map_gemm(const cbim_map_gemm_desc* d, void* stream) {
   CBIM_CHECK(d && d->A && d->X && d->OUT, CBIM_EINVAL, "map gemm: null operand");
   CBIM_CHECK(d->O > 0 && d->K > 0 && d->Nn > 0 && d->batch > 0, CBIM_EINVAL, "map gemm: empty problem %d x %d x %d, batch %d", d->O, d->K,
              d->Nn, d->batch);
-  CBIM_CHECK(!d->ln_mode || (!d->x_t && d->Nn <= MG_NT && d->Xn && d->rstd_out && !d->reduce_batch), CBIM_EUNSUPPORTED,
-             "map gemm: normalise-on-load needs X as [k][n] rows of at most %d columns", MG_NT);
-  CBIM_CHECK(!d->XH || (!d->o_t && d->Nn <= MG_NT && d->rstd_in && !d->reduce_batch), CBIM_EUNSUPPORTED,
-             "map gemm: the InstanceNorm-backward epilogue needs OUT as [o][n] rows of at most %d columns", MG_NT);
+  CBIM_CHECK(!d->ln_mode || (!d->x_t && d->Nn <= 128 && d->Xn && d->rstd_out && !d->reduce_batch), CBIM_EUNSUPPORTED,
+             "map gemm: normalise-on-load needs X as [k][n] rows of at most 128 columns");
+  CBIM_CHECK(!d->XH || (!d->o_t && d->Nn <= 128 && d->rstd_in && !d->reduce_batch), CBIM_EUNSUPPORTED,
+             "map gemm: the InstanceNorm-backward epilogue needs OUT as [o][n] rows of at most 128 columns");
   CBIM_CHECK(!d->R || !d->o_t, CBIM_EUNSUPPORTED, "map gemm: a residual needs OUT as [o][n]");
   CBIM_CHECK(!d->A2 || d->a_t, CBIM_EUNSUPPORTED, "map gemm: a second A tensor needs A as [k][o]");
   CBIM_CHECK(!d->X2 || d->x_t, CBIM_EUNSUPPORTED, "map gemm: a second X tensor needs X as [n][k]");
   CBIM_CHECK(!d->OUT2 || d->o_t, CBIM_EUNSUPPORTED, "map gemm: a second OUT tensor needs OUT as [n][o]");
-  dim3 grid((unsigned)((d->O + MG_OT - 1) / MG_OT), (unsigned)((d->Nn + MG_NT - 1) / MG_NT), (unsigned)(d->reduce_batch ? 1 : d->batch));
-  CBIM_LAUNCH(k_map_gemm, grid, dim3(MG_T), 0, (hipStream_t)stream, *d);
+  CBIM_CHECK((!d->A2 || d->a_split % 4 == 0) && (!d->X2 || d->x_split % 4 == 0), CBIM_EUNSUPPORTED,
+             "map gemm: operand splits (%d, %d) must be multiples of 4", d->a_split, d->x_split);
+  MgDims m;
+  m.lda = d->lda; m.a_batch = d->a_batch; m.ldx = d->ldx; m.x_batch = d->x_batch; m.ldo = d->ldo; m.o_batch = d->o_batch;
+  m.ldr = d->ldr; m.r_batch = d->r_batch; m.a_t = d->a_t; m.a_split = d->a_split; m.x_t = d->x_t; m.x_split = d->x_split;
+  m.o_t = d->o_t; m.o_split = d->o_split; m.O = d->O; m.K = d->K; m.Nn = d->Nn; m.batch = d->batch; m.reduce_batch = d->reduce_batch;
+  m.ln_mode = d->ln_mode; m.eps = d->eps;
+  // 64-column tiles when the rows fit (or the normalisation steps do not need a whole row in the tile: more workgroups);
+  // 128 otherwise
+  const bool whole_row = d->ln_mode || d->XH;
+  const int nc = (d->Nn <= 64 || !whole_row) ? 1 : 2;
+  const int NT = 64 * nc;
+  // 16-byte loads: every group of 4 an operand row is read in is whole and aligned
+  const bool a_vec = d->lda % 4 == 0 && d->a_batch % 4 == 0 && mg_al16(d->A) && (!d->A2 || mg_al16(d->A2)) &&
+                     (d->a_t ? d->O % 4 == 0 : d->K % 4 == 0);
+  const bool x_vec = d->ldx % 4 == 0 && d->x_batch % 4 == 0 && mg_al16(d->X) && (!d->X2 || mg_al16(d->X2)) &&
+                     (d->x_t ? d->K % 4 == 0 : d->Nn % 4 == 0);
+  const bool vec = a_vec && x_vec;
+  dim3 grid((unsigned)((d->O + MG_OT - 1) / MG_OT), (unsigned)((d->Nn + NT - 1) / NT), (unsigned)(d->reduce_batch ? 1 : d->batch));
+  hipStream_t st = (hipStream_t)stream;
+  if (nc == 1) { if (vec) mg_launch<1, true>(d, m, grid, st); else mg_launch<1, false>(d, m, grid, st); }
+  else { if (vec) mg_launch<2, true>(d, m, grid, st); else mg_launch<2, false>(d, m, grid, st); }
   hipError_t e = CBIM_LAST_LAUNCH();
   CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "map gemm launch: %s", hipGetErrorString(e));
   return CBIM_OK;
