@@ -427,6 +427,56 @@ def _release(dev):
     torch.cuda.empty_cache()
 
 
+def kernel_roofline(eager_step, rank, dtype, reps=3):
+    """Per-kernel matrix-core roofline of one eager step: every launch of the convolution kernel families timed with HIP events
+    on the launch stream (ops.PROFILE), algorithmic FLOPs / time.  Every rank must call it (the eager steps hold the gradient
+    collectives); rank 0 gets (table, per) — the other ranks (None, None)."""
+    from cbim_amd import ops
+    per = {}
+    for _ in range(reps):
+        ops.PROFILE = [] if rank == 0 else None
+        eager_step()
+        torch.cuda.synchronize()
+        for name, flops, e0, e1, shape, nbytes in (ops.PROFILE or ()):
+            d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
+            d[0] += flops
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+            d[3] += nbytes
+        ops.PROFILE = None
+    if rank != 0 or not per:
+        return None, None
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    table = {k: {"launches_per_step": v[2] // reps, "avg_launch_ms": v[1] / v[2] * 1e3,
+                 "alg_tflop_per_step": v[0] / reps / 1e12, "achieved_tflops": v[0] / v[1] / 1e12,
+                 "frac_of_peak": v[0] / v[1] / 1e12 / peak, "alg_bytes_per_launch": v[3] / v[2]} for k, v in per.items()}
+    return table, per
+
+
+DOMINANT_FAMILIES = ("k_conv_igemm", "k_conv3_r32", "k_conv3_rw", "k_wgrad_r32", "k_conv_wgrad")
+
+
+def _recorded_traffic(model, size):
+    """(per-kernel rows, per-step bytes, file name) of the committed rocprofv3 PMC passes for `model` (rocprofv3 cannot run
+    inside this process); empty when no recorded pass exists"""
+    names = {"resunet": ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_j_traffic.json",
+                         "r01_c_traffic.json"),
+             "medformer": ("r06_traffic_medformer.json", "r05_traffic_medformer.json", "r04_traffic_medformer.json"),
+             "swin_unetr": ("r06_traffic_swin_unetr.json", "r05_traffic_swin_unetr.json", "r04_traffic_swin_unetr.json")}[model]
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in names) if os.path.isfile(q)), "")
+    if size != 128 or not os.path.isfile(tpath):
+        return {}, None, ""
+    tj = json.load(open(tpath))
+    return tj, (tj.get("_step") or {}).get("hbm_bytes_per_step"), os.path.basename(tpath)
+
+
+# compulsory HBM bytes of one bf16 step (SURVEY.md 8d: every conv reads its input once and writes its output once, forward +
+# dgrad + wgrad; everything else fused).  ResUNet / MedFormer: SURVEY.md 8d; SwinUNETR (BASELINE.md §3: "to be derived"): the
+# same rule applied to the monai conv blocks and the trunk's Linears / attention cores (tools/r06/swin_bytes.py: sum(in + out) =
+# 2 370 Me -> 4.74 GB forward, 14.22 GB per step)
+ALG_BYTES_STEP = {"resunet": ALG_BYTES_BF16, "medformer": 15.9e9, "swin_unetr": 14.22e9}
+
+
 def secondary(args, dev):
     """BASELINE.json configs[2] (MedFormer), configs[4] (SwinUNETR, per-GPU part) and configs[3] (ResUNet with the on-device
     augmentation pipeline, per-GPU part) timed in THIS process after the headline: `--secondary-steps` replayed steps each
@@ -447,11 +497,29 @@ def secondary(args, dev):
             row = {"ms_per_step": rr["ms"], "volumes_per_s": 1e3 / rr["ms"], "steps": a.steps, "warmup": a.warmup,
                    "graph": rr["graph"], "final_loss": rr["loss"], "step_flops": 3.0 * fwd,
                    "step_frac_mfma": 3.0 * fwd / (rr["ms"] * 1e-3) / 1e12 / peak,
+                   "step_frac_hbm": ALG_BYTES_STEP[model] / (rr["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "workload": {"medformer": "configs[2]: 3D MedFormer (amos_ct/medformer_3d.yaml, aux loss), 1x1x128^3, 16 classes",
                                 "swin_unetr": "configs[4] per GPU: SwinUNETR feature 48, 1x4x128^3, 4 classes (the five MONAI conv "
                                               "blocks of its oracle are parity-unpinned: monai is not installable here)",
                                 "resunet_aug": "configs[3] per GPU: ResUNet 1x1x128^3 + HBM-resident volumes, affine / crop / "
                                                "intensity augmentation on the device, prefetched on a side stream"}[key]}
+            # the dominant kernel of THIS model on the same clock: three event-timed eager steps, as for the headline
+            if not args.no_roofline:
+                table, per = kernel_roofline(rr["eager_step"], 0, args.dtype)
+                if per:
+                    dom = max((k for k in per if k.startswith(DOMINANT_FAMILIES)), key=lambda k: per[k][1])
+                    f, tsec, nl, nby = per[dom]
+                    tj, step_traffic, tname = _recorded_traffic(model, args.size)
+                    traffic = (tj.get(dom) or {}).get("hbm_bytes_per_launch")
+                    row["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": f / tsec / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                       "frac": f / tsec / 1e12 / peak, "launches_per_step": nl // 3, "avg_launch_ms": tsec / nl * 1e3,
+                                       "share_of_conv_time": tsec / sum(v[1] for v in per.values()),
+                                       "alg_bytes_per_launch": nby / nl, "traffic": traffic,
+                                       "traffic_ratio": (traffic / (nby / nl)) if traffic else None,
+                                       "traffic_source": ("profiles/" + tname) if traffic else None,
+                                       "step_traffic_bytes": step_traffic,
+                                       "step_traffic_ratio": (step_traffic / ALG_BYTES_STEP[model]) if step_traffic else None,
+                                       "kernels": table}
             del rr
         except Exception as e:      # noqa: BLE001 - the row says what happened
             row = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -551,47 +619,25 @@ def _finish(args, out, box, rank, world, dev):
     ms, eager_step = r["ms"], r["eager_step"]
     # ---- roofline of the dominant kernel: every launch of the conv kernels in one step, HIP events on the launch stream
     # (N > 1: EVERY rank runs the three eager steps — they hold the gradient collectives — rank 0 alone records)
+    table = per = None
     if not args.no_roofline:
-        per = {}
-        reps = 3
-        for _ in range(reps):
-            ops.PROFILE = [] if rank == 0 else None
-            eager_step()
-            torch.cuda.synchronize()
-            for name, flops, e0, e1, shape, nbytes in (ops.PROFILE or ()):
-                d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
-                d[0] += flops
-                d[1] += e0.elapsed_time(e1) * 1e-3
-                d[2] += 1
-                d[3] += nbytes
-            ops.PROFILE = None
+        table, per = kernel_roofline(eager_step, rank, args.dtype)
     if not args.no_roofline and rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        table = {k: {"launches_per_step": v[2] // reps, "avg_launch_ms": v[1] / v[2] * 1e3,
-                     "alg_tflop_per_step": v[0] / reps / 1e12, "achieved_tflops": v[0] / v[1] / 1e12,
-                     "frac_of_peak": v[0] / v[1] / 1e12 / peak, "alg_bytes_per_launch": v[3] / v[2]} for k, v in per.items()}
         # the dominant kernel = the MFMA conv kernel with the largest share of the step (forward/dgrad kernels; the wgrad
         # entry sums k_conv_wgrad and its reduce)
-        dom = max((k for k in per if k.startswith(("k_conv_igemm", "k_conv3_r32", "k_conv3_rw", "k_wgrad_r32"))), key=lambda k: per[k][1])
+        dom = max((k for k in per if k.startswith(DOMINANT_FAMILIES[:4])), key=lambda k: per[k][1])
         f, tsec, nl, nby = per[dom]
         fwd128 = {"medformer": FWD_FLOPS_128_MEDFORMER, "swin_unetr": FWD_FLOPS_128_SWIN,
                   "resunet": FWD_FLOPS_128 * (args.base / 32.0) ** 2}[args.model]
         step_flops = 3.0 * fwd128 * (args.size / 128.0) ** 3
         # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run
         # inside this process); null when no recorded pass covers this kernel / dtype / model
-        traffic = None
-        # (per model: profiles/r04_traffic.json holds the ResUNet passes, r04_traffic_<model>.json the two others)
-        names = {"resunet": ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_j_traffic.json", "r01_c_traffic.json"),
-                 "medformer": ("r05_traffic_medformer.json", "r04_traffic_medformer.json"),
-                 "swin_unetr": ("r05_traffic_swin_unetr.json", "r04_traffic_swin_unetr.json")}[args.model]
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", t) for t in names) if os.path.isfile(q)), "")
-        step_traffic = None
-        if args.size == 128 and os.path.isfile(tpath):
-            tj = json.load(open(tpath))
-            # (rounds 2-4 recorded the k_conv3_rw row under the name of the kernel it grew out of)
-            row = tj.get(dom) or tj.get({"k_conv3_rw<bf16>": "k_conv3_r32<bf16>"}.get(dom, dom)) or {}
-            traffic = row.get("hbm_bytes_per_launch")
-            step_traffic = (tj.get("_step") or {}).get("hbm_bytes_per_step")
+        tj, step_traffic, tname = _recorded_traffic(args.model, args.size)
+        # (rounds 2-4 recorded the k_conv3_rw row under the name of the kernel it grew out of)
+        row = tj.get(dom) or tj.get({"k_conv3_rw<bf16>": "k_conv3_r32<bf16>"}.get(dom, dom)) or {}
+        traffic = row.get("hbm_bytes_per_launch")
+        tpath = tname
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": f / tsec / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": f / tsec / 1e12 / peak, "traffic": traffic,
@@ -601,11 +647,11 @@ def _finish(args, out, box, rank, world, dev):
             "alg_bytes_per_launch": nby / nl, "traffic_ratio": (traffic / (nby / nl)) if traffic else None,
             "step_flops": step_flops, "step_achieved": step_flops / (ms * 1e-3) / 1e12,
             "step_frac_mfma": step_flops / (ms * 1e-3) / 1e12 / peak,
-            "step_frac_hbm": (ALG_BYTES_BF16 * (2 if args.dtype == "fp32" else 1) / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+            "step_frac_hbm": (ALG_BYTES_STEP[args.model] * (2 if args.dtype == "fp32" else 1) / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
             # HBM bytes of ONE step summed over every kernel of the step (the same committed PMC passes, all kernel families)
-            # over the 11.6 GB compulsory model of SURVEY.md 8d; null until a pass that covers every kernel is recorded
-            "step_traffic_bytes": step_traffic if args.model == "resunet" and args.dtype == "bf16" else None,
-            "step_traffic_ratio": (step_traffic / ALG_BYTES_BF16) if (step_traffic and args.model == "resunet" and args.dtype == "bf16") else None,
+            # over the model's compulsory bytes (ALG_BYTES_STEP); null until a pass that covers every kernel is recorded
+            "step_traffic_bytes": step_traffic if args.dtype == "bf16" else None,
+            "step_traffic_ratio": (step_traffic / ALG_BYTES_STEP[args.model]) if (step_traffic and args.dtype == "bf16") else None,
             "kernels": table,
         }
     # ---- configs[2], [4], [3] on the same clock (same process, same box): 10 replayed steps each -----------------------------

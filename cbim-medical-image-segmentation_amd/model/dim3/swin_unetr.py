@@ -163,7 +163,7 @@ class PatchEmbed(nn.Module):
             _, _, D, H, W = x.shape
         x = x.reshape(B, Cc, D // p[0], p[0], H // p[1], p[1], W // p[2], p[2]).permute(0, 2, 4, 6, 1, 3, 5, 7)
         tok = x.reshape(B, D // p[0], H // p[1], W // p[2], -1)
-        if _in_tree(tok, self.proj):
+        if _in_tree(tok, self.proj) or _tree32(tok, self.proj):
             # the fp32 patch rows feed the row GEMM as they are (bf16 hi + lo fragments of rows AND weights: this Linear lies
             # outside the blocks' reduced-precision region and keeps fp32 accuracy); fp32 out = the residual stream
             return Fn.token_linear(tok.contiguous(), self.proj.weight, self.proj.bias, out_dtype=torch.float32, need_dx=False,
@@ -199,6 +199,30 @@ def _in_tree(x, lin) -> bool:
     cin = w.numel() // w.shape[0]
     return (_TOKEN_GEMM and _trunk_bf16(x) and x.dtype in (torch.bfloat16, torch.float32) and cin % 8 == 0 and w.shape[0] % 8 == 0
             and cin <= 4096 and w.dtype == torch.float32)
+
+
+# round 6: the fp32 PARITY mode can also run the trunk's Linears on the engine's row GEMM — fp32 rows as bf16 hi + lo fragments
+# against the weight image AND its residue image (three MFMAs per fragment pair: an fp32-accurate product), fp32 out — so that the
+# fp32 goldens pin k_conv_pw's token mode at model level instead of hipBLASLt.  Off by default: the weight
+# gradient of that kernel rounds its operands to bf16, so the default fp32 mode keeps torch's fp32 GEMMs for the backward's sake.
+_FP32_TOKEN_GEMM = os.environ.get("CBIM_SWIN_FP32_TOKEN_GEMM", "0") != "0"
+
+
+def set_fp32_token_gemm(on: bool) -> bool:
+    global _FP32_TOKEN_GEMM
+    old, _FP32_TOKEN_GEMM = _FP32_TOKEN_GEMM, bool(on)
+    return old
+
+
+def _tree32(x, lin) -> bool:
+    w = lin.weight
+    cin = w.numel() // w.shape[0]
+    return (_FP32_TOKEN_GEMM and _on_engine_device(x) and Fn.compute_dtype() == torch.float32 and x.dtype == torch.float32
+            and cin % 8 == 0 and w.shape[0] % 8 == 0 and cin <= 4096 and w.dtype == torch.float32)
+
+
+def _lin32(lin, x, res=None):
+    return Fn.token_linear(x, lin.weight, lin.bias, res=res, out_dtype=torch.float32, exact=True)
 
 
 class _TokenLinearFn(torch.autograd.Function):
@@ -267,6 +291,8 @@ class MLPBlock(nn.Module):
 
     def forward(self, x, res=None):
         """res: the fp32 residual stream to add (the block's `x + mlp(norm2(x))`, swin_unetr.py:552,640-643)"""
+        if _tree32(x, self.linear1) and _tree32(x, self.linear2):
+            return _lin32(self.linear2, F.gelu(_lin32(self.linear1, x)), res)
         if _in_tree(x, self.linear1) and _in_tree(x, self.linear2):
             h = Fn.token_linear(x, self.linear1.weight, self.linear1.bias)                       # pre-activation, bf16
             return Fn.token_linear(h, self.linear2.weight, self.linear2.bias, act_in=_GELU, res=res,   # GELU on load, + res
@@ -303,6 +329,10 @@ class WindowAttention(nn.Module):
     def forward(self, h, window, shift, res=None):
         """res: the fp32 residual stream to add (the block's `x + attn(norm1(x))`, swin_unetr.py:539-549)"""
         tree = _in_tree(h, self.qkv) and _in_tree(h, self.proj)
+        if _tree32(h, self.qkv) and _tree32(h, self.proj):
+            o = Fn.WindowAttnFn.apply(_lin32(self.qkv, h), self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
+                                      self.window_size)
+            return _lin32(self.proj, o, res)
         qkv = Fn.token_linear(h, self.qkv.weight, self.qkv.bias) if tree else _token_linear(self.qkv, h)
         o = Fn.WindowAttnFn.apply(qkv, self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
                                   self.window_size)
@@ -398,7 +428,7 @@ class PatchMerging(nn.Module):
             x = m.index_select(4, self._sel_index(x.device)).reshape(B, d2, h2, w2, 8 * Cc)
         else:
             x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self._SEL], -1)
-        if _in_tree(x, self.reduction):
+        if _in_tree(x, self.reduction) or _tree32(x, self.reduction):
             # fp32 LayerNorm rows feed the row GEMM as they are (bf16 hi + lo fragments); fp32 out = the next stage's stream
             return Fn.token_linear(_layer_norm(self.norm, x, torch.float32), self.reduction.weight, None, out_dtype=torch.float32,
                                    exact=True)

@@ -625,6 +625,8 @@ def conv_igemm(desc: ConvDesc, x, w_packed, out_shape, in_stats=None, res=None, 
             name = "k_conv3_r32<bf16>"
         elif lk == 4:            # 1x1x1 layers: conv_pw.hip
             name = "k_conv_pw<bf16>"
+        elif lk == 5:            # round 6: 48 output channels per workgroup (SwinUNETR's feature-48 layers)
+            name = "k_conv3_rw48<bf16>"
         else:
             if cfg[0] == 4:       # a shape the r32 kernel takes for other calls: k_conv_igemm runs its 8x8x8 configuration
                 cfg[0], cfg[1] = 2, (1 if desc.Cout <= 32 else 2)

@@ -83,3 +83,20 @@ def assert_fp32_parity(name, dev, backward=True):
     if backward:
         assert r["grad_norm_err"] < 1e-2 and r["grad_max_err"] < 2e-2, r
     return r
+
+
+def assert_fp32_token_gemm_parity(name, dev):
+    """the fp32 goldens pin hipBLASLt as long as the fp32 mode keeps F.linear for the trunk.  With
+    swin_unetr.set_fp32_token_gemm(True) every trunk Linear (patch embedding, qkv, proj, MLP, patch merging) runs on the engine's
+    row GEMM in its fp32-exact form (k_conv_pw token mode: hi + lo row fragments x weight + residue images): the five hidden
+    states of the transformer (pinned to the in-tree reference file) and the logits must meet the golden as in the default mode."""
+    from cbim_amd.model.dim3 import swin_unetr as sw
+    old = sw.set_fp32_token_gemm(True)
+    try:
+        r, g = run_case(name, dev, "fp32", backward=False)
+    finally:
+        sw.set_fp32_token_gemm(old)
+    assert r.get("hidden_err", 0.0) < 1e-4, r
+    assert r["logits_err"] < 1e-3 and r["argmax_mismatch"] == 0, r
+    assert abs(r["ce"] - float(g["ce"])) < 1e-4 and abs(r["dice"] - float(g["dice"])) < 1e-4, r
+    return r

@@ -212,6 +212,16 @@ def test_swin_unetr_fp32_matches_reference_golden(dev, name):
     print(name, sw_parity(name, dev))
 
 
+@pytest.mark.parametrize("name", ["swin_tiny", "swin_brats_64"])
+def test_swin_unetr_fp32_exact_token_gemm_matches_reference_golden(dev, name):
+    """the in-tree token GEMM (k_conv_pw token mode, fp32-exact form) instead of F.linear in the fp32 parity mode"""
+    from tests.swin_checks import assert_fp32_token_gemm_parity
+    r = assert_fp32_token_gemm_parity(name, dev)
+    print(name, r)
+    from tests.util import record_parity
+    record_parity(name + "_fp32_token_gemm", r)
+
+
 def test_swin_unetr_bf16_inside_envelope(dev):
     from tests.swin_checks import run_case as sw_run
     r, g = sw_run("swin_brats_64", dev, "bf16")

@@ -200,6 +200,13 @@ def test_swin_unetr_load_from_self_supervised_checkpoint(tmp_path):
         net.load_from({"state_dict": ck})
 
 
+def test_swin_unetr_fp32_exact_token_gemm_matches_reference_golden(dev):
+    """the trunk's Linears on the engine's own row GEMM (fp32-exact form) in the fp32 parity mode: hidden states and logits of
+    the swin_tiny golden (reference's swin_unetr.py executed unmodified)"""
+    from tests.swin_checks import assert_fp32_token_gemm_parity
+    print(assert_fp32_token_gemm_parity("swin_tiny", dev))
+
+
 def test_swin_unetr_fp32_matches_reference_golden(dev):
     # forward + losses on the host-side executor (the backward of every kernel involved is covered per op in
     # test_ops_emu.py and end to end on the GPU in test_gpu_parity.py; it would add ~90 s here)
