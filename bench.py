@@ -414,6 +414,20 @@ def time_model(args, dev, rank, world, on_hang=None):
     res = dict(facts, ms=ms, dt=dt, graph=bool(use_graph), loss=loss_val, eager_step=eager_step, ddp=ddp, keep=(net, opt, crit, x, lab))
     if eager_res is not None:
         res["eager_ms"] = eager_res["ms"]
+    if dist.is_initialized() and world > 1:
+        # what data parallelism promises (train_ddp.py:60,330,353): every rank trained on ITS OWN sample (own sampler shard / own
+        # augmentation draws) and the replicas hold THE SAME weights after the averaged-gradient steps — checked on the state the
+        # timed steps left behind, one small all-gather every rank takes part in
+        tdev = dev if dist.get_backend() == "nccl" else "cpu"
+        chk = torch.tensor([float(x.double().sum()), float(sum(p.detach().double().sum() for p in net.parameters())),
+                            float(sum(p.detach().double().abs().sum() for p in net.parameters()))], dtype=torch.float64, device=tdev)
+        lst = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(lst, chk)
+        lst = [t.cpu() for t in lst]
+        res["replica_check"] = {
+            "inputs_differ": len({round(float(t[0]), 6) for t in lst}) == world,
+            "weights_identical": all(abs(float(t[1] - lst[0][1])) <= 1e-9 * float(lst[0][2]) for t in lst),
+            "aug": bool(args.aug)}
     return res
 
 
@@ -571,6 +585,8 @@ def main():
             out["config"]["eager_ms_per_step"] = r["eager_ms"]
         if r.get("note"):
             out["config"]["note"] = r["note"]
+        if r.get("replica_check"):
+            out["config"]["replica_check"] = r["replica_check"]
         return out
 
     def on_hang(r):

@@ -70,8 +70,23 @@ def test_two_rank_control_flow_of_bench_on_one_gpu():
     assert d["config"]["graph"] is False and "eager_ms_per_step" in d["config"], (d["config"], err[-1500:])
     assert d["value"] == pytest.approx(2.0 / (d["ms_per_step"] * 1e-3))
     assert d["config"]["grad_bucket"] == {"written_in_place": 45, "copied": 0}
+    assert d["config"]["replica_check"] == {"inputs_differ": True, "weights_identical": True, "aug": False}
     assert d["roofline"]["kernel"].startswith(("k_conv3_rw", "k_wgrad_r32")) and 0 < d["roofline"]["frac"] < 1   # (64^3: the wgrad row leads)
     assert "TEST VEHICLE" in d["config"]["workload"]
+    import math
+    assert math.isfinite(d["config"]["final_loss"])
+
+
+def test_two_rank_bench_with_device_side_augmentation():
+    """BASELINE configs[3] is "DDP + GPU-side augmentation on": `bench.py --gpus 2 --aug 1` through the same two-rank vehicle.  The
+    ranks seed their augmentation draws differently (each trains on its own sample, train_ddp.py:60,330) and the averaged
+    gradients keep the replicas' weights identical (train_ddp.py:353) — bench.py checks both on the state the timed steps left and
+    reports it in config.replica_check."""
+    d, err = _bench2({}, "--aug", "1", "--no-roofline")
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2", d["config"]
+    rc = d["config"]["replica_check"]
+    assert rc["aug"] is True and rc["inputs_differ"] is True and rc["weights_identical"] is True, (rc, err[-1500:])
+    assert "on-device augmentation" in d["config"]["workload"]
     import math
     assert math.isfinite(d["config"]["final_loss"])
 
