@@ -63,7 +63,7 @@ struct IgemmParams {
   int hD, hH, hW;                  // halo extent = tile + k - 1
   int n_chunks, taps;
   unsigned mHW, mW;                // ceil(2^20 / (hH*hW)), ceil(2^20 / hW): division by multiply
-  int dbg;                         // timing ablations for tools/ (env CBIM_IGEMM_DBG); 0 in production
+  int dbg;                         // timing ablations of rounds 1-3 (tools/archive); always 0
   int P;                           // records per image of `partials` (cbim_conv3d_num_tiles)
   int ksplit;                      // > 1: blockIdx.z owns a slice of the Cin chunks, raw fp32 partials go to ws
   float* ws;                       // [ksplit][N*Do*Ho*Wo][Cout] fp32
@@ -931,7 +931,7 @@ static TileCfg pick_cfg(const cbim_conv_desc* d) {
     c.MT = 1; c.tD = 4;
   }
   // two 256-thread workgroups per CU on 4x8x8 tiles (phase overlap): 3x3x3, Cout <= 32 layers at full resolution
-  static const int half_on = getenv("CBIM_IGEMM_HALF") ? atoi(getenv("CBIM_IGEMM_HALF")) : 0;
+  static const int half_on = 0;
   if (half_on && c.MT == 2 && c.NTL == 1 && d->dtype == CBIM_BF16 && d->kD == 3 && d->kH == 3 && d->kW == 3 &&
       d->act == CBIM_ACT_RELU) {
     c.nth = 256;
@@ -951,7 +951,7 @@ static int pick_ksplit(const cbim_conv_desc* d, const TileCfg& c) {
   int BN = 32 * c.NTL;
   int64_t wgs = tiles * ((d->Cout + BN - 1) / BN);
   // the finish kernel keeps one 16-byte output chunk per thread (FT = 256 threads)
-  static const int target = getenv("CBIM_IGEMM_KSPLIT_TARGET") ? atoi(getenv("CBIM_IGEMM_KSPLIT_TARGET")) : 192;
+  static const int target = 192;
   if (wgs >= target / 2 || n_chunks < 2 || d->Cout / (d->dtype == CBIM_BF16 ? 8 : 4) > 256) return 1;
   int64_t s = (target + wgs - 1) / wgs;
   if (s > n_chunks) s = n_chunks;
@@ -1278,7 +1278,7 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
   int KC = kc_of(d->dtype);
   p.n_chunks = (d->Cin + KC - 1) / KC;
   p.taps = d->kD * d->kH * d->kW;
-  { const char* e = getenv("CBIM_IGEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
+  p.dbg = 0;
   int BN = 32 * c.NTL;
   size_t smem = (size_t)p.hD * p.hH * p.hW * RB + 2 * (size_t)d->kH * d->kW * KG * 2 * BN * 16 +
                 (size_t)nw * BN * 3 * sizeof(float) + 64 * 2 * sizeof(float) +
@@ -1325,14 +1325,14 @@ extern "C" int cbim_conv3d_igemm(const cbim_conv_desc* d, const void* x, int64_t
     // main kernel writes raw partials; the finish kernel owns residual / mask / statistics / store
     IgemmParams q = p;
     q.res = nullptr; q.mx = nullptr; q.partials = nullptr;
-    static const bool k3s_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : true;
+    static const bool k3s_on = true;
     const bool k3s = k3s_on && d->kH == 3 && d->kW == 3 && c.tH == 8;
     int rc = d->dtype == CBIM_BF16 ? dispatch_act<bf16_tag>(d->act, k3s, c, q, grid, smem, st)
                                    : dispatch_act<float>(d->act, k3s, c, q, grid, smem, st);
     if (rc) return rc;
     return launch_finish(d, workspace, p.ksplit, res, res_stride, mask_x, mask_stride, mask_stats, y, y_stride, partials, P_records, st);
   }
-  static const bool k3_on = getenv("CBIM_IGEMM_K3") ? atoi(getenv("CBIM_IGEMM_K3")) != 0 : true;
+  static const bool k3_on = true;
   const bool k3 = k3_on && d->kH == 3 && d->kW == 3 && c.tH == 8;   // hW == hH == 10: compile-time tap offsets
   return d->dtype == CBIM_BF16 ? dispatch_act<bf16_tag>(d->act, k3, c, p, grid, smem, st)
                                : dispatch_act<float>(d->act, k3, c, p, grid, smem, st);

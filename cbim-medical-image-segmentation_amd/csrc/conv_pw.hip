@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(PW_NT, 2) k_pw_wgrad(PwgParams p) {
 
 using namespace cbim;
 
-static int g_pw_on = getenv("CBIM_CONV_PW") ? atoi(getenv("CBIM_CONV_PW")) : 1;
+static int g_pw_on = 1;
 /* process-wide switch (tests, A/B): 0 = pointwise convolutions stay on k_conv_igemm; returns the old value */
 extern "C" int cbim_conv_pw_enable(int on) {
   const int old = g_pw_on;
@@ -553,7 +553,7 @@ static bool pw_desc_ok(const cbim_conv_desc* d) {
 
 // output channels per wave and the K-split form, from the descriptor alone (cbim_conv_pw_records must agree with the launch)
 static void pw_plan(const cbim_conv_desc* d, int* ntw, int* ks) {
-  static const int ks_env = getenv("CBIM_PW_KSPLIT") ? atoi(getenv("CBIM_PW_KSPLIT")) : 1;   // tools/ only: 0 = never split K
+  static const int ks_env = 1;   // tools/ only: 0 = never split K
   const int64_t S = (int64_t)d->Do * d->Ho * d->Wo;
   const int64_t row_wgs = (int64_t)d->N * ((S + PW_ROWS - 1) / PW_ROWS);
   int n = d->Cout <= 32 ? 1 : (d->Cout <= 64 ? 2 : 4);
@@ -627,7 +627,7 @@ static void pwg_cfg(const cbim_conv_desc* d, int* strips, int* rps, int* co_bloc
   *co_blocks = (d->Cout + 63) / 64; *ci_blocks = (d->Cin + 63) / 64;
   const int64_t pairs = (int64_t)*co_blocks * *ci_blocks * d->N;
   const int64_t stages = (S + PWG_VT - 1) / PWG_VT;
-  static const int64_t wgs = getenv("CBIM_PWG_WGS") ? atoi(getenv("CBIM_PWG_WGS")) : 768;   // (tools: A/B of the strip count)
+  static const int64_t wgs = 768;   // (tools: A/B of the strip count)
   int64_t want = (wgs + pairs - 1) / pairs;                 // ~3 workgroups per CU
   if (want > stages) want = stages;
   const size_t slab = (size_t)*co_blocks * 64 * *ci_blocks * 64 * sizeof(float);

@@ -737,9 +737,9 @@ using namespace cbim;
 static int64_t g_r32_min_voxels = 262144;   // same threshold as the 8x8x8 tile configuration of k_conv_igemm
 static int r32_tile_depth();
 
-// CBIM_CONV_R32: 0 off, 1 the single-chunk layers only (Cin = 32, Cout <= 32), 2 (default) every multiple of 32
+// mode (frozen at 2 since round 3): 0 off, 1 the single-chunk layers only (Cin = 32, Cout <= 32), 2 (default) every multiple of 32
 static int r32_mode() {
-  static const int m = getenv("CBIM_CONV_R32") ? atoi(getenv("CBIM_CONV_R32")) : 2;
+  static const int m = 2;
   return m;
 }
 bool cbim_conv_r32_eligible(const cbim_conv_desc* d, const void* x2, int cin_split, const float* in_stats, const void* res,
@@ -779,7 +779,7 @@ extern "C" int64_t cbim_conv_r32_min_voxels(int64_t v) {
 
 // 8: one 512-thread workgroup per CU on 8x8x8 tiles (default); 4: two 256-thread workgroups per CU on 4x8x8 tiles —
 // measured 5-15 % slower on 32->32 @128^3 (more halo per voxel, and the MFMA phase, not the overlap, is what limits)
-static int g_r32_td = getenv("CBIM_CONV_R32_TD") && atoi(getenv("CBIM_CONV_R32_TD")) == 4 ? 4 : 8;
+static int g_r32_td = 8;
 static int r32_tile_depth() { return g_r32_td; }
 extern "C" int cbim_conv_r32_tile_depth(int td) {
   const int old = g_r32_td;
@@ -836,7 +836,7 @@ int cbim_conv_r32_launch(const cbim_conv_desc* d, const void* x, int64_t x_strid
   p.pD = d->pD; p.pH = d->pH; p.pW = d->pW; p.act = d->act;
   const int td = r32_tile_depth();
   p.tiles_d = (d->Do + td - 1) / td; p.tiles_h = (d->Ho + 7) / 8; p.tiles_w = (d->Wo + 7) / 8;
-  { const char* e = getenv("CBIM_R32_DBG"); p.dbg = e ? atoi(e) : 0; }   // tools/r32_ablate.py timing ablations; 0 in production
+  p.dbg = 0;   // tools/r32_ablate.py timing ablations; 0 in production
   p.P = cbim_conv3d_num_tiles(d);
   CBIM_CHECK(!partials || p.P >= (int)cbim_conv_r32_grid(d), CBIM_EINVAL, "conv r32: %d partial records < grid", p.P);
   {

@@ -623,11 +623,11 @@ __global__ void __launch_bounds__(512, 1) k_conv3_rw48(R32Params p) {
 
 using namespace cbim;
 
-// CBIM_CONV_RW: 0 off (every call stays on k_conv3_r32 / k_conv_igemm), 1 (default) on
-static int g_rw_on = getenv("CBIM_CONV_RW") ? atoi(getenv("CBIM_CONV_RW")) : 1;
-// CBIM_CONV_RW_WIDE: 0 never, 1 (default) the wide form wherever Cout is a multiple of 64 and the grid still fills the chip,
+// g_rw_on (cbim_conv_rw_enable): 0 off (every call stays on k_conv3_r32 / k_conv_igemm), 1 (default) on
+static int g_rw_on = 1;
+// g_rw_wide (cbim_conv_rw_enable): 0 never, 1 (default) the wide form wherever Cout is a multiple of 64 and the grid still fills the chip,
 // 2 wherever Cout is a multiple of 64
-static int g_rw_wide = getenv("CBIM_CONV_RW_WIDE") ? atoi(getenv("CBIM_CONV_RW_WIDE")) : 1;
+static int g_rw_wide = 1;
 extern "C" int cbim_conv_rw_enable(int on, int wide) {
   const int old = g_rw_on | (g_rw_wide << 1);
   if (on >= 0) g_rw_on = on & 1;
@@ -821,8 +821,7 @@ int cbim_conv_rw_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride
 // split-K factor of a low-resolution layer: 0 when the layer already has >= 128 (tile, 32-cout block) workgroups or a single
 // Cin chunk; otherwise the divisor-free share-out of the Cin chunks that brings the launch closest to one workgroup per CU
 // (k_splitk_finish keeps one 16-byte output chunk per thread of 256: Cout <= 2048)
-// CBIM_CONV_RW_SPLIT=0 keeps those layers on k_conv_igemm's split-K
-static int g_rw_split = getenv("CBIM_CONV_RW_SPLIT") ? atoi(getenv("CBIM_CONV_RW_SPLIT")) : 1;
+static int g_rw_split = 1;
 int cbim_conv_rw_ksplit(const cbim_conv_desc* d) {
   if (!g_rw_on || !g_rw_split || d->dtype != CBIM_BF16) return 0;
   const int NC = d->Cin / 32;

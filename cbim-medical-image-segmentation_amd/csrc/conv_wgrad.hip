@@ -416,7 +416,7 @@ static WgCfg wg_cfg(const cbim_conv_desc* d) {
   int tiles_per_n = c.tiles_d * c.tiles_h * c.tiles_w;
   int64_t pairs = (int64_t)c.co_blocks * c.ci_blocks;
   // ~512 resident workgroups (2 per CU); every extra strip costs one slab of workspace traffic
-  static const int64_t wgs = getenv("CBIM_CWG_WGS") ? atoi(getenv("CBIM_CWG_WGS")) : 512;   // (tools: A/B of the strip count)
+  static const int64_t wgs = 512;   // (tools: A/B of the strip count)
   int64_t want = (wgs + pairs * d->N - 1) / (pairs * d->N);
   if (want < 1) want = 1;
   if (want > tiles_per_n) want = tiles_per_n;

@@ -53,7 +53,7 @@ struct WR32Params {
   int tiles_d, tiles_h, tiles_w;
   int ci_blocks, Cout_pad, Cin_pad;   // 32-channel blocks of Cin; the gradient's own Cout, Cin (slab layout [Cout][Cin][27])
   int cin_bytes, cout_bytes;          // 2 Cin, 2 Cout: the 16-byte slots of a last block past them are zero-filled (round 6: 48 channels)
-  int dbg;   // timing ablations for tools/ (env CBIM_WR32_DBG, wrong results); 0 in production
+  int dbg;   // timing ablations of round 3 (tools/archive); always 0
   int diag;  // depthwise form: blockIdx.y = 32-channel group, only the diagonal (co == ci) of the 32 x 32 block is kept
 };
 
@@ -505,8 +505,8 @@ __global__ void __launch_bounds__(512) k_wgrad_r32_reduce(const float* __restric
 
 using namespace cbim;
 
-// CBIM_WGRAD_R32=0 keeps every weight gradient on k_conv_wgrad (A/B runs)
-static int g_wr32_on = getenv("CBIM_WGRAD_R32") ? atoi(getenv("CBIM_WGRAD_R32")) : 1;
+// cbim_wgrad_r32_enable(0) keeps every weight gradient on k_conv_wgrad (tests: two-sided checks)
+static int g_wr32_on = 1;
 static int wr32_on() { return g_wr32_on; }
 // CBIM_WGRAD_R32_C16=0 keeps the layers whose channel counts are not multiples of 32 on k_conv_wgrad (A/B runs)
 static int g_wr32_c16 = getenv("CBIM_WGRAD_R32_C16") ? atoi(getenv("CBIM_WGRAD_R32_C16")) : 1;
@@ -516,8 +516,8 @@ extern "C" int cbim_wgrad_r32_enable(int on) {
   return old;
 }
 
-// CBIM_WGRAD_R32_WAVES=4|8: waves per workgroup (see k_wgrad_r32); process-wide knob for tools and tests
-static int g_wr32_waves = getenv("CBIM_WGRAD_R32_WAVES") && atoi(getenv("CBIM_WGRAD_R32_WAVES")) == 4 ? 4 : 8;
+// cbim_wgrad_r32_waves(4 | 8): waves per workgroup (see k_wgrad_r32); process-wide knob for tests
+static int g_wr32_waves = 8;
 static int wr32_waves() { return g_wr32_waves; }
 extern "C" int cbim_wgrad_r32_waves(int w) {
   const int old = g_wr32_waves;
@@ -559,7 +559,7 @@ int cbim_wgrad_r32_dw_strips(const cbim_conv_desc* d) {
   wr32_tiles(d, td, th, tw);
   return wr32_strips_for((int64_t)d->N * td * th * tw, (int64_t)(d->Cout / 32), (int64_t)27 * d->Cout * 4);
 }
-static int g_wr32_small_strips = getenv("CBIM_WGRAD_R32_SMALL_STRIPS") ? atoi(getenv("CBIM_WGRAD_R32_SMALL_STRIPS")) : 1;
+static int g_wr32_small_strips = 1;
 static int wr32_strips_for(int64_t n_tiles, int64_t pairs, int64_t slab) {
   int64_t gmax = (96ll << 20) / slab;
   if (gmax < 1) gmax = 1;
@@ -615,7 +615,7 @@ static int wr32_launch(const cbim_conv_desc* d, const void* x, int64_t x_stride,
   wr32_tiles(d, p.tiles_d, p.tiles_h, p.tiles_w);
   p.ci_blocks = (d->Cin + 31) / 32; p.Cout_pad = d->Cout; p.Cin_pad = d->Cin;
   p.cin_bytes = d->Cin * 2; p.cout_bytes = d->Cout * 2;
-  { const char* e = getenv("CBIM_WR32_DBG"); p.dbg = e ? atoi(e) : 0; }
+  p.dbg = 0;
   {
     // 32-bit byte offsets inside one halo box / one dy tile, built from 24-bit multiplies
     const int64_t box_rows = (int64_t)10 * d->Hi * d->Wi, xs = (x2 && x2_stride > x_stride ? x2_stride : x_stride) * 2;

@@ -1390,7 +1390,7 @@ extern "C" int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const f
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     const int mode = !in_stats ? 0 : act == CBIM_ACT_RELU ? 1 : act == CBIM_ACT_NONE ? 2 : 3;
-    static const int lds_on = getenv("CBIM_DWCONV_LDS") ? atoi(getenv("CBIM_DWCONV_LDS")) : 1;
+    static const int lds_on = 1;
     if (lds_on && g_dw_lds) {      // LDS-tiled form (round 4): one sweep of loads, the input transformed once
       const int tiles_d = (D + LTD - 1) / LTD, tiles_h = (H + LTH - 1) / LTH, tiles_w = (W + LTW - 1) / LTW;
       const int64_t tiles = (int64_t)N * tiles_d * tiles_h * tiles_w;
@@ -1481,7 +1481,7 @@ extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, c
   hipStream_t st = (hipStream_t)stream;
   // matrix-core form (k_wgrad_r32, diagonal of the 32-channel groups): raw input, no gradient bias (functional.DWConvFn
   // materialises act(IN(x)) and dy + bias first), bf16, extents >= 8
-  static const int dw_mfma = getenv("CBIM_DW_WGRAD_MFMA") ? atoi(getenv("CBIM_DW_WGRAD_MFMA")) : 1;
+  static const int dw_mfma = 1;
   if (dw_mfma && dtype == CBIM_BF16 && !in_stats && !dy_bias && kD == 3 && kH == 3 && kW == 3 && C % 32 == 0) {
     cbim_conv_desc cd = {};
     cd.dtype = CBIM_BF16; cd.N = N; cd.Di = D; cd.Hi = H; cd.Wi = W; cd.Cin = C; cd.Do = D; cd.Ho = H; cd.Wo = W; cd.Cout = C;
@@ -1596,7 +1596,7 @@ extern "C" int cbim_mappool_bwd_wide_launch(int dtype, const void* fw, int64_t f
                                             int L, int C, int M, void* stream);
 static bool attn_wide(int dh, int M) { return !(dh == 8 || dh == 16 || dh == 32) || M > MM; }
 static bool attn_mfma_on() {
-  static const int on = getenv("CBIM_ATTN_MFMA") ? atoi(getenv("CBIM_ATTN_MFMA")) : 1;
+  static const int on = 1;
   return on != 0;
 }
 
@@ -1699,7 +1699,7 @@ extern "C" int cbim_colsoftmax_pool_bwd(int dtype, const void* fw, int64_t fw_st
   int nblk = (L + AT - 1) / AT;
   hipStream_t st = (hipStream_t)stream;
   const int cpc = dtype == CBIM_BF16 ? 8 : 4;
-  static const int four = getenv("CBIM_MAPPOOL_BWD4") ? atoi(getenv("CBIM_MAPPOOL_BWD4")) : 1;
+  static const int four = 1;
   if (four && M % cpc == 0 && C % cpc == 0 && fw_stride % cpc == 0 && dfw_stride % cpc == 0) {
     const size_t smem = (size_t)(4 * 64 * (MM + 1) + MM) * sizeof(float);
 #ifndef CBIM_EMU

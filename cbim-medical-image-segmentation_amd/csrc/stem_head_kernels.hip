@@ -1052,7 +1052,7 @@ static StemCfg stem_cfg(int N, int Do, int Ho, int Wo) {
 
 using namespace cbim;
 
-static int g_stem_mfma = getenv("CBIM_STEM_MFMA") ? atoi(getenv("CBIM_STEM_MFMA")) : 1;
+static int g_stem_mfma = 1;
 /* process-wide switch (tests, A/B): 0 = the VALU stem kernels also where the matrix-core ones apply; returns the old value */
 extern "C" int cbim_stem_mfma_enable(int on) {
   const int old = g_stem_mfma;
@@ -1209,7 +1209,7 @@ extern "C" int cbim_head_fwd(int dtype, const void* x, const float* w, const flo
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
-static int g_head_mfma = getenv("CBIM_HEAD_MFMA") ? atoi(getenv("CBIM_HEAD_MFMA")) : 1;
+static int g_head_mfma = 1;
 /* process-wide switch (tests, A/B): 0 = the VALU head backward also where the matrix-core kernel applies; returns the old value */
 extern "C" int cbim_head_mfma_enable(int on) {
   const int old = g_head_mfma;

@@ -586,12 +586,12 @@ __global__ void __launch_bounds__(WB_NT) k_winattn_bwd_mfma(WinGeom g, const voi
 using namespace cbim;
 
 bool cbim_winattn_mfma_eligible(int dtype, const WinGeom& g) {
-  static const int on = getenv("CBIM_WINATTN_MFMA") ? atoi(getenv("CBIM_WINATTN_MFMA")) : 1;
+  static const int on = 1;
   return on && dtype == CBIM_BF16 && g.dh == WM_DH && g.w0 * g.w1 * g.w2 <= WMAX && g.C % 8 == 0;
 }
 
 bool cbim_winattn_mfma_bwd_eligible(int dtype, const WinGeom& g) {
-  static const int on = getenv("CBIM_WINATTN_MFMA_BWD") ? atoi(getenv("CBIM_WINATTN_MFMA_BWD")) : 1;
+  static const int on = 1;
   const int TS = (2 * g.tw0 - 1) * (2 * g.tw1 - 1) * (2 * g.tw2 - 1);
   return on && cbim_winattn_mfma_eligible(dtype, g) && (size_t)TS * 4 <= WB_HS;
 }
@@ -612,7 +612,7 @@ int cbim_winattn_mfma_bwd(const WinGeom& g, const void* qkv, const float* qkv_bi
 #endif
   dim3 grid(g.B * g.nw0 * g.nw1 * g.nw2, g.heads);
   // timing ablations (wrong results): CBIM_WM_DBG bit 0 no histogram atomics, bit 1 no pass A, bit 2 no pass B
-  const int dbg = getenv("CBIM_WM_DBG") ? atoi(getenv("CBIM_WM_DBG")) : 0;
+  const int dbg = 0;
   CBIM_LAUNCH(k_winattn_bwd_mfma, grid, dim3(WB_NT), smem, (hipStream_t)stream, g, qkv, qkv_bias, table, out, dout, lse, dqkv,
               part_tbl, part_pad, dbg);
   hipError_t e = CBIM_LAST_LAUNCH();

@@ -166,27 +166,19 @@ def _fusable(x: torch.Tensor, cout: int) -> bool:
     return cout % kc == 0 and cout % 32 == 0
 
 
-# A/B switch of the round-3 experiment "materialise act(IN(x)) once" (profiles/r03_*): 1 = every pre-activation conv
-# input of a BasicBlock is written ONCE as a = act(IN(x)) by a streaming pass and the forward conv, the weight-gradient
-# staging and the dgrad mask all read `a` as it is (pure LDS-DMA, no normalisation in LDS, no statistics tables);
-# 0 = normalise on load inside every consumer (round 2).
-_MATERIALIZE = os.environ.get("CBIM_MATERIALIZE", "1") not in ("", "0")
-
-
-def set_materialize(on: bool):
-    global _MATERIALIZE
-    _MATERIALIZE = bool(on)
+# Round 3 ("materialise act(IN(x)) once", profiles/r03_*; decided): every pre-activation conv input of a ReLU BasicBlock is written
+# ONCE as a = act(IN(x)) by a streaming pass and the forward conv, the weight-gradient staging and the dgrad mask all read `a` as it
+# is (pure LDS-DMA, no normalisation in LDS, no statistics tables).  Other activations normalise on load inside every consumer.
 
 
 def fused_up_block(block) -> bool:
     """True when the decoder level's first block can take the fused up-sample + concat + activation path
-    (UpBlockFirstFn): a ReLU BasicBlock with a shortcut conv, materialisation on."""
+    (UpBlockFirstFn): a ReLU BasicBlock with a shortcut conv."""
     from .model.dim3.conv_layers import BasicBlock, ConvNormAct
-    return (_MATERIALIZE and _FUSED_UP and isinstance(block, BasicBlock) and isinstance(block.shortcut, ConvNormAct)
+    return (isinstance(block, BasicBlock) and isinstance(block.shortcut, ConvNormAct)
             and block.conv1.act_code == ACT["relu"] and block.conv1.norm_kind == "in")
 
 
-_FUSED_UP = os.environ.get("CBIM_FUSED_UP", "1") not in ("", "0")
 def _bb_fwd(ctx, xshape, xin, sin, ident, w1, w2, wsc, act, want_out_stats, mat, train):
     """conv1 (+ shortcut conv as one Cout-concatenated GEMM where the channel counts allow) and conv2 with the residual add
     of a pre-activation BasicBlock.  xin / sin: the block input as the convolutions read it (activated tensor + None when
@@ -270,14 +262,14 @@ class BasicBlockFn(_GradAwareFunction):
     wgrad) / K-concatenated inputs (dgrad): the halo is staged and normalised once.
 
     ReLU blocks (every shipped configuration) materialise a = relu(IN(.)) of both conv inputs once
-    (`_MATERIALIZE`): zero padding after the activation (conv_layers.py:48-49) is then simply the
+    : zero padding after the activation (conv_layers.py:48-49) is then simply the
     zero halo of a raw convolution.
     """
 
     @staticmethod
     def forward(ctx, x, x_stats, w1, w2, wsc, act, want_out_stats):
         train = _training(ctx)
-        mat = _MATERIALIZE and act == ACT["relu"]
+        mat = act == ACT["relu"]
         xin, sin = (ops.norm_act_fwd(x, x_stats, act), None) if mat else (x, x_stats)
         out, so, y1, s1, yin = _bb_fwd(ctx, x, xin, sin, x, w1, w2, wsc, act, want_out_stats, mat, train)
         none = torch.empty(0)

@@ -2,23 +2,23 @@
 (/root/reference/model/dim3/swin_unetr.py:32-292 and the monai 1.1.0 blocks it imports, :24-27).
 
 Execution split:
-  * conv encoder/decoder (92 % of the FLOPs: UnetrBasicBlock / UnetrUpBlock / UnetOutBlock) — the implicit-GEMM
-    conv kernels with InstanceNorm(eps 1e-5)+LeakyReLU fused on load and statistics in the epilogue, the
-    post-norm residual tail as one streaming kernel (``functional.ResNormFn``), ConvTranspose3d(k=2,s=2) as a
-    1x1 GEMM + depth-to-space scatter;
+  * conv encoder/decoder (92 % of the FLOPs: UnetrBasicBlock / UnetrUpBlock / UnetOutBlock) — the engine's conv kernels: the
+    48-channel layers of the 128^3 / 64^3 levels on k_conv3_rw48 / k_wgrad_r32 with act(IN(x)) materialised once (round 6),
+    the others with InstanceNorm(eps 1e-5) + LeakyReLU fused on load; statistics in the epilogues, the post-norm residual tail as
+    one streaming kernel (``functional.ResNormFn``), ConvTranspose3d(k=2,s=2) as a 1x1 GEMM + depth-to-space scatter;
   * shifted-window attention — one kernel per block does pad/roll/partition/bias/mask/softmax/AV/reverse/crop
     (``functional.WindowAttnFn``);
-  * the token-wise Linear layers (qkv, proj, MLP, patch merging/embedding) are plain library GEMMs
-    (torch ``F.linear`` -> hipBLASLt), LayerNorm/GELU/residual adds are torch elementwise ops on the
-    channels-last token tensors.  The residual stream and LayerNorm of the trunk stay fp32; in the bf16 engine mode the
-    Linears, GELU and the window-attention kernel of each block run in bf16 (torch.autocast, as the reference under AMP).
+  * the token-wise Linear layers (qkv, proj, MLP, patch merging/embedding) on the engine's row GEMM (``functional.TokenLinearFn``:
+    bias, GELU on load, GELU' mask, fp32 residual add in the kernel) in the bf16 engine mode — the fp32 parity mode keeps torch's
+    fp32 GEMMs unless ``set_fp32_token_gemm(True)``; LayerNorm is ``k_layernorm_fwd/bwd``.  The residual stream and LayerNorm
+    of the trunk stay fp32; in the bf16 engine mode the Linears, GELU and the window-attention kernel of each block run in bf16
+    (as the reference under AMP).
 forward(x[B,C,D,H,W] fp32 NCDHW) -> logits[B,classes,D,H,W] fp32.
 """
 import itertools
 
 import torch
 import torch.nn as nn
-import os
 
 import torch.nn.functional as F
 
@@ -26,10 +26,8 @@ from ... import functional as Fn
 from ...functional import eager_only
 from ...ops import ACT
 
-from ...ops import colsum as ops_colsum
 from ...ops import ncdhw_to_ndhwc as ops_ncdhw_to_ndhwc
 
-_STEM_MFMA = os.environ.get("CBIM_SWIN_STEM_MFMA", "1") != "0"
 _EPS = 1e-5          # nn.InstanceNorm3d default (monai get_norm_layer("instance"))
 _LRELU = ACT["lrelu"]  # monai UnetResBlock act: LeakyReLU(0.01)
 _GELU = ACT["gelu"]    # monai MLPBlock act
@@ -69,7 +67,7 @@ class UnetResBlock(nn.Module):
 
     def forward(self, x, stem_dtype=None):
         """x: channels-last feature map, or (stem_dtype given) the NCDHW fp32 network input."""
-        if stem_dtype is not None and _STEM_MFMA and stem_dtype == torch.bfloat16 and x.shape[1] <= 8:
+        if stem_dtype is not None and stem_dtype == torch.bfloat16 and x.shape[1] <= 8:
             # the network input as an 8-channel (zero-padded) channels-last bf16 tensor: conv1 / conv3 of encoder1 then run
             # on the matrix cores like every other conv (k_stem_fwd / k_stem_wgrad<4>, direct vector-ALU kernels, were
             # 0.9 + 1.8 ms of the 32 ms step); the padded weight columns are zero and their gradient is sliced off
@@ -87,7 +85,7 @@ class UnetResBlock(nn.Module):
         if stem_dtype is not None:
             z1 = Fn.StemFn.apply(x, self.conv1.conv.weight, stem_dtype)
             s1 = Fn.ensure_stats(Fn.FMap(z1, None), _EPS).stats
-        elif self.downsample and _DUAL_CONV:
+        elif self.downsample:
             # conv1 and the 1x1x1 residual conv3 read the same tensor: one autograd node, the two input gradients accumulated in
             # the kernel (functional.DualRawConvFn)
             z1, s1, r, s3 = Fn.DualRawConvFn.apply(x, self.conv1.conv.weight, self.conv3.conv.weight, _EPS)
@@ -168,19 +166,12 @@ class PatchEmbed(nn.Module):
             # outside the blocks' reduced-precision region and keeps fp32 accuracy); fp32 out = the residual stream
             return Fn.token_linear(tok.contiguous(), self.proj.weight, self.proj.bias, out_dtype=torch.float32, need_dx=False,
                                    exact=True)
-        if _SPLITK_DW and tok.is_cuda and torch.is_grad_enabled() and self.proj.weight.requires_grad:
-            # (the weight gradient is a 48 x 32 output over 262 144 tokens: one workgroup and 612 us in the library's
-            #  default tiling; the split-K form of the other token Linears fills the chip)
-            return _TokenLinearFn.apply(tok, self.proj.weight.flatten(1), self.proj.bias)
-        return F.linear(tok, self.proj.weight.flatten(1), self.proj.bias)
+        return F.linear(tok, self.proj.weight.flatten(1), self.proj.bias)      # (the fp32 parity mode: torch's fp32 GEMM)
 
 
-_TRUNK_AMP = os.environ.get("CBIM_SWIN_TRUNK_AMP", "1") != "0"
-_SPLITK_DW = os.environ.get("CBIM_SWIN_SPLITK_DW", "1") != "0"
-# round 5: the token Linears of the trunk on the engine's own row-GEMM kernel (functional.TokenLinearFn: bias, GELU-on-load,
-# GELU' mask and the fp32 residual add in the kernel) instead of F.linear (hipBLASLt) + ATen element-wise launches; bf16 engine
-# mode only (the fp32 parity mode keeps torch's fp32 GEMMs).  CBIM_SWIN_TOKEN_GEMM=0: the round-4 path (A/B)
-_TOKEN_GEMM = os.environ.get("CBIM_SWIN_TOKEN_GEMM", "1") != "0"
+# The token Linears of the trunk run on the engine's own row-GEMM kernel in the bf16 engine mode (functional.TokenLinearFn: bias,
+# GELU on load, GELU' mask and the fp32 residual add in the kernel; round 5); the fp32 parity mode keeps torch's fp32 GEMMs unless
+# set_fp32_token_gemm(True) (round 6, below).
 
 
 def _on_engine_device(x) -> bool:
@@ -191,13 +182,13 @@ def _on_engine_device(x) -> bool:
 def _trunk_bf16(x) -> bool:
     """True when the trunk's token Linears / GELU / window attention run in bf16 (the bf16 engine mode, like the reference under
     AMP): LayerNorm and the residual stream stay fp32"""
-    return _on_engine_device(x) and Fn.compute_dtype() == torch.bfloat16 and _TRUNK_AMP
+    return _on_engine_device(x) and Fn.compute_dtype() == torch.bfloat16
 
 
 def _in_tree(x, lin) -> bool:
     w = lin.weight
     cin = w.numel() // w.shape[0]
-    return (_TOKEN_GEMM and _trunk_bf16(x) and x.dtype in (torch.bfloat16, torch.float32) and cin % 8 == 0 and w.shape[0] % 8 == 0
+    return (_trunk_bf16(x) and x.dtype in (torch.bfloat16, torch.float32) and cin % 8 == 0 and w.shape[0] % 8 == 0
             and cin <= 4096 and w.dtype == torch.float32)
 
 
@@ -205,7 +196,7 @@ def _in_tree(x, lin) -> bool:
 # against the weight image AND its residue image (three MFMAs per fragment pair: an fp32-accurate product), fp32 out — so that the
 # fp32 goldens pin k_conv_pw's token mode at model level instead of hipBLASLt.  Off by default: the weight
 # gradient of that kernel rounds its operands to bf16, so the default fp32 mode keeps torch's fp32 GEMMs for the backward's sake.
-_FP32_TOKEN_GEMM = os.environ.get("CBIM_SWIN_FP32_TOKEN_GEMM", "0") != "0"
+_FP32_TOKEN_GEMM = False
 
 
 def set_fp32_token_gemm(on: bool) -> bool:
@@ -225,60 +216,16 @@ def _lin32(lin, x, res=None):
     return Fn.token_linear(x, lin.weight, lin.bias, res=res, out_dtype=torch.float32, exact=True)
 
 
-class _TokenLinearFn(torch.autograd.Function):
-    """``F.linear`` on [tokens, C] rows whose weight gradient is a split-K batched GEMM.  At the first stage there
-    are 262 144 tokens and 48..192 features: dW = dY^T X is then a (192 x 262144) x (262144 x 48) product for which
-    the library picks a 64x64 output tiling = 3 workgroups on 256 CUs (567 us per layer).  64 K-slices as one bmm
-    plus an fp32 sum of the partials fill the chip."""
-
-    @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=None)
-    def forward(ctx, x, w, b):
-        y = F.linear(x, w, b)
-        # tensors as the GEMM saw them (under autocast: the bf16 casts), so that backward runs in the same dtype
-        xs, ws = (x.to(y.dtype), w.to(y.dtype)) if y.dtype != x.dtype else (x, w)
-        ctx.save_for_backward(xs, ws)
-        ctx.has_b = b is not None
-        return y
-
-    @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        gy = gy.to(x.dtype)
-        gx = gy @ w if ctx.needs_input_grad[0] else None
-        x2, g2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
-        T = int(x2.shape[0])
-        S = 64 if (T >= 32768 and T % 64 == 0) else 1
-        if S > 1:
-            gw = torch.bmm(g2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1)).float().sum(0)
-        else:
-            gw = (g2.t() @ x2).float()
-        gb = None
-        if ctx.has_b:
-            cp = 8 if g2.dtype == torch.bfloat16 else 4
-            if g2.is_contiguous() and g2.dtype in (torch.bfloat16, torch.float32) and g2.shape[1] % cp == 0 and g2.shape[1] // cp <= 256:
-                gb = ops_colsum(g2)                    # one pass over the gradient rows (no fp32 copy, fixed order)
-            else:
-                gb = g2.float().sum(0)
-        return gx, gw, gb
-
-
 def _token_linear(lin, x):
-    if _SPLITK_DW and x.is_cuda and torch.is_grad_enabled() and lin.weight.requires_grad:
-        return _TokenLinearFn.apply(x, lin.weight, lin.bias)
+    """the fp32 parity mode's Linear: torch's own GEMM (and its autograd)"""
     return lin(x)
 
 
-_FUSED_LN = os.environ.get("CBIM_SWIN_FUSED_LN", "1") != "0"
-_FUSED_MERGE = os.environ.get("CBIM_SWIN_FUSED_MERGE", "1") != "0"
-_DUAL_CONV = os.environ.get("CBIM_SWIN_DUAL_CONV", "1") != "0"     # round 5: conv1 | conv3 of a UnetResBlock as one autograd node
-_FUSED_RES = os.environ.get("CBIM_SWIN_FUSED_RES", "1") != "0"     # round 5: residual-stream gradient added inside k_layernorm_bwd
 
 
 def _layer_norm(ln, x, out_dtype):
     """nn.LayerNorm `ln` applied by the HIP kernel (fp32 rows in, `out_dtype` out) — torch's own op for shapes it does not take"""
-    if _FUSED_LN and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 3072:
+    if x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 3072:
         return Fn.layer_norm(x, ln.weight, ln.bias, ln.eps, out_dtype)
     return ln(x)
 
@@ -383,7 +330,7 @@ class SwinTransformerBlock(nn.Module):
         amp = _trunk_bf16(x)
         nd = torch.bfloat16 if amp else torch.float32       # the LayerNorm kernel stores what the Linears consume
         with torch.autocast(x.device.type, dtype=torch.bfloat16, enabled=amp):      # (the Linears that stay on torch: odd widths)
-            if _FUSED_LN and _FUSED_RES and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 3072:
+            if x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 3072:
                 # (LN(x), x) as one autograd node: its backward adds the residual-stream gradient inside the LayerNorm kernel
                 y, xr = Fn.LayerNormResFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, nd)
                 x = self.attn(y, ws, ss, res=xr)
@@ -419,7 +366,7 @@ class PatchMerging(nn.Module):
         if (d % 2) or (h % 2) or (w % 2):
             x = F.pad(x, (0, 0, 0, w % 2, 0, h % 2, 0, d % 2))
         cdiv = 8 if x.dtype == torch.bfloat16 else 4
-        if _FUSED_MERGE and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % cdiv == 0:
+        if x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % cdiv == 0:
             # the 8 strided slices as ONE gather kernel (octant o = 4 i + 2 j + k), then the v0.9 slice order — with its
             # repeated octants — as an index_select over the 8 channel blocks.  The slice-by-slice form costs autograd one
             # zero-filled full-size tensor and one strided add per slice in the backward (16 launches per layer).
@@ -469,7 +416,7 @@ class SwinTransformer(nn.Module):
         def out(t):   # proj_out (:970-983): F.layer_norm(x, [ch]) without affine parameters
             if not normalize:
                 return t
-            if _FUSED_LN and t.dtype == torch.float32 and t.shape[-1] % 4 == 0 and t.shape[-1] <= 3072:
+            if t.dtype == torch.float32 and t.shape[-1] % 4 == 0 and t.shape[-1] <= 3072:
                 return Fn.layer_norm(t, None, None, 1e-5, od)
             return F.layer_norm(t, (t.shape[-1],))
         x = self.patch_embed(x)

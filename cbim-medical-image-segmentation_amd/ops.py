@@ -250,11 +250,11 @@ def upcat_fwd_stats(low, skip, skip_first: bool = True, eps: float = IN_EPS):
     return out, stats
 
 
-UP_TILES = __import__("os").environ.get("CBIM_UP_TILES", "1") not in ("", "0")   # LDS-tiled up-path kernels (up_tile_kernels.hip); off: the gather kernels (A/B, tests)
+UP_TILES = True   # LDS-tiled up-path kernels (up_tile_kernels.hip); off: the gather kernels (A/B, tests)
 _UNSUPPORTED = -2   # CBIM_EUNSUPPORTED
 
 
-UP_GRAM = __import__("os").environ.get("CBIM_UP_GRAM", "1") not in ("", "0")   # statistics of the up-sampled tensor from the coarse grid (k_up_gram_stats)
+UP_GRAM = True   # statistics of the up-sampled tensor from the coarse grid (k_up_gram_stats)
 
 
 def up_stats(low, out_dhw, eps: float = IN_EPS):
@@ -301,7 +301,7 @@ def upcat_act_fwd(low, skip, stats_cat, act: int, skip_first: bool = True):
     return out
 
 
-UP_SEPARABLE = __import__("os").environ.get("CBIM_UP_SEPARABLE", "1") not in ("", "0")   # dup -> dlow as three 1-D passes; off: the one-pass gather (A/B, tests)
+UP_SEPARABLE = True   # dup -> dlow as three 1-D passes; off: the one-pass gather (A/B, tests)
 
 
 def _lin_adjoint(src, src_row, c_off, dst, outer, F, L, inner, vec=0):
@@ -849,7 +849,7 @@ def dwconv(x, w2d, k, in_stats=None, act: int = 0, bias=None, flip: bool = False
     return y
 
 
-DW_WGRAD_MFMA = __import__("os").environ.get("CBIM_DW_WGRAD_MFMA", "1") not in ("", "0")   # depthwise wgrad on k_wgrad_r32 (diagonal of 32-channel groups)
+DW_WGRAD_MFMA = True   # depthwise wgrad on k_wgrad_r32 (diagonal of 32-channel groups)
 
 
 def dwconv_wgrad_on_matrix_cores(x, k) -> bool:
@@ -1022,8 +1022,8 @@ def colsoftmax_pool_fwd(fw, Cf: int):
     return mp, cs
 
 
-MAPPOOL_BWD_GEMM = __import__("os").environ.get("CBIM_MAPPOOL_BWD_GEMM", "1") not in ("", "0")   # backward as two library GEMMs (off: k_mappool_bwd4)
-MAPPOOL_BWD_GEMM_MAX_L = int(__import__("os").environ.get("CBIM_MAPPOOL_BWD_GEMM_MAX_L", "1024"))   # voxels per image up to which it is used
+MAPPOOL_BWD_GEMM = True   # backward as two library GEMMs (off: k_mappool_bwd4)
+MAPPOOL_BWD_GEMM_MAX_L = 1024   # voxels per image up to which it is used
 
 
 def colsoftmax_pool_bwd(fw, Cf: int, mp, cs, dmap):

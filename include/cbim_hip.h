@@ -231,7 +231,7 @@ int cbim_conv_r32_tile_depth(int td);
 /* Round-4 form of that kernel (conv_rw.hip: plane-major buffer-addressed LDS-DMA, statistics sums in LDS, optional 64 output
  * channels per workgroup): on = 0 keeps every call on k_conv3_r32 / k_conv_igemm, wide = 0 keeps 32-channel workgroups; a
  * negative value leaves a switch as it is.  Returns the previous (on | wide << 1).  Process-wide knob for tests and tools
- * (env CBIM_CONV_RW, CBIM_CONV_RW_WIDE give the defaults); both kernels compute the same function. */
+ * (defaults 1, 1); both kernels compute the same function. */
 int cbim_conv_rw_enable(int on, int wide);
 /* Round 6 — 3x3x3 layers with Cout in multiples of 48 that the 32-channel kernels do not take (Cin or Cout not a multiple of
  * 32; Cin any multiple of 8): k_conv3_rw48 of conv_rw.hip, 48 output channels per workgroup with the tile's twelve (16-cout
@@ -244,7 +244,7 @@ int cbim_conv_rw_enable(int on, int wide);
 int cbim_conv_rw48_enable(int on);
 int cbim_conv_rw48_takes(const cbim_conv_desc* desc);
 /* bf16 1x1x1 convolutions on the row-GEMM kernel (conv_pw.hip) instead of k_conv_igemm: on = 0 | 1, < 0 only queries; returns the
- * previous value (default 1; env CBIM_CONV_PW).  The two kernels compute the same function. */
+ * previous value (default 1).  The two kernels compute the same function. */
 int cbim_conv_pw_enable(int on);
 /* Tile configuration the launcher picks for `desc`: out = {MT, NTL, tD, tH} (m-tiles per wave,
  * n-tiles per wave, tile depth, tile height; tile width is 8).  Informational (profiling labels). */
@@ -382,7 +382,7 @@ int cbim_dwconv3d(int dtype, const void* x, int64_t x_stride, const float* in_st
                   const float* bias, const float* w, int flip, void* y, int64_t y_stride, int N, int D,
                   int H, int W, int C, int kD, int kH, int kW, void* stream);
 /* 3x3x3-class depthwise convolutions on the LDS-tiled kernel (round 4) instead of the streaming one: on = 0 | 1, < 0 only queries;
- * returns the previous value (default 1; env CBIM_DWCONV_LDS).  Same function; in bf16 the transformed input is rounded to bf16. */
+ * returns the previous value (default 1).  Same function; in bf16 the transformed input is rounded to bf16. */
 int cbim_dwconv_lds_enable(int on);
 /* dw[c][t] = sum_{n,l} a(x)[n,l+off(t),c] * (dy[n,l,c] + dy_bias[n][c]); deterministic two-stage sum. */
 size_t cbim_dwconv3d_wgrad_workspace(int N, int D, int H, int W, int C, int kD, int kH, int kW);
