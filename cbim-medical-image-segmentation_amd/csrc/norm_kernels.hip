@@ -327,23 +327,44 @@ __device__ __forceinline__ void resnorm_pre(const float* fa, const float* fb, co
   }
 }
 
+// (round 6: fixed channel chunk per thread, the chunk's statistics in registers, RU rows in flight — the first form walked a flat
+//  index: two 64-bit divisions and 32-64 statistics loads per 16-byte chunk; k_resnorm_apply ran at 3.2 TB/s, 313 us at 128^3 x 48)
 template <typename T>
 __global__ void __launch_bounds__(NT) k_resnorm_fwd(const void* __restrict__ a, int64_t as, const float* __restrict__ sa,
                                                     const void* __restrict__ b, int64_t bs, const float* __restrict__ sb,
-                                                    void* __restrict__ y, int64_t ys, int64_t S, int C, int act,
-                                                    int64_t total) {
+                                                    void* __restrict__ y, int64_t ys, int64_t S, int C, int act, int Cl, int c_off) {
   constexpr int CPC = Elem<T>::CPC;
-  const int cch = C / CPC;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
-    int cc = (int)(i % cch);
-    int64_t row = i / cch, n = row / S;
-    float fa[CPC], fb[CPC], xa[CPC], xb[CPC], pre[CPC];
-    Elem<T>::unpack(ld_chunk<T>(a, (size_t)row * as + (size_t)cc * CPC), fa);
-    Elem<T>::unpack(ld_chunk<T>(b, (size_t)row * bs + (size_t)cc * CPC), fb);
-    resnorm_pre<T>(fa, fb, sa + ((size_t)n * C + cc * CPC) * 2, sb ? sb + ((size_t)n * C + cc * CPC) * 2 : nullptr, xa, xb, pre);
+  const int cch = C / CPC, vlc = NT / cch;
+  const int cc = threadIdx.x % cch + c_off / CPC, vl = threadIdx.x / cch;
+  if (vl >= vlc) return;
+  const int n = blockIdx.y;
+  float ca[2 * CPC], cb[2 * CPC];
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) pre[j] = act_fwd(pre[j], act);
-    st_chunk<T>(y, (size_t)row * ys + (size_t)cc * CPC, Elem<T>::pack(pre));
+  for (int j = 0; j < 2 * CPC; ++j) {
+    ca[j] = sa[((size_t)n * Cl + cc * CPC) * 2 + j];
+    cb[j] = sb ? sb[((size_t)n * Cl + cc * CPC) * 2 + j] : 0.f;
+  }
+  const size_t nb = (size_t)n * S;
+  const int64_t step = (int64_t)gridDim.x * vlc;
+  for (int64_t v = (int64_t)blockIdx.x * vlc + vl; v < S; v += step * RU) {
+    u32x4 ra[RU], rb[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (v + u * step < S) {
+        ra[u] = ld_chunk<T>(a, (nb + v + u * step) * as + (size_t)cc * CPC);
+        rb[u] = ld_chunk<T>(b, (nb + v + u * step) * bs + (size_t)cc * CPC);
+      }
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (v + u * step < S) {
+        float fa[CPC], fb[CPC], xa[CPC], xb[CPC], pre[CPC];
+        Elem<T>::unpack(ra[u], fa);
+        Elem<T>::unpack(rb[u], fb);
+        resnorm_pre<T>(fa, fb, ca, sb ? cb : nullptr, xa, xb, pre);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) pre[j] = act_fwd(pre[j], act);
+        st_chunk<T>(y, (nb + v + u * step) * ys + (size_t)cc * CPC, Elem<T>::pack(pre));
+      }
   }
 }
 
@@ -410,26 +431,48 @@ __global__ void __launch_bounds__(NT) k_resnorm_apply(const void* __restrict__ d
                                                       const float* __restrict__ ma, const void* __restrict__ b, int64_t bs,
                                                       const float* __restrict__ sb, const float* __restrict__ mb,
                                                       void* __restrict__ da, void* __restrict__ db, int64_t S, int C,
-                                                      int act, int64_t total) {
-  constexpr int CPC = Elem<T>::CPC;
-  const int cch = C / CPC;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
-    int cc = (int)(i % cch);
-    int64_t row = i / cch, n = row / S;
-    const size_t so = ((size_t)n * C + cc * CPC) * 2;
-    float fa[CPC], fb[CPC], fg[CPC], xa[CPC], xb[CPC], pre[CPC], oa[CPC], ob[CPC];
-    Elem<T>::unpack(ld_chunk<T>(a, (size_t)row * as + (size_t)cc * CPC), fa);
-    Elem<T>::unpack(ld_chunk<T>(b, (size_t)row * bs + (size_t)cc * CPC), fb);
-    Elem<T>::unpack(ld_chunk<T>(dy, (size_t)row * dys + (size_t)cc * CPC), fg);
-    resnorm_pre<T>(fa, fb, sa + so, sb ? sb + so : nullptr, xa, xb, pre);
+                                                      int act, int Cl, int c_off) {
+  constexpr int CPC = Elem<T>::CPC, RA = 2;
+  const int cch = C / CPC, vlc = NT / cch;
+  const int cc = threadIdx.x % cch + c_off / CPC, vl = threadIdx.x / cch;
+  if (vl >= vlc) return;
+  const int n = blockIdx.y;
+  float ca[2 * CPC], cb[2 * CPC], qa[2 * CPC], qb[2 * CPC];      // (mean, rstd) and the two backward means, per channel of the chunk
 #pragma unroll
-    for (int j = 0; j < CPC; ++j) {
-      float g = fg[j] * act_grad(pre[j], act);
-      oa[j] = sa[so + 2 * j + 1] * (g - ma[so + 2 * j] - xa[j] * ma[so + 2 * j + 1]);
-      ob[j] = sb ? sb[so + 2 * j + 1] * (g - mb[so + 2 * j] - xb[j] * mb[so + 2 * j + 1]) : g;
-    }
-    st_chunk<T>(da, (size_t)row * C + (size_t)cc * CPC, Elem<T>::pack(oa));
-    if (db) st_chunk<T>(db, (size_t)row * C + (size_t)cc * CPC, Elem<T>::pack(ob));
+  for (int j = 0; j < 2 * CPC; ++j) {
+    const size_t o = ((size_t)n * Cl + cc * CPC) * 2 + j;
+    ca[j] = sa[o]; qa[j] = ma[o];
+    cb[j] = sb ? sb[o] : 0.f; qb[j] = sb ? mb[o] : 0.f;
+  }
+  const size_t nb = (size_t)n * S;
+  const int64_t step = (int64_t)gridDim.x * vlc;
+  for (int64_t v = (int64_t)blockIdx.x * vlc + vl; v < S; v += step * RA) {
+    u32x4 ra[RA], rb[RA], rg[RA];
+#pragma unroll
+    for (int u = 0; u < RA; ++u)
+      if (v + u * step < S) {
+        ra[u] = ld_chunk<T>(a, (nb + v + u * step) * as + (size_t)cc * CPC);
+        rb[u] = ld_chunk<T>(b, (nb + v + u * step) * bs + (size_t)cc * CPC);
+        rg[u] = ld_chunk<T>(dy, (nb + v + u * step) * dys + (size_t)cc * CPC);
+      }
+#pragma unroll
+    for (int u = 0; u < RA; ++u)
+      if (v + u * step < S) {
+        float fa[CPC], fb[CPC], fg[CPC], xa[CPC], xb[CPC], pre[CPC], oa[CPC], ob[CPC];
+        Elem<T>::unpack(ra[u], fa);
+        Elem<T>::unpack(rb[u], fb);
+        Elem<T>::unpack(rg[u], fg);
+        resnorm_pre<T>(fa, fb, ca, sb ? cb : nullptr, xa, xb, pre);
+#pragma unroll
+        for (int j = 0; j < CPC; ++j) {
+          float g = fg[j] * act_grad(pre[j], act);
+          oa[j] = ca[2 * j + 1] * (g - qa[2 * j] - xa[j] * qa[2 * j + 1]);
+          ob[j] = sb ? cb[2 * j + 1] * (g - qb[2 * j] - xb[j] * qb[2 * j + 1]) : g;
+        }
+        const size_t o = (nb + v + u * step) * (size_t)Cl + (size_t)cc * CPC;
+        st_chunk<T>(da, o, Elem<T>::pack(oa));
+        if (db) st_chunk<T>(db, o, Elem<T>::pack(ob));
+      }
   }
 }
 
@@ -693,15 +736,16 @@ extern "C" int cbim_resnorm_fwd(int dtype, const void* a, int64_t a_stride, cons
                                 int act, void* stream) {
   if (int e = check_c(dtype, C)) return e;
   CBIM_CHECK(a && b && y && stats_a, CBIM_EINVAL, "null argument");
-  int cpc = dtype == CBIM_BF16 ? 8 : 4;
-  int64_t total = (int64_t)N * S * (C / cpc);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_resnorm_fwd<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, a, a_stride, stats_a, b, b_stride, stats_b,
-                y, y_stride, S, C, act, total);
-  else
-    CBIM_LAUNCH((k_resnorm_fwd<float>), dim3(grid_for(total)), dim3(NT), 0, st, a, a_stride, stats_a, b, b_stride, stats_b, y,
-                y_stride, S, C, act, total);
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    dim3 grid(row_blocks(dtype, S, Cg), N);
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_resnorm_fwd<bf16_tag>), grid, dim3(NT), 0, st, a, a_stride, stats_a, b, b_stride, stats_b, y, y_stride, S, Cg, act, C,
+                  c_off);
+    else
+      CBIM_LAUNCH((k_resnorm_fwd<float>), grid, dim3(NT), 0, st, a, a_stride, stats_a, b, b_stride, stats_b, y, y_stride, S, Cg, act, C,
+                  c_off);
+  }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
@@ -730,15 +774,16 @@ extern "C" int cbim_resnorm_bwd_apply(int dtype, const void* dy, int64_t dy_stri
                                       int C, int act, void* stream) {
   if (int e = check_c(dtype, C)) return e;
   CBIM_CHECK(dy && a && b && stats_a && sums_a && da && (!stats_b || sums_b), CBIM_EINVAL, "null argument");
-  int cpc = dtype == CBIM_BF16 ? 8 : 4;
-  int64_t total = (int64_t)N * S * (C / cpc);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CBIM_BF16)
-    CBIM_LAUNCH((k_resnorm_apply<bf16_tag>), dim3(grid_for(total)), dim3(NT), 0, st, dy, dy_stride, a, a_stride, stats_a, sums_a,
-                b, b_stride, stats_b, sums_b, da, db, S, C, act, total);
-  else
-    CBIM_LAUNCH((k_resnorm_apply<float>), dim3(grid_for(total)), dim3(NT), 0, st, dy, dy_stride, a, a_stride, stats_a, sums_a, b,
-                b_stride, stats_b, sums_b, da, db, S, C, act, total);
+  FOR_CHANNEL_GROUPS(dtype, C) {
+    dim3 grid(row_blocks(dtype, S, Cg), N);
+    if (dtype == CBIM_BF16)
+      CBIM_LAUNCH((k_resnorm_apply<bf16_tag>), grid, dim3(NT), 0, st, dy, dy_stride, a, a_stride, stats_a, sums_a, b, b_stride, stats_b,
+                  sums_b, da, db, S, Cg, act, C, c_off);
+    else
+      CBIM_LAUNCH((k_resnorm_apply<float>), grid, dim3(NT), 0, st, dy, dy_stride, a, a_stride, stats_a, sums_a, b, b_stride, stats_b,
+                  sums_b, da, db, S, Cg, act, C, c_off);
+  }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

@@ -277,6 +277,7 @@ def test_resnorm(dev, dtype):
     oc.check_resnorm(dev, dtype)
     oc.check_resnorm(dev, dtype, N=1, C=24, dhw=(2, 1, 1), with_b_stats=False)
     oc.check_resnorm(dev, dtype, N=1, C=768, dhw=(4, 4, 4))
+    oc.check_resnorm(dev, dtype, N=2, C=48, dhw=(33, 20, 17), seed=23)     # 6 chunks per row: threads 252..255 idle, ragged rows, RU in flight
 
 
 def test_fused_adamw_ema(dev):

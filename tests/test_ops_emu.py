@@ -241,6 +241,7 @@ def test_window_attention(dev, dtype):
 def test_resnorm(dev, dtype):
     oc.check_resnorm(dev, dtype)
     oc.check_resnorm(dev, dtype, N=1, C=24, dhw=(2, 1, 1), with_b_stats=False)
+    oc.check_resnorm(dev, dtype, N=2, C=48, dhw=(9, 7, 5), seed=23)        # 6 chunks per row: threads 252..255 idle, ragged rows
 
 
 def test_fused_adamw_ema(dev):
