@@ -369,6 +369,39 @@ __global__ void __launch_bounds__(NT, 2) k_conv_wgrad(WgradParams p) {
 // 64 outputs per workgroup x 4 slab phases: thread (o, ph) adds slabs ph, ph+4, .. (two independent chains), the four
 // phase sums are combined through LDS in fixed order.  (One thread per output walking all ~512 slabs left this at 108
 // workgroups for a 32x32x27 gradient: under a quarter of the chip, 21 us per call, 34 calls per step.)
+// Round 6 — the same fixed-order sum for weights with several taps, as a TRANSPOSE through LDS: a workgroup owns (co, 256 input
+// channels): for each tap the slabs' rows ws[s][tap][co][ci0 ..] are summed with coalesced loads (thread = ci) into T[tap][ci], then
+// the gradient's own rows dw[co][ci0 ..][0 .. taps) — taps x 256 contiguous floats — leave with coalesced stores.  k_wgrad_reduce
+// walks a flat output index (two 64-bit divisions per element) and writes dw with a stride of `taps` floats between lanes: on the
+// low-resolution SwinUNETR layers (192^2 ... 768^2 x 27 weights, 4-64 MB) it ran 60 us per launch, 0.6 ms per step.
+__global__ void __launch_bounds__(NT) k_wgrad_reduce_t(const float* __restrict__ ws, float* __restrict__ dw, int n_slabs, int taps,
+                                                       int Cout, int Cin, int Cout_pad, int Cin_pad) {
+  __shared__ float T[28 * 257];
+  const int t = threadIdx.x, co = blockIdx.y, ci0 = blockIdx.x * NT;
+  const size_t slab = (size_t)taps * Cout_pad * Cin_pad;
+  const int ci = ci0 + t;
+  for (int tap = 0; tap < taps; ++tap) {
+    float a0 = 0.f, a1 = 0.f;
+    if (ci < Cin) {
+      const float* src = ws + ((size_t)tap * Cout_pad + co) * Cin_pad + ci;
+      int sl = 0;
+      for (; sl + 1 < n_slabs; sl += 2) {
+        a0 += src[(size_t)sl * slab];
+        a1 += src[(size_t)(sl + 1) * slab];
+      }
+      if (sl < n_slabs) a0 += src[(size_t)sl * slab];
+    }
+    T[tap * 257 + t] = a0 + a1;
+  }
+  __syncthreads();
+  const int n_ci = Cin - ci0 < NT ? Cin - ci0 : NT;
+  float* dst = dw + ((size_t)co * Cin + ci0) * taps;
+  for (int e = t; e < n_ci * taps; e += NT) {
+    const int cl = e / taps, tap = e - cl * taps;
+    dst[e] = T[tap * 257 + cl];
+  }
+}
+
 __global__ void __launch_bounds__(NT) k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                      int n_slabs, int taps, int Cout, int Cin, int Cout_pad,
                                                      int Cin_pad, int64_t total) {
@@ -433,6 +466,8 @@ static WgCfg wg_cfg(const cbim_conv_desc* d) {
 }  // namespace cbim
 
 using namespace cbim;
+
+static void launch_reduce(const float* ws, float* dw, int n_slabs, int taps, int Cout, int Cin, int Cout_pad, int Cin_pad, hipStream_t st);
 
 extern "C" size_t cbim_conv3d_wgrad_workspace(const cbim_conv_desc* d) {
   if (!d) return 0;
@@ -584,22 +619,30 @@ extern "C" int cbim_conv3d_wgrad(const cbim_conv_desc* d, const void* x, int64_t
   else
     rc = relu ? dispatch_tpw<float, CBIM_ACT_RELU>(taps, p, grid, smem, st) : dispatch_tpw<float, -1>(taps, p, grid, smem, st);
   if (rc) return rc;
-  int64_t total = (int64_t)taps * d->Cout * d->Cin;
+  launch_reduce((const float*)workspace, dw, d->N * c.strips_per_n * (taps == 1 ? 4 : 1), taps, d->Cout, d->Cin, p.Cout_pad, p.Cin_pad, st);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+// taps > 1: the transposing form (k_wgrad_reduce_t); a single tap: the flat form
+static void launch_reduce(const float* ws, float* dw, int n_slabs, int taps, int Cout, int Cin, int Cout_pad, int Cin_pad, hipStream_t st) {
+  // the transposing form walks the slabs serially per (co, 256 ci) workgroup: for the big low-resolution weights (few slabs,
+  // hundreds of workgroups); the many-slab high-resolution layers keep the flat form (measured: Cout 48 x 1024 slabs 1017 us in
+  // the transposing form, 768 x 768 x 27 over 2 slabs 35 us against ~100; profiles/r06_s_reduce.txt)
+  if (taps > 1 && taps <= 28 && n_slabs <= 16 && Cin >= 128 && (int64_t)Cout * ((Cin + NT - 1) / NT) >= 96) {
+    CBIM_LAUNCH(k_wgrad_reduce_t, dim3((unsigned)((Cin + NT - 1) / NT), (unsigned)Cout), dim3(NT), 0, st, ws, dw, n_slabs, taps, Cout, Cin,
+                Cout_pad, Cin_pad);
+    return;
+  }
+  const int64_t total = (int64_t)taps * Cout * Cin;
   int64_t blocks = (total + 63) / 64;
   if (blocks > 4096) blocks = 4096;
-  CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, st, (const float*)workspace, dw,
-              d->N * c.strips_per_n * (taps == 1 ? 4 : 1), taps, d->Cout, d->Cin, p.Cout_pad, p.Cin_pad, total);
-  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+  CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, st, ws, dw, n_slabs, taps, Cout, Cin, Cout_pad, Cin_pad, total);
 }
 
 // the fixed-order slab reduce for launchers in other files (conv_pw.hip's token Linears): slabs [n_slabs][taps][Cout_pad][Cin_pad]
 int cbim_wgrad_reduce_launch(const float* ws, float* dw, int n_slabs, int taps, int Cout, int Cin, int Cout_pad, int Cin_pad,
                              void* stream) {
-  const int64_t total = (int64_t)taps * Cout * Cin;
-  int64_t blocks = (total + 63) / 64;
-  if (blocks > 4096) blocks = 4096;
-  CBIM_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, ws, dw, n_slabs, taps, Cout, Cin, Cout_pad,
-              Cin_pad, total);
+  launch_reduce(ws, dw, n_slabs, taps, Cout, Cin, Cout_pad, Cin_pad, (hipStream_t)stream);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
