@@ -124,6 +124,7 @@ _SIGS = {
     "cbim_dwconv3d_wgrad_workspace": (sz, [i32] * 8),
     "cbim_dwconv3d_wgrad": (i32, [i32, vp, i64, vp, i32, vp, i64, vp, vp] + [i32] * 8 + [vp, sz, vp]),
     "cbim_space_to_depth": (i32, [i32, vp, vp] + [i32] * 9 + [vp]),
+    "cbim_space_to_depth_strided": (i32, [i32, vp, vp] + [i32] * 9 + [i64, vp]),
     "cbim_attn_wide_max_codes": (i32, []),
     "cbim_bidir_attn_workspace": (sz, [i32] * 5),
     "cbim_bidir_attn_fwd": (i32, [i32, vp, i64, vp, vp, vp, vp, vp] + [i32] * 5 + [f32, vp, sz, vp]),

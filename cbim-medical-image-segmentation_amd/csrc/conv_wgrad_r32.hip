@@ -532,7 +532,8 @@ bool cbim_wgrad_r32_eligible(const cbim_conv_desc* d, const float* in_stats, con
   // round 6: channel counts in multiples of 16 run with a zero-filled last 32-channel block (SwinUNETR's 48 / 96-channel layers:
   // 48 x 48 = four (32 x 32) pairs, nine sixteenths of them inside the gradient) — still ahead of k_conv_wgrad, which pads the same way
   if (d->Cin % 32 != 0 || d->Cout % 32 != 0) {
-    if (!g_wr32_c16 || d->Cin % 16 != 0 || d->Cout % 16 != 0 || d->Cin < 32 || d->Cout < 32) return false;
+    // (Cin in multiples of 8 down to 8: the 8-channel padded network input of SwinUNETR's encoder1 — one quarter-filled block)
+    if (!g_wr32_c16 || d->Cin % 8 != 0 || d->Cout % 16 != 0 || d->Cout < 32) return false;
   }
   if (x2 && (cin_split <= 0 || cin_split >= d->Cin || cin_split % 32 != 0)) return false;
   if (dy2 && (cout_split <= 0 || cout_split >= d->Cout || cout_split % 32 != 0)) return false;

@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(NT) k_dwconv_wgrad_reduce(const float* __restr
 template <typename T>
 __global__ void __launch_bounds__(NT) k_space_to_depth(const void* __restrict__ src, void* __restrict__ dst,
                                                        int D, int H, int W, int C, int sD, int sH, int sW,
-                                                       int inverse, int64_t total) {
+                                                       int inverse, int64_t total, int64_t xs) {   // xs: row stride of the fine tensor
   constexpr int CPC = Elem<T>::CPC;
   const int Do = D / sD, Ho = H / sH, Wo = W / sW;
   const int Cm = C * sD * sH * sW, mch = Cm / CPC;
@@ -744,9 +744,9 @@ __global__ void __launch_bounds__(NT) k_space_to_depth(const void* __restrict__ 
     size_t xrow = (((size_t)n * D + dz * sD + ii) * H + ho * sH + jj) * W + wo * sW + kk;
     size_t mrow = (((size_t)n * Do + dz) * Ho + ho) * Wo + wo;
     if (inverse)
-      st_chunk<T>(dst, xrow * C + c, ld_chunk<T>(src, mrow * Cm + cm));
+      st_chunk<T>(dst, xrow * xs + c, ld_chunk<T>(src, mrow * Cm + cm));
     else
-      st_chunk<T>(dst, mrow * Cm + cm, ld_chunk<T>(src, xrow * C + c));
+      st_chunk<T>(dst, mrow * Cm + cm, ld_chunk<T>(src, xrow * xs + c));
   }
 }
 
@@ -1538,13 +1538,20 @@ extern "C" int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, c
 
 extern "C" int cbim_space_to_depth(int dtype, const void* src, void* dst, int N, int D, int H, int W, int C, int sD,
                                    int sH, int sW, int inverse, void* stream) {
+  return cbim_space_to_depth_strided(dtype, src, dst, N, D, H, W, C, sD, sH, sW, inverse, C, stream);
+}
+
+extern "C" int cbim_space_to_depth_strided(int dtype, const void* src, void* dst, int N, int D, int H, int W, int C, int sD,
+                                           int sH, int sW, int inverse, int64_t fine_stride, void* stream) {
   if (int e = check_c(dtype, C, "space_to_depth")) return e;
+  CBIM_CHECK(fine_stride >= C && fine_stride % (dtype == CBIM_BF16 ? 8 : 4) == 0, CBIM_EINVAL, "space_to_depth: row stride %lld of the "
+             "fine tensor (C = %d)", (long long)fine_stride, C);
   CBIM_CHECK(sD >= 1 && sH >= 1 && sW >= 1 && D % sD == 0 && H % sH == 0 && W % sW == 0, CBIM_EINVAL,
              "space_to_depth: %dx%dx%d not divisible by %dx%dx%d", D, H, W, sD, sH, sW);
   int cpc = dtype == CBIM_BF16 ? 8 : 4;
   int64_t total = (int64_t)N * D * H * W * (C / cpc);
   DISPATCH_T(dtype, k_space_to_depth, dim3(grid_for(total)), (hipStream_t)stream, src, dst, D, H, W, C, sD, sH, sW,
-             inverse, total);
+             inverse, total, fine_stride);
   return launch_ok("space_to_depth");
 }
 

@@ -940,6 +940,30 @@ class DepthToSpaceFn(torch.autograd.Function):
         return ops.space_to_depth(dy.contiguous(), ctx.scale), None
 
 
+class UpCatSkipFn(torch.autograd.Function):
+    """torch.cat((depth_to_space(t), skip), channel axis) of monai's UnetrUpBlock (/root/reference/model/dim3/swin_unetr.py:176-228:
+    transp_conv -> cat -> conv_block) without the stored up-sampled tensor: the scatter half of ConvTranspose3d(k = s = 2) writes
+    the first channels of the concatenated tensor directly, the skip tensor is copied behind it; the backward hands the skip's
+    gradient out as a channel-slice view and gathers the other slice back into the GEMM layout."""
+
+    @staticmethod
+    def forward(ctx, t, skip, scale):
+        N, D, H, W, Cs = map(int, skip.shape)
+        sD, sH, sW = scale
+        Cu = int(t.shape[-1]) // (sD * sH * sW)
+        out = torch.empty((N, D, H, W, Cu + Cs), dtype=t.dtype, device=t.device)
+        ops.depth_to_space_into(t.contiguous(), out, Cu, scale)
+        out[..., Cu:].copy_(skip)
+        ctx.cfg = (Cu, tuple(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Cu, scale = ctx.cfg
+        g = g if g.is_contiguous() else g.contiguous()
+        return ops.space_to_depth_from(g, Cu, scale), g[..., Cu:], None
+
+
 class NormActFn(torch.autograd.Function):
     """y = act(IN(z)) with given statistics (post-activation ConvNormAct tail, conv_layers.py:51)."""
 

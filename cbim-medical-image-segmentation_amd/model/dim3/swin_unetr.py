@@ -133,6 +133,8 @@ class UnetrUpBlock(nn.Module):
         cout = w.shape[1]
         w_eq = w.permute(2, 3, 4, 1, 0).reshape(8 * cout, w.shape[0], 1, 1, 1)
         t, _ = Fn.NormConvFn.apply(x, None, w_eq, 0, None, False, None, _EPS)
+        if skip.is_contiguous() and skip.dtype == t.dtype and tuple(skip.shape[1:4]) == tuple(2 * v for v in t.shape[1:4]):
+            return self.conv_block(Fn.UpCatSkipFn.apply(t, skip, (2, 2, 2)))     # round 6: the up-sampled tensor is never stored
         up = Fn.DepthToSpaceFn.apply(t, (2, 2, 2))
         return self.conv_block(torch.cat((up, skip), dim=-1))
 

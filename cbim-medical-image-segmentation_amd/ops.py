@@ -901,6 +901,27 @@ def depth_to_space(dy, in_shape, scale):
     return dx
 
 
+def depth_to_space_into(t, out, Cc: int, scale):
+    """scatter t [N, D/s, H/s, W/s, s^3 Cc] into the first Cc channels of the wider channels-last tensor out [N, D, H, W, >= Cc]"""
+    _dev_ok(t, out)
+    N, D, H, W = (int(v) for v in out.shape[:4])
+    sD, sH, sW = (int(i) for i in scale)
+    check(_lib.lib().cbim_space_to_depth_strided(_dt(t), _p(t), _p(out), N, D, H, W, Cc, sD, sH, sW, 1, int(out.stride(3)), _stream(t)),
+          "space_to_depth_strided(inverse)")
+    return out
+
+
+def space_to_depth_from(g, Cc: int, scale):
+    """gather the first Cc channels of the channels-last (row-strided) tensor g [N, D, H, W, >= Cc] into [N, D/s, H/s, W/s, s^3 Cc]"""
+    _dev_ok(g)
+    N, D, H, W = (int(v) for v in g.shape[:4])
+    sD, sH, sW = (int(i) for i in scale)
+    y = torch.empty((N, D // sD, H // sH, W // sW, Cc * sD * sH * sW), dtype=g.dtype, device=g.device)
+    check(_lib.lib().cbim_space_to_depth_strided(_dt(g), _p(g), _p(y), N, D, H, W, Cc, sD, sH, sW, 0, int(g.stride(3)), _stream(g)),
+          "space_to_depth_strided")
+    return y
+
+
 def _attn_ws(N, L, heads, dh, M, dev):
     nbytes = _lib.lib().cbim_bidir_attn_workspace(N, L, heads, dh, M)
     return torch.empty((nbytes,), dtype=torch.uint8, device=dev), nbytes

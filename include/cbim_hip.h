@@ -395,6 +395,12 @@ int cbim_dwconv3d_wgrad(int dtype, const void* x, int64_t x_stride, const float*
  * (src = merged tensor, dst = [N,D,H,W,C]).  D,H,W are always the UNMERGED extents. */
 int cbim_space_to_depth(int dtype, const void* src, void* dst, int N, int D, int H, int W, int C, int sD,
                         int sH, int sW, int inverse, void* stream);
+/* The same gather / scatter with the FINE-grid tensor (the source for inverse = 0, the destination for inverse = 1) given with a
+ * row stride `fine_stride` >= C elements: round 6 — monai's UnetrUpBlock in SwinUNETR (/root/reference/model/dim3/swin_unetr.py:
+ * 176-228: ConvTranspose3d(k = s = 2) -> torch.cat((up, skip))) scatters the transposed convolution's GEMM output straight into the
+ * first C channels of the concatenated tensor, and its backward gathers from that channel slice of the gradient. */
+int cbim_space_to_depth_strided(int dtype, const void* src, void* dst, int N, int D, int H, int W, int C, int sD,
+                                int sH, int sW, int inverse, int64_t fine_stride, void* stream);
 /* BidirectionAttention core (medformer_utils.py:63-97) on qv = [q | v] rows ([N][L][2*inner], row stride
  * qv_stride), inner = heads*dh, channel c = d*heads + h ("(dim_head heads)", :43-51):
  *   attn = q_f q_m^T * scale [L x M]; feat_out = softmax_M(attn) v_m; map_out = softmax_L(attn)^T v_f.

@@ -546,6 +546,26 @@ def check_map_branch(dev, B=1, C=40, I=48, M=64, seed=81):
         assert relerr(a.cpu(), b) < 5e-5, f"{nm}: {relerr(a.cpu(), b):.3e}"
 
 
+def check_upcat_skip(dev, dtype, N=2, Cu=16, Cs=24, dhw=(2, 3, 2), seed=91):
+    """functional.UpCatSkipFn (round 6: the scatter half of ConvTranspose3d(k = s = 2) written straight into the concatenated tensor of
+    monai's UnetrUpBlock, /root/reference/model/dim3/swin_unetr.py:176-228) against torch.cat((DepthToSpaceFn(t), skip)): bit-identical
+    forward, bit-identical gradients (pure data movement)."""
+    from cbim_amd import functional as Fn
+    torch.manual_seed(seed)
+    D, H, W = dhw
+    t0 = torch.randn(N, D, H, W, 8 * Cu).to(dtype)
+    sk0 = torch.randn(N, 2 * D, 2 * H, 2 * W, Cs).to(dtype)
+    g = torch.randn(N, 2 * D, 2 * H, 2 * W, Cu + Cs).to(dtype).to(dev)
+    outs = []
+    for fused in (False, True):
+        t, sk = t0.clone().to(dev).requires_grad_(True), sk0.clone().to(dev).requires_grad_(True)
+        y = Fn.UpCatSkipFn.apply(t, sk, (2, 2, 2)) if fused else torch.cat((Fn.DepthToSpaceFn.apply(t, (2, 2, 2)), sk), -1)
+        y.backward(g)
+        outs.append((y.detach().float().cpu(), t.grad.float().cpu(), sk.grad.float().cpu()))
+    for a, b, nm in zip(outs[0], outs[1], ("forward", "d t", "d skip")):
+        assert torch.equal(a, b), f"UpCatSkipFn {nm} differs"
+
+
 def check_conv_rw_split(dev, N=1, Cin=64, Cout=64, dhw=(8, 8, 8), seed=63):
     """Low-resolution layers: k_conv3_rw over slices of the Cin chunks (blockIdx.z) + k_splitk_finish, against k_conv_igemm's
     split-K on the same call (the same finish pass: residual, activated mask, statistics) and against torch."""

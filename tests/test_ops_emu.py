@@ -180,6 +180,12 @@ def test_map_branch_small_gemm(dev):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+def test_upcat_skip_scatter_into_the_concatenation(dev, dtype):
+    oc.check_upcat_skip(dev, dtype)
+    oc.check_upcat_skip(dev, dtype, N=1, Cu=48, Cs=48, dhw=(4, 4, 4), seed=92)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_head(dev, dtype):
     oc.check_stem_head(dev, dtype)
     oc.check_stem_head(dev, dtype, N=1, Cin=1, base=72, K=6, dhw=(5, 8, 9))     # head rows of 9 / 18 chunks: chunk groups on blockIdx.z
