@@ -138,3 +138,20 @@ def test_stock_ddp_wrapper_on_one_rank_rccl():
     finally:
         cbim_amd.set_compute_dtype(None)
         dist.destroy_process_group()
+
+
+def test_bench_line_is_the_same_over_20_and_200_steps():
+    """the driver's 20-step timed region is 0.2 s of a 60 s run.  The per-step time must not depend on
+    the length of the timed region: `bench.py --steps 200` against `--steps 20` in the same process conditions, within 2 %."""
+    def run(steps):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "5",
+                            "--no-cpu-baseline", "--no-roofline", "--secondary", "0"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = run(20), run(200)
+    assert a["steps"] == 20 and b["steps"] == 200 and a["config"]["graph"] and b["config"]["graph"]
+    rel = abs(a["ms_per_step"] - b["ms_per_step"]) / b["ms_per_step"]
+    print(f"ms/step over 20 steps {a['ms_per_step']:.3f}, over 200 steps {b['ms_per_step']:.3f} ({rel * 100:.2f} %)")
+    from tests.util import record_parity
+    record_parity("bench_20_vs_200_steps", {"ms_20": a["ms_per_step"], "ms_200": b["ms_per_step"], "rel": rel})
+    assert rel < 0.02, (a["ms_per_step"], b["ms_per_step"])

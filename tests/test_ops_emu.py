@@ -132,6 +132,7 @@ def test_mappool_more_than_64_codes(dev, dtype):
 def test_trilinear_planes(dev):
     oc.check_trilinear_planes(dev)
     oc.check_trilinear_planes(dev, lo=(1, 2, 2), hi=(4, 4, 4))
+    oc.check_trilinear_planes(dev, N=2, C=3, lo=(2, 3, 4), hi=(5, 6, 8))      # four outputs per thread (Wo % 4 == 0), several rows and slabs
 
 
 def test_conv_r32_weights_in_registers(dev):
