@@ -317,4 +317,138 @@ extern "C" int cbim_map_gemm(const cbim_map_gemm_desc* d, void* stream) {
   return CBIM_OK;
 }
 
+
+// ---- SEBlock excitation on the [N, C] channel means (round 6) ------------------------------------------------------------------
+//   gate = sigmoid(W2 relu(W1 m + b1) + b2),  W1 [H, C], W2 [C, H]        (/root/reference/model/dim3/conv_layers.py:159-175: squeeze ->
+//   1x1x1 conv -> ReLU -> 1x1x1 conv -> Sigmoid; one per MBConv of MedFormer's 16 BidirectionAttentionBlocks)
+// As torch ops this was two aten::linear, relu, sigmoid forward and four aten::mm, sigmoid_backward, threshold_backward and their
+// glue backward: ~13 launches per block on vectors of 64 ... 1280 numbers.  Here: two launches forward (the second applies ReLU to
+// its input on load and the sigmoid to its output), three backward (W2^T of the sigmoid-weighted gradient with the ReLU mask in the
+// epilogue; both outer products and bias gradients; W1^T for the gradient of the means).  Fixed summation order.
+namespace cbim {
+
+// y[n][o] = epi(sum_k W[o][k] * pro(x[n][k]) + b[o]); one wave per output row, lanes stride the row (coalesced)
+template <bool RELU_IN, bool SIGMOID_OUT>
+__global__ void __launch_bounds__(256) k_se_rows(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ x,
+                                                 float* __restrict__ y, int N, int O, int K) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  const float* w = W + (size_t)o * K;
+  for (int n = 0; n < N; ++n) {
+    float acc = 0.f;
+    if ((K & 3) == 0) {          // rows of whole 16-byte groups (the weights are [O][K] contiguous: every row then starts aligned)
+      const float* xr = x + (size_t)n * K;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int k = 4 * lane; k < K; k += 256) {
+        const f32x4 wv = *(const f32x4*)(w + k);
+        f32x4 xv = *(const f32x4*)(xr + k);
+        if (RELU_IN) { xv.x = xv.x > 0.f ? xv.x : 0.f; xv.y = xv.y > 0.f ? xv.y : 0.f; xv.z = xv.z > 0.f ? xv.z : 0.f; xv.w = xv.w > 0.f ? xv.w : 0.f; }
+        a0 = fmaf(wv.x, xv.x, a0); a1 = fmaf(wv.y, xv.y, a1); a2 = fmaf(wv.z, xv.z, a2); a3 = fmaf(wv.w, xv.w, a3);
+      }
+      acc = (a0 + a1) + (a2 + a3);
+    } else {
+      for (int k = lane; k < K; k += 64) {
+        float v = x[(size_t)n * K + k];
+        if (RELU_IN) v = v > 0.f ? v : 0.f;
+        acc = fmaf(w[k], v, acc);
+      }
+    }
+    acc = mg_wave_sum(acc);
+    if (lane == 0) {
+      float r = acc + (b ? b[o] : 0.f);
+      if (SIGMOID_OUT) r = 1.f / (1.f + expf(-r));
+      y[(size_t)n * O + o] = r;
+    }
+  }
+}
+
+// the input vector of the transposed products and of the outer products: MODE 0: v[o] = u[o]; MODE 1: v[o] = dg[o] g[o] (1 - g[o])
+template <int MODE>
+__device__ __forceinline__ float se_vec(const float* __restrict__ u, const float* __restrict__ g, size_t i) {
+  if (MODE == 0) return u[i];
+  const float gg = g[i];
+  return u[i] * gg * (1.f - gg);
+}
+
+// y[n][k] = mask(sum_o W[o][k] * v[n][o]): 16 columns per workgroup (a quarter wave reads 64 contiguous bytes of a row), 64 row
+// groups stride the rows and meet in LDS in group order; RELU_MASK: y *= [z[n][k] > 0].  (64 columns per workgroup left the
+// 1280 x 320 product of the widest MBConv on five workgroups: 33 us.)
+template <int MODE, bool RELU_MASK>
+__global__ void __launch_bounds__(1024) k_se_cols(const float* __restrict__ W, const float* __restrict__ u, const float* __restrict__ g,
+                                                  const float* __restrict__ z, float* __restrict__ y, int O, int K) {
+  __shared__ float red[64][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4, k = blockIdx.x * 16 + c, n = blockIdx.y;
+  float acc = 0.f;
+  if (k < K)
+    for (int o = rg; o < O; o += 64) acc = fmaf(W[(size_t)o * K + k], se_vec<MODE>(u, g, (size_t)n * O + o), acc);
+  red[rg][c] = acc;
+  __syncthreads();
+  if (rg == 0 && k < K) {
+    float r = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) r += red[q][c];
+    if (RELU_MASK) r = z[(size_t)n * K + k] > 0.f ? r : 0.f;
+    y[(size_t)n * K + k] = r;
+  }
+}
+
+// dW[o][k] = sum_n v[n][o] * pro(x[n][k]), db[o] = sum_n v[n][o]; blockIdx.y = 0: (W2: v from (dg, g), x = relu(z1)),
+// 1: (W1: v = dz1, x = m) — both outer products of the backward in one launch
+__global__ void __launch_bounds__(256) k_se_outer(const float* __restrict__ dg, const float* __restrict__ g, const float* __restrict__ z1,
+                                                  const float* __restrict__ dz1, const float* __restrict__ m, float* __restrict__ dW2,
+                                                  float* __restrict__ db2, float* __restrict__ dW1, float* __restrict__ db1, int N, int C,
+                                                  int H) {
+  const bool second = blockIdx.y == 1;
+  const int O = second ? H : C, K = second ? C : H;
+  const int o = blockIdx.x;
+  if (o >= O) return;
+  float* dW = second ? dW1 : dW2;
+  float* db = second ? db1 : db2;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float v = second ? dz1[(size_t)n * H + o] : se_vec<1>(dg, g, (size_t)n * C + o);
+      float xv = second ? m[(size_t)n * C + k] : z1[(size_t)n * H + k];
+      if (!second) xv = xv > 0.f ? xv : 0.f;
+      acc = fmaf(v, xv, acc);
+    }
+    dW[(size_t)o * K + k] = acc;
+  }
+  if (threadIdx.x == 0 && db) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += second ? dz1[(size_t)n * H + o] : se_vec<1>(dg, g, (size_t)n * C + o);
+    db[o] = acc;
+  }
+}
+
+}  // namespace cbim
+
+extern "C" int cbim_se_gate_fwd(const float* mean, const float* W1, const float* b1, const float* W2, const float* b2, float* z1,
+                                float* gate, int N, int C, int H, void* stream) {
+  CBIM_CHECK(mean && W1 && W2 && z1 && gate && N > 0 && C > 0 && H > 0, CBIM_EINVAL, "se gate: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  CBIM_LAUNCH((k_se_rows<false, false>), dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, W1, b1, mean, z1, N, H, C);
+  CBIM_LAUNCH((k_se_rows<true, true>), dim3((unsigned)((C + 3) / 4)), dim3(256), 0, st, W2, b2, (const float*)z1, gate, N, C, H);
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "se gate fwd launch: %s", hipGetErrorString(e));
+  return CBIM_OK;
+}
+
+extern "C" int cbim_se_gate_bwd(const float* dgate, const float* gate, const float* z1, const float* mean, const float* W1,
+                                const float* W2, float* dz1_ws, float* dW1, float* db1, float* dW2, float* db2, float* dmean, int N,
+                                int C, int H, void* stream) {
+  CBIM_CHECK(dgate && gate && z1 && mean && W1 && W2 && dz1_ws && dW1 && dW2 && N > 0 && C > 0 && H > 0, CBIM_EINVAL, "se gate bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  // dz1 = (W2^T (dgate g (1 - g))) * [z1 > 0]
+  CBIM_LAUNCH((k_se_cols<1, true>), dim3((unsigned)((H + 15) / 16), (unsigned)N), dim3(1024), 0, st, W2, dgate, gate, z1, dz1_ws, C, H);
+  CBIM_LAUNCH(k_se_outer, dim3((unsigned)(C > H ? C : H), 2), dim3(256), 0, st, dgate, gate, z1, (const float*)dz1_ws, mean, dW2, db2, dW1, db1, N,
+              C, H);
+  if (dmean)
+    CBIM_LAUNCH((k_se_cols<0, false>), dim3((unsigned)((C + 15) / 16), (unsigned)N), dim3(1024), 0, st, W1, (const float*)dz1_ws, (const float*)nullptr,
+                (const float*)nullptr, dmean, H, C);
+  hipError_t e = CBIM_LAST_LAUNCH();
+  CBIM_CHECK(e == hipSuccess, CBIM_ELAUNCH, "se gate bwd launch: %s", hipGetErrorString(e));
+  return CBIM_OK;
+}
+
 CBIM_DEFINE_WARM(map)

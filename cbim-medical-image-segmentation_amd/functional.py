@@ -676,6 +676,26 @@ class BidirAttnFn(torch.autograd.Function):
         return dqv, dmq, dmv, None, None
 
 
+class SEGateFn(torch.autograd.Function):
+    """SEBlock.excitation (conv_layers.py:159-175) on the float32 [N, C] channel means: sigmoid(W2 relu(W1 m + b1) + b2) — two launches
+    forward, three backward (ops.se_gate_fwd / se_gate_bwd) instead of ~13 ATen launches on vectors of a few hundred numbers."""
+
+    @staticmethod
+    def forward(ctx, mean, w1, b1, w2, b2):
+        mean, w1, w2 = mean.float().contiguous(), w1.contiguous(), w2.contiguous()
+        gate, z1 = ops.se_gate_fwd(mean, w1, b1, w2, b2)
+        ctx.save_for_backward(mean, w1, w2, z1, gate)
+        ctx.has_b = (b1 is not None, b2 is not None)
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        mean, w1, w2, z1, gate = ctx.saved_tensors
+        dmean, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate.float().contiguous(), gate, z1, mean, w1, w2,
+                                                    need_dmean=ctx.needs_input_grad[0], need_bias=ctx.has_b)
+        return dmean, dw1, db1, dw2, db2
+
+
 class MapQVFn(torch.autograd.Function):
     """norm2 + map_qv of BidirectionAttentionBlock on the semantic map (medformer_utils.py:36,66,113,127): smap float32 [B, C, M],
     w [2 inner, C] -> (map_q, map_v) float32 [B, M, inner] — one launch forward (InstanceNorm over the positions on load), two

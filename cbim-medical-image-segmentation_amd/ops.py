@@ -1029,6 +1029,34 @@ def map_out_bwd(g, wout, mo, need_dw=True):
     return dmo, dw
 
 
+def se_gate_fwd(mean, w1, b1, w2, b2):
+    """SEBlock.excitation on the channel means: mean [N, C], w1 [H, C], w2 [C, H] (float32) -> (gate [N, C], z1 [N, H])."""
+    ts = [t for t in (mean, w1, b1, w2, b2) if t is not None]
+    _dev_ok(*ts)
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in ts), "cbim_amd: se_gate takes contiguous float32 tensors"
+    N, Cc = (int(v) for v in mean.shape)
+    H = int(w1.shape[0])
+    z1 = torch.empty((N, H), dtype=torch.float32, device=mean.device)
+    gate = torch.empty((N, Cc), dtype=torch.float32, device=mean.device)
+    check(_lib.lib().cbim_se_gate_fwd(_p(mean), _p(w1), _p(b1), _p(w2), _p(b2), _p(z1), _p(gate), N, Cc, H, _stream(mean)), "se_gate_fwd")
+    return gate, z1
+
+
+def se_gate_bwd(dgate, gate, z1, mean, w1, w2, need_dmean=True, need_bias=(True, True)):
+    _dev_ok(dgate, gate, z1, mean, w1, w2)
+    N, Cc = (int(v) for v in mean.shape)
+    H = int(w1.shape[0])
+    dev = mean.device
+    dz1 = torch.empty((N, H), dtype=torch.float32, device=dev)
+    dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+    db1 = torch.empty((H,), dtype=torch.float32, device=dev) if need_bias[0] else None
+    db2 = torch.empty((Cc,), dtype=torch.float32, device=dev) if need_bias[1] else None
+    dmean = torch.empty_like(mean) if need_dmean else None
+    check(_lib.lib().cbim_se_gate_bwd(_p(dgate), _p(gate), _p(z1), _p(mean), _p(w1), _p(w2), _p(dz1), _p(dw1), _p(db1), _p(dw2), _p(db2),
+                                      _p(dmean), N, Cc, H, _stream(mean)), "se_gate_bwd")
+    return dmean, dw1, db1, dw2, db2
+
+
 def colsoftmax_pool_fwd(fw, Cf: int):
     """fw [N,D,H,W,Cf+M] -> map float32 [N,Cf,M], colstat float32 [N,M,2]."""
     _dev_ok(fw)

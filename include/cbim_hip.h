@@ -445,6 +445,15 @@ typedef struct {
   const float* XH; const float* rstd_in;
 } cbim_map_gemm_desc;
 int cbim_map_gemm(const cbim_map_gemm_desc* desc, void* stream);
+/* Round 6 — SEBlock.excitation on the [N, C] channel means (conv_layers.py:159-175: 1x1x1 conv -> ReLU -> 1x1x1 conv -> Sigmoid; one
+ * per MBConv of MedFormer): gate = sigmoid(W2 relu(W1 mean + b1) + b2) with W1 [H][C], W2 [C][H], biases optional, all float32.
+ * fwd writes z1 = W1 mean + b1 [N][H] (kept for the backward) and gate [N][C] (two launches).  bwd (three launches) takes d gate and
+ * writes dW1 [H][C], db1 [H], dW2 [C][H], db2 [C] (sums over the N images; db* optional) and d mean [N][C] (optional); dz1_ws: float
+ * [N][H] scratch.  Replaces the aten::linear / relu / sigmoid / mm / sigmoid_backward / threshold_backward launches of rounds 1-5. */
+int cbim_se_gate_fwd(const float* mean, const float* W1, const float* b1, const float* W2, const float* b2, float* z1, float* gate,
+                     int N, int C, int H, void* stream);
+int cbim_se_gate_bwd(const float* dgate, const float* gate, const float* z1, const float* mean, const float* W1, const float* W2,
+                     float* dz1_ws, float* dW1, float* db1, float* dW2, float* db2, float* dmean, int N, int C, int H, void* stream);
 /* SemanticMapGeneration tail (medformer_utils.py:218-228) on fw rows = [feat (C) | weight logits (M)]:
  * map[n][c][j] = sum_l feat[l,c] * softmax_L(logit[:,j])[l].  colstat: float [N][M][2].
  * M <= cbim_attn_wide_max_codes(). */

@@ -566,6 +566,26 @@ def check_upcat_skip(dev, dtype, N=2, Cu=16, Cs=24, dhw=(2, 3, 2), seed=91):
         assert torch.equal(a, b), f"UpCatSkipFn {nm} differs"
 
 
+def check_se_gate(dev, N=1, C=40, H=10, seed=95):
+    """functional.SEGateFn (k_se_rows / k_se_cols / k_se_outer, round 6) against the torch ops of SEBlock.excitation
+    (/root/reference/model/dim3/conv_layers.py:159-175): gate, and the gradients of the means, both weights and both biases."""
+    from cbim_amd import functional as Fn
+    torch.manual_seed(seed)
+    m = torch.randn(N, C) * 0.8 + 0.3
+    w1, b1 = torch.randn(H, C) * 0.3, torch.randn(H) * 0.2
+    w2, b2 = torch.randn(C, H) * 0.3, torch.randn(C) * 0.2
+    gout = torch.randn(N, C)
+    ref = [t.clone().requires_grad_(True) for t in (m, w1, b1, w2, b2)]
+    r = torch.sigmoid(F.linear(F.relu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4]))
+    r.backward(gout)
+    eng = [t.clone().to(dev).requires_grad_(True) for t in (m, w1, b1, w2, b2)]
+    e = Fn.SEGateFn.apply(*eng)
+    e.backward(gout.to(dev))
+    assert relerr(e.detach().cpu(), r.detach()) < 1e-5, "se gate"
+    for nm, a, b in zip(("d mean", "d w1", "d b1", "d w2", "d b2"), eng, ref):
+        assert relerr(a.grad.cpu(), b.grad) < 2e-5, f"se gate {nm}: {relerr(a.grad.cpu(), b.grad):.3e}"
+
+
 def check_conv_rw_split(dev, N=1, Cin=64, Cout=64, dhw=(8, 8, 8), seed=63):
     """Low-resolution layers: k_conv3_rw over slices of the Cin chunks (blockIdx.z) + k_splitk_finish, against k_conv_igemm's
     split-K on the same call (the same finish pass: residual, activated mask, statistics) and against torch."""

@@ -128,6 +128,12 @@ def test_map_branch_small_gemm(dev):
     oc.check_map_branch(dev, B=1, C=32, I=32, M=128, seed=84)         # the largest map
 
 
+def test_se_gate_excitation_kernels(dev):
+    oc.check_se_gate(dev)                                      # 40 channels, 10 hidden
+    oc.check_se_gate(dev, N=2, C=136, H=34, seed=96)           # two images (weight gradients summed), ragged column blocks
+    oc.check_se_gate(dev, N=1, C=1280, H=320, seed=97)         # MedFormer's widest MBConv (4 x 320 expanded channels)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_upcat_skip_scatter_into_the_concatenation(dev, dtype):
     oc.check_upcat_skip(dev, dtype)
