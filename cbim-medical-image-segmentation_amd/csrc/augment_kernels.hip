@@ -154,7 +154,7 @@ __global__ void k_chan_stats_final(const float* __restrict__ partials, int nblk,
 // mode 0: y = x*a + b                       (brightness_multiply / additive; prm = {a, b} per channel)
 // mode 1: y = pow((x-min)/rng, g)*rng + min (gamma, :126;  prm = {g}; st = stats of x)
 // mode 2: y = (x - m2)/s2*s1 + m1           (retain_stats, :128-130; st = stats of gamma output, st2 = of input)
-// mode 3: y = clamp((x-mean)*f + mean, min, max) (contrast, :158-161; prm = {f})
+// mode 3: y = clamp((x-mean)*f + mean, min, max) (contrast, :158-161; prm = {f, 1 = preserve_range False: no clamp})
 // mode 4: y = x + noise*a + b               (gaussian_noise, :17; prm = {std, mean})
 // stats index: stat_c = per_channel ? c : 0;  prm index likewise (prm_stride floats per channel)
 __global__ void __launch_bounds__(NT) k_intensity(const float* __restrict__ x, float* __restrict__ y, int C,
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(NT) k_intensity(const float* __restrict__ x, f
     if (mode == 0) r = v * pr[0] + pr[1];
     else if (mode == 1) { float mn = s1p[0], rng = s1p[1] - s1p[0]; r = powf((v - mn) / rng, pr[0]) * rng + mn; }
     else if (mode == 2) r = (v - s1p[2]) / s1p[3] * s2p[3] + s2p[2];
-    else if (mode == 3) { float m = s1p[2]; r = fminf(fmaxf((v - m) * pr[0] + m, s1p[0]), s1p[1]); }
+    else if (mode == 3) { float m = s1p[2]; r = (v - m) * pr[0] + m; if (pr[1] == 0.f) r = fminf(fmaxf(r, s1p[0]), s1p[1]); }
     else r = v + noise[(int64_t)c * S + i] * pr[0] + pr[1];
     yc[i] = r;
   }

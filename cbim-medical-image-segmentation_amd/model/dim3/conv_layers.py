@@ -48,6 +48,39 @@ def _raw_input_conv(cna, a, dtype):
     return Fn.NormConvFn.apply(t, None, w, 0, None, False, None, IN_EPS)[0]
 
 
+def bn_act(bn, t, act_code=0):
+    """act(BatchNorm3d(t)) on a channels-last tensor through the module `bn` (a parameter / buffer holder): batch statistics +
+    running-statistics update in train(), the running statistics in eval() (or when they are not tracked: always batch
+    statistics) — nn.BatchNorm3d.forward semantics"""
+    batch = bn.training or bn.running_mean is None
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = bn.momentum
+    if mom is None:                                   # cumulative moving average
+        mom = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return Fn.BatchNormActFn.apply(t, bn.weight, bn.bias, rm, rv, mom, bn.eps, act_code, batch)
+
+
+def norm_rows(norm, t, act_code=0):
+    """act(norm(t)) of a channels-last tensor through a `norm: bn | ln` module (nn.BatchNorm3d / trans_layers.LayerNorm)"""
+    if isinstance(norm, nn.BatchNorm3d):
+        return bn_act(norm, t, act_code)
+    y = norm.rows(t)
+    return y if act_code == 0 else Fn.ActFn.apply(y, act_code)
+
+
+def make_norm(kind, ch):
+    """`norm(ch)` as the reference's blocks build it OUTSIDE ConvNormAct (default eps 1e-5: medformer_utils.py:112-113,158):
+    nn.Identity for `in` (no parameters; the arithmetic is fused into the kernels), else the parameter holder"""
+    if kind == "bn":
+        return nn.BatchNorm3d(ch)
+    if kind == "ln":
+        from .trans_layers import LayerNorm
+        return LayerNorm(ch)
+    return nn.Identity()
+
+
 class ConvNormAct(nn.Module):
     """Parameter holder for one conv + (norm, act) description (conv_layers.py:16-53)."""
 
@@ -68,14 +101,10 @@ class ConvNormAct(nn.Module):
             # `norm: bn` (model/dim3/utils.py:15-21 of the reference): nn.BatchNorm3d(eps=1e-4) over in_ch (pre-activation) or
             # out_ch (conv_layers.py:40-43) — a PARAMETER / BUFFER holder with the reference's state_dict keys; its arithmetic
             # runs on the affine norm kernels (functional.BatchNormActFn)
-            if groups != 1:
-                raise NotImplementedError("cbim_amd: norm 'bn' is built for the dense convolutions of the UNet family")
             self.norm = nn.BatchNorm3d(in_ch if preact else out_ch, eps=IN_EPS)
         elif norm == "ln":
             # `norm: ln`: the reference's channels-first LayerNorm(eps=1e-4) (trans_layers.py:120-149) — per voxel over the
             # channels, which in the engine's channels-last layout is the token-row LayerNorm kernel
-            if groups != 1:
-                raise NotImplementedError("cbim_amd: norm 'ln' is built for the dense convolutions of the UNet family")
             from .trans_layers import LayerNorm
             self.norm = LayerNorm(in_ch if preact else out_ch, eps=IN_EPS)
         elif norm in ("in", None, False, True):
@@ -83,6 +112,7 @@ class ConvNormAct(nn.Module):
         else:
             raise NotImplementedError(f"cbim_amd: norm '{norm}' is not built")
         self.norm_kind = norm if norm in ("bn", "ln") else "in"
+        self.depthwise = groups != 1
         self.act = nn.Identity()
         self.act_code = ACT[act]
         self.preact = preact
@@ -95,17 +125,7 @@ class ConvNormAct(nn.Module):
         return self._bn_act(t)
 
     def _bn_act(self, t):
-        """act(BatchNorm3d(t)) on a channels-last tensor: batch statistics + running-statistics update in train(), the running
-        statistics in eval() (or when they are not tracked: always batch statistics) — nn.BatchNorm3d.forward semantics"""
-        bn = self.norm
-        batch = bn.training or bn.running_mean is None
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        mom = bn.momentum
-        if mom is None:                                   # cumulative moving average
-            mom = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
-        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        return Fn.BatchNormActFn.apply(t, bn.weight, bn.bias, rm, rv, mom, bn.eps, self.act_code, batch)
+        return bn_act(self.norm, t, self.act_code)
 
     def apply_generic(self, t, res=None):
         """The composed (unfused) form of ConvNormAct.forward for `norm: bn`: conv(act(BN(t))) [+ res] (pre-activation) or
@@ -121,6 +141,9 @@ class ConvNormAct(nn.Module):
     def raw_conv(self, a, res=None):
         """conv(a) [+ res] of a tensor used as it is: the stride-1 kernels directly, a stride of 2 through its space-to-depth form
         (functional.strided_conv; down_block(pool=False), unet_utils.py:36-39 of the reference)"""
+        if self.depthwise:
+            y = Fn.DWConvFn.apply(a, None, self.conv.weight, 0, False)[0]
+            return y if res is None else y + res
         if self.stride == (1, 1, 1):
             return Fn.NormConvFn.apply(a, None, self.conv.weight, 0, res, False, None, IN_EPS)[0]
         y = Fn.strided_conv(a, self.conv.weight, self.stride)
@@ -311,6 +334,11 @@ class SEBlock(nn.Module):
         return torch.sigmoid(F.linear(h, c2.weight.flatten(1), c2.bias))
 
 
+def _se_scale(t, gate):
+    """x * excitation (conv_layers.py:175) on a channels-last tensor: gate [N, C] broadcast over the voxels"""
+    return t * gate.to(t.dtype).view(gate.shape[0], 1, 1, 1, gate.shape[1])
+
+
 class MBConv(nn.Module):
     """expand 1x1 -> depthwise k^3 -> SE -> project 1x1, every ConvNormAct pre-activated, identity
     shortcut — conv_layers.py:197-238 (the MedFormer feed-forward, medformer_utils.py:124)."""
@@ -330,6 +358,13 @@ class MBConv(nn.Module):
         self.shortcut = nn.Sequential()
 
     def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
+        if self.expand_proj.norm_kind != "in":
+            # `norm: bn | ln` (round 6; no shipped yaml): the composed path — every pre-activation written by one streaming pass
+            # (affine norm kernels), the convolutions read it as it is, the SE gate is one broadcast multiply
+            e = self.expand_proj.apply_generic(f.t)
+            d, mean, _ = Fn.DWConvFn.apply(self.depthwise._norm_act(e), None, self.depthwise.conv.weight, 0, True)
+            gate = self.se.gate(mean)
+            return Fn.FMap(self.pointwise.apply_generic(_se_scale(d, gate), res=f.t), None)
         f = Fn.ensure_stats(f)
         act = self.expand_proj.act_code
         e, se_ = Fn.NormConvFn.apply(f.t, f.stats, self.expand_proj.conv.weight, act, None, True, None, IN_EPS)
@@ -359,6 +394,10 @@ class FusedMBConv(nn.Module):
         self.shortcut = nn.Sequential()
 
     def forward(self, f: Fn.FMap, want_out_stats=True) -> Fn.FMap:
+        if self.conv3x3.norm_kind != "in":            # `norm: bn | ln`: the composed path (see MBConv.forward)
+            e = self.conv3x3.apply_generic(f.t)
+            gate = self.se_block.gate(e.float().mean(dim=(1, 2, 3)))
+            return Fn.FMap(self.pointwise.apply_generic(_se_scale(e, gate), res=f.t), None)
         f = Fn.ensure_stats(f)
         act = self.conv3x3.act_code
         e, se_ = Fn.NormConvFn.apply(f.t, f.stats, self.conv3x3.conv.weight, act, None, True, None, IN_EPS)

@@ -21,7 +21,7 @@ class MedFormer(nn.Module):
         if conv_block != "BasicBlock":
             raise NotImplementedError("cbim_amd: MedFormer conv_block must be 'BasicBlock' (as in every shipped config)")
         dim_head = [chan_num[i] // num_heads[i] for i in range(8)]
-        block, norm, act = get_block(conv_block), get_norm(norm, allow=("in",)), get_act(act)
+        block, norm, act = get_block(conv_block), get_norm(norm), get_act(act)
         kw = dict(expansion=expansion, attn_drop=attn_drop, proj_drop=proj_drop, map_size=map_size, proj_type=proj_type,
                   norm=norm, act=act, conv_block=block)
         c = chan_num

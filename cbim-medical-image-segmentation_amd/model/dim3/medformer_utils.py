@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from ... import functional as Fn
 from ...ops import ACT, IN_EPS, MAP_MAX_POSITIONS
-from .conv_layers import BasicBlock, ConvNormAct, DepthwiseSeparableConv, FusedMBConv, MBConv, _k3
+from .conv_layers import BasicBlock, ConvNormAct, DepthwiseSeparableConv, FusedMBConv, MBConv, _k3, make_norm, norm_rows
 from .trans_layers import TransformerBlock
 
 _EPS_DEFAULT = 1e-5   # nn.InstanceNorm3d default, used by norm1/norm2 and PatchMerging.norm (:112-113,:158)
@@ -108,8 +108,11 @@ class BidirectionAttentionBlock(nn.Module):
                  attn_drop=0., proj_drop=0., map_size=(8, 8, 8), proj_type="depthwise", kernel_size=(3, 3, 3),
                  no_map_out=False):
         super().__init__()
-        self.norm1 = nn.Identity()   # InstanceNorm3d(feat_dim), eps 1e-5: fused into feat_qv's depthwise load
-        self.norm2 = nn.Identity()   # InstanceNorm3d(map_dim) on <= 64 positions: torch op below
+        # `in`: InstanceNorm3d(feat_dim), eps 1e-5, fused into feat_qv's depthwise load / InstanceNorm3d(map_dim) inside the map
+        # kernels (no parameters: nn.Identity holders).  `bn | ln` (round 6): the reference's parameter holders, composed path
+        self.norm_kind = norm if norm in ("bn", "ln") else "in"
+        self.norm1 = make_norm(self.norm_kind, feat_dim)
+        self.norm2 = make_norm(self.norm_kind, map_dim)
         self.attn = BidirectionAttention(feat_dim, map_dim, out_dim, heads, dim_head, attn_drop=attn_drop,
                                          proj_drop=proj_drop, map_size=map_size, proj_type=proj_type,
                                          kernel_size=kernel_size, no_map_out=no_map_out)
@@ -122,6 +125,14 @@ class BidirectionAttentionBlock(nn.Module):
             self.feedforward = MBConv(out_dim, out_dim, expansion=expansion, kernel_size=kernel_size, act=act, norm=norm)
 
     def forward(self, f: Fn.FMap, semantic_map, want_out_stats=True):
+        if self.norm_kind != "in":
+            # medformer_utils.py:126-138 step by step: norm1 of the features by one streaming pass (affine norm kernels), norm2 of
+            # the <= 128-position map through the holder's own forward, the attention on the normalised tensors as they are
+            feat = norm_rows(self.norm1, f.t)
+            mapp = self.norm2(semantic_map)
+            res = self.shortcut.apply_generic(f.t) if isinstance(self.shortcut, ConvNormAct) else f.t
+            out, mapp = self.attn(feat, None, mapp, res, False)
+            return self.feedforward(out, want_out_stats), mapp + semantic_map
         f = Fn.ensure_stats(f)                                   # eps 1e-4 (ConvNormAct convention)
         s5 = Fn.restat(f.stats, IN_EPS, _EPS_DEFAULT)
         if isinstance(self.shortcut, ConvNormAct):
@@ -156,10 +167,16 @@ class PatchMerging(nn.Module):
             self.reduction = nn.Conv3d(merged, out_dim, kernel_size=1, bias=False)
         else:
             self.reduction = DepthwiseSeparableConv(merged, out_dim, kernel_size=kernel_size)
-        self.norm = nn.Identity()   # InstanceNorm3d(merged), eps 1e-5: fused into the depthwise load
+        self.norm_kind = norm if norm in ("bn", "ln") else "in"
+        self.norm = make_norm(self.norm_kind, merged)   # `in`: InstanceNorm3d(merged), eps 1e-5, fused into the depthwise load
 
     def forward(self, f: Fn.FMap) -> Fn.FMap:
         m = Fn.SpaceToDepthFn.apply(f.t, tuple(self.down_scale))
+        if self.norm_kind != "in":                      # `norm: bn | ln`: the normalised tensor written once, projections read it
+            mn = norm_rows(self.norm, m)
+            if self.linear:
+                return Fn.FMap(Fn.NormConvFn.apply(mn, None, self.reduction.weight, 0, None, False, None, IN_EPS)[0], None)
+            return self.reduction(mn, None, 0)
         ms = Fn.ensure_stats(Fn.FMap(m, None), _EPS_DEFAULT).stats
         if self.linear:
             y, so = Fn.NormConvFn.apply(m, ms, self.reduction.weight, 0, None, True, None, IN_EPS)

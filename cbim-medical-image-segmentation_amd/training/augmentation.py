@@ -118,11 +118,9 @@ def contrast(tensor_img, contrast_range=(0.65, 1.5), per_channel=False, preserve
     f = torch.rand(Cc, 1) * (contrast_range[1] - contrast_range[0]) + contrast_range[0]
     if not per_channel and Cc != 1:
         raise RuntimeError("contrast(per_channel=False) is only defined for single-channel input (as in the reference)")
-    if not preserve_range:
-        raise NotImplementedError("cbim_amd: contrast(preserve_range=False) is not built")
     x = _flat_view(tensor_img.contiguous(), per_channel)
     st = _stats(x)
-    y = _intensity(x, 3, _prm(f.reshape(-1), [0.0] * Cc, x.device), True, st=st, st_pc=True)
+    y = _intensity(x, 3, _prm(f.reshape(-1), [0.0 if preserve_range else 1.0] * Cc, x.device), True, st=st, st_pc=True)
     return y.view(1, Cc, D, H, W)
 
 

@@ -180,9 +180,15 @@ class FusedAdamW(torch.optim.Optimizer):
 
 
 def get_optimizer(args, net, ema_net=None):
-    """training/utils.py:8-14 for ``optimizer: adamw`` (the only optimiser the shipped 3-D configs use)."""
+    """training/utils.py:8-14 with the EMA update (training/utils.py:98-105) folded into the same launch for ``optimizer: adamw``;
+    ``sgd`` / ``adam`` (no shipped 3-D configuration selects them) are torch's own optimizers on the engine's parameters, exactly
+    as the reference builds them — their EMA stays with ``training.utils.update_ema_variables``."""
+    if args.optimizer == "sgd":
+        return torch.optim.SGD(net.parameters(), lr=args.base_lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    if args.optimizer == "adam":
+        return torch.optim.Adam(net.parameters(), lr=args.base_lr, betas=args.betas, weight_decay=args.weight_decay)
     if args.optimizer != "adamw":
-        raise NotImplementedError(f"cbim_amd: optimizer '{args.optimizer}' is not built (shipped 3-D configs use adamw)")
+        return None    # the reference falls through the same way
     opt = FusedAdamW(net.parameters(), lr=args.base_lr, betas=args.betas, weight_decay=args.weight_decay, eps=1e-5,
                      ema_model=ema_net, ema_alpha=getattr(args, "ema_alpha", 0.99))
     if ema_net is not None:

@@ -8,7 +8,8 @@ trans_layers}.py`` over a ``state_dict`` with the reference's own parameter name
 Pinned against ``tests/golden/medformer_tiny_32.npz`` (outputs + every gradient of the REAL reference,
 ``tests/golden/make_golden_medformer.py``) by ``tests/test_oracle.py``.  Line numbers are in
 ``/root/reference/model/dim3``.  Restated: conv_block BasicBlock, proj_type 'depthwise' (every shipped yaml) and 'linear'
-(round 5, pinned by ``medformer_linear_tiny.npz``), norm 'in', dropout 0.
+(round 5, pinned by ``medformer_linear_tiny.npz``), norm 'in' and (round 6, ``medformer_bn_tiny.npz`` / ``medformer_ln_tiny.npz``)
+'bn' / 'ln' — told apart by the norm parameters the state_dict holds —, dropout 0.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ from typing import Dict, List
 import torch
 import torch.nn.functional as F
 
-from .unet_ref import _act, _k3, _pad, basic_block, instance_norm
+from .unet_ref import _act, _k3, _norm, _pad, conv_norm_act, named_norm
 
 EPS_DEFAULT = 1e-5   # nn.InstanceNorm3d / nn.LayerNorm default (medformer_utils.py:112-113,158; trans_layers.py:38)
 
@@ -34,7 +35,7 @@ def dw_separable(sd, p, x, k):
 
 def cna_preact(sd, p, x, k, act, groups=1):
     """pre-activation ConvNormAct (conv_layers.py:48-49), norm eps 1e-4 (:40); act=None -> no activation."""
-    h = instance_norm(x)
+    h = _norm(sd, p, x)
     if act:
         h = _act(h, act)
     w = sd[p + "conv.weight"]
@@ -94,8 +95,8 @@ def bidirection_attention(sd, p, feat, smap, heads, k, no_map_out):
 
 def attention_block(sd, p, x, smap, heads, k, act, no_map_out):
     """BidirectionAttentionBlock.forward (medformer_utils.py:126-138)."""
-    feat = instance_norm(x, EPS_DEFAULT)                                                # norm1 :128
-    mapp = instance_norm(smap, EPS_DEFAULT)                                             # norm2 :129
+    feat = named_norm(sd, p + "norm1.", x, EPS_DEFAULT)                                 # norm1 :128 (built with the default eps, :112)
+    mapp = named_norm(sd, p + "norm2.", smap, EPS_DEFAULT)                              # norm2 :129
     out, mapp = bidirection_attention(sd, p + "attn.", feat, mapp, heads, k, no_map_out)
     if (p + "shortcut.conv.weight") in sd:                                              # :119-121
         out = out + cna_preact(sd, p + "shortcut.", x, 1, act)
@@ -110,7 +111,7 @@ def patch_merging(sd, p, x, scale, k):
     """PatchMerging.forward (medformer_utils.py:159-175)."""
     parts = [x[:, :, i::scale[0], j::scale[1], kk::scale[2]]
              for i in range(scale[0]) for j in range(scale[1]) for kk in range(scale[2])]
-    return dw_separable(sd, p + "reduction.", instance_norm(torch.cat(parts, 1), EPS_DEFAULT), k)
+    return dw_separable(sd, p + "reduction.", named_norm(sd, p + "norm.", torch.cat(parts, 1), EPS_DEFAULT), k)    # :158,172
 
 
 def semantic_map_generation(sd, p, x, map_size):
@@ -187,12 +188,10 @@ def _up(sd, p, x1, x2, map1, map2, k, heads, act, map_shortcut, no_map_out):
 
 def basic_block_act(sd, p, x, k, act):
     """BasicBlock.forward (conv_layers.py:86-94) with the configured activation."""
-    if act == "relu":
-        return basic_block(sd, p, x, k)
-    h = F.conv3d(_act(instance_norm(x), act), sd[p + "conv1.conv.weight"], None, 1, _pad(k))
-    h = F.conv3d(_act(instance_norm(h), act), sd[p + "conv2.conv.weight"], None, 1, _pad(k))
+    h = conv_norm_act(sd, p + "conv1.", x, k, preact=True, act=act)
+    h = conv_norm_act(sd, p + "conv2.", h, k, preact=True, act=act)
     if (p + "shortcut.conv.weight") in sd:
-        x = F.conv3d(_act(instance_norm(x), act), sd[p + "shortcut.conv.weight"], None, 1, _pad(k))
+        x = conv_norm_act(sd, p + "shortcut.", x, k, preact=True, act=act)
     return h + x
 
 

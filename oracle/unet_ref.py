@@ -49,22 +49,28 @@ def instance_norm(x, eps=IN_EPS_CONV):
 BN_MOMENTUM = 0.1   # nn.BatchNorm3d default (model/dim3/utils.py:16: norm_map['bn'] = nn.BatchNorm3d, built with eps=1e-4 only)
 
 
-def _norm(sd, prefix, x, training=True):
-    """self.norm of a ConvNormAct (conv_layers.py:40-43): InstanceNorm3d(eps=1e-4, affine=False) when the state_dict holds no
-    norm parameters (`norm: in`), else nn.BatchNorm3d(eps=1e-4) (`norm: bn`): batch statistics + in-place running-statistics
-    update in training mode, the running statistics in eval mode (F.batch_norm semantics; num_batches_tracked counted)."""
-    if prefix + "norm.weight" not in sd:
-        return instance_norm(x)
-    if prefix + "norm.running_mean" not in sd:
-        # `norm: ln`: the channels-first LayerNorm of trans_layers.py:120-149 (eps 1e-4 from conv_layers.py:40-42) — per voxel over C
+def named_norm(sd, key, x, eps, training=True):
+    """A norm module of the configured kind under the state_dict prefix `key` (e.g. "down2.patch_merging.norm."):
+    InstanceNorm3d(eps, affine=False) when the state_dict holds no parameters there (`norm: in`), the channels-first LayerNorm of
+    trans_layers.py:120-149 when it holds weight / bias only (`norm: ln`), else nn.BatchNorm3d (`norm: bn`): batch statistics +
+    in-place running-statistics update in training mode, the running statistics in eval mode (F.batch_norm semantics;
+    num_batches_tracked counted)."""
+    if key + "weight" not in sd:
+        return instance_norm(x, eps)
+    if key + "running_mean" not in sd:
         u = x.mean(1, keepdim=True)
         v = (x - u).pow(2).mean(1, keepdim=True)
         shape = (1, -1) + (1,) * (x.dim() - 2)
-        return sd[prefix + "norm.weight"].view(shape) * ((x - u) / torch.sqrt(v + IN_EPS_CONV)) + sd[prefix + "norm.bias"].view(shape)
-    rm, rv = sd[prefix + "norm.running_mean"], sd[prefix + "norm.running_var"]
-    if training and prefix + "norm.num_batches_tracked" in sd:
-        sd[prefix + "norm.num_batches_tracked"] += 1
-    return F.batch_norm(x, rm, rv, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], training, BN_MOMENTUM, IN_EPS_CONV)
+        return sd[key + "weight"].view(shape) * ((x - u) / torch.sqrt(v + eps)) + sd[key + "bias"].view(shape)
+    rm, rv = sd[key + "running_mean"], sd[key + "running_var"]
+    if training and key + "num_batches_tracked" in sd:
+        sd[key + "num_batches_tracked"] += 1
+    return F.batch_norm(x, rm, rv, sd[key + "weight"], sd[key + "bias"], training, BN_MOMENTUM, eps)
+
+
+def _norm(sd, prefix, x, training=True):
+    """self.norm of a ConvNormAct (conv_layers.py:40-43): built with eps=1e-4 whatever the kind."""
+    return named_norm(sd, prefix + "norm.", x, IN_EPS_CONV, training)
 
 
 def conv_norm_act(sd, prefix, x, k, preact, act="relu", training=True, stride=1):

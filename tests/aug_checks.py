@@ -44,6 +44,7 @@ def run(dev, A=None):
     res["badd"] = _rel(_seeded(lambda: A.brightness_additive(img, std=0.1)).cpu(), g["badd"])
     res["gamma"] = _rel(_seeded(lambda: A.gamma(img.clone(), gamma_range=[0.7, 1.5])).cpu(), g["gamma"])
     res["contrast"] = _rel(_seeded(lambda: A.contrast(img.clone(), contrast_range=[0.7, 1.3])).cpu(), g["contrast"])
+    res["contrast_free"] = _rel(_seeded(lambda: A.contrast(img.clone(), contrast_range=[1.4, 1.8], preserve_range=False)).cpu(), g["contrast_free"])
     res["blur"] = _rel(_seeded(lambda: A.gaussian_blur(img, sigma_range=[0.5, 1.5])).cpu(), g["blur"])
     res["noise"] = _rel(_seeded(lambda: A.gaussian_noise(img, std=0.05)).cpu(), g["noise"])
     assert torch.equal(A.mirror(img, axis=1).cpu(), torch.from_numpy(g["mirror1"]))
@@ -126,7 +127,7 @@ def check(res, fused=None):
     assert res["affine_img"] < 2e-5, res
     assert res["affine_lab_mismatch"] < 2e-4, res     # nearest-neighbour ties at x.5 under fp32 coordinate rounding ...
     assert res["affine_lab_mismatch_decided"] == 0, res   # ... and ONLY there: exact wherever the rounding is decided
-    for k in ("bmul", "badd", "contrast", "noise"):
+    for k in ("bmul", "badd", "contrast", "contrast_free", "noise"):
         assert res[k] < 2e-6, (k, res)
     assert res["gamma"] < 2e-5 and res["blur"] < 2e-5, res
 

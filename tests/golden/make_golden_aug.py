@@ -44,6 +44,7 @@ def main():
     out["badd"] = seeded(lambda: A.brightness_additive(img, std=0.1)).numpy()
     out["gamma"] = seeded(lambda: A.gamma(img.clone(), gamma_range=[0.7, 1.5])).numpy()
     out["contrast"] = seeded(lambda: A.contrast(img.clone(), contrast_range=[0.7, 1.3])).numpy()
+    out["contrast_free"] = seeded(lambda: A.contrast(img.clone(), contrast_range=[1.4, 1.8], preserve_range=False)).numpy()
     out["blur"] = seeded(lambda: A.gaussian_blur(img, sigma_range=[0.5, 1.5])).numpy()
     out["noise"] = seeded(lambda: A.gaussian_noise(img, std=0.05)).numpy()
     out["mirror1"] = A.mirror(img, axis=1).numpy()

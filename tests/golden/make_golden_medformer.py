@@ -18,6 +18,10 @@ Same import shim as make_golden.py.  Cases
   medformer_lits_tiny the STRUCTURE of config/lits/medformer_3d.yaml: num_heads all 1 (d_head = channels: 32, 64,
                       80), aux_loss False (forward returns one tensor)
   medformer_linear_tiny  proj_type 'linear' at TINY's widths: 1x1x1 feature projections, FusedMBConv feed-forward
+  medformer_bn_tiny / medformer_ln_tiny  `norm: bn` / `norm: ln` at TINY's widths (round 6): nn.BatchNorm3d / the channels-first
+                      LayerNorm in every ConvNormAct (eps 1e-4), as norm1 / norm2 of every attention block and PatchMerging.norm
+                      (default eps) — train() mode, so BatchNorm runs on batch statistics and updates its running buffers (the
+                      updated buffers are stored as `b:<key>`)
 No reference source is copied; only tensors it produced.
 """
 import importlib
@@ -64,7 +68,10 @@ LITS_T = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num
 # proj_type 'linear' (medformer_utils.py:26-28,121-122,153-154: 1x1x1 feature projections, FusedMBConv(kernel_size=1) feed-forward,
 # 1x1x1 patch-merging reduction) at the reduced widths of TINY — no shipped yaml uses it; a constructor branch of the drop-in
 LIN_T = dict(TINY, proj_type="linear")
+BN_T, LN_T = dict(TINY, norm="bn"), dict(TINY, norm="ln")
 CASES = {
+    "medformer_bn_tiny": (1, 4, BN_T, (32, 32, 32), 1, 3061, 20000),
+    "medformer_ln_tiny": (1, 4, LN_T, (32, 32, 32), 1, 3062, 20000),
     # name: (in_chan, classes, kwargs, spatial, batch, seed, full)
     "medformer_linear_tiny": (1, 4, LIN_T, (32, 32, 32), 1, 3051, 20000),
     "medformer_tiny_32": (1, 4, TINY, (32, 32, 32), 1, 3031, True),
@@ -90,6 +97,7 @@ def main():
         torch.manual_seed(seed)
         net = MedFormer(in_ch, classes, **kw)
         net.train()
+        chk0 = state_dict_checksum(net.state_dict())      # of the constructor's state (BatchNorm buffers change in the forward)
         gen = torch.Generator().manual_seed(seed + 1)
         x = torch.randn((batch, in_ch) + shape, generator=gen).clamp_(-7.4, 2.2)
         lab = mg.make_labels(classes, shape, batch, gen)
@@ -108,6 +116,9 @@ def main():
         loss.backward()
         sd = net.state_dict()
         grads = {k: p.grad for k, p in net.named_parameters()}
+        zero = torch.zeros(())
+        for k in sd:                      # buffers (BatchNorm running statistics) have no gradient: 0 in the per-key arrays
+            grads.setdefault(k, zero)
         st = 1 if full else 4
         if st == 1 and full is not True:
             st = 2
@@ -122,19 +133,23 @@ def main():
             "keys": np.array(list(sd.keys())), "shapes": np.array([str(tuple(v.shape)) for v in sd.values()]),
             "grad_norms": np.array([float(grads[k].double().norm()) for k in sd.keys()]),
             "grad_sums": np.array([float(grads[k].double().sum()) for k in sd.keys()]),
-            "sd_checksum": np.float64(state_dict_checksum(sd)), "seed": np.int64(seed),
+            "sd_checksum": np.float64(chk0), "seed": np.int64(seed),
             "g:inc.conv1.weight": grads["inc.conv1.weight"].numpy(),
             "g:outc.weight": grads["outc.weight"].numpy(),
         }
         if kw["aux_loss"]:
             out["g:aux_out.weight"] = grads["aux_out.weight"].numpy()
+        pnames = {k for k, _ in net.named_parameters()}
+        for k, v in sd.items():
+            if k not in pnames:           # the buffers AFTER the training-mode forward (running statistics updated once)
+                out["b:" + k] = v.numpy()
         if full is True:
             for k, v in sd.items():
                 out["p:" + k] = v.numpy()
                 out["g:" + k] = grads[k].numpy()
         elif full:
             for k, v in sd.items():
-                if v.numel() <= full:
+                if v.numel() <= full and k in pnames:
                     out["g:" + k] = grads[k].numpy()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)

@@ -40,7 +40,10 @@ LITS_T = dict(base_chan=8, map_size=[2, 2, 2], conv_block="BasicBlock", conv_num
               attn_drop=0., proj_drop=0., proj_type="depthwise", norm="in", act="relu", kernel_size=[[3, 3, 3]] * 5,
               scale=[[2, 2, 2]] * 4, aux_loss=False)
 LIN_T = dict(TINY, proj_type="linear")
-MF_CASES = {"medformer_tiny_32": (1, 4, TINY), "medformer_linear_tiny": (1, 4, LIN_T), "medformer_amos_64": (1, 16, AMOS),
+# `norm: bn` / `norm: ln` (round 6; no shipped 3-D yaml): nn.BatchNorm3d / the channels-first LayerNorm in every ConvNormAct, as
+# norm1 / norm2 of the attention blocks and as PatchMerging.norm
+BN_T, LN_T = dict(TINY, norm="bn"), dict(TINY, norm="ln")
+MF_CASES = {"medformer_bn_tiny": (1, 4, BN_T), "medformer_ln_tiny": (1, 4, LN_T),"medformer_tiny_32": (1, 4, TINY), "medformer_linear_tiny": (1, 4, LIN_T), "medformer_amos_64": (1, 16, AMOS),
             "medformer_acdc_tiny": (1, 4, ACDC_T), "medformer_lits_tiny": (1, 3, LITS_T),
             "medformer_bcv_tiny": (1, 14, BCV_T)}
 AUX_WEIGHT = (0.5, 0.5)
@@ -78,7 +81,7 @@ def run_case(name, dev, mode):
         st = int(g["stride"])
         params = dict(net.named_parameters())
         keys = [str(k) for k in g["keys"]]
-        gn = np.array([float(params[k].grad.double().norm()) for k in keys])
+        gn = np.array([float(params[k].grad.double().norm()) if k in params else 0.0 for k in keys])   # buffers: no gradient
         scale = float(np.max(g["grad_norms"]))
         res = {
             "logits_err": rel_err(outs[0].detach().cpu()[..., ::st, ::st, ::st], g["logits"]),
@@ -96,6 +99,9 @@ def run_case(name, dev, mode):
         clear = (top2[:, 0] - top2[:, 1]) > 1e-4          # ties below the fp32 noise floor are masked
         mine = outs[0].detach().cpu()[..., ::st, ::st, ::st].argmax(1)
         res["argmax_mismatch"] = int(((mine != ref.argmax(1)) & clear).sum())
+        bufs = dict(net.named_buffers())
+        if any(("b:" + k) in g.files for k in bufs):    # BatchNorm running statistics after the training-mode forward
+            res["buffer_err"] = max(rel_err(bufs[k].detach().cpu().float(), g["b:" + k].astype(np.float32)) for k in bufs)
         stored = [k for k in keys if "g:" + k in g.files]
         if len(stored) > 3:                               # fixture with full gradients (all, or all small tensors)
             errs, meds = [], []
@@ -123,4 +129,6 @@ def assert_fp32_parity(name, dev):
     assert r["grad_norm_err"] < 2e-2 and r["g_stem"] < 2e-2 and r["g_head"] < 1e-3 and r["g_aux"] < 1e-3, r
     if "grad_max_err" in r:
         assert r["grad_max_err"] < 4e-2 and r["grad_med_err"] < 1e-2, r   # batch-1 fixture: InstanceNorm over 8 voxels at the deepest level
+    if "buffer_err" in r:
+        assert r["buffer_err"] < 1e-4, r
     return r

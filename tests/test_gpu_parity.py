@@ -204,6 +204,16 @@ def test_medformer_wide_heads_bf16_inside_envelope(dev, name):
     _medformer_envelope(dev, name)
 
 
+@pytest.mark.parametrize("name", ["medformer_bn_tiny", "medformer_ln_tiny"])
+def test_medformer_norm_branches_match_reference_golden(dev, name):
+    """`norm: bn` / `norm: ln` MedFormer (round 6; medformer_utils.py:112-113,119,122-124,158 with model/dim3/utils.py:15-21): fp32
+    engine mode against the real reference's train()-mode run (logits, losses, every gradient norm, the small gradients in full,
+    BatchNorm running statistics), bf16 engine mode inside 1.5 x the oracle's own autocast(bf16) deviation."""
+    from tests.medformer_checks import assert_fp32_parity as mf_parity
+    print(name, mf_parity(name, dev))
+    print(_medformer_envelope(dev, name))
+
+
 # ---- SwinUNETR (SURVEY.md §8 a21-a23) -------------------------------------------------------------
 
 @pytest.mark.parametrize("name", ["swin_tiny", "swin_brats_64", "swin_c1_tiny"])

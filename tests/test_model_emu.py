@@ -58,12 +58,11 @@ def test_same_seed_draws_reference_weights():
 
 def test_unbuilt_options_fail_loudly():
     from cbim_amd.model.utils import get_model
+    tiny = {k: v for k, v in __import__("tests.medformer_checks", fromlist=["TINY"]).TINY.items() if k != "norm"}
+    for kind, n_keys in (("bn", 428), ("ln", 260)):     # round 6: MedFormer `norm: bn | ln` is built (state_dict sizes of the reference)
+        assert len(get_model(_args(model="medformer", norm=kind, **tiny, down_scale=[[2, 2, 2]] * 4)).state_dict()) == n_keys
     with pytest.raises(NotImplementedError):
-        get_model(_args(model="medformer", norm="bn", **{k: v for k, v in __import__("tests.medformer_checks", fromlist=["TINY"]).TINY.items()
-                                                          if k not in ("norm",)}, down_scale=[[2, 2, 2]] * 4))
-    with pytest.raises(NotImplementedError):
-        get_model(_args(model="medformer", norm="ln", **{k: v for k, v in __import__("tests.medformer_checks", fromlist=["TINY"]).TINY.items()
-                                                          if k not in ("norm",)}, down_scale=[[2, 2, 2]] * 4))   # bn / ln: the UNet-family blocks
+        get_model(_args(model="medformer", **dict(tiny, attn_drop=0.1), down_scale=[[2, 2, 2]] * 4))
     assert get_model(_args(block="Bottleneck", norm="ln")).state_dict()["down1.conv.1.conv1.norm.weight"].shape == (32,)
     with pytest.raises(NotImplementedError):
         get_model(_args(model="vtunet"))
@@ -130,6 +129,15 @@ def test_medformer_linear_projections_fp32_match_reference_golden(dev):
     linear PatchMerging reduction, all on the row GEMM with InstanceNorm on load — against the real reference."""
     from tests.medformer_checks import assert_fp32_parity
     print(assert_fp32_parity("medformer_linear_tiny", dev))
+
+
+@pytest.mark.parametrize("name", ["medformer_bn_tiny", "medformer_ln_tiny"])
+def test_medformer_norm_branches_fp32_match_reference_golden(dev, name):
+    """`norm: bn` / `norm: ln` (round 6): BatchNorm3d / channels-first LayerNorm in every ConvNormAct (depthwise ones included), as
+    norm1 / norm2 of every attention block and as PatchMerging.norm — outputs, every gradient norm, the small gradients in full and
+    the BatchNorm running statistics against the real reference's run in train() mode."""
+    from tests.medformer_checks import assert_fp32_parity
+    print(assert_fp32_parity(name, dev))
 
 
 def test_medformer_acdc_structure_fp32_matches_reference_golden(dev):

@@ -201,7 +201,8 @@ def bf16_envelope_vs_oracle(dev, net, oracle_forward, x, lab, w, tag=None, loss_
     from oracle.loss_ref import ce_dice_loss
 
     def oracle_run(autocast):
-        sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+        pn = {k for k, _ in net.named_parameters()}      # buffers (BatchNorm running statistics, updated in place) take no gradient
+        sd = {k: v.detach().cpu().clone().requires_grad_(k in pn) for k, v in net.state_dict().items()}
         ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
         with ctx:
             outs = oracle_forward(sd, x)
