@@ -859,6 +859,17 @@ def dwconv_wgrad_on_matrix_cores(x, k) -> bool:
             and min(int(x.shape[1]), int(x.shape[2]), int(x.shape[3])) >= 8)
 
 
+_SHIFT_CONSTS = {}
+
+
+def _shift_consts(device):
+    """([-1, 0], [0, 1]) on `device`, built once (outside any graph capture: the first eager step)"""
+    key = str(device)
+    if key not in _SHIFT_CONSTS:
+        _SHIFT_CONSTS[key] = (torch.tensor([-1.0, 0.0], device=device), torch.tensor([0.0, 1.0], device=device))
+    return _SHIFT_CONSTS[key]
+
+
 def dwconv_wgrad(x, in_stats, act: int, dy, k, dy_bias=None):
     _dev_ok(x, in_stats, dy, dy_bias)
     N, D, H, W, Cc = map(int, x.shape)
@@ -870,7 +881,10 @@ def dwconv_wgrad(x, in_stats, act: int, dy, k, dy_bias=None):
         if in_stats is not None:
             x = norm_act_fwd(x, in_stats, act)
         if dy_bias is not None:
-            shift = torch.stack([-dy_bias.float(), torch.ones_like(dy_bias, dtype=torch.float32)], -1).contiguous()
+            # (mean, rstd) = (-bias, 1) per (n, c): dy + bias through the normalisation kernel; ONE broadcast launch builds the
+            # pairs (was neg / ones_like / stack: three launches per MBConv backward)
+            c, d = _shift_consts(dy_bias.device)
+            shift = torch.addcmul(d, dy_bias.float().unsqueeze(-1), c)
             dy = norm_act_fwd(dy, shift, ACT["none"])
         in_stats, dy_bias, act = None, None, 0
     nbytes = L.cbim_dwconv3d_wgrad_workspace(N, D, H, W, Cc, kD, kH, kW)
