@@ -218,15 +218,15 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x,
   const int cc = threadIdx.x % cch + c_off / CPC, vl = threadIdx.x / cch;
   if (vl >= vlc) return;
   const int n = blockIdx.y;
-  float mean[CPC], rstd[CPC];
+  float mean[CPC], rstd[CPC], ga[CPC], be[CPC];
 #pragma unroll
   for (int j = 0; j < CPC; ++j) {
     mean[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2];
     rstd[j] = stats[((size_t)n * Cl + cc * CPC + j) * 2 + 1];
-    if (AFF) {      // folded in fp32 registers: (x - mean') * rstd' with rstd' = gamma rstd, mean' rstd' = mean rstd' - beta
-      const float ga = affine[(size_t)(cc * CPC + j) * 2], be = affine[(size_t)(cc * CPC + j) * 2 + 1];
-      rstd[j] *= ga;
-      mean[j] = mean[j] * rstd[j] - be;             // now: y = x * rstd' - mean[j]
+    ga[j] = 1.f; be[j] = 0.f;
+    if (AFF) {      // z = gamma * xh + beta with xh = (x - mean) * rstd: the CENTRED form, the very expression the backward recomputes
+      ga[j] = affine[(size_t)(cc * CPC + j) * 2];   // (the folded form x * (gamma rstd) - (mean gamma rstd - beta) cancels for
+      be[j] = affine[(size_t)(cc * CPC + j) * 2 + 1];   //  |mean| >> std and lets the activation mask disagree with the backward's near 0)
     }
   }
   const size_t nb = (size_t)n * S;
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(NT) k_norm_act_fwd(const void* __restrict__ x,
         float f[CPC];
         Elem<T>::unpack(raw[u], f);
 #pragma unroll
-        for (int j = 0; j < CPC; ++j) f[j] = act_fwd(AFF ? fmaf(f[j], rstd[j], -mean[j]) : (f[j] - mean[j]) * rstd[j], act);
+        for (int j = 0; j < CPC; ++j) f[j] = act_fwd(AFF ? fmaf(ga[j], (f[j] - mean[j]) * rstd[j], be[j]) : (f[j] - mean[j]) * rstd[j], act);
         st_chunk<T>(y, (nb + v + u * step) * y_stride + (size_t)cc * CPC, Elem<T>::pack(f));
       }
     }

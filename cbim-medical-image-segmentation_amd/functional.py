@@ -18,6 +18,8 @@ import os
 import threading
 from typing import NamedTuple, Optional
 
+import weakref
+
 import torch
 
 from . import ops
@@ -103,6 +105,13 @@ def eager_only(fn):
     it does; torch.compiler.disable itself is applied lazily, the first time the forward runs while dynamo is loaded."""
     import functools
     import sys
+    if "torch._dynamo" in sys.modules:              # dynamo is already loaded at decoration time: its public API, nothing private
+        dis = getattr(getattr(torch, "compiler", None), "disable", None)
+        if dis is not None:
+            try:
+                return dis(fn)
+            except Exception:
+                pass
     state = {"wrapped": None}
 
     @functools.wraps(fn)
@@ -1107,13 +1116,17 @@ def _packed_slice(w, kd, geom, need_dgrad):
     key = (w.data_ptr(), tuple(w.shape), kd, geom.dtype)
     tag = (w._version, ops.PACKED.epoch, ops.PACKED.stale)
     e = _SLICE_PACK.get(key)
+    if e is not None and e[4]() is not w:          # the address was recycled by another tensor
+        e = None
     # (stale: a hipGraph replay moved the weights unseen; capturing: the pack launch must be IN the graph — a replay re-packs from the
     #  weights its own captured optimizer step left)
     capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
     if e is None or e[0] != tag or ops.PACKED.stale or capturing or (need_dgrad and e[3] is None):
         wk = w.detach()[:, :, kd:kd + 1].contiguous()
         wp, wpd = (ops.pack_weights_both(wk, geom) if need_dgrad else (ops.pack_weights(wk, geom, 0), None))
-        e = _SLICE_PACK[key] = (tag, wk, wp, wpd, w)          # (keeps the parameter alive: data_ptr stays unique)
+        if e is None:                              # weakly keyed: entries die with their parameter
+            weakref.finalize(w, _SLICE_PACK.pop, key, None)
+        e = _SLICE_PACK[key] = (tag, wk, wp, wpd, weakref.ref(w))
     return e[1], e[2], e[3]
 
 

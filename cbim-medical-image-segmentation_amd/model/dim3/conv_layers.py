@@ -95,6 +95,8 @@ class ConvNormAct(nn.Module):
         if groups not in (1, in_ch):
             raise NotImplementedError("cbim_amd: grouped convolutions other than depthwise are not built")
         k = _k3(kernel_size)
+        if self.stride != (1, 1, 1):
+            Fn._stride_plan(k, self.stride)      # unsupported (kernel, stride) pairs fail HERE, not at the first forward
         self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=k, stride=self.stride, padding=[i // 2 for i in k], groups=groups,
                               bias=False)
         if norm == "bn":

@@ -12,6 +12,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Sequence, Tuple
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -1237,6 +1239,8 @@ def lo_weights(w: torch.Tensor, geom: ConvGeom, need_dgrad: bool):
     _dev_ok(w)
     key = (w.data_ptr(), tuple(w.shape))
     e = _LO_CACHE.get(key)
+    if e is not None and e[3]() is not w:     # the address was recycled by another tensor (its finalizer has not run yet)
+        e = None
     capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()      # (the pack launch must be IN a captured step)
     stale = PACKED.stale or capturing or e is None or e[0] != (w._version, PACKED.epoch) or (need_dgrad and e[2] is None)
     if stale:
@@ -1245,7 +1249,9 @@ def lo_weights(w: torch.Tensor, geom: ConvGeom, need_dgrad: bool):
         p1 = e[2] if e is not None and e[2] is not None else (
             torch.empty((L.cbim_conv3d_packed_bytes(C.byref(geom.fwd), 1),), dtype=torch.uint8, device=w.device) if need_dgrad else None)
         check(L.cbim_conv3d_pack_weights_lo(C.byref(geom.fwd), _p(w.detach()), _p(p0), _p(p1), _stream(w)), "pack_weights_lo")
-        e = _LO_CACHE[key] = ((w._version, PACKED.epoch), p0, p1, w)       # (keeps the parameter alive: data_ptr stays unique)
+        if e is None:             # weakly keyed: the entry and its packed images go when the parameter does
+            weakref.finalize(w, _LO_CACHE.pop, key, None)
+        e = _LO_CACHE[key] = ((w._version, PACKED.epoch), p0, p1, weakref.ref(w))
     return e[1], (e[2] if need_dgrad else None)
 
 
