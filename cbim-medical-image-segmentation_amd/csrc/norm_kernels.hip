@@ -553,6 +553,7 @@ extern "C" int cbim_warm_layernorm(void* stream);
 extern "C" int cbim_warm_rw(void* stream);
 extern "C" int cbim_warm_pw(void* stream);
 extern "C" int cbim_warm_map(void* stream);
+extern "C" int cbim_warm_awg(void* stream);
 
 // One successful no-op launch from every code object of the library (see CBIM_DEFINE_WARM); the binding calls
 // this once per process before the first real launch.
@@ -578,6 +579,7 @@ extern "C" int cbim_runtime_warmup(void* stream) {
   if (int e = cbim_warm_rw(stream)) return e;
   if (int e = cbim_warm_pw(stream)) return e;
   if (int e = cbim_warm_map(stream)) return e;
+  if (int e = cbim_warm_awg(stream)) return e;
   return CBIM_OK;
 }
 

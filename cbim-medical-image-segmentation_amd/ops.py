@@ -48,6 +48,11 @@ def _dev_ok(*ts):
             raise RuntimeError("cbim_amd: non-contiguous tensor passed to a kernel")
 
 
+def _rows_ok(*ts):
+    """_dev_ok for the token-row entry points, which take a row stride: [rows, C'] channel slices of a wider row tensor pass"""
+    _dev_ok(*[t if (t is None or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]) else t.as_strided((1,), (1,)) for t in ts])
+
+
 def _is_row_view(t: torch.Tensor) -> bool:
     """channels-last [N,D,H,W,C'] view that selects a channel range of a wider contiguous tensor:
     unit channel stride, rows `row_stride` elements apart, voxels dense."""
@@ -1073,6 +1078,102 @@ def se_gate_bwd(dgate, gate, z1, mean, w1, w2, need_dmean=True, need_bias=(True,
     return dmean, dw1, db1, dw2, db2
 
 
+AWG_ROWS = 256        # include/cbim_hip.h CBIM_AWG_ROWS: rows of S per column record
+
+
+def awg_eligible(qv, mq, heads: int) -> bool:
+    """Whether the BidirectionAttention core of this call runs as matrix products (functional.BidirAttnFn): ONE head whose width is
+    a multiple of 32 (config/lits/medformer_3d.yaml), 32 | 64 | 128 map codes, bf16 feature rows."""
+    inner = int(qv.shape[-1]) // 2
+    return (AWG and heads == 1 and qv.dtype == torch.bfloat16 and inner % 32 == 0 and inner >= 64 and int(mq.shape[1]) in (32, 64, 128)
+            and _spatial(qv) >= 512)
+
+
+AWG = True
+
+
+def awg_rows(S, scale: float):
+    """S float32 [L, M] -> (P bf16 [L, M] = softmax over M of scale*S, column records float32 [ceil(L/256), M, 2])"""
+    _dev_ok(S)
+    Lr, M = int(S.shape[0]), int(S.shape[1])
+    P = torch.empty((Lr, M), dtype=torch.bfloat16, device=S.device)
+    rec = torch.empty(((Lr + AWG_ROWS - 1) // AWG_ROWS, M, 2), dtype=torch.float32, device=S.device)
+    check(_lib.lib().cbim_awg_rows(_p(S), Lr, M, float(scale), _p(P), _p(rec), _stream(S)), "awg_rows")
+    return P, rec
+
+
+def awg_cols(S, scale: float, rec):
+    """-> (Cs bf16 [L, M] = softmax over the L rows of scale*S, lse float32 [M])"""
+    _dev_ok(S, rec)
+    Lr, M = int(S.shape[0]), int(S.shape[1])
+    Cs = torch.empty((Lr, M), dtype=torch.bfloat16, device=S.device)
+    lse = torch.empty((M,), dtype=torch.float32, device=S.device)
+    check(_lib.lib().cbim_awg_cols(_p(S), Lr, M, float(scale), _p(rec), _p(lse), _p(Cs), _stream(S)), "awg_cols")
+    return Cs, lse
+
+
+def awg_ds(dP, P, dC, Cs, dmo, mo, scale: float):
+    """dS bf16 [L, M] = scale (P o (dP - rowsum(dP o P)) + C o (dC - <dmo[m], mo[m]>))"""
+    _dev_ok(dP, P, dC, Cs, dmo, mo)
+    Lr, M, D = int(dP.shape[0]), int(dP.shape[1]), int(mo.shape[1])
+    dS = torch.empty((Lr, M), dtype=torch.bfloat16, device=dP.device)
+    ws = torch.empty((M,), dtype=torch.float32, device=dP.device)
+    check(_lib.lib().cbim_awg_ds(_p(dP), _p(P), _p(dC), _p(Cs), _p(dmo), _p(mo), D, Lr, M, float(scale), _p(ws), _p(dS), _stream(dP)),
+          "awg_ds")
+    return dS
+
+
+def _pack_lin(w2d):
+    """packed forward image of a float32 [Cout, Cin] matrix used as the weight of a row GEMM"""
+    w2d = w2d.contiguous()
+    g = linear_geom(int(w2d.shape[1]), int(w2d.shape[0]))
+    return pack_weights(w2d.view(w2d.shape[0], w2d.shape[1], 1, 1, 1), g, 0)
+
+
+def bidir_attn_gemm_fwd(qv, mq, mv, scale: float):
+    """BidirectionAttention core of ONE head as matrix products (medformer_utils.py:63-97; csrc/attn_gemm_kernels.hip): per image
+    S = Q MQ^T (row GEMM, fp32 out) -> P, C (both softmaxes, bf16) -> feat_out = P MV (row GEMM), map_out = C^T FV (weight-gradient
+    GEMM over the voxels).  Returns (feat_out like qv[..., :inner], map_out float32 [N, M, inner], P, C)."""
+    N, Lr, inner = int(qv.shape[0]), _spatial(qv), int(qv.shape[-1]) // 2
+    M = int(mq.shape[1])
+    rows = qv.reshape(N, Lr, 2 * inner)
+    fo = torch.empty(tuple(qv.shape[:-1]) + (inner,), dtype=qv.dtype, device=qv.device)
+    fo_r = fo.view(N, Lr, inner)
+    mo = torch.empty((N, M, inner), dtype=torch.float32, device=qv.device)
+    Ps, Cs = [], []
+    for n in range(N):
+        q, v = rows[n, :, :inner], rows[n, :, inner:]
+        S = token_linear(q, _pack_lin(mq[n]), None, M, out_dtype=torch.float32)             # [L, M]
+        P, rec = awg_rows(S, scale)
+        Cn, _ = awg_cols(S, scale, rec)
+        token_linear(P, _pack_lin(mv[n].t()), None, inner, out=fo_r[n])                     # P [L, M] x MV [M, inner]
+        token_linear_wgrad(v, Cn, out=mo[n])                                                # sum_l C[l][m] v[l][d]
+        Ps.append(P)
+        Cs.append(Cn)
+    return fo, mo, torch.stack(Ps), torch.stack(Cs)
+
+
+def bidir_attn_gemm_bwd(qv, mq, mv, P, Cs, mo, dfo, dmo, scale: float):
+    N, Lr, inner = int(qv.shape[0]), _spatial(qv), int(qv.shape[-1]) // 2
+    M = int(mq.shape[1])
+    rows = qv.reshape(N, Lr, 2 * inner)
+    dfo_r = dfo.reshape(N, Lr, inner)
+    dqv = torch.empty(tuple(qv.shape), dtype=qv.dtype, device=qv.device)
+    dq_r = dqv.view(N, Lr, 2 * inner)
+    dmq = torch.empty((N, M, inner), dtype=torch.float32, device=qv.device)
+    dmv = torch.empty((N, M, inner), dtype=torch.float32, device=qv.device)
+    for n in range(N):
+        q, v = rows[n, :, :inner], rows[n, :, inner:]
+        dP = token_linear(dfo_r[n], _pack_lin(mv[n]), None, M, out_dtype=torch.float32)     # dfo [L, D] x MV^T
+        token_linear_wgrad(dfo_r[n], P[n], out=dmv[n])                                      # sum_l P[l][m] dfo[l][d]
+        dC = token_linear(v, _pack_lin(dmo[n]), None, M, out_dtype=torch.float32)           # FV [L, D] x dmo^T
+        token_linear(Cs[n], _pack_lin(dmo[n].t()), None, inner, out=dq_r[n, :, inner:])     # dFV = C dmo
+        dS = awg_ds(dP, P[n], dC, Cs[n], dmo[n], mo[n], scale)
+        token_linear(dS, _pack_lin(mq[n].t()), None, inner, out=dq_r[n, :, :inner])         # dQ = dS MQ
+        token_linear_wgrad(q, dS, out=dmq[n])                                               # dMQ = dS^T Q
+    return dqv, dmq, dmv
+
+
 def colsoftmax_pool_fwd(fw, Cf: int):
     """fw [N,D,H,W,Cf+M] -> map float32 [N,Cf,M], colstat float32 [N,M,2]."""
     _dev_ok(fw)
@@ -1256,16 +1357,17 @@ def lo_weights(w: torch.Tensor, geom: ConvGeom, need_dgrad: bool):
 
 
 def token_linear(x2d, w_packed, bias, Cout: int, act_in: int = 0, res=None, mask=None, mask_act: int = 0,
-                 out_dtype: torch.dtype = torch.bfloat16, w_lo=None):
+                 out_dtype: torch.dtype = torch.bfloat16, w_lo=None, out=None):
     """y = (act_in(x) @ W^T + bias) * act'(mask) + res over token rows (include/cbim_hip.h cbim_token_linear).
     x2d [rows, Cin] bf16 | fp32, res fp32 [rows, Cout] | None, mask bf16 [rows, Cout] | None -> y [rows, Cout] in out_dtype."""
-    _dev_ok(x2d, w_packed, bias, res, mask)
+    _rows_ok(x2d, w_packed, bias, res, mask, out)
     rows, Cin = int(x2d.shape[0]), int(x2d.shape[1])
     if res is not None and res.dtype != torch.float32:
         raise TypeError("cbim_amd: token_linear takes the float32 residual stream as `res`")
     if mask is not None and mask.dtype != torch.bfloat16:
         raise TypeError("cbim_amd: token_linear takes the bf16 pre-activation as `mask`")
-    y = torch.empty((rows, Cout), dtype=out_dtype, device=x2d.device)
+    # out: a [rows, Cout] view with its own row stride (a channel slice of a wider row tensor) written in place
+    y = torch.empty((rows, Cout), dtype=out_dtype, device=x2d.device) if out is None else out
     prof = PROFILE is not None and x2d.device.type == "cuda"
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1273,7 +1375,7 @@ def token_linear(x2d, w_packed, bias, Cout: int, act_in: int = 0, res=None, mask
     check(_lib.lib().cbim_token_linear(_p(x2d), _dt(x2d), int(x2d.stride(0)), act_in, _p(w_packed), _p(w_lo), _p(bias),
                                        _p(res), int(res.stride(0)) if res is not None else 0,
                                        _p(mask), int(mask.stride(0)) if mask is not None else 0, mask_act,
-                                       _p(y), _dt(y), Cout, rows, Cin, Cout, _stream(x2d)), "token_linear")
+                                       _p(y), _dt(y), int(y.stride(0)), rows, Cin, Cout, _stream(x2d)), "token_linear")
     if prof:
         e1.record()
         nbytes = rows * (Cin * x2d.element_size() + Cout * y.element_size() + (4 * Cout if res is not None else 0) +
@@ -1284,7 +1386,7 @@ def token_linear(x2d, w_packed, bias, Cout: int, act_in: int = 0, res=None, mask
 
 def token_linear_wgrad(x2d, dy2d, act_in: int = 0, out=None):
     """dW[co][ci] = sum_r dy[r][co] * act_in(x[r][ci]) -> float32 [Cout, Cin] (fixed summation order)."""
-    _dev_ok(x2d, dy2d)
+    _rows_ok(x2d, dy2d)
     rows, Cin, Cout = int(x2d.shape[0]), int(x2d.shape[1]), int(dy2d.shape[1])
     L = _lib.lib()
     nbytes = L.cbim_token_linear_wgrad_workspace(rows, Cin, Cout)
