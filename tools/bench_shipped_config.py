@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step from ONE hipGraph captured after warm-up (as bench.py does)")
     a = ap.parse_args()
     assert torch.cuda.is_available(), "needs a GPU (no CPU fallback for the product path)"
     dev = torch.device("cuda", 0)
@@ -61,12 +62,27 @@ def main():
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize()
+        run = step
+        if a.graph:          # the launch-bound step as one hipGraph (every kernel of fwd + loss + bwd + AdamW captured once)
+            graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                opt.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph, stream=side):
+                    static_loss = step()
+            torch.cuda.current_stream().wait_stream(side)
+
+            def run():
+                graph.replay()
+                return static_loss
+            run()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            loss = step()
+            loss = run()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / a.steps * 1e3
-        print(json.dumps({"config": name, "model": cfg["model"], "training_size": size, "dtype": a.dtype,
+        print(json.dumps({"config": name, "model": cfg["model"], "training_size": size, "dtype": a.dtype, "graph": bool(a.graph),
                           "ms_per_step": round(ms, 2), "volumes_per_s": round(1e3 / ms, 2), "steps": a.steps,
                           "final_loss": round(float(loss.detach()), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}),
               flush=True)
