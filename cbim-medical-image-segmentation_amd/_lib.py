@@ -132,9 +132,9 @@ _SIGS = {
     "cbim_map_gemm": (i32, [C.POINTER(MapGemmDesc), vp]),
     "cbim_se_gate_fwd": (i32, [vp] * 7 + [i32] * 3 + [vp]),
     "cbim_se_gate_bwd": (i32, [vp] * 12 + [i32] * 3 + [vp]),
-    "cbim_awg_rows": (i32, [vp, i64, i32, f32, vp, vp, vp]),
-    "cbim_awg_cols": (i32, [vp, i64, i32, f32, vp, vp, vp, vp]),
-    "cbim_awg_ds": (i32, [vp] * 6 + [i32, i64, i32, f32, vp, vp, vp]),
+    "cbim_awg_rows": (i32, [vp, i64, i32, i32, f32, vp, vp, vp]),
+    "cbim_awg_cols": (i32, [vp, i64, i32, i32, f32, vp, vp, vp, vp]),
+    "cbim_awg_ds": (i32, [vp] * 6 + [i32, i64, i32, i32, f32, vp, vp, vp]),
     "cbim_colsoftmax_pool_workspace": (sz, [i32] * 4),
     "cbim_colsoftmax_pool_fwd": (i32, [i32, vp, i64, vp, vp] + [i32] * 4 + [vp, sz, vp]),
     "cbim_colsoftmax_pool_bwd": (i32, [i32, vp, i64, vp, vp, vp, vp, i64] + [i32] * 4 + [vp]),

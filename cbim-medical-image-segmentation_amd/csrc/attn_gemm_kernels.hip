@@ -28,19 +28,22 @@ __device__ __forceinline__ void ag_merge(float& m, float& s, float m2, float s2)
   m = mm;
 }
 
-// M codes = LPR lanes x 8; a wave covers 64 / LPR rows per pass
+// Layout: S float32 [L voxels][H heads][M codes] (what the row GEMM writes when its weight is the block matrix of all heads), seen here as
+// R = L H rows of M codes.  A row is held by LPR = 4 | 8 | 16 lanes x 8 codes (the first LPR with 8 LPR >= M; lanes past M idle), a wave
+// covers RW = 64 / LPR rows per pass; H <= RW and H | RW, so the head of a lane's rows (row % H = (lane / LPR) % H) never changes.
 template <int LPR>
-__global__ void __launch_bounds__(AG_T) k_awg_rows(const float* __restrict__ S, int64_t L, float scale, bf16_t* __restrict__ P,
-                                                   float* __restrict__ rec) {
-  constexpr int M = LPR * 8, RW = 64 / LPR;
+__global__ void __launch_bounds__(AG_T) k_awg_rows(const float* __restrict__ S, int64_t R, int M, int H, float scale,
+                                                   bf16_t* __restrict__ P, float* __restrict__ rec) {
+  constexpr int RW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lc = lane % LPR, lr = lane / LPR;
+  const bool act = lc * 8 < M;
   const int64_t r0 = (int64_t)blockIdx.x * AG_ROWS;
   float cm[8], cs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { cm[j] = -INFINITY; cs[j] = 0.f; }
   for (int it = 0; it < AG_ROWS / (4 * RW); ++it) {
     const int64_t row = r0 + (int64_t)(it * 4 + wave) * RW + lr;
-    const bool ok = row < L;
+    const bool ok = row < R && act;
     float s[8];
     if (ok) {
       const f32x4 a = *(const f32x4*)(S + row * M + lc * 8), b = *(const f32x4*)(S + row * M + lc * 8 + 4);
@@ -70,54 +73,59 @@ __global__ void __launch_bounds__(AG_T) k_awg_rows(const float* __restrict__ S, 
       for (int j = 0; j < 8; ++j) ag_merge(cm[j], cs[j], s[j], 1.f);
     }
   }
-  // the rows of this wave (lanes with the same code chunk), then the four waves through LDS in wave order
+  // the rows of this wave that belong to the same head (lanes with the same code chunk and the same lr % H), then the four waves
+  // through LDS in wave order
 #pragma unroll
   for (int o = LPR; o < 64; o <<= 1) {
+    if (o < LPR * H) continue;                 // (lr bits below log2 H tell the heads apart)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float m2 = __shfl_xor(cm[j], o, 64), s2 = __shfl_xor(cs[j], o, 64);
-      ag_merge(cm[j], cs[j], m2, s2);      // (symmetric in its two pairs — fp multiply / add commute —: both partners hold the same result)
+      ag_merge(cm[j], cs[j], m2, s2);          // (symmetric in its two pairs — fp multiply / add commute —: both partners hold the same result)
     }
   }
-  __shared__ float red[4][M][2];
-  if (lr == 0) {
+  __shared__ float red[4][RW][LPR * 8][2];     // [wave][head (< H <= RW)][code]
+  if (lr < H && act) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[wave][lc * 8 + j][0] = cm[j]; red[wave][lc * 8 + j][1] = cs[j]; }
+    for (int j = 0; j < 8; ++j) { red[wave][lr][lc * 8 + j][0] = cm[j]; red[wave][lr][lc * 8 + j][1] = cs[j]; }
   }
   __syncthreads();
-  if (threadIdx.x < M) {
-    float m = red[0][threadIdx.x][0], s = red[0][threadIdx.x][1];
-    for (int w = 1; w < 4; ++w) ag_merge(m, s, red[w][threadIdx.x][0], red[w][threadIdx.x][1]);
-    rec[((size_t)blockIdx.x * M + threadIdx.x) * 2] = m;
-    rec[((size_t)blockIdx.x * M + threadIdx.x) * 2 + 1] = s;
+  for (int t = threadIdx.x; t < H * M; t += AG_T) {
+    const int hc = t / M, code = t % M;
+    float m = red[0][hc][code][0], s = red[0][hc][code][1];
+    for (int w = 1; w < 4; ++w) ag_merge(m, s, red[w][hc][code][0], red[w][hc][code][1]);
+    rec[((size_t)blockIdx.x * H * M + t) * 2] = m;
+    rec[((size_t)blockIdx.x * H * M + t) * 2 + 1] = s;
   }
 }
 
-// records [nrec][M][2] -> lse[m] = max + log(sum): 256 / M threads per code, each over every (256 / M)-th record in order, their
-// partial pairs merged in thread order (fixed order: bit-reproducible)
-__global__ void __launch_bounds__(AG_T) k_awg_merge(const float* __restrict__ rec, int nrec, int M, float* __restrict__ lse) {
-  const int m_ = threadIdx.x % M, g = threadIdx.x / M, G = AG_T / M;
+// records [nrec][HM][2] -> lse[c] = max + log(sum) per column c = head * M + code: 64 columns per workgroup, 4 threads per column
+// each over every 4th record in order, their partial pairs merged in thread order (fixed order: bit-reproducible)
+__global__ void __launch_bounds__(AG_T) k_awg_merge(const float* __restrict__ rec, int nrec, int HM, float* __restrict__ lse) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   float m = -INFINITY, s = 0.f;
-  for (int r = g; r < nrec; r += G) ag_merge(m, s, rec[((size_t)r * M + m_) * 2], rec[((size_t)r * M + m_) * 2 + 1]);
+  if (col < HM)
+    for (int r = g; r < nrec; r += 4) ag_merge(m, s, rec[((size_t)r * HM + col) * 2], rec[((size_t)r * HM + col) * 2 + 1]);
   __shared__ float red[AG_T][2];
   red[threadIdx.x][0] = m; red[threadIdx.x][1] = s;
   __syncthreads();
-  if (g == 0) {
-    for (int k = 1; k < G; ++k) ag_merge(m, s, red[k * M + m_][0], red[k * M + m_][1]);
-    lse[m_] = m + logf(s);
+  if (g == 0 && col < HM) {
+    for (int k = 1; k < 4; ++k) ag_merge(m, s, red[k * 64 + threadIdx.x][0], red[k * 64 + threadIdx.x][1]);
+    lse[col] = m + logf(s);
   }
 }
 
-// C[r][m] = exp(scale S[r][m] - lse[m]) -> bf16; thread = 8 codes of a row
-__global__ void __launch_bounds__(AG_T) k_awg_cols(const float* __restrict__ S, int64_t L, int M, float scale,
+// C[r][m] = exp(scale S[r][m] - lse[r % H][m]) -> bf16; thread = 8 codes of a row
+__global__ void __launch_bounds__(AG_T) k_awg_cols(const float* __restrict__ S, int64_t R, int M, int H, float scale,
                                                    const float* __restrict__ lse, bf16_t* __restrict__ Cc) {
   const int cpr = M / 8;
   const int64_t i = (int64_t)blockIdx.x * AG_T + threadIdx.x;
-  if (i >= L * cpr) return;
+  if (i >= R * cpr) return;
   const int64_t row = i / cpr;
   const int lc = (int)(i % cpr);
+  const float* ls = lse + (size_t)(row % H) * M + lc * 8;
   const f32x4 a = *(const f32x4*)(S + row * M + lc * 8), b = *(const f32x4*)(S + row * M + lc * 8 + 4);
-  const f32x4 la = *(const f32x4*)(lse + lc * 8), lb = *(const f32x4*)(lse + lc * 8 + 4);
+  const f32x4 la = *(const f32x4*)ls, lb = *(const f32x4*)(ls + 4);
   u32x4 v;
   v.x = pk_bf16(expf(a.x * scale - la.x), expf(a.y * scale - la.y));
   v.y = pk_bf16(expf(a.z * scale - la.z), expf(a.w * scale - la.w));
@@ -126,25 +134,26 @@ __global__ void __launch_bounds__(AG_T) k_awg_cols(const float* __restrict__ S, 
   *(u32x4*)(Cc + row * M + lc * 8) = v;
 }
 
-// colsum[m] = < dmo[m][:], mo[m][:] > over D (= sum over the voxels of dC o C): one wave per code
-__global__ void __launch_bounds__(64) k_awg_rowdot(const float* __restrict__ a, const float* __restrict__ b, int D,
+// colsum[h][m] = sum over the head's channels c = d H + h of dmo[m][c] mo[m][c] (= sum over the voxels of dC o C): one wave per (h, m)
+__global__ void __launch_bounds__(64) k_awg_rowdot(const float* __restrict__ a, const float* __restrict__ b, int inner, int M, int H,
                                                    float* __restrict__ out) {
-  const int m_ = blockIdx.x, lane = threadIdx.x;
+  const int h = blockIdx.x / M, m_ = blockIdx.x % M, lane = threadIdx.x;
   float s = 0.f;
-  for (int d = lane; d < D; d += 64) s = fmaf(a[(size_t)m_ * D + d], b[(size_t)m_ * D + d], s);
+  for (int c = lane * H + h; c < inner; c += 64 * H) s = fmaf(a[(size_t)m_ * inner + c], b[(size_t)m_ * inner + c], s);
   s = wave_sum(s);
-  if (lane == 0) out[m_] = s;
+  if (lane == 0) out[blockIdx.x] = s;
 }
 
-// dS = scale (P o (dP - rowsum(dP o P)) + C o (dC - colsum)) -> bf16
+// dS = scale (P o (dP - rowsum(dP o P)) + C o (dC - colsum[row % H])) -> bf16
 template <int LPR>
 __global__ void __launch_bounds__(AG_T) k_awg_ds(const float* __restrict__ dP, const bf16_t* __restrict__ P,
                                                  const float* __restrict__ dC, const bf16_t* __restrict__ Cc,
-                                                 const float* __restrict__ colsum, int64_t L, float scale, bf16_t* __restrict__ dS) {
-  constexpr int M = LPR * 8, RW = 64 / LPR;
+                                                 const float* __restrict__ colsum, int64_t R, int M, int H, float scale,
+                                                 bf16_t* __restrict__ dS) {
+  constexpr int RW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lc = lane % LPR, lr = lane / LPR;
   const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RW + lr;
-  const bool ok = row < L;
+  const bool ok = row < R && lc * 8 < M;
   float p[8], c[8], gp[8], gc[8];
   if (ok) {
     const u32x4 pv = *(const u32x4*)(P + row * M + lc * 8), cv = *(const u32x4*)(Cc + row * M + lc * 8);
@@ -168,57 +177,70 @@ __global__ void __launch_bounds__(AG_T) k_awg_ds(const float* __restrict__ dP, c
 #pragma unroll
   for (int o = 1; o < LPR; o <<= 1) rs += __shfl_xor(rs, o, 64);
   if (ok) {
+    const float* cs = colsum + (size_t)(row % H) * M + lc * 8;
     float o_[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o_[j] = scale * (p[j] * (gp[j] - rs) + c[j] * (gc[j] - colsum[lc * 8 + j]));
+    for (int j = 0; j < 8; ++j) o_[j] = scale * (p[j] * (gp[j] - rs) + c[j] * (gc[j] - cs[j]));
     u32x4 v;
     v.x = pk_bf16(o_[0], o_[1]); v.y = pk_bf16(o_[2], o_[3]); v.z = pk_bf16(o_[4], o_[5]); v.w = pk_bf16(o_[6], o_[7]);
     *(u32x4*)(dS + row * M + lc * 8) = v;
   }
 }
 
-static bool awg_codes_ok(int M) { return M == 32 || M == 64 || M == 128; }
+static int awg_lpr(int M) { return M <= 32 ? 4 : M <= 64 ? 8 : 16; }
+static bool awg_shape_ok(int M, int H) {
+  if (M < 8 || M > 128 || M % 8) return false;
+  const int rw = 64 / awg_lpr(M);
+  return (H == 1 || H == 2 || H == 4 || H == 8) && H <= rw;
+}
 
 }  // namespace cbim
 
 using namespace cbim;
 
-// P = softmax over the M codes of every row of scale * S (bf16), rec[ceil(L / CBIM_AWG_ROWS)][M][2] = column records
-extern "C" int cbim_awg_rows(const float* S, int64_t L, int M, float scale, void* P, float* rec, void* stream) {
+// P = softmax over the M codes of every (voxel, head) row of scale * S (bf16), rec[ceil(L H / CBIM_AWG_ROWS)][H][M][2] = column records
+extern "C" int cbim_awg_rows(const float* S, int64_t L, int heads, int M, float scale, void* P, float* rec, void* stream) {
   CBIM_CHECK(S && P && rec && L >= 1, CBIM_EINVAL, "awg_rows: null operand / no rows");
-  CBIM_CHECK(awg_codes_ok(M), CBIM_EUNSUPPORTED, "awg_rows: %d codes (32, 64 or 128)", M);
-  const dim3 grid((unsigned)((L + AG_ROWS - 1) / AG_ROWS));
+  CBIM_CHECK(awg_shape_ok(M, heads), CBIM_EUNSUPPORTED, "awg_rows: %d codes x %d heads (codes 8..128 in multiples of 8; 1 | 2 | 4 | 8 heads, at most 64 / lanes-per-row)", M, heads);
+  const int64_t R = L * heads;
+  const dim3 grid((unsigned)((R + AG_ROWS - 1) / AG_ROWS));
   hipStream_t st = (hipStream_t)stream;
-  if (M == 32) CBIM_LAUNCH((k_awg_rows<4>), grid, dim3(AG_T), 0, st, S, L, scale, (bf16_t*)P, rec);
-  else if (M == 64) CBIM_LAUNCH((k_awg_rows<8>), grid, dim3(AG_T), 0, st, S, L, scale, (bf16_t*)P, rec);
-  else CBIM_LAUNCH((k_awg_rows<16>), grid, dim3(AG_T), 0, st, S, L, scale, (bf16_t*)P, rec);
+  switch (awg_lpr(M)) {
+    case 4: CBIM_LAUNCH((k_awg_rows<4>), grid, dim3(AG_T), 0, st, S, R, M, heads, scale, (bf16_t*)P, rec); break;
+    case 8: CBIM_LAUNCH((k_awg_rows<8>), grid, dim3(AG_T), 0, st, S, R, M, heads, scale, (bf16_t*)P, rec); break;
+    default: CBIM_LAUNCH((k_awg_rows<16>), grid, dim3(AG_T), 0, st, S, R, M, heads, scale, (bf16_t*)P, rec); break;
+  }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
-// lse[m] from the records, then C = exp(scale S - lse) (bf16): the softmax over the voxels of every code
-extern "C" int cbim_awg_cols(const float* S, int64_t L, int M, float scale, const float* rec, float* lse, void* Cc, void* stream) {
+// lse[h][m] from the records, then C = exp(scale S - lse) (bf16): the softmax over the voxels of every (head, code)
+extern "C" int cbim_awg_cols(const float* S, int64_t L, int heads, int M, float scale, const float* rec, float* lse, void* Cc, void* stream) {
   CBIM_CHECK(S && rec && lse && Cc && L >= 1, CBIM_EINVAL, "awg_cols: null operand / no rows");
-  CBIM_CHECK(awg_codes_ok(M), CBIM_EUNSUPPORTED, "awg_cols: %d codes (32, 64 or 128)", M);
+  CBIM_CHECK(awg_shape_ok(M, heads), CBIM_EUNSUPPORTED, "awg_cols: %d codes x %d heads", M, heads);
   hipStream_t st = (hipStream_t)stream;
-  const int nrec = (int)((L + AG_ROWS - 1) / AG_ROWS);
-  CBIM_LAUNCH(k_awg_merge, dim3(1), dim3(AG_T), 0, st, rec, nrec, M, lse);
-  const int64_t items = L * (M / 8);
-  CBIM_LAUNCH(k_awg_cols, dim3((unsigned)((items + AG_T - 1) / AG_T)), dim3(AG_T), 0, st, S, L, M, scale, (const float*)lse, (bf16_t*)Cc);
+  const int64_t R = L * heads;
+  const int nrec = (int)((R + AG_ROWS - 1) / AG_ROWS), HM = heads * M;
+  CBIM_LAUNCH(k_awg_merge, dim3((HM + 63) / 64), dim3(AG_T), 0, st, rec, nrec, HM, lse);
+  const int64_t items = R * (M / 8);
+  CBIM_LAUNCH(k_awg_cols, dim3((unsigned)((items + AG_T - 1) / AG_T)), dim3(AG_T), 0, st, S, R, M, heads, scale, (const float*)lse, (bf16_t*)Cc);
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
-// dS (bf16) from dP, P, dC, C and the map-side pair (dmo, mo) [M, D]; colsum_ws: M floats of scratch
-extern "C" int cbim_awg_ds(const float* dP, const void* P, const float* dC, const void* Cc, const float* dmo, const float* mo, int D,
-                           int64_t L, int M, float scale, float* colsum_ws, void* dS, void* stream) {
-  CBIM_CHECK(dP && P && dC && Cc && dmo && mo && colsum_ws && dS && L >= 1 && D >= 1, CBIM_EINVAL, "awg_ds: null operand / bad sizes");
-  CBIM_CHECK(awg_codes_ok(M), CBIM_EUNSUPPORTED, "awg_ds: %d codes (32, 64 or 128)", M);
+// dS (bf16) from dP, P, dC, C [L][H][M] and the map-side pair (dmo, mo) [M][inner], channel c = d H + h; colsum_ws: H M floats
+extern "C" int cbim_awg_ds(const float* dP, const void* P, const float* dC, const void* Cc, const float* dmo, const float* mo, int inner,
+                           int64_t L, int heads, int M, float scale, float* colsum_ws, void* dS, void* stream) {
+  CBIM_CHECK(dP && P && dC && Cc && dmo && mo && colsum_ws && dS && L >= 1 && inner >= heads, CBIM_EINVAL, "awg_ds: null operand / bad sizes");
+  CBIM_CHECK(awg_shape_ok(M, heads) && inner % heads == 0, CBIM_EUNSUPPORTED, "awg_ds: %d codes x %d heads, %d channels", M, heads, inner);
   hipStream_t st = (hipStream_t)stream;
-  CBIM_LAUNCH(k_awg_rowdot, dim3(M), dim3(64), 0, st, dmo, mo, D, colsum_ws);
-  const int rows_per_wg = 4 * (64 / (M / 8));
-  const dim3 grid((unsigned)((L + rows_per_wg - 1) / rows_per_wg));
-  if (M == 32) CBIM_LAUNCH((k_awg_ds<4>), grid, dim3(AG_T), 0, st, dP, (const bf16_t*)P, dC, (const bf16_t*)Cc, (const float*)colsum_ws, L, scale, (bf16_t*)dS);
-  else if (M == 64) CBIM_LAUNCH((k_awg_ds<8>), grid, dim3(AG_T), 0, st, dP, (const bf16_t*)P, dC, (const bf16_t*)Cc, (const float*)colsum_ws, L, scale, (bf16_t*)dS);
-  else CBIM_LAUNCH((k_awg_ds<16>), grid, dim3(AG_T), 0, st, dP, (const bf16_t*)P, dC, (const bf16_t*)Cc, (const float*)colsum_ws, L, scale, (bf16_t*)dS);
+  CBIM_LAUNCH(k_awg_rowdot, dim3(heads * M), dim3(64), 0, st, dmo, mo, inner, M, heads, colsum_ws);
+  const int64_t R = L * heads;
+  const int lpr = awg_lpr(M), rows_per_wg = 4 * (64 / lpr);
+  const dim3 grid((unsigned)((R + rows_per_wg - 1) / rows_per_wg));
+  switch (lpr) {
+    case 4: CBIM_LAUNCH((k_awg_ds<4>), grid, dim3(AG_T), 0, st, dP, (const bf16_t*)P, dC, (const bf16_t*)Cc, (const float*)colsum_ws, R, M, heads, scale, (bf16_t*)dS); break;
+    case 8: CBIM_LAUNCH((k_awg_ds<8>), grid, dim3(AG_T), 0, st, dP, (const bf16_t*)P, dC, (const bf16_t*)Cc, (const float*)colsum_ws, R, M, heads, scale, (bf16_t*)dS); break;
+    default: CBIM_LAUNCH((k_awg_ds<16>), grid, dim3(AG_T), 0, st, dP, (const bf16_t*)P, dC, (const bf16_t*)Cc, (const float*)colsum_ws, R, M, heads, scale, (bf16_t*)dS); break;
+  }
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 

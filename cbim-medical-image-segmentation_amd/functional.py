@@ -675,9 +675,10 @@ class BidirAttnFn(torch.autograd.Function):
         ctx.heads, ctx.scale = heads, scale
         ctx.gemm = ops.awg_eligible(qv, mq, heads)
         if ctx.gemm:
-            # round 6: ONE wide head (config/lits: d_head = the channel count) — the four products on the row-GEMM kernels, the two
+            # round 6: one wide head (config/lits: d_head = the channel count) or a few heads with > 64 codes (config/acdc) — the four
+            # products on the row-GEMM kernels, the two
             # softmaxes between them (csrc/attn_gemm_kernels.hip); P and C are kept for the backward (bf16 [L, M] each)
-            fo, mo, P, Cs = ops.bidir_attn_gemm_fwd(qv, mq, mv, scale)
+            fo, mo, P, Cs = ops.bidir_attn_gemm_fwd(qv, mq, mv, heads, scale)
             ctx.save_for_backward(qv, mq, mv, P, Cs, mo)
             return fo, mo
         fo, mo, cs = ops.bidir_attn_fwd(qv, mq, mv, heads, scale)
@@ -688,7 +689,7 @@ class BidirAttnFn(torch.autograd.Function):
     def backward(ctx, dfo, dmo):
         if ctx.gemm:
             qv, mq, mv, P, Cs, mo = ctx.saved_tensors
-            dqv, dmq, dmv = ops.bidir_attn_gemm_bwd(qv, mq, mv, P, Cs, mo, dfo.contiguous(), dmo.float().contiguous(), ctx.scale)
+            dqv, dmq, dmv = ops.bidir_attn_gemm_bwd(qv, mq, mv, P, Cs, mo, dfo.contiguous(), dmo.float().contiguous(), ctx.heads, ctx.scale)
             return dqv, dmq, dmv, None, None
         qv, mq, mv, cs, mo = ctx.saved_tensors
         dqv, dmq, dmv = ops.bidir_attn_bwd(qv, mq, mv, cs, mo, dfo.contiguous(), dmo.float().contiguous(),

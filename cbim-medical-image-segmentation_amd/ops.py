@@ -1079,47 +1079,51 @@ def se_gate_bwd(dgate, gate, z1, mean, w1, w2, need_dmean=True, need_bias=(True,
 
 
 AWG_ROWS = 256        # include/cbim_hip.h CBIM_AWG_ROWS: rows of S per column record
+AWG = True            # the attention core as matrix products where the register-resident kernels do not apply (tests switch it off for A/Bs)
 
 
 def awg_eligible(qv, mq, heads: int) -> bool:
-    """Whether the BidirectionAttention core of this call runs as matrix products (functional.BidirAttnFn): ONE head whose width is
-    a multiple of 32 (config/lits/medformer_3d.yaml), 32 | 64 | 128 map codes, bf16 feature rows."""
-    inner = int(qv.shape[-1]) // 2
-    return (AWG and heads == 1 and qv.dtype == torch.bfloat16 and inner % 32 == 0 and inner >= 64 and int(mq.shape[1]) in (32, 64, 128)
-            and _spatial(qv) >= 512)
+    """Whether the BidirectionAttention core of this call runs as matrix products (functional.BidirAttnFn): bf16 feature rows, a head /
+    map size the register-resident kernels do not take (d_head not in 8 | 16 | 32, or more than 64 codes — csrc/medformer_kernels.hip
+    attn_wide) and that the softmax kernels of csrc/attn_gemm_kernels.hip do: 1 | 2 | 4 | 8 heads, codes in multiples of 8 up to 128
+    (config/lits: one head of 128 / 256 / 320 channels, 64 codes; config/acdc: 4 heads, 72 codes)."""
+    inner, M = int(qv.shape[-1]) // 2, int(mq.shape[1])
+    if not (AWG and qv.dtype == torch.bfloat16 and heads in (1, 2, 4, 8) and inner % heads == 0 and inner % 8 == 0 and inner >= 64):
+        return False
+    dh = inner // heads
+    wide = dh not in (8, 16, 32) or M > 64
+    lpr = 4 if M <= 32 else 8 if M <= 64 else 16
+    return wide and M % 8 == 0 and 8 <= M <= 128 and heads <= 64 // lpr and (heads * M) % 8 == 0 and _spatial(qv) >= 512
 
 
-AWG = True
-
-
-def awg_rows(S, scale: float):
-    """S float32 [L, M] -> (P bf16 [L, M] = softmax over M of scale*S, column records float32 [ceil(L/256), M, 2])"""
+def awg_rows(S, heads: int, scale: float):
+    """S float32 [L, H*M] -> (P bf16 [L, H*M] = softmax over the M codes of every (voxel, head), column records)"""
     _dev_ok(S)
-    Lr, M = int(S.shape[0]), int(S.shape[1])
-    P = torch.empty((Lr, M), dtype=torch.bfloat16, device=S.device)
-    rec = torch.empty(((Lr + AWG_ROWS - 1) // AWG_ROWS, M, 2), dtype=torch.float32, device=S.device)
-    check(_lib.lib().cbim_awg_rows(_p(S), Lr, M, float(scale), _p(P), _p(rec), _stream(S)), "awg_rows")
+    Lr, M = int(S.shape[0]), int(S.shape[1]) // heads
+    P = torch.empty((Lr, heads * M), dtype=torch.bfloat16, device=S.device)
+    rec = torch.empty(((Lr * heads + AWG_ROWS - 1) // AWG_ROWS, heads, M, 2), dtype=torch.float32, device=S.device)
+    check(_lib.lib().cbim_awg_rows(_p(S), Lr, heads, M, float(scale), _p(P), _p(rec), _stream(S)), "awg_rows")
     return P, rec
 
 
-def awg_cols(S, scale: float, rec):
-    """-> (Cs bf16 [L, M] = softmax over the L rows of scale*S, lse float32 [M])"""
+def awg_cols(S, heads: int, scale: float, rec):
+    """-> (Cs bf16 [L, H*M] = softmax over the L voxels of every (head, code), lse float32 [H, M])"""
     _dev_ok(S, rec)
-    Lr, M = int(S.shape[0]), int(S.shape[1])
-    Cs = torch.empty((Lr, M), dtype=torch.bfloat16, device=S.device)
-    lse = torch.empty((M,), dtype=torch.float32, device=S.device)
-    check(_lib.lib().cbim_awg_cols(_p(S), Lr, M, float(scale), _p(rec), _p(lse), _p(Cs), _stream(S)), "awg_cols")
+    Lr, M = int(S.shape[0]), int(S.shape[1]) // heads
+    Cs = torch.empty((Lr, heads * M), dtype=torch.bfloat16, device=S.device)
+    lse = torch.empty((heads, M), dtype=torch.float32, device=S.device)
+    check(_lib.lib().cbim_awg_cols(_p(S), Lr, heads, M, float(scale), _p(rec), _p(lse), _p(Cs), _stream(S)), "awg_cols")
     return Cs, lse
 
 
-def awg_ds(dP, P, dC, Cs, dmo, mo, scale: float):
-    """dS bf16 [L, M] = scale (P o (dP - rowsum(dP o P)) + C o (dC - <dmo[m], mo[m]>))"""
+def awg_ds(dP, P, dC, Cs, dmo, mo, heads: int, scale: float):
+    """dS bf16 [L, H*M] = scale (P o (dP - rowsum(dP o P)) + C o (dC - colsum)), colsum[h][m] = sum over the head's channels of dmo o mo"""
     _dev_ok(dP, P, dC, Cs, dmo, mo)
-    Lr, M, D = int(dP.shape[0]), int(dP.shape[1]), int(mo.shape[1])
-    dS = torch.empty((Lr, M), dtype=torch.bfloat16, device=dP.device)
-    ws = torch.empty((M,), dtype=torch.float32, device=dP.device)
-    check(_lib.lib().cbim_awg_ds(_p(dP), _p(P), _p(dC), _p(Cs), _p(dmo), _p(mo), D, Lr, M, float(scale), _p(ws), _p(dS), _stream(dP)),
-          "awg_ds")
+    Lr, M, inner = int(dP.shape[0]), int(dP.shape[1]) // heads, int(mo.shape[1])
+    dS = torch.empty((Lr, heads * M), dtype=torch.bfloat16, device=dP.device)
+    ws = torch.empty((heads * M,), dtype=torch.float32, device=dP.device)
+    check(_lib.lib().cbim_awg_ds(_p(dP), _p(P), _p(dC), _p(Cs), _p(dmo), _p(mo), inner, Lr, heads, M, float(scale), _p(ws), _p(dS),
+                                 _stream(dP)), "awg_ds")
     return dS
 
 
@@ -1130,12 +1134,43 @@ def _pack_lin(w2d):
     return pack_weights(w2d.view(w2d.shape[0], w2d.shape[1], 1, 1, 1), g, 0)
 
 
-def bidir_attn_gemm_fwd(qv, mq, mv, scale: float):
-    """BidirectionAttention core of ONE head as matrix products (medformer_utils.py:63-97; csrc/attn_gemm_kernels.hip): per image
-    S = Q MQ^T (row GEMM, fp32 out) -> P, C (both softmaxes, bf16) -> feat_out = P MV (row GEMM), map_out = C^T FV (weight-gradient
-    GEMM over the voxels).  Returns (feat_out like qv[..., :inner], map_out float32 [N, M, inner], P, C)."""
+_HEAD_MASKS = {}
+
+
+def _head_mask(heads: int, inner: int, device):
+    """float32 [H, 1, inner]: 1 where channel c belongs to head h (c % H == h — '(dim_head heads)', medformer_utils.py:43-59); built once"""
+    key = (heads, inner, str(device))
+    m = _HEAD_MASKS.get(key)
+    if m is None:
+        c = torch.arange(inner) % heads
+        m = _HEAD_MASKS[key] = (c[None, :] == torch.arange(heads)[:, None]).float().view(heads, 1, inner).to(device)
+    return m
+
+
+def _blocks(w, heads: int):
+    """map-side rows [M, inner] -> the block matrix of all heads [H*M, inner]: row h*M + m keeps the channels of head h"""
+    if heads == 1:
+        return w
+    return (w.unsqueeze(0) * _head_mask(heads, int(w.shape[1]), w.device)).reshape(heads * int(w.shape[0]), int(w.shape[1]))
+
+
+def _diag(G, heads: int):
+    """the inverse gather: G [H*M, inner] (a product over all head pairs) -> [M, inner], entry (m, c) from row (c % H)*M + m"""
+    if heads == 1:
+        return G
+    M = int(G.shape[0]) // heads
+    return (G.view(heads, M, int(G.shape[1])) * _head_mask(heads, int(G.shape[1]), G.device)).sum(0)
+
+
+def bidir_attn_gemm_fwd(qv, mq, mv, heads: int, scale: float):
+    """BidirectionAttention core as matrix products (medformer_utils.py:63-97; csrc/attn_gemm_kernels.hip): per image
+    S = Q MQ^T of all heads in ONE row GEMM whose weight is the block matrix of the heads (fp32 out, [L, H*M]) -> P, C (both softmaxes,
+    bf16) -> feat_out = P MV (row GEMM), map_out = the head-diagonal of C^T FV (weight-gradient GEMM over the voxels).  The products
+    between different heads that the block form computes and discards are a few GFLOP at most.
+    Returns (feat_out like qv[..., :inner], map_out float32 [N, M, inner], P, C)."""
     N, Lr, inner = int(qv.shape[0]), _spatial(qv), int(qv.shape[-1]) // 2
     M = int(mq.shape[1])
+    HM = heads * M
     rows = qv.reshape(N, Lr, 2 * inner)
     fo = torch.empty(tuple(qv.shape[:-1]) + (inner,), dtype=qv.dtype, device=qv.device)
     fo_r = fo.view(N, Lr, inner)
@@ -1143,19 +1178,23 @@ def bidir_attn_gemm_fwd(qv, mq, mv, scale: float):
     Ps, Cs = [], []
     for n in range(N):
         q, v = rows[n, :, :inner], rows[n, :, inner:]
-        S = token_linear(q, _pack_lin(mq[n]), None, M, out_dtype=torch.float32)             # [L, M]
-        P, rec = awg_rows(S, scale)
-        Cn, _ = awg_cols(S, scale, rec)
-        token_linear(P, _pack_lin(mv[n].t()), None, inner, out=fo_r[n])                     # P [L, M] x MV [M, inner]
-        token_linear_wgrad(v, Cn, out=mo[n])                                                # sum_l C[l][m] v[l][d]
+        S = token_linear(q, _pack_lin(_blocks(mq[n], heads)), None, HM, out_dtype=torch.float32)   # [L, H*M]
+        P, rec = awg_rows(S, heads, scale)
+        Cn, _ = awg_cols(S, heads, scale, rec)
+        token_linear(P, _pack_lin(_blocks(mv[n], heads).t()), None, inner, out=fo_r[n])            # P [L, H*M] x MV blocks [H*M, inner]
+        if heads == 1:
+            token_linear_wgrad(v, Cn, out=mo[n])                                                   # sum_l C[l][m] v[l][d]
+        else:
+            mo[n] = _diag(token_linear_wgrad(v, Cn), heads)
         Ps.append(P)
         Cs.append(Cn)
     return fo, mo, torch.stack(Ps), torch.stack(Cs)
 
 
-def bidir_attn_gemm_bwd(qv, mq, mv, P, Cs, mo, dfo, dmo, scale: float):
+def bidir_attn_gemm_bwd(qv, mq, mv, P, Cs, mo, dfo, dmo, heads: int, scale: float):
     N, Lr, inner = int(qv.shape[0]), _spatial(qv), int(qv.shape[-1]) // 2
     M = int(mq.shape[1])
+    HM = heads * M
     rows = qv.reshape(N, Lr, 2 * inner)
     dfo_r = dfo.reshape(N, Lr, inner)
     dqv = torch.empty(tuple(qv.shape), dtype=qv.dtype, device=qv.device)
@@ -1164,13 +1203,18 @@ def bidir_attn_gemm_bwd(qv, mq, mv, P, Cs, mo, dfo, dmo, scale: float):
     dmv = torch.empty((N, M, inner), dtype=torch.float32, device=qv.device)
     for n in range(N):
         q, v = rows[n, :, :inner], rows[n, :, inner:]
-        dP = token_linear(dfo_r[n], _pack_lin(mv[n]), None, M, out_dtype=torch.float32)     # dfo [L, D] x MV^T
-        token_linear_wgrad(dfo_r[n], P[n], out=dmv[n])                                      # sum_l P[l][m] dfo[l][d]
-        dC = token_linear(v, _pack_lin(dmo[n]), None, M, out_dtype=torch.float32)           # FV [L, D] x dmo^T
-        token_linear(Cs[n], _pack_lin(dmo[n].t()), None, inner, out=dq_r[n, :, inner:])     # dFV = C dmo
-        dS = awg_ds(dP, P[n], dC, Cs[n], dmo[n], mo[n], scale)
-        token_linear(dS, _pack_lin(mq[n].t()), None, inner, out=dq_r[n, :, :inner])         # dQ = dS MQ
-        token_linear_wgrad(q, dS, out=dmq[n])                                               # dMQ = dS^T Q
+        bq, bv, bd = _blocks(mq[n], heads), _blocks(mv[n], heads), _blocks(dmo[n], heads)
+        dP = token_linear(dfo_r[n], _pack_lin(bv), None, HM, out_dtype=torch.float32)             # dfo [L, inner] x MV^T
+        dC = token_linear(v, _pack_lin(bd), None, HM, out_dtype=torch.float32)                     # FV [L, inner] x dmo^T
+        token_linear(Cs[n], _pack_lin(bd.t()), None, inner, out=dq_r[n, :, inner:])                # dFV = C dmo
+        dS = awg_ds(dP, P[n], dC, Cs[n], dmo[n], mo[n], heads, scale)
+        token_linear(dS, _pack_lin(bq.t()), None, inner, out=dq_r[n, :, :inner])                   # dQ = dS MQ
+        if heads == 1:
+            token_linear_wgrad(dfo_r[n], P[n], out=dmv[n])                                         # sum_l P[l][m] dfo[l][d]
+            token_linear_wgrad(q, dS, out=dmq[n])                                                  # dMQ = dS^T Q
+        else:
+            dmv[n] = _diag(token_linear_wgrad(dfo_r[n], P[n]), heads)
+            dmq[n] = _diag(token_linear_wgrad(q, dS), heads)
     return dqv, dmq, dmv
 
 

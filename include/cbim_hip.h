@@ -454,21 +454,23 @@ int cbim_se_gate_fwd(const float* mean, const float* W1, const float* b1, const 
                      int N, int C, int H, void* stream);
 int cbim_se_gate_bwd(const float* dgate, const float* gate, const float* z1, const float* mean, const float* W1, const float* W2,
                      float* dz1_ws, float* dW1, float* db1, float* dW2, float* db2, float* dmean, int N, int C, int H, void* stream);
-/* BidirectionAttention core for ONE WIDE HEAD as matrix products (round 6; config/lits/medformer_3d.yaml: num_heads = 1, d_head =
- * 128 / 256 / 320) — the softmax side between the row GEMMs (cbim_token_linear / cbim_token_linear_wgrad), medformer_utils.py:77-90:
- * S float32 [L][M] = Q MQ^T from the row GEMM, M = 32 | 64 | 128 codes.
- *   cbim_awg_rows: P = softmax over the codes of each row of scale*S (bf16 [L][M], :80) + the column records
- *                  rec float32 [ceil(L / CBIM_AWG_ROWS)][M][2] = (max, sum exp) of every code over the workgroup's rows
- *   cbim_awg_cols: lse[m] from the records (fixed order), C = exp(scale*S - lse) (bf16 [L][M]): the softmax over the voxels (:82)
- *   cbim_awg_ds:   dS = scale (P o (dP - rowsum(dP o P)) + C o (dC - <dmo[m], mo[m]>)) (bf16 [L][M]): the backward of both
- *                  softmaxes; dP = dfeat_out MV^T and dC = FV dmap_out^T float32 [L][M] from the row GEMM, dmo / mo float32 [M][D],
- *                  colsum_ws M floats of scratch.
+/* BidirectionAttention core as matrix products (round 6) for the head / map sizes the register-resident kernels do not take — one wide
+ * head (config/lits/medformer_3d.yaml: num_heads = 1, d_head = 128 / 256 / 320) or a few heads with more than 64 codes (config/acdc:
+ * 4 heads, 72 codes) — the softmax side between the row GEMMs (cbim_token_linear / cbim_token_linear_wgrad), medformer_utils.py:77-90.
+ * S float32 [L][H][M] = Q MQ^T of all heads from ONE row GEMM (weight = the block matrix of the heads), M codes in multiples of 8 up
+ * to 128, H = 1 | 2 | 4 | 8 heads with H <= 64 / lanes-per-row (lanes-per-row = 4 | 8 | 16 for M <= 32 | 64 | 128).
+ *   cbim_awg_rows: P = softmax over the codes of each (voxel, head) row of scale*S (bf16 [L][H][M], :80) + the column records
+ *                  rec float32 [ceil(L H / CBIM_AWG_ROWS)][H][M][2] = (max, sum exp) of every (head, code) over the workgroup's rows
+ *   cbim_awg_cols: lse[h][m] from the records (fixed order), C = exp(scale*S - lse) (bf16 [L][H][M]): the softmax over the voxels (:82)
+ *   cbim_awg_ds:   dS = scale (P o (dP - rowsum(dP o P)) + C o (dC - colsum[h][m])) (bf16 [L][H][M]): the backward of both softmaxes;
+ *                  dP = dfeat_out MV^T and dC = FV dmap_out^T float32 [L][H][M] from the row GEMM; colsum[h][m] = the sum over the head's
+ *                  channels c = d H + h of dmo[m][c] mo[m][c], dmo / mo float32 [M][inner]; colsum_ws: H M floats of scratch.
  * Replaces torch.softmax(dim=-1) / torch.softmax(dim=-2) and their backward inside BidirectionAttention.forward. */
 #define CBIM_AWG_ROWS 256
-int cbim_awg_rows(const float* S, int64_t L, int M, float scale, void* P, float* rec, void* stream);
-int cbim_awg_cols(const float* S, int64_t L, int M, float scale, const float* rec, float* lse, void* C, void* stream);
-int cbim_awg_ds(const float* dP, const void* P, const float* dC, const void* C, const float* dmo, const float* mo, int D, int64_t L,
-                int M, float scale, float* colsum_ws, void* dS, void* stream);
+int cbim_awg_rows(const float* S, int64_t L, int heads, int M, float scale, void* P, float* rec, void* stream);
+int cbim_awg_cols(const float* S, int64_t L, int heads, int M, float scale, const float* rec, float* lse, void* C, void* stream);
+int cbim_awg_ds(const float* dP, const void* P, const float* dC, const void* C, const float* dmo, const float* mo, int inner, int64_t L,
+                int heads, int M, float scale, float* colsum_ws, void* dS, void* stream);
 /* SemanticMapGeneration tail (medformer_utils.py:218-228) on fw rows = [feat (C) | weight logits (M)]:
  * map[n][c][j] = sum_l feat[l,c] * softmax_L(logit[:,j])[l].  colstat: float [N][M][2].
  * M <= cbim_attn_wide_max_codes(). */

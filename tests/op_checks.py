@@ -980,12 +980,12 @@ def check_attn(dev, dtype, N=2, heads=3, dh=8, dhw=(5, 6, 7), M=8, seed=13):
     assert relerr(dmv.cpu().permute(0, 2, 1), mv.grad) < tol(dtype, 5e-5, 3e-2), "attn dmv"
 
 
-def check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64, seed=21):
+def check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64, seed=21, heads=1):
     """BidirectionAttention core of ONE wide head as matrix products (round 6: ops.bidir_attn_gemm_fwd / _bwd + csrc/attn_gemm_kernels.hip;
     config/lits/medformer_3d.yaml) — bf16 rows: against torch on the same rounded operands, and against the vector-ALU kernel of
     attn_wide.hip it replaces (fp32 accumulation of the same bf16 inputs): both softmaxes, all four products, every gradient."""
     torch.manual_seed(seed)
-    dtype, heads, inner = torch.bfloat16, 1, dh
+    dtype, inner = torch.bfloat16, heads * dh
     L = dhw[0] * dhw[1] * dhw[2]
     qv = torch.randn(N, 2 * inner, *dhw)
     qvl = to_cl(qv, dtype).to(dev)
@@ -997,10 +997,10 @@ def check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64, seed=21):
     mql = mq.detach().permute(0, 2, 1).contiguous().to(dev)
     mvl = mv.detach().permute(0, 2, 1).contiguous().to(dev)
     assert ops.awg_eligible(qvl, mql, heads) or L < 512
-    fo, mo, P, Cs = ops.bidir_attn_gemm_fwd(qvl, mql, mvl, scale)
+    fo, mo, P, Cs = ops.bidir_attn_gemm_fwd(qvl, mql, mvl, heads, scale)
     fo0, mo0, cs0 = ops.bidir_attn_fwd(qvl, mql, mvl, heads, scale)
     # P, C: rows / columns of probabilities (bf16)
-    assert float((P.float().sum(-1) - 1).abs().max()) < 2e-2 and float((Cs.float().sum(1) - 1).abs().max()) < 2e-2
+    assert float((P.float().view(N, L, heads, M).sum(-1) - 1).abs().max()) < 2e-2 and float((Cs.float().sum(1) - 1).abs().max()) < 2e-2
     for name, got, ref in (("feat_out", from_cl(fo.cpu()).reshape(N, inner, L), fo_r.detach()),
                            ("map_out", mo.cpu().permute(0, 2, 1), mo_r.detach())):
         assert relerr(got, ref) < 2e-2, "attn gemm " + name + " vs torch"
@@ -1011,7 +1011,7 @@ def check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64, seed=21):
     (fo_r * from_cl(dfol.cpu()).reshape(N, inner, L)).sum().backward(retain_graph=True)
     (mo_r * dmo).sum().backward()
     dmol = dmo.permute(0, 2, 1).contiguous().to(dev)
-    dqv, dmq, dmv = ops.bidir_attn_gemm_bwd(qvl, mql, mvl, P, Cs, mo, dfol, dmol, scale)
+    dqv, dmq, dmv = ops.bidir_attn_gemm_bwd(qvl, mql, mvl, P, Cs, mo, dfol, dmol, heads, scale)
     dqv0, dmq0, dmv0 = ops.bidir_attn_bwd(qvl, mql, mvl, cs0, mo0, dfol, dmol, heads, scale)
     assert relerr(from_cl(dqv.cpu()).reshape(N, 2 * inner, L), qvr.grad) < 4e-2, "attn gemm dqv"
     assert relerr(dmq.cpu().permute(0, 2, 1), mq.grad) < 4e-2, "attn gemm dmq"

@@ -237,10 +237,11 @@ def test_medformer_norm_branches_bf16_inside_envelope_over_eight_inputs(dev, nam
     assert not bad, bad
 
 
-def test_medformer_lits_config_one_wide_head_on_the_gemm_path_bf16_inside_envelope(dev):
-    """config/lits/medformer_3d.yaml at its shipped widths (num_heads all 1: d_head = 128 / 256 / 320, 64 map codes) on a 64^3 input:
-    the attention cores of the 16^3 and 8^3 levels run as matrix products (round 6: ops.bidir_attn_gemm_*, csrc/attn_gemm_kernels.hip;
-    the 4^3 level stays on attn_wide.hip).  bf16 engine inside 1.5 x the oracle's own autocast(bf16) deviation; the same step on the
+@pytest.mark.parametrize("cfg,size,n_gemm", [("lits/medformer_3d.yaml", (64, 64, 64), 12), ("acdc/medformer_3d.yaml", (8, 96, 96), None)])
+def test_medformer_wide_configs_on_the_gemm_attention_path_bf16_inside_envelope(dev, cfg, size, n_gemm):
+    """config/lits/medformer_3d.yaml (num_heads all 1: d_head = 128 / 256 / 320, 64 map codes; 64^3 input) and config/acdc/medformer_3d.yaml
+    (4 heads, 72 codes, anisotropic stem; 8x96x96 input) at their shipped widths: the attention cores of the levels with >= 512 voxels
+    run as matrix products (round 6: ops.bidir_attn_gemm_*, csrc/attn_gemm_kernels.hip; the coarsest level stays on attn_wide.hip).  bf16 engine inside 1.5 x the oracle's own autocast(bf16) deviation; the same step on the
     vector-ALU kernels it replaces is recorded beside it."""
     import json
     import os
@@ -252,17 +253,17 @@ def test_medformer_lits_config_one_wide_head_on_the_gemm_path_bf16_inside_envelo
     from oracle.medformer_ref import medformer_forward
     from tests.util import bf16_envelope_vs_oracle
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shipped_configs.json")) as f:
-        a = json.load(f)["lits/medformer_3d.yaml"]["args"]
+        a = json.load(f)[cfg]["args"]
     kw = {k: a[k] for k in ("base_chan", "map_size", "conv_block", "conv_num", "trans_num", "num_heads", "fusion_depth", "fusion_dim",
                             "fusion_heads", "expansion", "proj_type", "norm", "act", "kernel_size", "aux_loss")}
     kw.update(chan_num=a.get("chan_num", [64, 128, 256, 320, 256, 128, 64, 32]), scale=a["down_scale"], attn_drop=0., proj_drop=0.)
     fwd = partial(medformer_forward, map_size=kw["map_size"], num_heads=kw["num_heads"], fusion_heads=kw["fusion_heads"],
                   fusion_depth=kw["fusion_depth"], kernel_size=kw["kernel_size"], scale=kw["scale"], act=kw["act"], aux_loss=kw["aux_loss"])
-    S, classes = 64, int(a["classes"])
+    classes = int(a["classes"])
     g = torch.Generator().manual_seed(41)
-    coarse = torch.randint(0, classes, (1, 1, S // 8, S // 8, S // 8), generator=g)
-    lab = torch.nn.functional.interpolate(coarse.float(), size=(S,) * 3, mode="nearest").long()
-    x = torch.randn(1, 1, S, S, S, generator=g).clamp_(-7.4, 2.2)
+    coarse = torch.randint(0, classes, (1, 1) + tuple(max(1, e // 8) for e in size), generator=g)
+    lab = torch.nn.functional.interpolate(coarse.float(), size=tuple(size), mode="nearest").long()
+    x = torch.randn((1, 1) + tuple(size), generator=g).clamp_(-7.4, 2.2)
     w = torch.ones(classes)
     w[0] = 0.5
     torch.manual_seed(2024)
@@ -271,10 +272,12 @@ def test_medformer_lits_config_one_wide_head_on_the_gemm_path_bf16_inside_envelo
     orig = ops.bidir_attn_gemm_fwd
     ops.bidir_attn_gemm_fwd = lambda *args: (taken.append(int(args[0].shape[1])), orig(*args))[1]
     try:
-        env, bad = bf16_envelope_vs_oracle(dev, net, fwd, x, lab, w, tag="medformer_lits_64_gemm_attention_bf16_envelope")
+        env, bad = bf16_envelope_vs_oracle(dev, net, fwd, x, lab, w, tag="medformer_" + cfg.split("/")[0] + "_gemm_attention_bf16_envelope",
+                                           loss_weights=a.get("aux_weight") if kw["aux_loss"] else None)
     finally:
         ops.bidir_attn_gemm_fwd = orig
-    assert len(taken) == 12 and sorted(set(taken)) == [8, 16], taken      # 2 + 4 (down) + 4 + 2 (up) blocks at 16^3 / 8^3
+    print("attention cores on the GEMM path:", len(taken), "calls")
+    assert len(taken) > 0 and (n_gemm is None or len(taken) == n_gemm), taken      # lits: 2 + 4 (down) + 4 + 2 (up) blocks at 16^3 / 8^3
     assert not bad, bad
     # the same bf16 step on attn_wide.hip (fp32 accumulation of the same bf16 operands)
     def step():
@@ -283,7 +286,9 @@ def test_medformer_lits_config_one_wide_head_on_the_gemm_path_bf16_inside_envelo
         cbim_amd.set_compute_dtype("bf16")
         try:
             out = net(x.to(dev))
-            Fn.DiceCEFn.apply(out, lab.to(dev), w.to(dev))[2].backward()
+            outs = list(out) if isinstance(out, (list, tuple)) else [out]
+            sum(Fn.DiceCEFn.apply(o, lab.to(dev), w.to(dev))[2] for o in outs).backward()
+            out = outs[0]
         finally:
             cbim_amd.set_compute_dtype(None)
         return out.detach().float().cpu(), {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}
@@ -301,7 +306,7 @@ def test_medformer_lits_config_one_wide_head_on_the_gemm_path_bf16_inside_envelo
     # (a record, not a bar: on this untrained 30-block net two bf16 evaluations differ from each other about as much as each
     #  differs from the fp32 oracle — measured 0.17 of the logit range between them against 0.30 / 0.34 to the oracle for the
     #  engine / the oracle's own autocast run; the kernels are compared on identical operands in tests/op_checks.check_attn_gemm)
-    record_parity("medformer_lits_64_gemm_vs_wide", {"logits_rel": e, "grad_cos_min": cos})
+    record_parity("medformer_" + cfg.split("/")[0] + "_gemm_vs_wide", {"logits_rel": e, "grad_cos_min": cos})
 
 
 # ---- SwinUNETR -------------------------------------------------------------

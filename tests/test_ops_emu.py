@@ -127,7 +127,10 @@ def test_attn_one_wide_head_as_matrix_products(dev):
     """round 6: the BidirectionAttention core of ONE wide head (config/lits) on the row-GEMM kernels + csrc/attn_gemm_kernels.hip"""
     oc.check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64)
     oc.check_attn_gemm(dev, N=1, dh=160, dhw=(8, 8, 8), M=32)         # d_head not a power of two (lits: 320), 32 codes
-    oc.check_attn_gemm(dev, N=1, dh=64, dhw=(5, 9, 13), M=128)        # ragged last record (585 rows), 128 codes
+    oc.check_attn_gemm(dev, N=1, dh=64, dhw=(5, 9, 13), M=128)
+    oc.check_attn_gemm(dev, N=1, dh=32, dhw=(8, 12, 12), M=72, heads=4)     # acdc down2: 4 heads x 72 codes
+    oc.check_attn_gemm(dev, N=2, dh=80, dhw=(4, 12, 12), M=72, heads=4)     # acdc down4
+    oc.check_attn_gemm(dev, N=1, dh=40, dhw=(8, 8, 8), M=24, heads=2)       # 24 codes: lanes past M idle        # ragged last record (585 rows), 128 codes
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
