@@ -1,11 +1,25 @@
 """The 192-token fusion transformer of SemanticMapFusion with the reference's parameter names
 (/root/reference/model/dim3/trans_layers.py:16-118).  It sees 3 x 64 map tokens of width 320
 (0.5 GFLOP) — far below one kernel launch worth of work per op — so it is expressed
-with torch's own Linear/LayerNorm/softmax ops (hipBLASLt on the GPU) rather than hand-written kernels.
+with torch's own LayerNorm / softmax / matmul ops rather than hand-written kernels; its Linears run on the
+engine's row GEMM in its fp32-exact form (bf16 hi + lo fragments of rows and weights) in the bf16 engine mode —
+round 6: hipBLASLt picked 256-row macro tiles for the 216 tokens of config/acdc (60 - 80 us per GEMM).
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+def _lin(lin: nn.Linear, x):
+    """nn.Linear over the float32 token rows: the engine's fp32-exact row GEMM in the bf16 engine mode, torch's own otherwise"""
+    from ... import _lib
+    from ... import functional as Fn
+    w = lin.weight
+    if (Fn.compute_dtype() == torch.bfloat16 and x.dtype == torch.float32 and w.dtype == torch.float32
+            and x.device.type == ("cpu" if _lib.backend() == "emu" else "cuda") and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
+            and w.shape[1] <= 4096):
+        return Fn.token_linear(x, w, lin.bias, out_dtype=torch.float32, exact=True)
+    return lin(x)
 
 
 class Mlp(nn.Module):
@@ -16,7 +30,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hid_dim or in_dim, out_dim or in_dim)
 
     def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+        return _lin(self.fc2, self.act(_lin(self.fc1, x)))
 
 
 class PreNorm(nn.Module):
@@ -42,9 +56,9 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, Lt, _ = x.shape
-        q, k, v = (t.reshape(B, Lt, self.heads, -1).transpose(1, 2) for t in self.to_qkv(x).chunk(3, dim=-1))
+        q, k, v = (t.reshape(B, Lt, self.heads, -1).transpose(1, 2) for t in _lin(self.to_qkv, x).chunk(3, dim=-1))
         p = F.softmax(torch.matmul(q, k.transpose(-1, -2)) * self.scale, dim=-1)
-        return self.to_out(torch.matmul(p, v).transpose(1, 2).reshape(B, Lt, -1))
+        return _lin(self.to_out, torch.matmul(p, v).transpose(1, 2).reshape(B, Lt, -1))
 
 
 class TransformerBlock(nn.Module):
