@@ -238,7 +238,7 @@ def test_attn(dev, dtype):
     oc.check_attn(dev, dtype, N=1, heads=4, dh=32, dhw=(16, 16, 16), M=64)   # down3-sized
 
 
-def test_attn_one_wide_head_as_matrix_products(dev):
+def test_attn_core_as_matrix_products(dev):
     """round 6: the BidirectionAttention core of ONE wide head (config/lits) on the row-GEMM kernels + csrc/attn_gemm_kernels.hip"""
     oc.check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64)
     oc.check_attn_gemm(dev, N=1, dh=160, dhw=(8, 8, 8), M=32)
