@@ -64,6 +64,8 @@ _SIGS = {
     "cbim_norm_affine_act_fwd": (i32, [i32, vp, i64, vp, vp, vp, i64, i32, i64, i32, i32, vp]),
     "cbim_norm_affine_bwd_reduce": (i32, [i32, vp, i64, vp, i64, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp]),
     "cbim_norm_affine_bwd_apply": (i32, [i32, vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, vp]),
+    "cbim_bn_finish_fwd": (i32, [vp, i32, i32, C.c_double, f32, f32, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "cbim_bn_finish_bwd": (i32, [vp, i32, i32, C.c_double, vp, i32, vp, vp, vp, vp]),
     "cbim_maxpool3d_fwd": (i32, [i32, vp, vp, vp] + [i32] * 8 + [vp]),
     "cbim_maxpool3d_bwd": (i32, [i32, vp, vp, vp] + [i32] * 8 + [vp]),
     "cbim_upcat_fwd": (i32, [i32, vp, vp, vp] + [i32] * 10 + [vp]),

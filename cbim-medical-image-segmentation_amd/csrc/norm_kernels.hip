@@ -714,6 +714,86 @@ extern "C" int cbim_norm_affine_bwd_reduce(int dtype, const void* g, int64_t g_s
   return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
 }
 
+// ---- BatchNorm: the per-channel arithmetic between the per-image statistics and the streaming kernels (round 6) --------------------
+namespace cbim {
+__global__ void __launch_bounds__(256) k_bn_finish_fwd(const float* __restrict__ st, int N, int C, double S, float eps, float momentum,
+                                                       float* __restrict__ rm, float* __restrict__ rv, int use_batch,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ stats_out, float* __restrict__ affine_out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double mean_b, var_b;
+  if (use_batch) {
+    double sm = 0.0, sq = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const double m = (double)st[((size_t)n * C + c) * 2], r = (double)st[((size_t)n * C + c) * 2 + 1];
+      const double v = 1.0 / (r * r) - (double)eps;          // the per-image biased variance back from rstd
+      sm += m;
+      sq += v + m * m;
+    }
+    mean_b = sm / N;
+    var_b = sq / N - mean_b * mean_b;                          // biased variance of the batch (equal voxel counts per image)
+    if (var_b < 0.0) var_b = 0.0;
+    if (rm && rv) {
+      const double n = (double)N * S;
+      rm[c] = rm[c] * (1.f - momentum) + momentum * (float)mean_b;
+      rv[c] = rv[c] * (1.f - momentum) + momentum * (float)(var_b * (n / (n - 1.0 > 1.0 ? n - 1.0 : 1.0)));
+    }
+  } else {
+    mean_b = (double)rm[c];
+    var_b = (double)rv[c];
+  }
+  const float mb = (float)mean_b, rb = (float)(1.0 / sqrt(var_b + (double)eps));
+  for (int n = 0; n < N; ++n) {
+    stats_out[((size_t)n * C + c) * 2] = mb;
+    stats_out[((size_t)n * C + c) * 2 + 1] = rb;
+  }
+  affine_out[(size_t)c * 2] = gamma ? gamma[c] : 1.f;
+  affine_out[(size_t)c * 2 + 1] = beta ? beta[c] : 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_bn_finish_bwd(const float* __restrict__ sums, int N, int C, double cnt,
+                                                       const float* __restrict__ affine, int use_batch, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, float* __restrict__ sums_out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int n = 0; n < N; ++n) {
+    a += (double)sums[((size_t)n * C + c) * 2];
+    b += (double)sums[((size_t)n * C + c) * 2 + 1];
+  }
+  a /= N;
+  b /= N;
+  if (dgamma) dgamma[c] = (float)(b * cnt);
+  if (dbeta) dbeta[c] = (float)(a * cnt);
+  const double g = (double)affine[(size_t)c * 2];
+  const float s0 = use_batch ? (float)(g * a) : 0.f, s1 = use_batch ? (float)(g * b) : 0.f;
+  for (int n = 0; n < N; ++n) {
+    sums_out[((size_t)n * C + c) * 2] = s0;
+    sums_out[((size_t)n * C + c) * 2 + 1] = s1;
+  }
+}
+}  // namespace cbim
+
+extern "C" int cbim_bn_finish_fwd(const float* st, int N, int C, double S, float eps, float momentum, float* running_mean,
+                                  float* running_var, int use_batch, const float* gamma, const float* beta, float* stats_out,
+                                  float* affine_out, void* stream) {
+  CBIM_CHECK(stats_out && affine_out && N >= 1 && C >= 1 && S >= 1.0, CBIM_EINVAL, "bn_finish_fwd: null operand / bad sizes");
+  CBIM_CHECK(use_batch ? st != nullptr : (running_mean && running_var), CBIM_EINVAL, "bn_finish_fwd: the statistics this mode reads are missing");
+  CBIM_CHECK((running_mean == nullptr) == (running_var == nullptr), CBIM_EINVAL, "bn_finish_fwd: running mean and variance go together");
+  CBIM_LAUNCH(cbim::k_bn_finish_fwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, st, N, C, S, eps, momentum, running_mean,
+              running_var, use_batch, gamma, beta, stats_out, affine_out);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
+extern "C" int cbim_bn_finish_bwd(const float* sums, int N, int C, double cnt, const float* affine, int use_batch, float* dgamma,
+                                  float* dbeta, float* sums_out, void* stream) {
+  CBIM_CHECK(sums && affine && sums_out && N >= 1 && C >= 1, CBIM_EINVAL, "bn_finish_bwd: null operand / bad sizes");
+  CBIM_LAUNCH(cbim::k_bn_finish_bwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, N, C, cnt, affine, use_batch, dgamma,
+              dbeta, sums_out);
+  return CBIM_LAST_LAUNCH() == hipSuccess ? CBIM_OK : CBIM_ELAUNCH;
+}
+
 extern "C" int cbim_norm_affine_bwd_apply(int dtype, const void* g, int64_t g_stride, const void* x, int64_t x_stride,
                                           const float* stats, const float* affine, const float* sums, void* dx, int64_t dx_stride,
                                           int N, int64_t S, int C, int act, int masked, void* stream) {

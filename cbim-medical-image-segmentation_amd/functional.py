@@ -1072,24 +1072,18 @@ class BatchNormActFn(torch.autograd.Function):
         S = 1
         for d in x.shape[1:-1]:
             S *= int(d)
-        if use_batch_stats:
-            st = ops.instnorm_stats(x, eps).double()                       # [N, C, (mean, rstd)] per image
-            mean_nc, var_nc = st[..., 0], 1.0 / (st[..., 1] * st[..., 1]) - eps
-            mean_b = mean_nc.mean(0)
-            var_b = (var_nc + mean_nc * mean_nc).mean(0) - mean_b * mean_b   # biased variance of the batch
-            var_b = var_b.clamp_min(0.0)
-            if running_mean is not None:
-                with torch.no_grad():
-                    n = float(N * S)
-                    running_mean.mul_(1.0 - momentum).add_(mean_b.to(running_mean.dtype), alpha=momentum)
-                    running_var.mul_(1.0 - momentum).add_((var_b * (n / max(n - 1.0, 1.0))).to(running_var.dtype), alpha=momentum)
-        else:
-            mean_b, var_b = running_mean.detach().double(), running_var.detach().double()
-        rstd_b = torch.rsqrt(var_b + eps)
-        stats = torch.stack([mean_b, rstd_b], -1).float().unsqueeze(0).expand(N, C, 2).contiguous()
-        g32 = weight.detach().float() if weight is not None else torch.ones(C, device=x.device)
-        b32 = bias.detach().float() if bias is not None else torch.zeros(C, device=x.device)
-        affine = torch.stack([g32, b32], -1).contiguous()
+        def f32(t):
+            return None if t is None else (t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous())
+        # round 6: ONE launch for the per-channel arithmetic (batch statistics pooled in float64, running-statistics update in place,
+        # statistics repeated per image, affine pairs) — it was ~25 float64 ATen launches on [C] vectors per BatchNorm
+        rm, rv = f32(running_mean), f32(running_var)
+        copy_back = use_batch_stats and running_mean is not None and (rm.data_ptr() != running_mean.data_ptr() or rv.data_ptr() != running_var.data_ptr())
+        st = ops.instnorm_stats(x, eps) if use_batch_stats else None        # [N, C, (mean, rstd)] per image
+        stats, affine = ops.bn_finish_fwd(st, S, eps, momentum, rm, rv, use_batch_stats, f32(weight), f32(bias), N, C)
+        if copy_back:                                 # running statistics kept in another dtype / layout
+            with torch.no_grad():
+                running_mean.copy_(rm)
+                running_var.copy_(rv)
         ctx.save_for_backward(x, stats, affine)
         ctx.act, ctx.S, ctx.batch = act, S, bool(use_batch_stats)
         ctx.has = (weight is not None, bias is not None)
@@ -1100,18 +1094,10 @@ class BatchNormActFn(torch.autograd.Function):
         x, stats, affine = ctx.saved_tensors
         N, C = int(x.shape[0]), int(x.shape[-1])
         dy = dy.contiguous()
-        sums = ops.norm_affine_bwd_sums(dy, x, stats, affine, ctx.act, masked=True).double()   # per image: mean(dz), mean(dz xh)
-        a, b = sums[..., 0].mean(0), sums[..., 1].mean(0)
-        cnt = float(N * ctx.S)
-        dgamma, dbeta = (b * cnt).float(), (a * cnt).float()
-        g64 = affine[:, 0].double()
-        if ctx.batch:
-            sums_f = torch.stack([g64 * a, g64 * b], -1)
-        else:
-            sums_f = torch.zeros((C, 2), dtype=torch.float64, device=x.device)     # fixed statistics: no mean terms
-        sums_f = sums_f.float().unsqueeze(0).expand(N, C, 2).contiguous()
+        sums = ops.norm_affine_bwd_sums(dy, x, stats, affine, ctx.act, masked=True)     # per image: mean(dz), mean(dz xh)
+        dgamma, dbeta, sums_f = ops.bn_finish_bwd(sums, float(N * ctx.S), affine, ctx.batch, need_gamma=ctx.has[0], need_beta=ctx.has[1])
         dx = ops.norm_affine_bwd_apply(dy, x, stats, affine, sums_f, ctx.act, masked=True) if ctx.needs_input_grad[0] else None
-        return dx, (dgamma if ctx.has[0] else None), (dbeta if ctx.has[1] else None), None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 _SLICE_PACK = {}

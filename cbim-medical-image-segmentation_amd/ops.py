@@ -206,6 +206,31 @@ def norm_affine_bwd_apply(g, x, stats, affine, sums, act: int, masked: bool):
 # pooling / upsample+concat
 # ------------------------------------------------------------------------------------------------
 
+def bn_finish_fwd(st, S: int, eps: float, momentum: float, running_mean, running_var, use_batch: bool, gamma, beta, N: int, C: int):
+    """per-image (mean, rstd) [N, C, 2] -> (batch statistics repeated per image [N, C, 2], affine [C, 2]); updates the running
+    statistics in place in training mode (include/cbim_hip.h cbim_bn_finish_fwd)"""
+    dev = (st if st is not None else running_mean).device
+    _dev_ok(st, running_mean, running_var, gamma, beta)
+    stats = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
+    affine = torch.empty((C, 2), dtype=torch.float32, device=dev)
+    ref = st if st is not None else running_mean
+    check(_lib.lib().cbim_bn_finish_fwd(_p(st), N, C, float(S), float(eps), float(momentum), _p(running_mean), _p(running_var),
+                                        int(bool(use_batch)), _p(gamma), _p(beta), _p(stats), _p(affine), _stream(ref)), "bn_finish_fwd")
+    return stats, affine
+
+
+def bn_finish_bwd(sums, cnt: float, affine, use_batch: bool, need_gamma: bool = True, need_beta: bool = True):
+    """per-image means of g' and g' xh [N, C, 2] -> (d gamma | None, d beta | None, sums for norm_affine_bwd_apply [N, C, 2])"""
+    _dev_ok(sums, affine)
+    N, C = int(sums.shape[0]), int(sums.shape[1])
+    dg = torch.empty((C,), dtype=torch.float32, device=sums.device) if need_gamma else None
+    db = torch.empty((C,), dtype=torch.float32, device=sums.device) if need_beta else None
+    out = torch.empty((N, C, 2), dtype=torch.float32, device=sums.device)
+    check(_lib.lib().cbim_bn_finish_bwd(_p(sums), N, C, float(cnt), _p(affine), int(bool(use_batch)), _p(dg), _p(db), _p(out),
+                                        _stream(sums)), "bn_finish_bwd")
+    return dg, db, out
+
+
 def maxpool_fwd(x, scale: Sequence[int]):
     _dev_ok(x)
     N, D, H, W, Cc = map(int, x.shape)

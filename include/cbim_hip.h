@@ -111,6 +111,20 @@ int cbim_norm_affine_bwd_apply(int dtype, const void* g, int64_t g_stride, const
                                const float* stats, const float* affine, const float* sums, void* dx, int64_t dx_stride,
                                int N, int64_t S, int C, int act, int masked, void* stream);
 
+/* The per-channel arithmetic around them (round 6: one launch each instead of ~25 / ~12 float64 ATen launches on [C] vectors per
+ * BatchNorm — 660 launches of the shipped VNet step):
+ * bn_finish_fwd: per-image statistics st float32 [N][C][2] = (mean, rstd(eps)) -> the batch statistics of F.batch_norm(training=True)
+ *                (mean over N of the means; biased variance pooled over N S values, in float64), the running-statistics update
+ *                running = (1 - momentum) running + momentum (mean | var n/(n-1)) when the pointers are given, `stats_out`
+ *                [N][C][2] = (mean_b, rstd_b) repeated per image and affine_out [C][2] = (gamma | 1, beta | 0);
+ *                use_batch = 0: the statistics are the running ones (nn.BatchNorm3d in eval()).
+ * bn_finish_bwd: sums float32 [N][C][2] = per-image means of g' and g' xh -> d gamma = cnt mean(g' xh), d beta = cnt mean(g'),
+ *                sums_out [N][C][2] = gamma (mean g', mean g' xh) (zeros under running statistics) for bwd_apply. */
+int cbim_bn_finish_fwd(const float* st, int N, int C, double S, float eps, float momentum, float* running_mean, float* running_var,
+                       int use_batch, const float* gamma, const float* beta, float* stats_out, float* affine_out, void* stream);
+int cbim_bn_finish_bwd(const float* sums, int N, int C, double cnt, const float* affine, int use_batch, float* dgamma, float* dbeta,
+                       float* sums_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * nn.MaxPool3d(scale) — unet_utils.py:36 (kernel = stride = scale, floor mode).
  * idx: uint8 [N][Do][Ho][Wo][C] window position of the first maximum (scan order d,h,w).
