@@ -1103,7 +1103,7 @@ class BatchNormActFn(torch.autograd.Function):
 _SLICE_PACK = {}
 
 
-def _packed_slice(w, kd, geom, need_dgrad):
+def _packed_slice(w, kd, geom, need_dgrad, planes=None):
     """(weight slice [Cout, Cin, 1, kH, kW], packed forward image, packed dgrad image | None) of one kd plane of a 5x5x5 weight,
     re-packed only when the parameter moved (its version, or a hipGraph replay / whole-table re-pack: ops.PACKED.epoch) — ADVICE
     r04: the slices were re-packed on every forward AND backward (10 launches per convolution and step)."""
@@ -1120,7 +1120,9 @@ def _packed_slice(w, kd, geom, need_dgrad):
     #  weights its own captured optimizer step left)
     capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
     if e is None or e[0] != tag or ops.PACKED.stale or capturing or (need_dgrad and e[3] is None):
-        wk = w.detach()[:, :, kd:kd + 1].contiguous()
+        # planes: the caller's lazily built contiguous [kD, Cout, Cin, kH, kW] copy of the weight (ONE permute per convolution and
+        # step instead of one strided slice copy per plane — round 6: 125 launches of the VNet step)
+        wk = planes()[kd].unsqueeze(2) if planes is not None else w.detach()[:, :, kd:kd + 1].contiguous()
         wp, wpd = (ops.pack_weights_both(wk, geom) if need_dgrad else (ops.pack_weights(wk, geom, 0), None))
         if e is None:                              # weakly keyed: entries die with their parameter
             weakref.finalize(w, _SLICE_PACK.pop, key, None)
@@ -1142,6 +1144,12 @@ class ConvSlicesFn(torch.autograd.Function):
         wd = w.detach()
         y = torch.empty((N, D, H, W, Cout), dtype=x.dtype, device=x.device)
         plans = []
+        box = []
+
+        def planes():                                             # built at most once per call, only when a slice is re-packed
+            if not box:
+                box.append(wd.permute(2, 0, 1, 3, 4).contiguous())
+            return box[0]
         order = [pD] + [k for k in range(kD) if k != pD]          # the centre slice first: it covers every output plane
         for kd in order:
             o = kd - pD
@@ -1149,7 +1157,7 @@ class ConvSlicesFn(torch.autograd.Function):
             if d1 <= d0:
                 continue
             geom = ConvGeom(x.dtype, 1, (d1 - d0, H, W), Cin, Cout, (1, kH, kW), (0, pH, pW), 0)
-            wk, wp, _ = _packed_slice(w, kd, geom, bool(ctx.needs_input_grad[0]))
+            wk, wp, _ = _packed_slice(w, kd, geom, bool(ctx.needs_input_grad[0]), planes)
             for n in range(N):
                 ys = y[n:n + 1, d0:d1]
                 ops.conv_igemm(geom.fwd, x[n:n + 1, d0 + o:d1 + o], wp, tuple(ys.shape), res=None if kd == pD else ys, out=ys)
