@@ -1026,6 +1026,32 @@ def check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64, seed=21, heads=1):
     assert relerr(q2.grad.cpu(), dqv.cpu()) == 0.0 and relerr(a.grad.cpu(), dmq.cpu()) == 0.0 and relerr(b.grad.cpu(), dmv.cpu()) == 0.0
 
 
+def check_wgrad_133(dev, N=1, Cin=32, Cout=32, dhw=(8, 16, 16), seed=31):
+    """The weight gradient of a (1, 3, 3) convolution (config/acdc: kernel_size [[1,3,3],[1,3,3],...]) taken as the centre plane of the
+    3x3x3 weight gradient on k_wgrad_r32 (round 6, ops.WGRAD_EMBED_133): against torch and against k_conv_wgrad's nine-tap form."""
+    torch.manual_seed(seed)
+    dtype = torch.bfloat16
+    x = torch.randn(N, Cin, *dhw)
+    dy = torch.randn(N, Cout, *dhw) * 0.1
+    xl, dyl = to_cl(x, dtype).to(dev), to_cl(dy, dtype).to(dev)
+    xr, dyr = from_cl(xl.cpu()), from_cl(dyl.cpu())
+    w = torch.zeros(Cout, Cin, 1, 3, 3, requires_grad=True)
+    F.conv3d(xr, w, None, 1, (0, 1, 1)).backward(dyr)
+    g = ops.ConvGeom(dtype, N, dhw, Cin, Cout, (1, 3, 3), (0, 1, 1), 0)
+    keep = ops.WGRAD_EMBED_133
+    try:
+        ops.WGRAD_EMBED_133 = True
+        dw1 = ops.conv_wgrad(xl, None, dyl, g)
+        slot = torch.empty_like(dw1)
+        assert ops.conv_wgrad(xl, None, dyl, g, out=slot) is slot and torch.equal(slot, dw1)
+        ops.WGRAD_EMBED_133 = False
+        dw0 = ops.conv_wgrad(xl, None, dyl, g)
+    finally:
+        ops.WGRAD_EMBED_133 = keep
+    assert tuple(dw1.shape) == (Cout, Cin, 1, 3, 3) and dw1.is_contiguous()
+    assert relerr(dw1.cpu(), w.grad) < 2e-5 and relerr(dw0.cpu(), w.grad) < 2e-5, (relerr(dw1.cpu(), w.grad), relerr(dw0.cpu(), w.grad))
+
+
 def check_mappool(dev, dtype, N=2, C=24, M=8, dhw=(5, 6, 7), seed=14):
     """SemanticMapGeneration tail, medformer_utils.py:218-228."""
     torch.manual_seed(seed)

@@ -238,6 +238,11 @@ def test_attn(dev, dtype):
     oc.check_attn(dev, dtype, N=1, heads=4, dh=32, dhw=(16, 16, 16), M=64)   # down3-sized
 
 
+def test_wgrad_of_1x3x3_kernels_as_the_centre_plane_of_3x3x3(dev):
+    oc.check_wgrad_133(dev)
+    oc.check_wgrad_133(dev, N=2, Cin=64, Cout=32, dhw=(8, 8, 24))
+
+
 def test_attn_core_as_matrix_products(dev):
     """round 6: the BidirectionAttention core of ONE wide head (config/lits) on the row-GEMM kernels + csrc/attn_gemm_kernels.hip"""
     oc.check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64)

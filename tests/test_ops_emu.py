@@ -123,6 +123,11 @@ def test_attn_wide_heads_and_maps(dev, dtype):
     oc.check_attn(dev, dtype, N=1, heads=1, dh=40, dhw=(1, 1, 3), M=128)      # more codes than voxels, code limit
 
 
+def test_wgrad_of_1x3x3_kernels_as_the_centre_plane_of_3x3x3(dev):
+    oc.check_wgrad_133(dev)
+    oc.check_wgrad_133(dev, N=2, Cin=64, Cout=32, dhw=(8, 8, 24))
+
+
 def test_attn_core_as_matrix_products(dev):
     """round 6: the BidirectionAttention core of ONE wide head (config/lits) on the row-GEMM kernels + csrc/attn_gemm_kernels.hip"""
     oc.check_attn_gemm(dev, N=2, dh=64, dhw=(8, 8, 10), M=64)
